@@ -1,0 +1,202 @@
+/*
+ * mfmg_hip.h -- C ABI of libmfmg_hip.so: the MI355X (gfx950) drop-in for the
+ * V-cycle apply path of ORNL-CEES/mfmg.
+ *
+ * The reference exposes this path through C++ abstract classes
+ * (include/mfmg/common/{operator,smoother,solver,hierarchy}.hpp), selected by the
+ * string switch create_hierarchy_helpers (include/mfmg/common/hierarchy.hpp:49-153).
+ * The same classes are mirrored, deal.II-free, under mfmg_amd/csrc/mfmg/ ; this
+ * header is the flat boundary underneath them: plain pointers and sizes, device
+ * pointers in, status code out, no C++/torch types.  Every entry point cites the
+ * reference interface it replaces (path:line relative to the reference tree).
+ *
+ * Conventions
+ *  - all vectors are raw DEVICE pointers to `double` (or `float` for the _f32
+ *    entry points) of the length the operator reports; the caller owns them;
+ *  - matrices / operators / hierarchies are opaque handles that OWN their
+ *    device arrays (as SparseMatrixDevice does,
+ *    include/mfmg/cuda/sparse_matrix_device.templates.cuh:244-272);
+ *  - every call is asynchronous on the context's HIP stream unless stated;
+ *  - return value: MFMG_HIP_SUCCESS or an error code; the message of the last
+ *    error on the calling thread is available from mfmg_hip_last_error().
+ *    MFMG_HIP_ERROR_RUNTIME      <-> ASSERT_THROW  (std::runtime_error,
+ *                                    include/mfmg/common/exceptions.hpp:48-52)
+ *    MFMG_HIP_ERROR_NOT_IMPLEMENTED <-> ASSERT_THROW_NOT_IMPLEMENTED (:54-73)
+ */
+#ifndef MFMG_HIP_H
+#define MFMG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFMG_HIP_SUCCESS 0
+#define MFMG_HIP_ERROR_RUNTIME 1
+#define MFMG_HIP_ERROR_NOT_IMPLEMENTED 2
+#define MFMG_HIP_ERROR_INVALID_ARGUMENT 3
+#define MFMG_HIP_ERROR_DEVICE 4
+
+/* OperatorMode (include/mfmg/common/operator.hpp:19-23) */
+#define MFMG_HIP_NO_TRANS 0
+#define MFMG_HIP_TRANS 1
+
+typedef struct mfmg_hip_context_s *mfmg_hip_context_t;       /* CudaHandle, include/mfmg/cuda/cuda_handle.cuh:25-48 */
+typedef struct mfmg_hip_csr_s *mfmg_hip_csr_t;               /* SparseMatrixDevice<double>, include/mfmg/cuda/sparse_matrix_device.cuh:28-104 */
+typedef struct mfmg_hip_mf_laplace_s *mfmg_hip_mf_laplace_t; /* CudaMatrixFreeOperator + the user's LaplaceOperator, source/cuda/cuda_matrix_free_operator.cu:32-37, tests/laplace_matrix_free.hpp:121-156 */
+typedef struct mfmg_hip_hierarchy_s *mfmg_hip_hierarchy_t;   /* Hierarchy<VectorType>, include/mfmg/common/hierarchy.hpp:155-373 */
+
+const char *mfmg_hip_last_error(void);
+const char *mfmg_hip_version(void);
+
+/* ---- context: stream + scratch (CudaHandle, source/cuda/cuda_handle.cu:17-56) ---- */
+/* `hip_stream` may be NULL (the library creates its own non-blocking stream). */
+int mfmg_hip_context_create(void *hip_stream, mfmg_hip_context_t *ctx);
+int mfmg_hip_context_destroy(mfmg_hip_context_t ctx);
+int mfmg_hip_context_synchronize(mfmg_hip_context_t ctx);
+void *mfmg_hip_context_stream(mfmg_hip_context_t ctx);
+
+/* ---- host<->device marshalling (source/cuda/utils.cu:484-510, include/mfmg/cuda/utils.cuh:66-99) ---- */
+int mfmg_hip_malloc(void **dev_ptr, size_t bytes);                      /* cuda_malloc */
+int mfmg_hip_free(void *dev_ptr);                                       /* cuda_free */
+int mfmg_hip_copy_to_dev(void *dst_dev, const void *src_host, size_t bytes);  /* cuda_mem_copy_to_dev */
+int mfmg_hip_copy_to_host(void *dst_host, const void *src_dev, size_t bytes); /* cuda_mem_copy_to_host */
+
+/* ---- vector kernels used inside the cycle (deal.II CUDA vector ops called at
+ *      include/mfmg/common/hierarchy.hpp:258,286,302 and source/cuda/cuda_smoother.cu:50-59) ---- */
+int mfmg_hip_vector_set(mfmg_hip_context_t ctx, int64_t n, double value, double *x);                 /* x = value        */
+int mfmg_hip_vector_add(mfmg_hip_context_t ctx, int64_t n, double a, const double *v, double *x);    /* x.add(a, v)      */
+int mfmg_hip_vector_sadd(mfmg_hip_context_t ctx, int64_t n, double s, double a, const double *v, double *x); /* x.sadd(s,a,v) */
+int mfmg_hip_vector_dot(mfmg_hip_context_t ctx, int64_t n, const double *x, const double *y, double *result_host); /* synchronous */
+int mfmg_hip_vector_l2_norm(mfmg_hip_context_t ctx, int64_t n, const double *x, double *result_host);              /* synchronous, x.l2_norm() */
+
+/* ---- CSR matrix on device: SparseMatrixDevice<double> ---- */
+/* convert_matrix (source/cuda/utils.cu:39-168): upload a host CSR (0-based, int32). */
+int mfmg_hip_csr_create(mfmg_hip_context_t ctx, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                        const int32_t *row_ptr_host, const int32_t *col_host,
+                        const double *val_host, mfmg_hip_csr_t *out);
+int mfmg_hip_csr_destroy(mfmg_hip_csr_t a);
+int mfmg_hip_csr_shape(mfmg_hip_csr_t a, int64_t *n_rows, int64_t *n_cols, int64_t *nnz); /* m(), n(), n_nonzero_elements() */
+/* SparseMatrixDevice::vmult  (…templates.cuh:351-371): y = A x */
+int mfmg_hip_csr_vmult(mfmg_hip_csr_t a, const double *x, double *y);
+/* CudaMatrixOperator::apply (source/cuda/cuda_matrix_operator.cu:80-91); TRANS uses the
+ * explicit transpose built once by transpose() (:93-130) -- here on the host at first use. */
+int mfmg_hip_csr_apply(mfmg_hip_csr_t a, const double *x, double *y, int mode);
+/* CudaMatrixOperator::transpose (:93-130) */
+int mfmg_hip_csr_transpose(mfmg_hip_csr_t a, mfmg_hip_csr_t *out);
+/* SparseMatrixDevice::mmult / CudaMatrixOperator::multiply (…templates.cuh:373-434, cuda_matrix_operator.cu:132-149): C = A B (setup, host SpGEMM) */
+int mfmg_hip_csr_multiply(mfmg_hip_csr_t a, mfmg_hip_csr_t b, mfmg_hip_csr_t *out);
+/* download (copy_from_dev / convert_to_trilinos_matrix, source/cuda/utils.cu:170-204) */
+int mfmg_hip_csr_download(mfmg_hip_csr_t a, int32_t *row_ptr_host, int32_t *col_host, double *val_host);
+/* extract_inv_diag (source/cuda/cuda_smoother.cu:86-96): dinv[i] = 1/A_ii on device */
+int mfmg_hip_csr_inverse_diagonal(mfmg_hip_csr_t a, double *dinv);
+/* One fused Jacobi/Chebyshev step on an assembled operator:
+ * out = x + alpha (x - x_prev) - beta * dinv .* (A x - b).   x_prev may be NULL when alpha == 0.
+ * Replaces the r=Ax-b / tmp=B^-1 r / x-=tmp sequence of source/cuda/cuda_smoother.cu:48-59. `out` must not alias `x`. */
+int mfmg_hip_csr_smoother_step(mfmg_hip_csr_t a, const double *dinv, const double *b, const double *x,
+                               const double *x_prev, double alpha, double beta, double *out);
+/* res = A x - b  (include/mfmg/common/hierarchy.hpp:284-286, negative residual) */
+int mfmg_hip_csr_residual(mfmg_hip_csr_t a, const double *x, const double *b, double *res);
+
+/* ---- matrix-free Q1 Laplace operator on a logically structured hex mesh ---- */
+/* What the deal.II driver hands over (tests/laplace_matrix_free.hpp:243-313):
+ * the cell->DoF index array, the coefficient table _coefficient(cell,q)
+ * (:65,100-119), the constrained DoFs (AffineConstraints) and the Cartesian cell size. */
+typedef struct mfmg_hip_mesh_desc
+{
+  int32_t dim;             /* 3 (2 is accepted by the assembled path only) */
+  int32_t n_cells[3];      /* cells per direction, lexicographic cell order, x fastest */
+  double cell_size[3];     /* h_x, h_y, h_z (J = diag(h)) */
+  int64_t n_dofs;          /* (n_cells+1) product */
+  const int32_t *cell_dofs;     /* [n_cells_total][2^dim]  cell->get_dof_indices */
+  const double *coefficient;    /* [n_cells_total][2^dim]  _coefficient(cell,q) */
+  const uint8_t *constrained;   /* [n_dofs] 1 = Dirichlet-constrained DoF */
+  int32_t arrays_on_device;     /* 0: host pointers, 1: device pointers */
+} mfmg_hip_mesh_desc;
+
+int mfmg_hip_mf_laplace_create(mfmg_hip_context_t ctx, const mfmg_hip_mesh_desc *mesh, mfmg_hip_mf_laplace_t *out);
+int mfmg_hip_mf_laplace_destroy(mfmg_hip_mf_laplace_t op);
+int mfmg_hip_mf_laplace_size(mfmg_hip_mf_laplace_t op, int64_t *n_dofs);
+/* LaplaceOperator::vmult via matrix_free_evaluate_global (tests/test_hierarchy_helpers.hpp:370-375,
+ * source/dealii/dealii_matrix_free_operator.cc:31-36): y = A x, constrained rows y_c = x_c */
+int mfmg_hip_mf_laplace_vmult(mfmg_hip_mf_laplace_t op, const double *x, double *y);
+/* matrix_free_get_diagonal_inverse (tests/test_hierarchy_helpers.hpp:377-382; compute_diagonal
+ * tests/laplace_matrix_free.hpp:75-98): copies the inverse diagonal (constrained entries 1) */
+int mfmg_hip_mf_laplace_diagonal_inverse(mfmg_hip_mf_laplace_t op, double *dinv);
+int mfmg_hip_mf_laplace_diagonal(mfmg_hip_mf_laplace_t op, double *diag);
+/* res = A x - b */
+int mfmg_hip_mf_laplace_residual(mfmg_hip_mf_laplace_t op, const double *x, const double *b, double *res);
+/* fused smoother step, as mfmg_hip_csr_smoother_step (DealIIMatrixFreeSmoother::apply,
+ * source/dealii/dealii_matrix_free_smoother.cc:63-76, one polynomial term per call) */
+int mfmg_hip_mf_laplace_smoother_step(mfmg_hip_mf_laplace_t op, const double *b, const double *x,
+                                      const double *x_prev, double alpha, double beta, double *out);
+/* tuning knob: owned DoF rows / planes per workgroup tile (0 = heuristic) */
+int mfmg_hip_mf_laplace_set_tile(mfmg_hip_mf_laplace_t op, int tile_y, int tile_z);
+
+/* ---- hierarchy: Hierarchy<VectorType> ---- */
+/* Evaluator tag strings accepted by the string switch (create_hierarchy_helpers,
+ * include/mfmg/common/hierarchy.hpp:49-107):
+ *   "HipMeshEvaluator"            assembled CSR path (twin of "CudaMeshEvaluator")
+ *   "HipMatrixFreeMeshEvaluator"  matrix-free path   (the tag "CudaMatrixFreeMeshEvaluator",
+ *                                  source/cuda/cuda_matrix_free_mesh_evaluator.cu:21-24, is never dispatched upstream)
+ * `params_info` is the text of a boost::property_tree INFO file
+ * (tests/data/hierarchy_input.info); keys as consumed at hierarchy.hpp:168-172,215,
+ * dealii_matrix_free_smoother.cc:24-51, cuda_smoother.cu:105, cuda_solver.cu:215. */
+int mfmg_hip_hierarchy_create(mfmg_hip_context_t ctx, const char *evaluator_type,
+                              const mfmg_hip_mesh_desc *mesh, const char *params_info,
+                              mfmg_hip_hierarchy_t *out);
+int mfmg_hip_hierarchy_destroy(mfmg_hip_hierarchy_t h);
+/* Hierarchy::apply(b, x, 0)  (hierarchy.hpp:246-309) */
+int mfmg_hip_hierarchy_apply(mfmg_hip_hierarchy_t h, const double *b, double *x);
+/* Hierarchy::vmult(x, b)     (hierarchy.hpp:238-244) */
+int mfmg_hip_hierarchy_vmult(mfmg_hip_hierarchy_t h, double *x, const double *b);
+int mfmg_hip_hierarchy_n_levels(mfmg_hip_hierarchy_t h, int32_t *n_levels);
+int mfmg_hip_hierarchy_level_size(mfmg_hip_hierarchy_t h, int32_t level, int64_t *n);
+/* Level::get_operator()->apply (level.hpp:30-33) */
+int mfmg_hip_hierarchy_operator_apply(mfmg_hip_hierarchy_t h, int32_t level, const double *x, double *y, int mode);
+/* Level::get_smoother()->apply(b, x) (level.hpp:40-43) */
+int mfmg_hip_hierarchy_smoother_apply(mfmg_hip_hierarchy_t h, int32_t level, const double *b, double *x);
+/* levels[level].get_restrictor()->apply(in, out, mode): level >= 1 (level.hpp:35-38) */
+int mfmg_hip_hierarchy_restrictor_apply(mfmg_hip_hierarchy_t h, int32_t level, const double *in, double *out, int mode);
+/* coarsest Level::get_solver()->apply(b, x) (level.hpp:45-48) */
+int mfmg_hip_hierarchy_coarse_apply(mfmg_hip_hierarchy_t h, const double *b, double *x);
+/* Replace the restrictor (and re-derive the Galerkin coarse operator + coarse solver)
+ * from a host CSR so that CPU and GPU runs can share the identical R. */
+int mfmg_hip_hierarchy_set_restrictor(mfmg_hip_hierarchy_t h, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                                      const int32_t *row_ptr_host, const int32_t *col_host, const double *val_host);
+/* restrictor / coarse operator download for inspection: query sizes with *_shape first */
+int mfmg_hip_hierarchy_get_restrictor(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *r_borrowed);
+int mfmg_hip_hierarchy_get_coarse_operator(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *ac_borrowed);
+/* smoother polynomial actually used (degree, lambda_min, lambda_max) */
+int mfmg_hip_hierarchy_smoother_info(mfmg_hip_hierarchy_t h, int32_t *degree, double *lambda_min, double *lambda_max);
+/* TimerOutput-style accumulated wall times of the sections of hierarchy.hpp:164-271 as a text table */
+int mfmg_hip_hierarchy_timer_report(mfmg_hip_hierarchy_t h, char *buf, size_t buf_size);
+
+/* ---- host-side setup pieces (no GPU needed; SURVEY.md 8f rank 1-2, kept on the host cores) ----
+ * Opaque host CSR results are returned through a handle and copied out with *_host_csr_get. */
+typedef struct mfmg_hip_host_csr_s *mfmg_hip_host_csr_t;
+int mfmg_hip_host_csr_shape(mfmg_hip_host_csr_t m, int64_t *n_rows, int64_t *n_cols, int64_t *nnz);
+int mfmg_hip_host_csr_get(mfmg_hip_host_csr_t m, int32_t *row_ptr, int32_t *col, double *val);
+int mfmg_hip_host_csr_destroy(mfmg_hip_host_csr_t m);
+/* Laplace<dim>::assemble_system on the structured mesh (tests/laplace.hpp:154-204); semantics 0: assembled
+ * (AffineConstraints elimination), 1: matrix-free (identity rows on constrained DoFs). Host arrays only. */
+int mfmg_hip_host_assemble_matrix(const mfmg_hip_mesh_desc *mesh, int semantics, mfmg_hip_host_csr_t *out);
+/* AMGe restrictor (include/mfmg/common/amge.templates.hpp:271-325,412-499;
+ * include/mfmg/dealii/amge_host.templates.hpp:278-483; include/mfmg/cuda/amge_device.templates.cuh:217-310).
+ * `params_info`: INFO text with the eigensolver / agglomeration sections; `matrix_free` picks the evaluator flavour. */
+int mfmg_hip_host_build_restrictor(const mfmg_hip_mesh_desc *mesh, const char *params_info, int matrix_free,
+                                   mfmg_hip_host_csr_t *out);
+/* A_c = R (A R^T) (include/mfmg/common/hierarchy.hpp:214-233) from operator rows generated on the fly */
+int mfmg_hip_host_galerkin(const mfmg_hip_mesh_desc *mesh, int semantics, int64_t n_rows, int64_t nnz,
+                           const int32_t *r_row_ptr, const int32_t *r_col, const double *r_val,
+                           mfmg_hip_host_csr_t *out);
+/* boost::property_tree INFO round trip of the parameter reader (tests/test_utils.cc:23-60 exercises ptree2plist) */
+int mfmg_hip_host_params_get(const char *params_info, const char *path, char *value_buf, size_t buf_size);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFMG_HIP_H */

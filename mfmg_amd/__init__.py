@@ -1,0 +1,13 @@
+"""mfmg_amd: MI355X-native V-cycle apply path behind the mfmg operator API.
+
+Python is plumbing here (device memory through torch, process groups through
+torch.distributed); every numerical operation runs in libmfmg_hip.so."""
+from . import lib
+from .api import (Context, Hierarchy, MatrixFreeLaplace, SparseMatrixDevice, host_assemble_matrix,
+                  host_build_restrictor, host_galerkin, params_to_info)
+from .laplace import LaplaceProblem, material_property
+
+__all__ = [
+    "lib", "Context", "Hierarchy", "MatrixFreeLaplace", "SparseMatrixDevice", "LaplaceProblem",
+    "material_property", "host_assemble_matrix", "host_build_restrictor", "host_galerkin", "params_to_info",
+]

@@ -1,0 +1,374 @@
+"""Thin Python mirror of the mfmg classes over the C ABI (include/mfmg_hip.h).
+
+Vectors are torch CUDA tensors (float64, contiguous) -- torch only owns the memory;
+the arithmetic happens in libmfmg_hip.so on the stream of the Context."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .lib import MeshDesc, check
+
+
+def params_to_info(params: dict, indent: int = 0) -> str:
+    """dict -> boost::property_tree INFO text (tests/data/hierarchy_input.info)."""
+    out = []
+    pad = " " * indent
+    for k, v in params.items():
+        key = f'"{k}"' if (" " in str(k) or ":" in str(k)) else str(k)
+        if isinstance(v, dict):
+            out.append(f"{pad}{key}\n{pad}{{\n{params_to_info(v, indent + 2)}{pad}}}\n")
+        else:
+            if isinstance(v, bool):
+                v = "true" if v else "false"
+            elif isinstance(v, float):
+                v = repr(v)
+            sval = str(v)
+            if " " in sval or sval == "":
+                sval = f'"{sval}"'
+            out.append(f"{pad}{key} {sval}\n")
+    return "".join(out)
+
+
+def _dev_ptr(t: torch.Tensor, n: Optional[int] = None, dtype=torch.float64) -> int:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("expected a torch tensor")
+    if t.device.type != "cuda":
+        raise ValueError("vectors must live on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"vectors must be contiguous {dtype} tensors")
+    if n is not None and t.numel() != n:
+        raise ValueError(f"vector has {t.numel()} entries, expected {n}")
+    return t.data_ptr()
+
+
+class Context:
+    """CudaHandle twin: a HIP stream + scratch (source/cuda/cuda_handle.cu:17-56)."""
+
+    def __init__(self, stream: Optional[int] = None):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        check(self._lib.mfmg_hip_context_create(C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.handle = h
+
+    @classmethod
+    def on_current_torch_stream(cls) -> "Context":
+        return cls(torch.cuda.current_stream().cuda_stream)
+
+    def synchronize(self):
+        check(self._lib.mfmg_hip_context_synchronize(self.handle))
+
+    @property
+    def stream(self) -> int:
+        return self._lib.mfmg_hip_context_stream(self.handle)
+
+    def torch_stream(self) -> "torch.cuda.ExternalStream":
+        return torch.cuda.ExternalStream(self.stream)
+
+    def dot(self, x: torch.Tensor, y: torch.Tensor) -> float:
+        r = C.c_double()
+        check(self._lib.mfmg_hip_vector_dot(self.handle, x.numel(), _dev_ptr(x), _dev_ptr(y), C.byref(r)))
+        return r.value
+
+    def l2_norm(self, x: torch.Tensor) -> float:
+        r = C.c_double()
+        check(self._lib.mfmg_hip_vector_l2_norm(self.handle, x.numel(), _dev_ptr(x), C.byref(r)))
+        return r.value
+
+    def set(self, x: torch.Tensor, value: float):
+        check(self._lib.mfmg_hip_vector_set(self.handle, x.numel(), value, _dev_ptr(x)))
+
+    def add(self, x: torch.Tensor, a: float, v: torch.Tensor):
+        check(self._lib.mfmg_hip_vector_add(self.handle, x.numel(), a, _dev_ptr(v, x.numel()), _dev_ptr(x)))
+
+    def sadd(self, x: torch.Tensor, s: float, a: float, v: torch.Tensor):
+        check(self._lib.mfmg_hip_vector_sadd(self.handle, x.numel(), s, a, _dev_ptr(v, x.numel()), _dev_ptr(x)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.mfmg_hip_context_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def _csr_arrays(a):
+    """scipy.sparse matrix (or (row_ptr, col, val, shape)) -> int32/int32/float64 numpy arrays."""
+    if hasattr(a, "tocsr"):
+        a = a.tocsr()
+        a.sort_indices()
+        return (np.ascontiguousarray(a.indptr, dtype=np.int32), np.ascontiguousarray(a.indices, dtype=np.int32),
+                np.ascontiguousarray(a.data, dtype=np.float64), a.shape)
+    rp, cl, vl, shape = a
+    return (np.ascontiguousarray(rp, dtype=np.int32), np.ascontiguousarray(cl, dtype=np.int32),
+            np.ascontiguousarray(vl, dtype=np.float64), shape)
+
+
+class SparseMatrixDevice:
+    """SparseMatrixDevice<double> + CudaMatrixOperator (include/mfmg/cuda/sparse_matrix_device.cuh,
+    source/cuda/cuda_matrix_operator.cu)."""
+
+    def __init__(self, ctx: Context, matrix=None, _handle=None, _borrowed=False, _keepalive=None):
+        self._lib = _lib.load()
+        self.ctx = ctx
+        self._borrowed = _borrowed
+        self._keepalive = _keepalive
+        if _handle is not None:
+            self.handle = _handle
+        else:
+            rp, cl, vl, shape = _csr_arrays(matrix)
+            h = C.c_void_p()
+            check(self._lib.mfmg_hip_csr_create(ctx.handle, shape[0], shape[1], len(vl), rp.ctypes.data,
+                                                cl.ctypes.data, vl.ctypes.data, C.byref(h)))
+            self.handle = h
+
+    @property
+    def shape(self):
+        m, n, z = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self._lib.mfmg_hip_csr_shape(self.handle, C.byref(m), C.byref(n), C.byref(z)))
+        return (m.value, n.value)
+
+    @property
+    def nnz(self):
+        z = C.c_int64()
+        check(self._lib.mfmg_hip_csr_shape(self.handle, None, None, C.byref(z)))
+        return z.value
+
+    def vmult(self, dst: torch.Tensor, src: torch.Tensor):
+        m, n = self.shape
+        check(self._lib.mfmg_hip_csr_vmult(self.handle, _dev_ptr(src, n), _dev_ptr(dst, m)))
+
+    def apply(self, x: torch.Tensor, y: torch.Tensor, mode: int = _lib.NO_TRANS):
+        m, n = self.shape
+        nx, ny = (n, m) if mode == _lib.NO_TRANS else (m, n)
+        check(self._lib.mfmg_hip_csr_apply(self.handle, _dev_ptr(x, nx), _dev_ptr(y, ny), mode))
+
+    def transpose(self) -> "SparseMatrixDevice":
+        h = C.c_void_p()
+        check(self._lib.mfmg_hip_csr_transpose(self.handle, C.byref(h)))
+        return SparseMatrixDevice(self.ctx, _handle=h)
+
+    def multiply(self, b: "SparseMatrixDevice") -> "SparseMatrixDevice":
+        h = C.c_void_p()
+        check(self._lib.mfmg_hip_csr_multiply(self.handle, b.handle, C.byref(h)))
+        return SparseMatrixDevice(self.ctx, _handle=h)
+
+    def inverse_diagonal(self, dinv: torch.Tensor):
+        check(self._lib.mfmg_hip_csr_inverse_diagonal(self.handle, _dev_ptr(dinv, self.shape[0])))
+
+    def residual(self, x, b, res):
+        m, n = self.shape
+        check(self._lib.mfmg_hip_csr_residual(self.handle, _dev_ptr(x, n), _dev_ptr(b, m), _dev_ptr(res, m)))
+
+    def smoother_step(self, dinv, b, x, x_prev, alpha, beta, out):
+        n = self.shape[0]
+        check(self._lib.mfmg_hip_csr_smoother_step(self.handle, _dev_ptr(dinv, n), _dev_ptr(b, n), _dev_ptr(x, n),
+                                                   _dev_ptr(x_prev, n) if x_prev is not None else None,
+                                                   alpha, beta, _dev_ptr(out, n)))
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        m, n = self.shape
+        nnz = self.nnz
+        rp = np.empty(m + 1, dtype=np.int32)
+        cl = np.empty(nnz, dtype=np.int32)
+        vl = np.empty(nnz, dtype=np.float64)
+        check(self._lib.mfmg_hip_csr_download(self.handle, rp.ctypes.data, cl.ctypes.data, vl.ctypes.data))
+        return sp.csr_matrix((vl, cl, rp), shape=(m, n))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and not self._borrowed:
+                self._lib.mfmg_hip_csr_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class MatrixFreeLaplace:
+    """CudaMatrixFreeOperator + LaplaceOperator (source/cuda/cuda_matrix_free_operator.cu,
+    tests/laplace_matrix_free.hpp:121-156) on the GPU."""
+
+    def __init__(self, ctx: Context, problem):
+        self._lib = _lib.load()
+        self.ctx = ctx
+        self.problem = problem  # keeps the mesh arrays alive during construction
+        desc = problem.mesh_desc()
+        h = C.c_void_p()
+        check(self._lib.mfmg_hip_mf_laplace_create(ctx.handle, C.byref(desc), C.byref(h)))
+        self.handle = h
+        self.n_dofs = problem.n_dofs
+
+    def vmult(self, dst: torch.Tensor, src: torch.Tensor):
+        check(self._lib.mfmg_hip_mf_laplace_vmult(self.handle, _dev_ptr(src, self.n_dofs), _dev_ptr(dst, self.n_dofs)))
+
+    def residual(self, x, b, res):
+        n = self.n_dofs
+        check(self._lib.mfmg_hip_mf_laplace_residual(self.handle, _dev_ptr(x, n), _dev_ptr(b, n), _dev_ptr(res, n)))
+
+    def smoother_step(self, b, x, x_prev, alpha, beta, out):
+        n = self.n_dofs
+        check(self._lib.mfmg_hip_mf_laplace_smoother_step(self.handle, _dev_ptr(b, n), _dev_ptr(x, n),
+                                                          _dev_ptr(x_prev, n) if x_prev is not None else None,
+                                                          alpha, beta, _dev_ptr(out, n)))
+
+    def diagonal_inverse(self) -> torch.Tensor:
+        out = torch.empty(self.n_dofs, dtype=torch.float64, device="cuda")
+        check(self._lib.mfmg_hip_mf_laplace_diagonal_inverse(self.handle, _dev_ptr(out)))
+        self.ctx.synchronize()
+        return out
+
+    def diagonal(self) -> torch.Tensor:
+        out = torch.empty(self.n_dofs, dtype=torch.float64, device="cuda")
+        check(self._lib.mfmg_hip_mf_laplace_diagonal(self.handle, _dev_ptr(out)))
+        self.ctx.synchronize()
+        return out
+
+    def set_tile(self, ty: int, tz: int):
+        check(self._lib.mfmg_hip_mf_laplace_set_tile(self.handle, ty, tz))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.mfmg_hip_mf_laplace_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class Hierarchy:
+    """mfmg::Hierarchy<VectorType> (include/mfmg/common/hierarchy.hpp:155-373)."""
+
+    def __init__(self, ctx: Context, evaluator_type: str, problem, params: dict | str):
+        self._lib = _lib.load()
+        self.ctx = ctx
+        info = params if isinstance(params, str) else params_to_info(params)
+        desc = problem.mesh_desc()
+        h = C.c_void_p()
+        check(self._lib.mfmg_hip_hierarchy_create(ctx.handle, evaluator_type.encode(), C.byref(desc),
+                                                  info.encode(), C.byref(h)))
+        self.handle = h
+
+    @property
+    def n_levels(self) -> int:
+        n = C.c_int32()
+        check(self._lib.mfmg_hip_hierarchy_n_levels(self.handle, C.byref(n)))
+        return n.value
+
+    def level_size(self, level: int) -> int:
+        n = C.c_int64()
+        check(self._lib.mfmg_hip_hierarchy_level_size(self.handle, level, C.byref(n)))
+        return n.value
+
+    def apply(self, b: torch.Tensor, x: torch.Tensor):
+        n = self.level_size(0)
+        check(self._lib.mfmg_hip_hierarchy_apply(self.handle, _dev_ptr(b, n), _dev_ptr(x, n)))
+
+    def vmult(self, x: torch.Tensor, b: torch.Tensor):
+        n = self.level_size(0)
+        check(self._lib.mfmg_hip_hierarchy_vmult(self.handle, _dev_ptr(x, n), _dev_ptr(b, n)))
+
+    def operator_apply(self, level: int, x, y, mode: int = _lib.NO_TRANS):
+        n = self.level_size(level)
+        check(self._lib.mfmg_hip_hierarchy_operator_apply(self.handle, level, _dev_ptr(x, n), _dev_ptr(y, n), mode))
+
+    def smoother_apply(self, level: int, b, x):
+        n = self.level_size(level)
+        check(self._lib.mfmg_hip_hierarchy_smoother_apply(self.handle, level, _dev_ptr(b, n), _dev_ptr(x, n)))
+
+    def restrictor_apply(self, level: int, vin, vout, mode: int = _lib.NO_TRANS):
+        nf, nc = self.level_size(level - 1), self.level_size(level)
+        ni, no = (nf, nc) if mode == _lib.NO_TRANS else (nc, nf)
+        check(self._lib.mfmg_hip_hierarchy_restrictor_apply(self.handle, level, _dev_ptr(vin, ni), _dev_ptr(vout, no), mode))
+
+    def coarse_apply(self, b, x):
+        n = self.level_size(self.n_levels - 1)
+        check(self._lib.mfmg_hip_hierarchy_coarse_apply(self.handle, _dev_ptr(b, n), _dev_ptr(x, n)))
+
+    def set_restrictor(self, matrix):
+        rp, cl, vl, shape = _csr_arrays(matrix)
+        check(self._lib.mfmg_hip_hierarchy_set_restrictor(self.handle, shape[0], shape[1], len(vl), rp.ctypes.data,
+                                                          cl.ctypes.data, vl.ctypes.data))
+
+    def restrictor(self) -> SparseMatrixDevice:
+        h = C.c_void_p()
+        check(self._lib.mfmg_hip_hierarchy_get_restrictor(self.handle, C.byref(h)))
+        return SparseMatrixDevice(self.ctx, _handle=h, _borrowed=True, _keepalive=self)
+
+    def coarse_operator(self) -> SparseMatrixDevice:
+        h = C.c_void_p()
+        check(self._lib.mfmg_hip_hierarchy_get_coarse_operator(self.handle, C.byref(h)))
+        return SparseMatrixDevice(self.ctx, _handle=h, _borrowed=True, _keepalive=self)
+
+    def smoother_info(self):
+        d, lo, hi = C.c_int32(), C.c_double(), C.c_double()
+        check(self._lib.mfmg_hip_hierarchy_smoother_info(self.handle, C.byref(d), C.byref(lo), C.byref(hi)))
+        return d.value, lo.value, hi.value
+
+    def timer_report(self) -> str:
+        buf = C.create_string_buffer(8192)
+        check(self._lib.mfmg_hip_hierarchy_timer_report(self.handle, buf, len(buf)))
+        return buf.value.decode()
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.mfmg_hip_hierarchy_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+# ---- host-side setup pieces (no GPU) ------------------------------------------------------
+def _host_csr_to_scipy(lib, h):
+    import scipy.sparse as sp
+    m, n, z = C.c_int64(), C.c_int64(), C.c_int64()
+    check(lib.mfmg_hip_host_csr_shape(h, C.byref(m), C.byref(n), C.byref(z)))
+    rp = np.empty(m.value + 1, dtype=np.int32)
+    cl = np.empty(z.value, dtype=np.int32)
+    vl = np.empty(z.value, dtype=np.float64)
+    check(lib.mfmg_hip_host_csr_get(h, rp.ctypes.data, cl.ctypes.data, vl.ctypes.data))
+    lib.mfmg_hip_host_csr_destroy(h)
+    return sp.csr_matrix((vl, cl, rp), shape=(m.value, n.value))
+
+
+def host_assemble_matrix(problem, semantics: str = "assembled"):
+    lib = _lib.load()
+    assert problem.device.type == "cpu"
+    desc = problem.mesh_desc()
+    h = C.c_void_p()
+    check(lib.mfmg_hip_host_assemble_matrix(C.byref(desc), 0 if semantics == "assembled" else 1, C.byref(h)))
+    return _host_csr_to_scipy(lib, h)
+
+
+def host_build_restrictor(problem, params: dict | str, matrix_free: bool):
+    lib = _lib.load()
+    assert problem.device.type == "cpu"
+    desc = problem.mesh_desc()
+    info = params if isinstance(params, str) else params_to_info(params)
+    h = C.c_void_p()
+    check(lib.mfmg_hip_host_build_restrictor(C.byref(desc), info.encode(), 1 if matrix_free else 0, C.byref(h)))
+    return _host_csr_to_scipy(lib, h)
+
+
+def host_galerkin(problem, R, semantics: str = "assembled"):
+    lib = _lib.load()
+    assert problem.device.type == "cpu"
+    desc = problem.mesh_desc()
+    rp, cl, vl, shape = _csr_arrays(R)
+    h = C.c_void_p()
+    check(lib.mfmg_hip_host_galerkin(C.byref(desc), 0 if semantics == "assembled" else 1, shape[0], len(vl),
+                                     rp.ctypes.data, cl.ctypes.data, vl.ctypes.data, C.byref(h)))
+    return _host_csr_to_scipy(lib, h)
+
+
+def params_get(info: str, path: str) -> str:
+    lib = _lib.load()
+    buf = C.create_string_buffer(1024)
+    check(lib.mfmg_hip_host_params_get(info.encode(), path.encode(), buf, len(buf)))
+    return buf.value.decode()

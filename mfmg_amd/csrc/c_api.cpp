@@ -1,0 +1,705 @@
+// extern "C" boundary of libmfmg_hip.so (include/mfmg_hip.h): exceptions of the C++
+// mirror are mapped to status codes; messages are kept per thread.
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "mfmg/hierarchy.hpp"
+
+using namespace mfmg;
+
+namespace
+{
+thread_local std::string g_last_error;
+
+template <typename F>
+int guarded(F &&f)
+{
+  try
+  {
+    f();
+    return MFMG_HIP_SUCCESS;
+  }
+  catch (NotImplementedExc const &e)
+  {
+    g_last_error = e.what();
+    return MFMG_HIP_ERROR_NOT_IMPLEMENTED;
+  }
+  catch (InvalidArgumentExc const &e)
+  {
+    g_last_error = e.what();
+    return MFMG_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  catch (DeviceExc const &e)
+  {
+    g_last_error = e.what();
+    return MFMG_HIP_ERROR_DEVICE;
+  }
+  catch (std::exception const &e)
+  {
+    g_last_error = e.what();
+    return MFMG_HIP_ERROR_RUNTIME;
+  }
+  catch (...)
+  {
+    g_last_error = "unknown exception";
+    return MFMG_HIP_ERROR_RUNTIME;
+  }
+}
+
+void require(bool cond, char const *what)
+{
+  if (!cond)
+    throw InvalidArgumentExc(what);
+}
+} // namespace
+
+struct mfmg_hip_context_s
+{
+  std::unique_ptr<HipHandle> handle;
+};
+
+struct mfmg_hip_csr_s
+{
+  std::shared_ptr<HipMatrixOperator> op; // owns the SparseMatrixDevice
+  bool borrowed = false;
+};
+
+struct mfmg_hip_mf_laplace_s
+{
+  std::shared_ptr<MatrixFreeLaplaceDevice<double>> op;
+};
+
+struct mfmg_hip_host_csr_s
+{
+  HostCsr m;
+};
+
+struct mfmg_hip_hierarchy_s
+{
+  HipHandle *handle = nullptr;
+  std::shared_ptr<HipMeshEvaluator> evaluator;
+  std::shared_ptr<TimerOutput> timer;
+  std::unique_ptr<Hierarchy<DVector>> hierarchy;
+  mfmg_hip_csr_s restrictor_view, coarse_view;
+};
+
+extern "C" {
+
+const char *mfmg_hip_last_error(void) { return g_last_error.c_str(); }
+const char *mfmg_hip_version(void) { return "mfmg-hip 0.1.0 (gfx950)"; }
+
+// ---- context -------------------------------------------------------------------
+int mfmg_hip_context_create(void *hip_stream, mfmg_hip_context_t *ctx)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null output handle");
+    int n_dev = 0;
+    hipError_t err = hipGetDeviceCount(&n_dev);
+    if (err != hipSuccess || n_dev == 0)
+      throw DeviceExc("no HIP device available: the mfmg HIP path has no CPU fallback");
+    auto c = new mfmg_hip_context_s;
+    c->handle.reset(new HipHandle(static_cast<hipStream_t>(hip_stream)));
+    *ctx = c;
+  });
+}
+
+int mfmg_hip_context_destroy(mfmg_hip_context_t ctx)
+{
+  return guarded([&] { delete ctx; });
+}
+
+int mfmg_hip_context_synchronize(mfmg_hip_context_t ctx)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    MFMG_HIP_CHECK(hipStreamSynchronize(ctx->handle->stream));
+  });
+}
+
+void *mfmg_hip_context_stream(mfmg_hip_context_t ctx) { return ctx ? ctx->handle->stream : nullptr; }
+
+// ---- marshalling ---------------------------------------------------------------
+int mfmg_hip_malloc(void **dev_ptr, size_t bytes)
+{
+  return guarded([&] {
+    require(dev_ptr != nullptr, "null output pointer");
+    MFMG_HIP_CHECK(hipMalloc(dev_ptr, bytes));
+  });
+}
+int mfmg_hip_free(void *dev_ptr)
+{
+  return guarded([&] { MFMG_HIP_CHECK(hipFree(dev_ptr)); });
+}
+int mfmg_hip_copy_to_dev(void *dst_dev, const void *src_host, size_t bytes)
+{
+  return guarded([&] { MFMG_HIP_CHECK(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice)); });
+}
+int mfmg_hip_copy_to_host(void *dst_host, const void *src_dev, size_t bytes)
+{
+  return guarded([&] { MFMG_HIP_CHECK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost)); });
+}
+
+// ---- vector kernels ------------------------------------------------------------
+int mfmg_hip_vector_set(mfmg_hip_context_t ctx, int64_t n, double value, double *x)
+{
+  return guarded([&] {
+    require(ctx && x, "null argument");
+    vec::set<double>(*ctx->handle, n, value, x);
+  });
+}
+int mfmg_hip_vector_add(mfmg_hip_context_t ctx, int64_t n, double a, const double *v, double *x)
+{
+  return guarded([&] {
+    require(ctx && x && v, "null argument");
+    vec::add<double>(*ctx->handle, n, a, v, x);
+  });
+}
+int mfmg_hip_vector_sadd(mfmg_hip_context_t ctx, int64_t n, double s, double a, const double *v, double *x)
+{
+  return guarded([&] {
+    require(ctx && x && v, "null argument");
+    vec::sadd<double>(*ctx->handle, n, s, a, v, x);
+  });
+}
+int mfmg_hip_vector_dot(mfmg_hip_context_t ctx, int64_t n, const double *x, const double *y, double *result_host)
+{
+  return guarded([&] {
+    require(ctx && x && y && result_host, "null argument");
+    *result_host = vec::dot<double>(*ctx->handle, n, x, y);
+  });
+}
+int mfmg_hip_vector_l2_norm(mfmg_hip_context_t ctx, int64_t n, const double *x, double *result_host)
+{
+  return guarded([&] {
+    require(ctx && x && result_host, "null argument");
+    *result_host = vec::l2_norm<double>(*ctx->handle, n, x);
+  });
+}
+
+// ---- CSR -------------------------------------------------------------------------
+int mfmg_hip_csr_create(mfmg_hip_context_t ctx, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                        const int32_t *row_ptr_host, const int32_t *col_host, const double *val_host,
+                        mfmg_hip_csr_t *out)
+{
+  return guarded([&] {
+    require(ctx && out && row_ptr_host, "null argument");
+    require(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "negative size");
+    require(nnz == 0 || (col_host && val_host), "null column / value array");
+    std::vector<int32_t> rp(row_ptr_host, row_ptr_host + n_rows + 1);
+    require(rp[n_rows] == nnz, "row_ptr[n_rows] != nnz");
+    std::vector<int32_t> cl(col_host, col_host + nnz);
+    std::vector<double> vl(val_host, val_host + nnz);
+    auto m = std::make_shared<SparseMatrixDevice<double>>(*ctx->handle, n_rows, n_cols, std::move(rp), std::move(cl),
+                                                          std::move(vl));
+    auto h = new mfmg_hip_csr_s;
+    h->op = std::make_shared<HipMatrixOperator>(m);
+    *out = h;
+  });
+}
+
+int mfmg_hip_csr_destroy(mfmg_hip_csr_t a)
+{
+  return guarded([&] {
+    if (a && !a->borrowed)
+      delete a;
+  });
+}
+
+int mfmg_hip_csr_shape(mfmg_hip_csr_t a, int64_t *n_rows, int64_t *n_cols, int64_t *nnz)
+{
+  return guarded([&] {
+    require(a != nullptr, "null matrix");
+    auto m = a->op->get_matrix();
+    if (n_rows)
+      *n_rows = m->m();
+    if (n_cols)
+      *n_cols = m->n();
+    if (nnz)
+      *nnz = m->n_nonzero_elements();
+  });
+}
+
+int mfmg_hip_csr_vmult(mfmg_hip_csr_t a, const double *x, double *y)
+{
+  return guarded([&] {
+    require(a && x && y, "null argument");
+    a->op->get_matrix()->vmult(y, x);
+  });
+}
+
+int mfmg_hip_csr_apply(mfmg_hip_csr_t a, const double *x, double *y, int mode)
+{
+  return guarded([&] {
+    require(a && x && y, "null argument");
+    require(mode == MFMG_HIP_NO_TRANS || mode == MFMG_HIP_TRANS, "unknown operator mode");
+    if (mode == MFMG_HIP_NO_TRANS)
+      a->op->get_matrix()->vmult(y, x);
+    else
+      a->op->get_transposed_matrix()->vmult(y, x);
+  });
+}
+
+int mfmg_hip_csr_transpose(mfmg_hip_csr_t a, mfmg_hip_csr_t *out)
+{
+  return guarded([&] {
+    require(a && out, "null argument");
+    auto h = new mfmg_hip_csr_s;
+    h->op = std::dynamic_pointer_cast<HipMatrixOperator>(a->op->transpose());
+    *out = h;
+  });
+}
+
+int mfmg_hip_csr_multiply(mfmg_hip_csr_t a, mfmg_hip_csr_t b, mfmg_hip_csr_t *out)
+{
+  return guarded([&] {
+    require(a && b && out, "null argument");
+    auto h = new mfmg_hip_csr_s;
+    h->op = std::dynamic_pointer_cast<HipMatrixOperator>(a->op->multiply(b->op));
+    *out = h;
+  });
+}
+
+int mfmg_hip_csr_download(mfmg_hip_csr_t a, int32_t *row_ptr_host, int32_t *col_host, double *val_host)
+{
+  return guarded([&] {
+    require(a && row_ptr_host, "null argument");
+    std::vector<int32_t> rp, cl;
+    std::vector<double> vl;
+    a->op->get_matrix()->download(rp, cl, vl);
+    std::memcpy(row_ptr_host, rp.data(), rp.size() * sizeof(int32_t));
+    if (!cl.empty())
+    {
+      require(col_host && val_host, "null column / value array");
+      std::memcpy(col_host, cl.data(), cl.size() * sizeof(int32_t));
+      std::memcpy(val_host, vl.data(), vl.size() * sizeof(double));
+    }
+  });
+}
+
+int mfmg_hip_csr_inverse_diagonal(mfmg_hip_csr_t a, double *dinv)
+{
+  return guarded([&] {
+    require(a && dinv, "null argument");
+    a->op->get_matrix()->inverse_diagonal(dinv);
+  });
+}
+
+int mfmg_hip_csr_smoother_step(mfmg_hip_csr_t a, const double *dinv, const double *b, const double *x,
+                               const double *x_prev, double alpha, double beta, double *out)
+{
+  return guarded([&] {
+    require(a && dinv && b && x && out, "null argument");
+    auto m = a->op->get_matrix();
+    require(m->m() == m->n(), "the smoother needs a square matrix");
+    m->smoother_step(dinv, b, x, x_prev, alpha, beta, out);
+  });
+}
+
+int mfmg_hip_csr_residual(mfmg_hip_csr_t a, const double *x, const double *b, double *res)
+{
+  return guarded([&] {
+    require(a && x && b && res, "null argument");
+    a->op->get_matrix()->residual(x, b, res);
+  });
+}
+
+// ---- matrix-free Laplace -----------------------------------------------------------
+int mfmg_hip_mf_laplace_create(mfmg_hip_context_t ctx, const mfmg_hip_mesh_desc *mesh, mfmg_hip_mf_laplace_t *out)
+{
+  return guarded([&] {
+    require(ctx && mesh && out, "null argument");
+    auto h = new mfmg_hip_mf_laplace_s;
+    try
+    {
+      h->op = std::make_shared<MatrixFreeLaplaceDevice<double>>(*ctx->handle, *mesh);
+    }
+    catch (...)
+    {
+      delete h;
+      throw;
+    }
+    *out = h;
+  });
+}
+
+int mfmg_hip_mf_laplace_destroy(mfmg_hip_mf_laplace_t op)
+{
+  return guarded([&] { delete op; });
+}
+
+int mfmg_hip_mf_laplace_size(mfmg_hip_mf_laplace_t op, int64_t *n_dofs)
+{
+  return guarded([&] {
+    require(op && n_dofs, "null argument");
+    *n_dofs = op->op->n_dofs();
+  });
+}
+
+int mfmg_hip_mf_laplace_vmult(mfmg_hip_mf_laplace_t op, const double *x, double *y)
+{
+  return guarded([&] {
+    require(op && x && y, "null argument");
+    op->op->vmult(x, y);
+  });
+}
+
+int mfmg_hip_mf_laplace_diagonal_inverse(mfmg_hip_mf_laplace_t op, double *dinv)
+{
+  return guarded([&] {
+    require(op && dinv, "null argument");
+    vec::copy<double>(op->op->handle(), op->op->n_dofs(), op->op->diagonal_inverse(), dinv);
+  });
+}
+
+int mfmg_hip_mf_laplace_diagonal(mfmg_hip_mf_laplace_t op, double *diag)
+{
+  return guarded([&] {
+    require(op && diag, "null argument");
+    vec::copy<double>(op->op->handle(), op->op->n_dofs(), op->op->diagonal(), diag);
+  });
+}
+
+int mfmg_hip_mf_laplace_residual(mfmg_hip_mf_laplace_t op, const double *x, const double *b, double *res)
+{
+  return guarded([&] {
+    require(op && x && b && res, "null argument");
+    op->op->residual(x, b, res);
+  });
+}
+
+int mfmg_hip_mf_laplace_smoother_step(mfmg_hip_mf_laplace_t op, const double *b, const double *x,
+                                      const double *x_prev, double alpha, double beta, double *out)
+{
+  return guarded([&] {
+    require(op && b && x && out, "null argument");
+    op->op->smoother_step(b, x, x_prev, alpha, beta, out);
+  });
+}
+
+int mfmg_hip_mf_laplace_set_tile(mfmg_hip_mf_laplace_t op, int tile_y, int tile_z)
+{
+  return guarded([&] {
+    require(op != nullptr, "null argument");
+    require(tile_y >= 0 && tile_z >= 0 && tile_y <= 64 && tile_z <= 1024, "tile size out of range");
+    op->op->set_tile(tile_y, tile_z);
+  });
+}
+
+// ---- hierarchy -----------------------------------------------------------------------
+int mfmg_hip_hierarchy_create(mfmg_hip_context_t ctx, const char *evaluator_type, const mfmg_hip_mesh_desc *mesh,
+                              const char *params_info, mfmg_hip_hierarchy_t *out)
+{
+  return guarded([&] {
+    require(ctx && evaluator_type && mesh && out, "null argument");
+    auto params = std::make_shared<ptree>(ptree::parse_info(params_info ? params_info : ""));
+    std::unique_ptr<mfmg_hip_hierarchy_s> h(new mfmg_hip_hierarchy_s);
+    h->handle = ctx->handle.get();
+    std::string type(evaluator_type);
+    if (type == "HipMatrixFreeMeshEvaluator")
+      h->evaluator = std::make_shared<HipMatrixFreeMeshEvaluator>(*ctx->handle, *mesh);
+    else if (type == "HipMeshEvaluator")
+      h->evaluator = std::make_shared<HipMeshEvaluator>(*ctx->handle, *mesh);
+    else
+      ASSERT_THROW_NOT_IMPLEMENTED("mesh evaluator type \"" + type + "\" is not available in the HIP build");
+    h->timer = std::make_shared<TimerOutput>();
+    h->hierarchy.reset(new Hierarchy<DVector>(nullptr, h->evaluator, params, h->timer));
+    MFMG_HIP_CHECK(hipStreamSynchronize(ctx->handle->stream));
+    *out = h.release();
+  });
+}
+
+int mfmg_hip_hierarchy_destroy(mfmg_hip_hierarchy_t h)
+{
+  return guarded([&] { delete h; });
+}
+
+namespace
+{
+int64_t level_size(mfmg_hip_hierarchy_t h, int level)
+{
+  auto const &levels = h->hierarchy->levels();
+  require(level >= 0 && level < (int)levels.size(), "level out of range");
+  auto op = levels[level].get_operator();
+  if (auto m = std::dynamic_pointer_cast<HipMatrixOperator const>(op))
+    return m->get_matrix()->m();
+  return (int64_t)op->grid_complexity();
+}
+} // namespace
+
+int mfmg_hip_hierarchy_apply(mfmg_hip_hierarchy_t h, const double *b, double *x)
+{
+  return guarded([&] {
+    require(h && b && x, "null argument");
+    const int64_t n = level_size(h, 0);
+    DVector bv(*h->handle, n, const_cast<double *>(b)), xv(*h->handle, n, x);
+    h->hierarchy->apply(bv, xv);
+  });
+}
+
+int mfmg_hip_hierarchy_vmult(mfmg_hip_hierarchy_t h, double *x, const double *b)
+{
+  return guarded([&] {
+    require(h && b && x, "null argument");
+    const int64_t n = level_size(h, 0);
+    DVector bv(*h->handle, n, const_cast<double *>(b)), xv(*h->handle, n, x);
+    h->hierarchy->vmult(xv, bv);
+  });
+}
+
+int mfmg_hip_hierarchy_n_levels(mfmg_hip_hierarchy_t h, int32_t *n_levels)
+{
+  return guarded([&] {
+    require(h && n_levels, "null argument");
+    *n_levels = (int32_t)h->hierarchy->levels().size();
+  });
+}
+
+int mfmg_hip_hierarchy_level_size(mfmg_hip_hierarchy_t h, int32_t level, int64_t *n)
+{
+  return guarded([&] {
+    require(h && n, "null argument");
+    *n = level_size(h, level);
+  });
+}
+
+int mfmg_hip_hierarchy_operator_apply(mfmg_hip_hierarchy_t h, int32_t level, const double *x, double *y, int mode)
+{
+  return guarded([&] {
+    require(h && x && y, "null argument");
+    require(mode == MFMG_HIP_NO_TRANS || mode == MFMG_HIP_TRANS, "unknown operator mode");
+    const int64_t n = level_size(h, level);
+    DVector xv(*h->handle, n, const_cast<double *>(x)), yv(*h->handle, n, y);
+    h->hierarchy->levels()[level].get_operator()->apply(
+        xv, yv, mode == MFMG_HIP_TRANS ? OperatorMode::TRANS : OperatorMode::NO_TRANS);
+  });
+}
+
+int mfmg_hip_hierarchy_smoother_apply(mfmg_hip_hierarchy_t h, int32_t level, const double *b, double *x)
+{
+  return guarded([&] {
+    require(h && b && x, "null argument");
+    const int64_t n = level_size(h, level);
+    auto smoother = h->hierarchy->levels()[level].get_smoother();
+    require(smoother != nullptr, "this level has no smoother");
+    DVector bv(*h->handle, n, const_cast<double *>(b)), xv(*h->handle, n, x);
+    smoother->apply(bv, xv);
+  });
+}
+
+int mfmg_hip_hierarchy_restrictor_apply(mfmg_hip_hierarchy_t h, int32_t level, const double *in, double *out,
+                                        int mode)
+{
+  return guarded([&] {
+    require(h && in && out, "null argument");
+    require(mode == MFMG_HIP_NO_TRANS || mode == MFMG_HIP_TRANS, "unknown operator mode");
+    require(level >= 1 && level < (int)h->hierarchy->levels().size(), "restrictors live on levels >= 1");
+    const int64_t n_fine = level_size(h, level - 1), n_coarse = level_size(h, level);
+    auto r = h->hierarchy->levels()[level].get_restrictor();
+    if (mode == MFMG_HIP_NO_TRANS)
+    {
+      DVector iv(*h->handle, n_fine, const_cast<double *>(in)), ov(*h->handle, n_coarse, out);
+      r->apply(iv, ov, OperatorMode::NO_TRANS);
+    }
+    else
+    {
+      DVector iv(*h->handle, n_coarse, const_cast<double *>(in)), ov(*h->handle, n_fine, out);
+      r->apply(iv, ov, OperatorMode::TRANS);
+    }
+  });
+}
+
+int mfmg_hip_hierarchy_coarse_apply(mfmg_hip_hierarchy_t h, const double *b, double *x)
+{
+  return guarded([&] {
+    require(h && b && x, "null argument");
+    const int last = (int)h->hierarchy->levels().size() - 1;
+    const int64_t n = level_size(h, last);
+    DVector bv(*h->handle, n, const_cast<double *>(b)), xv(*h->handle, n, x);
+    h->hierarchy->levels()[last].get_solver()->apply(bv, xv);
+  });
+}
+
+int mfmg_hip_hierarchy_set_restrictor(mfmg_hip_hierarchy_t h, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                                      const int32_t *row_ptr_host, const int32_t *col_host, const double *val_host)
+{
+  return guarded([&] {
+    require(h && row_ptr_host && col_host && val_host, "null argument");
+    require(n_cols == level_size(h, 0), "the restrictor must have one column per fine DoF");
+    std::vector<int32_t> rp(row_ptr_host, row_ptr_host + n_rows + 1);
+    require(rp[n_rows] == nnz, "row_ptr[n_rows] != nnz");
+    std::vector<int32_t> cl(col_host, col_host + nnz);
+    std::vector<double> vl(val_host, val_host + nnz);
+    auto m = std::make_shared<SparseMatrixDevice<double>>(*h->handle, n_rows, n_cols, std::move(rp), std::move(cl),
+                                                          std::move(vl));
+    h->hierarchy->set_restrictor(std::make_shared<HipMatrixOperator>(m));
+    MFMG_HIP_CHECK(hipStreamSynchronize(h->handle->stream));
+  });
+}
+
+int mfmg_hip_hierarchy_get_restrictor(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *r_borrowed)
+{
+  return guarded([&] {
+    require(h && r_borrowed, "null argument");
+    require(h->hierarchy->levels().size() >= 2, "the hierarchy has a single level");
+    auto r = std::dynamic_pointer_cast<HipMatrixOperator const>(h->hierarchy->levels()[1].get_restrictor());
+    require(r != nullptr, "the restrictor is not a matrix operator");
+    h->restrictor_view.op = std::const_pointer_cast<HipMatrixOperator>(r);
+    h->restrictor_view.borrowed = true;
+    *r_borrowed = &h->restrictor_view;
+  });
+}
+
+int mfmg_hip_hierarchy_get_coarse_operator(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *ac_borrowed)
+{
+  return guarded([&] {
+    require(h && ac_borrowed, "null argument");
+    require(h->hierarchy->levels().size() >= 2, "the hierarchy has a single level");
+    auto a = std::dynamic_pointer_cast<HipMatrixOperator const>(h->hierarchy->levels().back().get_operator());
+    require(a != nullptr, "the coarse operator is not a matrix operator");
+    h->coarse_view.op = std::const_pointer_cast<HipMatrixOperator>(a);
+    h->coarse_view.borrowed = true;
+    *ac_borrowed = &h->coarse_view;
+  });
+}
+
+int mfmg_hip_hierarchy_smoother_info(mfmg_hip_hierarchy_t h, int32_t *degree, double *lambda_min, double *lambda_max)
+{
+  return guarded([&] {
+    require(h != nullptr, "null argument");
+    auto s = std::dynamic_pointer_cast<HipSmoother const>(h->hierarchy->levels()[0].get_smoother());
+    require(s != nullptr, "level 0 has no HIP smoother");
+    if (degree)
+      *degree = s->degree();
+    if (lambda_min)
+      *lambda_min = s->lambda_min();
+    if (lambda_max)
+      *lambda_max = s->lambda_max();
+  });
+}
+
+int mfmg_hip_hierarchy_timer_report(mfmg_hip_hierarchy_t h, char *buf, size_t buf_size)
+{
+  return guarded([&] {
+    require(h && buf && buf_size > 0, "null argument");
+    std::string s = h->timer->summary();
+    std::strncpy(buf, s.c_str(), buf_size - 1);
+    buf[buf_size - 1] = '\0';
+  });
+}
+
+// ---- host-side setup pieces -------------------------------------------------------------
+namespace
+{
+StructuredMesh host_mesh(const mfmg_hip_mesh_desc *mesh)
+{
+  require(mesh != nullptr, "null mesh");
+  require(mesh->arrays_on_device == 0, "the host entry points need host arrays");
+  return StructuredMesh::from_desc(*mesh, nullptr);
+}
+} // namespace
+
+int mfmg_hip_host_csr_shape(mfmg_hip_host_csr_t m, int64_t *n_rows, int64_t *n_cols, int64_t *nnz)
+{
+  return guarded([&] {
+    require(m != nullptr, "null matrix");
+    if (n_rows)
+      *n_rows = m->m.n_rows;
+    if (n_cols)
+      *n_cols = m->m.n_cols;
+    if (nnz)
+      *nnz = m->m.nnz();
+  });
+}
+
+int mfmg_hip_host_csr_get(mfmg_hip_host_csr_t m, int32_t *row_ptr, int32_t *col, double *val)
+{
+  return guarded([&] {
+    require(m && row_ptr, "null argument");
+    std::memcpy(row_ptr, m->m.row_ptr.data(), m->m.row_ptr.size() * sizeof(int32_t));
+    if (m->m.nnz() > 0)
+    {
+      require(col && val, "null column / value array");
+      std::memcpy(col, m->m.col.data(), m->m.col.size() * sizeof(int32_t));
+      std::memcpy(val, m->m.val.data(), m->m.val.size() * sizeof(double));
+    }
+  });
+}
+
+int mfmg_hip_host_csr_destroy(mfmg_hip_host_csr_t m)
+{
+  return guarded([&] { delete m; });
+}
+
+int mfmg_hip_host_assemble_matrix(const mfmg_hip_mesh_desc *mesh, int semantics, mfmg_hip_host_csr_t *out)
+{
+  return guarded([&] {
+    require(out != nullptr, "null output handle");
+    require(semantics == 0 || semantics == 1, "unknown constraint semantics");
+    auto sm = host_mesh(mesh);
+    auto h = new mfmg_hip_host_csr_s;
+    h->m = assemble_global_matrix(sm, semantics == 0 ? ConstraintSemantics::assembled
+                                                     : ConstraintSemantics::matrix_free);
+    *out = h;
+  });
+}
+
+int mfmg_hip_host_build_restrictor(const mfmg_hip_mesh_desc *mesh, const char *params_info, int matrix_free,
+                                   mfmg_hip_host_csr_t *out)
+{
+  return guarded([&] {
+    require(out != nullptr, "null output handle");
+    auto sm = host_mesh(mesh);
+    ptree params = ptree::parse_info(params_info ? params_info : "");
+    RestrictorOptions o;
+    o.agglomerate[0] = params.get("agglomeration.nx", 2);
+    o.agglomerate[1] = params.get("agglomeration.ny", 2);
+    o.agglomerate[2] = params.get("agglomeration.nz", 2);
+    o.n_eigenvectors = params.get("eigensolver.number of eigenvectors", 1);
+    o.variant = params.get("eigensolver.variant", matrix_free ? "mf" : "device");
+    o.selection = params.get("eigensolver.selection", matrix_free ? "krylov" : "lapack");
+    o.use_coefficient = params.get("eigensolver.use_coefficient", true);
+    auto diag = operator_diagonal(sm, matrix_free ? ConstraintSemantics::matrix_free : ConstraintSemantics::assembled);
+    auto h = new mfmg_hip_host_csr_s;
+    h->m = build_restrictor_structured(sm, diag, o);
+    *out = h;
+  });
+}
+
+int mfmg_hip_host_galerkin(const mfmg_hip_mesh_desc *mesh, int semantics, int64_t n_rows, int64_t nnz,
+                           const int32_t *r_row_ptr, const int32_t *r_col, const double *r_val,
+                           mfmg_hip_host_csr_t *out)
+{
+  return guarded([&] {
+    require(out && r_row_ptr && r_col && r_val, "null argument");
+    require(semantics == 0 || semantics == 1, "unknown constraint semantics");
+    auto sm = host_mesh(mesh);
+    HostCsr R, Rt;
+    R.n_rows = n_rows;
+    R.n_cols = sm.n_dofs;
+    R.row_ptr.assign(r_row_ptr, r_row_ptr + n_rows + 1);
+    require(R.row_ptr[n_rows] == nnz, "row_ptr[n_rows] != nnz");
+    R.col.assign(r_col, r_col + nnz);
+    R.val.assign(r_val, r_val + nnz);
+    Rt.n_rows = R.n_cols;
+    Rt.n_cols = R.n_rows;
+    csr_transpose_host<double>(R.n_rows, R.n_cols, R.row_ptr, R.col, R.val, Rt.row_ptr, Rt.col, Rt.val);
+    auto h = new mfmg_hip_host_csr_s;
+    h->m = galerkin_triple_product(
+        sm, semantics == 0 ? ConstraintSemantics::assembled : ConstraintSemantics::matrix_free, R, Rt);
+    *out = h;
+  });
+}
+
+int mfmg_hip_host_params_get(const char *params_info, const char *path, char *value_buf, size_t buf_size)
+{
+  return guarded([&] {
+    require(params_info && path && value_buf && buf_size > 0, "null argument");
+    ptree params = ptree::parse_info(params_info);
+    std::string v = params.get<std::string>(path);
+    std::strncpy(value_buf, v.c_str(), buf_size - 1);
+    value_buf[buf_size - 1] = '\0';
+  });
+}
+
+} // extern "C"

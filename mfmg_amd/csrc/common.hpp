@@ -1,0 +1,187 @@
+// Shared plumbing of libmfmg_hip: error conventions, device buffers, launch helpers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mfmg_hip.h"
+
+namespace mfmg
+{
+// ---- error conventions of include/mfmg/common/exceptions.hpp:33-73 ----
+// ASSERT_THROW throws std::runtime_error always; NotImplementedExc for
+// unsupported paths; HIP status checks are always on (the reference's
+// ASSERT_CUDA is debug-only, exceptions.hpp:193-217 -- a faulting kernel on
+// this pool is too expensive to leave unchecked).
+class NotImplementedExc : public std::exception
+{
+public:
+  explicit NotImplementedExc(std::string what = "The function is not implemented")
+      : _what(std::move(what))
+  {
+  }
+  const char *what() const noexcept override { return _what.c_str(); }
+
+private:
+  std::string _what;
+};
+
+class InvalidArgumentExc : public std::runtime_error
+{
+public:
+  using std::runtime_error::runtime_error;
+};
+
+class DeviceExc : public std::runtime_error
+{
+public:
+  using std::runtime_error::runtime_error;
+};
+
+inline void ASSERT_THROW(bool cond, std::string const &message)
+{
+  if (!cond)
+    throw std::runtime_error(message);
+}
+
+[[noreturn]] inline void ASSERT_THROW_NOT_IMPLEMENTED(std::string const &what = "")
+{
+  throw NotImplementedExc(what.empty() ? "The function is not implemented" : what);
+}
+
+inline void ASSERT_HIP(hipError_t err, const char *file, int line)
+{
+  if (err != hipSuccess)
+    throw DeviceExc(std::string("HIP error: ") + hipGetErrorString(err) + " at " + file + ":" +
+                    std::to_string(line));
+}
+#define MFMG_HIP_CHECK(expr) ::mfmg::ASSERT_HIP((expr), __FILE__, __LINE__)
+
+// block_size of include/mfmg/cuda/utils.cuh:35 is 512 (warp-32 era); 256 = 4 waves of 64.
+constexpr int block_size = 256;
+
+inline unsigned int n_blocks_for(int64_t n, int bs = block_size, int64_t cap = 1 << 20)
+{
+  int64_t nb = (n + bs - 1) / bs;
+  if (nb < 1)
+    nb = 1;
+  if (nb > cap)
+    nb = cap;
+  return static_cast<unsigned int>(nb);
+}
+
+// ---- owning device buffer (cuda_malloc/cuda_free, include/mfmg/cuda/utils.cuh:66-99) ----
+template <typename T>
+class DeviceBuffer
+{
+public:
+  DeviceBuffer() = default;
+  explicit DeviceBuffer(size_t n) { resize(n); }
+  DeviceBuffer(DeviceBuffer const &) = delete;
+  DeviceBuffer &operator=(DeviceBuffer const &) = delete;
+  DeviceBuffer(DeviceBuffer &&o) noexcept : _ptr(o._ptr), _n(o._n)
+  {
+    o._ptr = nullptr;
+    o._n = 0;
+  }
+  DeviceBuffer &operator=(DeviceBuffer &&o) noexcept
+  {
+    if (this != &o)
+    {
+      release();
+      _ptr = o._ptr;
+      _n = o._n;
+      o._ptr = nullptr;
+      o._n = 0;
+    }
+    return *this;
+  }
+  ~DeviceBuffer() { release(); }
+
+  void resize(size_t n)
+  {
+    release();
+    if (n > 0)
+    {
+      MFMG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&_ptr), n * sizeof(T)));
+      _n = n;
+    }
+  }
+  void release()
+  {
+    if (_ptr)
+      (void)hipFree(_ptr);
+    _ptr = nullptr;
+    _n = 0;
+  }
+  void upload(T const *host, size_t n, hipStream_t stream = nullptr)
+  {
+    if (n != _n)
+      resize(n);
+    if (n)
+    {
+      MFMG_HIP_CHECK(hipMemcpyAsync(_ptr, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
+      MFMG_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+  }
+  std::vector<T> download(hipStream_t stream = nullptr) const
+  {
+    std::vector<T> h(_n);
+    if (_n)
+    {
+      MFMG_HIP_CHECK(hipMemcpyAsync(h.data(), _ptr, _n * sizeof(T), hipMemcpyDeviceToHost, stream));
+      MFMG_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    return h;
+  }
+  T *data() { return _ptr; }
+  T const *data() const { return _ptr; }
+  size_t size() const { return _n; }
+
+private:
+  T *_ptr = nullptr;
+  size_t _n = 0;
+};
+
+// ---- HipHandle: stream + reduction scratch; twin of CudaHandle
+//      (include/mfmg/cuda/cuda_handle.cuh:25-48): borrowed by every object built from it ----
+struct HipHandle
+{
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  // scratch for two-stage deterministic reductions
+  DeviceBuffer<double> reduce_partials;
+  DeviceBuffer<double> reduce_result;
+  double *host_result = nullptr; // pinned
+
+  explicit HipHandle(hipStream_t s)
+  {
+    if (s == nullptr)
+    {
+      MFMG_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+      owns_stream = true;
+    }
+    else
+      stream = s;
+    reduce_partials.resize(4096);
+    reduce_result.resize(16);
+    MFMG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&host_result), 16 * sizeof(double)));
+  }
+  ~HipHandle()
+  {
+    if (host_result)
+      (void)hipHostFree(host_result);
+    if (owns_stream && stream)
+      (void)hipStreamDestroy(stream);
+  }
+  HipHandle(HipHandle const &) = delete;
+  HipHandle &operator=(HipHandle const &) = delete;
+};
+} // namespace mfmg

@@ -1,0 +1,626 @@
+// Implementation of the HIP back-end classes declared in mfmg/hip_hierarchy_helpers.hpp.
+#include "mfmg/hip_hierarchy_helpers.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+
+namespace mfmg
+{
+namespace
+{
+std::string to_lower(std::string s)
+{
+  std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return std::tolower(c); });
+  return s;
+}
+
+__global__ void dense_gemv_kernel(int n, double const *m, double const *x, double *y)
+{
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  double sum = 0.;
+  if (row < n)
+  {
+    double const *mr = m + (size_t)row * n;
+    for (int c = lane; c < n; c += 64)
+      sum += mr[c] * x[c];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    sum += __shfl_xor(sum, off);
+  if (row < n && lane == 0)
+    y[row] = sum;
+}
+
+std::shared_ptr<SparseMatrixDevice<double>> upload(HipHandle &handle, HostCsr &&m)
+{
+  return std::make_shared<SparseMatrixDevice<double>>(handle, m.n_rows, m.n_cols, std::move(m.row_ptr),
+                                                      std::move(m.col), std::move(m.val));
+}
+} // namespace
+
+void dense_gemv(HipHandle &handle, int n, double const *matrix, double const *x, double *y)
+{
+  if (n <= 0)
+    return;
+  const int rows_per_block = block_size / 64;
+  hipLaunchKernelGGL(dense_gemv_kernel, dim3((n + rows_per_block - 1) / rows_per_block), dim3(block_size), 0,
+                     handle.stream, n, matrix, x, y);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+// ---- evaluators ------------------------------------------------------------------
+HipMeshEvaluator::HipMeshEvaluator(HipHandle &handle, mfmg_hip_mesh_desc const &mesh)
+    : _handle(handle), _desc(mesh), _mesh(StructuredMesh::from_desc(mesh, handle.stream))
+{
+  // the hierarchy outlives the caller's arrays: setup works from the host copy
+  _desc.cell_dofs = _mesh.cell_dofs.data();
+  _desc.coefficient = _mesh.coefficient.data();
+  _desc.constrained = _mesh.constrained.data();
+  _desc.arrays_on_device = 0;
+}
+
+std::shared_ptr<SparseMatrixDevice<double>> HipMeshEvaluator::evaluate_global() const
+{
+  return upload(_handle, assemble_global_matrix(_mesh, ConstraintSemantics::assembled));
+}
+
+std::vector<double> HipMeshEvaluator::get_locally_relevant_diag() const
+{
+  return operator_diagonal(_mesh, ConstraintSemantics::assembled);
+}
+
+RestrictorOptions HipMeshEvaluator::agglomerate_options(ptree const &params) const
+{
+  RestrictorOptions o;
+  o.agglomerate[0] = params.get("agglomeration.nx", 2);
+  o.agglomerate[1] = params.get("agglomeration.ny", 2);
+  o.agglomerate[2] = params.get("agglomeration.nz", 2);
+  std::string const partitioner = params.get("agglomeration.partitioner", "block");
+  ASSERT_THROW(partitioner == "block", "only the block partitioner is available (zoltan/metis are mesh-library "
+                                       "bound and out of scope): \"" +
+                                           partitioner + "\"");
+  o.n_eigenvectors = params.get("eigensolver.number of eigenvectors", 1);
+  // AMGe_device ignores eigensolver.type: dense, unshifted, first columns
+  // (include/mfmg/cuda/amge_device.templates.cuh:256-310)
+  o.variant = params.get("eigensolver.variant", "device");
+  o.selection = params.get("eigensolver.selection", "lapack");
+  // the reference device test poses the agglomerate problems without the coefficient
+  // (tests/test_hierarchy_device.cu:239-244)
+  o.use_coefficient = params.get("eigensolver.use_coefficient", true);
+  return o;
+}
+
+HipMatrixFreeMeshEvaluator::HipMatrixFreeMeshEvaluator(HipHandle &handle, mfmg_hip_mesh_desc const &mesh)
+    : HipMeshEvaluator(handle, mesh)
+{
+  _op = std::make_shared<MatrixFreeLaplaceDevice<double>>(handle, _desc);
+}
+
+std::shared_ptr<DVector> HipMatrixFreeMeshEvaluator::build_range_vector() const
+{
+  return std::make_shared<DVector>(_handle, _mesh.n_dofs);
+}
+
+void HipMatrixFreeMeshEvaluator::matrix_free_evaluate_global(DVector const &src, DVector &dst) const
+{
+  _op->vmult(src.get_values(), dst.get_values());
+}
+
+double const *HipMatrixFreeMeshEvaluator::matrix_free_get_diagonal_inverse() const
+{
+  return _op->diagonal_inverse();
+}
+
+std::vector<double> HipMatrixFreeMeshEvaluator::get_diagonal() const
+{
+  std::vector<double> d(_mesh.n_dofs);
+  MFMG_HIP_CHECK(hipMemcpyAsync(d.data(), _op->diagonal(), d.size() * sizeof(double), hipMemcpyDeviceToHost,
+                                _handle.stream));
+  MFMG_HIP_CHECK(hipStreamSynchronize(_handle.stream));
+  return d;
+}
+
+RestrictorOptions HipMatrixFreeMeshEvaluator::agglomerate_options(ptree const &params) const
+{
+  RestrictorOptions o = HipMeshEvaluator::agglomerate_options(params);
+  // matrix-free agglomerate operator + Krylov eigensolver semantics
+  // (include/mfmg/dealii/amge_host.templates.hpp:278-350)
+  o.variant = params.get("eigensolver.variant", "mf");
+  o.selection = params.get("eigensolver.selection", "krylov");
+  return o;
+}
+
+// ---- HipMatrixOperator ---------------------------------------------------------
+HipMatrixOperator::HipMatrixOperator(std::shared_ptr<SparseMatrixDevice<double>> sparse_matrix)
+    : _matrix(std::move(sparse_matrix))
+{
+  ASSERT_THROW(_matrix != nullptr, "The matrix must exist");
+}
+
+std::shared_ptr<SparseMatrixDevice<double>> HipMatrixOperator::get_transposed_matrix() const
+{
+  if (!_transposed_matrix)
+    _transposed_matrix = _matrix->transpose();
+  return _transposed_matrix;
+}
+
+void HipMatrixOperator::apply(DVector const &x, DVector &y, OperatorMode mode) const
+{
+  if (mode == OperatorMode::NO_TRANS)
+  {
+    ASSERT_THROW(x.size() == _matrix->n() && y.size() == _matrix->m(), "vector sizes do not match the operator");
+    _matrix->vmult(y.get_values(), x.get_values());
+  }
+  else
+  {
+    ASSERT_THROW(x.size() == _matrix->m() && y.size() == _matrix->n(), "vector sizes do not match the operator");
+    get_transposed_matrix()->vmult(y.get_values(), x.get_values());
+  }
+}
+
+void HipMatrixOperator::residual(DVector const &x, DVector const &b, DVector &res) const
+{
+  _matrix->residual(x.get_values(), b.get_values(), res.get_values());
+}
+
+void HipMatrixOperator::apply_subtract(DVector const &x, DVector &y, OperatorMode mode) const
+{
+  if (mode == OperatorMode::NO_TRANS)
+    _matrix->vmult_subtract(y.get_values(), x.get_values());
+  else
+    get_transposed_matrix()->vmult_subtract(y.get_values(), x.get_values());
+}
+
+std::shared_ptr<Operator<DVector>> HipMatrixOperator::transpose() const
+{
+  return std::make_shared<HipMatrixOperator>(get_transposed_matrix());
+}
+
+std::shared_ptr<Operator<DVector>> HipMatrixOperator::multiply(std::shared_ptr<Operator<DVector> const> b) const
+{
+  // R->multiply(A R^T) for a matrix-free A: fused triple product
+  if (auto half = std::dynamic_pointer_cast<HipGalerkinHalfProduct const>(b))
+  {
+    ASSERT_THROW(half->get_r()->get_matrix() == _matrix, "the Galerkin product needs the same restrictor on both sides");
+    auto evaluator = half->get_a()->get_mesh_evaluator();
+    HostCsr R, Rt;
+    R.n_rows = _matrix->m();
+    R.n_cols = _matrix->n();
+    _matrix->download(R.row_ptr, R.col, R.val);
+    Rt.n_rows = R.n_cols;
+    Rt.n_cols = R.n_rows;
+    csr_transpose_host<double>(R.n_rows, R.n_cols, R.row_ptr, R.col, R.val, Rt.row_ptr, Rt.col, Rt.val);
+    HostCsr Ac = galerkin_triple_product(evaluator->get_mesh(), evaluator->constraint_semantics(), R, Rt);
+    return std::make_shared<HipMatrixOperator>(upload(_matrix->handle(), std::move(Ac)));
+  }
+  auto downcast_b = std::dynamic_pointer_cast<HipMatrixOperator const>(b);
+  ASSERT_THROW(downcast_b != nullptr, "HipMatrixOperator::multiply needs a HipMatrixOperator");
+  return std::make_shared<HipMatrixOperator>(_matrix->mmult(*downcast_b->get_matrix()));
+}
+
+std::shared_ptr<Operator<DVector>>
+HipMatrixOperator::multiply_transpose(std::shared_ptr<Operator<DVector> const> b) const
+{
+  // C = A B^T (source/cuda/cuda_matrix_operator.cu:151-225)
+  auto downcast_b = std::dynamic_pointer_cast<HipMatrixOperator const>(b);
+  ASSERT_THROW(downcast_b != nullptr, "HipMatrixOperator::multiply_transpose needs a HipMatrixOperator");
+  return std::make_shared<HipMatrixOperator>(_matrix->mmult(*downcast_b->get_transposed_matrix()));
+}
+
+std::shared_ptr<DVector> HipMatrixOperator::build_domain_vector() const
+{
+  return std::make_shared<DVector>(_matrix->handle(), _matrix->n());
+}
+
+std::shared_ptr<DVector> HipMatrixOperator::build_range_vector() const
+{
+  return std::make_shared<DVector>(_matrix->handle(), _matrix->m());
+}
+
+size_t HipMatrixOperator::grid_complexity() const { return _matrix->m(); }
+
+size_t HipMatrixOperator::operator_complexity() const { return _matrix->n_nonzero_elements(); }
+
+double const *HipMatrixOperator::get_diagonal_inverse() const
+{
+  if (_dinv.size() == 0)
+  {
+    _dinv.resize(_matrix->m());
+    _matrix->inverse_diagonal(_dinv.data());
+  }
+  return _dinv.data();
+}
+
+void HipMatrixOperator::smoother_step(DVector const &b, DVector const &x, DVector const *x_prev, double alpha,
+                                      double beta, DVector &out) const
+{
+  _matrix->smoother_step(get_diagonal_inverse(), b.get_values(), x.get_values(),
+                         x_prev ? x_prev->get_values() : nullptr, alpha, beta, out.get_values());
+}
+
+// ---- HipMatrixFreeOperator -----------------------------------------------------
+HipMatrixFreeOperator::HipMatrixFreeOperator(std::shared_ptr<HipMatrixFreeMeshEvaluator> matrix_free_mesh_evaluator)
+    : _mesh_evaluator(std::move(matrix_free_mesh_evaluator))
+{
+  ASSERT_THROW(_mesh_evaluator != nullptr, "downcasting failed");
+}
+
+void HipMatrixFreeOperator::vmult(DVector &dst, DVector const &src) const
+{
+  _mesh_evaluator->matrix_free_evaluate_global(src, dst);
+}
+
+void HipMatrixFreeOperator::apply(DVector const &x, DVector &y, OperatorMode mode) const
+{
+  if (mode != OperatorMode::NO_TRANS)
+    ASSERT_THROW_NOT_IMPLEMENTED(); // source/cuda/cuda_matrix_free_operator.cu:64-71
+  vmult(y, x);
+}
+
+std::shared_ptr<Operator<DVector>> HipMatrixFreeOperator::transpose() const
+{
+  ASSERT_THROW_NOT_IMPLEMENTED();
+  return nullptr;
+}
+
+std::shared_ptr<Operator<DVector>> HipMatrixFreeOperator::multiply(std::shared_ptr<Operator<DVector> const>) const
+{
+  ASSERT_THROW_NOT_IMPLEMENTED();
+  return nullptr;
+}
+
+std::shared_ptr<Operator<DVector>>
+HipMatrixFreeOperator::multiply_transpose(std::shared_ptr<Operator<DVector> const> b) const
+{
+  auto downcast_b = std::dynamic_pointer_cast<HipMatrixOperator const>(b);
+  ASSERT_THROW(downcast_b != nullptr, "HipMatrixFreeOperator::multiply_transpose needs a HipMatrixOperator");
+  auto self = std::make_shared<HipMatrixFreeOperator>(_mesh_evaluator);
+  return std::make_shared<HipGalerkinHalfProduct>(self, downcast_b);
+}
+
+std::shared_ptr<DVector> HipMatrixFreeOperator::build_domain_vector() const
+{
+  return _mesh_evaluator->build_range_vector();
+}
+
+std::shared_ptr<DVector> HipMatrixFreeOperator::build_range_vector() const
+{
+  return _mesh_evaluator->build_range_vector();
+}
+
+size_t HipMatrixFreeOperator::grid_complexity() const { return _mesh_evaluator->get_mesh().n_dofs; }
+
+size_t HipMatrixFreeOperator::operator_complexity() const
+{
+  ASSERT_THROW_NOT_IMPLEMENTED();
+  return 0;
+}
+
+void HipMatrixFreeOperator::residual(DVector const &x, DVector const &b, DVector &res) const
+{
+  _mesh_evaluator->get_device_operator()->residual(x.get_values(), b.get_values(), res.get_values());
+}
+
+void HipMatrixFreeOperator::smoother_step(DVector const &b, DVector const &x, DVector const *x_prev, double alpha,
+                                          double beta, DVector &out) const
+{
+  _mesh_evaluator->get_device_operator()->smoother_step(b.get_values(), x.get_values(),
+                                                        x_prev ? x_prev->get_values() : nullptr, alpha, beta,
+                                                        out.get_values());
+}
+
+double const *HipMatrixFreeOperator::get_diagonal_inverse() const
+{
+  return _mesh_evaluator->matrix_free_get_diagonal_inverse();
+}
+
+void HipGalerkinHalfProduct::apply(DVector const &x, DVector &y, OperatorMode mode) const
+{
+  if (mode != OperatorMode::NO_TRANS)
+    ASSERT_THROW_NOT_IMPLEMENTED();
+  auto tmp = _a->build_domain_vector();
+  _r->apply(x, *tmp, OperatorMode::TRANS);
+  _a->apply(*tmp, y);
+}
+
+// ---- HipSmoother ---------------------------------------------------------------
+HipSmoother::HipSmoother(std::shared_ptr<Operator<DVector> const> op, std::shared_ptr<ptree const> params)
+    : Smoother<DVector>(op, params)
+{
+  _hip_operator = std::dynamic_pointer_cast<HipOperator const>(this->_operator);
+  ASSERT_THROW(_hip_operator != nullptr, "HipSmoother must be constructed from a HipMatrixOperator or a "
+                                         "HipMatrixFreeOperator");
+  const bool matrix_free = std::dynamic_pointer_cast<HipMatrixFreeOperator const>(_hip_operator) != nullptr;
+  // defaults: Jacobi on the device matrix path (source/cuda/cuda_smoother.cu:105), Chebyshev on
+  // the matrix-free path (source/dealii/dealii_matrix_free_smoother.cc:24)
+  std::string prec_type = this->_params->get("smoother.type", matrix_free ? "Chebyshev" : "Jacobi");
+  _type = to_lower(prec_type);
+  if (_type == "jacobi")
+  {
+    _lambda_min = _lambda_max = 1.;
+    _coefficients = {{0., 1.}}; // x <- x - D^{-1}(A x - b)
+  }
+  else if (_type == "chebyshev")
+  {
+    // AdditionalData of dealii::PreconditionChebyshev as filled at
+    // source/dealii/dealii_matrix_free_smoother.cc:34-56 (deal.II 9.1 defaults)
+    int degree = this->_params->get("smoother.degree", 1);
+    double smoothing_range = this->_params->get("smoother.smoothing_range", 0.);
+    double max_eigenvalue = this->_params->get("smoother.max_eigenvalue", 1.);
+    int eig_cg_n_iterations = this->_params->get("smoother.eig_cg_n_iterations", 8);
+    double eig_cg_residual = this->_params->get("smoother.eig_cg_residual", 1e-2);
+    ASSERT_THROW(degree >= 1, "smoother.degree must be at least one");
+    auto lmax = this->_params->get_optional<double>("smoother.lambda_max");
+    auto lmin = this->_params->get_optional<double>("smoother.lambda_min");
+    double min_est = 1., max_est = max_eigenvalue;
+    if (lmax)
+    {
+      max_est = *lmax;
+      min_est = lmin ? *lmin : *lmax;
+    }
+    else if (eig_cg_n_iterations > 0)
+    {
+      estimate_eigenvalues(eig_cg_n_iterations, eig_cg_residual, min_est, max_est);
+      max_est *= 1.2; // safety factor: the CG is not converged
+    }
+    _lambda_max = max_est;
+    if (lmin)
+      _lambda_min = *lmin;
+    else
+      _lambda_min = smoothing_range > 1. ? max_est / smoothing_range : std::min(0.9 * max_est, min_est);
+    const double theta = 0.5 * (_lambda_max + _lambda_min);
+    const double delta = 0.5 * (_lambda_max - _lambda_min);
+    _coefficients.push_back({0., 1. / theta});
+    if (degree >= 2 && std::abs(delta) >= 1e-40)
+    {
+      double rhok = delta / theta;
+      const double sigma = theta / delta;
+      for (int k = 0; k < degree - 1; ++k)
+      {
+        const double rhokp = 1. / (2. * sigma - rhok);
+        _coefficients.push_back({rhokp * rhok, 2. * rhokp / delta});
+        rhok = rhokp;
+      }
+    }
+  }
+  else
+  {
+    // Gauss-Seidel / SSOR / ILU are sequential Ifpack algorithms outside the HIP path
+    ASSERT_THROW(false, "Unknown smoother name: \"" + _type + "\" (the HIP back-end implements Jacobi and Chebyshev)");
+  }
+}
+
+void HipSmoother::estimate_eigenvalues(int n_iterations, double residual, double &min_est, double &max_est) const
+{
+  // PreconditionChebyshev::estimate_eigenvalues (deal.II 9.1): CG on A with D^{-1}, rhs = the
+  // mean-free (i % 11) vector, eigenvalues of the Lanczos tridiagonal.
+  HipHandle &h = _hip_operator->get_hip_handle();
+  auto rhs = _hip_operator->build_range_vector();
+  const int64_t n = rhs->size();
+  {
+    std::vector<double> v(n);
+    double mean = 0.;
+    for (int64_t i = 0; i < n; ++i)
+    {
+      v[i] = double(i % 11);
+      mean += v[i];
+    }
+    mean /= double(n);
+    for (auto &e : v)
+      e -= mean;
+    MFMG_HIP_CHECK(hipMemcpyAsync(rhs->get_values(), v.data(), n * sizeof(double), hipMemcpyHostToDevice, h.stream));
+    MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
+  }
+  double const *dinv = _hip_operator->get_diagonal_inverse();
+  DVector x(h, n), r(*rhs), z(h, n), p(h, n), ap(h, n);
+  vec::scale_pointwise<double>(h, n, dinv, r.get_values(), z.get_values());
+  p = z;
+  double rz = r * z;
+  const double tol = std::max(residual * rhs->l2_norm(), 1e-300);
+  std::vector<double> alphas, betas;
+  for (int it = 0; it < n_iterations; ++it)
+  {
+    _hip_operator->apply(p, ap);
+    const double pap = p * ap;
+    if (pap == 0.)
+      break;
+    const double alpha = rz / pap;
+    x.add(alpha, p);
+    r.add(-alpha, ap);
+    alphas.push_back(alpha);
+    if (r.l2_norm() < tol)
+      break;
+    vec::scale_pointwise<double>(h, n, dinv, r.get_values(), z.get_values());
+    const double rz_new = r * z;
+    const double beta = rz_new / rz;
+    betas.push_back(beta);
+    rz = rz_new;
+    p.sadd(beta, 1., z);
+  }
+  const int m = (int)alphas.size();
+  if (m == 0)
+  {
+    min_est = max_est = 1.;
+    return;
+  }
+  std::vector<double> T((size_t)m * m, 0.), w, V;
+  for (int i = 0; i < m; ++i)
+  {
+    T[(size_t)i * m + i] = 1. / alphas[i] + (i > 0 ? betas[i - 1] / alphas[i - 1] : 0.);
+    if (i + 1 < m)
+      T[(size_t)i * m + i + 1] = T[(size_t)(i + 1) * m + i] = std::sqrt(betas[i]) / alphas[i];
+  }
+  symmetric_eigen(m, T, w, V);
+  min_est = w.front();
+  max_est = w.back();
+}
+
+void HipSmoother::apply(DVector const &b, DVector &x) const
+{
+  // x <- x - B^{-1}(A x - b) with B^{-1} the Jacobi / Chebyshev polynomial, one fused kernel
+  // per polynomial term.  Targets alternate between two scratch vectors so that the last
+  // term lands in x (a term may overwrite its own x_{k-1}, never its x_k).
+  const int d = (int)_coefficients.size();
+  if (!_scratch_a)
+    _scratch_a = this->_operator->build_domain_vector();
+  if (d >= 3 && !_scratch_b)
+    _scratch_b = this->_operator->build_domain_vector();
+  if (d == 1)
+  {
+    _hip_operator->smoother_step(b, x, nullptr, 0., _coefficients[0].second, *_scratch_a);
+    x = *_scratch_a;
+    return;
+  }
+  std::vector<DVector *> target(d);
+  target[d - 1] = &x;
+  for (int k = d - 2, flip = 0; k >= 0; --k, flip ^= 1)
+    target[k] = flip ? _scratch_b.get() : _scratch_a.get();
+  DVector const *cur = &x;
+  DVector const *prev = nullptr;
+  for (int k = 0; k < d; ++k)
+  {
+    _hip_operator->smoother_step(b, *cur, prev, _coefficients[k].first, _coefficients[k].second, *target[k]);
+    prev = cur;
+    cur = target[k];
+  }
+}
+
+// ---- HipSolver -----------------------------------------------------------------
+HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const> op,
+                     std::shared_ptr<ptree const> params)
+    : Solver<DVector>(op, params), _handle(handle)
+{
+  _solver = to_lower(this->_params->get("solver.type", "lu_dense"));
+  _matrix_operator = std::dynamic_pointer_cast<HipMatrixOperator const>(this->_operator);
+  ASSERT_THROW(_matrix_operator != nullptr, "HipSolver needs a HipMatrixOperator");
+  auto matrix = _matrix_operator->get_matrix();
+  ASSERT_THROW(matrix->m() == matrix->n(), "The coarse matrix is not square");
+  const int64_t n = matrix->m();
+  if (_solver == "cholesky" || _solver == "lu_dense" || _solver == "lu_sparse_host")
+  {
+    // the three direct variants of source/cuda/cuda_solver.cu:51-72 share one dense factorisation here
+    const int64_t limit = this->_params->get("solver.dense_limit", 8192);
+    ASSERT_THROW(n <= limit, "The coarse problem (" + std::to_string(n) +
+                                 " rows) is too large for the dense direct solver; use solver.type pcg");
+    std::vector<int32_t> rp, cl;
+    std::vector<double> vl;
+    matrix->download(rp, cl, vl);
+    std::vector<double> dense((size_t)n * n, 0.);
+    for (int64_t r = 0; r < n; ++r)
+      for (int p = rp[r]; p < rp[r + 1]; ++p)
+        dense[(size_t)r * n + cl[p]] += vl[p];
+    dense_inverse((int)n, dense);
+    _dense_inverse.upload(dense.data(), dense.size(), _handle.stream);
+  }
+  else if (_solver == "pcg")
+  {
+    _n_iterations = this->_params->get("solver.n_iterations", 10);
+    ASSERT_THROW(_n_iterations >= 0, "solver.n_iterations must be non-negative");
+    _scal.resize(8);
+    _dinv.resize(n);
+    matrix->inverse_diagonal(_dinv.data());
+  }
+  else if (_solver == "amgx")
+  {
+    ASSERT_THROW_NOT_IMPLEMENTED("AMGx is not part of the HIP build (no AmgX shim); use solver.type pcg");
+  }
+  else
+  {
+    ASSERT_THROW(false, "Unknown solver name: \"" + _solver + "\"");
+  }
+}
+
+void HipSolver::apply(DVector const &b, DVector &x) const
+{
+  auto matrix = _matrix_operator->get_matrix();
+  const int64_t n = matrix->m();
+  ASSERT_THROW(b.size() == n && x.size() == n, "vector sizes do not match the coarse operator");
+  if (_solver == "pcg")
+  {
+    // exactly n_iterations steps of Jacobi-preconditioned CG from a zero guess, all scalars on the
+    // device (no host synchronisation inside the cycle)
+    if (!_r)
+    {
+      _r = _matrix_operator->build_range_vector();
+      _z = _matrix_operator->build_range_vector();
+      _p = _matrix_operator->build_range_vector();
+      _ap = _matrix_operator->build_range_vector();
+    }
+    x = 0.;
+    *_r = b;
+    vec::scale_pointwise<double>(_handle, n, _dinv.data(), _r->get_values(), _z->get_values());
+    *_p = *_z;
+    vec::dot_async<double>(_handle, n, _r->get_values(), _z->get_values(), _scal.data(), 0);
+    for (int it = 0; it < _n_iterations; ++it)
+    {
+      const int cur = it & 1, nxt = cur ^ 1;
+      matrix->vmult(_ap->get_values(), _p->get_values());
+      vec::dot_async<double>(_handle, n, _p->get_values(), _ap->get_values(), _scal.data(), 2);
+      vec::cg_update<double>(_handle, n, _p->get_values(), _ap->get_values(), _dinv.data(), x.get_values(),
+                             _r->get_values(), _z->get_values(), _scal.data(), cur, 2);
+      vec::dot_async<double>(_handle, n, _r->get_values(), _z->get_values(), _scal.data(), nxt);
+      vec::cg_direction<double>(_handle, n, _z->get_values(), _p->get_values(), _scal.data(), nxt, cur);
+    }
+  }
+  else
+  {
+    dense_gemv(_handle, (int)n, _dense_inverse.data(), b.get_values(), x.get_values());
+  }
+}
+
+// ---- HipHierarchyHelpers ---------------------------------------------------------
+template <typename VectorType>
+std::shared_ptr<Operator<VectorType>>
+HipHierarchyHelpers<VectorType>::get_global_operator(std::shared_ptr<MeshEvaluator> mesh_evaluator)
+{
+  if (_operator == nullptr)
+  {
+    if (mesh_evaluator->get_mesh_evaluator_type() == "HipMatrixFreeMeshEvaluator")
+    {
+      auto mf = std::dynamic_pointer_cast<HipMatrixFreeMeshEvaluator>(mesh_evaluator);
+      ASSERT_THROW(mf != nullptr, "downcasting failed");
+      _operator = std::make_shared<HipMatrixFreeOperator>(mf);
+    }
+    else
+    {
+      auto hip_mesh_evaluator = std::dynamic_pointer_cast<HipMeshEvaluator>(mesh_evaluator);
+      ASSERT_THROW(hip_mesh_evaluator != nullptr, "downcasting failed");
+      _operator = std::make_shared<HipMatrixOperator>(hip_mesh_evaluator->evaluate_global());
+    }
+  }
+  return _operator;
+}
+
+template <typename VectorType>
+std::shared_ptr<Operator<VectorType>>
+HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<MeshEvaluator> mesh_evaluator,
+                                                  std::shared_ptr<ptree const> params)
+{
+  auto hip_mesh_evaluator = std::dynamic_pointer_cast<HipMeshEvaluator>(mesh_evaluator);
+  ASSERT_THROW(hip_mesh_evaluator != nullptr, "downcasting failed");
+  RestrictorOptions opts = hip_mesh_evaluator->agglomerate_options(*params);
+  auto global_diag = hip_mesh_evaluator->get_locally_relevant_diag();
+  HostCsr R = build_restrictor_structured(hip_mesh_evaluator->get_mesh(), global_diag, opts);
+  return std::make_shared<HipMatrixOperator>(upload(_handle, std::move(R)));
+}
+
+template <typename VectorType>
+std::shared_ptr<Smoother<VectorType>>
+HipHierarchyHelpers<VectorType>::build_smoother(std::shared_ptr<Operator<VectorType> const> op,
+                                                std::shared_ptr<ptree const> params)
+{
+  return std::make_shared<HipSmoother>(op, params);
+}
+
+template <typename VectorType>
+std::shared_ptr<Solver<VectorType>>
+HipHierarchyHelpers<VectorType>::build_coarse_solver(std::shared_ptr<Operator<VectorType> const> op,
+                                                     std::shared_ptr<ptree const> params)
+{
+  return std::make_shared<HipSolver>(_handle, op, params);
+}
+
+template class HipHierarchyHelpers<DVector>;
+} // namespace mfmg

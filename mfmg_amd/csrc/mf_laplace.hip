@@ -1,0 +1,639 @@
+// gfx950 kernels of the matrix-free Q1 Laplace operator.
+//
+// Data layout in HBM ("one cell slot per DoF"): the DoF grid is Nx x Ny x Nz;
+// slot (i,j,k) holds the cell whose lowest corner is DoF (i,j,k) (a phantom cell
+// with zero coefficient on the three high faces).  Slots are blocked by 64 along
+// x so that one wavefront reads, per cell row, one contiguous 2 KiB run of DoF
+// indices and one contiguous 4 KiB (FP64) run of coefficients with 16-byte loads:
+//   idx  int4  [(block*2 + half)*64 + lane]
+//   coef 16 B  [(block*NP + p)*64 + lane]
+// The indices are the caller's global DoF ids (any numbering); bit 31 carries the
+// Dirichlet flag, so the constrained-read-as-zero rule costs no extra load.
+//
+// Work decomposition (owner computes, no atomics, bit-reproducible): a workgroup
+// spans complete x-rows (thread t <-> column i = t), owns TY DoF rows x TZ DoF
+// planes and marches over the (TY+1) x (TZ+1) cell rows that touch them.  The 8
+// corner contributions of a cell are combined
+//   in x : wave shift of the right-face values (LDS hand-off at wave seams),
+//   in y : a register carried from the previous cell row,
+//   in z : a per-thread column in LDS carried from the previous cell layer,
+// so every DoF value is complete exactly when its own slot is visited and the
+// smoother epilogue (b, D^-1, x_prev) is fused there: A x is never stored.
+#include "mf_laplace.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace mfmg
+{
+namespace
+{
+constexpr unsigned int kFlag = 0x80000000u;
+
+template <typename T>
+struct MfArgs
+{
+  int4 const *idx;
+  void const *coef;
+  T const *x;
+  T const *b;
+  T const *dinv;
+  T const *xprev;
+  T *out;
+  int Nx, Ny, Nz;
+  int nxb;
+  int TY, TZ;
+  T fx, fy, fz;
+  T alpha, beta;
+  int mode;
+};
+
+// Gauss points of QGauss<1>(2) on [0,1]: interpolation weights S[p][i]
+#define MFMG_GA 0.78867513459481288225 // 1 - g0
+#define MFMG_GB 0.21132486540518711775 // g0
+
+template <typename T>
+__device__ __forceinline__ void load_coef(void const *base, size_t block, int lane, T c[8]);
+
+template <>
+__device__ __forceinline__ void load_coef<double>(void const *base, size_t block, int lane, double c[8])
+{
+  double2 const *p = reinterpret_cast<double2 const *>(base) + (block * 4) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+  {
+    double2 v = p[q * 64];
+    c[2 * q] = v.x;
+    c[2 * q + 1] = v.y;
+  }
+}
+
+template <>
+__device__ __forceinline__ void load_coef<float>(void const *base, size_t block, int lane, float c[8])
+{
+  float4 const *p = reinterpret_cast<float4 const *>(base) + (block * 2) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+  {
+    float4 v = p[q * 64];
+    c[4 * q] = v.x;
+    c[4 * q + 1] = v.y;
+    c[4 * q + 2] = v.z;
+    c[4 * q + 3] = v.w;
+  }
+}
+
+// v = h-scaled G^T diag(c) G u for one Cartesian Q1 cell, sum-factorised.
+// corner m = a + 2b + 4d ; quadrature point q = qa + 2qb + 4qc
+// (FEEvaluation::evaluate / submit_gradient / integrate of
+//  tests/laplace_matrix_free.hpp:145-155).
+template <typename T>
+__device__ __forceinline__ void cell_apply(T const u[8], T const c[8], T fx, T fy, T fz, T v[8])
+{
+  const T A = T(MFMG_GA), B = T(MFMG_GB);
+  // ---- x direction: dx[b][d] = u(1,b,d) - u(0,b,d)
+  T d00 = u[1] - u[0], d10 = u[3] - u[2], d01 = u[5] - u[4], d11 = u[7] - u[6];
+  // interpolate in y -> t[qb][d], then in z -> g[qb][qc]
+  T t00 = A * d00 + B * d10, t10 = B * d00 + A * d10;
+  T t01 = A * d01 + B * d11, t11 = B * d01 + A * d11;
+  T g00 = A * t00 + B * t01, g01 = B * t00 + A * t01; // g[qb=0][qc]
+  T g10 = A * t10 + B * t11, g11 = B * t10 + A * t11; // g[qb=1][qc]
+  // flux summed over qa: s[qb][qc] = g * (c(0,qb,qc) + c(1,qb,qc))
+  T s00 = g00 * (c[0] + c[1]), s10 = g10 * (c[2] + c[3]);
+  T s01 = g01 * (c[4] + c[5]), s11 = g11 * (c[6] + c[7]);
+  // transpose interpolation z then y: X[b][d]
+  T w00 = A * s00 + B * s01, w01 = B * s00 + A * s01; // w[qb=0][d]
+  T w10 = A * s10 + B * s11, w11 = B * s10 + A * s11; // w[qb=1][d]
+  T X00 = fx * (A * w00 + B * w10), X10 = fx * (B * w00 + A * w10);
+  T X01 = fx * (A * w01 + B * w11), X11 = fx * (B * w01 + A * w11);
+  v[0] = -X00;
+  v[1] = X00;
+  v[2] = -X10;
+  v[3] = X10;
+  v[4] = -X01;
+  v[5] = X01;
+  v[6] = -X11;
+  v[7] = X11;
+  // ---- y direction: dy[a][d] = u(a,1,d) - u(a,0,d)
+  d00 = u[2] - u[0];
+  d10 = u[3] - u[1];
+  d01 = u[6] - u[4];
+  d11 = u[7] - u[5];
+  t00 = A * d00 + B * d10; // t[qa][d]
+  t10 = B * d00 + A * d10;
+  t01 = A * d01 + B * d11;
+  t11 = B * d01 + A * d11;
+  g00 = A * t00 + B * t01; // g[qa][qc]
+  g01 = B * t00 + A * t01;
+  g10 = A * t10 + B * t11;
+  g11 = B * t10 + A * t11;
+  s00 = g00 * (c[0] + c[2]); // sum over qb
+  s10 = g10 * (c[1] + c[3]);
+  s01 = g01 * (c[4] + c[6]);
+  s11 = g11 * (c[5] + c[7]);
+  w00 = A * s00 + B * s01;
+  w01 = B * s00 + A * s01;
+  w10 = A * s10 + B * s11;
+  w11 = B * s10 + A * s11;
+  X00 = fy * (A * w00 + B * w10); // Y[a][d]
+  X10 = fy * (B * w00 + A * w10);
+  X01 = fy * (A * w01 + B * w11);
+  X11 = fy * (B * w01 + A * w11);
+  v[0] -= X00;
+  v[2] += X00;
+  v[1] -= X10;
+  v[3] += X10;
+  v[4] -= X01;
+  v[6] += X01;
+  v[5] -= X11;
+  v[7] += X11;
+  // ---- z direction: dz[a][b] = u(a,b,1) - u(a,b,0)
+  d00 = u[4] - u[0];
+  d10 = u[5] - u[1];
+  d01 = u[6] - u[2];
+  d11 = u[7] - u[3];
+  t00 = A * d00 + B * d10; // t[qa][b]
+  t10 = B * d00 + A * d10;
+  t01 = A * d01 + B * d11;
+  t11 = B * d01 + A * d11;
+  g00 = A * t00 + B * t01; // g[qa][qb]
+  g01 = B * t00 + A * t01;
+  g10 = A * t10 + B * t11;
+  g11 = B * t10 + A * t11;
+  s00 = g00 * (c[0] + c[4]); // sum over qc
+  s10 = g10 * (c[1] + c[5]);
+  s01 = g01 * (c[2] + c[6]);
+  s11 = g11 * (c[3] + c[7]);
+  w00 = A * s00 + B * s01;
+  w01 = B * s00 + A * s01;
+  w10 = A * s10 + B * s11;
+  w11 = B * s10 + A * s11;
+  X00 = fz * (A * w00 + B * w10); // Z[a][b]
+  X10 = fz * (B * w00 + A * w10);
+  X01 = fz * (A * w01 + B * w11);
+  X11 = fz * (B * w01 + A * w11);
+  v[0] -= X00;
+  v[4] += X00;
+  v[1] -= X10;
+  v[5] += X10;
+  v[2] -= X01;
+  v[6] += X01;
+  v[3] -= X11;
+  v[7] += X11;
+}
+
+template <typename T>
+__global__ void mf_laplace_kernel(MfArgs<T> a)
+{
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T *pt = reinterpret_cast<T *>(smem_raw); // [TY+1][blockDim.x] z-carry, thread private
+  const int nt = blockDim.x;
+  const int nw = nt >> 6;
+  T *edge = pt + (size_t)(a.TY + 1) * nt; // [2][nw][4] wave-seam hand-off
+
+  const int i = threadIdx.x;
+  const int lane = i & 63;
+  const int wave = i >> 6;
+  const int Y0 = blockIdx.x * a.TY;
+  const int Z0 = blockIdx.y * a.TZ;
+  const bool col_ok = i < a.Nx;
+  int parity = 0;
+
+  for (int kk = 0; kk <= a.TZ; ++kk)
+  {
+    const int k = Z0 - 1 + kk;
+    if (k >= a.Nz)
+      break;
+    T ry0 = T(0), ry1 = T(0);
+    for (int jj = 0; jj <= a.TY; ++jj)
+    {
+      const int j = Y0 - 1 + jj;
+      if (j >= a.Ny)
+        break;
+      const bool slot = col_ok && j >= 0 && k >= 0;
+      const bool cell = slot && (i < a.Nx - 1) && (j < a.Ny - 1) && (k < a.Nz - 1);
+
+      int id[8];
+      T c[8], u[8], v[8];
+      T x0 = T(0);
+      if (slot)
+      {
+        const size_t blk = ((size_t)k * a.Ny + j) * a.nxb + wave;
+        int4 const *ip = a.idx + (blk * 2) * 64 + lane;
+        int4 i0 = ip[0], i1 = ip[64];
+        id[0] = i0.x;
+        id[1] = i0.y;
+        id[2] = i0.z;
+        id[3] = i0.w;
+        id[4] = i1.x;
+        id[5] = i1.y;
+        id[6] = i1.z;
+        id[7] = i1.w;
+        if (cell)
+        {
+          load_coef<T>(a.coef, blk, lane, c);
+#pragma unroll
+          for (int m = 0; m < 8; ++m)
+          {
+            T xv = a.x[(unsigned int)id[m] & ~kFlag];
+            if (m == 0)
+              x0 = xv;
+            u[m] = (id[m] < 0) ? T(0) : xv; // constrained DoFs read as zero
+          }
+        }
+        else
+        {
+          x0 = a.x[(unsigned int)id[0] & ~kFlag];
+        }
+      }
+      if (cell)
+      {
+        cell_apply<T>(u, c, a.fx, a.fy, a.fz, v);
+      }
+      else
+      {
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+          v[m] = T(0);
+      }
+
+      // ---- x combine: DoF column i gets the a=0 corners of its own cell and
+      //      the a=1 corners of the cell of column i-1
+      T l0 = __shfl_up(v[1], 1), l1 = __shfl_up(v[3], 1), l2 = __shfl_up(v[5], 1),
+        l3 = __shfl_up(v[7], 1);
+      if (nw > 1)
+      {
+        T *e = edge + (size_t)parity * nw * 4;
+        if (lane == 63)
+        {
+          e[wave * 4 + 0] = v[1];
+          e[wave * 4 + 1] = v[3];
+          e[wave * 4 + 2] = v[5];
+          e[wave * 4 + 3] = v[7];
+        }
+        __syncthreads();
+        if (lane == 0 && wave > 0)
+        {
+          l0 = e[(wave - 1) * 4 + 0];
+          l1 = e[(wave - 1) * 4 + 1];
+          l2 = e[(wave - 1) * 4 + 2];
+          l3 = e[(wave - 1) * 4 + 3];
+        }
+        parity ^= 1;
+      }
+      if (i == 0)
+      {
+        l0 = l1 = l2 = l3 = T(0);
+      }
+      const T s00 = v[0] + l0; // s[b][d]: b=0,d=0
+      const T s10 = v[2] + l1; // b=1,d=0
+      const T s01 = v[4] + l2; // b=0,d=1
+      const T s11 = v[6] + l3; // b=1,d=1
+      // ---- y combine (register carry), z combine (LDS column carry)
+      const T t0 = s00 + ry0;
+      const T t1 = s01 + ry1;
+      ry0 = s10;
+      ry1 = s11;
+      T *ptj = pt + (size_t)jj * nt + i;
+      const T yv = (kk > 0) ? (t0 + *ptj) : T(0);
+      *ptj = t1;
+
+      if (slot && jj > 0 && kk > 0)
+      {
+        const unsigned int g = (unsigned int)id[0] & ~kFlag;
+        const T ax = (id[0] < 0) ? x0 : yv; // constrained rows: dst_c = src_c
+        T o;
+        if (a.mode == 0)
+          o = ax;
+        else if (a.mode == 1)
+          o = ax - a.b[g];
+        else if (a.mode == 2)
+          o = x0 - a.beta * a.dinv[g] * (ax - a.b[g]);
+        else
+          o = x0 + a.alpha * (x0 - a.xprev[g]) - a.beta * a.dinv[g] * (ax - a.b[g]);
+        a.out[g] = o;
+      }
+    }
+  }
+}
+
+// ---- setup kernels -----------------------------------------------------------
+template <typename T>
+__global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coefficient,
+                                 uint8_t const *constrained, int Nx, int Ny, int Nz, int nxb,
+                                 int4 *idx, T *coef)
+{
+  const int64_t n_slots = (int64_t)nxb * 64 * Ny * Nz;
+  const int nx = Nx - 1, ny = Ny - 1, nz = Nz - 1;
+  constexpr int W = 16 / sizeof(T); // values per 16-byte load
+  constexpr int NP = 8 / W;
+  for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n_slots;
+       s += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int lane = s & 63;
+    const int64_t blk = s >> 6;
+    const int bw = blk % nxb;
+    const int64_t row = blk / nxb;
+    const int j = row % Ny;
+    const int k = row / Ny;
+    const int i = bw * 64 + lane;
+    int id[8];
+    T c[8];
+    if (i >= Nx)
+    {
+      for (int m = 0; m < 8; ++m)
+      {
+        id[m] = 0;
+        c[m] = T(0);
+      }
+    }
+    else
+    {
+      const int ic = min(i, nx - 1), jc = min(j, ny - 1), kc = min(k, nz - 1);
+      const int64_t cidx = ic + (int64_t)nx * (jc + (int64_t)ny * kc);
+      const bool real = (i < nx) && (j < ny) && (k < nz);
+      if (real)
+      {
+        for (int m = 0; m < 8; ++m)
+        {
+          const int g = cell_dofs[cidx * 8 + m];
+          id[m] = g | (constrained[g] ? (int)kFlag : 0);
+          c[m] = T(coefficient[cidx * 8 + m]);
+        }
+      }
+      else
+      {
+        const int m0 = (i - ic) + 2 * (j - jc) + 4 * (k - kc);
+        const int g = cell_dofs[cidx * 8 + m0];
+        const int v = g | (constrained[g] ? (int)kFlag : 0);
+        for (int m = 0; m < 8; ++m)
+        {
+          id[m] = v;
+          c[m] = T(0);
+        }
+      }
+    }
+    idx[(blk * 2 + 0) * 64 + lane] = make_int4(id[0], id[1], id[2], id[3]);
+    idx[(blk * 2 + 1) * 64 + lane] = make_int4(id[4], id[5], id[6], id[7]);
+    for (int p = 0; p < NP; ++p)
+      for (int w = 0; w < W; ++w)
+        coef[((blk * NP + p) * 64 + lane) * W + w] = c[p * W + w];
+  }
+}
+
+// Every corner (a,b,d) of real cell (i,j,k) must be corner 0 of slot (i+a,j+b,k+d):
+// the logical-structure precondition of the tiled kernel.  Also checks index range.
+__global__ void mf_validate_kernel(int4 const *idx, int Nx, int Ny, int Nz, int nxb, int64_t n_dofs,
+                                   int *n_bad)
+{
+  const int64_t n = (int64_t)Nx * Ny * Nz;
+  for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n;
+       s += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int i = s % Nx;
+    const int j = (s / Nx) % Ny;
+    const int k = s / ((int64_t)Nx * Ny);
+    auto slot0 = [&](int ii, int jj, int kk) {
+      const int64_t blk = ((int64_t)kk * Ny + jj) * nxb + (ii >> 6);
+      return idx[(blk * 2) * 64 + (ii & 63)].x;
+    };
+    const int64_t blk = ((int64_t)k * Ny + j) * nxb + (i >> 6);
+    const int4 a = idx[(blk * 2) * 64 + (i & 63)];
+    const int4 b = idx[(blk * 2 + 1) * 64 + (i & 63)];
+    const int id[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    bool bad = false;
+    if ((int64_t)((unsigned int)id[0] & ~kFlag) >= n_dofs)
+      bad = true;
+    if (i < Nx - 1 && j < Ny - 1 && k < Nz - 1)
+    {
+      for (int m = 1; m < 8; ++m)
+        if (id[m] != slot0(i + (m & 1), j + ((m >> 1) & 1), k + (m >> 2)))
+          bad = true;
+    }
+    if (bad)
+      atomicAdd(n_bad, 1);
+  }
+}
+
+struct DiagTable
+{
+  double K[8][8]; // K[q][m] = sum_d f_d G[q,d,m]^2
+};
+
+// compute_diagonal (tests/laplace_matrix_free.hpp:75-98,158-199): per-cell
+// unit-vector applies summed per DoF; constrained entries set to one.
+template <typename T>
+__global__ void mf_diagonal_kernel(int4 const *idx, void const *coef, int Nx, int Ny, int Nz, int nxb,
+                                   DiagTable tab, T *diag, T *dinv)
+{
+  const int64_t n = (int64_t)Nx * Ny * Nz;
+  for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n;
+       s += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int i = s % Nx;
+    const int j = (s / Nx) % Ny;
+    const int k = s / ((int64_t)Nx * Ny);
+    const int64_t blk0 = ((int64_t)k * Ny + j) * nxb + (i >> 6);
+    const int id0 = idx[(blk0 * 2) * 64 + (i & 63)].x;
+    double sum = 0.;
+    for (int m = 0; m < 8; ++m)
+    {
+      const int ci = i - (m & 1), cj = j - ((m >> 1) & 1), ck = k - (m >> 2);
+      if (ci < 0 || cj < 0 || ck < 0 || ci >= Nx - 1 || cj >= Ny - 1 || ck >= Nz - 1)
+        continue;
+      const int64_t blk = ((int64_t)ck * Ny + cj) * nxb + (ci >> 6);
+      T c[8];
+      load_coef<T>(coef, blk, ci & 63, c);
+      for (int q = 0; q < 8; ++q)
+        sum += (double)c[q] * tab.K[q][m];
+    }
+    const unsigned int g = (unsigned int)id0 & ~kFlag;
+    const double d = (id0 < 0) ? 1. : sum;
+    diag[g] = T(d);
+    dinv[g] = T(1. / d);
+  }
+}
+} // namespace
+
+template <typename T>
+MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_mesh_desc const &mesh)
+    : _handle(handle)
+{
+  if (mesh.dim != 3)
+    ASSERT_THROW_NOT_IMPLEMENTED("the matrix-free HIP operator is implemented for dim = 3 only");
+  ASSERT_THROW(mesh.cell_dofs && mesh.coefficient && mesh.constrained,
+               "mesh description arrays must not be null");
+  int64_t nd = 1, nc = 1;
+  for (int d = 0; d < 3; ++d)
+  {
+    ASSERT_THROW(mesh.n_cells[d] >= 1, "n_cells must be positive");
+    _n[d] = mesh.n_cells[d];
+    _N[d] = _n[d] + 1;
+    _h[d] = mesh.cell_size[d];
+    ASSERT_THROW(_h[d] > 0., "cell_size must be positive");
+    nd *= _N[d];
+    nc *= _n[d];
+  }
+  ASSERT_THROW(nd == mesh.n_dofs, "n_dofs does not match the cell grid (Q1: (n+1)^dim)");
+  ASSERT_THROW(nd < (int64_t(1) << 31), "DoF ids must fit 31 bits (bit 31 carries the constraint flag)");
+  _n_dofs = nd;
+  _nxp = ((_N[0] + 63) / 64) * 64;
+  _nxb = _nxp / 64;
+  if (_nxp > 1024)
+    ASSERT_THROW_NOT_IMPLEMENTED("rows longer than 1024 DoFs need an x split of the workgroup tile");
+
+  hipStream_t st = _handle.stream;
+  // stage the plain arrays on the device if they are host arrays
+  DeviceBuffer<int32_t> cd_tmp;
+  DeviceBuffer<double> co_tmp;
+  DeviceBuffer<uint8_t> cn_tmp;
+  int32_t const *cd = mesh.cell_dofs;
+  double const *co = mesh.coefficient;
+  uint8_t const *cn = mesh.constrained;
+  if (!mesh.arrays_on_device)
+  {
+    cd_tmp.upload(mesh.cell_dofs, (size_t)nc * 8, st);
+    co_tmp.upload(mesh.coefficient, (size_t)nc * 8, st);
+    cn_tmp.upload(mesh.constrained, (size_t)nd, st);
+    cd = cd_tmp.data();
+    co = co_tmp.data();
+    cn = cn_tmp.data();
+  }
+  const size_t n_slots = (size_t)_nxp * _N[1] * _N[2];
+  _idx.resize(n_slots * 2);
+  _coef.resize(n_slots * 8);
+  _diag.resize(nd);
+  _dinv.resize(nd);
+
+  hipLaunchKernelGGL(mf_repack_kernel<T>, dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, cd,
+                     co, cn, _N[0], _N[1], _N[2], _nxb, _idx.data(), _coef.data());
+  MFMG_HIP_CHECK(hipGetLastError());
+
+  DeviceBuffer<int> bad(1);
+  MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
+  hipLaunchKernelGGL(mf_validate_kernel, dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
+                     _idx.data(), _N[0], _N[1], _N[2], _nxb, _n_dofs, bad.data());
+  MFMG_HIP_CHECK(hipGetLastError());
+  int n_bad = bad.download(st)[0];
+  ASSERT_THROW(n_bad == 0, "cell_dofs is not a logically structured hex mesh in lexicographic cell order (" +
+                               std::to_string(n_bad) + " inconsistent cells)");
+
+  // diagonal: K[q][m] = sum_d f_d (dphi_m/dxi_d)^2 at Gauss point q
+  DiagTable tab;
+  const double vol = _h[0] * _h[1] * _h[2];
+  const double f[3] = {vol / 8. / (_h[0] * _h[0]), vol / 8. / (_h[1] * _h[1]), vol / 8. / (_h[2] * _h[2])};
+  const double gp[2] = {MFMG_GB, MFMG_GA};
+  for (int q = 0; q < 8; ++q)
+    for (int m = 0; m < 8; ++m)
+    {
+      double sum = 0.;
+      for (int d = 0; d < 3; ++d)
+      {
+        double g = 1.;
+        for (int e = 0; e < 3; ++e)
+        {
+          const int bit = (m >> e) & 1;
+          const double xi = gp[(q >> e) & 1];
+          if (e == d)
+            g *= bit ? 1. : -1.;
+          else
+            g *= bit ? xi : (1. - xi);
+        }
+        sum += f[d] * g * g;
+      }
+      tab.K[q][m] = sum;
+    }
+  hipLaunchKernelGGL(mf_diagonal_kernel<T>, dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
+                     _idx.data(), _coef.data(), _N[0], _N[1], _N[2], _nxb, tab, _diag.data(), _dinv.data());
+  MFMG_HIP_CHECK(hipGetLastError());
+  MFMG_HIP_CHECK(hipStreamSynchronize(st));
+}
+
+template <typename T>
+void MatrixFreeLaplaceDevice<T>::choose_tile(int &ty, int &tz) const
+{
+  ty = _tile_y;
+  tz = _tile_z;
+  if (ty > 0 && tz > 0)
+    return;
+  // heuristic: the largest tile (least halo re-computation) that still yields
+  // >= 4 workgroups per CU-equivalent of waves; LDS column carry must fit.
+  const int64_t waves_per_row = _nxb;
+  const int64_t target_waves = 256 * 8;
+  int best_ty = 1, best_tz = 1;
+  double best_cost = 1e30;
+  const int cand_y[] = {2, 4, 8, 16, 32};
+  const int cand_z[] = {2, 4, 8, 16, 32, 64};
+  for (int cy : cand_y)
+    for (int cz : cand_z)
+    {
+      const size_t lds = ((size_t)(cy + 1) * _nxp + 2 * _nxb * 4) * sizeof(T);
+      if (lds > 72 * 1024)
+        continue;
+      const int64_t wgs = (int64_t)((_N[1] + cy - 1) / cy) * ((_N[2] + cz - 1) / cz);
+      const int64_t waves = wgs * waves_per_row;
+      double cost = (1. + 1. / cy) * (1. + 1. / cz);
+      if (waves < target_waves)
+        cost *= double(target_waves) / double(std::max<int64_t>(waves, 1));
+      if (cost < best_cost)
+      {
+        best_cost = cost;
+        best_ty = cy;
+        best_tz = cz;
+      }
+    }
+  if (ty <= 0)
+    ty = best_ty;
+  if (tz <= 0)
+    tz = best_tz;
+}
+
+template <typename T>
+void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha,
+                                        T beta, T *out) const
+{
+  ASSERT_THROW(x != nullptr && out != nullptr, "null vector");
+  ASSERT_THROW(x != out, "the operator kernel cannot run in place (out aliases x)");
+  if (mode != MfMode::apply)
+    ASSERT_THROW(b != nullptr, "null right-hand side");
+  if (mode == MfMode::next)
+    ASSERT_THROW(x_prev != nullptr, "null x_prev");
+  int ty, tz;
+  choose_tile(ty, tz);
+  MfArgs<T> a;
+  a.idx = _idx.data();
+  a.coef = _coef.data();
+  a.x = x;
+  a.b = b;
+  a.dinv = _dinv.data();
+  a.xprev = x_prev;
+  a.out = out;
+  a.Nx = _N[0];
+  a.Ny = _N[1];
+  a.Nz = _N[2];
+  a.nxb = _nxb;
+  a.TY = ty;
+  a.TZ = tz;
+  const double vol = _h[0] * _h[1] * _h[2];
+  a.fx = T(vol / 8. / (_h[0] * _h[0]));
+  a.fy = T(vol / 8. / (_h[1] * _h[1]));
+  a.fz = T(vol / 8. / (_h[2] * _h[2]));
+  a.alpha = alpha;
+  a.beta = beta;
+  a.mode = static_cast<int>(mode);
+  const size_t lds = ((size_t)(ty + 1) * _nxp + 2 * _nxb * 4) * sizeof(T);
+  static bool attr_set = false;
+  if (!attr_set)
+  {
+    MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mf_laplace_kernel<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set = true;
+  }
+  dim3 grid((_N[1] + ty - 1) / ty, (_N[2] + tz - 1) / tz);
+  hipLaunchKernelGGL(mf_laplace_kernel<T>, grid, dim3(_nxp), lds, _handle.stream, a);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+template class MatrixFreeLaplaceDevice<double>;
+template class MatrixFreeLaplaceDevice<float>;
+} // namespace mfmg

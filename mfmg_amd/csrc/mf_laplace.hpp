@@ -1,0 +1,85 @@
+// Matrix-free Q1 Laplace operator on a logically structured hex mesh, device resident.
+//
+// Fills the hole of the reference's CUDA back-end: CudaMatrixFreeOperator::vmult
+// only forwards to a user evaluator whose base class throws
+// (source/cuda/cuda_matrix_free_operator.cu:32-37,
+//  include/mfmg/cuda/cuda_matrix_free_mesh_evaluator.cuh:62-69); the arithmetic it
+// has to reproduce is LaplaceOperator::local_apply / compute_diagonal of
+// tests/laplace_matrix_free.hpp:75-98,129-156 with the constrained-row semantics of
+// deal.II's MatrixFreeOperators::Base::vmult.
+#pragma once
+
+#include "common.hpp"
+
+namespace mfmg
+{
+// Fused epilogues of the operator kernel.
+enum class MfMode : int
+{
+  apply = 0,    // out = A x
+  residual = 1, // out = A x - b                       (hierarchy.hpp:284-286)
+  first = 2,    // out = x - beta dinv (A x - b)       (Jacobi / first Chebyshev term)
+  next = 3      // out = x + alpha (x - x_prev) - beta dinv (A x - b)
+};
+
+template <typename T>
+class MatrixFreeLaplaceDevice
+{
+public:
+  MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_mesh_desc const &mesh);
+
+  int64_t n_dofs() const { return _n_dofs; }
+  int dof_grid(int d) const { return _N[d]; }
+  int n_cells(int d) const { return _n[d]; }
+  double cell_size(int d) const { return _h[d]; }
+
+  void vmult(T const *x, T *y) const { launch(MfMode::apply, x, nullptr, nullptr, T(0), T(0), y); }
+  void residual(T const *x, T const *b, T *res) const
+  {
+    launch(MfMode::residual, x, b, nullptr, T(0), T(0), res);
+  }
+  // out = x + alpha (x - x_prev) - beta dinv (A x - b); out must not alias x
+  void smoother_step(T const *b, T const *x, T const *x_prev, T alpha, T beta, T *out) const
+  {
+    if (x_prev == nullptr || alpha == T(0))
+      launch(MfMode::first, x, b, nullptr, T(0), beta, out);
+    else
+      launch(MfMode::next, x, b, x_prev, alpha, beta, out);
+  }
+
+  T const *diagonal() const { return _diag.data(); }
+  T const *diagonal_inverse() const { return _dinv.data(); }
+
+  void set_tile(int ty, int tz)
+  {
+    _tile_y = ty;
+    _tile_z = tz;
+  }
+  HipHandle &handle() const { return _handle; }
+
+  // algorithmic bytes of one operator application (112 B/DoF in FP64)
+  double algorithmic_bytes_apply() const
+  {
+    return double(_n_dofs) * (2.0 * sizeof(T) + 8 * 4 + 8 * sizeof(T));
+  }
+
+private:
+  void launch(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out) const;
+  void choose_tile(int &ty, int &tz) const;
+
+  HipHandle &_handle;
+  int _N[3]; // DoF grid
+  int _n[3]; // cells
+  double _h[3];
+  int64_t _n_dofs;
+  int _nxp; // threads per row = Nx rounded up to 64
+  int _nxb; // 64-slot blocks per row
+  // internal layout, one cell slot per DoF, blocked by 64 slots along x:
+  //   idx  : int4   [(block*2 + half)*64 + lane]   corners 4*half..4*half+3, bit31 = constrained
+  //   coef : 16 B   [(block*NP + p)*64 + lane]     NP = 8*sizeof(T)/16 loads per slot
+  DeviceBuffer<int4> _idx;
+  DeviceBuffer<T> _coef;
+  DeviceBuffer<T> _diag, _dinv;
+  int _tile_y = 0, _tile_z = 0;
+};
+} // namespace mfmg

@@ -1,0 +1,201 @@
+// Hierarchy<VectorType>: mirror of include/mfmg/common/hierarchy.hpp:155-373.
+// The constructor follows the reference line by line in *structure* (operator ->
+// smoother -> restrictor -> A R^T -> R (A R^T) -> coarse solver, hierarchy.hpp:159-236)
+// and apply() is the same recursive V-cycle with the negative-residual convention
+// (hierarchy.hpp:246-309); what changes is what runs underneath: fused HIP kernels,
+// temporaries built once per level, no host round trips.
+#pragma once
+
+#include "hierarchy_helpers.hpp"
+#include "hip_hierarchy_helpers.hpp"
+#include "level.hpp"
+#include "timer.hpp"
+
+namespace mfmg
+{
+// String switch on the evaluator tag (include/mfmg/common/hierarchy.hpp:49-153).
+template <typename VectorType>
+std::unique_ptr<HierarchyHelpers<VectorType>> create_hierarchy_helpers(std::shared_ptr<MeshEvaluator> evaluator)
+{
+  std::unique_ptr<HierarchyHelpers<VectorType>> hierarchy_helpers;
+  std::string evaluator_type = evaluator->get_mesh_evaluator_type();
+  if (evaluator_type == "HipMeshEvaluator" || evaluator_type == "HipMatrixFreeMeshEvaluator")
+  {
+    auto hip_evaluator = std::dynamic_pointer_cast<HipMeshEvaluator>(evaluator);
+    ASSERT_THROW(hip_evaluator != nullptr, "downcasting failed");
+    hierarchy_helpers.reset(new HipHierarchyHelpers<VectorType>(hip_evaluator->get_hip_handle()));
+  }
+  else
+  {
+    // "DealIIMeshEvaluator", "DealIIMatrixFreeMeshEvaluator", "CudaMeshEvaluator" belong to
+    // back-ends that are not part of this build.
+    ASSERT_THROW_NOT_IMPLEMENTED("mesh evaluator type \"" + evaluator_type + "\" is not available in the HIP build");
+  }
+  return hierarchy_helpers;
+}
+
+template <typename VectorType>
+class Hierarchy
+{
+public:
+  Hierarchy(Communicator comm, std::shared_ptr<MeshEvaluator> evaluator, std::shared_ptr<ptree> params = nullptr,
+            std::shared_ptr<TimerOutput> timer = nullptr)
+      : _timer(timer)
+  {
+    timer_enter_subsection(_timer, "Setup");
+    if (!params)
+      params = std::make_shared<ptree>();
+    _helpers = create_hierarchy_helpers<VectorType>(evaluator);
+    auto &hierarchy_helpers = _helpers;
+
+    _is_preconditioner = params->get("is preconditioner", true);
+    _n_smoothing_steps = params->get("smoother.n_smoothing_steps", 1);
+
+    int const num_levels = params->get("max levels", 2);
+    ASSERT_THROW(num_levels > 0, "number of levels specified by \"max levels\" parameter must be positive");
+    _levels.resize(num_levels);
+
+    _levels[0].set_operator(hierarchy_helpers->get_global_operator(evaluator));
+    for (int level_index = 0; level_index < num_levels; level_index++)
+    {
+      auto &level_fine = _levels[level_index];
+      auto a = level_fine.get_operator();
+
+      if (level_index == num_levels - 1)
+      {
+        if (level_index == 0)
+          params->put("coarse.params.zero starting solution", _is_preconditioner);
+
+        timer_enter_subsection(_timer, "Setup: build coarse solver");
+        auto coarse_solver = hierarchy_helpers->build_coarse_solver(a, params);
+        level_fine.set_solver(coarse_solver);
+        timer_leave_subsection(_timer);
+        break;
+      }
+
+      auto &level_coarse = _levels[level_index + 1];
+
+      timer_enter_subsection(_timer, "Setup: build smoother");
+      auto smoother = hierarchy_helpers->build_smoother(a, params);
+      level_fine.set_smoother(smoother);
+      timer_leave_subsection(_timer);
+
+      timer_enter_subsection(_timer, "Setup: build restrictor");
+      auto restrictor = hierarchy_helpers->build_restrictor(comm, evaluator, params);
+      level_coarse.set_restrictor(restrictor);
+      timer_leave_subsection(_timer);
+
+      std::shared_ptr<Operator<VectorType>> ap;
+      bool fast_ap = params->get("fast_ap", false);
+      if (fast_ap)
+      {
+        timer_enter_subsection(_timer, "Setup: fast_ap");
+        ap = hierarchy_helpers->fast_multiply_transpose();
+        timer_leave_subsection(_timer);
+      }
+      else
+      {
+        timer_enter_subsection(_timer, "Setup: ap");
+        ap = a->multiply_transpose(restrictor);
+        timer_leave_subsection(_timer);
+      }
+
+      timer_enter_subsection(_timer, "Setup: build coarse matrix");
+      auto a_coarse = restrictor->multiply(ap);
+      timer_leave_subsection(_timer);
+
+      level_coarse.set_operator(a_coarse);
+    }
+    _params = params;
+    timer_leave_subsection(_timer);
+  }
+
+  void vmult(VectorType &x, VectorType const &b) const
+  {
+    timer_enter_subsection(_timer, "Apply");
+    apply(b, x, 0);
+    timer_leave_subsection(_timer);
+  }
+
+  void apply(VectorType const &b, VectorType &x, int level_index = 0) const
+  {
+    auto const num_levels = _levels.size();
+
+    auto &level_fine = _levels[level_index];
+    auto a = level_fine.get_operator();
+
+    if (level_index > 0 || _is_preconditioner)
+    {
+      // Zero out any garbage in x (hierarchy.hpp:253-259).
+      x = 0.;
+    }
+
+    if (level_index == static_cast<int>(num_levels) - 1)
+    {
+      timer_enter_subsection(_timer, "Apply: coarsest level");
+      auto coarse_solver = level_fine.get_solver();
+      coarse_solver->apply(b, x);
+      timer_leave_subsection(_timer);
+    }
+    else
+    {
+      timer_enter_subsection(_timer, "Apply: fine levels");
+      auto &level_coarse = _levels[level_index + 1];
+      auto restrictor = level_coarse.get_restrictor();
+
+      // pre-smoother
+      auto smoother = level_fine.get_smoother();
+      for (unsigned int i = 0; i < _n_smoothing_steps; ++i)
+        smoother->apply(b, x);
+
+      // negative residual -r = A x - b (one fused kernel)
+      auto res = level_fine.workspace_vector(0);
+      a->residual(x, b, *res);
+
+      // restrict residual
+      auto b_coarse = level_coarse.workspace_vector(1);
+      restrictor->apply(*res, *b_coarse);
+
+      // coarse grid correction
+      auto x_coarse = level_coarse.workspace_vector(2);
+      apply(*b_coarse, *x_coarse, level_index + 1);
+
+      // x -= R^T x_c (prolongation fused with the update)
+      restrictor->apply_subtract(*x_coarse, x, OperatorMode::TRANS);
+
+      // post-smoother
+      for (unsigned int i = 0; i < _n_smoothing_steps; ++i)
+        smoother->apply(b, x);
+      timer_leave_subsection(_timer);
+    }
+  }
+
+  // Replace R on level 1 and re-derive A_c and the coarse solver (same sequence as
+  // the constructor, hierarchy.hpp:209-233,193-196): lets CPU and GPU runs share one R.
+  void set_restrictor(std::shared_ptr<Operator<VectorType>> restrictor)
+  {
+    ASSERT_THROW(_levels.size() == 2, "set_restrictor supports the two-level hierarchy only");
+    auto a = _levels[0].get_operator();
+    _levels[1].set_restrictor(restrictor);
+    auto ap = a->multiply_transpose(restrictor);
+    auto a_coarse = restrictor->multiply(ap);
+    _levels[1].set_operator(a_coarse);
+    _levels[1].set_solver(_helpers->build_coarse_solver(a_coarse, _params));
+  }
+
+  // stubbed to 0 upstream (hierarchy.hpp:311-366)
+  double grid_complexity() const { return 0; }
+  double operator_complexity() const { return 0; }
+
+  std::vector<Level<VectorType>> const &levels() const { return _levels; }
+  std::shared_ptr<TimerOutput> timer() const { return _timer; }
+
+private:
+  std::shared_ptr<TimerOutput> _timer;
+  std::unique_ptr<HierarchyHelpers<VectorType>> _helpers;
+  std::shared_ptr<ptree> _params;
+  std::vector<Level<VectorType>> _levels;
+  bool _is_preconditioner = true;
+  unsigned int _n_smoothing_steps;
+};
+} // namespace mfmg

@@ -1,0 +1,264 @@
+// The HIP back-end behind the mfmg operator API: twins of the classes of
+// include/mfmg/cuda/ (CudaMeshEvaluator, CudaMatrixFreeMeshEvaluator,
+// CudaMatrixOperator, CudaMatrixFreeOperator, CudaSmoother, CudaSolver,
+// CudaHierarchyHelpers) for VectorType = mfmg::Vector<double>.
+#pragma once
+
+#include "../amge_structured.hpp"
+#include "../mf_laplace.hpp"
+#include "../sparse_matrix_device.hpp"
+#include "hierarchy_helpers.hpp"
+#include "vector.hpp"
+
+namespace mfmg
+{
+using DVector = Vector<double>;
+
+// ---- evaluators ------------------------------------------------------------
+// Twin of CudaMeshEvaluator<dim> (include/mfmg/cuda/cuda_mesh_evaluator.cuh:30-72): the
+// user-facing object that knows the mesh.  deal.II's DoFHandler/AffineConstraints are
+// replaced by the plain mesh description of mfmg_hip_mesh_desc.
+class HipMeshEvaluator : public MeshEvaluator
+{
+public:
+  HipMeshEvaluator(HipHandle &handle, mfmg_hip_mesh_desc const &mesh);
+  ~HipMeshEvaluator() override = default;
+
+  int get_dim() const override { return _mesh.dim; }
+  std::string get_mesh_evaluator_type() const override { return "HipMeshEvaluator"; }
+
+  HipHandle &get_hip_handle() const { return _handle; }
+  StructuredMesh const &get_mesh() const { return _mesh; }
+  mfmg_hip_mesh_desc const &get_mesh_desc() const { return _desc; }
+
+  // evaluate_global (cuda_mesh_evaluator.cuh:39-44): the assembled system matrix on the device.
+  // Default: the Q1 Laplace of tests/laplace.hpp:154-204 assembled from the coefficient table.
+  virtual std::shared_ptr<SparseMatrixDevice<double>> evaluate_global() const;
+  // get_locally_relevant_diag (cuda_mesh_evaluator.cuh:57-60)
+  virtual std::vector<double> get_locally_relevant_diag() const;
+  // how the agglomerate eigenproblems are posed (evaluate_agglomerate, cuda_mesh_evaluator.cuh:46-55)
+  virtual RestrictorOptions agglomerate_options(ptree const &params) const;
+  virtual ConstraintSemantics constraint_semantics() const { return ConstraintSemantics::assembled; }
+
+protected:
+  HipHandle &_handle;
+  mfmg_hip_mesh_desc _desc;
+  StructuredMesh _mesh;
+};
+
+// Twin of CudaMatrixFreeMeshEvaluator<dim> (include/mfmg/cuda/cuda_matrix_free_mesh_evaluator.cuh:25-97),
+// whose hooks throw upstream; here they run the HIP Laplace kernels.
+class HipMatrixFreeMeshEvaluator : public HipMeshEvaluator
+{
+public:
+  HipMatrixFreeMeshEvaluator(HipHandle &handle, mfmg_hip_mesh_desc const &mesh);
+
+  std::string get_mesh_evaluator_type() const override { return "HipMatrixFreeMeshEvaluator"; }
+
+  std::shared_ptr<DVector> build_range_vector() const;
+  virtual void matrix_free_evaluate_global(DVector const &src, DVector &dst) const;
+  virtual double const *matrix_free_get_diagonal_inverse() const; // device pointer
+  virtual std::vector<double> get_diagonal() const;               // host copy, constrained entries 1
+  std::vector<double> get_locally_relevant_diag() const override { return get_diagonal(); }
+  RestrictorOptions agglomerate_options(ptree const &params) const override;
+  ConstraintSemantics constraint_semantics() const override { return ConstraintSemantics::matrix_free; }
+
+  std::shared_ptr<MatrixFreeLaplaceDevice<double>> get_device_operator() const { return _op; }
+
+private:
+  std::shared_ptr<MatrixFreeLaplaceDevice<double>> _op;
+};
+
+template <>
+struct is_matrix_free<HipMatrixFreeMeshEvaluator> : std::true_type
+{
+};
+
+// ---- operators ---------------------------------------------------------------
+// Common interface of operators a HipSmoother can drive with one fused kernel per
+// polynomial term.
+class HipOperator : public Operator<DVector>
+{
+public:
+  // out = x + alpha (x - x_prev) - beta D^{-1} (A x - b); x_prev may be null when alpha == 0
+  virtual void smoother_step(DVector const &b, DVector const &x, DVector const *x_prev, double alpha, double beta,
+                             DVector &out) const = 0;
+  virtual double const *get_diagonal_inverse() const = 0; // device pointer
+  virtual HipHandle &get_hip_handle() const = 0;
+};
+
+// Twin of CudaMatrixOperator (include/mfmg/cuda/cuda_matrix_operator.cuh, source/cuda/cuda_matrix_operator.cu)
+class HipMatrixOperator : public HipOperator
+{
+public:
+  explicit HipMatrixOperator(std::shared_ptr<SparseMatrixDevice<double>> sparse_matrix);
+
+  void apply(DVector const &x, DVector &y, OperatorMode mode = OperatorMode::NO_TRANS) const override;
+  std::shared_ptr<Operator<DVector>> transpose() const override;
+  std::shared_ptr<Operator<DVector>> multiply(std::shared_ptr<Operator<DVector> const> b) const override;
+  std::shared_ptr<Operator<DVector>> multiply_transpose(std::shared_ptr<Operator<DVector> const> b) const override;
+  std::shared_ptr<DVector> build_domain_vector() const override;
+  std::shared_ptr<DVector> build_range_vector() const override;
+  size_t grid_complexity() const override;
+  size_t operator_complexity() const override;
+  void residual(DVector const &x, DVector const &b, DVector &res) const override;
+  void apply_subtract(DVector const &x, DVector &y, OperatorMode mode) const override;
+
+  void smoother_step(DVector const &b, DVector const &x, DVector const *x_prev, double alpha, double beta,
+                     DVector &out) const override;
+  double const *get_diagonal_inverse() const override;
+  HipHandle &get_hip_handle() const override { return _matrix->handle(); }
+
+  std::shared_ptr<SparseMatrixDevice<double>> get_matrix() const { return _matrix; }
+  std::shared_ptr<SparseMatrixDevice<double>> get_transposed_matrix() const;
+
+private:
+  std::shared_ptr<SparseMatrixDevice<double>> _matrix;
+  mutable std::shared_ptr<SparseMatrixDevice<double>> _transposed_matrix; // built lazily (cuda_matrix_operator.cu:93-130)
+  mutable DeviceBuffer<double> _dinv;
+};
+
+// Twin of CudaMatrixFreeOperator (source/cuda/cuda_matrix_free_operator.cu)
+class HipMatrixFreeOperator : public HipOperator
+{
+public:
+  explicit HipMatrixFreeOperator(std::shared_ptr<HipMatrixFreeMeshEvaluator> matrix_free_mesh_evaluator);
+
+  void vmult(DVector &dst, DVector const &src) const;
+  void apply(DVector const &x, DVector &y, OperatorMode mode = OperatorMode::NO_TRANS) const override;
+  std::shared_ptr<Operator<DVector>> transpose() const override;
+  std::shared_ptr<Operator<DVector>> multiply(std::shared_ptr<Operator<DVector> const> b) const override;
+  std::shared_ptr<Operator<DVector>> multiply_transpose(std::shared_ptr<Operator<DVector> const> b) const override;
+  std::shared_ptr<DVector> build_domain_vector() const override;
+  std::shared_ptr<DVector> build_range_vector() const override;
+  size_t grid_complexity() const override;
+  size_t operator_complexity() const override;
+  void residual(DVector const &x, DVector const &b, DVector &res) const override;
+
+  void smoother_step(DVector const &b, DVector const &x, DVector const *x_prev, double alpha, double beta,
+                     DVector &out) const override;
+  double const *get_diagonal_inverse() const override;
+  HipHandle &get_hip_handle() const override { return _mesh_evaluator->get_hip_handle(); }
+  std::shared_ptr<HipMatrixFreeMeshEvaluator> get_mesh_evaluator() const { return _mesh_evaluator; }
+
+private:
+  std::shared_ptr<HipMatrixFreeMeshEvaluator> _mesh_evaluator;
+};
+
+// A R^T of the matrix-free operator, kept symbolic: R->multiply(ap) turns it into
+// A_c = R A R^T by a fused triple product on operator rows generated on the fly
+// (the reference builds A R^T with n_coarse operator applies, include/mfmg/dealii/dealii_utils.hpp:32-81).
+class HipGalerkinHalfProduct : public Operator<DVector>
+{
+public:
+  HipGalerkinHalfProduct(std::shared_ptr<HipMatrixFreeOperator const> a, std::shared_ptr<HipMatrixOperator const> r)
+      : _a(a), _r(r)
+  {
+  }
+  void apply(DVector const &x, DVector &y, OperatorMode mode = OperatorMode::NO_TRANS) const override;
+  std::shared_ptr<Operator<DVector>> transpose() const override
+  {
+    ASSERT_THROW_NOT_IMPLEMENTED();
+    return nullptr;
+  }
+  std::shared_ptr<Operator<DVector>> multiply(std::shared_ptr<Operator<DVector> const>) const override
+  {
+    ASSERT_THROW_NOT_IMPLEMENTED();
+    return nullptr;
+  }
+  std::shared_ptr<Operator<DVector>> multiply_transpose(std::shared_ptr<Operator<DVector> const>) const override
+  {
+    ASSERT_THROW_NOT_IMPLEMENTED();
+    return nullptr;
+  }
+  std::shared_ptr<DVector> build_domain_vector() const override { return _r->build_range_vector(); }
+  std::shared_ptr<DVector> build_range_vector() const override { return _a->build_range_vector(); }
+  size_t grid_complexity() const override { return 0; }
+  size_t operator_complexity() const override { return 0; }
+
+  std::shared_ptr<HipMatrixFreeOperator const> get_a() const { return _a; }
+  std::shared_ptr<HipMatrixOperator const> get_r() const { return _r; }
+
+private:
+  std::shared_ptr<HipMatrixFreeOperator const> _a;
+  std::shared_ptr<HipMatrixOperator const> _r;
+};
+
+// ---- smoother ------------------------------------------------------------------
+// Twin of CudaSmoother (source/cuda/cuda_smoother.cu:99-173, Jacobi) and of
+// DealIIMatrixFreeSmoother (source/dealii/dealii_matrix_free_smoother.cc:19-76, Chebyshev).
+class HipSmoother : public Smoother<DVector>
+{
+public:
+  HipSmoother(std::shared_ptr<Operator<DVector> const> op, std::shared_ptr<ptree const> params);
+
+  void apply(DVector const &b, DVector &x) const override;
+
+  int degree() const { return (int)_coefficients.size(); }
+  double lambda_min() const { return _lambda_min; }
+  double lambda_max() const { return _lambda_max; }
+  std::string const &type() const { return _type; }
+
+private:
+  void estimate_eigenvalues(int n_iterations, double residual, double &min_est, double &max_est) const;
+
+  std::shared_ptr<HipOperator const> _hip_operator;
+  std::string _type;
+  double _lambda_min = 1., _lambda_max = 1.;
+  std::vector<std::pair<double, double>> _coefficients; // (alpha_k, beta_k)
+  mutable std::shared_ptr<DVector> _scratch_a, _scratch_b;
+};
+
+// ---- coarse solver -------------------------------------------------------------
+// Twin of CudaSolver (source/cuda/cuda_solver.cu:204-515).
+class HipSolver : public Solver<DVector>
+{
+public:
+  HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const> op, std::shared_ptr<ptree const> params);
+
+  void apply(DVector const &b, DVector &x) const override;
+  std::string const &type() const { return _solver; }
+  int n_iterations() const { return _n_iterations; }
+
+private:
+  HipHandle &_handle;
+  std::string _solver;
+  std::shared_ptr<HipMatrixOperator const> _matrix_operator;
+  // direct: dense inverse, factored once at setup (the reference re-factorises in every
+  // apply, source/cuda/dealii_operator_device_helpers.cu:169-228)
+  DeviceBuffer<double> _dense_inverse;
+  // pcg
+  int _n_iterations = 0;
+  mutable DeviceBuffer<double> _scal;
+  mutable std::shared_ptr<DVector> _r, _z, _p, _ap;
+  DeviceBuffer<double> _dinv;
+};
+
+// ---- helpers -------------------------------------------------------------------
+// Twin of CudaHierarchyHelpers (source/cuda/cuda_hierarchy_helpers.cu:25-105).
+template <typename VectorType>
+class HipHierarchyHelpers : public HierarchyHelpers<VectorType>
+{
+public:
+  explicit HipHierarchyHelpers(HipHandle &handle) : _handle(handle) {}
+
+  std::shared_ptr<Operator<VectorType>> get_global_operator(std::shared_ptr<MeshEvaluator> mesh_evaluator) override;
+
+  std::shared_ptr<Operator<VectorType>> build_restrictor(Communicator comm,
+                                                         std::shared_ptr<MeshEvaluator> mesh_evaluator,
+                                                         std::shared_ptr<ptree const> params) override;
+
+  std::shared_ptr<Smoother<VectorType>> build_smoother(std::shared_ptr<Operator<VectorType> const> op,
+                                                       std::shared_ptr<ptree const> params) override;
+
+  std::shared_ptr<Solver<VectorType>> build_coarse_solver(std::shared_ptr<Operator<VectorType> const> op,
+                                                          std::shared_ptr<ptree const> params) override;
+
+private:
+  HipHandle &_handle;
+  std::shared_ptr<Operator<VectorType>> _operator;
+};
+
+// dense y = M x (row-major n x n), one wavefront per row
+void dense_gemv(HipHandle &handle, int n, double const *matrix, double const *x, double *y);
+} // namespace mfmg

@@ -1,0 +1,363 @@
+// gfx950 CSR SpMV with fused epilogues.  Replaces cusparseDcsrmv
+// (include/mfmg/cuda/sparse_matrix_device.templates.cuh:53-70) for A, R, R^T and A_c,
+// and folds the D^-1 "diagonal SpMV" + axpys of source/cuda/cuda_smoother.cu:48-59
+// into the epilogue.
+//
+// A row is shared by LPR consecutive lanes of a wavefront (LPR = 1..64, chosen
+// from the mean row length): consecutive lanes read consecutive (val, col) pairs,
+// partial sums are combined with an xor-butterfly of __shfl_xor, so the summation
+// order is fixed and the result is bit-reproducible.
+#include "sparse_matrix_device.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace mfmg
+{
+namespace
+{
+template <typename T>
+struct CsrArgs
+{
+  T const *val;
+  int32_t const *col;
+  int32_t const *row_ptr;
+  int64_t n_rows;
+  T const *x;
+  T const *b;
+  T const *dinv;
+  T const *xprev;
+  T *out;
+  T alpha, beta;
+  int mode;
+};
+
+template <typename T, int LPR>
+__global__ void csr_spmv_kernel(CsrArgs<T> a)
+{
+  const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t row = gtid / LPR;
+  const int sub = threadIdx.x % LPR;
+  T sum = T(0);
+  if (row < a.n_rows)
+  {
+    const int s = a.row_ptr[row], e = a.row_ptr[row + 1];
+    for (int p = s + sub; p < e; p += LPR)
+      sum += a.val[p] * a.x[a.col[p]];
+  }
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1)
+    sum += __shfl_xor(sum, off);
+  if (row < a.n_rows && sub == 0)
+  {
+    T o;
+    switch (a.mode)
+    {
+    case 0:
+      o = sum;
+      break;
+    case 1:
+      o = sum - a.b[row];
+      break;
+    case 2:
+      o = a.x[row] - a.beta * a.dinv[row] * (sum - a.b[row]);
+      break;
+    case 3:
+    {
+      const T xr = a.x[row];
+      o = xr + a.alpha * (xr - a.xprev[row]) - a.beta * a.dinv[row] * (sum - a.b[row]);
+      break;
+    }
+    case 4:
+      o = a.out[row] - sum;
+      break;
+    default:
+      o = a.out[row] + sum;
+      break;
+    }
+    a.out[row] = o;
+  }
+}
+
+template <typename T>
+__global__ void csr_inv_diag_kernel(T const *val, int32_t const *col, int32_t const *row_ptr,
+                                    int64_t n_rows, T *dinv)
+{
+  const int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (row >= n_rows)
+    return;
+  T d = T(0);
+  for (int p = row_ptr[row]; p < row_ptr[row + 1]; ++p)
+    if (col[p] == row)
+      d = val[p];
+  dinv[row] = T(1) / d;
+}
+
+template <typename T, int LPR>
+void launch_lpr(CsrArgs<T> const &a, hipStream_t st)
+{
+  const int64_t threads = a.n_rows * LPR;
+  const int64_t nb = (threads + block_size - 1) / block_size;
+  hipLaunchKernelGGL((csr_spmv_kernel<T, LPR>), dim3((unsigned int)std::max<int64_t>(nb, 1)),
+                     dim3(block_size), 0, st, a);
+}
+} // namespace
+
+template <typename T>
+SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int64_t n_cols,
+                                          std::vector<int32_t> row_ptr, std::vector<int32_t> col,
+                                          std::vector<T> val, bool keep_host)
+    : _handle(handle), _n_rows(n_rows), _n_cols(n_cols)
+{
+  ASSERT_THROW((int64_t)row_ptr.size() == n_rows + 1, "row_ptr has the wrong size");
+  _nnz = row_ptr.empty() ? 0 : row_ptr.back();
+  ASSERT_THROW((int64_t)col.size() == _nnz && (int64_t)val.size() == _nnz,
+               "column index / value arrays do not match row_ptr");
+  ASSERT_THROW(n_rows * 64 < (int64_t(1) << 40), "matrix too large");
+  for (int64_t r = 0; r < n_rows; ++r)
+    ASSERT_THROW(row_ptr[r] <= row_ptr[r + 1], "row_ptr must be non-decreasing");
+  for (int64_t p = 0; p < _nnz; ++p)
+    ASSERT_THROW(col[p] >= 0 && col[p] < n_cols, "column index out of range");
+  const double avg = n_rows > 0 ? double(_nnz) / double(n_rows) : 0.;
+  int lpr = 1;
+  while (lpr < 64 && lpr * 2 <= avg * 0.75 + 0.5)
+    lpr *= 2;
+  _lanes_per_row = lpr;
+  _val.upload(val.data(), val.size(), handle.stream);
+  _col.upload(col.data(), col.size(), handle.stream);
+  _row_ptr.upload(row_ptr.data(), row_ptr.size(), handle.stream);
+  if (keep_host)
+  {
+    _row_ptr_host = std::move(row_ptr);
+    _col_host = std::move(col);
+    _val_host = std::move(val);
+  }
+}
+
+template <typename T>
+void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const *dinv, T const *x_prev,
+                                   T alpha, T beta, T *out) const
+{
+  ASSERT_THROW(x != nullptr && out != nullptr, "null vector");
+  ASSERT_THROW(x != out, "SpMV cannot run in place (out aliases x)");
+  if (_n_rows == 0)
+    return;
+  CsrArgs<T> a;
+  a.val = _val.data();
+  a.col = _col.data();
+  a.row_ptr = _row_ptr.data();
+  a.n_rows = _n_rows;
+  a.x = x;
+  a.b = b;
+  a.dinv = dinv;
+  a.xprev = x_prev;
+  a.out = out;
+  a.alpha = alpha;
+  a.beta = beta;
+  a.mode = static_cast<int>(mode);
+  hipStream_t st = _handle.stream;
+  switch (_lanes_per_row)
+  {
+  case 1:
+    launch_lpr<T, 1>(a, st);
+    break;
+  case 2:
+    launch_lpr<T, 2>(a, st);
+    break;
+  case 4:
+    launch_lpr<T, 4>(a, st);
+    break;
+  case 8:
+    launch_lpr<T, 8>(a, st);
+    break;
+  case 16:
+    launch_lpr<T, 16>(a, st);
+    break;
+  case 32:
+    launch_lpr<T, 32>(a, st);
+    break;
+  default:
+    launch_lpr<T, 64>(a, st);
+    break;
+  }
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void SparseMatrixDevice<T>::inverse_diagonal(T *dinv) const
+{
+  ASSERT_THROW(_n_rows == _n_cols, "The matrix is not square. The matrix is a " + std::to_string(_n_rows) +
+                                       " by " + std::to_string(_n_cols) + " .");
+  if (_n_rows == 0)
+    return;
+  hipLaunchKernelGGL(csr_inv_diag_kernel<T>, dim3(n_blocks_for(_n_rows)), dim3(block_size), 0,
+                     _handle.stream, _val.data(), _col.data(), _row_ptr.data(), _n_rows, dinv);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void SparseMatrixDevice<T>::download(std::vector<int32_t> &row_ptr, std::vector<int32_t> &col,
+                                     std::vector<T> &val) const
+{
+  row_ptr = _row_ptr.download(_handle.stream);
+  col = _col.download(_handle.stream);
+  val = _val.download(_handle.stream);
+}
+
+template <typename T>
+void csr_transpose_host(int64_t n_rows, int64_t n_cols, std::vector<int32_t> const &row_ptr,
+                        std::vector<int32_t> const &col, std::vector<T> const &val,
+                        std::vector<int32_t> &t_row_ptr, std::vector<int32_t> &t_col, std::vector<T> &t_val)
+{
+  const int64_t nnz = row_ptr.empty() ? 0 : row_ptr[n_rows];
+  t_row_ptr.assign(n_cols + 1, 0);
+  for (int64_t p = 0; p < nnz; ++p)
+    t_row_ptr[col[p] + 1]++;
+  for (int64_t c = 0; c < n_cols; ++c)
+    t_row_ptr[c + 1] += t_row_ptr[c];
+  t_col.resize(nnz);
+  t_val.resize(nnz);
+  std::vector<int32_t> next(t_row_ptr.begin(), t_row_ptr.end() - 1);
+  for (int64_t r = 0; r < n_rows; ++r)
+    for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
+    {
+      const int q = next[col[p]]++;
+      t_col[q] = (int32_t)r; // rows visited in order -> sorted columns
+      t_val[q] = val[p];
+    }
+}
+
+// Gustavson row-by-row SpGEMM with a dense accumulator per thread; columns sorted.
+template <typename T>
+void csr_multiply_host(int64_t a_rows, int64_t a_cols, std::vector<int32_t> const &a_ptr,
+                       std::vector<int32_t> const &a_col, std::vector<T> const &a_val, int64_t b_cols,
+                       std::vector<int32_t> const &b_ptr, std::vector<int32_t> const &b_col,
+                       std::vector<T> const &b_val, std::vector<int32_t> &c_ptr, std::vector<int32_t> &c_col,
+                       std::vector<T> &c_val)
+{
+  (void)a_cols;
+  c_ptr.assign(a_rows + 1, 0);
+  std::vector<std::vector<int32_t>> row_cols(a_rows);
+  std::vector<std::vector<T>> row_vals(a_rows);
+#pragma omp parallel
+  {
+    std::vector<T> acc(b_cols, T(0));
+    std::vector<char> mark(b_cols, 0);
+    std::vector<int32_t> touched;
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t r = 0; r < a_rows; ++r)
+    {
+      touched.clear();
+      for (int p = a_ptr[r]; p < a_ptr[r + 1]; ++p)
+      {
+        const int k = a_col[p];
+        const T av = a_val[p];
+        for (int q = b_ptr[k]; q < b_ptr[k + 1]; ++q)
+        {
+          const int c = b_col[q];
+          if (!mark[c])
+          {
+            mark[c] = 1;
+            touched.push_back(c);
+          }
+          acc[c] += av * b_val[q];
+        }
+      }
+      std::sort(touched.begin(), touched.end());
+      row_cols[r].assign(touched.begin(), touched.end());
+      row_vals[r].resize(touched.size());
+      for (size_t t = 0; t < touched.size(); ++t)
+      {
+        row_vals[r][t] = acc[touched[t]];
+        acc[touched[t]] = T(0);
+        mark[touched[t]] = 0;
+      }
+    }
+  }
+  int64_t total = 0;
+  for (int64_t r = 0; r < a_rows; ++r)
+  {
+    total += (int64_t)row_cols[r].size();
+    ASSERT_THROW(total < (int64_t(1) << 31), "SpGEMM result exceeds int32 nnz");
+    c_ptr[r + 1] = (int32_t)total;
+  }
+  c_col.resize(total);
+  c_val.resize(total);
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < a_rows; ++r)
+  {
+    std::copy(row_cols[r].begin(), row_cols[r].end(), c_col.begin() + c_ptr[r]);
+    std::copy(row_vals[r].begin(), row_vals[r].end(), c_val.begin() + c_ptr[r]);
+  }
+}
+
+template <typename T>
+std::shared_ptr<SparseMatrixDevice<T>> SparseMatrixDevice<T>::transpose() const
+{
+  std::vector<int32_t> rp, cl, trp, tcl;
+  std::vector<T> vl, tvl;
+  if (has_host_copy())
+    csr_transpose_host<T>(_n_rows, _n_cols, _row_ptr_host, _col_host, _val_host, trp, tcl, tvl);
+  else
+  {
+    download(rp, cl, vl);
+    csr_transpose_host<T>(_n_rows, _n_cols, rp, cl, vl, trp, tcl, tvl);
+  }
+  return std::make_shared<SparseMatrixDevice<T>>(_handle, _n_cols, _n_rows, std::move(trp), std::move(tcl),
+                                                 std::move(tvl));
+}
+
+template <typename T>
+std::shared_ptr<SparseMatrixDevice<T>> SparseMatrixDevice<T>::mmult(SparseMatrixDevice<T> const &b) const
+{
+  ASSERT_THROW(_n_cols == b.m(), "The matrices cannot be multiplied together because their sizes are "
+                                 "incompatible.");
+  std::vector<int32_t> arp, acl, brp, bcl, crp, ccl;
+  std::vector<T> avl, bvl, cvl;
+  std::vector<int32_t> const *ap = &_row_ptr_host, *ac = &_col_host;
+  std::vector<T> const *av = &_val_host;
+  if (!has_host_copy())
+  {
+    download(arp, acl, avl);
+    ap = &arp;
+    ac = &acl;
+    av = &avl;
+  }
+  std::vector<int32_t> const *bp = &b._row_ptr_host, *bc = &b._col_host;
+  std::vector<T> const *bv = &b._val_host;
+  if (!b.has_host_copy())
+  {
+    b.download(brp, bcl, bvl);
+    bp = &brp;
+    bc = &bcl;
+    bv = &bvl;
+  }
+  csr_multiply_host<T>(_n_rows, _n_cols, *ap, *ac, *av, b.n(), *bp, *bc, *bv, crp, ccl, cvl);
+  return std::make_shared<SparseMatrixDevice<T>>(_handle, _n_rows, b.n(), std::move(crp), std::move(ccl),
+                                                 std::move(cvl));
+}
+
+template class SparseMatrixDevice<double>;
+template class SparseMatrixDevice<float>;
+template void csr_transpose_host<double>(int64_t, int64_t, std::vector<int32_t> const &,
+                                         std::vector<int32_t> const &, std::vector<double> const &,
+                                         std::vector<int32_t> &, std::vector<int32_t> &, std::vector<double> &);
+template void csr_transpose_host<float>(int64_t, int64_t, std::vector<int32_t> const &,
+                                        std::vector<int32_t> const &, std::vector<float> const &,
+                                        std::vector<int32_t> &, std::vector<int32_t> &, std::vector<float> &);
+template void csr_multiply_host<double>(int64_t, int64_t, std::vector<int32_t> const &,
+                                        std::vector<int32_t> const &, std::vector<double> const &, int64_t,
+                                        std::vector<int32_t> const &, std::vector<int32_t> const &,
+                                        std::vector<double> const &, std::vector<int32_t> &,
+                                        std::vector<int32_t> &, std::vector<double> &);
+template void csr_multiply_host<float>(int64_t, int64_t, std::vector<int32_t> const &,
+                                       std::vector<int32_t> const &, std::vector<float> const &, int64_t,
+                                       std::vector<int32_t> const &, std::vector<int32_t> const &,
+                                       std::vector<float> const &, std::vector<int32_t> &,
+                                       std::vector<int32_t> &, std::vector<float> &);
+} // namespace mfmg

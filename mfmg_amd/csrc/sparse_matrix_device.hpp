@@ -1,0 +1,115 @@
+// CSR matrix resident in HBM with hand-written gfx950 SpMV kernels.
+//
+// Twin of SparseMatrixDevice<ScalarType> (include/mfmg/cuda/sparse_matrix_device.cuh:28-104):
+// raw val/column_index/row_ptr device arrays owned by the object, 0-based, general.
+// What is NOT reproduced: the all-gather of the whole source vector + reorder_vector
+// kernel in front of every cusparseDcsrmv (…templates.cuh:104-138,351-371); column
+// indices here are local (owned + ghost) ids and ghosts arrive by halo exchange.
+#pragma once
+
+#include "common.hpp"
+
+namespace mfmg
+{
+enum class CsrMode : int
+{
+  apply = 0,    // out = A x
+  residual = 1, // out = A x - b
+  first = 2,    // out = x - beta dinv (A x - b)
+  next = 3,     // out = x + alpha (x - x_prev) - beta dinv (A x - b)
+  subtract = 4, // out -= A x            (x.add(-1, R^T x_c), hierarchy.hpp:297-302)
+  add = 5       // out += A x
+};
+
+template <typename T>
+class SparseMatrixDevice
+{
+public:
+  using value_type = T;
+
+  // convert_matrix (source/cuda/utils.cu:39-168): host CSR -> device
+  SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int64_t n_cols, std::vector<int32_t> row_ptr,
+                     std::vector<int32_t> col, std::vector<T> val, bool keep_host = true);
+
+  int64_t m() const { return _n_rows; }
+  int64_t n() const { return _n_cols; }
+  int64_t n_nonzero_elements() const { return _nnz; }
+  int64_t n_local_rows() const { return _n_rows; }
+
+  // dst = A src   (SparseMatrixDevice::vmult, …templates.cuh:351-371)
+  void vmult(T *dst, T const *src) const
+  {
+    launch(CsrMode::apply, src, nullptr, nullptr, nullptr, T(0), T(0), dst);
+  }
+  void residual(T const *x, T const *b, T *res) const
+  {
+    launch(CsrMode::residual, x, b, nullptr, nullptr, T(0), T(0), res);
+  }
+  void smoother_step(T const *dinv, T const *b, T const *x, T const *x_prev, T alpha, T beta, T *out) const
+  {
+    if (x_prev == nullptr || alpha == T(0))
+      launch(CsrMode::first, x, b, dinv, nullptr, T(0), beta, out);
+    else
+      launch(CsrMode::next, x, b, dinv, x_prev, alpha, beta, out);
+  }
+  void vmult_subtract(T *inout, T const *src) const
+  {
+    launch(CsrMode::subtract, src, nullptr, nullptr, nullptr, T(0), T(0), inout);
+  }
+  void vmult_add(T *inout, T const *src) const
+  {
+    launch(CsrMode::add, src, nullptr, nullptr, nullptr, T(0), T(0), inout);
+  }
+  // extract_inv_diag (source/cuda/cuda_smoother.cu:86-96)
+  void inverse_diagonal(T *dinv) const;
+
+  // setup-time algebra on the host copy (the reference does the transpose on the
+  // host through EpetraExt, cuda_matrix_operator.cu:93-130, and SpGEMM with
+  // cusparseDcsrgemm, …templates.cuh:373-434)
+  std::shared_ptr<SparseMatrixDevice<T>> transpose() const;
+  std::shared_ptr<SparseMatrixDevice<T>> mmult(SparseMatrixDevice<T> const &b) const;
+
+  std::vector<int32_t> const &host_row_ptr() const { return _row_ptr_host; }
+  std::vector<int32_t> const &host_col() const { return _col_host; }
+  std::vector<T> const &host_val() const { return _val_host; }
+  bool has_host_copy() const { return !_row_ptr_host.empty(); }
+  void download(std::vector<int32_t> &row_ptr, std::vector<int32_t> &col, std::vector<T> &val) const;
+
+  T const *val_dev() const { return _val.data(); }
+  int32_t const *column_index_dev() const { return _col.data(); }
+  int32_t const *row_ptr_dev() const { return _row_ptr.data(); }
+  HipHandle &handle() const { return _handle; }
+
+  // algorithmic bytes of one y = A x (12 B/nnz + 4 B/row ptr + x + y)
+  double algorithmic_bytes_apply() const
+  {
+    return double(_nnz) * (sizeof(T) + 4) + 4. * double(_n_rows + 1) + sizeof(T) * double(_n_cols) +
+           sizeof(T) * double(_n_rows);
+  }
+
+private:
+  void launch(CsrMode mode, T const *x, T const *b, T const *dinv, T const *x_prev, T alpha, T beta,
+              T *out) const;
+
+  HipHandle &_handle;
+  int64_t _n_rows, _n_cols, _nnz;
+  int _lanes_per_row;
+  DeviceBuffer<T> _val;
+  DeviceBuffer<int32_t> _col;
+  DeviceBuffer<int32_t> _row_ptr;
+  std::vector<int32_t> _row_ptr_host, _col_host;
+  std::vector<T> _val_host;
+};
+
+// host CSR helpers shared by the setup code
+template <typename T>
+void csr_transpose_host(int64_t n_rows, int64_t n_cols, std::vector<int32_t> const &row_ptr,
+                        std::vector<int32_t> const &col, std::vector<T> const &val,
+                        std::vector<int32_t> &t_row_ptr, std::vector<int32_t> &t_col, std::vector<T> &t_val);
+template <typename T>
+void csr_multiply_host(int64_t a_rows, int64_t a_cols, std::vector<int32_t> const &a_ptr,
+                       std::vector<int32_t> const &a_col, std::vector<T> const &a_val, int64_t b_cols,
+                       std::vector<int32_t> const &b_ptr, std::vector<int32_t> const &b_col,
+                       std::vector<T> const &b_val, std::vector<int32_t> &c_ptr, std::vector<int32_t> &c_col,
+                       std::vector<T> &c_val);
+} // namespace mfmg

@@ -1,0 +1,216 @@
+// Vector kernels (16-byte vectorised where alignment allows is left to the
+// compiler: these are grid-stride streaming loops) and deterministic reductions:
+// per-lane grid-stride partial -> wave __shfl_xor butterfly -> LDS across the 4
+// waves of the block -> one partial per block -> a second single-block pass in a
+// fixed order.  No atomics: the result does not depend on scheduling.
+#include "vector_ops.hpp"
+
+namespace mfmg
+{
+namespace vec
+{
+namespace
+{
+constexpr int kReduceBlocks = 1024;
+
+template <typename T>
+__global__ void set_kernel(int64_t n, T value, T *x)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = value;
+}
+
+template <typename T>
+__global__ void copy_kernel(int64_t n, T const *src, T *dst)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+template <typename T>
+__global__ void sadd_kernel(int64_t n, T s, T a, T const *v, T *x, int plain_add)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = plain_add ? (x[i] + a * v[i]) : (s * x[i] + a * v[i]);
+}
+
+template <typename T>
+__global__ void scale_pointwise_kernel(int64_t n, T const *d, T const *v, T *out)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = d[i] * v[i];
+}
+
+__device__ __forceinline__ double block_reduce_sum(double v)
+{
+  __shared__ double wsum[16];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    v += __shfl_xor(v, off);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  if (lane == 0)
+    wsum[wave] = v;
+  __syncthreads();
+  double total = 0.;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < nw; ++w)
+      total += wsum[w];
+  return total; // valid in thread 0
+}
+
+template <typename T>
+__global__ void dot_stage1_kernel(int64_t n, T const *x, T const *y, double *partials)
+{
+  double acc = 0.;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    acc += (double)x[i] * (double)y[i];
+  const double t = block_reduce_sum(acc);
+  if (threadIdx.x == 0)
+    partials[blockIdx.x] = t;
+}
+
+__global__ void dot_stage2_kernel(int n_partials, double const *partials, double *result, int slot)
+{
+  double acc = 0.;
+  for (int i = threadIdx.x; i < n_partials; i += blockDim.x)
+    acc += partials[i];
+  const double t = block_reduce_sum(acc);
+  if (threadIdx.x == 0)
+    result[slot] = t;
+}
+
+template <typename T>
+__global__ void cg_update_kernel(int64_t n, T const *p, T const *Ap, T const *dinv, T *x, T *r, T *z,
+                                 double const *scal, int slot_rz, int slot_pap)
+{
+  const double pap = scal[slot_pap];
+  const T alpha = (pap != 0.) ? T(scal[slot_rz] / pap) : T(0);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+  {
+    x[i] += alpha * p[i];
+    const T ri = r[i] - alpha * Ap[i];
+    r[i] = ri;
+    z[i] = dinv[i] * ri;
+  }
+}
+
+template <typename T>
+__global__ void cg_direction_kernel(int64_t n, T const *z, T *p, double const *scal, int slot_new, int slot_old)
+{
+  const double old = scal[slot_old];
+  const T beta = (old != 0.) ? T(scal[slot_new] / old) : T(0);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = z[i] + beta * p[i];
+}
+
+inline unsigned int stream_blocks(int64_t n) { return n_blocks_for(n, block_size, 256 * 16); }
+} // namespace
+
+template <typename T>
+void set(HipHandle &h, int64_t n, T value, T *x)
+{
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(set_kernel<T>, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, n, value, x);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void copy(HipHandle &h, int64_t n, T const *src, T *dst)
+{
+  if (n <= 0 || src == dst)
+    return;
+  hipLaunchKernelGGL(copy_kernel<T>, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, n, src, dst);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void add(HipHandle &h, int64_t n, T a, T const *v, T *x)
+{
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(sadd_kernel<T>, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, n, T(1), a, v, x, 1);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void sadd(HipHandle &h, int64_t n, T s, T a, T const *v, T *x)
+{
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(sadd_kernel<T>, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, n, s, a, v, x, 0);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void scale_pointwise(HipHandle &h, int64_t n, T const *d, T const *v, T *out)
+{
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(scale_pointwise_kernel<T>, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, n, d, v,
+                     out);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void dot_async(HipHandle &h, int64_t n, T const *x, T const *y, double *result_dev, int slot)
+{
+  const unsigned int nb = n_blocks_for(n, block_size, kReduceBlocks);
+  hipLaunchKernelGGL(dot_stage1_kernel<T>, dim3(nb), dim3(block_size), 0, h.stream, n, x, y,
+                     h.reduce_partials.data());
+  hipLaunchKernelGGL(dot_stage2_kernel, dim3(1), dim3(block_size), 0, h.stream, (int)nb,
+                     h.reduce_partials.data(), result_dev, slot);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+double dot(HipHandle &h, int64_t n, T const *x, T const *y)
+{
+  dot_async<T>(h, n, x, y, h.reduce_result.data(), 0);
+  MFMG_HIP_CHECK(hipMemcpyAsync(h.host_result, h.reduce_result.data(), sizeof(double), hipMemcpyDeviceToHost,
+                                h.stream));
+  MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
+  return h.host_result[0];
+}
+
+template <typename T>
+double l2_norm(HipHandle &h, int64_t n, T const *x)
+{
+  return std::sqrt(dot<T>(h, n, x, x));
+}
+
+template <typename T>
+void cg_update(HipHandle &h, int64_t n, T const *p, T const *Ap, T const *dinv, T *x, T *r, T *z,
+               double const *scal, int slot_rz, int slot_pap)
+{
+  hipLaunchKernelGGL(cg_update_kernel<T>, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, n, p, Ap, dinv,
+                     x, r, z, scal, slot_rz, slot_pap);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void cg_direction(HipHandle &h, int64_t n, T const *z, T *p, double const *scal, int slot_rz_new,
+                  int slot_rz_old)
+{
+  hipLaunchKernelGGL(cg_direction_kernel<T>, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, n, z, p,
+                     scal, slot_rz_new, slot_rz_old);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+#define MFMG_INSTANTIATE_VEC(T)                                                                              \
+  template void set<T>(HipHandle &, int64_t, T, T *);                                                        \
+  template void copy<T>(HipHandle &, int64_t, T const *, T *);                                               \
+  template void add<T>(HipHandle &, int64_t, T, T const *, T *);                                             \
+  template void sadd<T>(HipHandle &, int64_t, T, T, T const *, T *);                                         \
+  template void scale_pointwise<T>(HipHandle &, int64_t, T const *, T const *, T *);                         \
+  template void dot_async<T>(HipHandle &, int64_t, T const *, T const *, double *, int);                     \
+  template double dot<T>(HipHandle &, int64_t, T const *, T const *);                                        \
+  template double l2_norm<T>(HipHandle &, int64_t, T const *);                                               \
+  template void cg_update<T>(HipHandle &, int64_t, T const *, T const *, T const *, T *, T *, T *,           \
+                             double const *, int, int);                                                      \
+  template void cg_direction<T>(HipHandle &, int64_t, T const *, T *, double const *, int, int);
+MFMG_INSTANTIATE_VEC(double)
+MFMG_INSTANTIATE_VEC(float)
+} // namespace vec
+} // namespace mfmg

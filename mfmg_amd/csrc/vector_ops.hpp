@@ -1,0 +1,45 @@
+// Vector kernels used inside the cycle: the deal.II CUDA vector operations the
+// reference calls at include/mfmg/common/hierarchy.hpp:258,286,302 and
+// source/cuda/cuda_smoother.cu:50-59 (x = 0, add, sadd, copy, l2_norm), plus the
+// device-scalar building blocks of the coarse Krylov iteration.
+#pragma once
+
+#include "common.hpp"
+
+namespace mfmg
+{
+namespace vec
+{
+template <typename T>
+void set(HipHandle &h, int64_t n, T value, T *x); // x = value
+template <typename T>
+void copy(HipHandle &h, int64_t n, T const *src, T *dst);
+template <typename T>
+void add(HipHandle &h, int64_t n, T a, T const *v, T *x); // x += a v
+template <typename T>
+void sadd(HipHandle &h, int64_t n, T s, T a, T const *v, T *x); // x = s x + a v
+template <typename T>
+void scale_pointwise(HipHandle &h, int64_t n, T const *d, T const *v, T *out); // out = d .* v
+
+// Deterministic two-stage dot product; the result lands in device slot
+// `result_dev[slot]` (no host synchronisation).
+template <typename T>
+void dot_async(HipHandle &h, int64_t n, T const *x, T const *y, double *result_dev, int slot);
+// synchronous host result
+template <typename T>
+double dot(HipHandle &h, int64_t n, T const *x, T const *y);
+template <typename T>
+double l2_norm(HipHandle &h, int64_t n, T const *x);
+
+// ---- device-scalar CG building blocks (no host round trip, graph-capturable) ----
+// scal[] slots hold dot products computed by dot_async.
+// x += (scal[rz]/scal[pap]) p ; r -= (scal[rz]/scal[pap]) Ap ; z = dinv .* r
+template <typename T>
+void cg_update(HipHandle &h, int64_t n, T const *p, T const *Ap, T const *dinv, T *x, T *r, T *z,
+               double const *scal, int slot_rz, int slot_pap);
+// p = z + (scal[rz_new]/scal[rz_old]) p
+template <typename T>
+void cg_direction(HipHandle &h, int64_t n, T const *z, T *p, double const *scal, int slot_rz_new,
+                  int slot_rz_old);
+} // namespace vec
+} // namespace mfmg

@@ -1,0 +1,240 @@
+"""V-cycle parity: mfmg::Hierarchy on the GPU against the CPU oracle on the same problem,
+same R, same smoother parameters -- residual history equal to 1e-10 relative (BASELINE.json)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import mfmg_amd as M
+from mfmg_amd import lib as L
+import mfmg_oracle as O
+
+pytestmark = pytest.mark.gpu
+HIST_TOL = 1e-10
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def gpu_history(ctx, h, apply_monitor, b, x0, n_cycles=20):
+    """tests/test_hierarchy.cc:95-123 with the residual monitored by `apply_monitor(y, x)`."""
+    x = dev(x0)
+    bd = dev(b)
+    r = torch.empty_like(x)
+    apply_monitor(r, x)
+    ctx.sadd(r, -1.0, 1.0, bd)
+    r0 = ctx.l2_norm(r)
+    res = [1.0]
+    for _ in range(n_cycles):
+        h.apply(bd, x)
+        apply_monitor(r, x)
+        ctx.sadd(r, -1.0, 1.0, bd)
+        res.append(ctx.l2_norm(r) / r0)
+    ctx.synchronize()
+    return np.array(res), x.cpu().numpy()
+
+
+def base_params(n_eig=2, **extra):
+    p = {"eigensolver": {"number of eigenvectors": n_eig}, "agglomeration": {"nx": 2, "ny": 2, "nz": 2},
+         "is preconditioner": False, "max levels": 2}
+    p.update(extra)
+    return p
+
+
+@pytest.mark.parametrize("n,material,degree", [((4, 4, 4), "constant", 1), ((8, 8, 8), "linear", 3),
+                                               ((16, 16, 16), "constant", 3), ((12, 10, 6), "discontinuous", 2)])
+def test_matrix_free_chebyshev_vcycle_history(ctx, n, material, degree):
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, material)
+    con = mesh.constrained_mask()
+    mf = O.MatrixFreeLaplace(mesh, coef)
+    prob = M.LaplaceProblem(n, material, device="cuda")
+    params = base_params(smoother={"type": "Chebyshev", "degree": degree, "smoothing_range": 20.0})
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    deg, lmin, lmax = h.smoother_info()
+    assert deg == degree
+    # oracle with the same R (the product's own, downloaded) and the same polynomial
+    R = h.restrictor().to_scipy()
+    Ro = O.build_restrictor(mesh, coef, mf.diagonal(), n_eig=2, variant="mf", eig_mode="krylov").csr
+    assert abs(R - Ro).max() < 1e-11          # product setup == oracle setup (unique selection rule)
+    Ac = O.galerkin_coarse_matrix(mf.vmult, R)
+    assert abs(h.coarse_operator().to_scipy() - Ac).max() < 1e-11 * abs(Ac).max()
+    p = O.ChebyshevParams(degree=degree, lambda_max=lmax, lambda_min=lmin)
+    dinv = mf.diagonal_inverse()
+    smoother = lambda b, x: O.chebyshev_smoother_apply(mf.vmult, dinv, p, b, x)
+    ho = O.TwoLevelHierarchy(mf.vmult, smoother, R, O.direct_coarse_solver(Ac), 1, False)
+    x0 = O.random_initial_guess(mesh.n_dofs, con)
+    b = np.zeros(mesh.n_dofs)
+    res_o, rate_o, x_o = O.vcycle_history(ho, mf.vmult, b, x0)
+    op = M.MatrixFreeLaplace(ctx, prob)
+    res_g, x_g = gpu_history(ctx, h, lambda y, x: op.vmult(y, x), b, x0)
+    np.testing.assert_allclose(res_g, res_o, rtol=HIST_TOL)
+    assert res_g[-1] / res_g[-2] == pytest.approx(rate_o, rel=1e-8)
+    assert rate_o < 0.5
+
+
+def test_eigenvalue_estimate_matches_dealii_restatement(ctx):
+    n = (8, 8, 8)
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "linear")
+    mf = O.MatrixFreeLaplace(mesh, coef)
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", M.LaplaceProblem(n, "linear", device="cuda"),
+                    base_params(smoother={"type": "Chebyshev", "degree": 2}))
+    deg, lmin, lmax = h.smoother_info()
+    p = O.dealii_chebyshev_params(mf.vmult, mf.diagonal_inverse(), mesh.n_dofs, degree=2)
+    assert lmax == pytest.approx(p.lambda_max, rel=1e-10)
+    assert lmin == pytest.approx(p.lambda_min, rel=1e-10)
+
+
+def test_gold_cuda_jacobi_on_gpu(ctx):
+    """tests/test_hierarchy_device.cu:359-420 replayed on the MI355X: assembled operator, Jacobi,
+    dense coarse solve, x0 random on all DoFs in deal.II DoF-id order; R from the LAPACK-based oracle
+    (the gold depends on LAPACK's basis of a degenerate eigenspace)."""
+    n = (4, 4, 4)
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh)
+    con = mesh.constrained_mask()
+    A = O.assemble_csr(mesh, coef)
+    R = O.build_restrictor(mesh, np.ones_like(coef), A.diagonal(), n_eig=2, variant="device", eig_mode="lapack").csr
+    prob = M.LaplaceProblem(n, device="cuda")
+    params = base_params(smoother={"type": "Jacobi"}, solver={"type": "lu_dense"})
+    h = M.Hierarchy(ctx, "HipMeshEvaluator", prob, params)
+    assert h.n_levels == 2 and h.level_size(0) == 125 and h.level_size(1) == 16
+    h.set_restrictor(R)
+    dn = O.dealii_global_numbering(mesh)
+    x0 = O.random_initial_guess(mesh.n_dofs, con, order=np.argsort(dn), zero_constrained=False)
+    Ad = M.SparseMatrixDevice(ctx, A)
+    res, _ = gpu_history(ctx, h, lambda y, x: Ad.vmult(y, x), np.zeros(mesh.n_dofs), x0)
+    assert res[-1] / res[-2] == pytest.approx(0.14933479171507894, rel=1e-8)   # 1e-6 %
+    # and the oracle history on the same data
+    dinv = 1.0 / A.diagonal()
+    Ac = (R @ A @ R.T).tocsr()
+    smoother = lambda b, x: O.smoother_wrapper(lambda v: A @ v, lambda r: dinv * r, b, x)
+    ho = O.TwoLevelHierarchy(lambda v: A @ v, smoother, R, O.direct_coarse_solver(Ac), 1, False)
+    res_o, _, _ = O.vcycle_history(ho, lambda v: A @ v, np.zeros(mesh.n_dofs), x0)
+    np.testing.assert_allclose(res, res_o, rtol=HIST_TOL)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_assembled_jacobi_own_setup(ctx, dim):
+    """Assembled CSR path end to end with the product's own restrictor (2-D: BASELINE configs[0] mesh)."""
+    n = (8, 8) if dim == 2 else (8, 8, 8)
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "linear")
+    con = mesh.constrained_mask()
+    A = O.assemble_csr(mesh, coef)
+    prob = M.LaplaceProblem(n, "linear", device="cuda")
+    h = M.Hierarchy(ctx, "HipMeshEvaluator", prob, base_params(smoother={"type": "Jacobi"}))
+    R = h.restrictor().to_scipy()
+    Ac = (R @ A @ R.T).tocsr()
+    assert abs(h.coarse_operator().to_scipy() - Ac).max() < 1e-12 * abs(Ac).max()
+    dinv = 1.0 / A.diagonal()
+    smoother = lambda b, x: O.smoother_wrapper(lambda v: A @ v, lambda r: dinv * r, b, x)
+    ho = O.TwoLevelHierarchy(lambda v: A @ v, smoother, R, O.direct_coarse_solver(Ac), 1, False)
+    rng = np.random.default_rng(0)
+    x0 = np.where(con, 0.0, rng.random(mesh.n_dofs))
+    b = np.where(con, 0.0, rng.random(mesh.n_dofs))     # non-zero right-hand side
+    res_o, rate, _ = O.vcycle_history(ho, lambda v: A @ v, b, x0, n_cycles=12)
+    Ad = M.SparseMatrixDevice(ctx, A)
+    res_g, _ = gpu_history(ctx, h, lambda y, x: Ad.vmult(y, x), b, x0, n_cycles=12)
+    np.testing.assert_allclose(res_g, res_o, rtol=HIST_TOL)
+    assert np.all(np.diff(res_g) < 0)
+
+
+def test_components_and_preconditioner_mode(ctx):
+    """Level accessors (include/mfmg/common/level.hpp:30-48) one by one + 'is preconditioner' zeroing."""
+    n = (8, 6, 6)
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "linear_x")
+    mf = O.MatrixFreeLaplace(mesh, coef)
+    prob = M.LaplaceProblem(n, "linear_x", device="cuda")
+    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "lambda_max": 1.8, "lambda_min": 0.12})
+    params["is preconditioner"] = True
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    R = h.restrictor().to_scipy()
+    Ac = h.coarse_operator().to_scipy()
+    nf, nc = h.level_size(0), h.level_size(1)
+    rng = np.random.default_rng(7)
+    xf, bf, xc = rng.random(nf), rng.random(nf), rng.random(nc)
+    out_f = torch.empty(nf, dtype=torch.float64, device="cuda")
+    out_c = torch.empty(nc, dtype=torch.float64, device="cuda")
+    h.operator_apply(0, dev(xf), out_f)
+    np.testing.assert_allclose(out_f.cpu().numpy(), mf.vmult(xf), rtol=1e-12, atol=1e-13)
+    h.operator_apply(1, dev(xc), out_c)
+    np.testing.assert_allclose(out_c.cpu().numpy(), Ac @ xc, rtol=1e-12, atol=1e-13)
+    h.restrictor_apply(1, dev(xf), out_c)
+    np.testing.assert_allclose(out_c.cpu().numpy(), R @ xf, rtol=1e-12, atol=1e-13)
+    h.restrictor_apply(1, dev(xc), out_f, L.TRANS)
+    np.testing.assert_allclose(out_f.cpu().numpy(), R.T @ xc, rtol=1e-12, atol=1e-13)
+    h.coarse_apply(dev(xc), out_c)
+    np.testing.assert_allclose(out_c.cpu().numpy(), np.linalg.solve(Ac.toarray(), xc), rtol=1e-9)
+    p = O.ChebyshevParams(3, 1.8, 0.12)
+    xs = dev(xf)
+    h.smoother_apply(0, dev(bf), xs)
+    np.testing.assert_allclose(xs.cpu().numpy(), O.chebyshev_smoother_apply(mf.vmult, mf.diagonal_inverse(), p, bf, xf),
+                               rtol=1e-11, atol=1e-12)
+    with pytest.raises(L.MfmgNotImplementedError):
+        h.operator_apply(0, dev(xf), out_f, L.TRANS)      # cuda_matrix_free_operator.cu:64-71
+    # preconditioner mode: garbage in x must not matter (hierarchy.hpp:253-259)
+    smoother = lambda b, x: O.chebyshev_smoother_apply(mf.vmult, mf.diagonal_inverse(), p, b, x)
+    ho = O.TwoLevelHierarchy(mf.vmult, smoother, R, O.direct_coarse_solver(Ac), 1, True)
+    xg = dev(1e6 * rng.random(nf))
+    h.vmult(xg, dev(bf))
+    np.testing.assert_allclose(xg.cpu().numpy(), ho.apply(bf, np.zeros(nf)), rtol=1e-10, atol=1e-12)
+
+
+def test_pcg_coarse_solver_parity(ctx):
+    n = (16, 16, 16)
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "constant")
+    con = mesh.constrained_mask()
+    mf = O.MatrixFreeLaplace(mesh, coef)
+    prob = M.LaplaceProblem(n, device="cuda")
+    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0},
+                         solver={"type": "pcg", "n_iterations": 12})
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    deg, lmin, lmax = h.smoother_info()
+    R = h.restrictor().to_scipy()
+    Ac = h.coarse_operator().to_scipy()
+    p = O.ChebyshevParams(deg, lmax, lmin)
+    smoother = lambda b, x: O.chebyshev_smoother_apply(mf.vmult, mf.diagonal_inverse(), p, b, x)
+    ho = O.TwoLevelHierarchy(mf.vmult, smoother, R, O.pcg_coarse_solver(Ac, 12), 1, False)
+    x0 = O.random_initial_guess(mesh.n_dofs, con)
+    b = np.zeros(mesh.n_dofs)
+    res_o, _, _ = O.vcycle_history(ho, mf.vmult, b, x0, n_cycles=10)
+    op = M.MatrixFreeLaplace(ctx, prob)
+    res_g, _ = gpu_history(ctx, h, lambda y, x: op.vmult(y, x), b, x0, n_cycles=10)
+    np.testing.assert_allclose(res_g, res_o, rtol=1e-9)
+
+
+def test_error_conventions(ctx):
+    prob = M.LaplaceProblem((4, 4, 4), device="cuda")
+    with pytest.raises(L.MfmgError, match="Unknown smoother name"):       # cuda_smoother.cu:110
+        M.Hierarchy(ctx, "HipMeshEvaluator", prob, base_params(smoother={"type": "Gauss-Seidel"}))
+    with pytest.raises(L.MfmgError, match="Unknown solver name"):         # cuda_solver.cu:71
+        M.Hierarchy(ctx, "HipMeshEvaluator", prob, base_params(solver={"type": "multifrontal"}))
+    with pytest.raises(L.MfmgNotImplementedError):                        # no AmgX shim
+        M.Hierarchy(ctx, "HipMeshEvaluator", prob, base_params(solver={"type": "amgx"}))
+    with pytest.raises(L.MfmgNotImplementedError):                        # hierarchy.hpp:49-107 string switch
+        M.Hierarchy(ctx, "DealIIMeshEvaluator", prob, base_params())
+    with pytest.raises(L.MfmgNotImplementedError):                        # hierarchy_helpers.hpp:45-50
+        M.Hierarchy(ctx, "HipMeshEvaluator", prob, base_params(fast_ap=True))
+    with pytest.raises(L.MfmgError, match="must be positive"):            # hierarchy.hpp:173-175
+        M.Hierarchy(ctx, "HipMeshEvaluator", prob, base_params(**{"max levels": 0}))
+    h = M.Hierarchy(ctx, "HipMeshEvaluator", prob, base_params())
+    with pytest.raises(ValueError):
+        h.apply(torch.zeros(125, dtype=torch.float64), torch.zeros(125, dtype=torch.float64))   # host tensors
+    assert "Setup: build restrictor" in h.timer_report()
+
+
+def test_single_level_hierarchy_is_coarse_solve(ctx):
+    n = (4, 4, 4)
+    mesh = O.StructuredMesh(n)
+    A = O.assemble_csr(mesh, O.coefficient_table(mesh))
+    h = M.Hierarchy(ctx, "HipMeshEvaluator", M.LaplaceProblem(n, device="cuda"), base_params(**{"max levels": 1}))
+    assert h.n_levels == 1
+    b = np.random.default_rng(0).random(125)
+    x = dev(np.zeros(125))
+    h.apply(dev(b), x)
+    np.testing.assert_allclose(x.cpu().numpy(), np.linalg.solve(A.toarray(), b), rtol=1e-10)

@@ -1,0 +1,239 @@
+"""Parity of the hand-written HIP kernels against the CPU oracle, through the C ABI.
+FP64 tolerance: 1e-12 relative to the vector's max-norm per kernel (the V-cycle level
+requirement of BASELINE.json is 1e-10 relative on the residual history)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import mfmg_amd as M
+from mfmg_amd import lib as L
+import mfmg_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def host(t, ctx):
+    ctx.synchronize()
+    return t.cpu().numpy()
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+# ---- matrix-free operator --------------------------------------------------------------
+CASES = [((4, 4, 4), "constant"), ((7, 5, 6), "linear"), ((16, 16, 16), "discontinuous"),
+         ((64, 9, 11), "linear_x"), ((70, 12, 10), "linear"), ((130, 8, 7), "constant")]
+
+
+@pytest.mark.parametrize("n,material", CASES)
+def test_mf_vmult_matches_oracle(ctx, n, material):
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, material)
+    ref = O.MatrixFreeLaplace(mesh, coef)
+    prob = M.LaplaceProblem(n, material, device="cuda")
+    op = M.MatrixFreeLaplace(ctx, prob)
+    x = np.random.default_rng(0).random(mesh.n_dofs)   # nonzero on constrained DoFs too
+    y = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
+    op.vmult(y, dev(x))
+    assert relerr(host(y, ctx), ref.vmult(x)) < TOL
+    np.testing.assert_allclose(host(op.diagonal(), ctx), ref.diagonal(), rtol=1e-13)
+    np.testing.assert_allclose(host(op.diagonal_inverse(), ctx), ref.diagonal_inverse(), rtol=1e-13)
+
+
+@pytest.mark.parametrize("ty,tz", [(1, 1), (2, 3), (4, 8), (16, 2), (5, 64)])
+def test_mf_vmult_independent_of_tile(ctx, ty, tz):
+    n = (20, 13, 9)
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "linear")
+    ref = O.MatrixFreeLaplace(mesh, coef)
+    op = M.MatrixFreeLaplace(ctx, M.LaplaceProblem(n, "linear", device="cuda"))
+    x = np.random.default_rng(1).random(mesh.n_dofs)
+    y0 = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
+    op.vmult(y0, dev(x))
+    y0 = host(y0, ctx).copy()
+    op.set_tile(ty, tz)
+    y = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
+    op.vmult(y, dev(x))
+    y = host(y, ctx)
+    assert relerr(y, ref.vmult(x)) < TOL
+    # owner-computes without atomics: the tiling must not change a single bit
+    assert np.array_equal(y, y0)
+
+
+def test_mf_vmult_host_arrays_and_renumbered_dofs(ctx):
+    n = (9, 6, 5)
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "linear")
+    ref = O.MatrixFreeLaplace(mesh, coef)
+    perm = np.random.default_rng(5).permutation(mesh.n_dofs)
+    prob = M.LaplaceProblem(n, "linear", device="cpu", dof_numbering=torch.from_numpy(perm))
+    op = M.MatrixFreeLaplace(ctx, prob)          # host arrays are staged by the library
+    x_lex = np.random.default_rng(2).random(mesh.n_dofs)
+    x = np.empty_like(x_lex)
+    x[perm] = x_lex                               # value of node i lives at DoF perm[i]
+    y = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
+    op.vmult(y, dev(x))
+    assert relerr(host(y, ctx)[perm], ref.vmult(x_lex)) < TOL
+
+
+def test_mf_fused_epilogues(ctx):
+    n = (12, 10, 9)
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "discontinuous")
+    ref = O.MatrixFreeLaplace(mesh, coef)
+    dinv = ref.diagonal_inverse()
+    op = M.MatrixFreeLaplace(ctx, M.LaplaceProblem(n, "discontinuous", device="cuda"))
+    rng = np.random.default_rng(3)
+    x, b, xp = rng.random(mesh.n_dofs), rng.random(mesh.n_dofs), rng.random(mesh.n_dofs)
+    out = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
+    op.residual(dev(x), dev(b), out)
+    assert relerr(host(out, ctx), ref.vmult(x) - b) < TOL
+    op.smoother_step(dev(b), dev(x), None, 0.0, 0.7, out)
+    assert relerr(host(out, ctx), x - 0.7 * dinv * (ref.vmult(x) - b)) < TOL
+    op.smoother_step(dev(b), dev(x), dev(xp), 0.3, 0.45, out)
+    assert relerr(host(out, ctx), x + 0.3 * (x - xp) - 0.45 * dinv * (ref.vmult(x) - b)) < TOL
+    # the polynomial term may overwrite its own x_{k-1}
+    xp_d = dev(xp)
+    op.smoother_step(dev(b), dev(x), xp_d, 0.3, 0.45, xp_d)
+    assert relerr(host(xp_d, ctx), x + 0.3 * (x - xp) - 0.45 * dinv * (ref.vmult(x) - b)) < TOL
+    with pytest.raises(L.MfmgError, match="in place"):
+        xd = dev(x)
+        op.vmult(xd, xd)
+
+
+def test_mf_rejects_bad_input(ctx):
+    with pytest.raises(L.MfmgNotImplementedError):
+        M.MatrixFreeLaplace(ctx, M.LaplaceProblem((8, 8), device="cuda"))        # dim = 2
+    p = M.LaplaceProblem((3, 3, 3), device="cuda")
+    p.cell_dofs[5, 2] = p.cell_dofs[5, 3]
+    with pytest.raises(L.MfmgError, match="not a logically structured"):
+        M.MatrixFreeLaplace(ctx, p)
+
+
+def test_mf_operator_properties_large(ctx):
+    """Size-independent properties at a size the numpy oracle would not finish quickly:
+    symmetry <Ax,y> = <x,Ay>, linearity, constants in the kernel away from the boundary."""
+    n = (127, 127, 127)
+    prob = M.LaplaceProblem(n, "linear", device="cuda")
+    op = M.MatrixFreeLaplace(ctx, prob)
+    N = prob.n_dofs
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand(N, dtype=torch.float64, device="cuda", generator=g)
+    y = torch.rand(N, dtype=torch.float64, device="cuda", generator=g)
+    free = (prob.constrained == 0).to(torch.float64)
+    x, y = x * free, y * free
+    ax, ay, axy = (torch.empty_like(x) for _ in range(3))
+    op.vmult(ax, x)
+    op.vmult(ay, y)
+    assert abs(ctx.dot(ax, y) - ctx.dot(x, ay)) < 1e-12 * abs(ctx.dot(ax, y))
+    z = (2.0 * x - 3.0 * y).contiguous()
+    op.vmult(axy, z)
+    ctx.synchronize()
+    assert (axy - (2.0 * ax - 3.0 * ay)).abs().max().item() < 1e-12 * ax.abs().max().item()
+    ones = torch.ones(N, dtype=torch.float64, device="cuda")
+    a1 = torch.empty_like(ones)
+    op.vmult(a1, ones)           # constrained entries are *read as zero*: only rows next to the boundary see them
+    ctx.synchronize()
+    a1 = a1.reshape(128, 128, 128)
+    assert a1[2:-2, 2:-2, 2:-2].abs().max().item() < 1e-12
+
+
+# ---- CSR kernels --------------------------------------------------------------------------
+def test_csr_fixture_banded_operator(ctx):
+    """tests/test_sparse_matrix_device_operator.cu:23-137 (exact equality on integer data)."""
+    n_rows, nnz_per_row = 30, 10
+    rows = np.repeat(np.arange(n_rows), nnz_per_row)
+    cols = rows + np.tile(np.arange(nnz_per_row), n_rows)
+    A = sp.csr_matrix(((rows + cols).astype(float), (rows, cols)), shape=(n_rows, n_rows + nnz_per_row - 1))
+    Ad = M.SparseMatrixDevice(ctx, A)
+    assert Ad.shape == (30, 39)                     # build_range/domain_vector sizes
+    y = torch.empty(30, dtype=torch.float64, device="cuda")
+    Ad.apply(dev(np.ones(39)), y)
+    assert np.array_equal(host(y, ctx), A.toarray() @ np.ones(39))
+    At = Ad.transpose()
+    assert At.shape == (39, 30)
+    yt = torch.empty(39, dtype=torch.float64, device="cuda")
+    At.apply(dev(np.ones(30)), yt)
+    assert np.array_equal(host(yt, ctx), A.toarray().T @ np.ones(30))
+    Ad.apply(dev(np.ones(30)), yt, L.TRANS)
+    assert np.array_equal(host(yt, ctx), A.toarray().T @ np.ones(30))
+    C = Ad.multiply(At)
+    yc = torch.empty(30, dtype=torch.float64, device="cuda")
+    C.apply(dev(np.ones(30)), yc)
+    assert np.array_equal(host(yc, ctx), A.toarray() @ (A.toarray().T @ np.ones(30)))
+    assert abs(C.to_scipy() - A @ A.T).max() == 0.0
+
+
+def test_csr_fixture_random_pattern_and_jacobi(ctx):
+    from test_oracle_fixtures import random_pattern_matrix
+    A = random_pattern_matrix()                      # tests/test_sparse_matrix_device.cu:43-56
+    x = np.arange(10, dtype=float)
+    y = torch.empty(10, dtype=torch.float64, device="cuda")
+    M.SparseMatrixDevice(ctx, A).vmult(y, dev(x))
+    np.testing.assert_allclose(host(y, ctx), A @ x, rtol=1e-15)
+    # tests/test_smoother_device.cu:28-119
+    n = 30
+    T = sp.diags([-np.ones(n - 1), 4 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1]).tocsr()
+    Td = M.SparseMatrixDevice(ctx, T)
+    dinv = torch.empty(n, dtype=torch.float64, device="cuda")
+    Td.inverse_diagonal(dinv)
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    Td.smoother_step(dinv, dev(np.ones(n)), dev(np.zeros(n)), None, 0.0, 1.0, out)
+    np.testing.assert_allclose(host(out, ctx), 0.25 * np.ones(n), rtol=1e-14)
+
+
+@pytest.mark.parametrize("shape,density", [((1, 1), 1.0), ((200, 300), 0.02), ((1000, 1000), 0.03), ((500, 64), 0.5),
+                                          ((64, 5000), 0.2)])
+def test_csr_spmv_ragged(ctx, shape, density):
+    rng = np.random.default_rng(11)
+    A = sp.random(*shape, density=density, random_state=rng, format="csr", dtype=np.float64)
+    A.sort_indices()
+    x = rng.random(shape[1])
+    y = torch.empty(shape[0], dtype=torch.float64, device="cuda")
+    M.SparseMatrixDevice(ctx, A).vmult(y, dev(x))
+    ref = O.csr_spmv(A.indptr, A.indices, A.data, x)    # rows without entries give 0
+    assert np.abs(host(y, ctx) - ref).max() <= 1e-13 * max(np.abs(ref).max(), 1.0)
+
+
+def test_csr_fused_modes_27pt(ctx):
+    mesh = O.StructuredMesh((10, 9, 8))
+    coef = O.coefficient_table(mesh, "linear")
+    A = O.assemble_csr(mesh, coef)
+    Ad = M.SparseMatrixDevice(ctx, A)
+    n = mesh.n_dofs
+    rng = np.random.default_rng(4)
+    x, b, xp = rng.random(n), rng.random(n), rng.random(n)
+    dinv = 1.0 / A.diagonal()
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    Ad.residual(dev(x), dev(b), out)
+    assert relerr(host(out, ctx), A @ x - b) < TOL
+    Ad.smoother_step(dev(dinv), dev(b), dev(x), dev(xp), 0.25, 0.6, out)
+    assert relerr(host(out, ctx), x + 0.25 * (x - xp) - 0.6 * dinv * (A @ x - b)) < TOL
+    with pytest.raises(L.MfmgInvalidArgument):
+        M.SparseMatrixDevice(ctx, (np.array([0, 2], dtype=np.int32), np.array([0, 7], dtype=np.int32),
+                                   np.array([1.0, 1.0]), (1, 3))).shape
+
+
+def test_vector_kernels(ctx):
+    rng = np.random.default_rng(9)
+    for n in (1, 63, 64, 1000, 1 << 20):
+        x, v = rng.random(n), rng.random(n)
+        xd, vd = dev(x), dev(v)
+        assert ctx.dot(xd, vd) == pytest.approx(float(x @ v), rel=1e-13)
+        assert ctx.l2_norm(xd) == pytest.approx(float(np.linalg.norm(x)), rel=1e-13)
+        ctx.add(xd, -1.0, vd)                         # res->add(-1., b), hierarchy.hpp:286
+        np.testing.assert_array_equal(host(xd, ctx), x - v)
+        ctx.sadd(xd, -1.0, 1.0, vd)                   # residual.sadd(-1., 1., rhs), tests/test_hierarchy.cc:104
+        np.testing.assert_array_equal(host(xd, ctx), -(x - v) + v)
+        ctx.set(xd, 0.0)                              # x = 0., hierarchy.hpp:258
+        assert not host(xd, ctx).any()
+    # deterministic reduction: same bits on repeat
+    xd = dev(rng.random(1 << 20))
+    assert ctx.dot(xd, xd) == ctx.dot(xd, xd)
