@@ -52,7 +52,9 @@ const char *mfmg_hip_last_error(void);
 const char *mfmg_hip_version(void);
 
 /* ---- context: stream + scratch (CudaHandle, source/cuda/cuda_handle.cu:17-56) ---- */
-/* `hip_stream` may be NULL (the library creates its own non-blocking stream). */
+/* `hip_stream`: a hipStream_t borrowed from the caller; NULL = the legacy default stream (what the
+ * reference runs on); MFMG_HIP_OWN_STREAM = the library creates and owns a non-blocking stream. */
+#define MFMG_HIP_OWN_STREAM ((void *)(intptr_t)-1)
 int mfmg_hip_context_create(void *hip_stream, mfmg_hip_context_t *ctx);
 int mfmg_hip_context_destroy(mfmg_hip_context_t ctx);
 int mfmg_hip_context_synchronize(mfmg_hip_context_t ctx);

@@ -49,15 +49,20 @@ def _dev_ptr(t: torch.Tensor, n: Optional[int] = None, dtype=torch.float64) -> i
 class Context:
     """CudaHandle twin: a HIP stream + scratch (source/cuda/cuda_handle.cu:17-56)."""
 
-    def __init__(self, stream: Optional[int] = None):
+    def __init__(self, stream: Optional[int] = None, own_stream: bool = False):
+        """By default the context runs on torch's current stream, so that tensor operations issued
+        through torch and the library's kernels are ordered; `own_stream` asks the library for a
+        private non-blocking stream (the caller then synchronises explicitly)."""
         self._lib = _lib.load()
         h = C.c_void_p()
-        check(self._lib.mfmg_hip_context_create(C.c_void_p(stream) if stream else None, C.byref(h)))
+        if own_stream:
+            arg = C.c_void_p(-1)
+        else:
+            if stream is None and torch.cuda.is_available():
+                stream = torch.cuda.current_stream().cuda_stream
+            arg = C.c_void_p(stream) if stream else None
+        check(self._lib.mfmg_hip_context_create(arg, C.byref(h)))
         self.handle = h
-
-    @classmethod
-    def on_current_torch_stream(cls) -> "Context":
-        return cls(torch.cuda.current_stream().cuda_stream)
 
     def synchronize(self):
         check(self._lib.mfmg_hip_context_synchronize(self.handle))

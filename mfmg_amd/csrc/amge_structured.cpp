@@ -380,11 +380,11 @@ void symmetric_eigen(int n, std::vector<double> &A, std::vector<double> &w, std:
   V.swap(Vs);
 }
 
-void dense_inverse(int n, std::vector<double> &A)
+void dense_lu_factor(int n, std::vector<double> &A, std::vector<int32_t> &perm)
 {
-  std::vector<double> inv((size_t)n * n, 0.);
-  for (int i = 0; i < n; ++i)
-    inv[(size_t)i * n + i] = 1.;
+  perm.resize(n);
+  std::iota(perm.begin(), perm.end(), 0);
+  // right-looking LU on the row-major copy
   for (int col = 0; col < n; ++col)
   {
     int piv = col;
@@ -397,33 +397,29 @@ void dense_inverse(int n, std::vector<double> &A)
       }
     ASSERT_THROW(best > 0., "singular matrix in the dense coarse solver");
     if (piv != col)
+    {
       for (int c = 0; c < n; ++c)
-      {
         std::swap(A[(size_t)piv * n + c], A[(size_t)col * n + c]);
-        std::swap(inv[(size_t)piv * n + c], inv[(size_t)col * n + c]);
-      }
-    const double d = 1. / A[(size_t)col * n + col];
-    for (int c = 0; c < n; ++c)
-    {
-      A[(size_t)col * n + c] *= d;
-      inv[(size_t)col * n + c] *= d;
+      std::swap(perm[piv], perm[col]);
     }
-#pragma omp parallel for schedule(static) if (n > 256)
-    for (int r = 0; r < n; ++r)
+    const double d = 1. / A[(size_t)col * n + col];
+#pragma omp parallel for schedule(static) if (n - col > 256)
+    for (int r = col + 1; r < n; ++r)
     {
-      if (r == col)
-        continue;
-      const double f = A[(size_t)r * n + col];
+      const double f = A[(size_t)r * n + col] * d;
+      A[(size_t)r * n + col] = f;
       if (f == 0.)
         continue;
-      for (int c = 0; c < n; ++c)
-      {
+      for (int c = col + 1; c < n; ++c)
         A[(size_t)r * n + c] -= f * A[(size_t)col * n + c];
-        inv[(size_t)r * n + c] -= f * inv[(size_t)col * n + c];
-      }
     }
   }
-  A.swap(inv);
+  // to column-major for coalesced column sweeps in the device triangular solves
+  std::vector<double> cm((size_t)n * n);
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < n; ++c)
+      cm[(size_t)c * n + r] = A[(size_t)r * n + c];
+  A.swap(cm);
 }
 
 namespace

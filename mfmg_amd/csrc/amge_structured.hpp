@@ -94,8 +94,9 @@ HostCsr galerkin_triple_product(StructuredMesh const &mesh, ConstraintSemantics 
 // symmetric dense eigen-decomposition (cyclic Jacobi), ascending eigenvalues, V column-major n x n
 void symmetric_eigen(int n, std::vector<double> &A, std::vector<double> &w, std::vector<double> &V);
 
-// dense inverse by Gauss-Jordan with partial pivoting (row-major n x n); throws if singular
-void dense_inverse(int n, std::vector<double> &A);
+// dense LU with partial pivoting (getrf): on exit `A` (row-major in) holds L\\U in COLUMN-major
+// order, `perm[i]` = source row of row i of P A; throws if a pivot is exactly zero
+void dense_lu_factor(int n, std::vector<double> &A, std::vector<int32_t> &perm);
 
 // libstdc++ std::default_random_engine + uniform_real_distribution<double>(0,1)
 struct MinstdUniform

@@ -99,7 +99,8 @@ int mfmg_hip_context_create(void *hip_stream, mfmg_hip_context_t *ctx)
     if (err != hipSuccess || n_dev == 0)
       throw DeviceExc("no HIP device available: the mfmg HIP path has no CPU fallback");
     auto c = new mfmg_hip_context_s;
-    c->handle.reset(new HipHandle(static_cast<hipStream_t>(hip_stream)));
+    const bool own = (hip_stream == MFMG_HIP_OWN_STREAM);
+    c->handle.reset(new HipHandle(own ? nullptr : static_cast<hipStream_t>(hip_stream), own));
     *ctx = c;
   });
 }
@@ -657,7 +658,7 @@ int mfmg_hip_host_build_restrictor(const mfmg_hip_mesh_desc *mesh, const char *p
     o.agglomerate[2] = params.get("agglomeration.nz", 2);
     o.n_eigenvectors = params.get("eigensolver.number of eigenvectors", 1);
     o.variant = params.get("eigensolver.variant", matrix_free ? "mf" : "device");
-    o.selection = params.get("eigensolver.selection", matrix_free ? "krylov" : "lapack");
+    o.selection = params.get("eigensolver.selection", "krylov");
     o.use_coefficient = params.get("eigensolver.use_coefficient", true);
     auto diag = operator_diagonal(sm, matrix_free ? ConstraintSemantics::matrix_free : ConstraintSemantics::assembled);
     auto h = new mfmg_hip_host_csr_s;

@@ -161,9 +161,11 @@ struct HipHandle
   DeviceBuffer<double> reduce_result;
   double *host_result = nullptr; // pinned
 
-  explicit HipHandle(hipStream_t s)
+  // `s` is borrowed (nullptr = the legacy default stream the reference runs on); with
+  // `create_own` the handle creates and owns a non-blocking stream instead.
+  explicit HipHandle(hipStream_t s, bool create_own = false)
   {
-    if (s == nullptr)
+    if (create_own)
     {
       MFMG_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
       owns_stream = true;

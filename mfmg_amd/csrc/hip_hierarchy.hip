@@ -15,22 +15,36 @@ std::string to_lower(std::string s)
   return s;
 }
 
-__global__ void dense_gemv_kernel(int n, double const *m, double const *x, double *y)
+// One workgroup, right-hand side resident in LDS: forward substitution with the unit lower factor,
+// backward substitution with U, column sweeps (coalesced in the column-major packed LU).
+__global__ void dense_lu_solve_kernel(int n, double const *lu, int32_t const *perm, double const *b, double *x)
 {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  double sum = 0.;
-  if (row < n)
+  extern __shared__ double y[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < n; i += nt)
+    y[i] = b[perm[i]];
+  __syncthreads();
+  for (int j = 0; j < n - 1; ++j)
   {
-    double const *mr = m + (size_t)row * n;
-    for (int c = lane; c < n; c += 64)
-      sum += mr[c] * x[c];
+    const double yj = y[j];
+    double const *col = lu + (size_t)j * n;
+    for (int i = j + 1 + tid; i < n; i += nt)
+      y[i] -= col[i] * yj;
+    __syncthreads();
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1)
-    sum += __shfl_xor(sum, off);
-  if (row < n && lane == 0)
-    y[row] = sum;
+  for (int j = n - 1; j >= 0; --j)
+  {
+    double const *col = lu + (size_t)j * n;
+    if (tid == 0)
+      y[j] /= col[j];
+    __syncthreads();
+    const double yj = y[j];
+    for (int i = tid; i < j; i += nt)
+      y[i] -= col[i] * yj;
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += nt)
+    x[i] = y[i];
 }
 
 std::shared_ptr<SparseMatrixDevice<double>> upload(HipHandle &handle, HostCsr &&m)
@@ -40,13 +54,20 @@ std::shared_ptr<SparseMatrixDevice<double>> upload(HipHandle &handle, HostCsr &&
 }
 } // namespace
 
-void dense_gemv(HipHandle &handle, int n, double const *matrix, double const *x, double *y)
+void dense_lu_solve(HipHandle &handle, int n, double const *lu, int32_t const *perm, double const *b, double *x)
 {
   if (n <= 0)
     return;
-  const int rows_per_block = block_size / 64;
-  hipLaunchKernelGGL(dense_gemv_kernel, dim3((n + rows_per_block - 1) / rows_per_block), dim3(block_size), 0,
-                     handle.stream, n, matrix, x, y);
+  const int threads = n >= 1024 ? 1024 : (n >= 256 ? 256 : 64);
+  static bool attr_set = false;
+  if (!attr_set)
+  {
+    MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(dense_lu_solve_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(dense_lu_solve_kernel, dim3(1), dim3(threads), (size_t)n * sizeof(double), handle.stream, n,
+                     lu, perm, b, x);
   MFMG_HIP_CHECK(hipGetLastError());
 }
 
@@ -85,7 +106,10 @@ RestrictorOptions HipMeshEvaluator::agglomerate_options(ptree const &params) con
   // AMGe_device ignores eigensolver.type: dense, unshifted, first columns
   // (include/mfmg/cuda/amge_device.templates.cuh:256-310)
   o.variant = params.get("eigensolver.variant", "device");
-  o.selection = params.get("eigensolver.selection", "lapack");
+  // "lapack" (first columns of the dense solver, what AMGe_device does) is not unique inside degenerate
+  // eigenspaces and picks unit vectors of constrained DoFs; the default here is the Krylov rule, which
+  // is basis independent and never selects them
+  o.selection = params.get("eigensolver.selection", "krylov");
   // the reference device test poses the agglomerate problems without the coefficient
   // (tests/test_hierarchy_device.cu:239-244)
   o.use_coefficient = params.get("eigensolver.use_coefficient", true);
@@ -501,7 +525,7 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
   if (_solver == "cholesky" || _solver == "lu_dense" || _solver == "lu_sparse_host")
   {
     // the three direct variants of source/cuda/cuda_solver.cu:51-72 share one dense factorisation here
-    const int64_t limit = this->_params->get("solver.dense_limit", 8192);
+    const int64_t limit = std::min(this->_params->get("solver.dense_limit", 8192), 16384);
     ASSERT_THROW(n <= limit, "The coarse problem (" + std::to_string(n) +
                                  " rows) is too large for the dense direct solver; use solver.type pcg");
     std::vector<int32_t> rp, cl;
@@ -511,8 +535,10 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
     for (int64_t r = 0; r < n; ++r)
       for (int p = rp[r]; p < rp[r + 1]; ++p)
         dense[(size_t)r * n + cl[p]] += vl[p];
-    dense_inverse((int)n, dense);
-    _dense_inverse.upload(dense.data(), dense.size(), _handle.stream);
+    std::vector<int32_t> perm;
+    dense_lu_factor((int)n, dense, perm);
+    _dense_lu.upload(dense.data(), dense.size(), _handle.stream);
+    _dense_perm.upload(perm.data(), perm.size(), _handle.stream);
   }
   else if (_solver == "pcg")
   {
@@ -566,7 +592,8 @@ void HipSolver::apply(DVector const &b, DVector &x) const
   }
   else
   {
-    dense_gemv(_handle, (int)n, _dense_inverse.data(), b.get_values(), x.get_values());
+    ASSERT_THROW(b.get_values() != x.get_values(), "the coarse solve cannot run in place");
+    dense_lu_solve(_handle, (int)n, _dense_lu.data(), _dense_perm.data(), b.get_values(), x.get_values());
   }
 }
 

@@ -87,25 +87,57 @@ __device__ __forceinline__ void load_coef<float>(void const *base, size_t block,
 // corner m = a + 2b + 4d ; quadrature point q = qa + 2qb + 4qc
 // (FEEvaluation::evaluate / submit_gradient / integrate of
 //  tests/laplace_matrix_free.hpp:145-155).
+// Every multiply-add is written as an explicit fma and implicit contraction is off, so that a
+// cell evaluates to the same bits in whichever (peeled / unrolled) copy of the loop body it is
+// computed: a halo cell of one tile is an interior cell of its neighbour.
+template <typename T>
+__device__ __forceinline__ T fmadd(T a, T b, T c)
+{
+  return __builtin_fma(a, b, c);
+}
+template <>
+__device__ __forceinline__ float fmadd<float>(float a, float b, float c)
+{
+  return __builtin_fmaf(a, b, c);
+}
+
+// out[p][.] = S[p][0] in0 + S[p][1] in1 with S = [[A, B], [B, A]]
+#define MFMG_INTERP(o0, o1, i0, i1)                                                                          \
+  T o0 = fmadd<T>(A, i0, B * (i1));                                                                          \
+  T o1 = fmadd<T>(B, i0, A * (i1));
+
+template <typename T>
+__device__ __forceinline__ void direction_apply(T d00, T d10, T d01, T d11, T c00, T c10, T c01, T c11, T f,
+                                                T &X00, T &X10, T &X01, T &X11)
+{
+#pragma clang fp contract(off)
+  const T A = T(MFMG_GA), B = T(MFMG_GB);
+  // interpolate the one-sided differences d[p][r] to the 2x2 Gauss points of the two other directions
+  MFMG_INTERP(t00, t10, d00, d10) // t[qp][r=0]
+  MFMG_INTERP(t01, t11, d01, d11) // t[qp][r=1]
+  MFMG_INTERP(g00, g01, t00, t01) // g[qp=0][qr]
+  MFMG_INTERP(g10, g11, t10, t11) // g[qp=1][qr]
+  // flux, already summed over the two Gauss points of the differentiated direction
+  const T s00 = g00 * c00, s10 = g10 * c10, s01 = g01 * c01, s11 = g11 * c11;
+  // transposed interpolation back to the corners
+  MFMG_INTERP(w00, w01, s00, s01) // w[qp=0][r]
+  MFMG_INTERP(w10, w11, s10, s11) // w[qp=1][r]
+  MFMG_INTERP(x00, x10, w00, w10) // x[p][r=0]
+  MFMG_INTERP(x01, x11, w01, w11) // x[p][r=1]
+  X00 = f * x00;
+  X10 = f * x10;
+  X01 = f * x01;
+  X11 = f * x11;
+}
+
 template <typename T>
 __device__ __forceinline__ void cell_apply(T const u[8], T const c[8], T fx, T fy, T fz, T v[8])
 {
-  const T A = T(MFMG_GA), B = T(MFMG_GB);
-  // ---- x direction: dx[b][d] = u(1,b,d) - u(0,b,d)
-  T d00 = u[1] - u[0], d10 = u[3] - u[2], d01 = u[5] - u[4], d11 = u[7] - u[6];
-  // interpolate in y -> t[qb][d], then in z -> g[qb][qc]
-  T t00 = A * d00 + B * d10, t10 = B * d00 + A * d10;
-  T t01 = A * d01 + B * d11, t11 = B * d01 + A * d11;
-  T g00 = A * t00 + B * t01, g01 = B * t00 + A * t01; // g[qb=0][qc]
-  T g10 = A * t10 + B * t11, g11 = B * t10 + A * t11; // g[qb=1][qc]
-  // flux summed over qa: s[qb][qc] = g * (c(0,qb,qc) + c(1,qb,qc))
-  T s00 = g00 * (c[0] + c[1]), s10 = g10 * (c[2] + c[3]);
-  T s01 = g01 * (c[4] + c[5]), s11 = g11 * (c[6] + c[7]);
-  // transpose interpolation z then y: X[b][d]
-  T w00 = A * s00 + B * s01, w01 = B * s00 + A * s01; // w[qb=0][d]
-  T w10 = A * s10 + B * s11, w11 = B * s10 + A * s11; // w[qb=1][d]
-  T X00 = fx * (A * w00 + B * w10), X10 = fx * (B * w00 + A * w10);
-  T X01 = fx * (A * w01 + B * w11), X11 = fx * (B * w01 + A * w11);
+#pragma clang fp contract(off)
+  T X00, X10, X01, X11;
+  // x: differences along a, (p, r) = (b, d); coefficient pairs summed over qa
+  direction_apply<T>(u[1] - u[0], u[3] - u[2], u[5] - u[4], u[7] - u[6], c[0] + c[1], c[2] + c[3], c[4] + c[5],
+                     c[6] + c[7], fx, X00, X10, X01, X11);
   v[0] = -X00;
   v[1] = X00;
   v[2] = -X10;
@@ -114,31 +146,9 @@ __device__ __forceinline__ void cell_apply(T const u[8], T const c[8], T fx, T f
   v[5] = X01;
   v[6] = -X11;
   v[7] = X11;
-  // ---- y direction: dy[a][d] = u(a,1,d) - u(a,0,d)
-  d00 = u[2] - u[0];
-  d10 = u[3] - u[1];
-  d01 = u[6] - u[4];
-  d11 = u[7] - u[5];
-  t00 = A * d00 + B * d10; // t[qa][d]
-  t10 = B * d00 + A * d10;
-  t01 = A * d01 + B * d11;
-  t11 = B * d01 + A * d11;
-  g00 = A * t00 + B * t01; // g[qa][qc]
-  g01 = B * t00 + A * t01;
-  g10 = A * t10 + B * t11;
-  g11 = B * t10 + A * t11;
-  s00 = g00 * (c[0] + c[2]); // sum over qb
-  s10 = g10 * (c[1] + c[3]);
-  s01 = g01 * (c[4] + c[6]);
-  s11 = g11 * (c[5] + c[7]);
-  w00 = A * s00 + B * s01;
-  w01 = B * s00 + A * s01;
-  w10 = A * s10 + B * s11;
-  w11 = B * s10 + A * s11;
-  X00 = fy * (A * w00 + B * w10); // Y[a][d]
-  X10 = fy * (B * w00 + A * w10);
-  X01 = fy * (A * w01 + B * w11);
-  X11 = fy * (B * w01 + A * w11);
+  // y: differences along b, (p, r) = (a, d); summed over qb
+  direction_apply<T>(u[2] - u[0], u[3] - u[1], u[6] - u[4], u[7] - u[5], c[0] + c[2], c[1] + c[3], c[4] + c[6],
+                     c[5] + c[7], fy, X00, X10, X01, X11);
   v[0] -= X00;
   v[2] += X00;
   v[1] -= X10;
@@ -147,31 +157,9 @@ __device__ __forceinline__ void cell_apply(T const u[8], T const c[8], T fx, T f
   v[6] += X01;
   v[5] -= X11;
   v[7] += X11;
-  // ---- z direction: dz[a][b] = u(a,b,1) - u(a,b,0)
-  d00 = u[4] - u[0];
-  d10 = u[5] - u[1];
-  d01 = u[6] - u[2];
-  d11 = u[7] - u[3];
-  t00 = A * d00 + B * d10; // t[qa][b]
-  t10 = B * d00 + A * d10;
-  t01 = A * d01 + B * d11;
-  t11 = B * d01 + A * d11;
-  g00 = A * t00 + B * t01; // g[qa][qb]
-  g01 = B * t00 + A * t01;
-  g10 = A * t10 + B * t11;
-  g11 = B * t10 + A * t11;
-  s00 = g00 * (c[0] + c[4]); // sum over qc
-  s10 = g10 * (c[1] + c[5]);
-  s01 = g01 * (c[2] + c[6]);
-  s11 = g11 * (c[3] + c[7]);
-  w00 = A * s00 + B * s01;
-  w01 = B * s00 + A * s01;
-  w10 = A * s10 + B * s11;
-  w11 = B * s10 + A * s11;
-  X00 = fz * (A * w00 + B * w10); // Z[a][b]
-  X10 = fz * (B * w00 + A * w10);
-  X01 = fz * (A * w01 + B * w11);
-  X11 = fz * (B * w01 + A * w11);
+  // z: differences along d, (p, r) = (a, b); summed over qc
+  direction_apply<T>(u[4] - u[0], u[5] - u[1], u[6] - u[2], u[7] - u[3], c[0] + c[4], c[1] + c[5], c[2] + c[6],
+                     c[3] + c[7], fz, X00, X10, X01, X11);
   v[0] -= X00;
   v[4] += X00;
   v[1] -= X10;
@@ -185,6 +173,7 @@ __device__ __forceinline__ void cell_apply(T const u[8], T const c[8], T fx, T f
 template <typename T>
 __global__ void mf_laplace_kernel(MfArgs<T> a)
 {
+#pragma clang fp contract(off)
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T *pt = reinterpret_cast<T *>(smem_raw); // [TY+1][blockDim.x] z-carry, thread private
   const int nt = blockDim.x;
@@ -307,10 +296,12 @@ __global__ void mf_laplace_kernel(MfArgs<T> a)
           o = ax;
         else if (a.mode == 1)
           o = ax - a.b[g];
-        else if (a.mode == 2)
-          o = x0 - a.beta * a.dinv[g] * (ax - a.b[g]);
         else
-          o = x0 + a.alpha * (x0 - a.xprev[g]) - a.beta * a.dinv[g] * (ax - a.b[g]);
+        {
+          const T w = -(a.beta * a.dinv[g]);
+          const T r = ax - a.b[g];
+          o = (a.mode == 2) ? fmadd<T>(w, r, x0) : fmadd<T>(w, r, fmadd<T>(a.alpha, x0 - a.xprev[g], x0));
+        }
         a.out[g] = o;
       }
     }

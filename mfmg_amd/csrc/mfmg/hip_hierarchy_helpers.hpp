@@ -224,9 +224,10 @@ private:
   HipHandle &_handle;
   std::string _solver;
   std::shared_ptr<HipMatrixOperator const> _matrix_operator;
-  // direct: dense inverse, factored once at setup (the reference re-factorises in every
-  // apply, source/cuda/dealii_operator_device_helpers.cu:169-228)
-  DeviceBuffer<double> _dense_inverse;
+  // direct: dense LU with partial pivoting, factored ONCE at setup (the reference re-factorises in
+  // every apply, source/cuda/dealii_operator_device_helpers.cu:169-228); apply = two triangular solves
+  DeviceBuffer<double> _dense_lu; // column-major L\\U
+  DeviceBuffer<int32_t> _dense_perm;
   // pcg
   int _n_iterations = 0;
   mutable DeviceBuffer<double> _scal;
@@ -259,6 +260,6 @@ private:
   std::shared_ptr<Operator<VectorType>> _operator;
 };
 
-// dense y = M x (row-major n x n), one wavefront per row
-void dense_gemv(HipHandle &handle, int n, double const *matrix, double const *x, double *y);
+// x = U^{-1} L^{-1} P b with the packed column-major LU of dense_lu_factor (getrs)
+void dense_lu_solve(HipHandle &handle, int n, double const *lu, int32_t const *perm, double const *b, double *x);
 } // namespace mfmg

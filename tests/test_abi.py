@@ -103,7 +103,8 @@ def test_host_restrictor_device_variant_properties(mfmg_lib):
     mesh = O.StructuredMesh((4, 4, 4))
     coef = O.coefficient_table(mesh)
     A = O.assemble_csr(mesh, coef)
-    R = M.host_build_restrictor(p, PRM, matrix_free=False)
+    prm = {"eigensolver": {"number of eigenvectors": 2, "selection": "lapack"}, "agglomeration": PRM["agglomeration"]}
+    R = M.host_build_restrictor(p, prm, matrix_free=False)
     ref = O.build_restrictor(mesh, coef, A.diagonal(), n_eig=2, variant="device", eig_mode="lapack")
     assert R.shape == ref.csr.shape == (16, 125)
     assert np.array_equal(R.indptr, ref.csr.indptr) and np.array_equal(R.indices, ref.csr.indices)
@@ -114,6 +115,21 @@ def test_host_restrictor_device_variant_properties(mfmg_lib):
         r_mine = R[2 * a].toarray().ravel()
         r_ref = ref.csr[2 * a].toarray().ravel()
         assert min(np.abs(r_mine - r_ref).max(), np.abs(r_mine + r_ref).max()) < 1e-12
+
+
+@pytest.mark.parametrize("n", [(4, 4, 4), (8, 8), (6, 5, 4)])
+def test_host_restrictor_assembled_default_matches_oracle(mfmg_lib, n):
+    """Default of the assembled evaluator: unshifted dense eigenproblem + the (unique) Krylov selection."""
+    p = M.LaplaceProblem(n, "linear")
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "linear")
+    A = O.assemble_csr(mesh, coef)
+    R = M.host_build_restrictor(p, PRM, matrix_free=False)
+    Ro = O.build_restrictor(mesh, coef, A.diagonal(), agg=(2, 2, 2)[:len(n)], n_eig=2, variant="device",
+                            eig_mode="krylov").csr
+    assert R.shape == Ro.shape and abs(R - Ro).max() < 1e-11
+    Ac = M.host_galerkin(p, R, "assembled")
+    assert abs(Ac - Ro @ A @ Ro.T).max() < 1e-11 * abs(Ac).max()
 
 
 def test_host_rejects_unstructured_index_array(mfmg_lib):

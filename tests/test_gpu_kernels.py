@@ -216,7 +216,7 @@ def test_csr_fused_modes_27pt(ctx):
     assert relerr(host(out, ctx), A @ x - b) < TOL
     Ad.smoother_step(dev(dinv), dev(b), dev(x), dev(xp), 0.25, 0.6, out)
     assert relerr(host(out, ctx), x + 0.25 * (x - xp) - 0.6 * dinv * (A @ x - b)) < TOL
-    with pytest.raises(L.MfmgInvalidArgument):
+    with pytest.raises(L.MfmgError, match="out of range"):
         M.SparseMatrixDevice(ctx, (np.array([0, 2], dtype=np.int32), np.array([0, 7], dtype=np.int32),
                                    np.array([1.0, 1.0]), (1, 3))).shape
 
