@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py -- V-cycle throughput of the MI355X-native mfmg hot path.
+
+One "step" = one `Hierarchy::apply` (V-cycle: Chebyshev(3) pre-smooth, residual, restriction,
+coarse Jacobi-PCG, prolongation, Chebyshev(3) post-smooth) on the matrix-free Q1 Laplace of a
+synthetic 3-D hyper-cube, FP64, inputs resident in HBM.  Metric (BASELINE.json): fine-DoFs/sec per
+V-cycle.  One process per GPU; rank 0 prints ONE JSON line.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=256, help="fine DoFs per direction PER GPU (Q1, n-1 cells)")
+    ap.add_argument("--degree", type=int, default=3, help="Chebyshev degree of the smoother")
+    ap.add_argument("--coarse-iters", type=int, default=10, help="Jacobi-PCG steps of the coarse 'solve'")
+    ap.add_argument("--material", default="constant")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cycles", type=int, default=2, help="timed V-cycles of the CPU baseline sample")
+    ap.add_argument("--no-smoother-512", action="store_true",
+                    help="skip the extra fine-level smoother measurement at 512^3 (north_star target config)")
+    ap.add_argument("--tile", type=str, default="", help="ty,tz override of the operator tile")
+    return ap.parse_args()
+
+
+def smoother_coefficients(degree, lmin, lmax):
+    """(alpha_k, beta_k) of the three-term Chebyshev recurrence (deal.II PreconditionChebyshev)."""
+    theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+    out = [(0.0, 1.0 / theta)]
+    if degree >= 2 and abs(delta) >= 1e-40:
+        rhok, sigma = delta / theta, theta / delta
+        for _ in range(degree - 1):
+            rhokp = 1.0 / (2.0 * sigma - rhok)
+            out.append((rhokp * rhok, 2.0 * rhokp / delta))
+            rhok = rhokp
+    return out
+
+
+def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=5, tile=None):
+    """Fine-level smoother apply (degree fused operator kernels) on its own: ms per apply from HIP
+    events on the kernels' stream, algorithmic GB/s."""
+    prob = M.LaplaceProblem((n_dofs_per_dim - 1,) * 3, "constant", device="cuda")
+    op = M.MatrixFreeLaplace(ctx, prob)
+    if tile:
+        op.set_tile(*tile)
+    N = prob.n_dofs
+    del prob
+    torch.cuda.empty_cache()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand(N, dtype=torch.float64, device="cuda", generator=g)
+    b = torch.zeros(N, dtype=torch.float64, device="cuda")
+    s1, s2 = torch.empty_like(x), torch.empty_like(x)
+    coefs = smoother_coefficients(degree, 0.09, 1.8)
+
+    def apply():
+        # x_{k+1} targets alternate so that the last term lands in x (HipSmoother::apply)
+        bufs = [s1, s2]
+        cur, prev = x, None
+        for k, (al, be) in enumerate(coefs):
+            tgt = x if k == len(coefs) - 1 and len(coefs) > 1 else bufs[(len(coefs) - 2 - k) % 2]
+            op.smoother_step(b, cur, prev, al, be, tgt)
+            prev, cur = cur, tgt
+
+    apply()
+    ctx.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        apply()
+    ev1.record()
+    ev1.synchronize()
+    ms = ev0.elapsed_time(ev1) / reps
+    # exact algorithmic bytes per DoF: operator 112 (x, out, 8 idx, 8 coef) + b + D^-1 (+ x_prev from the
+    # second term on); A x is never stored
+    bytes_per_dof = (112 + 16) + (len(coefs) - 1) * (112 + 24)
+    gbs = N * bytes_per_dof / (ms * 1e-3) / 1e9
+    return {"n_dofs": N, "degree": degree, "ms_per_apply": ms, "algorithmic_bytes_per_dof": bytes_per_dof,
+            "achieved_GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS}
+
+
+def cpu_baseline(args, M, h, prob, lmin, lmax, torch):
+    """The oracle's C++/OpenMP restatement ("port") of the same V-cycle on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle_native as ON
+
+    n = prob.n
+    cd = prob.cell_dofs.cpu().numpy()
+    co = prob.coefficient.cpu().numpy()
+    cn = prob.constrained.cpu().numpy()
+    R = h.restrictor().to_scipy()
+    Ac = h.coarse_operator().to_scipy()
+    # D^-1 of the matrix-free operator (constrained entries one), from the product's operator
+    op = M.MatrixFreeLaplace(h.ctx, prob)
+    dinv = op.diagonal_inverse().cpu().numpy()
+    del op
+    rng = np.random.default_rng(0)
+    x0 = np.where(cn.astype(bool), 0.0, rng.random(prob.n_dofs))
+    b = np.zeros(prob.n_dofs)
+    cores = ON.effective_cpu_count()
+    ON.set_num_threads(cores)
+    x, _ = ON.vcycles(n, prob.h, cd, co, cn, dinv, args.degree, lmin, lmax, R, Ac, args.coarse_iters, b, x0, 1,
+                      want_history=False)
+    t0 = time.perf_counter()
+    ON.vcycles(n, prob.h, cd, co, cn, dinv, args.degree, lmin, lmax, R, Ac, args.coarse_iters, b, x, args.cpu_cycles,
+               want_history=False)
+    dt = (time.perf_counter() - t0) / args.cpu_cycles
+    return {"value": prob.n_dofs / dt, "unit": "DoF/s", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_cycles} V-cycles (after 1 warm-up) of the same {prob.N[0]}^3-DoF workload, "
+                      f"oracle/oracle_kernels.cpp with OpenMP on {cores} host threads",
+            "ms_per_step": dt * 1e3}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import mfmg_amd as M
+
+    ctx = M.Context()
+    n = args.n
+    t_setup = time.perf_counter()
+    prob = M.LaplaceProblem((n - 1,) * 3, args.material, device="cuda")
+    params = {
+        "eigensolver": {"number of eigenvectors": 2},
+        "agglomeration": {"partitioner": "block", "nx": 2, "ny": 2, "nz": 2},
+        "smoother": {"type": "Chebyshev", "degree": args.degree, "smoothing_range": 20.0, "n_smoothing_steps": 1},
+        "solver": {"type": "pcg", "n_iterations": args.coarse_iters},
+        "is preconditioner": False,
+        "max levels": 2,
+    }
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    ctx.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    degree, lmin, lmax = h.smoother_info()
+    n_fine, n_coarse = h.level_size(0), h.level_size(1)
+
+    g = torch.Generator(device="cuda").manual_seed(1 + rank)
+    x = torch.rand(n_fine, dtype=torch.float64, device="cuda", generator=g)
+    x *= (prob.constrained == 0).to(torch.float64)
+    b = torch.zeros(n_fine, dtype=torch.float64, device="cuda")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        h.apply(b, x)
+    ctx.profile_enable(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h.apply(b, x)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    launches, k_ms, k_bytes = ctx.profile_query("mf_laplace_kernel")
+    c_launches, c_ms, c_bytes = ctx.profile_query("csr_spmv_kernel")
+    ctx.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * n_fine / (dt / args.steps)
+
+    if rank == 0:
+        achieved = (k_bytes / launches) / (k_ms / launches * 1e-3) / 1e9 if launches else 0.0
+        out = {
+            "metric": "fine-DoFs/sec per V-cycle (3D Laplace)",
+            "value": value,
+            "unit": "DoF/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"3D Laplace on the unit cube, Q1 matrix-free, {n}^3 DoFs per GPU "
+                            f"(BASELINE.json configs[3] = 512^3 on 8 GPUs is this workload at N=8), two-level "
+                            f"spectral AMGe (2x2x2 agglomerates, 2 eigenvectors), Chebyshev({degree}) smoother, "
+                            f"coarse {n_coarse} DoFs: {args.coarse_iters} Jacobi-PCG steps, FP64",
+                "fine_dofs_per_gpu": n_fine,
+                "coarse_dofs_per_gpu": n_coarse,
+                "smoother": {"type": "Chebyshev", "degree": degree, "lambda_min": lmin, "lambda_max": lmax},
+                "parallelism": "1 GPU" if world == 1 else f"{world} replicas (domain decomposition pending)",
+                "setup_seconds": t_setup,
+            },
+            "roofline": {
+                "kernel": "mf_laplace_kernel (fused matrix-free operator + smoother/residual epilogue)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "launches_in_timed_region": launches,
+                "avg_launch_ms": k_ms / launches if launches else None,
+                "algorithmic_bytes_per_launch": k_bytes / launches if launches else None,
+                "share_of_step_time": k_ms / (ms_per_step * args.steps) if launches else None,
+            },
+            "other_kernels": {
+                "csr_spmv_kernel": {"launches": c_launches, "total_ms": c_ms,
+                                    "achieved_GBs": (c_bytes / (c_ms * 1e-3) / 1e9) if c_ms else None,
+                                    "share_of_step_time": c_ms / (ms_per_step * args.steps) if c_ms else None},
+            },
+        }
+        tile = tuple(int(v) for v in args.tile.split(",")) if args.tile else None
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, M, h, prob, lmin, lmax, torch)
+        if world == 1 and not args.no_smoother_512:
+            del h, x, b
+            torch.cuda.empty_cache()
+            try:
+                out["smoother_apply_512cubed"] = measure_smoother(ctx, torch, M, 512, args.degree, tile=tile)
+            except Exception as e:  # noqa: BLE001 - report, do not hide the main result
+                out["smoother_apply_512cubed"] = {"error": str(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -60,6 +60,13 @@ int mfmg_hip_context_destroy(mfmg_hip_context_t ctx);
 int mfmg_hip_context_synchronize(mfmg_hip_context_t ctx);
 void *mfmg_hip_context_stream(mfmg_hip_context_t ctx);
 
+/* Per-kernel timing with HIP events recorded on the launch stream (the reference only has the
+ * wall-clock dealii::TimerOutput sections, include/mfmg/common/hierarchy.hpp:36-47).  Kernel names:
+ * "mf_laplace_kernel", "csr_spmv_kernel".  `algorithmic_bytes` sums SURVEY.md 8d's per-launch figures. */
+int mfmg_hip_profile_enable(mfmg_hip_context_t ctx, int enabled);
+int mfmg_hip_profile_query(mfmg_hip_context_t ctx, const char *kernel_name, int64_t *n_launches, double *total_ms,
+                           double *algorithmic_bytes);
+
 /* ---- host<->device marshalling (source/cuda/utils.cu:484-510, include/mfmg/cuda/utils.cuh:66-99) ---- */
 int mfmg_hip_malloc(void **dev_ptr, size_t bytes);                      /* cuda_malloc */
 int mfmg_hip_free(void *dev_ptr);                                       /* cuda_free */

@@ -74,6 +74,15 @@ class Context:
     def torch_stream(self) -> "torch.cuda.ExternalStream":
         return torch.cuda.ExternalStream(self.stream)
 
+    def profile_enable(self, enabled: bool = True):
+        check(self._lib.mfmg_hip_profile_enable(self.handle, 1 if enabled else 0))
+
+    def profile_query(self, kernel: str):
+        """(launches, total milliseconds, summed algorithmic bytes) of one kernel since profile_enable."""
+        n, ms, by = C.c_int64(), C.c_double(), C.c_double()
+        check(self._lib.mfmg_hip_profile_query(self.handle, kernel.encode(), C.byref(n), C.byref(ms), C.byref(by)))
+        return n.value, ms.value, by.value
+
     def dot(self, x: torch.Tensor, y: torch.Tensor) -> float:
         r = C.c_double()
         check(self._lib.mfmg_hip_vector_dot(self.handle, x.numel(), _dev_ptr(x), _dev_ptr(y), C.byref(r)))

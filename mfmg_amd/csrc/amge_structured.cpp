@@ -3,8 +3,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <fstream>
 #include <map>
+#include <mutex>
 #include <numeric>
+#include <sched.h>
+#include <thread>
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -17,6 +21,43 @@ namespace
 constexpr double kG0 = 0.21132486540518711775; // (1 - 1/sqrt(3))/2
 constexpr double kG1 = 0.78867513459481288225;
 } // namespace
+
+int effective_cpu_count()
+{
+  int n = (int)std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0)
+    n = CPU_COUNT(&set);
+  // cgroup v2: "<quota> <period>" or "max <period>"
+  std::ifstream f("/sys/fs/cgroup/cpu.max");
+  std::string quota;
+  double period = 0.;
+  if (f && (f >> quota >> period) && quota != "max" && period > 0.)
+  {
+    const int q = (int)std::ceil(std::stod(quota) / period);
+    if (q >= 1)
+      n = std::min(n, q);
+  }
+  else
+  {
+    std::ifstream fq("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), fp("/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+    double q = -1., p = 0.;
+    if (fq && fp && (fq >> q) && (fp >> p) && q > 0. && p > 0.)
+      n = std::min(n, (int)std::ceil(q / p));
+  }
+  return std::max(n, 1);
+}
+
+void configure_host_threads()
+{
+  static std::once_flag once;
+  std::call_once(once, [] {
+#ifdef _OPENMP
+    if (std::getenv("OMP_NUM_THREADS") == nullptr)
+      omp_set_num_threads(effective_cpu_count());
+#endif
+  });
+}
 
 double MinstdUniform::next()
 {
@@ -169,6 +210,7 @@ void operator_row(StructuredMesh const &mesh, std::vector<double> const &Kq, Con
   cols.clear();
   vals.clear();
   const int nc = mesh.nc();
+  const int dim = mesh.dim;
   const int32_t g = mesh.node_dof[mesh.node_index(i, j, k)];
   const bool con = mesh.constrained[g];
   if (con && sem == ConstraintSemantics::matrix_free)
@@ -177,48 +219,47 @@ void operator_row(StructuredMesh const &mesh, std::vector<double> const &Kq, Con
     vals.push_back(1.);
     return;
   }
-  const int kd = (mesh.dim == 3) ? 2 : 1;
-  double diag = 0.;
+  // contributions are gathered in a 3^dim stencil indexed by the offset of the neighbouring node
+  double st[27];
+  const int ns = (dim == 3) ? 27 : 9;
+  for (int t = 0; t < ns; ++t)
+    st[t] = 0.;
   for (int m = 0; m < nc; ++m)
   {
-    const int ci = i - (m & 1), cj = j - ((m >> 1) & 1), ck = (mesh.dim == 3) ? k - ((m >> 2) & 1) : 0;
-    if (ci < 0 || cj < 0 || ck < 0 || ci >= mesh.n[0] || cj >= mesh.n[1] || (mesh.dim == 3 && ck >= mesh.n[2]))
+    const int a = m & 1, b = (m >> 1) & 1, d = (m >> 2) & 1;
+    const int ci = i - a, cj = j - b, ck = (dim == 3) ? k - d : 0;
+    if (ci < 0 || cj < 0 || ck < 0 || ci >= mesh.n[0] || cj >= mesh.n[1] || (dim == 3 && ck >= mesh.n[2]))
       continue;
-    (void)kd;
     const int64_t c = mesh.cell_index(ci, cj, ck);
     double const *coef = &mesh.coefficient[c * nc];
-    int32_t const *cd = &mesh.cell_dofs[c * nc];
     for (int mp = 0; mp < nc; ++mp)
     {
+      if (con && mp != m)
+        continue;
+      double const *kq = &Kq[(size_t)m * nc + mp];
       double v = 0.;
       for (int q = 0; q < nc; ++q)
-        v += coef[q] * Kq[((size_t)q * nc + m) * nc + mp];
-      if (con)
-      {
-        if (mp == m)
-          diag += v;
-        continue;
-      }
-      const int32_t gp = cd[mp];
-      if (mesh.constrained[gp])
-        continue;
-      size_t t = 0;
-      for (; t < cols.size(); ++t)
-        if (cols[t] == gp)
-          break;
-      if (t == cols.size())
-      {
-        cols.push_back(gp);
-        vals.push_back(v);
-      }
-      else
-        vals[t] += v;
+        v += coef[q] * kq[(size_t)q * nc * nc];
+      const int da = (mp & 1) - a + 1, db = ((mp >> 1) & 1) - b + 1, dd = (dim == 3) ? ((mp >> 2) & 1) - d + 1 : 0;
+      st[da + 3 * db + 9 * dd] += v;
     }
   }
   if (con)
   {
     cols.push_back(g);
-    vals.push_back(diag);
+    vals.push_back(st[(dim == 3) ? 13 : 4]);
+    return;
+  }
+  for (int t = 0; t < ns; ++t)
+  {
+    const int ni = i + (t % 3) - 1, nj = j + ((t / 3) % 3) - 1, nk = (dim == 3) ? k + (t / 9) - 1 : 0;
+    if (ni < 0 || nj < 0 || nk < 0 || ni >= mesh.N[0] || nj >= mesh.N[1] || (dim == 3 && nk >= mesh.N[2]))
+      continue;
+    const int32_t gp = mesh.node_dof[mesh.node_index(ni, nj, nk)];
+    if (mesh.constrained[gp])
+      continue;
+    cols.push_back(gp);
+    vals.push_back(st[t]);
   }
 }
 
@@ -241,6 +282,7 @@ inline void node_ijk(StructuredMesh const &mesh, int64_t nd, int &i, int &j, int
 
 HostCsr assemble_global_matrix(StructuredMesh const &mesh, ConstraintSemantics sem)
 {
+  configure_host_threads();
   const auto Kq = reference_cell_tables(mesh.dim, mesh.h);
   const auto dn = dof_to_node(mesh);
   HostCsr A;
@@ -463,14 +505,15 @@ HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<doub
   std::vector<std::vector<int32_t>> dofs_of(n_agg);
   // identical agglomerates (same shape, constraints and local matrix) share one eigen-solve;
   // the table is capped so that a spatially varying coefficient cannot blow up host memory
-  std::map<AggKey, std::shared_ptr<AggResult const>> memo; // guarded by a critical section
-  constexpr size_t kMemoCap = 4096;
+  // (one table per thread: no lock on the hot path; at most threads x classes eigen-solves)
+  constexpr size_t kMemoCap = 1024;
+  configure_host_threads();
 
 #pragma omp parallel
   {
     std::vector<double> A, M, w, V, v0, proj;
     std::vector<char> lcon;
-    std::vector<int> lnode_perm;
+    std::map<AggKey, std::shared_ptr<AggResult const>> memo; // thread private
 #pragma omp for schedule(dynamic, 64)
     for (int64_t a = 0; a < n_agg; ++a)
     {
@@ -528,7 +571,6 @@ HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<doub
       std::memcpy(key.bytes.data() + 3 * sizeof(int), lcon.data(), nloc);
       std::memcpy(key.bytes.data() + 3 * sizeof(int) + nloc, A.data(), A.size() * sizeof(double));
       std::shared_ptr<AggResult const> found;
-#pragma omp critical(mfmg_amge_memo)
       {
         auto it = memo.find(key);
         if (it != memo.end())
@@ -661,11 +703,8 @@ HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<doub
           for (int l = 0; l < nloc; ++l)
             res.weights[(size_t)e * nloc + l] = diag_loc[l] * sel[e][l];
         found = std::make_shared<AggResult const>(std::move(res));
-#pragma omp critical(mfmg_amge_memo)
-        {
-          if (memo.size() < kMemoCap)
-            memo.emplace(std::move(key), found);
-        }
+        if (memo.size() < kMemoCap)
+          memo.emplace(std::move(key), found);
       }
       result_of[a] = found;
     }
@@ -720,6 +759,7 @@ HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<doub
 HostCsr galerkin_triple_product(StructuredMesh const &mesh, ConstraintSemantics sem, HostCsr const &R,
                                 HostCsr const &Rt)
 {
+  configure_host_threads();
   ASSERT_THROW(R.n_cols == mesh.n_dofs && Rt.n_rows == mesh.n_dofs && Rt.n_cols == R.n_rows,
                "restrictor shape does not match the mesh");
   const auto Kq = reference_cell_tables(mesh.dim, mesh.h);
@@ -736,7 +776,7 @@ HostCsr galerkin_triple_product(StructuredMesh const &mesh, ConstraintSemantics 
     std::vector<char> cmark(nc_rows, 0);
     std::vector<int32_t> ctouched;
     // tiny direct-mapped cache of operator rows (the eigenvectors of one agglomerate share them)
-    constexpr int kCache = 128;
+    constexpr int kCache = 256; // keyed by the position inside the restrictor row
     std::vector<int32_t> cache_g(kCache, -1);
     std::vector<std::vector<int32_t>> cache_cols(kCache);
     std::vector<std::vector<double>> cache_vals(kCache);
@@ -750,7 +790,7 @@ HostCsr galerkin_triple_product(StructuredMesh const &mesh, ConstraintSemantics 
         const double wgt = R.val[p];
         if (wgt == 0.)
           continue;
-        const int slot = g % kCache;
+        const int slot = (p - R.row_ptr[r]) % kCache;
         if (cache_g[slot] != g)
         {
           int i, j, k;

@@ -98,6 +98,11 @@ void symmetric_eigen(int n, std::vector<double> &A, std::vector<double> &w, std:
 // order, `perm[i]` = source row of row i of P A; throws if a pivot is exactly zero
 void dense_lu_factor(int n, std::vector<double> &A, std::vector<int32_t> &perm);
 
+// Host threads the setup may use: min(affinity mask, cgroup cpu.max quota); applied to OpenMP once
+// (an over-subscribed quota-limited container is what makes a 256-thread default pathological).
+int effective_cpu_count();
+void configure_host_threads();
+
 // libstdc++ std::default_random_engine + uniform_real_distribution<double>(0,1)
 struct MinstdUniform
 {

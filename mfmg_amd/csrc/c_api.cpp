@@ -120,6 +120,33 @@ int mfmg_hip_context_synchronize(mfmg_hip_context_t ctx)
 
 void *mfmg_hip_context_stream(mfmg_hip_context_t ctx) { return ctx ? ctx->handle->stream : nullptr; }
 
+// ---- per-kernel HIP-event timing (bench.py roofline leg) ---------------------------
+int mfmg_hip_profile_enable(mfmg_hip_context_t ctx, int enabled)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    ctx->handle->profiler.enabled = enabled != 0;
+    ctx->handle->profiler.reset();
+  });
+}
+
+int mfmg_hip_profile_query(mfmg_hip_context_t ctx, const char *kernel_name, int64_t *n_launches, double *total_ms,
+                           double *algorithmic_bytes)
+{
+  return guarded([&] {
+    require(ctx && kernel_name, "null argument");
+    int64_t n = 0;
+    double ms = 0., bytes = 0.;
+    ctx->handle->profiler.query(kernel_name, n, ms, bytes);
+    if (n_launches)
+      *n_launches = n;
+    if (total_ms)
+      *total_ms = ms;
+    if (algorithmic_bytes)
+      *algorithmic_bytes = bytes;
+  });
+}
+
 // ---- marshalling ---------------------------------------------------------------
 int mfmg_hip_malloc(void **dev_ptr, size_t bytes)
 {

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -150,6 +151,80 @@ private:
   size_t _n = 0;
 };
 
+// ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) ----
+// Off by default; when enabled every instrumented launch is bracketed by an event pair.
+struct KernelProfiler
+{
+  struct Entry
+  {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t used = 0;
+    double algorithmic_bytes = 0.;
+  };
+  bool enabled = false;
+  std::map<std::string, Entry> entries;
+
+  ~KernelProfiler()
+  {
+    for (auto &kv : entries)
+      for (auto &ev : kv.second.events)
+      {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+      }
+  }
+  void reset()
+  {
+    for (auto &kv : entries)
+    {
+      kv.second.used = 0;
+      kv.second.algorithmic_bytes = 0.;
+    }
+  }
+  // returns the stop event to record after the launch (nullptr when disabled)
+  hipEvent_t begin(char const *name, double bytes, hipStream_t stream)
+  {
+    if (!enabled)
+      return nullptr;
+    Entry &e = entries[name];
+    if (e.used == e.events.size())
+    {
+      hipEvent_t a, b;
+      MFMG_HIP_CHECK(hipEventCreate(&a));
+      MFMG_HIP_CHECK(hipEventCreate(&b));
+      e.events.emplace_back(a, b);
+    }
+    auto &ev = e.events[e.used++];
+    e.algorithmic_bytes += bytes;
+    MFMG_HIP_CHECK(hipEventRecord(ev.first, stream));
+    return ev.second;
+  }
+  static void end(hipEvent_t stop, hipStream_t stream)
+  {
+    if (stop)
+      MFMG_HIP_CHECK(hipEventRecord(stop, stream));
+  }
+  // synchronises; total milliseconds and launches of one kernel since the last reset
+  void query(std::string const &name, int64_t &launches, double &total_ms, double &bytes)
+  {
+    launches = 0;
+    total_ms = 0.;
+    bytes = 0.;
+    auto it = entries.find(name);
+    if (it == entries.end())
+      return;
+    for (size_t i = 0; i < it->second.used; ++i)
+    {
+      MFMG_HIP_CHECK(hipEventSynchronize(it->second.events[i].second));
+      float ms = 0.f;
+      MFMG_HIP_CHECK(hipEventElapsedTime(&ms, it->second.events[i].first, it->second.events[i].second));
+      total_ms += ms;
+    }
+    launches = (int64_t)it->second.used;
+    bytes = it->second.algorithmic_bytes;
+  }
+};
+
 // ---- HipHandle: stream + reduction scratch; twin of CudaHandle
 //      (include/mfmg/cuda/cuda_handle.cuh:25-48): borrowed by every object built from it ----
 struct HipHandle
@@ -160,6 +235,7 @@ struct HipHandle
   DeviceBuffer<double> reduce_partials;
   DeviceBuffer<double> reduce_result;
   double *host_result = nullptr; // pinned
+  KernelProfiler profiler;
 
   // `s` is borrowed (nullptr = the legacy default stream the reference runs on); with
   // `create_own` the handle creates and owns a non-blocking stream instead.

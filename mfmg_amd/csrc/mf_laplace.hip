@@ -621,7 +621,12 @@ void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T c
     attr_set = true;
   }
   dim3 grid((_N[1] + ty - 1) / ty, (_N[2] + tz - 1) / tz);
+  // algorithmic bytes per launch: x + out + 8 idx + 8 coef, plus b / D^-1 / x_prev reads
+  const double extra = (mode == MfMode::apply) ? 0. : (mode == MfMode::residual) ? 1. : (mode == MfMode::first) ? 2. : 3.;
+  hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel", algorithmic_bytes_apply() + extra * sizeof(T) * double(_n_dofs),
+                                           _handle.stream);
   hipLaunchKernelGGL(mf_laplace_kernel<T>, grid, dim3(_nxp), lds, _handle.stream, a);
+  KernelProfiler::end(stop, _handle.stream);
   MFMG_HIP_CHECK(hipGetLastError());
 }
 

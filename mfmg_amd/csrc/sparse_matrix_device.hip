@@ -8,6 +8,7 @@
 // partial sums are combined with an xor-butterfly of __shfl_xor, so the summation
 // order is fixed and the result is bit-reproducible.
 #include "sparse_matrix_device.hpp"
+#include "amge_structured.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -161,6 +162,9 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
   a.beta = beta;
   a.mode = static_cast<int>(mode);
   hipStream_t st = _handle.stream;
+  const double extra = (mode == CsrMode::apply) ? 0. : (mode == CsrMode::first) ? 3. : (mode == CsrMode::next) ? 4. : 1.;
+  hipEvent_t stop =
+      _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes_apply() + extra * sizeof(T) * double(_n_rows), st);
   switch (_lanes_per_row)
   {
   case 1:
@@ -185,6 +189,7 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
     launch_lpr<T, 64>(a, st);
     break;
   }
+  KernelProfiler::end(stop, st);
   MFMG_HIP_CHECK(hipGetLastError());
 }
 
@@ -241,6 +246,7 @@ void csr_multiply_host(int64_t a_rows, int64_t a_cols, std::vector<int32_t> cons
                        std::vector<T> &c_val)
 {
   (void)a_cols;
+  configure_host_threads();
   c_ptr.assign(a_rows + 1, 0);
   std::vector<std::vector<int32_t>> row_cols(a_rows);
   std::vector<std::vector<T>> row_vals(a_rows);

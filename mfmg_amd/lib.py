@@ -82,6 +82,8 @@ def load() -> C.CDLL:
         "mfmg_hip_context_destroy": (C.c_int, [vp]),
         "mfmg_hip_context_synchronize": (C.c_int, [vp]),
         "mfmg_hip_context_stream": (vp, [vp]),
+        "mfmg_hip_profile_enable": (C.c_int, [vp, C.c_int]),
+        "mfmg_hip_profile_query": (C.c_int, [vp, C.c_char_p, P(i64), P(dbl), P(dbl)]),
         "mfmg_hip_malloc": (C.c_int, [P(vp), sz]),
         "mfmg_hip_free": (C.c_int, [vp]),
         "mfmg_hip_copy_to_dev": (C.c_int, [vp, vp, sz]),
