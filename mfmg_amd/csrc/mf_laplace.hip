@@ -1,24 +1,27 @@
 // gfx950 kernels of the matrix-free Q1 Laplace operator.
 //
-// Data layout in HBM ("one cell slot per DoF"): the DoF grid is Nx x Ny x Nz;
-// slot (i,j,k) holds the cell whose lowest corner is DoF (i,j,k) (a phantom cell
-// with zero coefficient on the three high faces).  Slots are blocked by 64 along
-// x so that one wavefront reads, per cell row, one contiguous 2 KiB run of DoF
-// indices and one contiguous 4 KiB (FP64) run of coefficients with 16-byte loads:
-//   idx  int4  [(block*2 + half)*64 + lane]
-//   coef 16 B  [(block*NP + p)*64 + lane]
-// The indices are the caller's global DoF ids (any numbering); bit 31 carries the
-// Dirichlet flag, so the constrained-read-as-zero rule costs no extra load.
+// Data layout in HBM ("one cell slot per DoF", row-major slot = i + Nx (j + Ny k)): slot
+// (i,j,k) holds the cell whose lowest corner is DoF (i,j,k); cells that stick out of the mesh
+// on a high face are phantoms with zero coefficient.  Per slot, as planes of 16-byte vectors so
+// that a wavefront reads 1 KiB contiguous per load instruction from any starting column:
+//   fb0  int4 [slot]      DoF ids of the b=0 face: corners (0,0,0) (1,0,0) (0,0,1) (1,0,1)
+//   fb1  int4 [slot]      DoF ids of the b=1 face: corners (0,1,0) (1,1,0) (0,1,1) (1,1,1)
+//   coef 16 B [p][slot]   the 8 quadrature coefficients, p = 0..NP-1
+// The ids are the caller's global DoF ids (any numbering); bit 31 carries the Dirichlet flag,
+// so the constrained-read-as-zero rule costs no extra load.
 //
-// Work decomposition (owner computes, no atomics, bit-reproducible): a workgroup
-// spans complete x-rows (thread t <-> column i = t), owns TY DoF rows x TZ DoF
-// planes and marches over the (TY+1) x (TZ+1) cell rows that touch them.  The 8
-// corner contributions of a cell are combined
-//   in x : wave shift of the right-face values (LDS hand-off at wave seams),
+// Work decomposition (owner computes, no atomics, no inter-wave synchronisation, results
+// independent of the tiling bit for bit): ONE WAVEFRONT per workgroup marches over a tile of
+// 64 cell columns x (TY+1) cell rows x (TZ+1) cell layers and owns the 63 x TY x TZ DoFs whose
+// eight cells all lie inside (one halo column / row / layer on the low side is recomputed).
+// The 8 corner contributions of a cell are combined
+//   in x : shift by one lane of the right-face values,
 //   in y : a register carried from the previous cell row,
-//   in z : a per-thread column in LDS carried from the previous cell layer,
-// so every DoF value is complete exactly when its own slot is visited and the
-// smoother epilogue (b, D^-1, x_prev) is fused there: A x is never stored.
+//   in z : a per-lane column in LDS carried from the previous cell layer,
+// so every DoF value is complete exactly when its own slot is visited and the smoother
+// epilogue (b, D^-1, x_prev) is fused there: A x is never stored.  The b=0 face of a cell is
+// the b=1 face of the previous row: its ids and x values are carried in registers, so the
+// steady state loads one id vector and gathers four x values per cell.
 #include "mf_laplace.hpp"
 
 #include <algorithm>
@@ -33,15 +36,16 @@ constexpr unsigned int kFlag = 0x80000000u;
 template <typename T>
 struct MfArgs
 {
-  int4 const *idx;
+  int4 const *fb0;
+  int4 const *fb1;
   void const *coef;
+  size_t n_slots;
   T const *x;
   T const *b;
   T const *dinv;
   T const *xprev;
   T *out;
   int Nx, Ny, Nz;
-  int nxb;
   int TY, TZ;
   T fx, fy, fz;
   T alpha, beta;
@@ -53,29 +57,29 @@ struct MfArgs
 #define MFMG_GB 0.21132486540518711775 // g0
 
 template <typename T>
-__device__ __forceinline__ void load_coef(void const *base, size_t block, int lane, T c[8]);
+__device__ __forceinline__ void load_coef(void const *base, size_t n_slots, size_t slot, T c[8]);
 
 template <>
-__device__ __forceinline__ void load_coef<double>(void const *base, size_t block, int lane, double c[8])
+__device__ __forceinline__ void load_coef<double>(void const *base, size_t n_slots, size_t slot, double c[8])
 {
-  double2 const *p = reinterpret_cast<double2 const *>(base) + (block * 4) * 64 + lane;
+  double2 const *p = reinterpret_cast<double2 const *>(base) + slot;
 #pragma unroll
   for (int q = 0; q < 4; ++q)
   {
-    double2 v = p[q * 64];
+    double2 v = p[q * n_slots];
     c[2 * q] = v.x;
     c[2 * q + 1] = v.y;
   }
 }
 
 template <>
-__device__ __forceinline__ void load_coef<float>(void const *base, size_t block, int lane, float c[8])
+__device__ __forceinline__ void load_coef<float>(void const *base, size_t n_slots, size_t slot, float c[8])
 {
-  float4 const *p = reinterpret_cast<float4 const *>(base) + (block * 2) * 64 + lane;
+  float4 const *p = reinterpret_cast<float4 const *>(base) + slot;
 #pragma unroll
   for (int q = 0; q < 2; ++q)
   {
-    float4 v = p[q * 64];
+    float4 v = p[q * n_slots];
     c[4 * q] = v.x;
     c[4 * q + 1] = v.y;
     c[4 * q + 2] = v.z;
@@ -171,22 +175,18 @@ __device__ __forceinline__ void cell_apply(T const u[8], T const c[8], T fx, T f
 }
 
 template <typename T>
-__global__ void mf_laplace_kernel(MfArgs<T> a)
+__global__ __launch_bounds__(64) void mf_laplace_kernel(MfArgs<T> a)
 {
 #pragma clang fp contract(off)
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  T *pt = reinterpret_cast<T *>(smem_raw); // [TY+1][blockDim.x] z-carry, thread private
-  const int nt = blockDim.x;
-  const int nw = nt >> 6;
-  T *edge = pt + (size_t)(a.TY + 1) * nt; // [2][nw][4] wave-seam hand-off
+  T *pt = reinterpret_cast<T *>(smem_raw); // [TY+1][64] z-carry, lane private
 
-  const int i = threadIdx.x;
-  const int lane = i & 63;
-  const int wave = i >> 6;
-  const int Y0 = blockIdx.x * a.TY;
-  const int Z0 = blockIdx.y * a.TZ;
-  const bool col_ok = i < a.Nx;
-  int parity = 0;
+  const int lane = threadIdx.x;
+  const int ci = (int)blockIdx.x * 63 - 1 + lane; // cell / DoF column of this lane
+  const int Y0 = blockIdx.y * a.TY;
+  const int Z0 = blockIdx.z * a.TZ;
+  const bool col_ok = ci >= 0 && ci < a.Nx;
+  const bool col_owned = lane >= 1 && ci < a.Nx;
 
   for (int kk = 0; kk <= a.TZ; ++kk)
   {
@@ -194,103 +194,96 @@ __global__ void mf_laplace_kernel(MfArgs<T> a)
     if (k >= a.Nz)
       break;
     T ry0 = T(0), ry1 = T(0);
+    // b=0 face carried from the previous cell row: raw x values, ids (flag in bit 31)
+    T cx[4] = {T(0), T(0), T(0), T(0)};
+    int cid[4] = {0, 0, 0, 0};
+    bool carried = false;
     for (int jj = 0; jj <= a.TY; ++jj)
     {
       const int j = Y0 - 1 + jj;
       if (j >= a.Ny)
         break;
       const bool slot = col_ok && j >= 0 && k >= 0;
-      const bool cell = slot && (i < a.Nx - 1) && (j < a.Ny - 1) && (k < a.Nz - 1);
-
-      int id[8];
-      T c[8], u[8], v[8];
+      const bool cell = slot && (ci < a.Nx - 1) && (j < a.Ny - 1) && (k < a.Nz - 1);
+      T v[8];
       T x0 = T(0);
+      int id0 = 0;
       if (slot)
       {
-        const size_t blk = ((size_t)k * a.Ny + j) * a.nxb + wave;
-        int4 const *ip = a.idx + (blk * 2) * 64 + lane;
-        int4 i0 = ip[0], i1 = ip[64];
-        id[0] = i0.x;
-        id[1] = i0.y;
-        id[2] = i0.z;
-        id[3] = i0.w;
-        id[4] = i1.x;
-        id[5] = i1.y;
-        id[6] = i1.z;
-        id[7] = i1.w;
-        if (cell)
+        const size_t s = (size_t)ci + (size_t)a.Nx * ((size_t)j + (size_t)a.Ny * (size_t)k);
+        if (!carried)
         {
-          load_coef<T>(a.coef, blk, lane, c);
-#pragma unroll
-          for (int m = 0; m < 8; ++m)
+          const int4 f0 = a.fb0[s];
+          cid[0] = f0.x;
+          cid[1] = f0.y;
+          cid[2] = f0.z;
+          cid[3] = f0.w;
+          cx[0] = a.x[(unsigned int)f0.x & ~kFlag];
+          if (cell)
           {
-            T xv = a.x[(unsigned int)id[m] & ~kFlag];
-            if (m == 0)
-              x0 = xv;
-            u[m] = (id[m] < 0) ? T(0) : xv; // constrained DoFs read as zero
+            cx[1] = a.x[(unsigned int)f0.y & ~kFlag];
+            cx[2] = a.x[(unsigned int)f0.z & ~kFlag];
+            cx[3] = a.x[(unsigned int)f0.w & ~kFlag];
           }
         }
-        else
+        id0 = cid[0];
+        x0 = cx[0];
+        if (cell)
         {
-          x0 = a.x[(unsigned int)id[0] & ~kFlag];
+          const int4 f1 = a.fb1[s];
+          T c[8], u[8];
+          load_coef<T>(a.coef, a.n_slots, s, c);
+          const T n0 = a.x[(unsigned int)f1.x & ~kFlag];
+          const T n1 = a.x[(unsigned int)f1.y & ~kFlag];
+          const T n2 = a.x[(unsigned int)f1.z & ~kFlag];
+          const T n3 = a.x[(unsigned int)f1.w & ~kFlag];
+          // constrained DoFs read as zero
+          u[0] = (cid[0] < 0) ? T(0) : cx[0];
+          u[1] = (cid[1] < 0) ? T(0) : cx[1];
+          u[4] = (cid[2] < 0) ? T(0) : cx[2];
+          u[5] = (cid[3] < 0) ? T(0) : cx[3];
+          u[2] = (f1.x < 0) ? T(0) : n0;
+          u[3] = (f1.y < 0) ? T(0) : n1;
+          u[6] = (f1.z < 0) ? T(0) : n2;
+          u[7] = (f1.w < 0) ? T(0) : n3;
+          cell_apply<T>(u, c, a.fx, a.fy, a.fz, v);
+          cx[0] = n0;
+          cx[1] = n1;
+          cx[2] = n2;
+          cx[3] = n3;
+          cid[0] = f1.x;
+          cid[1] = f1.y;
+          cid[2] = f1.z;
+          cid[3] = f1.w;
         }
       }
-      if (cell)
-      {
-        cell_apply<T>(u, c, a.fx, a.fy, a.fz, v);
-      }
-      else
+      carried = cell;
+      if (!cell)
       {
 #pragma unroll
         for (int m = 0; m < 8; ++m)
           v[m] = T(0);
       }
 
-      // ---- x combine: DoF column i gets the a=0 corners of its own cell and
-      //      the a=1 corners of the cell of column i-1
-      T l0 = __shfl_up(v[1], 1), l1 = __shfl_up(v[3], 1), l2 = __shfl_up(v[5], 1),
-        l3 = __shfl_up(v[7], 1);
-      if (nw > 1)
-      {
-        T *e = edge + (size_t)parity * nw * 4;
-        if (lane == 63)
-        {
-          e[wave * 4 + 0] = v[1];
-          e[wave * 4 + 1] = v[3];
-          e[wave * 4 + 2] = v[5];
-          e[wave * 4 + 3] = v[7];
-        }
-        __syncthreads();
-        if (lane == 0 && wave > 0)
-        {
-          l0 = e[(wave - 1) * 4 + 0];
-          l1 = e[(wave - 1) * 4 + 1];
-          l2 = e[(wave - 1) * 4 + 2];
-          l3 = e[(wave - 1) * 4 + 3];
-        }
-        parity ^= 1;
-      }
-      if (i == 0)
-      {
-        l0 = l1 = l2 = l3 = T(0);
-      }
-      const T s00 = v[0] + l0; // s[b][d]: b=0,d=0
-      const T s10 = v[2] + l1; // b=1,d=0
-      const T s01 = v[4] + l2; // b=0,d=1
-      const T s11 = v[6] + l3; // b=1,d=1
+      // ---- x combine: DoF column ci gets the a=0 corners of its own cell and the a=1 corners of
+      //      the cell of the lane to the left (lane 0 is the halo column: its sum is never used)
+      const T s00 = v[0] + __shfl_up(v[1], 1); // s[b][d]: b=0,d=0
+      const T s10 = v[2] + __shfl_up(v[3], 1); // b=1,d=0
+      const T s01 = v[4] + __shfl_up(v[5], 1); // b=0,d=1
+      const T s11 = v[6] + __shfl_up(v[7], 1); // b=1,d=1
       // ---- y combine (register carry), z combine (LDS column carry)
       const T t0 = s00 + ry0;
       const T t1 = s01 + ry1;
       ry0 = s10;
       ry1 = s11;
-      T *ptj = pt + (size_t)jj * nt + i;
+      T *ptj = pt + jj * 64 + lane;
       const T yv = (kk > 0) ? (t0 + *ptj) : T(0);
       *ptj = t1;
 
-      if (slot && jj > 0 && kk > 0)
+      if (slot && col_owned && jj > 0 && kk > 0)
       {
-        const unsigned int g = (unsigned int)id[0] & ~kFlag;
-        const T ax = (id[0] < 0) ? x0 : yv; // constrained rows: dst_c = src_c
+        const unsigned int g = (unsigned int)id0 & ~kFlag;
+        const T ax = (id0 < 0) ? x0 : yv; // constrained rows: dst_c = src_c
         T o;
         if (a.mode == 0)
           o = ax;
@@ -311,95 +304,76 @@ __global__ void mf_laplace_kernel(MfArgs<T> a)
 // ---- setup kernels -----------------------------------------------------------
 template <typename T>
 __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coefficient,
-                                 uint8_t const *constrained, int Nx, int Ny, int Nz, int nxb,
-                                 int4 *idx, T *coef)
+                                 uint8_t const *constrained, int Nx, int Ny, int Nz, int4 *fb0, int4 *fb1,
+                                 T *coef)
 {
-  const int64_t n_slots = (int64_t)nxb * 64 * Ny * Nz;
+  const int64_t n_slots = (int64_t)Nx * Ny * Nz;
   const int nx = Nx - 1, ny = Ny - 1, nz = Nz - 1;
-  constexpr int W = 16 / sizeof(T); // values per 16-byte load
+  constexpr int W = 16 / sizeof(T); // values per 16-byte vector
   constexpr int NP = 8 / W;
   for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n_slots;
-       s += (int64_t)gridDim.x * blockDim.x)
-  {
-    const int lane = s & 63;
-    const int64_t blk = s >> 6;
-    const int bw = blk % nxb;
-    const int64_t row = blk / nxb;
-    const int j = row % Ny;
-    const int k = row / Ny;
-    const int i = bw * 64 + lane;
-    int id[8];
-    T c[8];
-    if (i >= Nx)
-    {
-      for (int m = 0; m < 8; ++m)
-      {
-        id[m] = 0;
-        c[m] = T(0);
-      }
-    }
-    else
-    {
-      const int ic = min(i, nx - 1), jc = min(j, ny - 1), kc = min(k, nz - 1);
-      const int64_t cidx = ic + (int64_t)nx * (jc + (int64_t)ny * kc);
-      const bool real = (i < nx) && (j < ny) && (k < nz);
-      if (real)
-      {
-        for (int m = 0; m < 8; ++m)
-        {
-          const int g = cell_dofs[cidx * 8 + m];
-          id[m] = g | (constrained[g] ? (int)kFlag : 0);
-          c[m] = T(coefficient[cidx * 8 + m]);
-        }
-      }
-      else
-      {
-        const int m0 = (i - ic) + 2 * (j - jc) + 4 * (k - kc);
-        const int g = cell_dofs[cidx * 8 + m0];
-        const int v = g | (constrained[g] ? (int)kFlag : 0);
-        for (int m = 0; m < 8; ++m)
-        {
-          id[m] = v;
-          c[m] = T(0);
-        }
-      }
-    }
-    idx[(blk * 2 + 0) * 64 + lane] = make_int4(id[0], id[1], id[2], id[3]);
-    idx[(blk * 2 + 1) * 64 + lane] = make_int4(id[4], id[5], id[6], id[7]);
-    for (int p = 0; p < NP; ++p)
-      for (int w = 0; w < W; ++w)
-        coef[((blk * NP + p) * 64 + lane) * W + w] = c[p * W + w];
-  }
-}
-
-// Every corner (a,b,d) of real cell (i,j,k) must be corner 0 of slot (i+a,j+b,k+d):
-// the logical-structure precondition of the tiled kernel.  Also checks index range.
-__global__ void mf_validate_kernel(int4 const *idx, int Nx, int Ny, int Nz, int nxb, int64_t n_dofs,
-                                   int *n_bad)
-{
-  const int64_t n = (int64_t)Nx * Ny * Nz;
-  for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n;
        s += (int64_t)gridDim.x * blockDim.x)
   {
     const int i = s % Nx;
     const int j = (s / Nx) % Ny;
     const int k = s / ((int64_t)Nx * Ny);
-    auto slot0 = [&](int ii, int jj, int kk) {
-      const int64_t blk = ((int64_t)kk * Ny + jj) * nxb + (ii >> 6);
-      return idx[(blk * 2) * 64 + (ii & 63)].x;
+    // DoF id of node (ii,jj,kk) through any real cell that has it as a corner
+    auto node = [&](int ii, int jj, int kk) {
+      const int ic = min(ii, nx - 1), jc = min(jj, ny - 1), kc = min(kk, nz - 1);
+      const int64_t cidx = ic + (int64_t)nx * (jc + (int64_t)ny * kc);
+      const int g = cell_dofs[cidx * 8 + (ii - ic) + 2 * (jj - jc) + 4 * (kk - kc)];
+      return g | (constrained[g] ? (int)kFlag : 0);
     };
-    const int64_t blk = ((int64_t)k * Ny + j) * nxb + (i >> 6);
-    const int4 a = idx[(blk * 2) * 64 + (i & 63)];
-    const int4 b = idx[(blk * 2 + 1) * 64 + (i & 63)];
-    const int id[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    bool bad = false;
-    if ((int64_t)((unsigned int)id[0] & ~kFlag) >= n_dofs)
-      bad = true;
-    if (i < Nx - 1 && j < Ny - 1 && k < Nz - 1)
+    int id[8];
+    T c[8];
+    const bool real = (i < nx) && (j < ny) && (k < nz);
+    const int own = node(i, j, k);
+    for (int m = 0; m < 8; ++m)
     {
-      for (int m = 1; m < 8; ++m)
-        if (id[m] != slot0(i + (m & 1), j + ((m >> 1) & 1), k + (m >> 2)))
-          bad = true;
+      const int ii = i + (m & 1), jj = j + ((m >> 1) & 1), kk = k + (m >> 2);
+      // corners of phantom cells that fall outside the mesh point at the slot's own DoF
+      id[m] = (ii < Nx && jj < Ny && kk < Nz) ? node(ii, jj, kk) : own;
+      c[m] = real ? T(coefficient[(i + (int64_t)nx * (j + (int64_t)ny * k)) * 8 + m]) : T(0);
+    }
+    fb0[s] = make_int4(id[0], id[1], id[4], id[5]);
+    fb1[s] = make_int4(id[2], id[3], id[6], id[7]);
+    for (int p = 0; p < NP; ++p)
+      for (int w = 0; w < W; ++w)
+        coef[((size_t)p * n_slots + s) * W + w] = c[p * W + w];
+  }
+}
+
+__global__ void mf_range_kernel(int32_t const *cell_dofs, int64_t n, int64_t n_dofs, int *n_bad)
+{
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+    if (cell_dofs[t] < 0 || cell_dofs[t] >= n_dofs)
+      atomicAdd(n_bad, 1);
+}
+
+// Every corner (a,b,d) of real cell (i,j,k) as read from cell_dofs must be corner 0 of slot
+// (i+a,j+b,k+d): the logical-structure precondition of the tiled kernel.  Also checks the id range.
+__global__ void mf_validate_kernel(int32_t const *cell_dofs, int4 const *fb0, int Nx, int Ny, int Nz,
+                                   int64_t n_dofs, int *n_bad)
+{
+  const int nx = Nx - 1, ny = Ny - 1, nz = Nz - 1;
+  const int64_t n = (int64_t)nx * ny * nz;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int i = c % nx;
+    const int j = (c / nx) % ny;
+    const int k = c / ((int64_t)nx * ny);
+    bool bad = false;
+    for (int m = 0; m < 8; ++m)
+    {
+      const int g = cell_dofs[c * 8 + m];
+      if (g < 0 || g >= n_dofs)
+      {
+        bad = true;
+        continue;
+      }
+      const int64_t s = (i + (m & 1)) + (int64_t)Nx * ((j + ((m >> 1) & 1)) + (int64_t)Ny * (k + (m >> 2)));
+      if ((int)((unsigned int)fb0[s].x & ~kFlag) != g)
+        bad = true;
     }
     if (bad)
       atomicAdd(n_bad, 1);
@@ -414,8 +388,8 @@ struct DiagTable
 // compute_diagonal (tests/laplace_matrix_free.hpp:75-98,158-199): per-cell
 // unit-vector applies summed per DoF; constrained entries set to one.
 template <typename T>
-__global__ void mf_diagonal_kernel(int4 const *idx, void const *coef, int Nx, int Ny, int Nz, int nxb,
-                                   DiagTable tab, T *diag, T *dinv)
+__global__ void mf_diagonal_kernel(int4 const *fb0, void const *coef, int Nx, int Ny, int Nz, DiagTable tab,
+                                   T *diag, T *dinv)
 {
   const int64_t n = (int64_t)Nx * Ny * Nz;
   for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n;
@@ -424,17 +398,15 @@ __global__ void mf_diagonal_kernel(int4 const *idx, void const *coef, int Nx, in
     const int i = s % Nx;
     const int j = (s / Nx) % Ny;
     const int k = s / ((int64_t)Nx * Ny);
-    const int64_t blk0 = ((int64_t)k * Ny + j) * nxb + (i >> 6);
-    const int id0 = idx[(blk0 * 2) * 64 + (i & 63)].x;
+    const int id0 = fb0[s].x;
     double sum = 0.;
     for (int m = 0; m < 8; ++m)
     {
       const int ci = i - (m & 1), cj = j - ((m >> 1) & 1), ck = k - (m >> 2);
       if (ci < 0 || cj < 0 || ck < 0 || ci >= Nx - 1 || cj >= Ny - 1 || ck >= Nz - 1)
         continue;
-      const int64_t blk = ((int64_t)ck * Ny + cj) * nxb + (ci >> 6);
       T c[8];
-      load_coef<T>(coef, blk, ci & 63, c);
+      load_coef<T>(coef, (size_t)n, (size_t)ci + (size_t)Nx * ((size_t)cj + (size_t)Ny * (size_t)ck), c);
       for (int q = 0; q < 8; ++q)
         sum += (double)c[q] * tab.K[q][m];
     }
@@ -468,10 +440,8 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   ASSERT_THROW(nd == mesh.n_dofs, "n_dofs does not match the cell grid (Q1: (n+1)^dim)");
   ASSERT_THROW(nd < (int64_t(1) << 31), "DoF ids must fit 31 bits (bit 31 carries the constraint flag)");
   _n_dofs = nd;
-  _nxp = ((_N[0] + 63) / 64) * 64;
-  _nxb = _nxp / 64;
-  if (_nxp > 1024)
-    ASSERT_THROW_NOT_IMPLEMENTED("rows longer than 1024 DoFs need an x split of the workgroup tile");
+  for (int d = 0; d < 3; ++d)
+    ASSERT_THROW(_n[d] >= 1, "n_cells must be positive");
 
   hipStream_t st = _handle.stream;
   // stage the plain arrays on the device if they are host arrays
@@ -490,20 +460,28 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
     co = co_tmp.data();
     cn = cn_tmp.data();
   }
-  const size_t n_slots = (size_t)_nxp * _N[1] * _N[2];
-  _idx.resize(n_slots * 2);
+  const size_t n_slots = (size_t)nd;
+  _fb0.resize(n_slots);
+  _fb1.resize(n_slots);
   _coef.resize(n_slots * 8);
   _diag.resize(nd);
   _dinv.resize(nd);
 
-  hipLaunchKernelGGL(mf_repack_kernel<T>, dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, cd,
-                     co, cn, _N[0], _N[1], _N[2], _nxb, _idx.data(), _coef.data());
-  MFMG_HIP_CHECK(hipGetLastError());
-
+  // range check of the ids comes first: the repack kernel dereferences constrained[id]
   DeviceBuffer<int> bad(1);
   MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
-  hipLaunchKernelGGL(mf_validate_kernel, dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
-                     _idx.data(), _N[0], _N[1], _N[2], _nxb, _n_dofs, bad.data());
+  hipLaunchKernelGGL(mf_range_kernel, dim3(n_blocks_for(nc * 8, 256, 1 << 16)), dim3(256), 0, st, cd, nc * 8, nd,
+                     bad.data());
+  MFMG_HIP_CHECK(hipGetLastError());
+  ASSERT_THROW(bad.download(st)[0] == 0, "cell_dofs is not a logically structured hex mesh in lexicographic cell "
+                                         "order (DoF ids out of range)");
+  hipLaunchKernelGGL(mf_repack_kernel<T>, dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, cd,
+                     co, cn, _N[0], _N[1], _N[2], _fb0.data(), _fb1.data(), _coef.data());
+  MFMG_HIP_CHECK(hipGetLastError());
+
+  MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
+  hipLaunchKernelGGL(mf_validate_kernel, dim3(n_blocks_for(nc, 256, 1 << 16)), dim3(256), 0, st, cd,
+                     _fb0.data(), _N[0], _N[1], _N[2], _n_dofs, bad.data());
   MFMG_HIP_CHECK(hipGetLastError());
   int n_bad = bad.download(st)[0];
   ASSERT_THROW(n_bad == 0, "cell_dofs is not a logically structured hex mesh in lexicographic cell order (" +
@@ -535,7 +513,7 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
       tab.K[q][m] = sum;
     }
   hipLaunchKernelGGL(mf_diagonal_kernel<T>, dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
-                     _idx.data(), _coef.data(), _N[0], _N[1], _N[2], _nxb, tab, _diag.data(), _dinv.data());
+                     _fb0.data(), _coef.data(), _N[0], _N[1], _N[2], tab, _diag.data(), _dinv.data());
   MFMG_HIP_CHECK(hipGetLastError());
   MFMG_HIP_CHECK(hipStreamSynchronize(st));
 }
@@ -547,10 +525,10 @@ void MatrixFreeLaplaceDevice<T>::choose_tile(int &ty, int &tz) const
   tz = _tile_z;
   if (ty > 0 && tz > 0)
     return;
-  // heuristic: the largest tile (least halo re-computation) that still yields
-  // >= 4 workgroups per CU-equivalent of waves; LDS column carry must fit.
-  const int64_t waves_per_row = _nxb;
-  const int64_t target_waves = 256 * 8;
+  // heuristic: the largest tile (least halo re-computation) that still yields >= 16 resident
+  // wavefronts per CU
+  const int64_t cols = (_N[0] + 62) / 63;
+  const int64_t target_waves = 256 * 16;
   int best_ty = 1, best_tz = 1;
   double best_cost = 1e30;
   const int cand_y[] = {2, 4, 8, 16, 32};
@@ -558,11 +536,7 @@ void MatrixFreeLaplaceDevice<T>::choose_tile(int &ty, int &tz) const
   for (int cy : cand_y)
     for (int cz : cand_z)
     {
-      const size_t lds = ((size_t)(cy + 1) * _nxp + 2 * _nxb * 4) * sizeof(T);
-      if (lds > 72 * 1024)
-        continue;
-      const int64_t wgs = (int64_t)((_N[1] + cy - 1) / cy) * ((_N[2] + cz - 1) / cz);
-      const int64_t waves = wgs * waves_per_row;
+      const int64_t waves = cols * ((_N[1] + cy - 1) / cy) * ((_N[2] + cz - 1) / cz);
       double cost = (1. + 1. / cy) * (1. + 1. / cz);
       if (waves < target_waves)
         cost *= double(target_waves) / double(std::max<int64_t>(waves, 1));
@@ -592,8 +566,10 @@ void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T c
   int ty, tz;
   choose_tile(ty, tz);
   MfArgs<T> a;
-  a.idx = _idx.data();
+  a.fb0 = _fb0.data();
+  a.fb1 = _fb1.data();
   a.coef = _coef.data();
+  a.n_slots = (size_t)_n_dofs;
   a.x = x;
   a.b = b;
   a.dinv = _dinv.data();
@@ -602,7 +578,6 @@ void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T c
   a.Nx = _N[0];
   a.Ny = _N[1];
   a.Nz = _N[2];
-  a.nxb = _nxb;
   a.TY = ty;
   a.TZ = tz;
   const double vol = _h[0] * _h[1] * _h[2];
@@ -612,20 +587,15 @@ void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T c
   a.alpha = alpha;
   a.beta = beta;
   a.mode = static_cast<int>(mode);
-  const size_t lds = ((size_t)(ty + 1) * _nxp + 2 * _nxb * 4) * sizeof(T);
-  static bool attr_set = false;
-  if (!attr_set)
-  {
-    MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mf_laplace_kernel<T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    attr_set = true;
-  }
-  dim3 grid((_N[1] + ty - 1) / ty, (_N[2] + tz - 1) / tz);
+  const size_t lds = (size_t)(ty + 1) * 64 * sizeof(T);
+  const unsigned int gy = (_N[1] + ty - 1) / ty, gz = (_N[2] + tz - 1) / tz;
+  ASSERT_THROW(gy <= 65535 && gz <= 65535, "operator tile too small for this mesh (grid dimension limit)");
+  dim3 grid((_N[0] + 62) / 63, gy, gz);
   // algorithmic bytes per launch: x + out + 8 idx + 8 coef, plus b / D^-1 / x_prev reads
   const double extra = (mode == MfMode::apply) ? 0. : (mode == MfMode::residual) ? 1. : (mode == MfMode::first) ? 2. : 3.;
   hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel", algorithmic_bytes_apply() + extra * sizeof(T) * double(_n_dofs),
                                            _handle.stream);
-  hipLaunchKernelGGL(mf_laplace_kernel<T>, grid, dim3(_nxp), lds, _handle.stream, a);
+  hipLaunchKernelGGL(mf_laplace_kernel<T>, grid, dim3(64), lds, _handle.stream, a);
   KernelProfiler::end(stop, _handle.stream);
   MFMG_HIP_CHECK(hipGetLastError());
 }

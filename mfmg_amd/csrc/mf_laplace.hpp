@@ -72,12 +72,10 @@ private:
   int _n[3]; // cells
   double _h[3];
   int64_t _n_dofs;
-  int _nxp; // threads per row = Nx rounded up to 64
-  int _nxb; // 64-slot blocks per row
-  // internal layout, one cell slot per DoF, blocked by 64 slots along x:
-  //   idx  : int4   [(block*2 + half)*64 + lane]   corners 4*half..4*half+3, bit31 = constrained
-  //   coef : 16 B   [(block*NP + p)*64 + lane]     NP = 8*sizeof(T)/16 loads per slot
-  DeviceBuffer<int4> _idx;
+  // internal layout, one cell slot per DoF, row-major slot = i + Nx (j + Ny k), planes of 16-byte vectors:
+  //   fb0 / fb1 : int4 [slot]     DoF ids of the b=0 / b=1 face of the cell, bit31 = constrained
+  //   coef      : 16 B [p][slot]  NP = 8*sizeof(T)/16 planes
+  DeviceBuffer<int4> _fb0, _fb1;
   DeviceBuffer<T> _coef;
   DeviceBuffer<T> _diag, _dinv;
   int _tile_y = 0, _tile_z = 0;
