@@ -29,9 +29,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=256, help="fine DoFs per direction PER GPU (Q1, n-1 cells)")
+    ap.add_argument("--cells", type=int, default=256,
+                    help="cells per direction PER GPU (deal.II refine_global(r): 2^r cells, 2^r + 1 DoFs)")
     ap.add_argument("--degree", type=int, default=3, help="Chebyshev degree of the smoother")
-    ap.add_argument("--coarse-iters", type=int, default=10, help="Jacobi-PCG steps of the coarse 'solve'")
+    ap.add_argument("--coarse", default="amg", choices=["amg", "pcg"],
+                    help="coarse 'solve': one V-cycle of the smoothed-aggregation hierarchy, or Jacobi-PCG steps")
+    ap.add_argument("--coarse-iters", type=int, default=10, help="Jacobi-PCG steps when --coarse pcg")
     ap.add_argument("--material", default="constant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cycles", type=int, default=2, help="timed V-cycles of the CPU baseline sample")
@@ -117,11 +120,12 @@ def cpu_baseline(args, M, h, prob, lmin, lmax, torch):
     b = np.zeros(prob.n_dofs)
     cores = ON.effective_cpu_count()
     ON.set_num_threads(cores)
+    amg = h.coarse_amg_levels() if args.coarse == "amg" else None
     x, _ = ON.vcycles(n, prob.h, cd, co, cn, dinv, args.degree, lmin, lmax, R, Ac, args.coarse_iters, b, x0, 1,
-                      want_history=False)
+                      want_history=False, amg_levels=amg)
     t0 = time.perf_counter()
     ON.vcycles(n, prob.h, cd, co, cn, dinv, args.degree, lmin, lmax, R, Ac, args.coarse_iters, b, x, args.cpu_cycles,
-               want_history=False)
+               want_history=False, amg_levels=amg)
     dt = (time.perf_counter() - t0) / args.cpu_cycles
     return {"value": prob.n_dofs / dt, "unit": "DoF/s", "cores": cores, "kind": "port",
             "sample": f"{args.cpu_cycles} V-cycles (after 1 warm-up) of the same {prob.N[0]}^3-DoF workload, "
@@ -147,14 +151,15 @@ def main():
     import mfmg_amd as M
 
     ctx = M.Context()
-    n = args.n
+    n = args.cells + 1
     t_setup = time.perf_counter()
-    prob = M.LaplaceProblem((n - 1,) * 3, args.material, device="cuda")
+    prob = M.LaplaceProblem((args.cells,) * 3, args.material, device="cuda")
     params = {
         "eigensolver": {"number of eigenvectors": 2},
         "agglomeration": {"partitioner": "block", "nx": 2, "ny": 2, "nz": 2},
         "smoother": {"type": "Chebyshev", "degree": args.degree, "smoothing_range": 20.0, "n_smoothing_steps": 1},
-        "solver": {"type": "pcg", "n_iterations": args.coarse_iters},
+        "solver": ({"type": "pcg", "n_iterations": args.coarse_iters} if args.coarse == "pcg" else
+                   {"type": "amg", "amg": {"smoother_degree": 2, "smoothing_range": 10.0, "n_cycles": 1}}),
         "is preconditioner": False,
         "max levels": 2,
     }
@@ -173,6 +178,16 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # residual norms around the run: a bench of a cycle that does not contract would be meaningless
+    op_monitor = M.MatrixFreeLaplace(ctx, prob)
+    r = torch.empty_like(x)
+
+    def residual_norm():
+        op_monitor.vmult(r, x)
+        ctx.sadd(r, -1.0, 1.0, b)
+        return ctx.l2_norm(r)
+
+    res_start = residual_norm()
     for _ in range(args.warmup):
         h.apply(b, x)
     ctx.profile_enable(True)
@@ -184,6 +199,9 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    res_end = residual_norm()
+    contraction = (res_end / res_start) ** (1.0 / max(args.warmup + args.steps, 1)) if res_start > 0 else 0.0
+    del op_monitor, r
     launches, k_ms, k_bytes = ctx.profile_query("mf_laplace_kernel")
     c_launches, c_ms, c_bytes = ctx.profile_query("csr_spmv_kernel")
     ctx.profile_enable(False)
@@ -194,6 +212,8 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * n_fine / (dt / args.steps)
 
+    coarse_desc = (f"{args.coarse_iters} Jacobi-PCG steps" if args.coarse == "pcg" else
+                   "one V-cycle of a smoothed-aggregation hierarchy (Chebyshev(2) smoothers, dense LU at the bottom)")
     if rank == 0:
         achieved = (k_bytes / launches) / (k_ms / launches * 1e-3) / 1e9 if launches else 0.0
         out = {
@@ -210,15 +230,16 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"3D Laplace on the unit cube, Q1 matrix-free, {n}^3 DoFs per GPU "
-                            f"(BASELINE.json configs[3] = 512^3 on 8 GPUs is this workload at N=8), two-level "
-                            f"spectral AMGe (2x2x2 agglomerates, 2 eigenvectors), Chebyshev({degree}) smoother, "
-                            f"coarse {n_coarse} DoFs: {args.coarse_iters} Jacobi-PCG steps, FP64",
+                "workload": f"3D Laplace on the unit cube, Q1 matrix-free, {args.cells}^3 cells = {n}^3 DoFs per GPU "
+                            f"(the mesh deal.II's refine_global gives; BASELINE.json configs[3] '512^3 on 8 GPUs' "
+                            f"is this workload at N=8), spectral AMGe (2x2x2 agglomerates, 2 eigenvectors), "
+                            f"Chebyshev({degree}) smoother, coarse level {n_coarse} DoFs: " + coarse_desc + ", FP64",
                 "fine_dofs_per_gpu": n_fine,
                 "coarse_dofs_per_gpu": n_coarse,
                 "smoother": {"type": "Chebyshev", "degree": degree, "lambda_min": lmin, "lambda_max": lmax},
                 "parallelism": "1 GPU" if world == 1 else f"{world} replicas (domain decomposition pending)",
                 "setup_seconds": t_setup,
+                "mean_residual_contraction_per_cycle": contraction,
             },
             "roofline": {
                 "kernel": "mf_laplace_kernel (fused matrix-free operator + smoother/residual epilogue)",

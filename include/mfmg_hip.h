@@ -178,6 +178,12 @@ int mfmg_hip_hierarchy_set_restrictor(mfmg_hip_hierarchy_t h, int64_t n_rows, in
 /* restrictor / coarse operator download for inspection: query sizes with *_shape first */
 int mfmg_hip_hierarchy_get_restrictor(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *r_borrowed);
 int mfmg_hip_hierarchy_get_coarse_operator(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *ac_borrowed);
+/* levels of the multilevel coarse solver (0 when the coarse solver is direct / pcg): operator A_l,
+ * prolongator P_l (which = 0 / 1, borrowed handles) and the Chebyshev bounds of its smoother */
+int mfmg_hip_hierarchy_coarse_amg_levels(mfmg_hip_hierarchy_t h, int32_t *n_levels);
+int mfmg_hip_hierarchy_coarse_amg_get(mfmg_hip_hierarchy_t h, int32_t level, int32_t which, mfmg_hip_csr_t *borrowed);
+int mfmg_hip_hierarchy_coarse_amg_smoother(mfmg_hip_hierarchy_t h, int32_t level, int32_t *degree, double *lambda_min,
+                                           double *lambda_max);
 /* smoother polynomial actually used (degree, lambda_min, lambda_max) */
 int mfmg_hip_hierarchy_smoother_info(mfmg_hip_hierarchy_t h, int32_t *degree, double *lambda_min, double *lambda_max);
 /* TimerOutput-style accumulated wall times of the sections of hierarchy.hpp:164-271 as a text table */
@@ -201,6 +207,20 @@ int mfmg_hip_host_build_restrictor(const mfmg_hip_mesh_desc *mesh, const char *p
 int mfmg_hip_host_galerkin(const mfmg_hip_mesh_desc *mesh, int semantics, int64_t n_rows, int64_t nnz,
                            const int32_t *r_row_ptr, const int32_t *r_col, const double *r_val,
                            mfmg_hip_host_csr_t *out);
+/* Multilevel coarse solver setup ("solver.type amg": smoothed aggregation, the role ML plays at
+ * source/dealii/dealii_solver.cc:48-66): level operators A_l and prolongators P_l on the host.
+ * which = 0: A_l, 1: P_l (from level l+1 to l; empty on the last level). */
+typedef struct mfmg_hip_host_amg_s *mfmg_hip_host_amg_t;
+/* grid_dims / node_of_row / component_of_row (optional, may be NULL): rows live on nodes of a structured
+ * grid (for the AMGe coarse level: the agglomerates, x fastest), several rows (components) per node;
+ * aggregates are 2x2x2 blocks of nodes, one aggregate per component. */
+int mfmg_hip_host_amg_build(int64_t n_rows, int64_t nnz, const int32_t *row_ptr, const int32_t *col, const double *val,
+                            const double *near_null, const int32_t *grid_dims, const int32_t *node_of_row,
+                            const int32_t *component_of_row, const char *params_info, mfmg_hip_host_amg_t *out);
+int mfmg_hip_host_amg_n_levels(mfmg_hip_host_amg_t amg, int32_t *n_levels);
+int mfmg_hip_host_amg_get(mfmg_hip_host_amg_t amg, int32_t level, int32_t which, mfmg_hip_host_csr_t *out);
+int mfmg_hip_host_amg_destroy(mfmg_hip_host_amg_t amg);
+
 /* boost::property_tree INFO round trip of the parameter reader (tests/test_utils.cc:23-60 exercises ptree2plist) */
 int mfmg_hip_host_params_get(const char *params_info, const char *path, char *value_buf, size_t buf_size);
 

@@ -4,10 +4,10 @@ Python is plumbing here (device memory through torch, process groups through
 torch.distributed); every numerical operation runs in libmfmg_hip.so."""
 from . import lib
 from .api import (Context, Hierarchy, MatrixFreeLaplace, SparseMatrixDevice, host_assemble_matrix,
-                  host_build_restrictor, host_galerkin, params_to_info)
+                  host_amg_build, host_build_restrictor, host_galerkin, params_to_info)
 from .laplace import LaplaceProblem, material_property
 
 __all__ = [
     "lib", "Context", "Hierarchy", "MatrixFreeLaplace", "SparseMatrixDevice", "LaplaceProblem",
-    "material_property", "host_assemble_matrix", "host_build_restrictor", "host_galerkin", "params_to_info",
+    "material_property", "host_assemble_matrix", "host_build_restrictor", "host_galerkin", "host_amg_build", "params_to_info",
 ]

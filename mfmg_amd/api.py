@@ -319,6 +319,25 @@ class Hierarchy:
         check(self._lib.mfmg_hip_hierarchy_get_coarse_operator(self.handle, C.byref(h)))
         return SparseMatrixDevice(self.ctx, _handle=h, _borrowed=True, _keepalive=self)
 
+    def coarse_amg_levels(self):
+        """[(A_l, P_l or None, (degree, lambda_min, lambda_max) or None)] of the multilevel coarse solver."""
+        n = C.c_int32()
+        check(self._lib.mfmg_hip_hierarchy_coarse_amg_levels(self.handle, C.byref(n)))
+        out = []
+        for l in range(n.value):
+            h = C.c_void_p()
+            check(self._lib.mfmg_hip_hierarchy_coarse_amg_get(self.handle, l, 0, C.byref(h)))
+            A = SparseMatrixDevice(self.ctx, _handle=h, _borrowed=True, _keepalive=self).to_scipy()
+            P = cheb = None
+            if l + 1 < n.value:
+                check(self._lib.mfmg_hip_hierarchy_coarse_amg_get(self.handle, l, 1, C.byref(h)))
+                P = SparseMatrixDevice(self.ctx, _handle=h, _borrowed=True, _keepalive=self).to_scipy()
+                d, lo, hi = C.c_int32(), C.c_double(), C.c_double()
+                check(self._lib.mfmg_hip_hierarchy_coarse_amg_smoother(self.handle, l, C.byref(d), C.byref(lo), C.byref(hi)))
+                cheb = (d.value, lo.value, hi.value)
+            out.append((A, P, cheb))
+        return out
+
     def smoother_info(self):
         d, lo, hi = C.c_int32(), C.c_double(), C.c_double()
         check(self._lib.mfmg_hip_hierarchy_smoother_info(self.handle, C.byref(d), C.byref(lo), C.byref(hi)))
@@ -379,6 +398,38 @@ def host_galerkin(problem, R, semantics: str = "assembled"):
     check(lib.mfmg_hip_host_galerkin(C.byref(desc), 0 if semantics == "assembled" else 1, shape[0], len(vl),
                                      rp.ctypes.data, cl.ctypes.data, vl.ctypes.data, C.byref(h)))
     return _host_csr_to_scipy(lib, h)
+
+
+def host_amg_build(A, near_null=None, params: dict | str = "", grid_dims=None, node_of_row=None,
+                   component_of_row=None):
+    """Smoothed-aggregation hierarchy of the multilevel coarse solver on the host: [(A_l, P_l or None)]."""
+    lib = _lib.load()
+    rp, cl, vl, shape = _csr_arrays(A)
+    info = params if isinstance(params, str) else params_to_info(params)
+    nn = None if near_null is None else np.ascontiguousarray(near_null, dtype=np.float64)
+    gd = None if grid_dims is None else np.ascontiguousarray(grid_dims, dtype=np.int32)
+    nr = None if node_of_row is None else np.ascontiguousarray(node_of_row, dtype=np.int32)
+    cr = None if component_of_row is None else np.ascontiguousarray(component_of_row, dtype=np.int32)
+    h = C.c_void_p()
+    check(lib.mfmg_hip_host_amg_build(shape[0], len(vl), rp.ctypes.data, cl.ctypes.data, vl.ctypes.data,
+                                      nn.ctypes.data if nn is not None else None,
+                                      gd.ctypes.data if gd is not None else None,
+                                      nr.ctypes.data if nr is not None else None,
+                                      cr.ctypes.data if cr is not None else None, info.encode(), C.byref(h)))
+    n = C.c_int32()
+    check(lib.mfmg_hip_host_amg_n_levels(h, C.byref(n)))
+    out = []
+    for l in range(n.value):
+        m = C.c_void_p()
+        check(lib.mfmg_hip_host_amg_get(h, l, 0, C.byref(m)))
+        Al = _host_csr_to_scipy(lib, m)
+        Pl = None
+        if l + 1 < n.value:
+            check(lib.mfmg_hip_host_amg_get(h, l, 1, C.byref(m)))
+            Pl = _host_csr_to_scipy(lib, m)
+        out.append((Al, Pl))
+    lib.mfmg_hip_host_amg_destroy(h)
+    return out
 
 
 def params_get(info: str, path: str) -> str:

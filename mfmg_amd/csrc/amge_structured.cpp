@@ -480,7 +480,8 @@ struct AggKey
 } // namespace
 
 HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<double> const &global_diag,
-                                    RestrictorOptions const &opts)
+                                    RestrictorOptions const &opts, std::vector<int32_t> *row_agglomerate,
+                                    int *agglomerate_counts)
 {
   const int dim = mesh.dim;
   const int nc = mesh.nc();
@@ -717,6 +718,16 @@ HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<doub
   for (int64_t a = 0; a < n_agg; ++a)
     first_row[a + 1] = first_row[a] + result_of[a]->n_vec;
   R.n_rows = first_row[n_agg];
+  if (row_agglomerate)
+  {
+    row_agglomerate->resize(R.n_rows);
+    for (int64_t a = 0; a < n_agg; ++a)
+      for (int64_t r = first_row[a]; r < first_row[a + 1]; ++r)
+        (*row_agglomerate)[r] = (int32_t)a;
+  }
+  if (agglomerate_counts)
+    for (int d = 0; d < 3; ++d)
+      agglomerate_counts[d] = cnt[d];
   R.row_ptr.assign(R.n_rows + 1, 0);
   for (int64_t a = 0; a < n_agg; ++a)
     for (int e = 0; e < result_of[a]->n_vec; ++e)

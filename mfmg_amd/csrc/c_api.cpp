@@ -75,13 +75,18 @@ struct mfmg_hip_host_csr_s
   HostCsr m;
 };
 
+struct mfmg_hip_host_amg_s
+{
+  std::vector<AmgLevelHost> levels;
+};
+
 struct mfmg_hip_hierarchy_s
 {
   HipHandle *handle = nullptr;
   std::shared_ptr<HipMeshEvaluator> evaluator;
   std::shared_ptr<TimerOutput> timer;
   std::unique_ptr<Hierarchy<DVector>> hierarchy;
-  mfmg_hip_csr_s restrictor_view, coarse_view;
+  mfmg_hip_csr_s restrictor_view, coarse_view, amg_view;
 };
 
 extern "C" {
@@ -591,6 +596,56 @@ int mfmg_hip_hierarchy_get_coarse_operator(mfmg_hip_hierarchy_t h, mfmg_hip_csr_
   });
 }
 
+namespace
+{
+HipSolver const *coarse_solver_of(mfmg_hip_hierarchy_t h)
+{
+  require(h != nullptr, "null argument");
+  auto s = std::dynamic_pointer_cast<HipSolver const>(h->hierarchy->levels().back().get_solver());
+  require(s != nullptr, "the hierarchy has no HIP coarse solver");
+  return s.get();
+}
+} // namespace
+
+int mfmg_hip_hierarchy_coarse_amg_levels(mfmg_hip_hierarchy_t h, int32_t *n_levels)
+{
+  return guarded([&] {
+    require(n_levels != nullptr, "null argument");
+    *n_levels = (int32_t)coarse_solver_of(h)->amg_levels().size();
+  });
+}
+
+int mfmg_hip_hierarchy_coarse_amg_get(mfmg_hip_hierarchy_t h, int32_t level, int32_t which, mfmg_hip_csr_t *borrowed)
+{
+  return guarded([&] {
+    require(borrowed != nullptr, "null argument");
+    auto const &lv = coarse_solver_of(h)->amg_levels();
+    require(level >= 0 && level < (int)lv.size(), "level out of range");
+    require(which == 0 || which == 1, "which must be 0 (A) or 1 (P)");
+    auto op = which == 0 ? lv[level].a : lv[level].prolongator;
+    require(op != nullptr, "the last level has no prolongator");
+    h->amg_view.op = op;
+    h->amg_view.borrowed = true;
+    *borrowed = &h->amg_view;
+  });
+}
+
+int mfmg_hip_hierarchy_coarse_amg_smoother(mfmg_hip_hierarchy_t h, int32_t level, int32_t *degree, double *lambda_min,
+                                           double *lambda_max)
+{
+  return guarded([&] {
+    auto const &lv = coarse_solver_of(h)->amg_levels();
+    require(level >= 0 && level + 1 < (int)lv.size(), "level out of range (the last level is solved directly)");
+    auto const &s = lv[level].smoother;
+    if (degree)
+      *degree = s->degree();
+    if (lambda_min)
+      *lambda_min = s->lambda_min();
+    if (lambda_max)
+      *lambda_max = s->lambda_max();
+  });
+}
+
 int mfmg_hip_hierarchy_smoother_info(mfmg_hip_hierarchy_t h, int32_t *degree, double *lambda_min, double *lambda_max)
 {
   return guarded([&] {
@@ -717,6 +772,70 @@ int mfmg_hip_host_galerkin(const mfmg_hip_mesh_desc *mesh, int semantics, int64_
         sm, semantics == 0 ? ConstraintSemantics::assembled : ConstraintSemantics::matrix_free, R, Rt);
     *out = h;
   });
+}
+
+int mfmg_hip_host_amg_build(int64_t n_rows, int64_t nnz, const int32_t *row_ptr, const int32_t *col, const double *val,
+                            const double *near_null, const int32_t *grid_dims, const int32_t *node_of_row,
+                            const int32_t *component_of_row, const char *params_info, mfmg_hip_host_amg_t *out)
+{
+  return guarded([&] {
+    require(row_ptr && col && val && out, "null argument");
+    HostCsr A;
+    A.n_rows = A.n_cols = n_rows;
+    A.row_ptr.assign(row_ptr, row_ptr + n_rows + 1);
+    require(A.row_ptr[n_rows] == nnz, "row_ptr[n_rows] != nnz");
+    A.col.assign(col, col + nnz);
+    A.val.assign(val, val + nnz);
+    std::vector<double> b0 = near_null ? std::vector<double>(near_null, near_null + n_rows)
+                                       : std::vector<double>(n_rows, 1.);
+    ptree params = ptree::parse_info(params_info ? params_info : "");
+    AmgOptions opts;
+    opts.max_levels = params.get("solver.amg.max_levels", 10);
+    opts.coarsest_size = params.get("solver.amg.coarsest_size", 3000);
+    opts.strength = params.get("solver.amg.strength", 0.08);
+    opts.smooth_prolongator = params.get("solver.amg.smooth_prolongator", true);
+    AmgGridHint grid;
+    if (grid_dims && node_of_row)
+    {
+      for (int d = 0; d < 3; ++d)
+        grid.dims[d] = grid_dims[d];
+      grid.node_of_row.assign(node_of_row, node_of_row + n_rows);
+      if (component_of_row)
+      {
+        grid.component_of_row.assign(component_of_row, component_of_row + n_rows);
+        for (auto c : grid.component_of_row)
+          grid.n_components = std::max(grid.n_components, c + 1);
+      }
+    }
+    auto h = new mfmg_hip_host_amg_s;
+    h->levels = build_aggregation_hierarchy(std::move(A), std::move(b0), opts, grid.valid(n_rows) ? &grid : nullptr);
+    *out = h;
+  });
+}
+
+int mfmg_hip_host_amg_n_levels(mfmg_hip_host_amg_t amg, int32_t *n_levels)
+{
+  return guarded([&] {
+    require(amg && n_levels, "null argument");
+    *n_levels = (int32_t)amg->levels.size();
+  });
+}
+
+int mfmg_hip_host_amg_get(mfmg_hip_host_amg_t amg, int32_t level, int32_t which, mfmg_hip_host_csr_t *out)
+{
+  return guarded([&] {
+    require(amg && out, "null argument");
+    require(level >= 0 && level < (int)amg->levels.size(), "level out of range");
+    require(which == 0 || which == 1, "which must be 0 (A) or 1 (P)");
+    auto h = new mfmg_hip_host_csr_s;
+    h->m = which == 0 ? amg->levels[level].A : amg->levels[level].P;
+    *out = h;
+  });
+}
+
+int mfmg_hip_host_amg_destroy(mfmg_hip_host_amg_t amg)
+{
+  return guarded([&] { delete amg; });
 }
 
 int mfmg_hip_host_params_get(const char *params_info, const char *path, char *value_buf, size_t buf_size)

@@ -386,6 +386,12 @@ HipSmoother::HipSmoother(std::shared_ptr<Operator<DVector> const> op, std::share
     }
     else if (eig_cg_n_iterations > 0)
     {
+      // start vector of the CG: deal.II's (i % 11) pattern looks like a single plane wave under a
+      // lexicographic numbering whose row length is a multiple of 11 +/- small (e.g. 128, 256) and then
+      // under-estimates lambda_max badly (1.08 instead of 1.5: the smoother diverges); the default is a
+      // numbering-independent hashed vector, "dealii" restores the reference pattern.
+      _eig_start = to_lower(this->_params->get("smoother.eig_start_vector", "hashed"));
+      ASSERT_THROW(_eig_start == "hashed" || _eig_start == "dealii", "unknown smoother.eig_start_vector");
       estimate_eigenvalues(eig_cg_n_iterations, eig_cg_residual, min_est, max_est);
       max_est *= 1.2; // safety factor: the CG is not converged
     }
@@ -428,7 +434,10 @@ void HipSmoother::estimate_eigenvalues(int n_iterations, double residual, double
     double mean = 0.;
     for (int64_t i = 0; i < n; ++i)
     {
-      v[i] = double(i % 11);
+      if (_eig_start == "dealii")
+        v[i] = double(i % 11);
+      else // Knuth multiplicative hash of the DoF id, in [0, 1)
+        v[i] = double((uint64_t(i) * 2654435761ull) & 0xffffffffull) / 4294967296.0;
       mean += v[i];
     }
     mean /= double(n);
@@ -512,8 +521,26 @@ void HipSmoother::apply(DVector const &b, DVector &x) const
 }
 
 // ---- HipSolver -----------------------------------------------------------------
+void HipSolver::setup_direct(std::shared_ptr<SparseMatrixDevice<double>> matrix, DeviceBuffer<double> &lu,
+                             DeviceBuffer<int32_t> &perm_dev) const
+{
+  const int64_t n = matrix->m();
+  std::vector<int32_t> rp, cl;
+  std::vector<double> vl;
+  matrix->download(rp, cl, vl);
+  std::vector<double> dense((size_t)n * n, 0.);
+  for (int64_t r = 0; r < n; ++r)
+    for (int p = rp[r]; p < rp[r + 1]; ++p)
+      dense[(size_t)r * n + cl[p]] += vl[p];
+  std::vector<int32_t> perm;
+  dense_lu_factor((int)n, dense, perm);
+  lu.upload(dense.data(), dense.size(), _handle.stream);
+  perm_dev.upload(perm.data(), perm.size(), _handle.stream);
+}
+
 HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const> op,
-                     std::shared_ptr<ptree const> params)
+                     std::shared_ptr<ptree const> params, std::vector<double> const *near_null,
+                     AmgGridHint const *grid)
     : Solver<DVector>(op, params), _handle(handle)
 {
   _solver = to_lower(this->_params->get("solver.type", "lu_dense"));
@@ -528,17 +555,51 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
     const int64_t limit = std::min(this->_params->get("solver.dense_limit", 8192), 16384);
     ASSERT_THROW(n <= limit, "The coarse problem (" + std::to_string(n) +
                                  " rows) is too large for the dense direct solver; use solver.type pcg");
-    std::vector<int32_t> rp, cl;
-    std::vector<double> vl;
-    matrix->download(rp, cl, vl);
-    std::vector<double> dense((size_t)n * n, 0.);
-    for (int64_t r = 0; r < n; ++r)
-      for (int p = rp[r]; p < rp[r + 1]; ++p)
-        dense[(size_t)r * n + cl[p]] += vl[p];
-    std::vector<int32_t> perm;
-    dense_lu_factor((int)n, dense, perm);
-    _dense_lu.upload(dense.data(), dense.size(), _handle.stream);
-    _dense_perm.upload(perm.data(), perm.size(), _handle.stream);
+    setup_direct(matrix, _dense_lu, _dense_perm);
+  }
+  else if (_solver == "amg")
+  {
+    // smoothed-aggregation hierarchy on the host (the role of ML / AMGx upstream), V-cycle on the device
+    AmgOptions opts;
+    opts.max_levels = this->_params->get("solver.amg.max_levels", 10);
+    opts.coarsest_size = this->_params->get("solver.amg.coarsest_size", 3000);
+    opts.strength = this->_params->get("solver.amg.strength", 0.08);
+    opts.smooth_prolongator = this->_params->get("solver.amg.smooth_prolongator", true);
+    _amg_cycles = this->_params->get("solver.amg.n_cycles", 1);
+    ASSERT_THROW(opts.coarsest_size <= 16384, "solver.amg.coarsest_size is limited by the dense LU (16384)");
+    HostCsr A0;
+    A0.n_rows = A0.n_cols = n;
+    matrix->download(A0.row_ptr, A0.col, A0.val);
+    std::vector<double> b0;
+    if (near_null && (int64_t)near_null->size() == n)
+      b0 = *near_null;
+    else
+      b0.assign(n, 1.);
+    const bool geometric = this->_params->get("solver.amg.geometric_aggregates", true);
+    auto host_levels = build_aggregation_hierarchy(std::move(A0), std::move(b0), opts, geometric ? grid : nullptr);
+    auto smoother_params = std::make_shared<ptree>();
+    smoother_params->put("smoother.type", "Chebyshev");
+    smoother_params->put("smoother.degree", this->_params->get("solver.amg.smoother_degree", 2));
+    smoother_params->put("smoother.smoothing_range", this->_params->get("solver.amg.smoothing_range", 10.));
+    smoother_params->put("smoother.eig_cg_n_iterations", this->_params->get("solver.amg.eig_cg_n_iterations", 10));
+    _amg.resize(host_levels.size());
+    for (size_t l = 0; l < host_levels.size(); ++l)
+    {
+      if (l == 0)
+        _amg[l].a = std::const_pointer_cast<HipMatrixOperator>(_matrix_operator);
+      else
+        _amg[l].a = std::make_shared<HipMatrixOperator>(upload(_handle, std::move(host_levels[l].A)));
+      if (l + 1 < host_levels.size())
+      {
+        _amg[l].prolongator = std::make_shared<HipMatrixOperator>(upload(_handle, std::move(host_levels[l].P)));
+        _amg[l].restrictor = std::dynamic_pointer_cast<HipMatrixOperator>(_amg[l].prolongator->transpose());
+        _amg[l].smoother = std::make_shared<HipSmoother>(_amg[l].a, smoother_params);
+      }
+    }
+    auto last = _amg.back().a->get_matrix();
+    ASSERT_THROW(last->m() <= 16384, "the coarsest level of the multilevel solver is too large for the dense LU (" +
+                                         std::to_string(last->m()) + " rows)");
+    setup_direct(last, _amg_lu, _amg_perm);
   }
   else if (_solver == "pcg")
   {
@@ -563,7 +624,26 @@ void HipSolver::apply(DVector const &b, DVector &x) const
   auto matrix = _matrix_operator->get_matrix();
   const int64_t n = matrix->m();
   ASSERT_THROW(b.size() == n && x.size() == n, "vector sizes do not match the coarse operator");
-  if (_solver == "pcg")
+  if (_solver == "amg")
+  {
+    x = 0.;
+    if (_amg_cycles <= 1)
+      amg_cycle(0, b, x);
+    else
+    {
+      // stationary iteration: x += V(b - A x); the first cycle starts from zero
+      amg_cycle(0, b, x);
+      auto r = _amg[0].a->build_range_vector();
+      auto e = _amg[0].a->build_range_vector();
+      for (int c = 1; c < _amg_cycles; ++c)
+      {
+        _amg[0].a->residual(x, b, *r); // A x - b
+        amg_cycle(0, *r, *e);
+        x.add(-1., *e);
+      }
+    }
+  }
+  else if (_solver == "pcg")
   {
     // exactly n_iterations steps of Jacobi-preconditioned CG from a zero guess, all scalars on the
     // device (no host synchronisation inside the cycle)
@@ -595,6 +675,32 @@ void HipSolver::apply(DVector const &b, DVector &x) const
     ASSERT_THROW(b.get_values() != x.get_values(), "the coarse solve cannot run in place");
     dense_lu_solve(_handle, (int)n, _dense_lu.data(), _dense_perm.data(), b.get_values(), x.get_values());
   }
+}
+
+// One V-cycle of the aggregation hierarchy: the same recursion as Hierarchy::apply
+// (include/mfmg/common/hierarchy.hpp:246-309) with restrictor = P^T; x must be zero on entry.
+void HipSolver::amg_cycle(size_t level, DVector const &b, DVector &x) const
+{
+  AmgLevel const &L = _amg[level];
+  if (level + 1 == _amg.size())
+  {
+    dense_lu_solve(_handle, (int)L.a->get_matrix()->m(), _amg_lu.data(), _amg_perm.data(), b.get_values(),
+                   x.get_values());
+    return;
+  }
+  if (!L.res)
+  {
+    L.res = L.a->build_range_vector();
+    L.b_coarse = _amg[level + 1].a->build_range_vector();
+    L.x_coarse = _amg[level + 1].a->build_range_vector();
+  }
+  L.smoother->apply(b, x);
+  L.a->residual(x, b, *L.res);
+  L.restrictor->apply(*L.res, *L.b_coarse);
+  *L.x_coarse = 0.;
+  amg_cycle(level + 1, *L.b_coarse, *L.x_coarse);
+  L.prolongator->apply_subtract(*L.x_coarse, x, OperatorMode::NO_TRANS);
+  L.smoother->apply(b, x);
 }
 
 // ---- HipHierarchyHelpers ---------------------------------------------------------
@@ -629,8 +735,23 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
   ASSERT_THROW(hip_mesh_evaluator != nullptr, "downcasting failed");
   RestrictorOptions opts = hip_mesh_evaluator->agglomerate_options(*params);
   auto global_diag = hip_mesh_evaluator->get_locally_relevant_diag();
-  HostCsr R = build_restrictor_structured(hip_mesh_evaluator->get_mesh(), global_diag, opts);
-  return std::make_shared<HipMatrixOperator>(upload(_handle, std::move(R)));
+  _grid_hint = AmgGridHint();
+  HostCsr R = build_restrictor_structured(hip_mesh_evaluator->get_mesh(), global_diag, opts, &_grid_hint.node_of_row,
+                                          _grid_hint.dims);
+  // component of a coarse row = its position among the eigenvectors of its agglomerate
+  _grid_hint.component_of_row.resize(_grid_hint.node_of_row.size());
+  _grid_hint.n_components = 1;
+  for (size_t r = 0; r < _grid_hint.node_of_row.size(); ++r)
+  {
+    const int comp = (r > 0 && _grid_hint.node_of_row[r] == _grid_hint.node_of_row[r - 1])
+                         ? _grid_hint.component_of_row[r - 1] + 1
+                         : 0;
+    _grid_hint.component_of_row[r] = comp;
+    _grid_hint.n_components = std::max(_grid_hint.n_components, comp + 1);
+  }
+  auto restrictor = std::make_shared<HipMatrixOperator>(upload(_handle, std::move(R)));
+  _own_restrictor = restrictor;
+  return restrictor;
 }
 
 template <typename VectorType>
@@ -646,7 +767,32 @@ std::shared_ptr<Solver<VectorType>>
 HipHierarchyHelpers<VectorType>::build_coarse_solver(std::shared_ptr<Operator<VectorType> const> op,
                                                      std::shared_ptr<ptree const> params)
 {
-  return std::make_shared<HipSolver>(_handle, op, params);
+  // near-null-space hint for the multilevel solver: the coarse image R 1 of the constant
+  std::vector<double> near_null;
+  auto r = std::dynamic_pointer_cast<HipMatrixOperator const>(_restrictor_hint);
+  auto a = std::dynamic_pointer_cast<HipMatrixOperator const>(op);
+  if (r && a && r->get_matrix()->m() == a->get_matrix()->m())
+  {
+    std::vector<int32_t> rp, cl;
+    std::vector<double> vl;
+    r->get_matrix()->download(rp, cl, vl);
+    near_null.assign(rp.size() - 1, 0.);
+    for (size_t i = 0; i + 1 < rp.size(); ++i)
+      for (int p = rp[i]; p < rp[i + 1]; ++p)
+        near_null[i] += vl[p];
+  }
+  // the agglomerate grid is known only for the restrictor this object built itself
+  const bool own = _restrictor_hint && _restrictor_hint == _own_restrictor;
+  if (own && !near_null.empty())
+  {
+    // candidates per component: the image of the constant for the first eigenvector of every
+    // agglomerate, the unit coefficient for the others (smooth fields have smooth coefficients)
+    for (size_t i = 0; i < near_null.size(); ++i)
+      if (_grid_hint.component_of_row[i] > 0)
+        near_null[i] = 1.;
+  }
+  return std::make_shared<HipSolver>(_handle, op, params, near_null.empty() ? nullptr : &near_null,
+                                     own ? &_grid_hint : nullptr);
 }
 
 template class HipHierarchyHelpers<DVector>;

@@ -1,14 +1,17 @@
 // gfx950 kernels of the matrix-free Q1 Laplace operator.
 //
-// Data layout in HBM ("one cell slot per DoF", row-major slot = i + Nx (j + Ny k)): slot
-// (i,j,k) holds the cell whose lowest corner is DoF (i,j,k); cells that stick out of the mesh
-// on a high face are phantoms with zero coefficient.  Per slot, as planes of 16-byte vectors so
-// that a wavefront reads 1 KiB contiguous per load instruction from any starting column:
-//   fb0  int4 [slot]      DoF ids of the b=0 face: corners (0,0,0) (1,0,0) (0,0,1) (1,0,1)
-//   fb1  int4 [slot]      DoF ids of the b=1 face: corners (0,1,0) (1,1,0) (0,1,1) (1,1,1)
-//   coef 16 B [p][slot]   the 8 quadrature coefficients, p = 0..NP-1
-// The ids are the caller's global DoF ids (any numbering); bit 31 carries the Dirichlet flag,
-// so the constrained-read-as-zero rule costs no extra load.
+// Data layout in HBM ("one cell slot per DoF", rows cut into aligned 64-slot chunks): the DoF
+// columns are cut into runs of 63; chunk c of row (j,k) stores the 64 cell slots of the cells
+// i = 63c-1 .. 63c+62 (the low halo cell is stored again, +1.6 % memory), so that every load of a
+// wavefront is one aligned, contiguous KiB (no power-of-two stride between concurrent wavefronts):
+//   S(c,k,j,lane) = ((k Ny + j) ncols + c) 64 + lane
+//   fb0  int4 [S]      DoF ids of the b=0 face: corners (0,0,0) (1,0,0) (0,0,1) (1,0,1)
+//   fb1  int4 [S]      DoF ids of the b=1 face: corners (0,1,0) (1,1,0) (0,1,1) (1,1,1)
+//   coef 16 B [p][S]   the 8 quadrature coefficients, p = 0..NP-1
+// Slot (i,j,k) holds the cell whose lowest corner is DoF (i,j,k); cells that stick out of the
+// mesh on a high face are phantoms with zero coefficient.  The ids are the caller's global DoF
+// ids (any numbering); bit 31 carries the Dirichlet flag, so the constrained-read-as-zero rule
+// costs no extra load.
 //
 // Work decomposition (owner computes, no atomics, no inter-wave synchronisation, results
 // independent of the tiling bit for bit): ONE WAVEFRONT per workgroup marches over a tile of
@@ -19,9 +22,10 @@
 //   in y : a register carried from the previous cell row,
 //   in z : a per-lane column in LDS carried from the previous cell layer,
 // so every DoF value is complete exactly when its own slot is visited and the smoother
-// epilogue (b, D^-1, x_prev) is fused there: A x is never stored.  The b=0 face of a cell is
-// the b=1 face of the previous row: its ids and x values are carried in registers, so the
-// steady state loads one id vector and gathers four x values per cell.
+// epilogue (b, D^-1, x_prev) is fused there: A x is never stored.  x is read once per tile: the
+// b=0 face of a cell is the b=1 face of the previous row (registers), the d=0 edge is the d=1 edge
+// of the previous layer (a second per-lane LDS column), the a=1 corners are the a=0 corners of the
+// next lane (DPP wave shift); the steady state loads one id vector and gathers ONE x value per cell.
 #include "mf_laplace.hpp"
 
 #include <algorithm>
@@ -47,6 +51,7 @@ struct MfArgs
   T *out;
   int Nx, Ny, Nz;
   int TY, TZ;
+  unsigned int ncols, ntiles_y, ntiles_z;
   T fx, fy, fz;
   T alpha, beta;
   int mode;
@@ -103,6 +108,27 @@ template <>
 __device__ __forceinline__ float fmadd<float>(float a, float b, float c)
 {
   return __builtin_fmaf(a, b, c);
+}
+
+// value held by the previous / next lane of the wavefront (DPP wave shift: a VALU move, no LDS
+// crossbar traffic); lanes without a source keep their own value
+__device__ __forceinline__ int dpp_from_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_from_next(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ double from_prev_lane(double v)
+{
+  return __hiloint2double(dpp_from_prev(__double2hiint(v)), dpp_from_prev(__double2loint(v)));
+}
+__device__ __forceinline__ float from_prev_lane(float v)
+{
+  return __int_as_float(dpp_from_prev(__float_as_int(v)));
+}
+__device__ __forceinline__ double from_next_lane(double v)
+{
+  return __hiloint2double(dpp_from_next(__double2hiint(v)), dpp_from_next(__double2loint(v)));
+}
+__device__ __forceinline__ float from_next_lane(float v)
+{
+  return __int_as_float(dpp_from_next(__float_as_int(v)));
 }
 
 // out[p][.] = S[p][0] in0 + S[p][1] in1 with S = [[A, B], [B, A]]
@@ -179,20 +205,38 @@ __global__ __launch_bounds__(64) void mf_laplace_kernel(MfArgs<T> a)
 {
 #pragma clang fp contract(off)
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  T *pt = reinterpret_cast<T *>(smem_raw); // [TY+1][64] z-carry, lane private
+  T *pt = reinterpret_cast<T *>(smem_raw); // [TY+1][64] z-carry of the partial sums, lane private
+  T *xz = pt + (a.TY + 1) * 64;            // [TY+1][64] z-carry of x: x(ci, j+1, k) of cell row jj
 
   const int lane = threadIdx.x;
-  const int ci = (int)blockIdx.x * 63 - 1 + lane; // cell / DoF column of this lane
-  const int Y0 = blockIdx.y * a.TY;
-  const int Z0 = blockIdx.z * a.TZ;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8,
+  // observed, speed only); give every XCD a contiguous run of the tile list.
+  const unsigned int n_tiles = a.ncols * a.ntiles_y * a.ntiles_z;
+  unsigned int w = blockIdx.x;
+  if (n_tiles >= 64)
+  {
+    const unsigned int per_xcd = (n_tiles + 7) / 8;
+    w = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (w >= n_tiles)
+      return; // (whole wavefront: no barrier is ever reached)
+  }
+  const int tc = w % a.ncols;
+  const int tyi = (w / a.ncols) % a.ntiles_y;
+  const int tzi = w / (a.ncols * a.ntiles_y);
+  const int ci = tc * 63 - 1 + lane; // cell / DoF column of this lane
+  const int Y0 = tyi * a.TY;
+  const int Z0 = tzi * a.TZ;
   const bool col_ok = ci >= 0 && ci < a.Nx;
   const bool col_owned = lane >= 1 && ci < a.Nx;
+  // the lane whose a=1 corners are not the a=0 corners of lane+1 inside this wavefront
+  const bool no_next = (lane == 63) || (ci + 1 >= a.Nx);
 
   for (int kk = 0; kk <= a.TZ; ++kk)
   {
     const int k = Z0 - 1 + kk;
     if (k >= a.Nz)
       break;
+    const bool layer_carry = (kk > 0) && (k >= 1); // xz holds x(., ., k) written by layer k-1
     T ry0 = T(0), ry1 = T(0);
     // b=0 face carried from the previous cell row: raw x values, ids (flag in bit 31)
     T cx[4] = {T(0), T(0), T(0), T(0)};
@@ -208,9 +252,12 @@ __global__ __launch_bounds__(64) void mf_laplace_kernel(MfArgs<T> a)
       T v[8];
       T x0 = T(0);
       int id0 = 0;
+      T n0 = T(0), n2 = T(0), n1x = T(0), n3x = T(0);
+      int4 f1 = make_int4(0, 0, 0, 0);
+      T c[8];
+      const size_t s = (((size_t)max(k, 0) * a.Ny + (size_t)max(j, 0)) * a.ncols + (size_t)tc) * 64 + lane;
       if (slot)
       {
-        const size_t s = (size_t)ci + (size_t)a.Nx * ((size_t)j + (size_t)a.Ny * (size_t)k);
         if (!carried)
         {
           const int4 f0 = a.fb0[s];
@@ -230,47 +277,61 @@ __global__ __launch_bounds__(64) void mf_laplace_kernel(MfArgs<T> a)
         x0 = cx[0];
         if (cell)
         {
-          const int4 f1 = a.fb1[s];
-          T c[8], u[8];
+          f1 = a.fb1[s];
           load_coef<T>(a.coef, a.n_slots, s, c);
-          const T n0 = a.x[(unsigned int)f1.x & ~kFlag];
-          const T n1 = a.x[(unsigned int)f1.y & ~kFlag];
-          const T n2 = a.x[(unsigned int)f1.z & ~kFlag];
-          const T n3 = a.x[(unsigned int)f1.w & ~kFlag];
-          // constrained DoFs read as zero
-          u[0] = (cid[0] < 0) ? T(0) : cx[0];
-          u[1] = (cid[1] < 0) ? T(0) : cx[1];
-          u[4] = (cid[2] < 0) ? T(0) : cx[2];
-          u[5] = (cid[3] < 0) ? T(0) : cx[3];
-          u[2] = (f1.x < 0) ? T(0) : n0;
-          u[3] = (f1.y < 0) ? T(0) : n1;
-          u[6] = (f1.z < 0) ? T(0) : n2;
-          u[7] = (f1.w < 0) ? T(0) : n3;
-          cell_apply<T>(u, c, a.fx, a.fy, a.fz, v);
-          cx[0] = n0;
-          cx[1] = n1;
-          cx[2] = n2;
-          cx[3] = n3;
-          cid[0] = f1.x;
-          cid[1] = f1.y;
-          cid[2] = f1.z;
-          cid[3] = f1.w;
+          n2 = a.x[(unsigned int)f1.z & ~kFlag];                                   // x(ci, j+1, k+1)
+          n0 = layer_carry ? xz[jj * 64 + lane] : a.x[(unsigned int)f1.x & ~kFlag]; // x(ci, j+1, k)
+          if (no_next) // issued together with n2 so that the wavefront pays one memory round trip per row
+          {
+            n1x = a.x[(unsigned int)f1.y & ~kFlag];
+            n3x = a.x[(unsigned int)f1.w & ~kFlag];
+          }
         }
       }
-      carried = cell;
-      if (!cell)
+      // a=1 corners: the a=0 corners of the next lane (every lane takes part in the shift)
+      T n1 = from_next_lane(n0), n3 = from_next_lane(n2);
+      if (cell)
+      {
+        if (no_next)
+        {
+          n1 = n1x;
+          n3 = n3x;
+        }
+        xz[jj * 64 + lane] = n2;
+        T u[8];
+        // constrained DoFs read as zero
+        u[0] = (cid[0] < 0) ? T(0) : cx[0];
+        u[1] = (cid[1] < 0) ? T(0) : cx[1];
+        u[4] = (cid[2] < 0) ? T(0) : cx[2];
+        u[5] = (cid[3] < 0) ? T(0) : cx[3];
+        u[2] = (f1.x < 0) ? T(0) : n0;
+        u[3] = (f1.y < 0) ? T(0) : n1;
+        u[6] = (f1.z < 0) ? T(0) : n2;
+        u[7] = (f1.w < 0) ? T(0) : n3;
+        cell_apply<T>(u, c, a.fx, a.fy, a.fz, v);
+        cx[0] = n0;
+        cx[1] = n1;
+        cx[2] = n2;
+        cx[3] = n3;
+        cid[0] = f1.x;
+        cid[1] = f1.y;
+        cid[2] = f1.z;
+        cid[3] = f1.w;
+      }
+      else
       {
 #pragma unroll
         for (int m = 0; m < 8; ++m)
           v[m] = T(0);
       }
+      carried = cell;
 
       // ---- x combine: DoF column ci gets the a=0 corners of its own cell and the a=1 corners of
       //      the cell of the lane to the left (lane 0 is the halo column: its sum is never used)
-      const T s00 = v[0] + __shfl_up(v[1], 1); // s[b][d]: b=0,d=0
-      const T s10 = v[2] + __shfl_up(v[3], 1); // b=1,d=0
-      const T s01 = v[4] + __shfl_up(v[5], 1); // b=0,d=1
-      const T s11 = v[6] + __shfl_up(v[7], 1); // b=1,d=1
+      const T s00 = v[0] + from_prev_lane(v[1]); // s[b][d]: b=0,d=0
+      const T s10 = v[2] + from_prev_lane(v[3]); // b=1,d=0
+      const T s01 = v[4] + from_prev_lane(v[5]); // b=0,d=1
+      const T s11 = v[6] + from_prev_lane(v[7]); // b=1,d=1
       // ---- y combine (register carry), z combine (LDS column carry)
       const T t0 = s00 + ry0;
       const T t1 = s01 + ry1;
@@ -291,9 +352,9 @@ __global__ __launch_bounds__(64) void mf_laplace_kernel(MfArgs<T> a)
           o = ax - a.b[g];
         else
         {
-          const T w = -(a.beta * a.dinv[g]);
+          const T wgt = -(a.beta * a.dinv[g]);
           const T r = ax - a.b[g];
-          o = (a.mode == 2) ? fmadd<T>(w, r, x0) : fmadd<T>(w, r, fmadd<T>(a.alpha, x0 - a.xprev[g], x0));
+          o = (a.mode == 2) ? fmadd<T>(wgt, r, x0) : fmadd<T>(wgt, r, fmadd<T>(a.alpha, x0 - a.xprev[g], x0));
         }
         a.out[g] = o;
       }
@@ -304,43 +365,65 @@ __global__ __launch_bounds__(64) void mf_laplace_kernel(MfArgs<T> a)
 // ---- setup kernels -----------------------------------------------------------
 template <typename T>
 __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coefficient,
-                                 uint8_t const *constrained, int Nx, int Ny, int Nz, int4 *fb0, int4 *fb1,
-                                 T *coef)
+                                 uint8_t const *constrained, int Nx, int Ny, int Nz, int ncols, int4 *fb0,
+                                 int4 *fb1, T *coef)
 {
-  const int64_t n_slots = (int64_t)Nx * Ny * Nz;
+  const int64_t n_slots = (int64_t)ncols * Nz * Ny * 64;
   const int nx = Nx - 1, ny = Ny - 1, nz = Nz - 1;
   constexpr int W = 16 / sizeof(T); // values per 16-byte vector
   constexpr int NP = 8 / W;
   for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n_slots;
        s += (int64_t)gridDim.x * blockDim.x)
   {
-    const int i = s % Nx;
-    const int j = (s / Nx) % Ny;
-    const int k = s / ((int64_t)Nx * Ny);
-    // DoF id of node (ii,jj,kk) through any real cell that has it as a corner
-    auto node = [&](int ii, int jj, int kk) {
-      const int ic = min(ii, nx - 1), jc = min(jj, ny - 1), kc = min(kk, nz - 1);
-      const int64_t cidx = ic + (int64_t)nx * (jc + (int64_t)ny * kc);
-      const int g = cell_dofs[cidx * 8 + (ii - ic) + 2 * (jj - jc) + 4 * (kk - kc)];
-      return g | (constrained[g] ? (int)kFlag : 0);
-    };
+    const int lane = s & 63;
+    const int64_t chunk = s >> 6;
+    const int c = chunk % ncols;
+    const int j = (chunk / ncols) % Ny;
+    const int k = chunk / ((int64_t)ncols * Ny);
+    const int i = c * 63 - 1 + lane;
     int id[8];
-    T c[8];
-    const bool real = (i < nx) && (j < ny) && (k < nz);
-    const int own = node(i, j, k);
-    for (int m = 0; m < 8; ++m)
+    T cf[8];
+    if (i < 0 || i >= Nx)
     {
-      const int ii = i + (m & 1), jj = j + ((m >> 1) & 1), kk = k + (m >> 2);
-      // corners of phantom cells that fall outside the mesh point at the slot's own DoF
-      id[m] = (ii < Nx && jj < Ny && kk < Nz) ? node(ii, jj, kk) : own;
-      c[m] = real ? T(coefficient[(i + (int64_t)nx * (j + (int64_t)ny * k)) * 8 + m]) : T(0);
+      for (int m = 0; m < 8; ++m)
+      {
+        id[m] = 0;
+        cf[m] = T(0);
+      }
+    }
+    else
+    {
+      // DoF id of node (ii,jj,kk) through any real cell that has it as a corner
+      auto node = [&](int ii, int jj, int kk) {
+        const int ic = min(ii, nx - 1), jc = min(jj, ny - 1), kc = min(kk, nz - 1);
+        const int64_t cidx = ic + (int64_t)nx * (jc + (int64_t)ny * kc);
+        const int g = cell_dofs[cidx * 8 + (ii - ic) + 2 * (jj - jc) + 4 * (kk - kc)];
+        return g | (constrained[g] ? (int)kFlag : 0);
+      };
+      const bool real = (i < nx) && (j < ny) && (k < nz);
+      const int own = node(i, j, k);
+      for (int m = 0; m < 8; ++m)
+      {
+        const int ii = i + (m & 1), jj = j + ((m >> 1) & 1), kk = k + (m >> 2);
+        // corners of phantom cells that fall outside the mesh point at the slot's own DoF
+        id[m] = (ii < Nx && jj < Ny && kk < Nz) ? node(ii, jj, kk) : own;
+        cf[m] = real ? T(coefficient[(i + (int64_t)nx * (j + (int64_t)ny * k)) * 8 + m]) : T(0);
+      }
     }
     fb0[s] = make_int4(id[0], id[1], id[4], id[5]);
     fb1[s] = make_int4(id[2], id[3], id[6], id[7]);
     for (int p = 0; p < NP; ++p)
       for (int w = 0; w < W; ++w)
-        coef[((size_t)p * n_slots + s) * W + w] = c[p * W + w];
+        coef[((size_t)p * n_slots + s) * W + w] = cf[p * W + w];
   }
+}
+
+// slot of cell / DoF (i,j,k) in the tile-column-major layout (the copy owned by its column)
+__device__ __forceinline__ size_t slot_of(int i, int j, int k, int Ny, int ncols)
+{
+  const int c = (i + 1) / 63;
+  const int lane = i + 1 - 63 * c;
+  return (((size_t)k * Ny + j) * ncols + c) * 64 + lane;
 }
 
 __global__ void mf_range_kernel(int32_t const *cell_dofs, int64_t n, int64_t n_dofs, int *n_bad)
@@ -352,7 +435,7 @@ __global__ void mf_range_kernel(int32_t const *cell_dofs, int64_t n, int64_t n_d
 
 // Every corner (a,b,d) of real cell (i,j,k) as read from cell_dofs must be corner 0 of slot
 // (i+a,j+b,k+d): the logical-structure precondition of the tiled kernel.  Also checks the id range.
-__global__ void mf_validate_kernel(int32_t const *cell_dofs, int4 const *fb0, int Nx, int Ny, int Nz,
+__global__ void mf_validate_kernel(int32_t const *cell_dofs, int4 const *fb0, int Nx, int Ny, int Nz, int ncols,
                                    int64_t n_dofs, int *n_bad)
 {
   const int nx = Nx - 1, ny = Ny - 1, nz = Nz - 1;
@@ -371,7 +454,7 @@ __global__ void mf_validate_kernel(int32_t const *cell_dofs, int4 const *fb0, in
         bad = true;
         continue;
       }
-      const int64_t s = (i + (m & 1)) + (int64_t)Nx * ((j + ((m >> 1) & 1)) + (int64_t)Ny * (k + (m >> 2)));
+      const size_t s = slot_of(i + (m & 1), j + ((m >> 1) & 1), k + (m >> 2), Ny, ncols);
       if ((int)((unsigned int)fb0[s].x & ~kFlag) != g)
         bad = true;
     }
@@ -388,17 +471,17 @@ struct DiagTable
 // compute_diagonal (tests/laplace_matrix_free.hpp:75-98,158-199): per-cell
 // unit-vector applies summed per DoF; constrained entries set to one.
 template <typename T>
-__global__ void mf_diagonal_kernel(int4 const *fb0, void const *coef, int Nx, int Ny, int Nz, DiagTable tab,
-                                   T *diag, T *dinv)
+__global__ void mf_diagonal_kernel(int4 const *fb0, void const *coef, size_t n_slots, int Nx, int Ny, int Nz,
+                                   int ncols, DiagTable tab, T *diag, T *dinv)
 {
   const int64_t n = (int64_t)Nx * Ny * Nz;
-  for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n;
-       s += (int64_t)gridDim.x * blockDim.x)
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n;
+       t += (int64_t)gridDim.x * blockDim.x)
   {
-    const int i = s % Nx;
-    const int j = (s / Nx) % Ny;
-    const int k = s / ((int64_t)Nx * Ny);
-    const int id0 = fb0[s].x;
+    const int i = t % Nx;
+    const int j = (t / Nx) % Ny;
+    const int k = t / ((int64_t)Nx * Ny);
+    const int id0 = fb0[slot_of(i, j, k, Ny, ncols)].x;
     double sum = 0.;
     for (int m = 0; m < 8; ++m)
     {
@@ -406,7 +489,7 @@ __global__ void mf_diagonal_kernel(int4 const *fb0, void const *coef, int Nx, in
       if (ci < 0 || cj < 0 || ck < 0 || ci >= Nx - 1 || cj >= Ny - 1 || ck >= Nz - 1)
         continue;
       T c[8];
-      load_coef<T>(coef, (size_t)n, (size_t)ci + (size_t)Nx * ((size_t)cj + (size_t)Ny * (size_t)ck), c);
+      load_coef<T>(coef, n_slots, slot_of(ci, cj, ck, Ny, ncols), c);
       for (int q = 0; q < 8; ++q)
         sum += (double)c[q] * tab.K[q][m];
     }
@@ -460,7 +543,9 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
     co = co_tmp.data();
     cn = cn_tmp.data();
   }
-  const size_t n_slots = (size_t)nd;
+  _ncols = (_N[0] + 62) / 63;
+  const size_t n_slots = (size_t)_ncols * _N[2] * _N[1] * 64;
+  _n_slots = n_slots;
   _fb0.resize(n_slots);
   _fb1.resize(n_slots);
   _coef.resize(n_slots * 8);
@@ -476,12 +561,12 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   ASSERT_THROW(bad.download(st)[0] == 0, "cell_dofs is not a logically structured hex mesh in lexicographic cell "
                                          "order (DoF ids out of range)");
   hipLaunchKernelGGL(mf_repack_kernel<T>, dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, cd,
-                     co, cn, _N[0], _N[1], _N[2], _fb0.data(), _fb1.data(), _coef.data());
+                     co, cn, _N[0], _N[1], _N[2], _ncols, _fb0.data(), _fb1.data(), _coef.data());
   MFMG_HIP_CHECK(hipGetLastError());
 
   MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
   hipLaunchKernelGGL(mf_validate_kernel, dim3(n_blocks_for(nc, 256, 1 << 16)), dim3(256), 0, st, cd,
-                     _fb0.data(), _N[0], _N[1], _N[2], _n_dofs, bad.data());
+                     _fb0.data(), _N[0], _N[1], _N[2], _ncols, _n_dofs, bad.data());
   MFMG_HIP_CHECK(hipGetLastError());
   int n_bad = bad.download(st)[0];
   ASSERT_THROW(n_bad == 0, "cell_dofs is not a logically structured hex mesh in lexicographic cell order (" +
@@ -513,7 +598,7 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
       tab.K[q][m] = sum;
     }
   hipLaunchKernelGGL(mf_diagonal_kernel<T>, dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
-                     _fb0.data(), _coef.data(), _N[0], _N[1], _N[2], tab, _diag.data(), _dinv.data());
+                     _fb0.data(), _coef.data(), _n_slots, _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
   MFMG_HIP_CHECK(hipGetLastError());
   MFMG_HIP_CHECK(hipStreamSynchronize(st));
 }
@@ -569,7 +654,7 @@ void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T c
   a.fb0 = _fb0.data();
   a.fb1 = _fb1.data();
   a.coef = _coef.data();
-  a.n_slots = (size_t)_n_dofs;
+  a.n_slots = _n_slots;
   a.x = x;
   a.b = b;
   a.dinv = _dinv.data();
@@ -587,10 +672,14 @@ void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T c
   a.alpha = alpha;
   a.beta = beta;
   a.mode = static_cast<int>(mode);
-  const size_t lds = (size_t)(ty + 1) * 64 * sizeof(T);
-  const unsigned int gy = (_N[1] + ty - 1) / ty, gz = (_N[2] + tz - 1) / tz;
-  ASSERT_THROW(gy <= 65535 && gz <= 65535, "operator tile too small for this mesh (grid dimension limit)");
-  dim3 grid((_N[0] + 62) / 63, gy, gz);
+  const size_t lds = (size_t)2 * (ty + 1) * 64 * sizeof(T);
+  a.ncols = _ncols;
+  a.ntiles_y = (_N[1] + ty - 1) / ty;
+  a.ntiles_z = (_N[2] + tz - 1) / tz;
+  const uint64_t n_tiles = (uint64_t)a.ncols * a.ntiles_y * a.ntiles_z;
+  ASSERT_THROW(n_tiles < (1ull << 31), "operator tile too small for this mesh (grid size limit)");
+  // one wavefront per tile; rounded up to a multiple of 8 for the XCD-contiguous tile order
+  dim3 grid((unsigned int)(n_tiles >= 64 ? ((n_tiles + 7) / 8) * 8 : n_tiles));
   // algorithmic bytes per launch: x + out + 8 idx + 8 coef, plus b / D^-1 / x_prev reads
   const double extra = (mode == MfMode::apply) ? 0. : (mode == MfMode::residual) ? 1. : (mode == MfMode::first) ? 2. : 3.;
   hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel", algorithmic_bytes_apply() + extra * sizeof(T) * double(_n_dofs),

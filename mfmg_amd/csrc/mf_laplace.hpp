@@ -72,9 +72,12 @@ private:
   int _n[3]; // cells
   double _h[3];
   int64_t _n_dofs;
-  // internal layout, one cell slot per DoF, row-major slot = i + Nx (j + Ny k), planes of 16-byte vectors:
-  //   fb0 / fb1 : int4 [slot]     DoF ids of the b=0 / b=1 face of the cell, bit31 = constrained
-  //   coef      : 16 B [p][slot]  NP = 8*sizeof(T)/16 planes
+  // internal layout, one cell slot per DoF, rows cut into aligned chunks S = ((k Ny + j) ncols + c) 64 + lane with
+  // columns of 63 owned DoFs + the low halo cell, planes of 16-byte vectors:
+  //   fb0 / fb1 : int4 [S]     DoF ids of the b=0 / b=1 face of the cell, bit31 = constrained
+  //   coef      : 16 B [p][S]  NP = 8*sizeof(T)/16 planes
+  int _ncols = 0;
+  size_t _n_slots = 0;
   DeviceBuffer<int4> _fb0, _fb1;
   DeviceBuffer<T> _coef;
   DeviceBuffer<T> _diag, _dinv;

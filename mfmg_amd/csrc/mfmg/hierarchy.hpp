@@ -83,6 +83,7 @@ public:
       timer_enter_subsection(_timer, "Setup: build restrictor");
       auto restrictor = hierarchy_helpers->build_restrictor(comm, evaluator, params);
       level_coarse.set_restrictor(restrictor);
+      hierarchy_helpers->set_coarse_space_hint(restrictor);
       timer_leave_subsection(_timer);
 
       std::shared_ptr<Operator<VectorType>> ap;
@@ -180,6 +181,7 @@ public:
     auto ap = a->multiply_transpose(restrictor);
     auto a_coarse = restrictor->multiply(ap);
     _levels[1].set_operator(a_coarse);
+    _helpers->set_coarse_space_hint(restrictor);
     _levels[1].set_solver(_helpers->build_coarse_solver(a_coarse, _params));
   }
 

@@ -39,5 +39,9 @@ public:
 
   virtual std::shared_ptr<Solver<vector_type>>
   build_coarse_solver(std::shared_ptr<Operator<vector_type> const> op, std::shared_ptr<ptree const> params) = 0;
+
+  // Extension: the restrictor the coarse operator was built with, so that a multilevel coarse solver can
+  // derive its near-null-space vector (the coarse image of the constant) from it.  Default: ignored.
+  virtual void set_coarse_space_hint(std::shared_ptr<Operator<vector_type> const> /*restrictor*/) {}
 };
 } // namespace mfmg

@@ -4,6 +4,7 @@
 // CudaHierarchyHelpers) for VectorType = mfmg::Vector<double>.
 #pragma once
 
+#include "../amg_setup.hpp"
 #include "../amge_structured.hpp"
 #include "../mf_laplace.hpp"
 #include "../sparse_matrix_device.hpp"
@@ -204,6 +205,7 @@ private:
 
   std::shared_ptr<HipOperator const> _hip_operator;
   std::string _type;
+  std::string _eig_start = "hashed";
   double _lambda_min = 1., _lambda_max = 1.;
   std::vector<std::pair<double, double>> _coefficients; // (alpha_k, beta_k)
   mutable std::shared_ptr<DVector> _scratch_a, _scratch_b;
@@ -214,13 +216,34 @@ private:
 class HipSolver : public Solver<DVector>
 {
 public:
-  HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const> op, std::shared_ptr<ptree const> params);
+  // `near_null` (optional): near-null-space vector of the operator for solver.type amg
+  HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const> op, std::shared_ptr<ptree const> params,
+            std::vector<double> const *near_null = nullptr, AmgGridHint const *grid = nullptr);
 
   void apply(DVector const &b, DVector &x) const override;
   std::string const &type() const { return _solver; }
   int n_iterations() const { return _n_iterations; }
 
+  // multilevel coarse solver (solver.type amg): one V-cycle per apply over an aggregation hierarchy
+  struct AmgLevel
+  {
+    std::shared_ptr<HipMatrixOperator> a;
+    std::shared_ptr<HipMatrixOperator> restrictor; // P^T as a matrix; its (lazy) transpose is P
+    std::shared_ptr<HipMatrixOperator> prolongator;
+    std::shared_ptr<HipSmoother> smoother;
+    mutable std::shared_ptr<DVector> res, b_coarse, x_coarse;
+  };
+  std::vector<AmgLevel> const &amg_levels() const { return _amg; }
+
 private:
+  void amg_cycle(size_t level, DVector const &b, DVector &x) const;
+  void setup_direct(std::shared_ptr<SparseMatrixDevice<double>> matrix, DeviceBuffer<double> &lu,
+                    DeviceBuffer<int32_t> &perm) const;
+  std::vector<AmgLevel> _amg;
+  int _amg_cycles = 1;
+  DeviceBuffer<double> _amg_lu;
+  DeviceBuffer<int32_t> _amg_perm;
+
   HipHandle &_handle;
   std::string _solver;
   std::shared_ptr<HipMatrixOperator const> _matrix_operator;
@@ -255,9 +278,17 @@ public:
   std::shared_ptr<Solver<VectorType>> build_coarse_solver(std::shared_ptr<Operator<VectorType> const> op,
                                                           std::shared_ptr<ptree const> params) override;
 
+  void set_coarse_space_hint(std::shared_ptr<Operator<VectorType> const> restrictor) override
+  {
+    _restrictor_hint = restrictor;
+  }
+
 private:
   HipHandle &_handle;
   std::shared_ptr<Operator<VectorType>> _operator;
+  std::shared_ptr<Operator<VectorType> const> _restrictor_hint;
+  std::shared_ptr<Operator<VectorType> const> _own_restrictor; // the one build_restrictor made (grid known)
+  AmgGridHint _grid_hint;
 };
 
 // x = U^{-1} L^{-1} P b with the packed column-major LU of dense_lu_factor (getrs)

@@ -135,6 +135,13 @@ def load() -> C.CDLL:
         "mfmg_hip_host_build_restrictor": (C.c_int, [P(MeshDesc), C.c_char_p, C.c_int, P(vp)]),
         "mfmg_hip_host_galerkin": (C.c_int, [P(MeshDesc), C.c_int, i64, i64, vp, vp, vp, P(vp)]),
         "mfmg_hip_host_params_get": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, sz]),
+        "mfmg_hip_host_amg_build": (C.c_int, [i64, i64, vp, vp, vp, vp, vp, vp, vp, C.c_char_p, P(vp)]),
+        "mfmg_hip_host_amg_n_levels": (C.c_int, [vp, P(i32)]),
+        "mfmg_hip_host_amg_get": (C.c_int, [vp, i32, i32, P(vp)]),
+        "mfmg_hip_host_amg_destroy": (C.c_int, [vp]),
+        "mfmg_hip_hierarchy_coarse_amg_levels": (C.c_int, [vp, P(i32)]),
+        "mfmg_hip_hierarchy_coarse_amg_get": (C.c_int, [vp, i32, i32, P(vp)]),
+        "mfmg_hip_hierarchy_coarse_amg_smoother": (C.c_int, [vp, i32, P(i32), P(dbl), P(dbl)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -422,13 +422,21 @@ def dealii_chebyshev_initial_guess(n: int, first_local: int = 0) -> np.ndarray:
     return v - v.mean()
 
 
+def hashed_initial_guess(n: int) -> np.ndarray:
+    """Numbering-independent start vector used by the HIP build by default (Knuth multiplicative hash of
+    the DoF id, mean-free): deal.II's (i % 11) pattern degenerates to a plane wave for lexicographic
+    numberings with row lengths such as 128 or 256 and then under-estimates lambda_max."""
+    v = ((np.arange(n, dtype=np.uint64) * np.uint64(2654435761)) & np.uint64(0xffffffff)).astype(float) / 4294967296.0
+    return v - v.mean()
+
+
 def dealii_chebyshev_eigen_estimate(apply_A, dinv, n, n_iter=8, residual=1e-2,
-                                    constrained=None):
+                                    constrained=None, start="dealii"):
     """Restates PreconditionChebyshev::estimate_eigenvalues (deal.II 9.1): CG on
     A with preconditioner D^{-1}, rhs = initial guess, at most eig_cg_n_iterations
     steps (or until |r| < eig_cg_residual*|rhs|), eigenvalues of the Lanczos
     tridiagonal; returns (min_est, 1.2*max_est)."""
-    rhs = dealii_chebyshev_initial_guess(n)
+    rhs = dealii_chebyshev_initial_guess(n) if start == "dealii" else hashed_initial_guess(n)
     if constrained is not None:
         rhs = np.where(constrained, 0.0, rhs)
     x = np.zeros(n)
@@ -463,11 +471,11 @@ def dealii_chebyshev_eigen_estimate(apply_A, dinv, n, n_iter=8, residual=1e-2,
 
 
 def dealii_chebyshev_params(apply_A, dinv, n, degree=1, smoothing_range=0.0,
-                            constrained=None) -> ChebyshevParams:
+                            constrained=None, start="dealii") -> ChebyshevParams:
     """AdditionalData defaults of deal.II 9.1 (degree=1, smoothing_range=0,
     eig_cg_n_iterations=8, eig_cg_residual=1e-2) as consumed by
     source/dealii/dealii_matrix_free_smoother.cc:34-56."""
-    mn, mx = dealii_chebyshev_eigen_estimate(apply_A, dinv, n, constrained=constrained)
+    mn, mx = dealii_chebyshev_eigen_estimate(apply_A, dinv, n, constrained=constrained, start=start)
     alpha = mx / smoothing_range if smoothing_range > 1.0 else min(0.9 * mx, mn)
     return ChebyshevParams(degree=degree, lambda_max=mx, lambda_min=alpha)
 
@@ -727,6 +735,43 @@ def pcg_coarse_solver(Ac: sp.csr_matrix, n_iter: int):
             beta = rz_new / rz
             rz = rz_new
             p = z + beta * p
+        return x
+
+    return solve
+
+
+def amg_coarse_solver(levels, n_cycles: int = 1):
+    """Build-defined multilevel coarse 'solve' (the role ML / AMGx play upstream,
+    source/dealii/dealii_solver.cc:48-66, source/cuda/cuda_solver.cu:204-445): `n_cycles` V-cycles from a
+    zero guess over a given aggregation hierarchy.  `levels` = [(A_l, P_l or None, (degree, lmin, lmax)
+    or None)], the last level is solved by dense LU.  Every level runs the recursion of
+    Hierarchy::apply (hierarchy.hpp:246-309) with restrictor P_l^T and a Chebyshev smoother."""
+    data = []
+    for (A, P, cheb) in levels:
+        A = A.tocsr()
+        if P is None:
+            data.append((A, None, None, sla.lu_factor(A.toarray())))
+        else:
+            dinv = 1.0 / A.diagonal()
+            data.append((A, P.tocsr(), (dinv, ChebyshevParams(cheb[0], cheb[2], cheb[1])), None))
+
+    def cycle(l, b):
+        A, P, sm, lu = data[l]
+        if P is None:
+            return sla.lu_solve(lu, b)
+        dinv, p = sm
+        x = np.zeros_like(b)
+        x = chebyshev_smoother_apply(lambda z: A @ z, dinv, p, b, x)
+        res = A @ x - b
+        xc = cycle(l + 1, P.T @ res)
+        x = x - P @ xc
+        return chebyshev_smoother_apply(lambda z: A @ z, dinv, p, b, x)
+
+    def solve(b):
+        x = cycle(0, b)
+        A0 = data[0][0]
+        for _ in range(n_cycles - 1):
+            x = x - cycle(0, A0 @ x - b)
         return x
 
     return solve

@@ -169,9 +169,114 @@ void chebyshev_smoother(const Mesh &m, const double *dinv, int degree, double lm
   for (int64_t i = 0; i < n; ++i)
     x[i] -= dst[i];
 }
+// x <- x - B^{-1}(A x - b) on a CSR level, same polynomial as chebyshev_smoother
+void csr_chebyshev_smoother(const Csr &A, const double *dinv, int degree, double lmin, double lmax, const double *b,
+                            double *x, std::vector<double> &r, std::vector<double> &dst, std::vector<double> &up1,
+                            std::vector<double> &up2)
+{
+  const int64_t n = A.n_rows;
+  csr_spmv(n, A.rp, A.col, A.val, x, r.data());
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i)
+    r[i] -= b[i];
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i)
+  {
+    up1[i] = dinv[i] * r[i] / theta;
+    dst[i] = up1[i];
+  }
+  if (degree >= 2 && std::abs(delta) >= 1e-40)
+  {
+    double rhok = delta / theta;
+    const double sigma = theta / delta;
+    for (int k = 0; k < degree - 1; ++k)
+    {
+      csr_spmv(n, A.rp, A.col, A.val, dst.data(), up2.data());
+      const double rhokp = 1. / (2. * sigma - rhok);
+      const double f1 = rhokp * rhok, f2 = 2. * rhokp / delta;
+      rhok = rhokp;
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i)
+      {
+        up1[i] = f1 * up1[i] - f2 * dinv[i] * (up2[i] - r[i]);
+        dst[i] += up1[i];
+      }
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i)
+    x[i] -= dst[i];
+}
+
+struct AmgLevelData
+{
+  Csr A, P, Pt;
+  int degree;
+  double lmin, lmax;
+  std::vector<double> dinv, r, dst, up1, up2, res, bc, xc;
+  std::vector<double> lu; // dense, row-major (last level)
+  std::vector<int> perm;
+};
+
+void amg_cycle(std::vector<AmgLevelData> &L, size_t l, const double *b, double *x)
+{
+  AmgLevelData &lv = L[l];
+  const int64_t n = lv.A.n_rows;
+  if (l + 1 == L.size())
+  {
+    // dense LU solve (getrs)
+    std::vector<double> y(n);
+    for (int64_t i = 0; i < n; ++i)
+      y[i] = b[lv.perm[i]];
+    for (int64_t i = 0; i < n; ++i)
+      for (int64_t j = 0; j < i; ++j)
+        y[i] -= lv.lu[i * n + j] * y[j];
+    for (int64_t i = n - 1; i >= 0; --i)
+    {
+      for (int64_t j = i + 1; j < n; ++j)
+        y[i] -= lv.lu[i * n + j] * y[j];
+      y[i] /= lv.lu[i * n + i];
+    }
+    std::copy(y.begin(), y.end(), x);
+    return;
+  }
+  const int64_t nc = lv.Pt.n_rows;
+  csr_chebyshev_smoother(lv.A, lv.dinv.data(), lv.degree, lv.lmin, lv.lmax, b, x, lv.r, lv.dst, lv.up1, lv.up2);
+  csr_spmv(n, lv.A.rp, lv.A.col, lv.A.val, x, lv.res.data());
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i)
+    lv.res[i] -= b[i];
+  csr_spmv(nc, lv.Pt.rp, lv.Pt.col, lv.Pt.val, lv.res.data(), lv.bc.data());
+  std::fill(lv.xc.begin(), lv.xc.end(), 0.);
+  amg_cycle(L, l + 1, lv.bc.data(), lv.xc.data());
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i)
+  {
+    double sum = 0.;
+    for (int p = lv.P.rp[i]; p < lv.P.rp[i + 1]; ++p)
+      sum += lv.P.val[p] * lv.xc[lv.P.col[p]];
+    x[i] -= sum;
+  }
+  csr_chebyshev_smoother(lv.A, lv.dinv.data(), lv.degree, lv.lmin, lv.lmax, b, x, lv.r, lv.dst, lv.up1, lv.up2);
+}
 } // namespace
 
 extern "C" {
+
+// level descriptor passed from Python (ctypes.Structure with the same layout)
+struct OracleCsr
+{
+  int64_t n_rows, n_cols;
+  const int32_t *rp, *col;
+  const double *val;
+};
+struct OracleAmgLevel
+{
+  OracleCsr A, P, Pt;
+  int32_t degree;
+  double lmin, lmax;
+};
 
 int oracle_num_threads()
 {
@@ -230,7 +335,8 @@ void oracle_vcycles(const int *n, const double *h, const int32_t *cell_dofs, con
                     const double *dinv, int degree, double lmin, double lmax, int64_t n_coarse, const int32_t *r_rp,
                     const int32_t *r_col, const double *r_val, const int32_t *rt_rp, const int32_t *rt_col,
                     const double *rt_val, const int32_t *ac_rp, const int32_t *ac_col, const double *ac_val,
-                    int coarse_iters, const double *b, double *x, int n_cycles, double *history)
+                    int coarse_iters, int n_amg_levels, const OracleAmgLevel *amg_levels, const double *b, double *x,
+                    int n_cycles, double *history)
 {
   Mesh m = make_mesh(n, h, cell_dofs, coef, con);
   const int64_t nf = m.n_dofs, ncs = n_coarse;
@@ -244,6 +350,66 @@ void oracle_vcycles(const int *n, const double *h, const int32_t *cell_dofs, con
       if (ac_col[p] == i)
         d = ac_val[p];
     cdinv[i] = 1. / d;
+  }
+  // multilevel coarse solver (n_amg_levels > 0): level data + dense LU of the last level
+  std::vector<AmgLevelData> amg(n_amg_levels);
+  for (int l = 0; l < n_amg_levels; ++l)
+  {
+    AmgLevelData &lv = amg[l];
+    auto conv = [](OracleCsr const &c) { return Csr{c.n_rows, c.rp, c.col, c.val}; };
+    lv.A = conv(amg_levels[l].A);
+    lv.P = conv(amg_levels[l].P);
+    lv.Pt = conv(amg_levels[l].Pt);
+    lv.P.n_rows = amg_levels[l].P.n_rows;
+    lv.degree = amg_levels[l].degree;
+    lv.lmin = amg_levels[l].lmin;
+    lv.lmax = amg_levels[l].lmax;
+    const int64_t n = lv.A.n_rows;
+    if (l + 1 < n_amg_levels)
+    {
+      lv.dinv.assign(n, 1.);
+      for (int64_t i = 0; i < n; ++i)
+        for (int p = lv.A.rp[i]; p < lv.A.rp[i + 1]; ++p)
+          if (lv.A.col[p] == i)
+            lv.dinv[i] = 1. / lv.A.val[p];
+      for (auto *v : {&lv.r, &lv.dst, &lv.up1, &lv.up2, &lv.res})
+        v->assign(n, 0.);
+      lv.bc.assign(amg_levels[l].P.n_cols, 0.);
+      lv.xc.assign(amg_levels[l].P.n_cols, 0.);
+    }
+    else
+    {
+      lv.lu.assign((size_t)n * n, 0.);
+      for (int64_t i = 0; i < n; ++i)
+        for (int p = lv.A.rp[i]; p < lv.A.rp[i + 1]; ++p)
+          lv.lu[i * n + lv.A.col[p]] += lv.A.val[p];
+      lv.perm.resize(n);
+      for (int64_t i = 0; i < n; ++i)
+        lv.perm[i] = (int)i;
+      for (int64_t c = 0; c < n; ++c)
+      {
+        int64_t piv = c;
+        for (int64_t r2 = c + 1; r2 < n; ++r2)
+          if (std::abs(lv.lu[r2 * n + c]) > std::abs(lv.lu[piv * n + c]))
+            piv = r2;
+        if (piv != c)
+        {
+          for (int64_t cc = 0; cc < n; ++cc)
+            std::swap(lv.lu[piv * n + cc], lv.lu[c * n + cc]);
+          std::swap(lv.perm[piv], lv.perm[c]);
+        }
+        const double d = 1. / lv.lu[c * n + c];
+#pragma omp parallel for schedule(static) if (n - c > 256)
+        for (int64_t r2 = c + 1; r2 < n; ++r2)
+        {
+          const double f = lv.lu[r2 * n + c] * d;
+          lv.lu[r2 * n + c] = f;
+          if (f != 0.)
+            for (int64_t cc = c + 1; cc < n; ++cc)
+              lv.lu[r2 * n + cc] -= f * lv.lu[c * n + cc];
+        }
+      }
+    }
   }
   auto resnorm = [&]() {
     mf_apply(m, x, res.data());
@@ -270,8 +436,10 @@ void oracle_vcycles(const int *n, const double *h, const int32_t *cell_dofs, con
     for (int64_t i = 0; i < nf; ++i)
       res[i] -= b[i]; // negative residual
     csr_spmv(ncs, r_rp, r_col, r_val, res.data(), bc.data());
-    // coarse PCG from zero
     std::fill(xc.begin(), xc.end(), 0.);
+    if (n_amg_levels > 0)
+      amg_cycle(amg, 0, bc.data(), xc.data());
+    // coarse PCG from zero (coarse_iters = 0 when the multilevel solver is used)
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < ncs; ++i)
     {

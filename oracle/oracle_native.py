@@ -106,9 +106,29 @@ def csr_spmv(A, x):
     return y
 
 
+class _Csr(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_cols", C.c_int64), ("rp", C.c_void_p), ("col", C.c_void_p),
+                ("val", C.c_void_p)]
+
+
+class _AmgLevel(C.Structure):
+    _fields_ = [("A", _Csr), ("P", _Csr), ("Pt", _Csr), ("degree", C.c_int32), ("lmin", C.c_double),
+                ("lmax", C.c_double)]
+
+
+def _csr_struct(M, keep):
+    M = M.tocsr()
+    M.sort_indices()
+    arrs = (np.ascontiguousarray(M.indptr, dtype=np.int32), np.ascontiguousarray(M.indices, dtype=np.int32),
+            np.ascontiguousarray(M.data, dtype=np.float64))
+    keep.append(arrs)
+    return _Csr(M.shape[0], M.shape[1], arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data)
+
+
 def vcycles(n, h, cell_dofs, coef, con, dinv, degree, lmin, lmax, R, Ac, coarse_iters, b, x0, n_cycles,
-            want_history=True):
-    """n_cycles V-cycles (matrix-free fine level, Chebyshev(degree), PCG(coarse_iters) coarse 'solve');
+            want_history=True, amg_levels=None):
+    """n_cycles V-cycles (matrix-free fine level, Chebyshev(degree); coarse 'solve' = PCG(coarse_iters), or
+    one V-cycle of the aggregation hierarchy `amg_levels` = [(A_l, P_l or None, (deg, lmin, lmax) or None)]);
     returns (x, history or None)."""
     lib = load()
     n_a = np.asarray(n, dtype=np.int32)
@@ -130,7 +150,26 @@ def vcycles(n, h, cell_dofs, coef, con, dinv, degree, lmin, lmax, R, Ac, coarse_
     b = np.ascontiguousarray(b, dtype=np.float64)
     x = np.array(x0, dtype=np.float64, copy=True)
     hist = np.zeros(n_cycles + 1) if want_history else None
+    keep = []
+    n_amg = 0
+    lv_arr = None
+    if amg_levels:
+        import scipy.sparse as sp
+        n_amg = len(amg_levels)
+        lv_arr = (_AmgLevel * n_amg)()
+        for l, (A_l, P_l, cheb) in enumerate(amg_levels):
+            lv_arr[l].A = _csr_struct(A_l, keep)
+            if P_l is not None:
+                lv_arr[l].P = _csr_struct(P_l, keep)
+                lv_arr[l].Pt = _csr_struct(P_l.T, keep)
+                lv_arr[l].degree, lv_arr[l].lmin, lv_arr[l].lmax = cheb
+            else:
+                empty = sp.csr_matrix((A_l.shape[0], 0))
+                lv_arr[l].P = _csr_struct(empty, keep)
+                lv_arr[l].Pt = _csr_struct(empty.T, keep)
+        coarse_iters = 0
     lib.oracle_vcycles(_p(n_a), _p(h_a), _p(cd), _p(co), _p(cn), _p(dinv), C.c_int(degree), C.c_double(lmin),
                        C.c_double(lmax), C.c_int64(R.shape[0]), *[_p(a) for a in arrs], C.c_int(coarse_iters),
-                       _p(b), _p(x), C.c_int(n_cycles), _p(hist) if want_history else None)
+                       C.c_int(n_amg), lv_arr, _p(b), _p(x), C.c_int(n_cycles),
+                       _p(hist) if want_history else None)
     return x, hist

@@ -132,6 +132,46 @@ def test_host_restrictor_assembled_default_matches_oracle(mfmg_lib, n):
     assert abs(Ac - Ro @ A @ Ro.T).max() < 1e-11 * abs(Ac).max()
 
 
+def test_host_amg_hierarchy_properties(mfmg_lib):
+    """Smoothed-aggregation hierarchy of the multilevel coarse solver: Galerkin consistency, coarsening by
+    8 per level with the components kept apart, constants reproduced by the tentative space."""
+    n = (16, 16, 16)
+    p = M.LaplaceProblem(n)
+    R = M.host_build_restrictor(p, PRM, matrix_free=True)
+    Ac = M.host_galerkin(p, R, "matrix_free")
+    rows = np.arange(Ac.shape[0])
+    B = np.where(rows % 2 == 0, np.asarray(R.sum(axis=1)).ravel(), 1.0)
+    levels = M.host_amg_build(Ac, B, {"solver": {"amg": {"coarsest_size": 100}}}, grid_dims=[8, 8, 8],
+                              node_of_row=rows // 2, component_of_row=rows % 2)
+    sizes = [A.shape[0] for A, _ in levels]
+    assert sizes == [1024, 128, 16]
+    for l in range(len(levels) - 1):
+        A, P = levels[l]
+        An = levels[l + 1][0]
+        assert P.shape == (A.shape[0], An.shape[0])
+        G = (P.T @ A @ P).tocsr()
+        assert abs(G - An).max() < 1e-13 * abs(An).max()
+        assert abs(An - An.T).max() < 1e-13 * abs(An).max()
+    assert levels[-1][1] is None
+    # the multilevel cycle (restated in the oracle) is a contraction for the coarse problem
+    lv = []
+    for (A, P) in levels:
+        if P is None:
+            lv.append((A, None, None))
+        else:
+            mn, mx = O.dealii_chebyshev_eigen_estimate(lambda z: A @ z, 1.0 / A.diagonal(), A.shape[0], n_iter=10,
+                                                       start="hashed")
+            lv.append((A, P, (2, 1.2 * mx / 10.0, 1.2 * mx)))
+    solve = O.amg_coarse_solver(lv)
+    rhs = Ac @ np.random.default_rng(0).random(Ac.shape[0])
+    x = solve(rhs)
+    e0 = np.linalg.norm(rhs)
+    assert np.linalg.norm(rhs - Ac @ x) < 0.6 * e0
+    # without the geometric hint the greedy strength-of-connection aggregation is used
+    alg = M.host_amg_build(Ac, B, {"solver": {"amg": {"coarsest_size": 100}}})
+    assert alg[0][0].shape[0] == 1024 and alg[1][0].shape[0] < 1024
+
+
 def test_host_rejects_unstructured_index_array(mfmg_lib):
     p = M.LaplaceProblem((3, 3, 3))
     p.cell_dofs[5, 2] = p.cell_dofs[5, 3]          # break the shared-vertex structure

@@ -75,15 +75,16 @@ def test_matrix_free_chebyshev_vcycle_history(ctx, n, material, degree):
     assert rate_o < 0.5
 
 
-def test_eigenvalue_estimate_matches_dealii_restatement(ctx):
+@pytest.mark.parametrize("start", ["dealii", "hashed"])
+def test_eigenvalue_estimate_matches_dealii_restatement(ctx, start):
     n = (8, 8, 8)
     mesh = O.StructuredMesh(n)
     coef = O.coefficient_table(mesh, "linear")
     mf = O.MatrixFreeLaplace(mesh, coef)
     h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", M.LaplaceProblem(n, "linear", device="cuda"),
-                    base_params(smoother={"type": "Chebyshev", "degree": 2}))
+                    base_params(smoother={"type": "Chebyshev", "degree": 2, "eig_start_vector": start}))
     deg, lmin, lmax = h.smoother_info()
-    p = O.dealii_chebyshev_params(mf.vmult, mf.diagonal_inverse(), mesh.n_dofs, degree=2)
+    p = O.dealii_chebyshev_params(mf.vmult, mf.diagonal_inverse(), mesh.n_dofs, degree=2, start=start)
     assert lmax == pytest.approx(p.lambda_max, rel=1e-10)
     assert lmin == pytest.approx(p.lambda_min, rel=1e-10)
 
@@ -207,6 +208,65 @@ def test_pcg_coarse_solver_parity(ctx):
     op = M.MatrixFreeLaplace(ctx, prob)
     res_g, _ = gpu_history(ctx, h, lambda y, x: op.vmult(y, x), b, x0, n_cycles=10)
     np.testing.assert_allclose(res_g, res_o, rtol=1e-9, atol=HIST_ATOL)
+
+
+def test_smoother_bounds_cover_the_spectrum_at_row_length_128(ctx):
+    """lambda_max(D^-1 A) of the Q1 Laplacian is 1.5; the hashed start vector must not under-estimate
+    it on a lexicographic mesh with 128 DoFs per row (deal.II's i % 11 pattern does: 1.08)."""
+    prob = M.LaplaceProblem((127, 15, 15), device="cuda")
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob,
+                    base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0},
+                                solver={"type": "pcg", "n_iterations": 5}))
+    _, lmin, lmax = h.smoother_info()
+    assert lmax > 1.45
+    # and the cycle contracts
+    x = torch.rand(prob.n_dofs, dtype=torch.float64, device="cuda") * (prob.constrained == 0)
+    b = torch.zeros_like(x)
+    op = M.MatrixFreeLaplace(ctx, prob)
+    r = torch.empty_like(x)
+    norms = []
+    for _ in range(4):
+        op.vmult(r, x)
+        norms.append(ctx.l2_norm(r))
+        h.apply(b, x)
+    assert norms[3] < norms[2] < norms[1] < norms[0]
+
+
+@pytest.mark.parametrize("n_cycles", [1, 2])
+def test_amg_coarse_solver_parity(ctx, n_cycles):
+    """solver.type amg: the V-cycle over the aggregation hierarchy on the GPU against its oracle restatement,
+    run on the level matrices downloaded from the product."""
+    n = (32, 32, 32)
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "constant")
+    con = mesh.constrained_mask()
+    mf = O.MatrixFreeLaplace(mesh, coef)
+    prob = M.LaplaceProblem(n, device="cuda")
+    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0},
+                         solver={"type": "amg", "amg": {"coarsest_size": 600, "n_cycles": n_cycles}})
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    levels = h.coarse_amg_levels()
+    assert [A.shape[0] for A, _, _ in levels] == [8192, 1024, 128]
+    deg, lmin, lmax = h.smoother_info()
+    R = h.restrictor().to_scipy()
+    # coarse solve alone
+    solve = O.amg_coarse_solver(levels, n_cycles)
+    bc = np.random.default_rng(1).random(R.shape[0])
+    xc = torch.empty(R.shape[0], dtype=torch.float64, device="cuda")
+    h.coarse_apply(dev(bc), xc)
+    ref = solve(bc)
+    assert np.abs(xc.cpu().numpy() - ref).max() < 1e-10 * np.abs(ref).max()
+    # whole cycle
+    p = O.ChebyshevParams(deg, lmax, lmin)
+    smoother = lambda b, x: O.chebyshev_smoother_apply(mf.vmult, mf.diagonal_inverse(), p, b, x)
+    ho = O.TwoLevelHierarchy(mf.vmult, smoother, R, solve, 1, False)
+    x0 = O.random_initial_guess(mesh.n_dofs, con)
+    b = np.zeros(mesh.n_dofs)
+    res_o, rate, _ = O.vcycle_history(ho, mf.vmult, b, x0, n_cycles=10)
+    op = M.MatrixFreeLaplace(ctx, prob)
+    res_g, _ = gpu_history(ctx, h, lambda y, x: op.vmult(y, x), b, x0, n_cycles=10)
+    np.testing.assert_allclose(res_g, res_o, rtol=1e-9, atol=HIST_ATOL)
+    assert rate < 0.35
 
 
 def test_error_conventions(ctx):
