@@ -159,7 +159,7 @@ def main():
         "agglomeration": {"partitioner": "block", "nx": 2, "ny": 2, "nz": 2},
         "smoother": {"type": "Chebyshev", "degree": args.degree, "smoothing_range": 20.0, "n_smoothing_steps": 1},
         "solver": ({"type": "pcg", "n_iterations": args.coarse_iters} if args.coarse == "pcg" else
-                   {"type": "amg", "amg": {"smoother_degree": 2, "smoothing_range": 10.0, "n_cycles": 1}}),
+                   {"type": "amg", "amg": {"smoother_degree": 1, "smoothing_range": 4.0, "n_cycles": 1}}),
         "is preconditioner": False,
         "max levels": 2,
     }
@@ -213,7 +213,7 @@ def main():
     value = world * n_fine / (dt / args.steps)
 
     coarse_desc = (f"{args.coarse_iters} Jacobi-PCG steps" if args.coarse == "pcg" else
-                   "one V-cycle of a smoothed-aggregation hierarchy (Chebyshev(2) smoothers, dense LU at the bottom)")
+                   "one V-cycle of a smoothed-aggregation hierarchy (Chebyshev(1) = damped-Jacobi smoothers, dense LU at the bottom)")
     if rank == 0:
         achieved = (k_bytes / launches) / (k_ms / launches * 1e-3) / 1e9 if launches else 0.0
         out = {

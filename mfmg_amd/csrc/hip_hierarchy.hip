@@ -579,8 +579,8 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
     auto host_levels = build_aggregation_hierarchy(std::move(A0), std::move(b0), opts, geometric ? grid : nullptr);
     auto smoother_params = std::make_shared<ptree>();
     smoother_params->put("smoother.type", "Chebyshev");
-    smoother_params->put("smoother.degree", this->_params->get("solver.amg.smoother_degree", 2));
-    smoother_params->put("smoother.smoothing_range", this->_params->get("solver.amg.smoothing_range", 10.));
+    smoother_params->put("smoother.degree", this->_params->get("solver.amg.smoother_degree", 1));
+    smoother_params->put("smoother.smoothing_range", this->_params->get("solver.amg.smoothing_range", 4.));
     smoother_params->put("smoother.eig_cg_n_iterations", this->_params->get("solver.amg.eig_cg_n_iterations", 10));
     _amg.resize(host_levels.size());
     for (size_t l = 0; l < host_levels.size(); ++l)
