@@ -60,6 +60,28 @@ int mfmg_hip_context_destroy(mfmg_hip_context_t ctx);
 int mfmg_hip_context_synchronize(mfmg_hip_context_t ctx);
 void *mfmg_hip_context_stream(mfmg_hip_context_t ctx);
 
+/* ---- distributed runs: one process per GPU, slab decomposition of the mesh along z ----
+ * Replaces deal.II's distributed::Vector ghost exchange inside MatrixFree::cell_loop and the all-gather of
+ * the whole vector in front of every SpMV on the CUDA path (source/cuda/utils.cu:363-482,
+ * include/mfmg/cuda/sparse_matrix_device.templates.cuh:104-138).  The local mesh of a rank is its owned
+ * cell slab plus `ghost_cells_low/high` (0 or 2 = one agglomerate) cell layers of its neighbours; local DoF
+ * numbering must be lexicographic; ghost (not owned) DoFs carry the value 2 in mfmg_hip_mesh_desc.constrained.
+ * Before every operator application the library copies the boundary layers of the input vector into the
+ * registered device staging buffers, calls `exchange(user, space, hip_stream)` -- which must enqueue, on that
+ * stream, send_low -> rank-1, send_high -> rank+1 and the matching receives into recv_low / recv_high -- and
+ * copies the received layers into the ghost layers.  space 1 = fine DoFs (one plane), 2 = first coarse level
+ * (one layer of agglomerates).  `allreduce` sums `n` doubles over all ranks in place (setup and norms only). */
+typedef int (*mfmg_hip_exchange_fn)(void *user, int space, void *hip_stream);
+typedef int (*mfmg_hip_allreduce_fn)(void *user, double *values, int n);
+int mfmg_hip_context_set_communicator(mfmg_hip_context_t ctx, int32_t rank, int32_t n_ranks, int32_t ghost_cells_low,
+                                      int32_t ghost_cells_high, mfmg_hip_exchange_fn exchange,
+                                      mfmg_hip_allreduce_fn allreduce, void *user);
+int mfmg_hip_context_set_halo_buffers(mfmg_hip_context_t ctx, int32_t space, int64_t n_elems, double *send_low,
+                                      double *send_high, double *recv_low, double *recv_high);
+/* layout of a distributed space after the hierarchy was built: entries per layer, local layers, owned range */
+int mfmg_hip_context_halo_layout(mfmg_hip_context_t ctx, int32_t space, int64_t *layer_elems, int64_t *n_layers,
+                                 int64_t *owned_begin, int64_t *owned_count);
+
 /* Per-kernel timing with HIP events recorded on the launch stream (the reference only has the
  * wall-clock dealii::TimerOutput sections, include/mfmg/common/hierarchy.hpp:36-47).  Kernel names:
  * "mf_laplace_kernel", "csr_spmv_kernel".  `algorithmic_bytes` sums SURVEY.md 8d's per-launch figures. */

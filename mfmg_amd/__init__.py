@@ -6,8 +6,9 @@ from . import lib
 from .api import (Context, Hierarchy, MatrixFreeLaplace, SparseMatrixDevice, host_assemble_matrix,
                   host_amg_build, host_build_restrictor, host_galerkin, params_to_info)
 from .laplace import LaplaceProblem, material_property
+from .distributed import HaloTransport, SlabPartition
 
 __all__ = [
     "lib", "Context", "Hierarchy", "MatrixFreeLaplace", "SparseMatrixDevice", "LaplaceProblem",
-    "material_property", "host_assemble_matrix", "host_build_restrictor", "host_galerkin", "host_amg_build", "params_to_info",
+    "material_property", "SlabPartition", "HaloTransport", "host_assemble_matrix", "host_build_restrictor", "host_galerkin", "host_amg_build", "params_to_info",
 ]

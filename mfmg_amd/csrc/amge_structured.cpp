@@ -212,7 +212,7 @@ void operator_row(StructuredMesh const &mesh, std::vector<double> const &Kq, Con
   const int nc = mesh.nc();
   const int dim = mesh.dim;
   const int32_t g = mesh.node_dof[mesh.node_index(i, j, k)];
-  const bool con = mesh.constrained[g];
+  const bool con = mesh.constrained[g] == 1;
   if (con && sem == ConstraintSemantics::matrix_free)
   {
     cols.push_back(g);
@@ -256,7 +256,7 @@ void operator_row(StructuredMesh const &mesh, std::vector<double> const &Kq, Con
     if (ni < 0 || nj < 0 || nk < 0 || ni >= mesh.N[0] || nj >= mesh.N[1] || (dim == 3 && nk >= mesh.N[2]))
       continue;
     const int32_t gp = mesh.node_dof[mesh.node_index(ni, nj, nk)];
-    if (mesh.constrained[gp])
+    if (mesh.constrained[gp] == 1)
       continue;
     cols.push_back(gp);
     vals.push_back(st[t]);
@@ -357,7 +357,7 @@ std::vector<double> operator_diagonal(StructuredMesh const &mesh, ConstraintSema
       }
   if (sem == ConstraintSemantics::matrix_free)
     for (int64_t g = 0; g < mesh.n_dofs; ++g)
-      if (mesh.constrained[g])
+      if (mesh.constrained[g] == 1)
         diag[g] = 1.;
   return diag;
 }
@@ -542,7 +542,7 @@ HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<doub
           {
             const int32_t g = mesh.node_dof[mesh.node_index(lo[0] + i, lo[1] + j, (dim == 3) ? lo[2] + k : 0)];
             gl[lidx(i, j, k)] = g;
-            lcon[lidx(i, j, k)] = mesh.constrained[g];
+            lcon[lidx(i, j, k)] = (mesh.constrained[g] == 1);
           }
       // local (Neumann) matrix from the cell matrices of the agglomerate
       A.assign((size_t)nloc * nloc, 0.);

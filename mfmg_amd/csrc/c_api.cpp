@@ -125,6 +125,65 @@ int mfmg_hip_context_synchronize(mfmg_hip_context_t ctx)
 
 void *mfmg_hip_context_stream(mfmg_hip_context_t ctx) { return ctx ? ctx->handle->stream : nullptr; }
 
+// ---- distributed runs -----------------------------------------------------------------
+int mfmg_hip_context_set_communicator(mfmg_hip_context_t ctx, int32_t rank, int32_t n_ranks, int32_t ghost_cells_low,
+                                      int32_t ghost_cells_high, mfmg_hip_exchange_fn exchange,
+                                      mfmg_hip_allreduce_fn allreduce, void *user)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    require(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "rank out of range");
+    require((ghost_cells_low == 0 || ghost_cells_low == 2) && (ghost_cells_high == 0 || ghost_cells_high == 2),
+            "ghost cell layers must be 0 or 2 (one agglomerate layer)");
+    require(n_ranks == 1 || (exchange && allreduce), "null transport callbacks");
+    require((ghost_cells_low == 2) == (rank > 0) && (ghost_cells_high == 2) == (rank + 1 < n_ranks),
+            "ghost layers must be present exactly towards existing neighbours");
+    HaloCommunicator &c = ctx->handle->comm;
+    c = HaloCommunicator();
+    c.rank = rank;
+    c.n_ranks = n_ranks;
+    c.ghost_cells_low = ghost_cells_low;
+    c.ghost_cells_high = ghost_cells_high;
+    c.exchange_fn = exchange;
+    c.allreduce_fn = allreduce;
+    c.user = user;
+  });
+}
+
+int mfmg_hip_context_set_halo_buffers(mfmg_hip_context_t ctx, int32_t space, int64_t n_elems, double *send_low,
+                                      double *send_high, double *recv_low, double *recv_high)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    require(space == 1 || space == 2, "space must be 1 (fine) or 2 (coarse)");
+    require(n_elems > 0 && send_low && send_high && recv_low && recv_high, "null staging buffer");
+    HaloSpace &s = ctx->handle->comm.spaces[space];
+    s.send_low = send_low;
+    s.send_high = send_high;
+    s.recv_low = recv_low;
+    s.recv_high = recv_high;
+    s.staging_elems = n_elems;
+  });
+}
+
+int mfmg_hip_context_halo_layout(mfmg_hip_context_t ctx, int32_t space, int64_t *layer_elems, int64_t *n_layers,
+                                 int64_t *owned_begin, int64_t *owned_count)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    require(space == 1 || space == 2, "space must be 1 (fine) or 2 (coarse)");
+    HaloSpace const &s = ctx->handle->comm.spaces[space];
+    if (layer_elems)
+      *layer_elems = s.layer_elems;
+    if (n_layers)
+      *n_layers = s.n_layers;
+    if (owned_begin)
+      *owned_begin = s.owned_begin;
+    if (owned_count)
+      *owned_count = s.owned_count;
+  });
+}
+
 // ---- per-kernel HIP-event timing (bench.py roofline leg) ---------------------------
 int mfmg_hip_profile_enable(mfmg_hip_context_t ctx, int enabled)
 {

@@ -225,6 +225,35 @@ struct KernelProfiler
   }
 };
 
+// ---- distributed vectors: slab decomposition along the slowest index ----
+// The reference gets its ghost exchange from deal.II's distributed::Vector inside
+// MatrixFree::cell_loop / Epetra Import (and all-gathers the whole vector on the CUDA path,
+// source/cuda/utils.cu:363-482).  Here a rank's vector is [ghost layers | owned layers | ghost layers],
+// layers contiguous; exchange() refreshes the one ghost layer on each side that operator applications
+// read, through staging buffers and a caller-provided transport (RCCL send/recv via torch.distributed).
+struct HaloSpace
+{
+  int64_t layer_elems = 0;   // entries per layer (a DoF plane, or a layer of agglomerates)
+  int64_t n_layers = 0;      // layers of the local vector
+  int64_t owned_begin = 0;   // first owned layer
+  int64_t owned_count = 0;   // owned layers
+  bool has_low = false, has_high = false;
+  double *send_low = nullptr, *send_high = nullptr, *recv_low = nullptr, *recv_high = nullptr; // device staging
+  int64_t staging_elems = 0;
+  bool configured() const { return layer_elems > 0; }
+};
+
+struct HaloCommunicator
+{
+  int rank = 0, n_ranks = 1;
+  int ghost_cells_low = 0, ghost_cells_high = 0; // ghost cell layers of the local mesh along z
+  int (*exchange_fn)(void *user, int space, void *stream) = nullptr;
+  int (*allreduce_fn)(void *user, double *values, int n) = nullptr;
+  void *user = nullptr;
+  HaloSpace spaces[3]; // [1] fine DoFs, [2] first coarse level
+  bool enabled() const { return n_ranks > 1; }
+};
+
 // ---- HipHandle: stream + reduction scratch; twin of CudaHandle
 //      (include/mfmg/cuda/cuda_handle.cuh:25-48): borrowed by every object built from it ----
 struct HipHandle
@@ -236,6 +265,40 @@ struct HipHandle
   DeviceBuffer<double> reduce_result;
   double *host_result = nullptr; // pinned
   KernelProfiler profiler;
+  HaloCommunicator comm;
+
+  // refresh the ghost layers of a distributed vector (no-op on one rank / for local spaces)
+  void exchange(int space, double *v)
+  {
+    if (!comm.enabled() || space <= 0)
+      return;
+    HaloSpace &s = comm.spaces[space];
+    if (!s.configured())
+      throw std::runtime_error("halo exchange requested for an unconfigured vector space");
+    if (s.staging_elems < s.layer_elems || comm.exchange_fn == nullptr)
+      throw std::runtime_error("halo staging buffers / transport were not registered");
+    const size_t bytes = (size_t)s.layer_elems * sizeof(double);
+    if (s.has_low)
+      MFMG_HIP_CHECK(hipMemcpyAsync(s.send_low, v + s.owned_begin * s.layer_elems, bytes, hipMemcpyDeviceToDevice, stream));
+    if (s.has_high)
+      MFMG_HIP_CHECK(hipMemcpyAsync(s.send_high, v + (s.owned_begin + s.owned_count - 1) * s.layer_elems, bytes,
+                                    hipMemcpyDeviceToDevice, stream));
+    if (comm.exchange_fn(comm.user, space, stream) != 0)
+      throw std::runtime_error("halo exchange transport failed");
+    if (s.has_low)
+      MFMG_HIP_CHECK(hipMemcpyAsync(v + (s.owned_begin - 1) * s.layer_elems, s.recv_low, bytes, hipMemcpyDeviceToDevice, stream));
+    if (s.has_high)
+      MFMG_HIP_CHECK(hipMemcpyAsync(v + (s.owned_begin + s.owned_count) * s.layer_elems, s.recv_high, bytes,
+                                    hipMemcpyDeviceToDevice, stream));
+  }
+  double allreduce_sum(double v)
+  {
+    if (!comm.enabled())
+      return v;
+    if (comm.allreduce_fn == nullptr || comm.allreduce_fn(comm.user, &v, 1) != 0)
+      throw std::runtime_error("all-reduce transport failed");
+    return v;
+  }
 
   // `s` is borrowed (nullptr = the legacy default stream the reference runs on); with
   // `create_own` the handle creates and owns a non-blocking stream instead.

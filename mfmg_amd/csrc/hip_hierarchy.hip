@@ -54,6 +54,41 @@ std::shared_ptr<SparseMatrixDevice<double>> upload(HipHandle &handle, HostCsr &&
 }
 } // namespace
 
+double distributed_dot(HipHandle &handle, int space, DVector const &x, DVector const &y)
+{
+  if (!handle.comm.enabled() || space <= 0)
+    return x * y;
+  HaloSpace const &s = handle.comm.spaces[space];
+  const int64_t off = s.owned_begin * s.layer_elems, n = s.owned_count * s.layer_elems;
+  const double local = vec::dot<double>(handle, n, x.get_values() + off, y.get_values() + off);
+  return handle.allreduce_sum(local);
+}
+
+namespace
+{
+// rows outside [row_begin, row_end) become empty: a rank computes only the rows it owns
+void empty_rows_outside(HostCsr &m, int64_t row_begin, int64_t row_end)
+{
+  std::vector<int32_t> rp(m.n_rows + 1, 0), cl;
+  std::vector<double> vl;
+  cl.reserve(m.col.size());
+  vl.reserve(m.val.size());
+  for (int64_t r = 0; r < m.n_rows; ++r)
+  {
+    if (r >= row_begin && r < row_end)
+      for (int p = m.row_ptr[r]; p < m.row_ptr[r + 1]; ++p)
+      {
+        cl.push_back(m.col[p]);
+        vl.push_back(m.val[p]);
+      }
+    rp[r + 1] = (int32_t)cl.size();
+  }
+  m.row_ptr.swap(rp);
+  m.col.swap(cl);
+  m.val.swap(vl);
+}
+} // namespace
+
 void dense_lu_solve(HipHandle &handle, int n, double const *lu, int32_t const *perm, double const *b, double *x)
 {
   if (n <= 0)
@@ -120,6 +155,25 @@ HipMatrixFreeMeshEvaluator::HipMatrixFreeMeshEvaluator(HipHandle &handle, mfmg_h
     : HipMeshEvaluator(handle, mesh)
 {
   _op = std::make_shared<MatrixFreeLaplaceDevice<double>>(handle, _desc);
+  HaloCommunicator &c = handle.comm;
+  if (c.enabled())
+  {
+    // fine DoF space: z-planes of the local (extended) mesh; owned planes [z0, z1) (+ the top plane on the
+    // last rank); the planes below / above belong to the neighbours
+    ASSERT_THROW(_mesh.dim == 3, "distributed runs need a 3-D mesh");
+    HaloSpace &s = c.spaces[1];
+    s.layer_elems = (int64_t)_mesh.N[0] * _mesh.N[1];
+    s.n_layers = _mesh.N[2];
+    s.has_low = c.ghost_cells_low > 0;
+    s.has_high = c.ghost_cells_high > 0;
+    s.owned_begin = c.ghost_cells_low;
+    s.owned_count = _mesh.N[2] - c.ghost_cells_low - (s.has_high ? c.ghost_cells_high + 1 : 0);
+    ASSERT_THROW(s.owned_count >= 2 && s.owned_count % 2 == (s.has_high ? 0 : 1),
+                 "the owned slab must hold a whole number of agglomerate layers");
+    // local numbering must be lexicographic so that planes are contiguous
+    for (int64_t nd = 0; nd < (int64_t)_mesh.node_dof.size(); nd += std::max<int64_t>(1, (int64_t)_mesh.node_dof.size() / 4099))
+      ASSERT_THROW(_mesh.node_dof[nd] == nd, "distributed runs need lexicographic local DoF numbering");
+  }
 }
 
 std::shared_ptr<DVector> HipMatrixFreeMeshEvaluator::build_range_vector() const
@@ -175,22 +229,27 @@ void HipMatrixOperator::apply(DVector const &x, DVector &y, OperatorMode mode) c
   if (mode == OperatorMode::NO_TRANS)
   {
     ASSERT_THROW(x.size() == _matrix->n() && y.size() == _matrix->m(), "vector sizes do not match the operator");
+    _matrix->handle().exchange(_domain_space, const_cast<double *>(x.get_values()));
     _matrix->vmult(y.get_values(), x.get_values());
   }
   else
   {
     ASSERT_THROW(x.size() == _matrix->m() && y.size() == _matrix->n(), "vector sizes do not match the operator");
+    _matrix->handle().exchange(_range_space, const_cast<double *>(x.get_values()));
     get_transposed_matrix()->vmult(y.get_values(), x.get_values());
   }
 }
 
 void HipMatrixOperator::residual(DVector const &x, DVector const &b, DVector &res) const
 {
+  _matrix->handle().exchange(_domain_space, const_cast<double *>(x.get_values()));
   _matrix->residual(x.get_values(), b.get_values(), res.get_values());
 }
 
 void HipMatrixOperator::apply_subtract(DVector const &x, DVector &y, OperatorMode mode) const
 {
+  _matrix->handle().exchange(mode == OperatorMode::NO_TRANS ? _domain_space : _range_space,
+                             const_cast<double *>(x.get_values()));
   if (mode == OperatorMode::NO_TRANS)
     _matrix->vmult_subtract(y.get_values(), x.get_values());
   else
@@ -217,7 +276,17 @@ std::shared_ptr<Operator<DVector>> HipMatrixOperator::multiply(std::shared_ptr<O
     Rt.n_cols = R.n_rows;
     csr_transpose_host<double>(R.n_rows, R.n_cols, R.row_ptr, R.col, R.val, Rt.row_ptr, Rt.col, Rt.val);
     HostCsr Ac = galerkin_triple_product(evaluator->get_mesh(), evaluator->constraint_semantics(), R, Rt);
-    return std::make_shared<HipMatrixOperator>(upload(_matrix->handle(), std::move(Ac)));
+    HipHandle &hh = _matrix->handle();
+    if (hh.comm.enabled())
+    {
+      // rows of agglomerates owned by the neighbours are incomplete on the local mesh: a rank applies
+      // only its own rows, the others arrive by halo exchange
+      HaloSpace const &cs = hh.comm.spaces[2];
+      empty_rows_outside(Ac, cs.owned_begin * cs.layer_elems, (cs.owned_begin + cs.owned_count) * cs.layer_elems);
+    }
+    auto coarse = std::make_shared<HipMatrixOperator>(upload(hh, std::move(Ac)));
+    coarse->set_spaces(_range_space, _range_space);
+    return coarse;
   }
   auto downcast_b = std::dynamic_pointer_cast<HipMatrixOperator const>(b);
   ASSERT_THROW(downcast_b != nullptr, "HipMatrixOperator::multiply needs a HipMatrixOperator");
@@ -260,6 +329,7 @@ double const *HipMatrixOperator::get_diagonal_inverse() const
 void HipMatrixOperator::smoother_step(DVector const &b, DVector const &x, DVector const *x_prev, double alpha,
                                       double beta, DVector &out) const
 {
+  _matrix->handle().exchange(_domain_space, const_cast<double *>(x.get_values()));
   _matrix->smoother_step(get_diagonal_inverse(), b.get_values(), x.get_values(),
                          x_prev ? x_prev->get_values() : nullptr, alpha, beta, out.get_values());
 }
@@ -273,6 +343,7 @@ HipMatrixFreeOperator::HipMatrixFreeOperator(std::shared_ptr<HipMatrixFreeMeshEv
 
 void HipMatrixFreeOperator::vmult(DVector &dst, DVector const &src) const
 {
+  get_hip_handle().exchange(1, const_cast<double *>(src.get_values()));
   _mesh_evaluator->matrix_free_evaluate_global(src, dst);
 }
 
@@ -324,12 +395,14 @@ size_t HipMatrixFreeOperator::operator_complexity() const
 
 void HipMatrixFreeOperator::residual(DVector const &x, DVector const &b, DVector &res) const
 {
+  get_hip_handle().exchange(1, const_cast<double *>(x.get_values()));
   _mesh_evaluator->get_device_operator()->residual(x.get_values(), b.get_values(), res.get_values());
 }
 
 void HipMatrixFreeOperator::smoother_step(DVector const &b, DVector const &x, DVector const *x_prev, double alpha,
                                           double beta, DVector &out) const
 {
+  get_hip_handle().exchange(1, const_cast<double *>(x.get_values()));
   _mesh_evaluator->get_device_operator()->smoother_step(b.get_values(), x.get_values(),
                                                         x_prev ? x_prev->get_values() : nullptr, alpha, beta,
                                                         out.get_values());
@@ -447,26 +520,28 @@ void HipSmoother::estimate_eigenvalues(int n_iterations, double residual, double
     MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
   }
   double const *dinv = _hip_operator->get_diagonal_inverse();
+  const int space = _hip_operator->domain_space();
+  auto ddot = [&](DVector const &a, DVector const &b2) { return distributed_dot(h, space, a, b2); };
   DVector x(h, n), r(*rhs), z(h, n), p(h, n), ap(h, n);
   vec::scale_pointwise<double>(h, n, dinv, r.get_values(), z.get_values());
   p = z;
-  double rz = r * z;
-  const double tol = std::max(residual * rhs->l2_norm(), 1e-300);
+  double rz = ddot(r, z);
+  const double tol = std::max(residual * std::sqrt(ddot(*rhs, *rhs)), 1e-300);
   std::vector<double> alphas, betas;
   for (int it = 0; it < n_iterations; ++it)
   {
     _hip_operator->apply(p, ap);
-    const double pap = p * ap;
+    const double pap = ddot(p, ap);
     if (pap == 0.)
       break;
     const double alpha = rz / pap;
     x.add(alpha, p);
     r.add(-alpha, ap);
     alphas.push_back(alpha);
-    if (r.l2_norm() < tol)
+    if (std::sqrt(ddot(r, r)) < tol)
       break;
     vec::scale_pointwise<double>(h, n, dinv, r.get_values(), z.get_values());
-    const double rz_new = r * z;
+    const double rz_new = ddot(r, z);
     const double beta = rz_new / rz;
     betas.push_back(beta);
     rz = rz_new;
@@ -549,6 +624,10 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
   auto matrix = _matrix_operator->get_matrix();
   ASSERT_THROW(matrix->m() == matrix->n(), "The coarse matrix is not square");
   const int64_t n = matrix->m();
+  const int op_space = _matrix_operator->domain_space();
+  const bool distributed = _handle.comm.enabled() && op_space > 0;
+  if (distributed && _solver != "amg")
+    ASSERT_THROW_NOT_IMPLEMENTED("distributed runs support solver.type amg only (\"" + _solver + "\" requested)");
   if (_solver == "cholesky" || _solver == "lu_dense" || _solver == "lu_sparse_host")
   {
     // the three direct variants of source/cuda/cuda_solver.cu:51-72 share one dense factorisation here
@@ -576,7 +655,67 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
     else
       b0.assign(n, 1.);
     const bool geometric = this->_params->get("solver.amg.geometric_aggregates", true);
-    auto host_levels = build_aggregation_hierarchy(std::move(A0), std::move(b0), opts, geometric ? grid : nullptr);
+    AmgGridHint local_grid;
+    if (geometric && grid)
+      local_grid = *grid;
+    int64_t row_off = 0;
+    if (distributed)
+    {
+      // levels below this one are built on the OWNED block (owned rows x owned columns) and stay local to
+      // the rank; the first level itself is applied with halo exchange
+      HaloSpace const &cs = _handle.comm.spaces[op_space];
+      row_off = cs.owned_begin * cs.layer_elems;
+      const int64_t n_own = cs.owned_count * cs.layer_elems;
+      HostCsr Ao;
+      Ao.n_rows = Ao.n_cols = n_own;
+      Ao.row_ptr.assign(n_own + 1, 0);
+      for (int64_t r = 0; r < n_own; ++r)
+      {
+        for (int p = A0.row_ptr[row_off + r]; p < A0.row_ptr[row_off + r + 1]; ++p)
+        {
+          const int64_t cidx = A0.col[p] - row_off;
+          if (cidx >= 0 && cidx < n_own)
+          {
+            Ao.col.push_back((int32_t)cidx);
+            Ao.val.push_back(A0.val[p]);
+          }
+        }
+        Ao.row_ptr[r + 1] = (int32_t)Ao.col.size();
+      }
+      A0 = std::move(Ao);
+      b0 = std::vector<double>(b0.begin() + row_off, b0.begin() + row_off + n_own);
+      if (local_grid.valid(n))
+      {
+        AmgGridHint og = local_grid;
+        const int32_t node_off = (int32_t)(cs.owned_begin * (int64_t)local_grid.dims[0] * local_grid.dims[1]);
+        og.dims[2] = (int)cs.owned_count;
+        og.node_of_row.assign(local_grid.node_of_row.begin() + row_off, local_grid.node_of_row.begin() + row_off + n_own);
+        for (auto &v : og.node_of_row)
+          v -= node_off;
+        if (!local_grid.component_of_row.empty())
+          og.component_of_row.assign(local_grid.component_of_row.begin() + row_off,
+                                     local_grid.component_of_row.begin() + row_off + n_own);
+        local_grid = std::move(og);
+      }
+    }
+    auto host_levels = build_aggregation_hierarchy(std::move(A0), std::move(b0), opts,
+                                                   local_grid.valid(distributed ? _handle.comm.spaces[op_space].owned_count *
+                                                                                      _handle.comm.spaces[op_space].layer_elems
+                                                                                : n)
+                                                       ? &local_grid
+                                                       : nullptr);
+    if (distributed && host_levels.size() > 1)
+    {
+      // embed the first prolongator into the local numbering (ghost rows stay empty)
+      HostCsr &P = host_levels[0].P;
+      std::vector<int32_t> rp(n + 1, 0);
+      for (int64_t r = 0; r < P.n_rows; ++r)
+        rp[row_off + r + 1] = P.row_ptr[r + 1] - P.row_ptr[r];
+      for (int64_t r = 0; r < n; ++r)
+        rp[r + 1] += rp[r];
+      P.row_ptr.swap(rp);
+      P.n_rows = n;
+    }
     auto smoother_params = std::make_shared<ptree>();
     smoother_params->put("smoother.type", "Chebyshev");
     smoother_params->put("smoother.degree", this->_params->get("solver.amg.smoother_degree", 1));
@@ -594,6 +733,7 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
         _amg[l].prolongator = std::make_shared<HipMatrixOperator>(upload(_handle, std::move(host_levels[l].P)));
         _amg[l].restrictor = std::dynamic_pointer_cast<HipMatrixOperator>(_amg[l].prolongator->transpose());
         _amg[l].smoother = std::make_shared<HipSmoother>(_amg[l].a, smoother_params);
+        ASSERT_THROW(!distributed || l == 0 || _amg[l].a->domain_space() == 0, "internal: deeper levels are local");
       }
     }
     auto last = _amg.back().a->get_matrix();
@@ -749,7 +889,28 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
     _grid_hint.component_of_row[r] = comp;
     _grid_hint.n_components = std::max(_grid_hint.n_components, comp + 1);
   }
+  HaloCommunicator &comm = _handle.comm;
+  if (comm.enabled())
+  {
+    // first coarse level: layers of agglomerates along z, `n_components` unknowns per agglomerate
+    ASSERT_THROW(opts.agglomerate[2] == 2, "distributed runs need agglomeration.nz = 2");
+    HaloSpace &cs = comm.spaces[2];
+    const int64_t per_layer = (int64_t)_grid_hint.dims[0] * _grid_hint.dims[1] * _grid_hint.n_components;
+    ASSERT_THROW(R.n_rows == per_layer * _grid_hint.dims[2],
+                 "distributed runs need the same number of eigenvectors on every agglomerate");
+    cs.layer_elems = per_layer;
+    cs.n_layers = _grid_hint.dims[2];
+    cs.has_low = comm.ghost_cells_low > 0;
+    cs.has_high = comm.ghost_cells_high > 0;
+    cs.owned_begin = comm.ghost_cells_low / 2;
+    cs.owned_count = cs.n_layers - comm.ghost_cells_low / 2 - comm.ghost_cells_high / 2;
+    // the rows of the upper neighbour's agglomerates are never needed (its prolongation reaches down only to
+    // the interface plane, which it owns); the lower neighbour's are (their top face is my first owned plane)
+    empty_rows_outside(R, 0, (cs.owned_begin + cs.owned_count) * cs.layer_elems);
+  }
   auto restrictor = std::make_shared<HipMatrixOperator>(upload(_handle, std::move(R)));
+  if (comm.enabled())
+    restrictor->set_spaces(1, 2);
   _own_restrictor = restrictor;
   return restrictor;
 }

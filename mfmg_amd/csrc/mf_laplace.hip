@@ -35,7 +35,9 @@ namespace mfmg
 {
 namespace
 {
-constexpr unsigned int kFlag = 0x80000000u;
+constexpr unsigned int kFlag = 0x80000000u;  // bit 31: Dirichlet-constrained DoF (read as zero, row = identity)
+constexpr unsigned int kGhost = 0x40000000u; // bit 30: DoF owned by another rank (read normally, never written)
+constexpr unsigned int kIdMask = ~(kFlag | kGhost);
 
 template <typename T>
 struct MfArgs
@@ -265,12 +267,12 @@ __global__ __launch_bounds__(64) void mf_laplace_kernel(MfArgs<T> a)
           cid[1] = f0.y;
           cid[2] = f0.z;
           cid[3] = f0.w;
-          cx[0] = a.x[(unsigned int)f0.x & ~kFlag];
+          cx[0] = a.x[(unsigned int)f0.x & kIdMask];
           if (cell)
           {
-            cx[1] = a.x[(unsigned int)f0.y & ~kFlag];
-            cx[2] = a.x[(unsigned int)f0.z & ~kFlag];
-            cx[3] = a.x[(unsigned int)f0.w & ~kFlag];
+            cx[1] = a.x[(unsigned int)f0.y & kIdMask];
+            cx[2] = a.x[(unsigned int)f0.z & kIdMask];
+            cx[3] = a.x[(unsigned int)f0.w & kIdMask];
           }
         }
         id0 = cid[0];
@@ -279,12 +281,12 @@ __global__ __launch_bounds__(64) void mf_laplace_kernel(MfArgs<T> a)
         {
           f1 = a.fb1[s];
           load_coef<T>(a.coef, a.n_slots, s, c);
-          n2 = a.x[(unsigned int)f1.z & ~kFlag];                                   // x(ci, j+1, k+1)
-          n0 = layer_carry ? xz[jj * 64 + lane] : a.x[(unsigned int)f1.x & ~kFlag]; // x(ci, j+1, k)
+          n2 = a.x[(unsigned int)f1.z & kIdMask];                                   // x(ci, j+1, k+1)
+          n0 = layer_carry ? xz[jj * 64 + lane] : a.x[(unsigned int)f1.x & kIdMask]; // x(ci, j+1, k)
           if (no_next) // issued together with n2 so that the wavefront pays one memory round trip per row
           {
-            n1x = a.x[(unsigned int)f1.y & ~kFlag];
-            n3x = a.x[(unsigned int)f1.w & ~kFlag];
+            n1x = a.x[(unsigned int)f1.y & kIdMask];
+            n3x = a.x[(unsigned int)f1.w & kIdMask];
           }
         }
       }
@@ -341,9 +343,9 @@ __global__ __launch_bounds__(64) void mf_laplace_kernel(MfArgs<T> a)
       const T yv = (kk > 0) ? (t0 + *ptj) : T(0);
       *ptj = t1;
 
-      if (slot && col_owned && jj > 0 && kk > 0)
+      if (slot && col_owned && jj > 0 && kk > 0 && !((unsigned int)id0 & kGhost))
       {
-        const unsigned int g = (unsigned int)id0 & ~kFlag;
+        const unsigned int g = (unsigned int)id0 & kIdMask;
         const T ax = (id0 < 0) ? x0 : yv; // constrained rows: dst_c = src_c
         T o;
         if (a.mode == 0)
@@ -398,7 +400,8 @@ __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coeffic
         const int ic = min(ii, nx - 1), jc = min(jj, ny - 1), kc = min(kk, nz - 1);
         const int64_t cidx = ic + (int64_t)nx * (jc + (int64_t)ny * kc);
         const int g = cell_dofs[cidx * 8 + (ii - ic) + 2 * (jj - jc) + 4 * (kk - kc)];
-        return g | (constrained[g] ? (int)kFlag : 0);
+        const int c = constrained[g];
+        return g | (c == 1 ? (int)kFlag : (c == 2 ? (int)kGhost : 0));
       };
       const bool real = (i < nx) && (j < ny) && (k < nz);
       const int own = node(i, j, k);
@@ -455,7 +458,7 @@ __global__ void mf_validate_kernel(int32_t const *cell_dofs, int4 const *fb0, in
         continue;
       }
       const size_t s = slot_of(i + (m & 1), j + ((m >> 1) & 1), k + (m >> 2), Ny, ncols);
-      if ((int)((unsigned int)fb0[s].x & ~kFlag) != g)
+      if ((int)((unsigned int)fb0[s].x & kIdMask) != g)
         bad = true;
     }
     if (bad)
@@ -493,7 +496,7 @@ __global__ void mf_diagonal_kernel(int4 const *fb0, void const *coef, size_t n_s
       for (int q = 0; q < 8; ++q)
         sum += (double)c[q] * tab.K[q][m];
     }
-    const unsigned int g = (unsigned int)id0 & ~kFlag;
+    const unsigned int g = (unsigned int)id0 & kIdMask;
     const double d = (id0 < 0) ? 1. : sum;
     diag[g] = T(d);
     dinv[g] = T(1. / d);
@@ -521,7 +524,7 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
     nc *= _n[d];
   }
   ASSERT_THROW(nd == mesh.n_dofs, "n_dofs does not match the cell grid (Q1: (n+1)^dim)");
-  ASSERT_THROW(nd < (int64_t(1) << 31), "DoF ids must fit 31 bits (bit 31 carries the constraint flag)");
+  ASSERT_THROW(nd < (int64_t(1) << 30), "DoF ids must fit 30 bits (bits 30/31 carry the ghost / constraint flags)");
   _n_dofs = nd;
   for (int d = 0; d < 3; ++d)
     ASSERT_THROW(_n[d] >= 1, "n_cells must be positive");

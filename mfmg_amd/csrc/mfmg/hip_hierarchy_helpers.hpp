@@ -86,7 +86,13 @@ public:
                              DVector &out) const = 0;
   virtual double const *get_diagonal_inverse() const = 0; // device pointer
   virtual HipHandle &get_hip_handle() const = 0;
+  // distributed vector space of the domain / range (0: rank-local, 1: fine DoFs, 2: first coarse level)
+  virtual int domain_space() const { return 0; }
+  virtual int range_space() const { return 0; }
 };
+
+// dot product over the owned entries of a distributed space, summed over the ranks
+double distributed_dot(HipHandle &handle, int space, DVector const &x, DVector const &y);
 
 // Twin of CudaMatrixOperator (include/mfmg/cuda/cuda_matrix_operator.cuh, source/cuda/cuda_matrix_operator.cu)
 class HipMatrixOperator : public HipOperator
@@ -112,8 +118,16 @@ public:
 
   std::shared_ptr<SparseMatrixDevice<double>> get_matrix() const { return _matrix; }
   std::shared_ptr<SparseMatrixDevice<double>> get_transposed_matrix() const;
+  int domain_space() const override { return _domain_space; }
+  int range_space() const override { return _range_space; }
+  void set_spaces(int domain, int range)
+  {
+    _domain_space = domain;
+    _range_space = range;
+  }
 
 private:
+  int _domain_space = 0, _range_space = 0;
   std::shared_ptr<SparseMatrixDevice<double>> _matrix;
   mutable std::shared_ptr<SparseMatrixDevice<double>> _transposed_matrix; // built lazily (cuda_matrix_operator.cu:93-130)
   mutable DeviceBuffer<double> _dinv;
@@ -141,6 +155,8 @@ public:
   double const *get_diagonal_inverse() const override;
   HipHandle &get_hip_handle() const override { return _mesh_evaluator->get_hip_handle(); }
   std::shared_ptr<HipMatrixFreeMeshEvaluator> get_mesh_evaluator() const { return _mesh_evaluator; }
+  int domain_space() const override { return 1; }
+  int range_space() const override { return 1; }
 
 private:
   std::shared_ptr<HipMatrixFreeMeshEvaluator> _mesh_evaluator;
@@ -217,6 +233,8 @@ class HipSolver : public Solver<DVector>
 {
 public:
   // `near_null` (optional): near-null-space vector of the operator for solver.type amg
+  // (`grid`: agglomerate grid of the rows, see AmgGridHint; in a distributed run the hierarchy below
+  // the first coarse level is built on, and stays local to, the owned block of the operator)
   HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const> op, std::shared_ptr<ptree const> params,
             std::vector<double> const *near_null = nullptr, AmgGridHint const *grid = nullptr);
 

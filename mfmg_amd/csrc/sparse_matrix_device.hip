@@ -96,7 +96,7 @@ __global__ void csr_inv_diag_kernel(T const *val, int32_t const *col, int32_t co
   for (int p = row_ptr[row]; p < row_ptr[row + 1]; ++p)
     if (col[p] == row)
       d = val[p];
-  dinv[row] = T(1) / d;
+  dinv[row] = (d != T(0)) ? T(1) / d : T(0); // emptied (ghost) rows have no diagonal
 }
 
 template <typename T, int LPR>

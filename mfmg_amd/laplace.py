@@ -44,12 +44,17 @@ class LaplaceProblem:
 
     def __init__(self, n_cells: Sequence[int], material: str = "constant", length: float = 1.0,
                  device: str | torch.device = "cpu", dof_numbering: Optional[torch.Tensor] = None,
-                 dirichlet: bool = True):
+                 dirichlet: bool = True, cell_size: Optional[Sequence[float]] = None,
+                 cell_offset: Optional[Sequence[int]] = None):
+        """`cell_size` / `cell_offset` describe a sub-box of a larger mesh (the slab of one rank, first
+        cell = global cell `cell_offset`): the coefficient is evaluated at the true coordinates, with
+        the same arithmetic as on the global mesh."""
         self.n = tuple(int(v) for v in n_cells)
         self.dim = len(self.n)
         assert self.dim in (2, 3)
         self.N = tuple(v + 1 for v in self.n)
-        self.h = tuple(length / v for v in self.n)
+        self.h = tuple(cell_size) if cell_size is not None else tuple(length / v for v in self.n)
+        self.cell_offset = tuple(int(v) for v in cell_offset) if cell_offset is not None else (0,) * self.dim
         self.device = torch.device(device)
         self.n_dofs = math.prod(self.N)
         self.n_cells_total = math.prod(self.n)
@@ -97,7 +102,7 @@ class LaplaceProblem:
         pts = torch.empty((self.n_cells_total, nc, self.dim), dtype=torch.float64, device=dev)
         for q in range(nc):
             for d in range(self.dim):
-                pts[:, q, d] = (org[d].to(torch.float64) + _G[(q >> d) & 1]) * self.h[d]
+                pts[:, q, d] = ((org[d] + self.cell_offset[d]).to(torch.float64) + _G[(q >> d) & 1]) * self.h[d]
         self.coefficient = material_property(material, pts).to(torch.float64).contiguous()
         self.material = material
 

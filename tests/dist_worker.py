@@ -1,0 +1,206 @@
+"""Worker of the distributed tests: run with torch.distributed.run, backend gloo.
+
+  --mode cpu : no GPU.  Every rank rebuilds its part of the operators with the product's HOST setup on its
+               local extended slab and applies them with the oracle's numpy kernels + a gloo halo exchange;
+               the owned parts must reproduce the global operators (partition correct by construction).
+  --mode gpu : the library path on cuda:0 (all ranks share the GPU, layers staged through the host): fine
+               operator / smoother / residual / restriction / prolongation / coarse operator against the
+               single-process global hierarchy, then V-cycles must contract."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+
+import mfmg_amd as M  # noqa: E402
+import mfmg_oracle as O  # noqa: E402
+
+PRM = {"eigensolver": {"number of eigenvectors": 2}, "agglomeration": {"nx": 2, "ny": 2, "nz": 2}}
+
+
+def exchange_np(v, part, layer, owned_begin, owned_count):
+    """Refresh one ghost layer on each side of a numpy vector (same protocol as HaloTransport)."""
+    rank, n = part.rank, part.n_ranks
+    ops, bufs = [], {}
+    if rank > 0:
+        s = torch.from_numpy(v[owned_begin * layer:(owned_begin + 1) * layer].copy())
+        r = torch.empty(layer, dtype=torch.float64)
+        ops += [dist.P2POp(dist.isend, s, rank - 1), dist.P2POp(dist.irecv, r, rank - 1)]
+        bufs["low"] = r
+    if rank + 1 < n:
+        s = torch.from_numpy(v[(owned_begin + owned_count - 1) * layer:(owned_begin + owned_count) * layer].copy())
+        r = torch.empty(layer, dtype=torch.float64)
+        ops += [dist.P2POp(dist.isend, s, rank + 1), dist.P2POp(dist.irecv, r, rank + 1)]
+        bufs["high"] = r
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    if "low" in bufs:
+        v[(owned_begin - 1) * layer: owned_begin * layer] = bufs["low"].numpy()
+    if "high" in bufs:
+        v[(owned_begin + owned_count) * layer:(owned_begin + owned_count + 1) * layer] = bufs["high"].numpy()
+
+
+def gather_owned(local, part, n_global, sl_local, sl_global):
+    """All ranks end up with the global vector assembled from the owned parts."""
+    out = torch.zeros(n_global, dtype=torch.float64)
+    out[sl_global] = torch.from_numpy(np.ascontiguousarray(local[sl_local]))
+    dist.all_reduce(out)
+    return out.numpy()
+
+
+def mode_cpu(args):
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cells = (8, 6, 4 * world)
+    material = "linear"
+    part = M.SlabPartition(cells, rank, world)
+    # ---- global reference (every rank computes it; tiny)
+    mesh = O.StructuredMesh(cells)
+    mesh.h = tuple(1.0 / c for c in cells)
+    gprob = M.LaplaceProblem(cells, material, cell_size=part.h)
+    coef_g = gprob.coefficient.numpy()
+    mf_g = O.MatrixFreeLaplace(mesh, coef_g)
+    Rg = M.host_build_restrictor(gprob, PRM, matrix_free=True)
+    Acg = M.host_galerkin(gprob, Rg, "matrix_free")
+    rng = np.random.default_rng(0)
+    xg = rng.random(mesh.n_dofs)
+    # ---- local slab
+    lprob = part.local_problem(material)
+    lmesh = O.StructuredMesh(part.local_cells)
+    lmesh.h = part.h
+    flags = lprob.constrained.numpy()
+    mf_l = O.MatrixFreeLaplace(lmesh, lprob.coefficient.numpy(), constrained=(flags == 1))
+    # coefficient table of the slab == slice of the global table
+    nxy = cells[0] * cells[1]
+    np.testing.assert_array_equal(lprob.coefficient.numpy(), coef_g[part.z_offset * nxy:(part.z_offset + part.local_cells[2]) * nxy])
+    xl = part.local_from_global(torch.from_numpy(xg)).numpy()
+    # garbage in the ghosts, then the exchange must restore them
+    xl_g = xl.copy()
+    lo, cnt = part.owned_plane_begin, part.owned_plane_count
+    xl_g[:lo * part.plane] = -7.0
+    xl_g[(lo + cnt) * part.plane:] = -7.0
+    exchange_np(xl_g, part, part.plane, lo, cnt)
+    yl = mf_l.vmult(xl_g)
+    y = gather_owned(yl, part, mesh.n_dofs, part.owned_slice(), part.global_slice())
+    np.testing.assert_allclose(y, mf_g.vmult(xg), rtol=1e-13, atol=1e-14)
+    # ---- restrictor / coarse operator of the local slab against the global ones
+    Rl = M.host_build_restrictor(lprob, PRM, matrix_free=True)
+    per_layer = (cells[0] // 2) * (cells[1] // 2) * 2
+    c_lo, c_cnt = part.ghost_low // 2, (part.z1 - part.z0) // 2
+    c_glob0 = part.z0 // 2
+    # restriction of owned agglomerates needs the ghost plane above: same rows as the global R
+    rl = Rl @ xl                      # xl has correct ghosts
+    own_c = slice(c_lo * per_layer, (c_lo + c_cnt) * per_layer)
+    glob_c = slice(c_glob0 * per_layer, (c_glob0 + c_cnt) * per_layer)
+    np.testing.assert_allclose(rl[own_c], (Rg @ xg)[glob_c], rtol=1e-12, atol=1e-14)
+    # prolongation at owned nodes needs the coarse ghost layer below
+    xc_g = rng.random(Rg.shape[0])
+    lo_c_glob = (c_glob0 - c_lo) * per_layer
+    xc_l = xc_g[lo_c_glob: lo_c_glob + Rl.shape[0]].copy()
+    Rl_used = Rl.tolil()
+    Rl_used[(c_lo + c_cnt) * per_layer:, :] = 0      # rows of the upper neighbour are emptied by the library
+    pl = Rl_used.tocsr().T @ xc_l
+    p = gather_owned(pl, part, mesh.n_dofs, part.owned_slice(), part.global_slice())
+    np.testing.assert_allclose(p, Rg.T @ xc_g, rtol=1e-12, atol=1e-14)
+    # coarse operator: owned rows of the local Galerkin product == global rows (columns shifted)
+    Acl = M.host_galerkin(lprob, Rl, "matrix_free")
+    al = Acl @ xc_l
+    np.testing.assert_allclose(al[own_c], (Acg @ xc_g)[glob_c], rtol=1e-11, atol=1e-14)
+    if rank == 0:
+        print("cpu distributed checks passed", flush=True)
+
+
+def mode_gpu(args):
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    cells = (16, 12, 8 * world)
+    material = "linear"
+    part = M.SlabPartition(cells, rank, world)
+    params = dict(PRM)
+    params.update({"smoother": {"type": "Chebyshev", "degree": 3, "lambda_max": 1.75, "lambda_min": 0.0875},
+                   "solver": {"type": "amg", "amg": {"coarsest_size": 300}}, "is preconditioner": False})
+    ctx = M.Context()
+    tr = M.HaloTransport(ctx, part, 2)
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", part.local_problem(material, "cuda"), params)
+    # global single-process reference on the same GPU (rank-local context without communicator)
+    gctx = M.Context()
+    gprob = M.LaplaceProblem(cells, material, device="cuda", cell_size=part.h)
+    gparams = dict(params)
+    hg = M.Hierarchy(gctx, "HipMatrixFreeMeshEvaluator", gprob, gparams)
+    ng, nl = gprob.n_dofs, part.plane * part.n_local_planes
+    rng = np.random.default_rng(0)
+    xg, bg = rng.random(ng), rng.random(ng)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    def local(vg, poison=True):
+        v = part.local_from_global(torch.from_numpy(vg)).numpy()
+        if poison:   # ghosts must come from the exchange, not from the test
+            lo, cnt = part.owned_plane_begin, part.owned_plane_count
+            v[:lo * part.plane] = 1e30
+            v[(lo + cnt) * part.plane:] = 1e30
+        return v
+    def check(local_out, global_out, what, tol=1e-12):
+        got = gather_owned(local_out.cpu().numpy(), part, ng, part.owned_slice(), part.global_slice())
+        ref = global_out.cpu().numpy()
+        err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300)
+        assert err < tol, f"{what}: {err}"
+    # fine operator
+    yl = torch.zeros(nl, dtype=torch.float64, device="cuda"); yg = torch.empty(ng, dtype=torch.float64, device="cuda")
+    h.operator_apply(0, dev(local(xg)), yl); hg.operator_apply(0, dev(xg), yg)
+    check(yl, yg, "fine operator")
+    # smoother (3 fused steps, 3 exchanges)
+    xl = dev(local(xg)); xs = dev(xg)
+    h.smoother_apply(0, dev(local(bg, False)), xl); hg.smoother_apply(0, dev(bg), xs)
+    check(xl, xs, "smoother")
+    # restriction / prolongation / coarse operator
+    lay, nlay, cb, cc = tr.layout(2)
+    ncl, ncg = lay * nlay, hg.level_size(1)
+    assert h.level_size(1) == ncl
+    c_glob0 = (part.z0 // 2 - cb) * lay
+    def gather_c(v):
+        out = torch.zeros(ncg, dtype=torch.float64)
+        out[c_glob0 + cb * lay: c_glob0 + (cb + cc) * lay] = v.cpu()[cb * lay:(cb + cc) * lay]
+        dist.all_reduce(out)
+        return out.numpy()
+    rl = torch.zeros(ncl, dtype=torch.float64, device="cuda"); rg = torch.empty(ncg, dtype=torch.float64, device="cuda")
+    h.restrictor_apply(1, dev(local(xg)), rl); hg.restrictor_apply(1, dev(xg), rg)
+    np.testing.assert_allclose(gather_c(rl), rg.cpu().numpy(), rtol=1e-12, atol=1e-13)
+    xcg = rng.random(ncg)
+    xcl = xcg[c_glob0: c_glob0 + ncl].copy()
+    xcl[:cb * lay] = 1e30
+    xcl[(cb + cc) * lay:] = 1e30
+    pl = torch.zeros(nl, dtype=torch.float64, device="cuda"); pg = torch.empty(ng, dtype=torch.float64, device="cuda")
+    h.restrictor_apply(1, dev(xcl), pl, 1); hg.restrictor_apply(1, dev(xcg), pg, 1)
+    check(pl, pg, "prolongation")
+    al = torch.zeros(ncl, dtype=torch.float64, device="cuda"); ag = torch.empty(ncg, dtype=torch.float64, device="cuda")
+    h.operator_apply(1, dev(xcl), al); hg.operator_apply(1, dev(xcg), ag)
+    np.testing.assert_allclose(gather_c(al), ag.cpu().numpy(), rtol=1e-11, atol=1e-13)
+    # V-cycles contract (the levels below the first coarse level are rank-local in a distributed run)
+    con = (part.local_problem(material).constrained == 1).numpy()
+    x = dev(np.where(con, 0.0, local(xg, False)))
+    b = torch.zeros(nl, dtype=torch.float64, device="cuda")
+    r = torch.empty_like(x)
+    norms = []
+    for _ in range(6):
+        h.operator_apply(0, x, r)
+        norms.append(tr.owned_norm(r))
+        h.apply(b, x)
+    assert all(norms[i + 1] < 0.7 * norms[i] for i in range(5)), norms
+    if rank == 0:
+        print("gpu distributed checks passed; residuals", ["%.3e" % v for v in norms], flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="cpu")
+    a = ap.parse_args()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    try:
+        (mode_cpu if a.mode == "cpu" else mode_gpu)(a)
+    finally:
+        dist.destroy_process_group()
