@@ -143,17 +143,40 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU")
-    torch.cuda.set_device(local_rank)
+    backend = os.environ.get("MFMG_BENCH_BACKEND", "nccl")   # "gloo": rehearsal with ranks sharing a card
+    device_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     import mfmg_amd as M
 
     ctx = M.Context()
     n = args.cells + 1
     t_setup = time.perf_counter()
-    prob = M.LaplaceProblem((args.cells,) * 3, args.material, device="cuda")
+    # weak scaling: every GPU owns cells^3 cells; the global box doubles in z, y, x in turn, so that N = 8 is
+    # the cube with 2*cells per direction (BASELINE.json configs[3]); slabs are cut along z
+    gx, gy, gz = args.cells, args.cells, args.cells
+    for i in range(int(round(math.log2(world)))):
+        if i % 3 == 0:
+            gz *= 2
+        elif i % 3 == 1:
+            gy *= 2
+        else:
+            gx *= 2
+    part = transport = None
+    if world > 1:
+        if world & (world - 1):
+            raise SystemExit("--gpus must be a power of two")
+        part = M.SlabPartition((gx, gy, gz), rank, world, length=(gx / args.cells, gy / args.cells, gz / args.cells))
+        transport = M.HaloTransport(ctx, part, 2)
+        prob = part.local_problem(args.material, device="cuda")
+    else:
+        prob = M.LaplaceProblem((args.cells,) * 3, args.material, device="cuda")
     params = {
         "eigensolver": {"number of eigenvectors": 2},
         "agglomeration": {"partitioner": "block", "nx": 2, "ny": 2, "nz": 2},
@@ -167,12 +190,15 @@ def main():
     ctx.synchronize()
     t_setup = time.perf_counter() - t_setup
     degree, lmin, lmax = h.smoother_info()
-    n_fine, n_coarse = h.level_size(0), h.level_size(1)
+    n_local, n_coarse = h.level_size(0), h.level_size(1)
+    # DoFs this rank owns (the local vector also holds the ghost planes of the neighbours)
+    n_fine = n_local if part is None else part.plane * part.owned_plane_count
+    n_global = n_fine if part is None else part.n_global_dofs
 
     g = torch.Generator(device="cuda").manual_seed(1 + rank)
-    x = torch.rand(n_fine, dtype=torch.float64, device="cuda", generator=g)
-    x *= (prob.constrained == 0).to(torch.float64)
-    b = torch.zeros(n_fine, dtype=torch.float64, device="cuda")
+    x = torch.rand(n_local, dtype=torch.float64, device="cuda", generator=g)
+    x *= (prob.constrained != 1).to(torch.float64)
+    b = torch.zeros(n_local, dtype=torch.float64, device="cuda")
 
     def barrier():
         if world > 1:
@@ -183,9 +209,12 @@ def main():
     r = torch.empty_like(x)
 
     def residual_norm():
-        op_monitor.vmult(r, x)
-        ctx.sadd(r, -1.0, 1.0, b)
-        return ctx.l2_norm(r)
+        if transport is None:
+            op_monitor.vmult(r, x)
+            ctx.sadd(r, -1.0, 1.0, b)
+            return ctx.l2_norm(r)
+        h.operator_apply(0, x, r)          # with halo exchange; b = 0
+        return transport.owned_norm(r)
 
     res_start = residual_norm()
     for _ in range(args.warmup):
@@ -210,7 +239,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * n_fine / (dt / args.steps)
+    value = n_global / (dt / args.steps)
 
     coarse_desc = (f"{args.coarse_iters} Jacobi-PCG steps" if args.coarse == "pcg" else
                    "one V-cycle of a smoothed-aggregation hierarchy (Chebyshev(1) = damped-Jacobi smoothers, dense LU at the bottom)")
@@ -237,7 +266,11 @@ def main():
                 "fine_dofs_per_gpu": n_fine,
                 "coarse_dofs_per_gpu": n_coarse,
                 "smoother": {"type": "Chebyshev", "degree": degree, "lambda_min": lmin, "lambda_max": lmax},
-                "parallelism": "1 GPU" if world == 1 else f"{world} replicas (domain decomposition pending)",
+                "parallelism": "1 GPU" if world == 1 else
+                               f"{world} GPUs, z-slab domain decomposition of a {gx}x{gy}x{gz}-cell box, one-plane halo "
+                               f"exchange per operator application (RCCL send/recv), levels below the first coarse "
+                               f"level rank-local",
+                "global_dofs": n_global,
                 "setup_seconds": t_setup,
                 "mean_residual_contraction_per_cycle": contraction,
             },

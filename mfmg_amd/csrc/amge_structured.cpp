@@ -54,7 +54,13 @@ void configure_host_threads()
   std::call_once(once, [] {
 #ifdef _OPENMP
     if (std::getenv("OMP_NUM_THREADS") == nullptr)
-      omp_set_num_threads(effective_cpu_count());
+    {
+      // one process per GPU on a shared node: split the host cores between the local ranks
+      int share = effective_cpu_count();
+      if (char const *lws = std::getenv("LOCAL_WORLD_SIZE"))
+        share = std::max(1, share / std::max(1, std::atoi(lws)));
+      omp_set_num_threads(share);
+    }
 #endif
   });
 }

@@ -904,9 +904,8 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
     cs.has_high = comm.ghost_cells_high > 0;
     cs.owned_begin = comm.ghost_cells_low / 2;
     cs.owned_count = cs.n_layers - comm.ghost_cells_low / 2 - comm.ghost_cells_high / 2;
-    // the rows of the upper neighbour's agglomerates are never needed (its prolongation reaches down only to
-    // the interface plane, which it owns); the lower neighbour's are (their top face is my first owned plane)
-    empty_rows_outside(R, 0, (cs.owned_begin + cs.owned_count) * cs.layer_elems);
+    // rows of the neighbours' agglomerates stay: the lower neighbour's top face is my first owned plane
+    // (prolongation), and the Galerkin product of my boundary rows couples to both ghost layers
   }
   auto restrictor = std::make_shared<HipMatrixOperator>(upload(_handle, std::move(R)));
   if (comm.enabled())

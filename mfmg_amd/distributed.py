@@ -103,6 +103,11 @@ class HaloTransport:
                                                               b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(),
                                                               b[3].data_ptr()))
         ctx._transport = self  # keep the callbacks alive as long as the context
+        if self.backend == "nccl":
+            # RCCL builds its communicators at the first collective: do it here, with every rank present
+            warm = torch.zeros(1, dtype=torch.float64, device="cuda")
+            dist.all_reduce(warm, group=group)
+            torch.cuda.synchronize()
 
     # -- callbacks (invoked from inside the library, on the calling Python thread) ------------------
     def _exchange(self, user, space, stream_ptr):

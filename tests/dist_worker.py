@@ -58,10 +58,10 @@ def mode_cpu(args):
     rank, world = dist.get_rank(), dist.get_world_size()
     cells = (8, 6, 4 * world)
     material = "linear"
-    part = M.SlabPartition(cells, rank, world)
+    part = M.SlabPartition(cells, rank, world, length=tuple(c / 8.0 for c in cells))
     # ---- global reference (every rank computes it; tiny)
     mesh = O.StructuredMesh(cells)
-    mesh.h = tuple(1.0 / c for c in cells)
+    mesh.h = part.h
     gprob = M.LaplaceProblem(cells, material, cell_size=part.h)
     coef_g = gprob.coefficient.numpy()
     mf_g = O.MatrixFreeLaplace(mesh, coef_g)
@@ -102,9 +102,7 @@ def mode_cpu(args):
     xc_g = rng.random(Rg.shape[0])
     lo_c_glob = (c_glob0 - c_lo) * per_layer
     xc_l = xc_g[lo_c_glob: lo_c_glob + Rl.shape[0]].copy()
-    Rl_used = Rl.tolil()
-    Rl_used[(c_lo + c_cnt) * per_layer:, :] = 0      # rows of the upper neighbour are emptied by the library
-    pl = Rl_used.tocsr().T @ xc_l
+    pl = Rl.T @ xc_l
     p = gather_owned(pl, part, mesh.n_dofs, part.owned_slice(), part.global_slice())
     np.testing.assert_allclose(p, Rg.T @ xc_g, rtol=1e-12, atol=1e-14)
     # coarse operator: owned rows of the local Galerkin product == global rows (columns shifted)
@@ -120,17 +118,20 @@ def mode_gpu(args):
     torch.cuda.set_device(0)
     cells = (16, 12, 8 * world)
     material = "linear"
-    part = M.SlabPartition(cells, rank, world)
+    part = M.SlabPartition(cells, rank, world, length=tuple(c / 16.0 for c in cells))   # cubic cells
     params = dict(PRM)
-    params.update({"smoother": {"type": "Chebyshev", "degree": 3, "lambda_max": 1.75, "lambda_min": 0.0875},
+    params.update({"smoother": {"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0},
                    "solver": {"type": "amg", "amg": {"coarsest_size": 300}}, "is preconditioner": False})
     ctx = M.Context()
     tr = M.HaloTransport(ctx, part, 2)
     h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", part.local_problem(material, "cuda"), params)
-    # global single-process reference on the same GPU (rank-local context without communicator)
+    deg, lmin, lmax = h.smoother_info()       # estimated with dot products summed over the ranks
+    assert 1.4 < lmax < 2.2, lmax
+    # global single-process reference on the same GPU (rank-local context without communicator), same polynomial
     gctx = M.Context()
     gprob = M.LaplaceProblem(cells, material, device="cuda", cell_size=part.h)
     gparams = dict(params)
+    gparams["smoother"] = {"type": "Chebyshev", "degree": 3, "lambda_max": lmax, "lambda_min": lmin}
     hg = M.Hierarchy(gctx, "HipMatrixFreeMeshEvaluator", gprob, gparams)
     ng, nl = gprob.n_dofs, part.plane * part.n_local_planes
     rng = np.random.default_rng(0)
