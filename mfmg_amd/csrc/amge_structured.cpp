@@ -53,14 +53,17 @@ void configure_host_threads()
   static std::once_flag once;
   std::call_once(once, [] {
 #ifdef _OPENMP
-    if (std::getenv("OMP_NUM_THREADS") == nullptr)
-    {
-      // one process per GPU on a shared node: split the host cores between the local ranks
-      int share = effective_cpu_count();
-      if (char const *lws = std::getenv("LOCAL_WORLD_SIZE"))
-        share = std::max(1, share / std::max(1, std::atoi(lws)));
-      omp_set_num_threads(share);
-    }
+    // MFMG_HOST_THREADS wins; under torchrun (LOCAL_WORLD_SIZE set) the host cores are split between the
+    // local ranks -- torchrun's blanket OMP_NUM_THREADS=1 would make the setup single-threaded; otherwise a
+    // user-set OMP_NUM_THREADS is respected
+    char const *forced = std::getenv("MFMG_HOST_THREADS");
+    char const *lws = std::getenv("LOCAL_WORLD_SIZE");
+    if (forced)
+      omp_set_num_threads(std::max(1, std::atoi(forced)));
+    else if (lws)
+      omp_set_num_threads(std::max(1, effective_cpu_count() / std::max(1, std::atoi(lws))));
+    else if (std::getenv("OMP_NUM_THREADS") == nullptr)
+      omp_set_num_threads(effective_cpu_count());
 #endif
   });
 }

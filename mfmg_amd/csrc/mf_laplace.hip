@@ -613,14 +613,14 @@ void MatrixFreeLaplaceDevice<T>::choose_tile(int &ty, int &tz) const
   tz = _tile_z;
   if (ty > 0 && tz > 0)
     return;
-  // heuristic: the largest tile (least halo re-computation) that still yields >= 16 resident
-  // wavefronts per CU
+  // heuristic (measured on MI355X, profiles/): the kernel is latency-bound below ~4 rounds of resident
+  // wavefronts (256 CUs x 20), so take the largest tile (least halo re-computation) that still yields that many
   const int64_t cols = (_N[0] + 62) / 63;
-  const int64_t target_waves = 256 * 16;
+  const int64_t target_waves = 256 * 80;
   int best_ty = 1, best_tz = 1;
   double best_cost = 1e30;
-  const int cand_y[] = {2, 4, 8, 16, 32};
-  const int cand_z[] = {2, 4, 8, 16, 32, 64};
+  const int cand_y[] = {2, 4, 8, 16};
+  const int cand_z[] = {4, 8, 16, 32, 64};
   for (int cy : cand_y)
     for (int cz : cand_z)
     {
