@@ -85,6 +85,72 @@ __global__ void csr_spmv_kernel(CsrArgs<T> a)
   }
 }
 
+// LDS-cached SpMV: the x entries a block of rows touches are gathered once (coalesced through the sorted
+// list l2g) into LDS; rows then stream (val, 16-bit local column) pairs.  For the coarse operators of the
+// AMGe hierarchy a 128-row block touches ~1200 distinct columns for ~7000 non-zeros, so x is fetched once
+// instead of ~6 times through L1/L2, and the index stream halves.
+template <typename T, int LPR>
+__global__ void csr_spmv_lds_kernel(CsrArgs<T> a, int32_t const *blk_ptr, int32_t const *l2g, uint16_t const *lcol,
+                                    int rows_per_block)
+{
+  extern __shared__ __align__(16) unsigned char csr_smem[];
+  T *xs = reinterpret_cast<T *>(csr_smem);
+  __shared__ int rp[256 + 1];
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t row1 = min(row0 + rows_per_block, a.n_rows);
+  const int l0 = blk_ptr[blockIdx.x], l1 = blk_ptr[blockIdx.x + 1];
+  for (int i = threadIdx.x; i <= (int)(row1 - row0); i += blockDim.x)
+    rp[i] = a.row_ptr[row0 + i];
+  for (int i = threadIdx.x; i < l1 - l0; i += blockDim.x)
+    xs[i] = a.x[l2g[l0 + i]];
+  __syncthreads();
+  const int group = threadIdx.x / LPR, sub = threadIdx.x % LPR, n_groups = blockDim.x / LPR;
+  // every lane runs the same number of passes so that the shuffles are wave-uniform
+  for (int64_t base = row0; base < row1; base += n_groups)
+  {
+    const int64_t row = base + group;
+    T sum = T(0);
+    if (row < row1)
+    {
+      const int s = rp[row - row0], e = rp[row - row0 + 1];
+      for (int p = s + sub; p < e; p += LPR)
+        sum += a.val[p] * xs[lcol[p]];
+    }
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1)
+      sum += __shfl_xor(sum, off);
+    if (row < row1 && sub == 0)
+    {
+      T o;
+      switch (a.mode)
+      {
+      case 0:
+        o = sum;
+        break;
+      case 1:
+        o = sum - a.b[row];
+        break;
+      case 2:
+        o = a.x[row] - a.beta * a.dinv[row] * (sum - a.b[row]);
+        break;
+      case 3:
+      {
+        const T xr = a.x[row];
+        o = xr + a.alpha * (xr - a.xprev[row]) - a.beta * a.dinv[row] * (sum - a.b[row]);
+        break;
+      }
+      case 4:
+        o = a.out[row] - sum;
+        break;
+      default:
+        o = a.out[row] + sum;
+        break;
+      }
+      a.out[row] = o;
+    }
+  }
+}
+
 template <typename T>
 __global__ void csr_inv_diag_kernel(T const *val, int32_t const *col, int32_t const *row_ptr,
                                     int64_t n_rows, T *dinv)
@@ -97,6 +163,15 @@ __global__ void csr_inv_diag_kernel(T const *val, int32_t const *col, int32_t co
     if (col[p] == row)
       d = val[p];
   dinv[row] = (d != T(0)) ? T(1) / d : T(0); // emptied (ghost) rows have no diagonal
+}
+
+template <typename T, int LPR>
+void launch_lds(CsrArgs<T> const &a, hipStream_t st, int32_t const *blk_ptr, int32_t const *l2g, uint16_t const *lcol,
+                int rows_per_block, int max_cols)
+{
+  const int64_t nb = (a.n_rows + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL((csr_spmv_lds_kernel<T, LPR>), dim3((unsigned int)nb), dim3(1024),
+                     (size_t)max_cols * sizeof(T), st, a, blk_ptr, l2g, lcol, rows_per_block);
 }
 
 template <typename T, int LPR>
@@ -129,6 +204,51 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
   while (lpr < 64 && lpr * 2 <= avg * 0.75 + 0.5)
     lpr *= 2;
   _lanes_per_row = lpr;
+  // ---- block-local column compression for the LDS-cached kernel
+  if (n_rows >= 4 * kRowsPerBlock && avg >= 4.)
+  {
+    const int64_t nb = (n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
+    std::vector<int32_t> blk_ptr(nb + 1, 0);
+    std::vector<std::vector<int32_t>> uniq(nb);
+    bool ok = true;
+    int max_cols = 0;
+#pragma omp parallel for schedule(static) reduction(max : max_cols)
+    for (int64_t b = 0; b < nb; ++b)
+    {
+      const int64_t r0 = b * kRowsPerBlock, r1 = std::min<int64_t>(r0 + kRowsPerBlock, n_rows);
+      std::vector<int32_t> &u = uniq[b];
+      u.assign(col.begin() + row_ptr[r0], col.begin() + row_ptr[r1]);
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+      max_cols = std::max<int>(max_cols, (int)u.size());
+    }
+    int64_t total = 0;
+    for (int64_t b = 0; b < nb; ++b)
+    {
+      total += (int64_t)uniq[b].size();
+      blk_ptr[b + 1] = (int32_t)std::min<int64_t>(total, INT32_MAX);
+    }
+    // worth it when a column is reused at least ~3 times inside a block and the slice fits LDS comfortably
+    ok = max_cols <= 6144 && total < INT32_MAX && double(_nnz) >= 3. * double(total);
+    if (ok)
+    {
+      std::vector<int32_t> l2g(total);
+      std::vector<uint16_t> lcol(_nnz);
+#pragma omp parallel for schedule(static)
+      for (int64_t b = 0; b < nb; ++b)
+      {
+        std::copy(uniq[b].begin(), uniq[b].end(), l2g.begin() + blk_ptr[b]);
+        const int64_t r0 = b * kRowsPerBlock, r1 = std::min<int64_t>(r0 + kRowsPerBlock, n_rows);
+        for (int64_t p = row_ptr[r0]; p < row_ptr[r1]; ++p)
+          lcol[p] = (uint16_t)(std::lower_bound(uniq[b].begin(), uniq[b].end(), col[p]) - uniq[b].begin());
+      }
+      _blk_ptr.upload(blk_ptr.data(), blk_ptr.size(), handle.stream);
+      _l2g.upload(l2g.data(), l2g.size(), handle.stream);
+      _lcol.upload(lcol.data(), lcol.size(), handle.stream);
+      _use_lds = true;
+      _lds_max_cols = max_cols;
+    }
+  }
   _val.upload(val.data(), val.size(), handle.stream);
   _col.upload(col.data(), col.size(), handle.stream);
   _row_ptr.upload(row_ptr.data(), row_ptr.size(), handle.stream);
@@ -165,6 +285,34 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
   const double extra = (mode == CsrMode::apply) ? 0. : (mode == CsrMode::first) ? 3. : (mode == CsrMode::next) ? 4. : 1.;
   hipEvent_t stop =
       _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes_apply() + extra * sizeof(T) * double(_n_rows), st);
+  if (_use_lds)
+  {
+    int32_t const *bp = _blk_ptr.data(), *lg = _l2g.data();
+    uint16_t const *lc = _lcol.data();
+    switch (_lanes_per_row)
+    {
+    case 1:
+    case 2:
+    case 4:
+      launch_lds<T, 4>(a, st, bp, lg, lc, kRowsPerBlock, _lds_max_cols);
+      break;
+    case 8:
+      launch_lds<T, 8>(a, st, bp, lg, lc, kRowsPerBlock, _lds_max_cols);
+      break;
+    case 16:
+      launch_lds<T, 16>(a, st, bp, lg, lc, kRowsPerBlock, _lds_max_cols);
+      break;
+    case 32:
+      launch_lds<T, 32>(a, st, bp, lg, lc, kRowsPerBlock, _lds_max_cols);
+      break;
+    default:
+      launch_lds<T, 64>(a, st, bp, lg, lc, kRowsPerBlock, _lds_max_cols);
+      break;
+    }
+    KernelProfiler::end(stop, st);
+    MFMG_HIP_CHECK(hipGetLastError());
+    return;
+  }
   switch (_lanes_per_row)
   {
   case 1:

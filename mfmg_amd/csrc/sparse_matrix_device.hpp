@@ -80,6 +80,7 @@ public:
   int32_t const *row_ptr_dev() const { return _row_ptr.data(); }
   HipHandle &handle() const { return _handle; }
 
+  bool uses_lds_path() const { return _use_lds; }
   // algorithmic bytes of one y = A x (12 B/nnz + 4 B/row ptr + x + y)
   double algorithmic_bytes_apply() const
   {
@@ -94,6 +95,14 @@ private:
   HipHandle &_handle;
   int64_t _n_rows, _n_cols, _nnz;
   int _lanes_per_row;
+  // LDS-cached variant (chosen at construction when the columns of a block of rows are few): per
+  // block of kRowsPerBlock rows the sorted unique columns (`l2g`) are gathered once into LDS and the
+  // matrix stream carries 16-bit block-local column ids instead of 32-bit global ones
+  static constexpr int kRowsPerBlock = 128;
+  bool _use_lds = false;
+  int _lds_max_cols = 0;
+  DeviceBuffer<int32_t> _blk_ptr, _l2g;
+  DeviceBuffer<uint16_t> _lcol;
   DeviceBuffer<T> _val;
   DeviceBuffer<int32_t> _col;
   DeviceBuffer<int32_t> _row_ptr;
