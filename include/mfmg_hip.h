@@ -163,6 +163,17 @@ int mfmg_hip_mf_laplace_residual(mfmg_hip_mf_laplace_t op, const double *x, cons
  * source/dealii/dealii_matrix_free_smoother.cc:63-76, one polynomial term per call) */
 int mfmg_hip_mf_laplace_smoother_step(mfmg_hip_mf_laplace_t op, const double *b, const double *x,
                                       const double *x_prev, double alpha, double beta, double *out);
+/* FP32 instance of the same operator (BASELINE.json configs[4]; the coefficient table is converted once,
+ * vectors are device `float`).  The cell kernel stays on the vector ALU: at ~11 flop/B it sits below the
+ * FP32-MFMA ridge, so a batched-GEMM reformulation would not lift the HBM bound. */
+typedef struct mfmg_hip_mf_laplace_f32_s *mfmg_hip_mf_laplace_f32_t;
+int mfmg_hip_mf_laplace_f32_create(mfmg_hip_context_t ctx, const mfmg_hip_mesh_desc *mesh, mfmg_hip_mf_laplace_f32_t *out);
+int mfmg_hip_mf_laplace_f32_destroy(mfmg_hip_mf_laplace_f32_t op);
+int mfmg_hip_mf_laplace_f32_vmult(mfmg_hip_mf_laplace_f32_t op, const float *x, float *y);
+int mfmg_hip_mf_laplace_f32_diagonal_inverse(mfmg_hip_mf_laplace_f32_t op, float *dinv);
+int mfmg_hip_mf_laplace_f32_residual(mfmg_hip_mf_laplace_f32_t op, const float *x, const float *b, float *res);
+int mfmg_hip_mf_laplace_f32_smoother_step(mfmg_hip_mf_laplace_f32_t op, const float *b, const float *x,
+                                          const float *x_prev, float alpha, float beta, float *out);
 /* tuning knob: owned DoF rows / planes per workgroup tile (0 = heuristic) */
 int mfmg_hip_mf_laplace_set_tile(mfmg_hip_mf_laplace_t op, int tile_y, int tile_z);
 

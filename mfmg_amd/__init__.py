@@ -3,12 +3,12 @@
 Python is plumbing here (device memory through torch, process groups through
 torch.distributed); every numerical operation runs in libmfmg_hip.so."""
 from . import lib
-from .api import (Context, Hierarchy, MatrixFreeLaplace, SparseMatrixDevice, host_assemble_matrix,
+from .api import (Context, Hierarchy, MatrixFreeLaplace, MatrixFreeLaplaceF32, SparseMatrixDevice, host_assemble_matrix,
                   host_amg_build, host_build_restrictor, host_galerkin, params_to_info)
 from .laplace import LaplaceProblem, material_property
 from .distributed import HaloTransport, SlabPartition
 
 __all__ = [
-    "lib", "Context", "Hierarchy", "MatrixFreeLaplace", "SparseMatrixDevice", "LaplaceProblem",
+    "lib", "Context", "Hierarchy", "MatrixFreeLaplace", "MatrixFreeLaplaceF32", "SparseMatrixDevice", "LaplaceProblem",
     "material_property", "SlabPartition", "HaloTransport", "host_assemble_matrix", "host_build_restrictor", "host_galerkin", "host_amg_build", "params_to_info",
 ]

@@ -255,6 +255,47 @@ class MatrixFreeLaplace:
             pass
 
 
+class MatrixFreeLaplaceF32:
+    """FP32 instance of the matrix-free operator (BASELINE.json configs[4]); vectors are float32 tensors."""
+
+    def __init__(self, ctx: Context, problem):
+        self._lib = _lib.load()
+        self.ctx = ctx
+        desc = problem.mesh_desc()
+        h = C.c_void_p()
+        check(self._lib.mfmg_hip_mf_laplace_f32_create(ctx.handle, C.byref(desc), C.byref(h)))
+        self.handle = h
+        self.n_dofs = problem.n_dofs
+
+    def _p(self, t):
+        return _dev_ptr(t, self.n_dofs, torch.float32)
+
+    def vmult(self, dst, src):
+        check(self._lib.mfmg_hip_mf_laplace_f32_vmult(self.handle, self._p(src), self._p(dst)))
+
+    def residual(self, x, b, res):
+        check(self._lib.mfmg_hip_mf_laplace_f32_residual(self.handle, self._p(x), self._p(b), self._p(res)))
+
+    def smoother_step(self, b, x, x_prev, alpha, beta, out):
+        check(self._lib.mfmg_hip_mf_laplace_f32_smoother_step(self.handle, self._p(b), self._p(x),
+                                                              self._p(x_prev) if x_prev is not None else None,
+                                                              alpha, beta, self._p(out)))
+
+    def diagonal_inverse(self) -> torch.Tensor:
+        out = torch.empty(self.n_dofs, dtype=torch.float32, device="cuda")
+        check(self._lib.mfmg_hip_mf_laplace_f32_diagonal_inverse(self.handle, self._p(out)))
+        self.ctx.synchronize()
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.mfmg_hip_mf_laplace_f32_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 class Hierarchy:
     """mfmg::Hierarchy<VectorType> (include/mfmg/common/hierarchy.hpp:155-373)."""
 

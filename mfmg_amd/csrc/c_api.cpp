@@ -70,6 +70,11 @@ struct mfmg_hip_mf_laplace_s
   std::shared_ptr<MatrixFreeLaplaceDevice<double>> op;
 };
 
+struct mfmg_hip_mf_laplace_f32_s
+{
+  std::shared_ptr<MatrixFreeLaplaceDevice<float>> op;
+};
+
 struct mfmg_hip_host_csr_s
 {
   HostCsr m;
@@ -469,6 +474,50 @@ int mfmg_hip_mf_laplace_smoother_step(mfmg_hip_mf_laplace_t op, const double *b,
   });
 }
 
+// ---- FP32 instance ----------------------------------------------------------------------
+int mfmg_hip_mf_laplace_f32_create(mfmg_hip_context_t ctx, const mfmg_hip_mesh_desc *mesh, mfmg_hip_mf_laplace_f32_t *out)
+{
+  return guarded([&] {
+    require(ctx && mesh && out, "null argument");
+    std::unique_ptr<mfmg_hip_mf_laplace_f32_s> h(new mfmg_hip_mf_laplace_f32_s);
+    h->op = std::make_shared<MatrixFreeLaplaceDevice<float>>(*ctx->handle, *mesh);
+    *out = h.release();
+  });
+}
+int mfmg_hip_mf_laplace_f32_destroy(mfmg_hip_mf_laplace_f32_t op)
+{
+  return guarded([&] { delete op; });
+}
+int mfmg_hip_mf_laplace_f32_vmult(mfmg_hip_mf_laplace_f32_t op, const float *x, float *y)
+{
+  return guarded([&] {
+    require(op && x && y, "null argument");
+    op->op->vmult(x, y);
+  });
+}
+int mfmg_hip_mf_laplace_f32_diagonal_inverse(mfmg_hip_mf_laplace_f32_t op, float *dinv)
+{
+  return guarded([&] {
+    require(op && dinv, "null argument");
+    vec::copy<float>(op->op->handle(), op->op->n_dofs(), op->op->diagonal_inverse(), dinv);
+  });
+}
+int mfmg_hip_mf_laplace_f32_residual(mfmg_hip_mf_laplace_f32_t op, const float *x, const float *b, float *res)
+{
+  return guarded([&] {
+    require(op && x && b && res, "null argument");
+    op->op->residual(x, b, res);
+  });
+}
+int mfmg_hip_mf_laplace_f32_smoother_step(mfmg_hip_mf_laplace_f32_t op, const float *b, const float *x,
+                                          const float *x_prev, float alpha, float beta, float *out)
+{
+  return guarded([&] {
+    require(op && b && x && out, "null argument");
+    op->op->smoother_step(b, x, x_prev, alpha, beta, out);
+  });
+}
+
 int mfmg_hip_mf_laplace_set_tile(mfmg_hip_mf_laplace_t op, int tile_y, int tile_z)
 {
   return guarded([&] {
@@ -850,7 +899,7 @@ int mfmg_hip_host_amg_build(int64_t n_rows, int64_t nnz, const int32_t *row_ptr,
     ptree params = ptree::parse_info(params_info ? params_info : "");
     AmgOptions opts;
     opts.max_levels = params.get("solver.amg.max_levels", 10);
-    opts.coarsest_size = params.get("solver.amg.coarsest_size", 3000);
+    opts.coarsest_size = params.get("solver.amg.coarsest_size", 400);
     opts.strength = params.get("solver.amg.strength", 0.08);
     opts.smooth_prolongator = params.get("solver.amg.smooth_prolongator", true);
     AmgGridHint grid;

@@ -641,7 +641,7 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
     // smoothed-aggregation hierarchy on the host (the role of ML / AMGx upstream), V-cycle on the device
     AmgOptions opts;
     opts.max_levels = this->_params->get("solver.amg.max_levels", 10);
-    opts.coarsest_size = this->_params->get("solver.amg.coarsest_size", 3000);
+    opts.coarsest_size = this->_params->get("solver.amg.coarsest_size", 400);
     opts.strength = this->_params->get("solver.amg.strength", 0.08);
     opts.smooth_prolongator = this->_params->get("solver.amg.smooth_prolongator", true);
     _amg_cycles = this->_params->get("solver.amg.n_cycles", 1);

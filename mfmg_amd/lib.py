@@ -116,6 +116,12 @@ def load() -> C.CDLL:
         "mfmg_hip_mf_laplace_residual": (C.c_int, [vp, vp, vp, vp]),
         "mfmg_hip_mf_laplace_smoother_step": (C.c_int, [vp, vp, vp, vp, dbl, dbl, vp]),
         "mfmg_hip_mf_laplace_set_tile": (C.c_int, [vp, C.c_int, C.c_int]),
+        "mfmg_hip_mf_laplace_f32_create": (C.c_int, [vp, P(MeshDesc), P(vp)]),
+        "mfmg_hip_mf_laplace_f32_destroy": (C.c_int, [vp]),
+        "mfmg_hip_mf_laplace_f32_vmult": (C.c_int, [vp, vp, vp]),
+        "mfmg_hip_mf_laplace_f32_diagonal_inverse": (C.c_int, [vp, vp]),
+        "mfmg_hip_mf_laplace_f32_residual": (C.c_int, [vp, vp, vp, vp]),
+        "mfmg_hip_mf_laplace_f32_smoother_step": (C.c_int, [vp, vp, vp, vp, C.c_float, C.c_float, vp]),
         "mfmg_hip_hierarchy_create": (C.c_int, [vp, C.c_char_p, P(MeshDesc), C.c_char_p, P(vp)]),
         "mfmg_hip_hierarchy_destroy": (C.c_int, [vp]),
         "mfmg_hip_hierarchy_apply": (C.c_int, [vp, vp, vp]),

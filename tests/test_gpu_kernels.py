@@ -108,6 +108,31 @@ def test_mf_fused_epilogues(ctx):
         op.vmult(xd, xd)
 
 
+def test_mf_fp32_instance(ctx):
+    """BASELINE.json configs[4] (FP32): same kernels instantiated for float; tolerance 1e-4 relative
+     against the FP64 oracle."""
+    n = (20, 12, 9)
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "linear")
+    ref = O.MatrixFreeLaplace(mesh, coef)
+    op = M.MatrixFreeLaplaceF32(ctx, M.LaplaceProblem(n, "linear", device="cuda"))
+    rng = np.random.default_rng(8)
+    x, b, xp = rng.random(mesh.n_dofs), rng.random(mesh.n_dofs), rng.random(mesh.n_dofs)
+    f = lambda a: torch.from_numpy(a.astype(np.float32)).cuda()
+    out = torch.empty(mesh.n_dofs, dtype=torch.float32, device="cuda")
+    op.vmult(out, f(x))
+    ctx.synchronize()
+    assert relerr(out.cpu().numpy().astype(float), ref.vmult(x)) < 1e-4
+    dinv = ref.diagonal_inverse()
+    np.testing.assert_allclose(op.diagonal_inverse().cpu().numpy(), dinv, rtol=1e-5)
+    op.smoother_step(f(b), f(x), f(xp), 0.3, 0.45, out)
+    ctx.synchronize()
+    assert relerr(out.cpu().numpy().astype(float), x + 0.3 * (x - xp) - 0.45 * dinv * (ref.vmult(x) - b)) < 1e-4
+    op.residual(f(x), f(b), out)
+    ctx.synchronize()
+    assert relerr(out.cpu().numpy().astype(float), ref.vmult(x) - b) < 1e-4
+
+
 def test_mf_rejects_bad_input(ctx):
     with pytest.raises(L.MfmgNotImplementedError):
         M.MatrixFreeLaplace(ctx, M.LaplaceProblem((8, 8), device="cuda"))        # dim = 2
