@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--cpu-cycles", type=int, default=2, help="timed V-cycles of the CPU baseline sample")
     ap.add_argument("--no-smoother-512", action="store_true",
                     help="skip the extra fine-level smoother measurement at 512^3 (north_star target config)")
-    ap.add_argument("--tile", type=str, default="", help="ty,tz override of the operator tile")
+    ap.add_argument("--tile", type=str, default="", help="ty,tz[,waves] override of the operator tile (default: timed choice)")
     return ap.parse_args()
 
 

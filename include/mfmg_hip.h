@@ -176,6 +176,8 @@ int mfmg_hip_mf_laplace_f32_smoother_step(mfmg_hip_mf_laplace_f32_t op, const fl
                                           const float *x_prev, float alpha, float beta, float *out);
 /* tuning knob: owned DoF rows / planes per workgroup tile (0 = heuristic) */
 int mfmg_hip_mf_laplace_set_tile(mfmg_hip_mf_laplace_t op, int tile_y, int tile_z);
+/* wavefronts per workgroup (1..8) stacked in y that hand their boundary sums on through LDS (0 = heuristic) */
+int mfmg_hip_mf_laplace_set_tile_waves(mfmg_hip_mf_laplace_t op, int n_waves);
 
 /* ---- hierarchy: Hierarchy<VectorType> ---- */
 /* Evaluator tag strings accepted by the string switch (create_hierarchy_helpers,

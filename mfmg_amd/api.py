@@ -243,8 +243,10 @@ class MatrixFreeLaplace:
         self.ctx.synchronize()
         return out
 
-    def set_tile(self, ty: int, tz: int):
+    def set_tile(self, ty: int, tz: int, waves: int = None):
         check(self._lib.mfmg_hip_mf_laplace_set_tile(self.handle, ty, tz))
+        if waves is not None:
+            check(self._lib.mfmg_hip_mf_laplace_set_tile_waves(self.handle, waves))
 
     def __del__(self):
         try:

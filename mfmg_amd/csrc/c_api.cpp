@@ -518,6 +518,14 @@ int mfmg_hip_mf_laplace_f32_smoother_step(mfmg_hip_mf_laplace_f32_t op, const fl
   });
 }
 
+int mfmg_hip_mf_laplace_set_tile_waves(mfmg_hip_mf_laplace_t op, int n_waves)
+{
+  return guarded([&] {
+    require(op != nullptr, "null operator");
+    require(n_waves >= 0 && n_waves <= 8, "0..8 wavefronts per workgroup");
+    op->op->set_tile_waves(n_waves);
+  });
+}
 int mfmg_hip_mf_laplace_set_tile(mfmg_hip_mf_laplace_t op, int tile_y, int tile_z)
 {
   return guarded([&] {

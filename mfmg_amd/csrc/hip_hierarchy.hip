@@ -595,6 +595,21 @@ void HipSmoother::apply(DVector const &b, DVector &x) const
   }
 }
 
+void HipSmoother::apply_zero_guess(DVector const &b, DVector &x) const
+{
+  // the same update for x = 0 on entry: the first polynomial term is x_1 = beta_0 D^{-1} b (what the fused
+  // kernel returns for A 0 = 0, bit for bit), which needs no operator application
+  const int d = (int)_coefficients.size();
+  if (d != 1)
+  {
+    x = 0.;
+    apply(b, x);
+    return;
+  }
+  vec::scaled_pointwise<double>(_hip_operator->get_hip_handle(), x.size(), _coefficients[0].second,
+                                _hip_operator->get_diagonal_inverse(), b.get_values(), x.get_values());
+}
+
 // ---- HipSolver -----------------------------------------------------------------
 void HipSolver::setup_direct(std::shared_ptr<SparseMatrixDevice<double>> matrix, DeviceBuffer<double> &lu,
                              DeviceBuffer<int32_t> &perm_dev) const
@@ -766,7 +781,6 @@ void HipSolver::apply(DVector const &b, DVector &x) const
   ASSERT_THROW(b.size() == n && x.size() == n, "vector sizes do not match the coarse operator");
   if (_solver == "amg")
   {
-    x = 0.;
     if (_amg_cycles <= 1)
       amg_cycle(0, b, x);
     else
@@ -818,7 +832,8 @@ void HipSolver::apply(DVector const &b, DVector &x) const
 }
 
 // One V-cycle of the aggregation hierarchy: the same recursion as Hierarchy::apply
-// (include/mfmg/common/hierarchy.hpp:246-309) with restrictor = P^T; x must be zero on entry.
+// (include/mfmg/common/hierarchy.hpp:246-309) with restrictor = P^T and a zero initial guess (the
+// content of x on entry is ignored).
 void HipSolver::amg_cycle(size_t level, DVector const &b, DVector &x) const
 {
   AmgLevel const &L = _amg[level];
@@ -834,10 +849,9 @@ void HipSolver::amg_cycle(size_t level, DVector const &b, DVector &x) const
     L.b_coarse = _amg[level + 1].a->build_range_vector();
     L.x_coarse = _amg[level + 1].a->build_range_vector();
   }
-  L.smoother->apply(b, x);
+  L.smoother->apply_zero_guess(b, x); // x = 0 on entry by construction
   L.a->residual(x, b, *L.res);
   L.restrictor->apply(*L.res, *L.b_coarse);
-  *L.x_coarse = 0.;
   amg_cycle(level + 1, *L.b_coarse, *L.x_coarse);
   L.prolongator->apply_subtract(*L.x_coarse, x, OperatorMode::NO_TRANS);
   L.smoother->apply(b, x);

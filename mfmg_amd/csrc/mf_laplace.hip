@@ -1,35 +1,46 @@
-// gfx950 kernels of the matrix-free Q1 Laplace operator.
+// gfx950 kernel of the matrix-free Q1 Laplace operator.
 //
 // Data layout in HBM ("one cell slot per DoF", rows cut into aligned 64-slot chunks): the DoF
-// columns are cut into runs of 63; chunk c of row (j,k) stores the 64 cell slots of the cells
-// i = 63c-1 .. 63c+62 (the low halo cell is stored again, +1.6 % memory), so that every load of a
-// wavefront is one aligned, contiguous KiB (no power-of-two stride between concurrent wavefronts):
-//   S(c,k,j,lane) = ((k Ny + j) ncols + c) 64 + lane
-//   fb0  int4 [S]      DoF ids of the b=0 face: corners (0,0,0) (1,0,0) (0,0,1) (1,0,1)
-//   fb1  int4 [S]      DoF ids of the b=1 face: corners (0,1,0) (1,1,0) (0,1,1) (1,1,1)
-//   coef 16 B [p][S]   the 8 quadrature coefficients, p = 0..NP-1
+// columns are cut into runs of 63; chunk c of row (j,k) holds the 64 cell slots of the cells
+// i = 63c-1 .. 63c+62 (the low halo cell is stored again, +1.6 % memory).  Everything the steady
+// state of the kernel needs for one chunk sits in ONE contiguous record, so that a wavefront streams
+// a single run of memory per row instead of one run per array:
+//   chunk r(c,j,k) = (k Ny + j) ncols + c
+//   rec  [r]  : fb1   int4 [64]      DoF ids of the b=1 face: corners (0,1,0) (1,1,0) (0,1,1) (1,1,1)
+//               coef  16 B [NP][64]  the 8 quadrature coefficients of the cell (NP = 8 sizeof(T) / 16)
+//               dinv  T    [64]      1 / diagonal entry of the slot's own DoF
+//   fb0  [r]  : int4 [64]            DoF ids of the b=0 face: corners (0,0,0) (1,0,0) (0,0,1) (1,0,1)
+//                                    (read for the first row of a tile and by lanes without a cell only)
 // Slot (i,j,k) holds the cell whose lowest corner is DoF (i,j,k); cells that stick out of the
 // mesh on a high face are phantoms with zero coefficient.  The ids are the caller's global DoF
 // ids (any numbering); bit 31 carries the Dirichlet flag, so the constrained-read-as-zero rule
-// costs no extra load.
+// costs no extra load, bit 30 marks DoFs owned by another rank (read, never written).
 //
-// Work decomposition (owner computes, no atomics, no inter-wave synchronisation, results
-// independent of the tiling bit for bit): ONE WAVEFRONT per workgroup marches over a tile of
-// 64 cell columns x (TY+1) cell rows x (TZ+1) cell layers and owns the 63 x TY x TZ DoFs whose
-// eight cells all lie inside (one halo column / row / layer on the low side is recomputed).
+// Work decomposition (owner computes, no atomics, results independent of the tiling bit for bit):
+// a workgroup of NW wavefronts marches over a tile of 64 cell columns x NW TY cell rows x (TZ+1)
+// cell layers and owns the 63 x (NW TY - 1) x TZ DoFs whose eight cells all lie inside (one halo
+// column / row / layer on the low side is recomputed).  Wavefront w computes the TY cell rows
+// [Yb + w TY, Yb + (w+1) TY) and hands the b=1 partial sums of its last row to wavefront w+1 through
+// LDS (one barrier per layer) instead of letting w+1 recompute that row.
 // The 8 corner contributions of a cell are combined
-//   in x : shift by one lane of the right-face values,
-//   in y : a register carried from the previous cell row,
+//   in x : shift by one lane of the right-face values (DPP),
+//   in y : a register carried from the previous cell row (LDS hand-over between wavefronts),
 //   in z : a per-lane column in LDS carried from the previous cell layer,
 // so every DoF value is complete exactly when its own slot is visited and the smoother
 // epilogue (b, D^-1, x_prev) is fused there: A x is never stored.  x is read once per tile: the
 // b=0 face of a cell is the b=1 face of the previous row (registers), the d=0 edge is the d=1 edge
 // of the previous layer (a second per-lane LDS column), the a=1 corners are the a=0 corners of the
-// next lane (DPP wave shift); the steady state loads one id vector and gathers ONE x value per cell.
+// next lane; the steady state reads one record and gathers ONE x value per cell.
+//
+// Memory pipeline: a wavefront pays one memory round trip per row.  The ids of row j+1 are fetched
+// while row j is computed, and the operands of the epilogue (which depend only on the id of the row's
+// own DoF, known one row ahead) are requested together with the coefficients at the top of the row.
+// Vector accesses use a uniform (SGPR) base and a 32-bit per-lane byte offset.
 #include "mf_laplace.hpp"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace mfmg
 {
@@ -39,16 +50,25 @@ constexpr unsigned int kFlag = 0x80000000u;  // bit 31: Dirichlet-constrained Do
 constexpr unsigned int kGhost = 0x40000000u; // bit 30: DoF owned by another rank (read normally, never written)
 constexpr unsigned int kIdMask = ~(kFlag | kGhost);
 
+// geometry of one chunk record
+template <typename T>
+struct Rec
+{
+  static constexpr int W = 16 / sizeof(T);                           // values per 16-byte vector
+  static constexpr int NP = 8 / W;                                    // coefficient vectors per slot
+  static constexpr size_t kCoefOff = 1024;                            // after fb1
+  static constexpr size_t kDinvOff = (size_t)(1 + NP) * 1024;         // after the coefficients
+  static constexpr size_t kBytes = kDinvOff + 64 * sizeof(T);         // 5632 (FP64) / 3328 (FP32)
+};
+
 template <typename T>
 struct MfArgs
 {
+  unsigned char const *rec;
   int4 const *fb0;
-  int4 const *fb1;
-  void const *coef;
-  size_t n_slots;
   T const *x;
   T const *b;
-  T const *dinv;
+  T const *dinv; // by DoF id (the rows handed over between wavefronts)
   T const *xprev;
   T *out;
   int Nx, Ny, Nz;
@@ -62,37 +82,6 @@ struct MfArgs
 // Gauss points of QGauss<1>(2) on [0,1]: interpolation weights S[p][i]
 #define MFMG_GA 0.78867513459481288225 // 1 - g0
 #define MFMG_GB 0.21132486540518711775 // g0
-
-template <typename T>
-__device__ __forceinline__ void load_coef(void const *base, size_t n_slots, size_t slot, T c[8]);
-
-template <>
-__device__ __forceinline__ void load_coef<double>(void const *base, size_t n_slots, size_t slot, double c[8])
-{
-  double2 const *p = reinterpret_cast<double2 const *>(base) + slot;
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-  {
-    double2 v = p[q * n_slots];
-    c[2 * q] = v.x;
-    c[2 * q + 1] = v.y;
-  }
-}
-
-template <>
-__device__ __forceinline__ void load_coef<float>(void const *base, size_t n_slots, size_t slot, float c[8])
-{
-  float4 const *p = reinterpret_cast<float4 const *>(base) + slot;
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-  {
-    float4 v = p[q * n_slots];
-    c[4 * q] = v.x;
-    c[4 * q + 1] = v.y;
-    c[4 * q + 2] = v.z;
-    c[4 * q + 3] = v.w;
-  }
-}
 
 // v = h-scaled G^T diag(c) G u for one Cartesian Q1 cell, sum-factorised.
 // corner m = a + 2b + 4d ; quadrature point q = qa + 2qb + 4qc
@@ -202,15 +191,78 @@ __device__ __forceinline__ void cell_apply(T const u[8], T const c[8], T fx, T f
   v[7] += X11;
 }
 
+// 32-bit byte offsets from a uniform base: the global_load takes the base from SGPRs and one VGPR per
+// lane instead of a 64-bit VGPR pair per request (vectors are limited to 2^32 bytes, checked on the host)
 template <typename T>
-__global__ __launch_bounds__(64) void mf_laplace_kernel(MfArgs<T> a)
+__device__ __forceinline__ T ld_off(T const *base, unsigned int byte_off)
+{
+  return *reinterpret_cast<T const *>(reinterpret_cast<char const *>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ void st_off(T *base, unsigned int byte_off, T v)
+{
+  *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+template <typename T>
+__device__ __forceinline__ unsigned int id_off(int id)
+{
+  return ((unsigned int)id & kIdMask) * (unsigned int)sizeof(T);
+}
+
+template <typename T>
+__device__ __forceinline__ void load_coef(unsigned char const *rec, int lane, T c[8]);
+template <>
+__device__ __forceinline__ void load_coef<double>(unsigned char const *rec, int lane, double c[8])
+{
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+  {
+    const double2 v = reinterpret_cast<double2 const *>(rec + Rec<double>::kCoefOff + q * 1024)[lane];
+    c[2 * q] = v.x;
+    c[2 * q + 1] = v.y;
+  }
+}
+template <>
+__device__ __forceinline__ void load_coef<float>(unsigned char const *rec, int lane, float c[8])
+{
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+  {
+    const float4 v = reinterpret_cast<float4 const *>(rec + Rec<float>::kCoefOff + q * 1024)[lane];
+    c[4 * q] = v.x;
+    c[4 * q + 1] = v.y;
+    c[4 * q + 2] = v.z;
+    c[4 * q + 3] = v.w;
+  }
+}
+
+// fused epilogue of one DoF: ax = (A x)_g, x0 = x_g
+template <typename T>
+__device__ __forceinline__ T mf_epilogue(MfArgs<T> const &a, int id0, T x0, T yv, T lb, T ld, T lxp)
+{
+#pragma clang fp contract(off)
+  const T ax = (id0 < 0) ? x0 : yv; // constrained rows: dst_c = src_c
+  if (a.mode == 0)
+    return ax;
+  if (a.mode == 1)
+    return ax - lb;
+  const T wgt = -(a.beta * ld);
+  const T r = ax - lb;
+  return (a.mode == 2) ? fmadd<T>(wgt, r, x0) : fmadd<T>(wgt, r, fmadd<T>(a.alpha, x0 - lxp, x0));
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
 {
 #pragma clang fp contract(off)
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  T *pt = reinterpret_cast<T *>(smem_raw); // [TY+1][64] z-carry of the partial sums, lane private
-  T *xz = pt + (a.TY + 1) * 64;            // [TY+1][64] z-carry of x: x(ci, j+1, k) of cell row jj
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, keep it scalar
+  const int NW = blockDim.x >> 6;
+  T *pt = reinterpret_cast<T *>(smem_raw) + (size_t)wv * 2 * a.TY * 64;   // [TY][64] z-carry of the partial sums
+  T *xz = pt + a.TY * 64;                                                  // [TY][64] z-carry of x
+  T *xport = reinterpret_cast<T *>(smem_raw) + (size_t)NW * 2 * a.TY * 64; // [2][NW][2][64] hand-over rows
 
-  const int lane = threadIdx.x;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8,
   // observed, speed only); give every XCD a contiguous run of the tile list.
   const unsigned int n_tiles = a.ncols * a.ntiles_y * a.ntiles_z;
@@ -220,76 +272,119 @@ __global__ __launch_bounds__(64) void mf_laplace_kernel(MfArgs<T> a)
     const unsigned int per_xcd = (n_tiles + 7) / 8;
     w = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (w >= n_tiles)
-      return; // (whole wavefront: no barrier is ever reached)
+      return; // the whole workgroup leaves: no barrier is left waiting
   }
   const int tc = w % a.ncols;
   const int tyi = (w / a.ncols) % a.ntiles_y;
   const int tzi = w / (a.ncols * a.ntiles_y);
-  const int ci = tc * 63 - 1 + lane; // cell / DoF column of this lane
-  const int Y0 = tyi * a.TY;
+  const int ci = tc * 63 - 1 + lane;                     // cell / DoF column of this lane
+  const int Yb = tyi * (NW * a.TY - 1) - 1 + wv * a.TY; // first cell row of this wavefront
   const int Z0 = tzi * a.TZ;
   const bool col_ok = ci >= 0 && ci < a.Nx;
+  const bool col_cell = col_ok && ci < a.Nx - 1;
   const bool col_owned = lane >= 1 && ci < a.Nx;
   // the lane whose a=1 corners are not the a=0 corners of lane+1 inside this wavefront
   const bool no_next = (lane == 63) || (ci + 1 >= a.Nx);
+  const int jj0 = (Yb < 0) ? 1 : 0; // cell row -1 does not exist (its sums are the zero initial carries)
+  const size_t rec_row = (size_t)a.ncols * Rec<T>::kBytes;
+  const size_t fb0_row = (size_t)a.ncols * 64;
 
   for (int kk = 0; kk <= a.TZ; ++kk)
   {
     const int k = Z0 - 1 + kk;
     if (k >= a.Nz)
-      break;
+      break; // uniform over the workgroup
+    const bool kin = k >= 0;
+    const bool kcell = kin && (k < a.Nz - 1);
     const bool layer_carry = (kk > 0) && (k >= 1); // xz holds x(., ., k) written by layer k-1
     T ry0 = T(0), ry1 = T(0);
     // b=0 face carried from the previous cell row: raw x values, ids (flag in bit 31)
     T cx[4] = {T(0), T(0), T(0), T(0)};
     int cid[4] = {0, 0, 0, 0};
     bool carried = false;
-    for (int jj = 0; jj <= a.TY; ++jj)
+    // first DoF row of a wavefront w > 0, finished after the barrier
+    T d00 = T(0), d01 = T(0), dx0 = T(0);
+    int did0 = 0;
+    bool dlive = false;
+
+    // ids of the first row of the layer
+    int j = Yb + jj0;
+    const size_t r0 = ((size_t)max(k, 0) * a.Ny + (size_t)j) * a.ncols + (size_t)tc; // uniform
+    unsigned char const *recp = a.rec + r0 * Rec<T>::kBytes;
+    int4 const *fb0p = a.fb0 + r0 * 64;
+    bool slot = col_ok && kin && (j < a.Ny) && (jj0 < a.TY);
+    bool cell = slot && col_cell && (j < a.Ny - 1) && kcell;
+    int4 pf0 = make_int4(0, 0, 0, 0), pf1 = make_int4(0, 0, 0, 0);
+    if (slot)
+      pf0 = fb0p[lane];
+    if (cell)
+      pf1 = reinterpret_cast<int4 const *>(recp)[lane];
+
+    for (int jj = jj0; jj < a.TY; ++jj, ++j)
     {
-      const int j = Y0 - 1 + jj;
       if (j >= a.Ny)
         break;
-      const bool slot = col_ok && j >= 0 && k >= 0;
-      const bool cell = slot && (ci < a.Nx - 1) && (j < a.Ny - 1) && (k < a.Nz - 1);
+      const bool rown = (jj + 1 < a.TY) && (j + 1 < a.Ny);
+      const bool slotn = col_ok && kin && rown;
+      const bool celln = slotn && col_cell && (j + 1 < a.Ny - 1) && kcell;
+      unsigned char const *recn = recp + rec_row;
+      int4 const *fb0n = fb0p + fb0_row;
       T v[8];
-      T x0 = T(0);
-      int id0 = 0;
-      T n0 = T(0), n2 = T(0), n1x = T(0), n3x = T(0);
-      int4 f1 = make_int4(0, 0, 0, 0);
       T c[8];
-      const size_t s = (((size_t)max(k, 0) * a.Ny + (size_t)max(j, 0)) * a.ncols + (size_t)tc) * 64 + lane;
+      T n0 = T(0), n2 = T(0), n1x = T(0), n3x = T(0);
+      T lb = T(0), ld = T(0), lxp = T(0);
+      const int4 f1 = pf1;
+      if (slot && !carried)
+      {
+        cid[0] = pf0.x;
+        cid[1] = pf0.y;
+        cid[2] = pf0.z;
+        cid[3] = pf0.w;
+      }
+      const int id0 = cid[0];
+      const bool stores = slot && col_owned && jj > 0 && kk > 0 && !((unsigned int)id0 & kGhost);
+      // ---- every request of this row, and the ids of the next one
       if (slot)
       {
         if (!carried)
         {
-          const int4 f0 = a.fb0[s];
-          cid[0] = f0.x;
-          cid[1] = f0.y;
-          cid[2] = f0.z;
-          cid[3] = f0.w;
-          cx[0] = a.x[(unsigned int)f0.x & kIdMask];
+          cx[0] = ld_off<T>(a.x, id_off<T>(cid[0]));
           if (cell)
           {
-            cx[1] = a.x[(unsigned int)f0.y & kIdMask];
-            cx[2] = a.x[(unsigned int)f0.z & kIdMask];
-            cx[3] = a.x[(unsigned int)f0.w & kIdMask];
+            cx[1] = ld_off<T>(a.x, id_off<T>(cid[1]));
+            cx[2] = ld_off<T>(a.x, id_off<T>(cid[2]));
+            cx[3] = ld_off<T>(a.x, id_off<T>(cid[3]));
           }
         }
-        id0 = cid[0];
-        x0 = cx[0];
         if (cell)
         {
-          f1 = a.fb1[s];
-          load_coef<T>(a.coef, a.n_slots, s, c);
-          n2 = a.x[(unsigned int)f1.z & kIdMask];                                   // x(ci, j+1, k+1)
-          n0 = layer_carry ? xz[jj * 64 + lane] : a.x[(unsigned int)f1.x & kIdMask]; // x(ci, j+1, k)
-          if (no_next) // issued together with n2 so that the wavefront pays one memory round trip per row
+          load_coef<T>(recp, lane, c);
+          n2 = ld_off<T>(a.x, id_off<T>(f1.z));                                     // x(ci, j+1, k+1)
+          n0 = layer_carry ? xz[jj * 64 + lane] : ld_off<T>(a.x, id_off<T>(f1.x)); // x(ci, j+1, k)
+          if (no_next)
           {
-            n1x = a.x[(unsigned int)f1.y & kIdMask];
-            n3x = a.x[(unsigned int)f1.w & kIdMask];
+            n1x = ld_off<T>(a.x, id_off<T>(f1.y));
+            n3x = ld_off<T>(a.x, id_off<T>(f1.w));
           }
         }
+        if (stores && a.mode != 0)
+        {
+          const unsigned int g = id_off<T>(id0);
+          lb = ld_off<T>(a.b, g);
+          if (a.mode >= 2)
+            ld = reinterpret_cast<T const *>(recp + Rec<T>::kDinvOff)[lane];
+          if (a.mode == 3)
+            lxp = ld_off<T>(a.xprev, g);
+        }
       }
+      int4 pf1n = make_int4(0, 0, 0, 0);
+      int pf0n = 0;
+      if (celln)
+        pf1n = reinterpret_cast<int4 const *>(recn)[lane];
+      if (slotn && !celln)
+        pf0n = reinterpret_cast<int const *>(fb0n)[4 * lane];
+
+      const T x0 = cx[0];
       // a=1 corners: the a=0 corners of the next lane (every lane takes part in the shift)
       T n1 = from_next_lane(n0), n3 = from_next_lane(n2);
       if (cell)
@@ -334,31 +429,63 @@ __global__ __launch_bounds__(64) void mf_laplace_kernel(MfArgs<T> a)
       const T s10 = v[2] + from_prev_lane(v[3]); // b=1,d=0
       const T s01 = v[4] + from_prev_lane(v[5]); // b=0,d=1
       const T s11 = v[6] + from_prev_lane(v[7]); // b=1,d=1
-      // ---- y combine (register carry), z combine (LDS column carry)
-      const T t0 = s00 + ry0;
-      const T t1 = s01 + ry1;
+      if (jj == 0 && wv > 0)
+      {
+        // the b=1 sums of the row below arrive from wavefront w-1 after the barrier
+        d00 = s00;
+        d01 = s01;
+        dx0 = x0;
+        did0 = id0;
+        dlive = slot && col_owned && kk > 0 && !((unsigned int)id0 & kGhost);
+      }
+      else
+      {
+        // ---- y combine (register carry), z combine (LDS column carry)
+        const T t0 = s00 + ry0;
+        const T t1 = s01 + ry1;
+        T *ptj = pt + jj * 64 + lane;
+        const T yv = (kk > 0) ? (t0 + *ptj) : T(0);
+        *ptj = t1;
+        if (stores)
+          st_off<T>(a.out, id_off<T>(id0), mf_epilogue<T>(a, id0, x0, yv, lb, ld, lxp));
+      }
       ry0 = s10;
       ry1 = s11;
-      T *ptj = pt + jj * 64 + lane;
-      const T yv = (kk > 0) ? (t0 + *ptj) : T(0);
-      *ptj = t1;
-
-      if (slot && col_owned && jj > 0 && kk > 0 && !((unsigned int)id0 & kGhost))
+      pf1 = pf1n;
+      pf0.x = pf0n;
+      slot = slotn;
+      cell = celln;
+      recp = recn;
+      fb0p = fb0n;
+    }
+    if (NW > 1)
+    {
+      // exports are double-buffered by layer parity: a slot written in layer k is read after barrier k
+      // and rewritten in layer k+2, i.e. after barrier k+1, which the reader only passes once it has read
+      T *xp = xport + ((size_t)((kk & 1) * NW + wv) * 2) * 64 + lane;
+      xp[0] = ry0;
+      xp[64] = ry1;
+      __syncthreads();
+      if (wv > 0)
       {
-        const unsigned int g = (unsigned int)id0 & kIdMask;
-        const T ax = (id0 < 0) ? x0 : yv; // constrained rows: dst_c = src_c
-        T o;
-        if (a.mode == 0)
-          o = ax;
-        else if (a.mode == 1)
-          o = ax - a.b[g];
-        else
+        T const *ip = xport + ((size_t)((kk & 1) * NW + wv - 1) * 2) * 64 + lane;
+        const T t0 = d00 + ip[0];
+        const T t1 = d01 + ip[64];
+        T *ptj = pt + lane;
+        const T yv = (kk > 0) ? (t0 + *ptj) : T(0);
+        *ptj = t1;
+        if (dlive)
         {
-          const T wgt = -(a.beta * a.dinv[g]);
-          const T r = ax - a.b[g];
-          o = (a.mode == 2) ? fmadd<T>(wgt, r, x0) : fmadd<T>(wgt, r, fmadd<T>(a.alpha, x0 - a.xprev[g], x0));
+          const unsigned int g = id_off<T>(did0);
+          T lb = T(0), ld = T(0), lxp = T(0);
+          if (a.mode != 0)
+            lb = ld_off<T>(a.b, g);
+          if (a.mode >= 2)
+            ld = ld_off<T>(a.dinv, g);
+          if (a.mode == 3)
+            lxp = ld_off<T>(a.xprev, g);
+          st_off<T>(a.out, g, mf_epilogue<T>(a, did0, dx0, yv, lb, ld, lxp));
         }
-        a.out[g] = o;
       }
     }
   }
@@ -368,12 +495,12 @@ __global__ __launch_bounds__(64) void mf_laplace_kernel(MfArgs<T> a)
 template <typename T>
 __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coefficient,
                                  uint8_t const *constrained, int Nx, int Ny, int Nz, int ncols, int4 *fb0,
-                                 int4 *fb1, T *coef)
+                                 unsigned char *rec)
 {
   const int64_t n_slots = (int64_t)ncols * Nz * Ny * 64;
   const int nx = Nx - 1, ny = Ny - 1, nz = Nz - 1;
-  constexpr int W = 16 / sizeof(T); // values per 16-byte vector
-  constexpr int NP = 8 / W;
+  constexpr int W = Rec<T>::W;
+  constexpr int NP = Rec<T>::NP;
   for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n_slots;
        s += (int64_t)gridDim.x * blockDim.x)
   {
@@ -414,19 +541,21 @@ __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coeffic
       }
     }
     fb0[s] = make_int4(id[0], id[1], id[4], id[5]);
-    fb1[s] = make_int4(id[2], id[3], id[6], id[7]);
+    unsigned char *r = rec + (size_t)chunk * Rec<T>::kBytes;
+    reinterpret_cast<int4 *>(r)[lane] = make_int4(id[2], id[3], id[6], id[7]);
     for (int p = 0; p < NP; ++p)
       for (int w = 0; w < W; ++w)
-        coef[((size_t)p * n_slots + s) * W + w] = cf[p * W + w];
+        reinterpret_cast<T *>(r + Rec<T>::kCoefOff + p * 1024)[lane * W + w] = cf[p * W + w];
+    reinterpret_cast<T *>(r + Rec<T>::kDinvOff)[lane] = T(0);
   }
 }
 
-// slot of cell / DoF (i,j,k) in the tile-column-major layout (the copy owned by its column)
-__device__ __forceinline__ size_t slot_of(int i, int j, int k, int Ny, int ncols)
+// chunk and lane of cell / DoF (i,j,k) (the copy owned by its column)
+__device__ __forceinline__ size_t chunk_of(int i, int j, int k, int Ny, int ncols, int &lane)
 {
   const int c = (i + 1) / 63;
-  const int lane = i + 1 - 63 * c;
-  return (((size_t)k * Ny + j) * ncols + c) * 64 + lane;
+  lane = i + 1 - 63 * c;
+  return ((size_t)k * Ny + j) * ncols + c;
 }
 
 __global__ void mf_range_kernel(int32_t const *cell_dofs, int64_t n, int64_t n_dofs, int *n_bad)
@@ -457,8 +586,9 @@ __global__ void mf_validate_kernel(int32_t const *cell_dofs, int4 const *fb0, in
         bad = true;
         continue;
       }
-      const size_t s = slot_of(i + (m & 1), j + ((m >> 1) & 1), k + (m >> 2), Ny, ncols);
-      if ((int)((unsigned int)fb0[s].x & kIdMask) != g)
+      int lane;
+      const size_t r = chunk_of(i + (m & 1), j + ((m >> 1) & 1), k + (m >> 2), Ny, ncols, lane);
+      if ((int)((unsigned int)fb0[r * 64 + lane].x & kIdMask) != g)
         bad = true;
     }
     if (bad)
@@ -474,8 +604,8 @@ struct DiagTable
 // compute_diagonal (tests/laplace_matrix_free.hpp:75-98,158-199): per-cell
 // unit-vector applies summed per DoF; constrained entries set to one.
 template <typename T>
-__global__ void mf_diagonal_kernel(int4 const *fb0, void const *coef, size_t n_slots, int Nx, int Ny, int Nz,
-                                   int ncols, DiagTable tab, T *diag, T *dinv)
+__global__ void mf_diagonal_kernel(int4 const *fb0, unsigned char const *rec, int Nx, int Ny, int Nz, int ncols,
+                                   DiagTable tab, T *diag, T *dinv)
 {
   const int64_t n = (int64_t)Nx * Ny * Nz;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n;
@@ -484,7 +614,9 @@ __global__ void mf_diagonal_kernel(int4 const *fb0, void const *coef, size_t n_s
     const int i = t % Nx;
     const int j = (t / Nx) % Ny;
     const int k = t / ((int64_t)Nx * Ny);
-    const int id0 = fb0[slot_of(i, j, k, Ny, ncols)].x;
+    int lane;
+    const size_t r = chunk_of(i, j, k, Ny, ncols, lane);
+    const int id0 = fb0[r * 64 + lane].x;
     double sum = 0.;
     for (int m = 0; m < 8; ++m)
     {
@@ -492,7 +624,9 @@ __global__ void mf_diagonal_kernel(int4 const *fb0, void const *coef, size_t n_s
       if (ci < 0 || cj < 0 || ck < 0 || ci >= Nx - 1 || cj >= Ny - 1 || ck >= Nz - 1)
         continue;
       T c[8];
-      load_coef<T>(coef, n_slots, slot_of(ci, cj, ck, Ny, ncols), c);
+      int cl;
+      const size_t cr = chunk_of(ci, cj, ck, Ny, ncols, cl);
+      load_coef<T>(rec + cr * Rec<T>::kBytes, cl, c);
       for (int q = 0; q < 8; ++q)
         sum += (double)c[q] * tab.K[q][m];
     }
@@ -500,6 +634,24 @@ __global__ void mf_diagonal_kernel(int4 const *fb0, void const *coef, size_t n_s
     const double d = (id0 < 0) ? 1. : sum;
     diag[g] = T(d);
     dinv[g] = T(1. / d);
+  }
+}
+
+// copy of D^-1 in slot order inside the records (every slot of a real DoF, the duplicated halo slots too)
+template <typename T>
+__global__ void mf_fill_dinv_kernel(int4 const *fb0, T const *dinv, int Nx, int ncols, int64_t n_slots,
+                                    unsigned char *rec)
+{
+  for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n_slots;
+       s += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int lane = s & 63;
+    const int64_t chunk = s >> 6;
+    const int i = (int)(chunk % ncols) * 63 - 1 + lane;
+    if (i < 0 || i >= Nx)
+      continue;
+    const unsigned int g = (unsigned int)fb0[s].x & kIdMask;
+    reinterpret_cast<T *>(rec + (size_t)chunk * Rec<T>::kBytes + Rec<T>::kDinvOff)[lane] = dinv[g];
   }
 }
 } // namespace
@@ -525,6 +677,8 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   }
   ASSERT_THROW(nd == mesh.n_dofs, "n_dofs does not match the cell grid (Q1: (n+1)^dim)");
   ASSERT_THROW(nd < (int64_t(1) << 30), "DoF ids must fit 30 bits (bits 30/31 carry the ghost / constraint flags)");
+  ASSERT_THROW((uint64_t)nd * sizeof(T) <= (uint64_t(1) << 32),
+               "vectors are addressed with 32-bit byte offsets: at most 2^32 bytes per vector and rank");
   _n_dofs = nd;
   for (int d = 0; d < 3; ++d)
     ASSERT_THROW(_n[d] >= 1, "n_cells must be positive");
@@ -550,8 +704,7 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   const size_t n_slots = (size_t)_ncols * _N[2] * _N[1] * 64;
   _n_slots = n_slots;
   _fb0.resize(n_slots);
-  _fb1.resize(n_slots);
-  _coef.resize(n_slots * 8);
+  _rec.resize((n_slots / 64) * Rec<T>::kBytes);
   _diag.resize(nd);
   _dinv.resize(nd);
 
@@ -564,7 +717,7 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   ASSERT_THROW(bad.download(st)[0] == 0, "cell_dofs is not a logically structured hex mesh in lexicographic cell "
                                          "order (DoF ids out of range)");
   hipLaunchKernelGGL(mf_repack_kernel<T>, dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, cd,
-                     co, cn, _N[0], _N[1], _N[2], _ncols, _fb0.data(), _fb1.data(), _coef.data());
+                     co, cn, _N[0], _N[1], _N[2], _ncols, _fb0.data(), _rec.data());
   MFMG_HIP_CHECK(hipGetLastError());
 
   MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
@@ -601,63 +754,87 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
       tab.K[q][m] = sum;
     }
   hipLaunchKernelGGL(mf_diagonal_kernel<T>, dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
-                     _fb0.data(), _coef.data(), _n_slots, _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
+                     _fb0.data(), _rec.data(), _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
+  MFMG_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(mf_fill_dinv_kernel<T>, dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st,
+                     _fb0.data(), _dinv.data(), _N[0], _ncols, (int64_t)n_slots, _rec.data());
   MFMG_HIP_CHECK(hipGetLastError());
   MFMG_HIP_CHECK(hipStreamSynchronize(st));
 }
 
+// ---- tile choice ---------------------------------------------------------------------------------
+// The result does not depend on the tile (bit for bit), only the speed does, and the best tile depends on
+// how the mesh divides into tiles and rounds of workgroups; so the first launch times a short list of
+// candidates on scratch vectors and keeps the fastest (a few launches each; small meshes skip this).
 template <typename T>
-void MatrixFreeLaplaceDevice<T>::choose_tile(int &ty, int &tz) const
+void MatrixFreeLaplaceDevice<T>::choose_tile(int &nw, int &ty, int &tz) const
 {
+  nw = _tile_waves;
   ty = _tile_y;
   tz = _tile_z;
-  if (ty > 0 && tz > 0)
+  if (nw > 0 && ty > 0 && tz > 0)
     return;
-  // heuristic (measured on MI355X, profiles/): the kernel is latency-bound below ~4 rounds of resident
-  // wavefronts (256 CUs x 20), so take the largest tile (least halo re-computation) that still yields that many
-  const int64_t cols = (_N[0] + 62) / 63;
-  const int64_t target_waves = 256 * 80;
-  int best_ty = 1, best_tz = 1;
-  double best_cost = 1e30;
-  const int cand_y[] = {2, 4, 8, 16};
-  const int cand_z[] = {4, 8, 16, 32, 64};
-  for (int cy : cand_y)
-    for (int cz : cand_z)
-    {
-      const int64_t waves = cols * ((_N[1] + cy - 1) / cy) * ((_N[2] + cz - 1) / cz);
-      double cost = (1. + 1. / cy) * (1. + 1. / cz);
-      if (waves < target_waves)
-        cost *= double(target_waves) / double(std::max<int64_t>(waves, 1));
-      if (cost < best_cost)
-      {
-        best_cost = cost;
-        best_ty = cy;
-        best_tz = cz;
-      }
-    }
+  if (_tuned[0] == 0)
+  {
+    _tuned[0] = 4;
+    _tuned[1] = 4;
+    _tuned[2] = 16;
+    if (_n_dofs >= (int64_t(1) << 21))
+      autotune();
+  }
+  if (nw <= 0)
+    nw = _tuned[0];
   if (ty <= 0)
-    ty = best_ty;
+    ty = _tuned[1];
   if (tz <= 0)
-    tz = best_tz;
+    tz = _tuned[2];
+  if (nw * ty < 2)
+    ty = 2;
 }
 
 template <typename T>
-void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha,
-                                        T beta, T *out) const
+void MatrixFreeLaplaceDevice<T>::autotune() const
 {
-  ASSERT_THROW(x != nullptr && out != nullptr, "null vector");
-  ASSERT_THROW(x != out, "the operator kernel cannot run in place (out aliases x)");
-  if (mode != MfMode::apply)
-    ASSERT_THROW(b != nullptr, "null right-hand side");
-  if (mode == MfMode::next)
-    ASSERT_THROW(x_prev != nullptr, "null x_prev");
-  int ty, tz;
-  choose_tile(ty, tz);
+  static const int cand[][3] = {{4, 4, 16}, {4, 3, 16}, {4, 6, 16}, {4, 4, 8},  {4, 8, 16}, {2, 4, 16},
+                                {2, 8, 16}, {8, 4, 16}, {4, 6, 13}, {4, 5, 16}, {4, 4, 32}, {8, 3, 16}};
+  DeviceBuffer<T> x(_n_dofs), y(_n_dofs);
+  hipStream_t st = _handle.stream;
+  MFMG_HIP_CHECK(hipMemcpyAsync(x.data(), _dinv.data(), sizeof(T) * _n_dofs, hipMemcpyDeviceToDevice, st));
+  hipEvent_t e0, e1;
+  MFMG_HIP_CHECK(hipEventCreate(&e0));
+  MFMG_HIP_CHECK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (auto const &c : cand)
+  {
+    run(MfMode::next, x.data(), _diag.data(), _dinv.data(), T(0.3), T(0.4), y.data(), c[0], c[1], c[2]);
+    MFMG_HIP_CHECK(hipEventRecord(e0, st));
+    for (int r = 0; r < 2; ++r)
+      run(MfMode::next, x.data(), _diag.data(), _dinv.data(), T(0.3), T(0.4), y.data(), c[0], c[1], c[2]);
+    MFMG_HIP_CHECK(hipEventRecord(e1, st));
+    MFMG_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MFMG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best)
+    {
+      best = ms;
+      _tuned[0] = c[0];
+      _tuned[1] = c[1];
+      _tuned[2] = c[2];
+    }
+  }
+  MFMG_HIP_CHECK(hipEventDestroy(e0));
+  MFMG_HIP_CHECK(hipEventDestroy(e1));
+}
+
+template <typename T>
+void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out,
+                                     int nw, int ty, int tz) const
+{
+  ASSERT_THROW(nw >= 1 && nw <= 8, "1..8 wavefronts per workgroup");
+  ASSERT_THROW(ty >= 1 && tz >= 1 && nw * ty >= 2, "operator tile too small");
   MfArgs<T> a;
+  a.rec = _rec.data();
   a.fb0 = _fb0.data();
-  a.fb1 = _fb1.data();
-  a.coef = _coef.data();
-  a.n_slots = _n_slots;
   a.x = x;
   a.b = b;
   a.dinv = _dinv.data();
@@ -675,21 +852,38 @@ void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T c
   a.alpha = alpha;
   a.beta = beta;
   a.mode = static_cast<int>(mode);
-  const size_t lds = (size_t)2 * (ty + 1) * 64 * sizeof(T);
   a.ncols = _ncols;
-  a.ntiles_y = (_N[1] + ty - 1) / ty;
+  // ty cell rows per wavefront, nw ty - 1 owned DoF rows per workgroup
+  a.ntiles_y = (_N[1] + nw * ty - 2) / (nw * ty - 1);
   a.ntiles_z = (_N[2] + tz - 1) / tz;
+  const size_t lds = ((size_t)nw * 2 * ty + (size_t)2 * nw * 2) * 64 * sizeof(T);
+  ASSERT_THROW(lds <= 64 * 1024, "operator tile too large for the LDS");
   const uint64_t n_tiles = (uint64_t)a.ncols * a.ntiles_y * a.ntiles_z;
   ASSERT_THROW(n_tiles < (1ull << 31), "operator tile too small for this mesh (grid size limit)");
-  // one wavefront per tile; rounded up to a multiple of 8 for the XCD-contiguous tile order
+  // rounded up to a multiple of 8 for the XCD-contiguous tile order
   dim3 grid((unsigned int)(n_tiles >= 64 ? ((n_tiles + 7) / 8) * 8 : n_tiles));
+  hipLaunchKernelGGL(mf_laplace_kernel<T>, grid, dim3(64 * nw), lds, _handle.stream, a);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha,
+                                        T beta, T *out) const
+{
+  ASSERT_THROW(x != nullptr && out != nullptr, "null vector");
+  ASSERT_THROW(x != out, "the operator kernel cannot run in place (out aliases x)");
+  if (mode != MfMode::apply)
+    ASSERT_THROW(b != nullptr, "null right-hand side");
+  if (mode == MfMode::next)
+    ASSERT_THROW(x_prev != nullptr, "null x_prev");
+  int nw, ty, tz;
+  choose_tile(nw, ty, tz);
   // algorithmic bytes per launch: x + out + 8 idx + 8 coef, plus b / D^-1 / x_prev reads
   const double extra = (mode == MfMode::apply) ? 0. : (mode == MfMode::residual) ? 1. : (mode == MfMode::first) ? 2. : 3.;
   hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel", algorithmic_bytes_apply() + extra * sizeof(T) * double(_n_dofs),
                                            _handle.stream);
-  hipLaunchKernelGGL(mf_laplace_kernel<T>, grid, dim3(64), lds, _handle.stream, a);
+  run(mode, x, b, x_prev, alpha, beta, out, nw, ty, tz);
   KernelProfiler::end(stop, _handle.stream);
-  MFMG_HIP_CHECK(hipGetLastError());
 }
 
 template class MatrixFreeLaplaceDevice<double>;

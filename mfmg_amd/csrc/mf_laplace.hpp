@@ -50,11 +50,13 @@ public:
   T const *diagonal() const { return _diag.data(); }
   T const *diagonal_inverse() const { return _dinv.data(); }
 
+  // tile of one workgroup: n_waves wavefronts of ty cell rows each, tz layers (0 = timed choice at first use)
   void set_tile(int ty, int tz)
   {
     _tile_y = ty;
     _tile_z = tz;
   }
+  void set_tile_waves(int nw) { _tile_waves = nw; }
   HipHandle &handle() const { return _handle; }
 
   // algorithmic bytes of one operator application (112 B/DoF in FP64)
@@ -65,22 +67,24 @@ public:
 
 private:
   void launch(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out) const;
-  void choose_tile(int &ty, int &tz) const;
+  void run(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out, int nw, int ty,
+           int tz) const;
+  void choose_tile(int &nw, int &ty, int &tz) const;
+  void autotune() const;
 
   HipHandle &_handle;
   int _N[3]; // DoF grid
   int _n[3]; // cells
   double _h[3];
   int64_t _n_dofs;
-  // internal layout, one cell slot per DoF, rows cut into aligned chunks S = ((k Ny + j) ncols + c) 64 + lane with
-  // columns of 63 owned DoFs + the low halo cell, planes of 16-byte vectors:
-  //   fb0 / fb1 : int4 [S]     DoF ids of the b=0 / b=1 face of the cell, bit31 = constrained
-  //   coef      : 16 B [p][S]  NP = 8*sizeof(T)/16 planes
+  // internal layout (mf_laplace.hip): rows cut into aligned chunks of 64 cell slots (63 owned DoFs + the low
+  // halo cell); one record per chunk with the b=1 face ids, the coefficients and D^-1, plus the b=0 face ids
   int _ncols = 0;
   size_t _n_slots = 0;
-  DeviceBuffer<int4> _fb0, _fb1;
-  DeviceBuffer<T> _coef;
+  DeviceBuffer<int4> _fb0;
+  DeviceBuffer<unsigned char> _rec;
   DeviceBuffer<T> _diag, _dinv;
-  int _tile_y = 0, _tile_z = 0;
+  int _tile_y = 0, _tile_z = 0, _tile_waves = 0;
+  mutable int _tuned[3] = {0, 0, 0};
 };
 } // namespace mfmg

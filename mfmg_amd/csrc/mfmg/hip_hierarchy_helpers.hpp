@@ -210,6 +210,8 @@ public:
   HipSmoother(std::shared_ptr<Operator<DVector> const> op, std::shared_ptr<ptree const> params);
 
   void apply(DVector const &b, DVector &x) const override;
+  // same update when x is known to be zero on entry (content of x ignored); saves one operator application
+  void apply_zero_guess(DVector const &b, DVector &x) const;
 
   int degree() const { return (int)_coefficients.size(); }
   double lambda_min() const { return _lambda_min; }

@@ -41,6 +41,13 @@ __global__ void scale_pointwise_kernel(int64_t n, T const *d, T const *v, T *out
     out[i] = d[i] * v[i];
 }
 
+template <typename T>
+__global__ void scaled_pointwise_kernel(int64_t n, T s, T const *d, T const *v, T *out)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (s * d[i]) * v[i];
+}
+
 __device__ __forceinline__ double block_reduce_sum(double v)
 {
   __shared__ double wsum[16];
@@ -154,6 +161,16 @@ void scale_pointwise(HipHandle &h, int64_t n, T const *d, T const *v, T *out)
 }
 
 template <typename T>
+void scaled_pointwise(HipHandle &h, int64_t n, T s, T const *d, T const *v, T *out)
+{
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(scaled_pointwise_kernel<T>, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, n, s, d,
+                     v, out);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
 void dot_async(HipHandle &h, int64_t n, T const *x, T const *y, double *result_dev, int slot)
 {
   const unsigned int nb = n_blocks_for(n, block_size, kReduceBlocks);
@@ -204,6 +221,7 @@ void cg_direction(HipHandle &h, int64_t n, T const *z, T *p, double const *scal,
   template void add<T>(HipHandle &, int64_t, T, T const *, T *);                                             \
   template void sadd<T>(HipHandle &, int64_t, T, T, T const *, T *);                                         \
   template void scale_pointwise<T>(HipHandle &, int64_t, T const *, T const *, T *);                         \
+  template void scaled_pointwise<T>(HipHandle &, int64_t, T, T const *, T const *, T *);                     \
   template void dot_async<T>(HipHandle &, int64_t, T const *, T const *, double *, int);                     \
   template double dot<T>(HipHandle &, int64_t, T const *, T const *);                                        \
   template double l2_norm<T>(HipHandle &, int64_t, T const *);                                               \

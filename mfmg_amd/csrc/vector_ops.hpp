@@ -20,6 +20,8 @@ template <typename T>
 void sadd(HipHandle &h, int64_t n, T s, T a, T const *v, T *x); // x = s x + a v
 template <typename T>
 void scale_pointwise(HipHandle &h, int64_t n, T const *d, T const *v, T *out); // out = d .* v
+template <typename T>
+void scaled_pointwise(HipHandle &h, int64_t n, T s, T const *d, T const *v, T *out); // out = (s d) .* v
 
 // Deterministic two-stage dot product; the result lands in device slot
 // `result_dev[slot]` (no host synchronisation).

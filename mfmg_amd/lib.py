@@ -116,6 +116,7 @@ def load() -> C.CDLL:
         "mfmg_hip_mf_laplace_residual": (C.c_int, [vp, vp, vp, vp]),
         "mfmg_hip_mf_laplace_smoother_step": (C.c_int, [vp, vp, vp, vp, dbl, dbl, vp]),
         "mfmg_hip_mf_laplace_set_tile": (C.c_int, [vp, C.c_int, C.c_int]),
+        "mfmg_hip_mf_laplace_set_tile_waves": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_mf_laplace_f32_create": (C.c_int, [vp, P(MeshDesc), P(vp)]),
         "mfmg_hip_mf_laplace_f32_destroy": (C.c_int, [vp]),
         "mfmg_hip_mf_laplace_f32_vmult": (C.c_int, [vp, vp, vp]),

@@ -1,6 +1,6 @@
 # usage: smoother_only.py n ty tz reps [calib]
-import sys, torch
-sys.path.insert(0,'.')
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import mfmg_amd as M
 from bench import smoother_coefficients
 n, ty, tz, reps = (int(v) for v in sys.argv[1:5])
@@ -9,7 +9,7 @@ prob = M.LaplaceProblem((n-1,)*3, device='cuda')
 op = M.MatrixFreeLaplace(ctx, prob)
 N = prob.n_dofs
 del prob; torch.cuda.empty_cache()
-op.set_tile(ty, tz)
+op.set_tile(ty, tz, int(os.environ.get('WAVES', '1')))
 x = torch.rand(N, dtype=torch.float64, device='cuda'); b = torch.zeros_like(x); s1=torch.empty_like(x); s2=torch.empty_like(x)
 coefs = smoother_coefficients(3, 0.09, 1.8)
 for _ in range(reps):

@@ -47,8 +47,9 @@ def test_mf_vmult_matches_oracle(ctx, n, material):
     np.testing.assert_allclose(host(op.diagonal_inverse(), ctx), ref.diagonal_inverse(), rtol=1e-13)
 
 
-@pytest.mark.parametrize("ty,tz", [(1, 1), (2, 3), (4, 8), (16, 2), (5, 64)])
-def test_mf_vmult_independent_of_tile(ctx, ty, tz):
+@pytest.mark.parametrize("nw,ty,tz", [(1, 2, 1), (1, 5, 3), (2, 3, 8), (4, 4, 16), (8, 1, 2), (3, 2, 5), (4, 12, 2),
+                                      (8, 5, 64), (0, 1, 1)])
+def test_mf_vmult_independent_of_tile(ctx, nw, ty, tz):
     n = (20, 13, 9)
     mesh = O.StructuredMesh(n)
     coef = O.coefficient_table(mesh, "linear")
@@ -58,7 +59,7 @@ def test_mf_vmult_independent_of_tile(ctx, ty, tz):
     y0 = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
     op.vmult(y0, dev(x))
     y0 = host(y0, ctx).copy()
-    op.set_tile(ty, tz)
+    op.set_tile(ty, tz, nw)
     y = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
     op.vmult(y, dev(x))
     y = host(y, ctx)
