@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--cpu-cycles", type=int, default=2, help="timed V-cycles of the CPU baseline sample")
     ap.add_argument("--no-smoother-512", action="store_true",
                     help="skip the extra fine-level smoother measurement at 512^3 (north_star target config)")
+    ap.add_argument("--amg-block", type=int, default=2, help="nodes per direction of one aggregate of the coarse AMG")
+    ap.add_argument("--amg-degree", type=int, default=1, help="Chebyshev degree of the coarse AMG smoothers")
     ap.add_argument("--tile", type=str, default="", help="ty,tz[,waves] override of the operator tile (default: timed choice)")
     return ap.parse_args()
 
@@ -182,7 +184,8 @@ def main():
         "agglomeration": {"partitioner": "block", "nx": 2, "ny": 2, "nz": 2},
         "smoother": {"type": "Chebyshev", "degree": args.degree, "smoothing_range": 20.0, "n_smoothing_steps": 1},
         "solver": ({"type": "pcg", "n_iterations": args.coarse_iters} if args.coarse == "pcg" else
-                   {"type": "amg", "amg": {"smoother_degree": 1, "smoothing_range": 4.0, "n_cycles": 1}}),
+                   {"type": "amg", "amg": {"smoother_degree": args.amg_degree, "smoothing_range": 4.0, "n_cycles": 1,
+                                           "aggregate_block": args.amg_block}}),
         "is preconditioner": False,
         "max levels": 2,
     }
@@ -265,6 +268,7 @@ def main():
                             f"Chebyshev({degree}) smoother, coarse level {n_coarse} DoFs: " + coarse_desc + ", FP64",
                 "fine_dofs_per_gpu": n_fine,
                 "coarse_dofs_per_gpu": n_coarse,
+                "coarse_amg_levels_rows_nnzA_nnzP": (h.coarse_amg_shapes() if args.coarse == "amg" else None),
                 "smoother": {"type": "Chebyshev", "degree": degree, "lambda_min": lmin, "lambda_max": lmax},
                 "parallelism": "1 GPU" if world == 1 else
                                f"{world} GPUs, z-slab domain decomposition of a {gx}x{gy}x{gz}-cell box, one-plane halo "

@@ -153,6 +153,14 @@ class SparseMatrixDevice:
         check(self._lib.mfmg_hip_csr_shape(self.handle, None, None, C.byref(z)))
         return z.value
 
+    def set_kernel(self, lanes_per_row: int = 0, use_lds: int = -1):
+        check(self._lib.mfmg_hip_csr_set_kernel(self.handle, lanes_per_row, use_lds))
+
+    def get_kernel(self):
+        a, b = C.c_int(), C.c_int()
+        check(self._lib.mfmg_hip_csr_get_kernel(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def vmult(self, dst: torch.Tensor, src: torch.Tensor):
         m, n = self.shape
         check(self._lib.mfmg_hip_csr_vmult(self.handle, _dev_ptr(src, n), _dev_ptr(dst, m)))
@@ -379,6 +387,23 @@ class Hierarchy:
                 check(self._lib.mfmg_hip_hierarchy_coarse_amg_smoother(self.handle, l, C.byref(d), C.byref(lo), C.byref(hi)))
                 cheb = (d.value, lo.value, hi.value)
             out.append((A, P, cheb))
+        return out
+
+    def coarse_amg_shapes(self):
+        """[(rows, nnz(A_l), nnz(P_l) or 0)] of the multilevel coarse solver (no download)."""
+        n = C.c_int32()
+        check(self._lib.mfmg_hip_hierarchy_coarse_amg_levels(self.handle, C.byref(n)))
+        out = []
+        for l in range(n.value):
+            h = C.c_void_p()
+            check(self._lib.mfmg_hip_hierarchy_coarse_amg_get(self.handle, l, 0, C.byref(h)))
+            A = SparseMatrixDevice(self.ctx, _handle=h, _borrowed=True, _keepalive=self)
+            rows, an, pn = A.shape[0], A.nnz, 0
+            if l + 1 < n.value:
+                hp = C.c_void_p()
+                check(self._lib.mfmg_hip_hierarchy_coarse_amg_get(self.handle, l, 1, C.byref(hp)))
+                pn = SparseMatrixDevice(self.ctx, _handle=hp, _borrowed=True, _keepalive=self).nnz
+            out.append((rows, an, pn))
         return out
 
     def smoother_info(self):

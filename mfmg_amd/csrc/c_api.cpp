@@ -303,6 +303,23 @@ int mfmg_hip_csr_destroy(mfmg_hip_csr_t a)
   });
 }
 
+int mfmg_hip_csr_set_kernel(mfmg_hip_csr_t a, int lanes_per_row, int use_lds)
+{
+  return guarded([&] {
+    require(a != nullptr, "null matrix");
+    require(lanes_per_row >= 0 && lanes_per_row <= 64 && (lanes_per_row & (lanes_per_row - 1)) == 0,
+            "lanes_per_row must be 0 or a power of two up to 64");
+    a->op->get_matrix()->set_kernel(lanes_per_row, use_lds);
+  });
+}
+int mfmg_hip_csr_get_kernel(mfmg_hip_csr_t a, int *lanes_per_row, int *use_lds)
+{
+  return guarded([&] {
+    require(a && lanes_per_row && use_lds, "null argument");
+    *lanes_per_row = a->op->get_matrix()->lanes_per_row();
+    *use_lds = a->op->get_matrix()->kernel_kind();
+  });
+}
 int mfmg_hip_csr_shape(mfmg_hip_csr_t a, int64_t *n_rows, int64_t *n_cols, int64_t *nnz)
 {
   return guarded([&] {
@@ -916,6 +933,10 @@ int mfmg_hip_host_amg_build(int64_t n_rows, int64_t nnz, const int32_t *row_ptr,
       for (int d = 0; d < 3; ++d)
         grid.dims[d] = grid_dims[d];
       grid.node_of_row.assign(node_of_row, node_of_row + n_rows);
+      const int blk = params.get("solver.amg.aggregate_block", 2);
+      require(blk >= 2 && blk <= 8, "solver.amg.aggregate_block must be in 2..8");
+      for (int d = 0; d < 3; ++d)
+        grid.block[d] = blk;
       if (component_of_row)
       {
         grid.component_of_row.assign(component_of_row, component_of_row + n_rows);

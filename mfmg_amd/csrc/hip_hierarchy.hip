@@ -672,7 +672,13 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
     const bool geometric = this->_params->get("solver.amg.geometric_aggregates", true);
     AmgGridHint local_grid;
     if (geometric && grid)
+    {
       local_grid = *grid;
+      const int blk = this->_params->get("solver.amg.aggregate_block", 2);
+      ASSERT_THROW(blk >= 2 && blk <= 8, "solver.amg.aggregate_block must be in 2..8");
+      for (int d = 0; d < 3; ++d)
+        local_grid.block[d] = blk;
+    }
     int64_t row_off = 0;
     if (distributed)
     {

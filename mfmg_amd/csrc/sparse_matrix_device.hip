@@ -165,6 +165,63 @@ __global__ void csr_inv_diag_kernel(T const *val, int32_t const *col, int32_t co
   dinv[row] = (d != T(0)) ? T(1) / d : T(0); // emptied (ghost) rows have no diagonal
 }
 
+// Block-diagonal ("stencil") storage for square matrices whose rows come in nodes of C unknowns on a
+// lexicographically numbered grid -- the coarse operators of the AMGe hierarchy on structured agglomerates:
+// every C x C block sits on one of D block diagonals, node + offs[d].  Values are kept per diagonal and
+// block column, val[(d C + cc) n_rows + r], so a wavefront reads 512 contiguous bytes per request and the
+// matrix stream carries no column indices at all (8 B per stored entry instead of 10-12); x is read
+// through L1/L2 (consecutive rows read consecutive entries).  One thread per row, fixed summation order.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void bdia_spmv_kernel(CsrArgs<T> a, T const *val, int32_t const *offs, int D)
+{
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= a.n_rows)
+    return;
+  const int64_t n_nodes = a.n_rows / C;
+  const int64_t node = r / C;
+  T const *vp = val + r;
+  const size_t stride = (size_t)a.n_rows;
+  T sum = T(0);
+#pragma unroll 4
+  for (int d = 0; d < D; ++d)
+  {
+    const int64_t nb = node + offs[d];
+    if (nb >= 0 && nb < n_nodes)
+    {
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc)
+        sum += vp[(size_t)(d * C + cc) * stride] * a.x[nb * C + cc];
+    }
+  }
+  const int64_t row = r;
+  T o;
+  switch (a.mode)
+  {
+  case 0:
+    o = sum;
+    break;
+  case 1:
+    o = sum - a.b[row];
+    break;
+  case 2:
+    o = a.x[row] - a.beta * a.dinv[row] * (sum - a.b[row]);
+    break;
+  case 3:
+  {
+    const T xr = a.x[row];
+    o = xr + a.alpha * (xr - a.xprev[row]) - a.beta * a.dinv[row] * (sum - a.b[row]);
+    break;
+  }
+  case 4:
+    o = a.out[row] - sum;
+    break;
+  default:
+    o = a.out[row] + sum;
+    break;
+  }
+  a.out[row] = o;
+}
+
 template <typename T, int LPR>
 void launch_lds(CsrArgs<T> const &a, hipStream_t st, int32_t const *blk_ptr, int32_t const *l2g, uint16_t const *lcol,
                 int rows_per_block, int max_cols)
@@ -200,12 +257,16 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
   for (int64_t p = 0; p < _nnz; ++p)
     ASSERT_THROW(col[p] >= 0 && col[p] < n_cols, "column index out of range");
   const double avg = n_rows > 0 ? double(_nnz) / double(n_rows) : 0.;
-  int lpr = 1;
-  while (lpr < 64 && lpr * 2 <= avg * 0.75 + 0.5)
+  // lanes per row: about 3-6 entries per lane (measured on R, R^T, A_c and the prolongators, profiles/)
+  int lpr = 4;
+  while (lpr < 64 && lpr * 2 <= avg / 3.3)
     lpr *= 2;
+  if (avg < 3.)
+    lpr = avg < 1.5 ? 1 : 2;
   _lanes_per_row = lpr;
   // ---- block-local column compression for the LDS-cached kernel
-  if (n_rows >= 4 * kRowsPerBlock && avg >= 4.)
+  // (a 128-row block per workgroup: below ~256 blocks the plain kernel fills the chip better)
+  if (n_rows >= 256 * kRowsPerBlock && avg >= 4.)
   {
     const int64_t nb = (n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
     std::vector<int32_t> blk_ptr(nb + 1, 0);
@@ -249,6 +310,9 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
       _lds_max_cols = max_cols;
     }
   }
+  // ---- block-diagonal storage (see bdia_spmv_kernel)
+  if (n_rows == n_cols && n_rows >= 32768 && avg >= 8.)
+    build_block_diagonals(row_ptr, col, val);
   _val.upload(val.data(), val.size(), handle.stream);
   _col.upload(col.data(), col.size(), handle.stream);
   _row_ptr.upload(row_ptr.data(), row_ptr.size(), handle.stream);
@@ -258,6 +322,77 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
     _col_host = std::move(col);
     _val_host = std::move(val);
   }
+}
+
+template <typename T>
+void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &row_ptr, std::vector<int32_t> const &col,
+                                                  std::vector<T> const &val)
+{
+  const int64_t n = _n_rows;
+  int best_c = 0;
+  std::vector<int32_t> best_offs;
+  double best_fill = 0.;
+  for (int c = 1; c <= 4; ++c)
+  {
+    if (n % c != 0)
+      continue;
+    // block offsets met on a sample of the rows; the fill pass below checks every entry
+    std::vector<int32_t> offs;
+    bool too_many = false;
+    int64_t step = std::max<int64_t>(1, n / 65536);
+    while (step % 2 == 0 || step % 3 == 0) // the sample must meet every row position inside a node
+      ++step;
+    for (int64_t r = 0; r < n && !too_many; r += step)
+      for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
+      {
+        const int32_t o = (int32_t)(col[p] / c - r / c);
+        auto it = std::lower_bound(offs.begin(), offs.end(), o);
+        if (it == offs.end() || *it != o)
+        {
+          offs.insert(it, o);
+          if (offs.size() > 160)
+          {
+            too_many = true;
+            break;
+          }
+        }
+      }
+    if (too_many || offs.empty())
+      continue;
+    const double fill = double(_nnz) / (double(n) * double(offs.size()) * c);
+    if (fill > best_fill)
+    {
+      best_fill = fill;
+      best_c = c;
+      best_offs = offs;
+    }
+  }
+  if (best_c == 0 || best_fill < 0.8)
+    return;
+  const int c = best_c, D = (int)best_offs.size();
+  std::vector<T> dv((size_t)n * D * c, T(0));
+  bool ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : ok)
+  for (int64_t r = 0; r < n; ++r)
+    for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
+    {
+      const int32_t o = (int32_t)(col[p] / c - r / c);
+      auto it = std::lower_bound(best_offs.begin(), best_offs.end(), o);
+      if (it == best_offs.end() || *it != o)
+      {
+        ok = false;
+        continue;
+      }
+      const int d = (int)(it - best_offs.begin());
+      dv[((size_t)d * c + (size_t)(col[p] % c)) * n + r] += val[p];
+    }
+  if (!ok)
+    return;
+  _bdia_val.upload(dv.data(), dv.size(), _handle.stream);
+  _bdia_offs.upload(best_offs.data(), best_offs.size(), _handle.stream);
+  _bdia_c = c;
+  _bdia_d = D;
+  _use_bdia = true;
 }
 
 template <typename T>
@@ -285,6 +420,30 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
   const double extra = (mode == CsrMode::apply) ? 0. : (mode == CsrMode::first) ? 3. : (mode == CsrMode::next) ? 4. : 1.;
   hipEvent_t stop =
       _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes_apply() + extra * sizeof(T) * double(_n_rows), st);
+  if (_use_bdia)
+  {
+    const dim3 grid((unsigned int)((_n_rows + 255) / 256));
+    T const *dv = _bdia_val.data();
+    int32_t const *of = _bdia_offs.data();
+    switch (_bdia_c)
+    {
+    case 1:
+      hipLaunchKernelGGL((bdia_spmv_kernel<T, 1>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+      break;
+    case 2:
+      hipLaunchKernelGGL((bdia_spmv_kernel<T, 2>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+      break;
+    case 3:
+      hipLaunchKernelGGL((bdia_spmv_kernel<T, 3>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+      break;
+    default:
+      hipLaunchKernelGGL((bdia_spmv_kernel<T, 4>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+      break;
+    }
+    KernelProfiler::end(stop, st);
+    MFMG_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (_use_lds)
   {
     int32_t const *bp = _blk_ptr.data(), *lg = _l2g.data();

@@ -247,6 +247,51 @@ def test_csr_fused_modes_27pt(ctx):
                                    np.array([1.0, 1.0]), (1, 3))).shape
 
 
+@pytest.mark.parametrize("comps", [1, 2, 3])
+def test_csr_kernel_variants_on_stencil_matrix(ctx, comps):
+    """A stencil matrix with `comps` unknowns per grid node (the shape of the AMGe coarse operators): the
+    block-diagonal storage is chosen and every kernel variant / fused mode agrees with the CPU SpMV."""
+    import scipy.sparse as sp
+    dims = (37, 33, 29)
+    rng = np.random.default_rng(11)
+
+    def t1(n):
+        return sp.diags([np.ones(n - 1), np.ones(n), np.ones(n - 1)], [-1, 0, 1])
+    pattern = sp.kron(t1(dims[2]), sp.kron(t1(dims[1]), t1(dims[0]))).tocsr()
+    A = sp.kron(pattern, np.ones((comps, comps))).tocsr()
+    A.data = rng.random(A.nnz) - 0.3
+    # a few rows lose entries (boundary-like irregularity stays inside the stencil)
+    A.data[rng.integers(0, A.nnz, 500)] = 0.0
+    A.eliminate_zeros()
+    A = (A + sp.diags(np.full(A.shape[0], 30.0))).tocsr()
+    A.sort_indices()
+    n = A.shape[0]
+    Ad = M.SparseMatrixDevice(ctx, A)
+    lpr, kind = Ad.get_kernel()
+    assert kind == 2, "block-diagonal storage expected for a stencil matrix"
+    x, b, xp = rng.random(n), rng.random(n), rng.random(n)
+    dinv = 1.0 / A.diagonal()
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    ref = O.csr_spmv(A.indptr, A.indices, A.data, x)
+    for k in (2, 1, 0):
+        Ad.set_kernel(0, k)
+        if k == 1 and Ad.get_kernel()[1] != 1:
+            continue                         # LDS lists are only built for large matrices
+        Ad.vmult(out, dev(x))
+        assert relerr(host(out, ctx), ref) < TOL
+        Ad.residual(dev(x), dev(b), out)
+        assert relerr(host(out, ctx), ref - b) < TOL
+        Ad.smoother_step(dev(dinv), dev(b), dev(x), dev(xp), 0.25, 0.6, out)
+        assert relerr(host(out, ctx), x + 0.25 * (x - xp) - 0.6 * dinv * (ref - b)) < TOL
+        Ad.smoother_step(dev(dinv), dev(b), dev(x), None, 0.0, 0.6, out)
+        assert relerr(host(out, ctx), x - 0.6 * dinv * (ref - b)) < TOL
+    # an unstructured matrix of the same size keeps the CSR kernels
+    cols = rng.integers(0, n, size=(n, 20))
+    B = sp.csr_matrix((rng.random(n * 20), cols.ravel(), np.arange(0, 20 * n + 1, 20)), shape=(n, n))
+    B.sum_duplicates()
+    assert M.SparseMatrixDevice(ctx, B).get_kernel()[1] != 2
+
+
 def test_vector_kernels(ctx):
     rng = np.random.default_rng(9)
     for n in (1, 63, 64, 1000, 1 << 20):
