@@ -188,3 +188,24 @@ def test_renumbered_dofs_give_permuted_matrix(mfmg_lib):
     A0 = M.host_assemble_matrix(M.LaplaceProblem(n, "linear")).toarray()
     pn = perm.numpy()
     np.testing.assert_allclose(A[np.ix_(pn, pn)], A0, rtol=1e-14, atol=1e-15)
+
+
+def test_info_parser_reads_the_reference_data_file():
+    """tests/golden/reference_hierarchy_input.info is the reference's tests/data/hierarchy_input.info; the
+    values the reference's tests read from it (tests/test_hierarchy.cc:60-75) come out of the INFO parser."""
+    import json
+    import os
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    info = open(os.path.join(golden, "reference_hierarchy_input.info")).read()
+    want = json.load(open(os.path.join(golden, "reference_golds.json")))["ptree_defaults"]
+    for key, value in want.items():
+        if key == "reference":
+            continue
+        got = params_get(info, key)
+        if isinstance(value, bool):
+            assert got == ("true" if value else "false")
+        elif isinstance(value, (int, float)):
+            assert float(got) == float(value)
+        else:
+            assert got == value
+    assert params_get(info, "hidden.coarse.params.coarse: type") == "Amesos-KLU"

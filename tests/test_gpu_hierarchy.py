@@ -75,6 +75,33 @@ def test_matrix_free_chebyshev_vcycle_history(ctx, n, material, degree):
     assert rate_o < 0.5
 
 
+@pytest.mark.parametrize("name", ["mf_cheb3_8x8x8_linear", "mf_cheb3_12x6x4_constant"])
+def test_vcycle_against_committed_vectors(ctx, name):
+    """The HIP path against tests/golden/oracle_vcycle_*.npz (inputs and expected outputs frozen by
+    tests/golden/make_fixtures.py): operator, setup (R, A_c, smoother bounds) and residual history."""
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"oracle_vcycle_{name}.npz"))
+    n = tuple(int(v) for v in f["cells"])
+    prob = M.LaplaceProblem(n, str(f["material"]), device="cuda")
+    op = M.MatrixFreeLaplace(ctx, prob)
+    y = torch.empty(prob.n_dofs, dtype=torch.float64, device="cuda")
+    op.vmult(y, dev(f["x0"]))
+    ctx.synchronize()
+    np.testing.assert_allclose(y.cpu().numpy(), f["vmult_x0"], rtol=1e-12, atol=1e-13)
+    params = base_params(smoother={"type": "Chebyshev", "degree": int(f["degree"]), "smoothing_range": 20.0})
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    deg, lmin, lmax = h.smoother_info()
+    assert lmax == pytest.approx(float(f["lambda_max"]), rel=1e-10)
+    assert lmin == pytest.approx(float(f["lambda_min"]), rel=1e-10)
+    R = h.restrictor().to_scipy()
+    Rf = sp.csr_matrix((f["R_data"], f["R_indices"], f["R_indptr"]), shape=tuple(f["R_shape"]))
+    assert abs(R - Rf).max() < 1e-11
+    Acf = sp.csr_matrix((f["Ac_data"], f["Ac_indices"], f["Ac_indptr"]), shape=(Rf.shape[0],) * 2)
+    assert abs(h.coarse_operator().to_scipy() - Acf).max() < 1e-11 * abs(Acf).max()
+    res_g, x_g = gpu_history(ctx, h, lambda yy, xx: op.vmult(yy, xx), f["b"], f["x0"])
+    np.testing.assert_allclose(res_g, f["history"], rtol=HIST_TOL, atol=HIST_ATOL)
+
+
 @pytest.mark.parametrize("start", ["dealii", "hashed"])
 def test_eigenvalue_estimate_matches_dealii_restatement(ctx, start):
     n = (8, 8, 8)

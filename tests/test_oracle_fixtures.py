@@ -1,6 +1,9 @@
 """Pins the CPU oracle (oracle/mfmg_oracle.py) against the reference's own fixtures:
 known-answer tests and gold numbers held by /root/reference/tests (cited per test).
 No GPU, no product code."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -232,3 +235,32 @@ def test_minstd_rand0_known_answer():
     for _ in range(10000):
         v = g.next_u32()
     assert v == 1043618065
+
+
+# ---- committed fixtures (tests/golden) ------------------------------------------------------
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_reference_gold_table_is_what_the_tests_above_check():
+    """tests/golden/reference_golds.json lists the reference's known answers; the three gold tests above use
+    exactly these numbers."""
+    import json
+    golds = {g["name"]: g for g in json.load(open(os.path.join(GOLDEN, "reference_golds.json")))["convergence_rates"]}
+    assert golds["cuda_jacobi_hyper_cube"]["value"] == 0.14933479171507894
+    assert golds["cpu_gauss_seidel_hyper_cube"]["value"] == 0.0235237332
+    assert golds["cpu_matrix_free_chebyshev_hyper_cube"]["value"] == 0.0880045475
+
+
+@pytest.mark.parametrize("name", ["mf_cheb3_8x8x8_linear", "mf_cheb3_12x6x4_constant"])
+def test_oracle_reproduces_committed_vectors(name):
+    """The oracle of the day against the vectors frozen by tests/golden/make_fixtures.py."""
+    sys.path.insert(0, GOLDEN)
+    import make_fixtures
+    f = np.load(os.path.join(GOLDEN, f"oracle_vcycle_{name}.npz"))
+    out = make_fixtures.build(*make_fixtures.CASES[name])
+    np.testing.assert_array_equal(out["x0"], f["x0"])
+    np.testing.assert_allclose(out["vmult_x0"], f["vmult_x0"], rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(out["R_data"], f["R_data"], rtol=0, atol=1e-11)
+    np.testing.assert_array_equal(out["R_indices"], f["R_indices"])
+    assert out["lambda_max"] == pytest.approx(float(f["lambda_max"]), rel=1e-12)
+    np.testing.assert_allclose(out["history"], f["history"], rtol=1e-9, atol=1e-13)
