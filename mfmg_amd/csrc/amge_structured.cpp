@@ -473,6 +473,40 @@ void dense_lu_factor(int n, std::vector<double> &A, std::vector<int32_t> &perm)
   A.swap(cm);
 }
 
+void dense_triangular_inverses(int n, std::vector<double> &lu)
+{
+  // column-major packed L\\U -> L^{-1} (unit diagonal implied) below, U^{-1} on and above the diagonal;
+  // every column of an inverse is an independent substitution
+  std::vector<double> out((size_t)n * n, 0.);
+  auto at = [n](std::vector<double> const &m, int r, int c) { return m[(size_t)c * n + r]; };
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int j = 0; j < n; ++j)
+  {
+    std::vector<double> x(n, 0.);
+    // L x = e_j
+    x[j] = 1.;
+    for (int i = j + 1; i < n; ++i)
+    {
+      double s = 0.;
+      for (int k = j; k < i; ++k)
+        s += at(lu, i, k) * x[k];
+      x[i] = -s;
+      out[(size_t)j * n + i] = x[i];
+    }
+    // U x = e_j
+    std::fill(x.begin(), x.end(), 0.);
+    for (int i = j; i >= 0; --i)
+    {
+      double s = (i == j) ? 1. : 0.;
+      for (int k = i + 1; k <= j; ++k)
+        s -= at(lu, i, k) * x[k];
+      x[i] = s / at(lu, i, i);
+      out[(size_t)j * n + i] = x[i];
+    }
+  }
+  lu.swap(out);
+}
+
 namespace
 {
 struct AggResult

@@ -47,6 +47,34 @@ __global__ void dense_lu_solve_kernel(int n, double const *lu, int32_t const *pe
     x[i] = y[i];
 }
 
+// Small systems (n <= kTriangularInverseLimit): the factors are stored inverted, the solve is two dense
+// triangular products x = U^{-1} (L^{-1} (P b)) -- no dependent sweeps, thread i owns entry i.
+__global__ void dense_tri_inverse_solve_kernel(int n, double const *inv, int32_t const *perm, double const *b,
+                                               double *x)
+{
+  __shared__ double y[kTriangularInverseLimit];
+  __shared__ double z[kTriangularInverseLimit];
+  const int i = threadIdx.x;
+  if (i < n)
+    y[i] = b[perm[i]];
+  __syncthreads();
+  if (i < n)
+  {
+    double s = y[i];
+    for (int j = 0; j < i; ++j)
+      s += inv[(size_t)j * n + i] * y[j];
+    z[i] = s;
+  }
+  __syncthreads();
+  if (i < n)
+  {
+    double s = 0.;
+    for (int j = i; j < n; ++j)
+      s += inv[(size_t)j * n + i] * z[j];
+    x[i] = s;
+  }
+}
+
 std::shared_ptr<SparseMatrixDevice<double>> upload(HipHandle &handle, HostCsr &&m)
 {
   return std::make_shared<SparseMatrixDevice<double>>(handle, m.n_rows, m.n_cols, std::move(m.row_ptr),
@@ -93,6 +121,13 @@ void dense_lu_solve(HipHandle &handle, int n, double const *lu, int32_t const *p
 {
   if (n <= 0)
     return;
+  if (n <= kTriangularInverseLimit)
+  {
+    hipLaunchKernelGGL(dense_tri_inverse_solve_kernel, dim3(1), dim3(((n + 63) / 64) * 64), 0, handle.stream, n, lu,
+                       perm, b, x);
+    MFMG_HIP_CHECK(hipGetLastError());
+    return;
+  }
   const int threads = n >= 1024 ? 1024 : (n >= 256 ? 256 : 64);
   static bool attr_set = false;
   if (!attr_set)
@@ -624,6 +659,8 @@ void HipSolver::setup_direct(std::shared_ptr<SparseMatrixDevice<double>> matrix,
       dense[(size_t)r * n + cl[p]] += vl[p];
   std::vector<int32_t> perm;
   dense_lu_factor((int)n, dense, perm);
+  if (n <= kTriangularInverseLimit)
+    dense_triangular_inverses((int)n, dense);
   lu.upload(dense.data(), dense.size(), _handle.stream);
   perm_dev.upload(perm.data(), perm.size(), _handle.stream);
 }
