@@ -265,13 +265,19 @@ void HipMatrixOperator::apply(DVector const &x, DVector &y, OperatorMode mode) c
   {
     ASSERT_THROW(x.size() == _matrix->n() && y.size() == _matrix->m(), "vector sizes do not match the operator");
     _matrix->handle().exchange(_domain_space, const_cast<double *>(x.get_values()));
-    _matrix->vmult(y.get_values(), x.get_values());
+    if (_structured)
+      _structured->restrict_to_coarse(x.get_values(), y.get_values());
+    else
+      _matrix->vmult(y.get_values(), x.get_values());
   }
   else
   {
     ASSERT_THROW(x.size() == _matrix->m() && y.size() == _matrix->n(), "vector sizes do not match the operator");
     _matrix->handle().exchange(_range_space, const_cast<double *>(x.get_values()));
-    get_transposed_matrix()->vmult(y.get_values(), x.get_values());
+    if (_structured)
+      _structured->prolongate(x.get_values(), y.get_values(), false);
+    else
+      get_transposed_matrix()->vmult(y.get_values(), x.get_values());
   }
 }
 
@@ -287,6 +293,8 @@ void HipMatrixOperator::apply_subtract(DVector const &x, DVector &y, OperatorMod
                              const_cast<double *>(x.get_values()));
   if (mode == OperatorMode::NO_TRANS)
     _matrix->vmult_subtract(y.get_values(), x.get_values());
+  else if (_structured)
+    _structured->prolongate(x.get_values(), y.get_values(), true);
   else
     get_transposed_matrix()->vmult_subtract(y.get_values(), x.get_values());
 }
@@ -964,7 +972,12 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
     // rows of the neighbours' agglomerates stay: the lower neighbour's top face is my first owned plane
     // (prolongation), and the Galerkin product of my boundary rows couples to both ghost layers
   }
+  std::shared_ptr<StructuredRestrictorDevice> structured;
+  if (!comm.enabled() && params->get("restrictor.structured", true))
+    structured = StructuredRestrictorDevice::create(_handle, hip_mesh_evaluator->get_mesh(), opts.agglomerate,
+                                                    _grid_hint.dims, _grid_hint.node_of_row, R);
   auto restrictor = std::make_shared<HipMatrixOperator>(upload(_handle, std::move(R)));
+  restrictor->set_structured(structured);
   if (comm.enabled())
     restrictor->set_spaces(1, 2);
   _own_restrictor = restrictor;

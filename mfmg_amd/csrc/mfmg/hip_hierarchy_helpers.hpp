@@ -8,6 +8,7 @@
 #include "../amge_structured.hpp"
 #include "../mf_laplace.hpp"
 #include "../sparse_matrix_device.hpp"
+#include "../structured_restrictor.hpp"
 #include "hierarchy_helpers.hpp"
 #include "vector.hpp"
 
@@ -125,11 +126,16 @@ public:
     _domain_space = domain;
     _range_space = range;
   }
+  // agglomerate-wise evaluation of a restrictor and its transpose (structured_restrictor.hpp); the CSR copy
+  // stays for the setup algebra and for get_restrictor
+  void set_structured(std::shared_ptr<StructuredRestrictorDevice> s) { _structured = std::move(s); }
+  bool has_structured() const { return _structured != nullptr; }
 
 private:
   int _domain_space = 0, _range_space = 0;
   std::shared_ptr<SparseMatrixDevice<double>> _matrix;
   mutable std::shared_ptr<SparseMatrixDevice<double>> _transposed_matrix; // built lazily (cuda_matrix_operator.cu:93-130)
+  std::shared_ptr<StructuredRestrictorDevice> _structured;
   mutable DeviceBuffer<double> _dinv;
 };
 

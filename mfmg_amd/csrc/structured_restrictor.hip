@@ -1,0 +1,234 @@
+// gfx950 kernels of the agglomerate-wise restrictor (structured_restrictor.hpp).
+//
+// restrict : one thread per coarse row r = a E + e.  Consecutive lanes are consecutive rows, so every
+//            plane is read as one contiguous run; the x entries of the patch are shared by the E rows of an
+//            agglomerate and by neighbouring agglomerates (L1/L2).
+// prolong  : one thread per fine node, owner computes (no atomics, fixed summation order).  A node lies
+//            in at most two agglomerates per direction: the one it starts (position m = i mod a) and, on an
+//            agglomerate boundary, the previous one (position m = a).  Lanes of even / odd nodes read two
+//            planes at the rows of consecutive agglomerates; the two eigenvector passes use both halves of
+//            every sector.
+#include "structured_restrictor.hpp"
+
+namespace mfmg
+{
+namespace
+{
+struct SrArgs
+{
+  double const *planes;
+  int32_t const *node_dof; // nullptr: identity
+  int64_t n_coarse;
+  int N[3], na[3], a[3];
+  int n_eig, patch;
+};
+
+__global__ __launch_bounds__(256) void sr_restrict_kernel(SrArgs s, double const *x, double *y)
+{
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= s.n_coarse)
+    return;
+  const int64_t ag = r / s.n_eig;
+  const int ai = ag % s.na[0], aj = (ag / s.na[0]) % s.na[1], ak = ag / ((int64_t)s.na[0] * s.na[1]);
+  const int64_t base = (int64_t)ai * s.a[0] + (int64_t)s.N[0] * ((int64_t)aj * s.a[1] + (int64_t)s.N[1] * ((int64_t)ak * s.a[2]));
+  double const *p = s.planes + r;
+  double sum = 0.;
+  int m = 0;
+  for (int mz = 0; mz <= s.a[2]; ++mz)
+    for (int my = 0; my <= s.a[1]; ++my)
+    {
+      const int64_t row = base + (int64_t)s.N[0] * (my + (int64_t)s.N[1] * mz);
+#pragma unroll 3
+      for (int mx = 0; mx <= s.a[0]; ++mx, ++m)
+      {
+        const int64_t node = row + mx;
+        const int64_t id = s.node_dof ? (int64_t)s.node_dof[node] : node;
+        sum += p[(size_t)m * s.n_coarse] * x[id];
+      }
+    }
+  y[r] = sum;
+}
+
+__global__ __launch_bounds__(256) void sr_prolong_kernel(SrArgs s, double const *y, double *out, int subtract)
+{
+  const int64_t node = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t n_nodes = (int64_t)s.N[0] * s.N[1] * s.N[2];
+  if (node >= n_nodes)
+    return;
+  const int i = node % s.N[0], j = (node / s.N[0]) % s.N[1], k = node / ((int64_t)s.N[0] * s.N[1]);
+  // candidate agglomerates per direction: c = 0 the one the node starts, c = 1 the previous one
+  int ax[2], mx[2], ay[2], my[2], az[2], mz[2];
+  auto candidates = [](int idx, int a, int na, int ag[2], int mm[2]) {
+    ag[0] = idx / a;
+    mm[0] = idx % a;
+    if (ag[0] >= na)
+      ag[0] = -1;
+    ag[1] = (idx % a == 0 && idx / a >= 1) ? idx / a - 1 : -1;
+    mm[1] = a;
+  };
+  candidates(i, s.a[0], s.na[0], ax, mx);
+  candidates(j, s.a[1], s.na[1], ay, my);
+  candidates(k, s.a[2], s.na[2], az, mz);
+  const int px = s.a[0] + 1, py = s.a[1] + 1;
+  double sum = 0.;
+  for (int cz = 0; cz < 2; ++cz)
+  {
+    if (az[cz] < 0)
+      continue;
+    for (int cy = 0; cy < 2; ++cy)
+    {
+      if (ay[cy] < 0)
+        continue;
+      for (int cx = 0; cx < 2; ++cx)
+      {
+        if (ax[cx] < 0)
+          continue;
+        const int64_t ag = ax[cx] + (int64_t)s.na[0] * (ay[cy] + (int64_t)s.na[1] * az[cz]);
+        const int m = mx[cx] + px * (my[cy] + py * mz[cz]);
+        double const *p = s.planes + (size_t)m * s.n_coarse + ag * s.n_eig;
+        double const *yy = y + ag * s.n_eig;
+        for (int e = 0; e < s.n_eig; ++e)
+          sum += p[e] * yy[e];
+      }
+    }
+  }
+  const int64_t id = s.node_dof ? (int64_t)s.node_dof[node] : node;
+  out[id] = subtract ? out[id] - sum : sum;
+}
+} // namespace
+
+std::shared_ptr<StructuredRestrictorDevice>
+StructuredRestrictorDevice::create(HipHandle &handle, StructuredMesh const &mesh, int const agglomerate[3],
+                                   int const agg_dims[3], std::vector<int32_t> const &row_agglomerate,
+                                   HostCsr const &R)
+{
+  if (mesh.dim != 3 || R.n_rows == 0 || (int64_t)row_agglomerate.size() != R.n_rows)
+    return nullptr;
+  int64_t n_agg = 1, n_nodes = 1;
+  for (int d = 0; d < 3; ++d)
+  {
+    if (agglomerate[d] < 1 || mesh.n[d] % agglomerate[d] != 0 || agg_dims[d] != mesh.n[d] / agglomerate[d])
+      return nullptr; // clipped agglomerates have smaller patches
+    n_agg *= agg_dims[d];
+    n_nodes *= mesh.N[d];
+  }
+  if (R.n_rows % n_agg != 0 || R.n_cols != mesh.n_dofs || n_nodes != mesh.n_dofs)
+    return nullptr;
+  const int n_eig = (int)(R.n_rows / n_agg);
+  for (int64_t r = 0; r < R.n_rows; ++r)
+    if (row_agglomerate[r] != r / n_eig)
+      return nullptr;
+  const int px = agglomerate[0] + 1, py = agglomerate[1] + 1, pz = agglomerate[2] + 1;
+  const int patch = px * py * pz;
+  if ((int64_t)mesh.node_dof.size() != n_nodes)
+    return nullptr;
+  // node of every DoF
+  std::vector<int32_t> dof_node(mesh.n_dofs, -1);
+  bool identity = true;
+  for (int64_t nd = 0; nd < n_nodes; ++nd)
+  {
+    const int32_t g = mesh.node_dof[nd];
+    if (g < 0 || g >= mesh.n_dofs)
+      return nullptr;
+    dof_node[g] = (int32_t)nd;
+    identity = identity && (g == nd);
+  }
+  std::vector<double> planes((size_t)patch * R.n_rows, 0.);
+  bool ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : ok)
+  for (int64_t r = 0; r < R.n_rows; ++r)
+  {
+    const int64_t ag = r / n_eig;
+    const int ai = (int)(ag % agg_dims[0]), aj = (int)((ag / agg_dims[0]) % agg_dims[1]),
+              ak = (int)(ag / ((int64_t)agg_dims[0] * agg_dims[1]));
+    for (int p = R.row_ptr[r]; p < R.row_ptr[r + 1]; ++p)
+    {
+      const int32_t nd = dof_node[R.col[p]];
+      if (nd < 0)
+      {
+        ok = false;
+        continue;
+      }
+      const int i = nd % mesh.N[0], j = (nd / mesh.N[0]) % mesh.N[1], k = nd / (mesh.N[0] * mesh.N[1]);
+      const int mx = i - ai * agglomerate[0], my = j - aj * agglomerate[1], mz = k - ak * agglomerate[2];
+      if (mx < 0 || mx >= px || my < 0 || my >= py || mz < 0 || mz >= pz)
+      {
+        ok = false;
+        continue;
+      }
+      planes[(size_t)(mx + px * (my + py * mz)) * R.n_rows + r] += R.val[p];
+    }
+  }
+  if (!ok)
+    return nullptr;
+  std::shared_ptr<StructuredRestrictorDevice> s(new StructuredRestrictorDevice(handle));
+  for (int d = 0; d < 3; ++d)
+  {
+    s->_N[d] = mesh.N[d];
+    s->_na[d] = agg_dims[d];
+    s->_a[d] = agglomerate[d];
+  }
+  s->_n_eig = n_eig;
+  s->_patch = patch;
+  s->_n_coarse = R.n_rows;
+  s->_n_fine = mesh.n_dofs;
+  s->_nnz = R.row_ptr[R.n_rows];
+  s->_identity_numbering = identity;
+  s->_planes.upload(planes.data(), planes.size(), handle.stream);
+  if (!identity)
+    s->_node_dof.upload(mesh.node_dof.data(), mesh.node_dof.size(), handle.stream);
+  MFMG_HIP_CHECK(hipStreamSynchronize(handle.stream));
+  return s;
+}
+
+double StructuredRestrictorDevice::algorithmic_bytes() const
+{
+  return double(_nnz) * 12. + 4. * double(_n_coarse + 1) + 8. * double(_n_fine) + 8. * double(_n_coarse);
+}
+
+namespace
+{
+SrArgs make_args(double const *planes, int32_t const *node_dof, int64_t n_coarse, int const N[3], int const na[3],
+                 int const a[3], int n_eig, int patch)
+{
+  SrArgs s;
+  s.planes = planes;
+  s.node_dof = node_dof;
+  s.n_coarse = n_coarse;
+  for (int d = 0; d < 3; ++d)
+  {
+    s.N[d] = N[d];
+    s.na[d] = na[d];
+    s.a[d] = a[d];
+  }
+  s.n_eig = n_eig;
+  s.patch = patch;
+  return s;
+}
+} // namespace
+
+void StructuredRestrictorDevice::restrict_to_coarse(double const *x, double *y) const
+{
+  ASSERT_THROW(x != nullptr && y != nullptr && x != y, "bad vectors");
+  SrArgs s = make_args(_planes.data(), _identity_numbering ? nullptr : _node_dof.data(), _n_coarse, _N, _na, _a,
+                       _n_eig, _patch);
+  hipEvent_t stop = _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes(), _handle.stream);
+  hipLaunchKernelGGL(sr_restrict_kernel, dim3((unsigned int)((_n_coarse + 255) / 256)), dim3(256), 0,
+                     _handle.stream, s, x, y);
+  KernelProfiler::end(stop, _handle.stream);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+void StructuredRestrictorDevice::prolongate(double const *y, double *out, bool subtract) const
+{
+  ASSERT_THROW(y != nullptr && out != nullptr && y != out, "bad vectors");
+  SrArgs s = make_args(_planes.data(), _identity_numbering ? nullptr : _node_dof.data(), _n_coarse, _N, _na, _a,
+                       _n_eig, _patch);
+  hipEvent_t stop = _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes() + (subtract ? 8. * double(_n_fine) : 0.),
+                                           _handle.stream);
+  hipLaunchKernelGGL(sr_prolong_kernel, dim3((unsigned int)((_n_fine + 255) / 256)), dim3(256), 0, _handle.stream, s,
+                     y, out, subtract ? 1 : 0);
+  KernelProfiler::end(stop, _handle.stream);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+} // namespace mfmg

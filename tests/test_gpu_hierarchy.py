@@ -75,6 +75,42 @@ def test_matrix_free_chebyshev_vcycle_history(ctx, n, material, degree):
     assert rate_o < 0.5
 
 
+@pytest.mark.parametrize("n,numbering", [((8, 6, 4), "lexicographic"), ((6, 6, 6), "random"), ((10, 4, 2), "lexicographic")])
+def test_agglomerate_wise_restrictor_equals_csr(ctx, n, numbering):
+    """The agglomerate-wise evaluation of R and R^T (structured_restrictor.hpp) against the CSR kernels and
+    scipy on the same R, for a lexicographic and a renumbered DoF set; the V-cycle agrees to rounding."""
+    rng = np.random.default_rng(12)
+    nd = int(np.prod([v + 1 for v in n]))
+    perm = torch.from_numpy(rng.permutation(nd)) if numbering == "random" else None
+    hs = {}
+    for structured in (True, False):
+        prob = M.LaplaceProblem(n, "linear", device="cuda", dof_numbering=perm)
+        params = base_params(smoother={"type": "Chebyshev", "degree": 2}, restrictor={"structured": structured})
+        hs[structured] = (M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params), prob)
+    R = hs[False][0].restrictor().to_scipy()
+    assert abs(hs[True][0].restrictor().to_scipy() - R).max() == 0.0
+    xf, xc = rng.random(R.shape[1]), rng.random(R.shape[0])
+    for structured in (True, False):
+        h = hs[structured][0]
+        yc = torch.empty(R.shape[0], dtype=torch.float64, device="cuda")
+        h.restrictor_apply(1, dev(xf), yc)
+        ctx.synchronize()
+        np.testing.assert_allclose(yc.cpu().numpy(), R @ xf, rtol=1e-13, atol=1e-14)
+        yf = torch.full((R.shape[1],), np.nan, dtype=torch.float64, device="cuda")
+        h.restrictor_apply(1, dev(xc), yf, L.TRANS)
+        ctx.synchronize()
+        np.testing.assert_allclose(yf.cpu().numpy(), R.T @ xc, rtol=1e-13, atol=1e-14)
+    b = np.zeros(nd)
+    x0 = rng.random(nd) * (hs[True][1].constrained.cpu().numpy() != 1)
+    out = []
+    for structured in (True, False):
+        h, prob = hs[structured]
+        op = M.MatrixFreeLaplace(ctx, prob)
+        res, _ = gpu_history(ctx, h, lambda yy, xx: op.vmult(yy, xx), b, x0, n_cycles=8)
+        out.append(res)
+    np.testing.assert_allclose(out[0], out[1], rtol=1e-10, atol=HIST_ATOL)
+
+
 @pytest.mark.parametrize("name", ["mf_cheb3_8x8x8_linear", "mf_cheb3_12x6x4_constant"])
 def test_vcycle_against_committed_vectors(ctx, name):
     """The HIP path against tests/golden/oracle_vcycle_*.npz (inputs and expected outputs frozen by
