@@ -59,6 +59,17 @@ def smoother_coefficients(degree, lmin, lmax):
     return out
 
 
+def committed_traffic(args):
+    """HBM bytes per launch of the operator kernel from the PMC passes committed under profiles/ (2 x FETCH_SIZE
+    + WRITE_SIZE, MI355X_MICROARCH.md): counters need rocprofv3 around the process, so this is not a live
+    reading; it only applies to the workload it was collected on (256^3 cells per GPU, degree 3)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "mf_kernel_traffic.json")
+    if args.cells != 256 or args.degree != 3 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["traffic_bytes_per_launch"]
+
+
 def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=5, tile=None):
     """Fine-level smoother apply (degree fused operator kernels) on its own: ms per apply from HIP
     events on the kernels' stream, algorithmic GB/s."""
@@ -285,7 +296,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": committed_traffic(args),
                 "launches_in_timed_region": launches,
                 "avg_launch_ms": k_ms / launches if launches else None,
                 "algorithmic_bytes_per_launch": k_bytes / launches if launches else None,
