@@ -973,7 +973,9 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
     // (prolongation), and the Galerkin product of my boundary rows couples to both ghost layers
   }
   std::shared_ptr<StructuredRestrictorDevice> structured;
-  if (!comm.enabled() && params->get("restrictor.structured", true))
+  // (distributed runs: the local mesh -- owned slab plus one agglomerate layer of each neighbour -- is itself a
+  // full structured mesh and R keeps the rows of the neighbours' agglomerates, so the same evaluation applies)
+  if (params->get("restrictor.structured", true))
     structured = StructuredRestrictorDevice::create(_handle, hip_mesh_evaluator->get_mesh(), opts.agglomerate,
                                                     _grid_hint.dims, _grid_hint.node_of_row, R);
   auto restrictor = std::make_shared<HipMatrixOperator>(upload(_handle, std::move(R)));
