@@ -231,6 +231,10 @@ def main():
         return transport.owned_norm(r)
 
     res_start = residual_norm()
+    if args.tile:
+        _t = [int(v) for v in args.tile.split(',')]
+        h.set_operator_tile(_t[2] if len(_t) > 2 else 0, _t[0], _t[1])
+    mf_tile = h.operator_tile()
     for _ in range(args.warmup):
         h.apply(b, x)
     ctx.profile_enable(True)
@@ -297,7 +301,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": committed_traffic(args),
-                "launches_in_timed_region": launches,
+                "launches_in_timed_region": launches, "tile_waves_ty_tz": list(mf_tile),
                 "avg_launch_ms": k_ms / launches if launches else None,
                 "algorithmic_bytes_per_launch": k_bytes / launches if launches else None,
                 "share_of_step_time": k_ms / (ms_per_step * args.steps) if launches else None,

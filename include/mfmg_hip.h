@@ -183,6 +183,8 @@ int mfmg_hip_mf_laplace_f32_smoother_step(mfmg_hip_mf_laplace_f32_t op, const fl
 int mfmg_hip_mf_laplace_set_tile(mfmg_hip_mf_laplace_t op, int tile_y, int tile_z);
 /* wavefronts per workgroup (1..8) stacked in y that hand their boundary sums on through LDS (0 = heuristic) */
 int mfmg_hip_mf_laplace_set_tile_waves(mfmg_hip_mf_laplace_t op, int n_waves);
+/* the tile in use */
+int mfmg_hip_mf_laplace_get_tile(mfmg_hip_mf_laplace_t op, int *n_waves, int *tile_y, int *tile_z);
 
 /* ---- hierarchy: Hierarchy<VectorType> ---- */
 /* Evaluator tag strings accepted by the string switch (create_hierarchy_helpers,
@@ -226,6 +228,9 @@ int mfmg_hip_hierarchy_coarse_amg_smoother(mfmg_hip_hierarchy_t h, int32_t level
                                            double *lambda_max);
 /* smoother polynomial actually used (degree, lambda_min, lambda_max) */
 int mfmg_hip_hierarchy_smoother_info(mfmg_hip_hierarchy_t h, int32_t *degree, double *lambda_min, double *lambda_max);
+/* tile of the matrix-free fine-level operator (n_waves, rows per wavefront, layers), see mfmg_hip_mf_laplace_get_tile */
+int mfmg_hip_hierarchy_operator_tile(mfmg_hip_hierarchy_t h, int *n_waves, int *tile_y, int *tile_z);
+int mfmg_hip_hierarchy_set_operator_tile(mfmg_hip_hierarchy_t h, int n_waves, int tile_y, int tile_z); /* 0 = automatic */
 /* TimerOutput-style accumulated wall times of the sections of hierarchy.hpp:164-271 as a text table */
 int mfmg_hip_hierarchy_timer_report(mfmg_hip_hierarchy_t h, char *buf, size_t buf_size);
 

@@ -251,6 +251,12 @@ class MatrixFreeLaplace:
         self.ctx.synchronize()
         return out
 
+    def get_tile(self):
+        """(waves, ty, tz) of the next launch."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.mfmg_hip_mf_laplace_get_tile(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def set_tile(self, ty: int, tz: int, waves: int = None):
         check(self._lib.mfmg_hip_mf_laplace_set_tile(self.handle, ty, tz))
         if waves is not None:
@@ -410,6 +416,14 @@ class Hierarchy:
         d, lo, hi = C.c_int32(), C.c_double(), C.c_double()
         check(self._lib.mfmg_hip_hierarchy_smoother_info(self.handle, C.byref(d), C.byref(lo), C.byref(hi)))
         return d.value, lo.value, hi.value
+
+    def operator_tile(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.mfmg_hip_hierarchy_operator_tile(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def set_operator_tile(self, waves: int, ty: int, tz: int):
+        check(self._lib.mfmg_hip_hierarchy_set_operator_tile(self.handle, waves, ty, tz))
 
     def timer_report(self) -> str:
         buf = C.create_string_buffer(8192)

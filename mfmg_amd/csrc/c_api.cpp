@@ -535,6 +535,13 @@ int mfmg_hip_mf_laplace_f32_smoother_step(mfmg_hip_mf_laplace_f32_t op, const fl
   });
 }
 
+int mfmg_hip_mf_laplace_get_tile(mfmg_hip_mf_laplace_t op, int *n_waves, int *tile_y, int *tile_z)
+{
+  return guarded([&] {
+    require(op && n_waves && tile_y && tile_z, "null argument");
+    op->op->get_tile(*n_waves, *tile_y, *tile_z);
+  });
+}
 int mfmg_hip_mf_laplace_set_tile_waves(mfmg_hip_mf_laplace_t op, int n_waves)
 {
   return guarded([&] {
@@ -791,6 +798,29 @@ int mfmg_hip_hierarchy_smoother_info(mfmg_hip_hierarchy_t h, int32_t *degree, do
       *lambda_min = s->lambda_min();
     if (lambda_max)
       *lambda_max = s->lambda_max();
+  });
+}
+
+int mfmg_hip_hierarchy_operator_tile(mfmg_hip_hierarchy_t h, int *n_waves, int *tile_y, int *tile_z)
+{
+  return guarded([&] {
+    require(h && n_waves && tile_y && tile_z, "null argument");
+    auto op = std::dynamic_pointer_cast<HipMatrixFreeOperator const>(h->hierarchy->levels()[0].get_operator());
+    require(op != nullptr, "the fine-level operator is not matrix-free");
+    op->get_mesh_evaluator()->get_device_operator()->get_tile(*n_waves, *tile_y, *tile_z);
+  });
+}
+
+int mfmg_hip_hierarchy_set_operator_tile(mfmg_hip_hierarchy_t h, int n_waves, int tile_y, int tile_z)
+{
+  return guarded([&] {
+    require(h != nullptr, "null argument");
+    require(n_waves >= 0 && n_waves <= 8 && tile_y >= 0 && tile_z >= 0, "bad tile");
+    auto op = std::dynamic_pointer_cast<HipMatrixFreeOperator const>(h->hierarchy->levels()[0].get_operator());
+    require(op != nullptr, "the fine-level operator is not matrix-free");
+    auto dev = op->get_mesh_evaluator()->get_device_operator();
+    dev->set_tile(tile_y, tile_z);
+    dev->set_tile_waves(n_waves);
   });
 }
 

@@ -6,7 +6,7 @@
 // state of the kernel needs for one chunk sits in ONE contiguous record, so that a wavefront streams
 // a single run of memory per row instead of one run per array:
 //   chunk r(c,j,k) = (k Ny + j) ncols + c
-//   rec  [r]  : fb1   int4 [64]      DoF ids of the b=1 face: corners (0,1,0) (1,1,0) (0,1,1) (1,1,1)
+//   rec  [r]  : own   int  [64]      DoF id of the slot's own DoF (corner (0,0,0) of its cell)
 //               coef  16 B [NP][64]  the 8 quadrature coefficients of the cell (NP = 8 sizeof(T) / 16)
 //               dinv  T    [64]      1 / diagonal entry of the slot's own DoF
 //   fb0  [r]  : int4 [64]            DoF ids of the b=0 face: corners (0,0,0) (1,0,0) (0,0,1) (1,0,1)
@@ -15,6 +15,9 @@
 // mesh on a high face are phantoms with zero coefficient.  The ids are the caller's global DoF
 // ids (any numbering); bit 31 carries the Dirichlet flag, so the constrained-read-as-zero rule
 // costs no extra load, bit 30 marks DoFs owned by another rank (read, never written).
+// The seven other corner ids of a cell are the own ids of neighbouring slots: the b=1 face of row j is
+// read as the own ids of row j+1 in layers k and k+1 (the lane+1 corners by a DPP shift, the layer-k pair
+// from an LDS column written one layer earlier), so the steady state fetches 4 B of ids per cell, not 32.
 //
 // Work decomposition (owner computes, no atomics, results independent of the tiling bit for bit):
 // a workgroup of NW wavefronts marches over a tile of 64 cell columns x NW TY cell rows x (TZ+1)
@@ -56,9 +59,9 @@ struct Rec
 {
   static constexpr int W = 16 / sizeof(T);                           // values per 16-byte vector
   static constexpr int NP = 8 / W;                                    // coefficient vectors per slot
-  static constexpr size_t kCoefOff = 1024;                            // after fb1
-  static constexpr size_t kDinvOff = (size_t)(1 + NP) * 1024;         // after the coefficients
-  static constexpr size_t kBytes = kDinvOff + 64 * sizeof(T);         // 5632 (FP64) / 3328 (FP32)
+  static constexpr size_t kCoefOff = 256;                             // after the own ids
+  static constexpr size_t kDinvOff = kCoefOff + (size_t)NP * 1024;    // after the coefficients
+  static constexpr size_t kBytes = kDinvOff + 64 * sizeof(T);         // 4864 (FP64) / 2560 (FP32)
 };
 
 template <typename T>
@@ -262,6 +265,7 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
   T *pt = reinterpret_cast<T *>(smem_raw) + (size_t)wv * 2 * a.TY * 64;   // [TY][64] z-carry of the partial sums
   T *xz = pt + a.TY * 64;                                                  // [TY][64] z-carry of x
   T *xport = reinterpret_cast<T *>(smem_raw) + (size_t)NW * 2 * a.TY * 64; // [2][NW][2][64] hand-over rows
+  int2 *idz = reinterpret_cast<int2 *>(xport + (size_t)2 * NW * 2 * 64) + (size_t)wv * a.TY * 64; // [TY][64] z-carry of the ids
 
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8,
   // observed, speed only); give every XCD a contiguous run of the tile list.
@@ -287,6 +291,8 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
   const bool no_next = (lane == 63) || (ci + 1 >= a.Nx);
   const int jj0 = (Yb < 0) ? 1 : 0; // cell row -1 does not exist (its sums are the zero initial carries)
   const size_t rec_row = (size_t)a.ncols * Rec<T>::kBytes;
+  const size_t rec_layer = (size_t)a.Ny * rec_row;
+  const bool next_chunk = (lane == 63) && (ci + 1 < a.Nx); // its a=1 corners are lane 1 of the next chunk
   const size_t fb0_row = (size_t)a.ncols * 64;
 
   for (int kk = 0; kk <= a.TZ; ++kk)
@@ -314,11 +320,26 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
     int4 const *fb0p = a.fb0 + r0 * 64;
     bool slot = col_ok && kin && (j < a.Ny) && (jj0 < a.TY);
     bool cell = slot && col_cell && (j < a.Ny - 1) && kcell;
-    int4 pf0 = make_int4(0, 0, 0, 0), pf1 = make_int4(0, 0, 0, 0);
+    int4 pf0 = make_int4(0, 0, 0, 0);
+    // own ids of row j+1 in layer k (A) and k+1 (B); x: the same for column ci+1 where it lies in the next chunk
+    int pfA = 0, pfB = 0, pfAx = 0, pfBx = 0;
     if (slot)
       pf0 = fb0p[lane];
-    if (cell)
-      pf1 = reinterpret_cast<int4 const *>(recp)[lane];
+    {
+      const bool nodes = col_ok && kcell && (j + 1 < a.Ny) && (jj0 < a.TY);
+      if (nodes)
+      {
+        pfB = reinterpret_cast<int const *>(recp + rec_row + rec_layer)[lane];
+        if (!layer_carry)
+          pfA = reinterpret_cast<int const *>(recp + rec_row)[lane];
+        if (next_chunk)
+        {
+          pfBx = reinterpret_cast<int const *>(recp + rec_row + rec_layer + Rec<T>::kBytes)[1];
+          if (!layer_carry)
+            pfAx = reinterpret_cast<int const *>(recp + rec_row + Rec<T>::kBytes)[1];
+        }
+      }
+    }
 
     for (int jj = jj0; jj < a.TY; ++jj, ++j)
     {
@@ -333,7 +354,24 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
       T c[8];
       T n0 = T(0), n2 = T(0), n1x = T(0), n3x = T(0);
       T lb = T(0), ld = T(0), lxp = T(0);
-      const int4 f1 = pf1;
+      int4 f1;
+      {
+        const int bn = dpp_from_next(pfB);
+        f1.z = pfB;
+        f1.w = next_chunk ? pfBx : bn;
+        if (layer_carry)
+        {
+          const int2 c2 = cell ? idz[jj * 64 + lane] : make_int2(0, 0);
+          f1.x = c2.x;
+          f1.y = c2.y;
+        }
+        else
+        {
+          const int an = dpp_from_next(pfA);
+          f1.x = pfA;
+          f1.y = next_chunk ? pfAx : an;
+        }
+      }
       if (slot && !carried)
       {
         cid[0] = pf0.x;
@@ -377,10 +415,20 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
             lxp = ld_off<T>(a.xprev, g);
         }
       }
-      int4 pf1n = make_int4(0, 0, 0, 0);
+      int pfAn = 0, pfBn = 0, pfAxn = 0, pfBxn = 0;
       int pf0n = 0;
-      if (celln)
-        pf1n = reinterpret_cast<int4 const *>(recn)[lane];
+      if (col_ok && kcell && rown && (j + 2 < a.Ny))
+      {
+        pfBn = reinterpret_cast<int const *>(recn + rec_row + rec_layer)[lane];
+        if (!layer_carry)
+          pfAn = reinterpret_cast<int const *>(recn + rec_row)[lane];
+        if (next_chunk)
+        {
+          pfBxn = reinterpret_cast<int const *>(recn + rec_row + rec_layer + Rec<T>::kBytes)[1];
+          if (!layer_carry)
+            pfAxn = reinterpret_cast<int const *>(recn + rec_row + Rec<T>::kBytes)[1];
+        }
+      }
       if (slotn && !celln)
         pf0n = reinterpret_cast<int const *>(fb0n)[4 * lane];
 
@@ -395,6 +443,7 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
           n3 = n3x;
         }
         xz[jj * 64 + lane] = n2;
+        idz[jj * 64 + lane] = make_int2(f1.z, f1.w);
         T u[8];
         // constrained DoFs read as zero
         u[0] = (cid[0] < 0) ? T(0) : cx[0];
@@ -451,7 +500,10 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
       }
       ry0 = s10;
       ry1 = s11;
-      pf1 = pf1n;
+      pfA = pfAn;
+      pfB = pfBn;
+      pfAx = pfAxn;
+      pfBx = pfBxn;
       pf0.x = pf0n;
       slot = slotn;
       cell = celln;
@@ -542,7 +594,7 @@ __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coeffic
     }
     fb0[s] = make_int4(id[0], id[1], id[4], id[5]);
     unsigned char *r = rec + (size_t)chunk * Rec<T>::kBytes;
-    reinterpret_cast<int4 *>(r)[lane] = make_int4(id[2], id[3], id[6], id[7]);
+    reinterpret_cast<int *>(r)[lane] = id[0];
     for (int p = 0; p < NP; ++p)
       for (int w = 0; w < W; ++w)
         reinterpret_cast<T *>(r + Rec<T>::kCoefOff + p * 1024)[lane * W + w] = cf[p * W + w];
@@ -763,9 +815,12 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
 }
 
 // ---- tile choice ---------------------------------------------------------------------------------
-// The result does not depend on the tile (bit for bit), only the speed does, and the best tile depends on
-// how the mesh divides into tiles and rounds of workgroups; so the first launch times a short list of
-// candidates on scratch vectors and keeps the fastest (a few launches each; small meshes skip this).
+// The result does not depend on the tile (bit for bit), only the speed does.  Measured inside the V-cycle
+// on MI355X (profiles/README.md): the largest tile wins as long as the launch still has about three
+// workgroups of four wavefronts per CU and XCD round; below that the shorter tiles win (257^3 DoFs:
+// (4,3,8) 0.450 ms, (4,4,8) 0.457, (4,4,16) 0.500; 513^3 DoFs: (4,4,16) 3.26 ms, (4,3,8) 3.43).  A timed
+// choice at first use was tried and dropped: timings outside the cycle did not rank the tiles the way
+// the cycle does, and the pick changed from run to run.
 template <typename T>
 void MatrixFreeLaplaceDevice<T>::choose_tile(int &nw, int &ty, int &tz) const
 {
@@ -774,56 +829,27 @@ void MatrixFreeLaplaceDevice<T>::choose_tile(int &nw, int &ty, int &tz) const
   tz = _tile_z;
   if (nw > 0 && ty > 0 && tz > 0)
     return;
-  if (_tuned[0] == 0)
+  static const int pref[][3] = {{4, 4, 16}, {4, 4, 8}, {4, 3, 8}, {4, 2, 8}, {2, 2, 8}, {2, 2, 4}, {1, 2, 4}};
+  constexpr int n_pref = sizeof(pref) / sizeof(pref[0]);
+  int pick = n_pref - 1;
+  for (int c = 0; c < n_pref; ++c)
   {
-    _tuned[0] = 4;
-    _tuned[1] = 4;
-    _tuned[2] = 16;
-    if (_n_dofs >= (int64_t(1) << 21))
-      autotune();
-  }
-  if (nw <= 0)
-    nw = _tuned[0];
-  if (ty <= 0)
-    ty = _tuned[1];
-  if (tz <= 0)
-    tz = _tuned[2];
-  if (nw * ty < 2)
-    ty = 2;
-}
-
-template <typename T>
-void MatrixFreeLaplaceDevice<T>::autotune() const
-{
-  static const int cand[][3] = {{4, 4, 16}, {4, 3, 16}, {4, 6, 16}, {4, 4, 8},  {4, 8, 16}, {2, 4, 16},
-                                {2, 8, 16}, {8, 4, 16}, {4, 6, 13}, {4, 5, 16}, {4, 4, 32}, {8, 3, 16}};
-  DeviceBuffer<T> x(_n_dofs), y(_n_dofs);
-  hipStream_t st = _handle.stream;
-  MFMG_HIP_CHECK(hipMemcpyAsync(x.data(), _dinv.data(), sizeof(T) * _n_dofs, hipMemcpyDeviceToDevice, st));
-  hipEvent_t e0, e1;
-  MFMG_HIP_CHECK(hipEventCreate(&e0));
-  MFMG_HIP_CHECK(hipEventCreate(&e1));
-  float best = 1e30f;
-  for (auto const &c : cand)
-  {
-    run(MfMode::next, x.data(), _diag.data(), _dinv.data(), T(0.3), T(0.4), y.data(), c[0], c[1], c[2]);
-    MFMG_HIP_CHECK(hipEventRecord(e0, st));
-    for (int r = 0; r < 2; ++r)
-      run(MfMode::next, x.data(), _diag.data(), _dinv.data(), T(0.3), T(0.4), y.data(), c[0], c[1], c[2]);
-    MFMG_HIP_CHECK(hipEventRecord(e1, st));
-    MFMG_HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0.f;
-    MFMG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    if (ms < best)
+    const int64_t wgs = (int64_t)_ncols * ((_N[1] + pref[c][0] * pref[c][1] - 2) / (pref[c][0] * pref[c][1] - 1)) *
+                        ((_N[2] + pref[c][2] - 1) / pref[c][2]);
+    if (wgs >= 3 * 1024)
     {
-      best = ms;
-      _tuned[0] = c[0];
-      _tuned[1] = c[1];
-      _tuned[2] = c[2];
+      pick = c;
+      break;
     }
   }
-  MFMG_HIP_CHECK(hipEventDestroy(e0));
-  MFMG_HIP_CHECK(hipEventDestroy(e1));
+  if (nw <= 0)
+    nw = pref[pick][0];
+  if (ty <= 0)
+    ty = pref[pick][1];
+  if (tz <= 0)
+    tz = pref[pick][2];
+  if (nw * ty < 2)
+    ty = 2;
 }
 
 template <typename T>
@@ -856,8 +882,15 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
   // ty cell rows per wavefront, nw ty - 1 owned DoF rows per workgroup
   a.ntiles_y = (_N[1] + nw * ty - 2) / (nw * ty - 1);
   a.ntiles_z = (_N[2] + tz - 1) / tz;
-  const size_t lds = ((size_t)nw * 2 * ty + (size_t)2 * nw * 2) * 64 * sizeof(T);
-  ASSERT_THROW(lds <= 64 * 1024, "operator tile too large for the LDS");
+  const size_t lds = ((size_t)nw * 2 * ty + (size_t)2 * nw * 2) * 64 * sizeof(T) + (size_t)nw * ty * 64 * sizeof(int2);
+  ASSERT_THROW(lds <= 160 * 1024, "operator tile too large for the LDS");
+  static bool lds_attr_set = false; // (one flag per instantiation of this member)
+  if (!lds_attr_set)
+  {
+    MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mf_laplace_kernel<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    lds_attr_set = true;
+  }
   const uint64_t n_tiles = (uint64_t)a.ncols * a.ntiles_y * a.ntiles_z;
   ASSERT_THROW(n_tiles < (1ull << 31), "operator tile too small for this mesh (grid size limit)");
   // rounded up to a multiple of 8 for the XCD-contiguous tile order

@@ -50,13 +50,15 @@ public:
   T const *diagonal() const { return _diag.data(); }
   T const *diagonal_inverse() const { return _dinv.data(); }
 
-  // tile of one workgroup: n_waves wavefronts of ty cell rows each, tz layers (0 = timed choice at first use)
+  // tile of one workgroup: n_waves wavefronts of ty cell rows each, tz layers (0 = chosen from the mesh size)
   void set_tile(int ty, int tz)
   {
     _tile_y = ty;
     _tile_z = tz;
   }
   void set_tile_waves(int nw) { _tile_waves = nw; }
+  // the tile the next launch uses
+  void get_tile(int &nw, int &ty, int &tz) const { choose_tile(nw, ty, tz); }
   HipHandle &handle() const { return _handle; }
 
   // algorithmic bytes of one operator application (112 B/DoF in FP64)
@@ -70,7 +72,6 @@ private:
   void run(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out, int nw, int ty,
            int tz) const;
   void choose_tile(int &nw, int &ty, int &tz) const;
-  void autotune() const;
 
   HipHandle &_handle;
   int _N[3]; // DoF grid
@@ -85,6 +86,5 @@ private:
   DeviceBuffer<unsigned char> _rec;
   DeviceBuffer<T> _diag, _dinv;
   int _tile_y = 0, _tile_z = 0, _tile_waves = 0;
-  mutable int _tuned[3] = {0, 0, 0};
 };
 } // namespace mfmg

@@ -119,6 +119,7 @@ def load() -> C.CDLL:
         "mfmg_hip_mf_laplace_smoother_step": (C.c_int, [vp, vp, vp, vp, dbl, dbl, vp]),
         "mfmg_hip_mf_laplace_set_tile": (C.c_int, [vp, C.c_int, C.c_int]),
         "mfmg_hip_mf_laplace_set_tile_waves": (C.c_int, [vp, C.c_int]),
+        "mfmg_hip_mf_laplace_get_tile": (C.c_int, [vp, P(C.c_int), P(C.c_int), P(C.c_int)]),
         "mfmg_hip_mf_laplace_f32_create": (C.c_int, [vp, P(MeshDesc), P(vp)]),
         "mfmg_hip_mf_laplace_f32_destroy": (C.c_int, [vp]),
         "mfmg_hip_mf_laplace_f32_vmult": (C.c_int, [vp, vp, vp]),
@@ -139,6 +140,8 @@ def load() -> C.CDLL:
         "mfmg_hip_hierarchy_get_restrictor": (C.c_int, [vp, P(vp)]),
         "mfmg_hip_hierarchy_get_coarse_operator": (C.c_int, [vp, P(vp)]),
         "mfmg_hip_hierarchy_smoother_info": (C.c_int, [vp, P(i32), P(dbl), P(dbl)]),
+        "mfmg_hip_hierarchy_operator_tile": (C.c_int, [vp, P(C.c_int), P(C.c_int), P(C.c_int)]),
+        "mfmg_hip_hierarchy_set_operator_tile": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "mfmg_hip_hierarchy_timer_report": (C.c_int, [vp, C.c_char_p, sz]),
         "mfmg_hip_host_csr_shape": (C.c_int, [vp, P(i64), P(i64), P(i64)]),
         "mfmg_hip_host_csr_get": (C.c_int, [vp, vp, vp, vp]),

@@ -40,9 +40,9 @@ def apply():
     op.smoother_step(b, x, None, coefs[0][0], coefs[0][1], s2)
     op.smoother_step(b, s2, x, coefs[1][0], coefs[1][1], s1)
     op.smoother_step(b, s1, s2, coefs[2][0], coefs[2][1], x)
-cfgs = [(1, 4, 8), (1, 4, 16), (1, 8, 16), (1, 2, 16),
-        (2, 4, 8), (2, 4, 16), (2, 8, 16), (4, 2, 8), (4, 2, 16), (4, 4, 8), (4, 4, 16), (4, 4, 32), (4, 8, 16), (4, 8, 32),
-        (8, 2, 16), (8, 4, 16), (8, 4, 32), (8, 2, 32), (8, 1, 16), (4, 3, 16), (4, 6, 16), (8, 3, 16)]
+cfgs = [(4, 3, 8), (4, 4, 8), (4, 3, 16), (4, 4, 16), (2, 4, 8), (1, 4, 8), (4, 2, 8), (8, 2, 8), (8, 3, 8), (4, 3, 12), (4, 3, 6), (4, 3, 8)]
+if os.environ.get("SKIP_CHECK"):
+    pass
 for (nw, ty, tz) in cfgs:
     op.set_tile(ty, tz, nw)
     apply(); ctx.synchronize()
