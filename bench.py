@@ -42,6 +42,10 @@ def parse_args():
                     help="skip the extra fine-level smoother measurement at 512^3 (north_star target config)")
     ap.add_argument("--amg-block", type=int, default=2, help="nodes per direction of one aggregate of the coarse AMG")
     ap.add_argument("--amg-degree", type=int, default=1, help="Chebyshev degree of the coarse AMG smoothers")
+    ap.add_argument("--evaluator", default="matrix_free", choices=["matrix_free", "assembled"],
+                    help="fine-level operator: matrix-free (BASELINE configs[1]/[3]) or assembled CSR (configs[2])")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra single-GPU lines (configs[1] 128^3 V-cycle, configs[4] FP32 smoother apply)")
     ap.add_argument("--tile", type=str, default="", help="ty,tz[,waves] override of the operator tile (default: timed choice)")
     return ap.parse_args()
 
@@ -68,6 +72,63 @@ def committed_traffic(args):
         return None
     with open(path) as f:
         return json.load(f)["traffic_bytes_per_launch"]
+
+
+def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3):
+    """BASELINE.json configs[1]: the same V-cycle on a `cells`^3 mesh, wall clock around `steps` cycles."""
+    prob = M.LaplaceProblem((cells,) * 3, "constant", device="cuda")
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    n = h.level_size(0)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    x *= (prob.constrained != 1).to(torch.float64)
+    b = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for _ in range(warmup):
+        h.apply(b, x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        h.apply(b, x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": f"{cells}^3 cells = {cells + 1}^3 DoFs, matrix-free, Chebyshev(3), same hierarchy parameters",
+            "n_dofs": n, "ms_per_step": dt * 1e3, "value": n / dt, "unit": "DoF/s"}
+
+
+def measure_smoother_f32(ctx, torch, M, cells, degree, reps=5):
+    """BASELINE.json configs[4] (FP32): smoother apply with the FP32 instance of the operator kernel (vector
+    ALU: at ~11 flop/B the cell kernel sits below the FP32-MFMA ridge)."""
+    prob = M.LaplaceProblem((cells,) * 3, "constant", device="cuda")
+    op = M.MatrixFreeLaplaceF32(ctx, prob)
+    N = prob.n_dofs
+    del prob
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand(N, dtype=torch.float32, device="cuda", generator=g)
+    b = torch.zeros(N, dtype=torch.float32, device="cuda")
+    s1, s2 = torch.empty_like(x), torch.empty_like(x)
+    coefs = smoother_coefficients(degree, 0.09, 1.8)
+
+    def apply():
+        bufs = [s1, s2]
+        cur, prev = x, None
+        for k, (al, be) in enumerate(coefs):
+            tgt = x if k == len(coefs) - 1 and len(coefs) > 1 else bufs[(len(coefs) - 2 - k) % 2]
+            op.smoother_step(b, cur, prev, al, be, tgt)
+            prev, cur = cur, tgt
+
+    apply()
+    ctx.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        apply()
+    ev1.record()
+    ev1.synchronize()
+    ms = ev0.elapsed_time(ev1) / reps
+    # FP32: x 4 + out 4 + 8 idx 32 + 8 coef 32 = 72, + b + D^-1 (+ x_prev from the second term on)
+    per_dof = sum(72 + 8 + (4 if k > 0 else 0) for k in range(len(coefs)))
+    return {"n_dofs": N, "degree": degree, "dtype": "f32", "ms_per_apply": ms, "algorithmic_bytes_per_dof": per_dof,
+            "achieved_GBs": N * per_dof / (ms * 1e-3) / 1e9, "frac_of_8TBs": N * per_dof / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
 def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=5, tile=None):
@@ -200,7 +261,8 @@ def main():
         "is preconditioner": False,
         "max levels": 2,
     }
-    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    evaluator = "HipMatrixFreeMeshEvaluator" if args.evaluator == "matrix_free" else "HipMeshEvaluator"
+    h = M.Hierarchy(ctx, evaluator, prob, params)
     ctx.synchronize()
     t_setup = time.perf_counter() - t_setup
     degree, lmin, lmax = h.smoother_info()
@@ -219,10 +281,14 @@ def main():
             dist.barrier()
 
     # residual norms around the run: a bench of a cycle that does not contract would be meaningless
-    op_monitor = M.MatrixFreeLaplace(ctx, prob)
+    assembled = args.evaluator == "assembled"
+    op_monitor = None if assembled else M.MatrixFreeLaplace(ctx, prob)
     r = torch.empty_like(x)
 
     def residual_norm():
+        if assembled and transport is None:
+            h.operator_apply(0, x, r)      # b = 0
+            return ctx.l2_norm(r)
         if transport is None:
             op_monitor.vmult(r, x)
             ctx.sadd(r, -1.0, 1.0, b)
@@ -231,10 +297,10 @@ def main():
         return transport.owned_norm(r)
 
     res_start = residual_norm()
-    if args.tile:
+    if args.tile and not assembled:
         _t = [int(v) for v in args.tile.split(',')]
         h.set_operator_tile(_t[2] if len(_t) > 2 else 0, _t[0], _t[1])
-    mf_tile = h.operator_tile()
+    mf_tile = (0, 0, 0) if assembled else h.operator_tile()
     for _ in range(args.warmup):
         h.apply(b, x)
     ctx.profile_enable(True)
@@ -277,7 +343,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"3D Laplace on the unit cube, Q1 matrix-free, {args.cells}^3 cells = {n}^3 DoFs per GPU "
+                "workload": f"3D Laplace on the unit cube, Q1 {'assembled CSR (BASELINE.json configs[2])' if assembled else 'matrix-free'}, {args.cells}^3 cells = {n}^3 DoFs per GPU "
                             f"(the mesh deal.II's refine_global gives; BASELINE.json configs[3] '512^3 on 8 GPUs' "
                             f"is this workload at N=8), spectral AMGe (2x2x2 agglomerates, 2 eigenvectors), "
                             f"Chebyshev({degree}) smoother, coarse level {n_coarse} DoFs: " + coarse_desc + ", FP64",
@@ -313,8 +379,23 @@ def main():
             },
         }
         tile = tuple(int(v) for v in args.tile.split(",")) if args.tile else None
-        if world == 1 and not args.no_cpu_baseline:
+        if assembled:
+            # the dominant kernel of the assembled path is the SpMV family
+            rf = out["roofline"]
+            ach = (c_bytes / (c_ms * 1e-3) / 1e9) if c_ms else 0.0
+            rf.update({"kernel": "csr_spmv_kernel family (fine operator with fused smoother epilogues, R, R^T, coarse levels)",
+                       "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches_in_timed_region": c_launches,
+                       "avg_launch_ms": c_ms / c_launches if c_launches else None,
+                       "algorithmic_bytes_per_launch": c_bytes / c_launches if c_launches else None,
+                       "share_of_step_time": c_ms / (ms_per_step * args.steps) if c_ms else None})
+        if world == 1 and not args.no_cpu_baseline and not assembled:
             out["cpu_baseline"] = cpu_baseline(args, M, h, prob, lmin, lmax, torch)
+        if world == 1 and not args.no_extras:
+            try:
+                out["vcycle_128cubed_config1"] = measure_vcycle_small(ctx, torch, M, 128, params)
+                out["smoother_apply_256cubed_f32_config5"] = measure_smoother_f32(ctx, torch, M, 256, args.degree)
+            except Exception as e:  # noqa: BLE001 - report, do not hide the main result
+                out["extras_error"] = str(e)
         if world == 1 and not args.no_smoother_512:
             del h, x, b
             torch.cuda.empty_cache()
