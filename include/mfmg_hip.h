@@ -78,6 +78,9 @@ int mfmg_hip_context_set_communicator(mfmg_hip_context_t ctx, int32_t rank, int3
                                       mfmg_hip_allreduce_fn allreduce, void *user);
 int mfmg_hip_context_set_halo_buffers(mfmg_hip_context_t ctx, int32_t space, int64_t n_elems, double *send_low,
                                       double *send_high, double *recv_low, double *recv_high);
+/* Distributed runs: overlap the exchange of the fine-level ghost planes with the operator tiles that do not read
+ * them (second HIP stream; default on).  Off: exchange first, then one launch over all tiles.  Same results. */
+int mfmg_hip_context_set_overlap_exchange(mfmg_hip_context_t ctx, int enable);
 /* layout of a distributed space after the hierarchy was built: entries per layer, local layers, owned range */
 int mfmg_hip_context_halo_layout(mfmg_hip_context_t ctx, int32_t space, int64_t *layer_elems, int64_t *n_layers,
                                  int64_t *owned_begin, int64_t *owned_count);

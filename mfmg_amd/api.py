@@ -74,6 +74,10 @@ class Context:
     def torch_stream(self) -> "torch.cuda.ExternalStream":
         return torch.cuda.ExternalStream(self.stream)
 
+    def set_overlap_exchange(self, enable: bool):
+        """Distributed runs: overlap the fine-level halo exchange with interior operator tiles (default on)."""
+        check(self._lib.mfmg_hip_context_set_overlap_exchange(self.handle, int(bool(enable))))
+
     def profile_enable(self, enabled: bool = True):
         check(self._lib.mfmg_hip_profile_enable(self.handle, 1 if enabled else 0))
 

@@ -155,6 +155,14 @@ int mfmg_hip_context_set_communicator(mfmg_hip_context_t ctx, int32_t rank, int3
   });
 }
 
+int mfmg_hip_context_set_overlap_exchange(mfmg_hip_context_t ctx, int enable)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    ctx->handle->overlap_exchange = enable != 0;
+  });
+}
+
 int mfmg_hip_context_set_halo_buffers(mfmg_hip_context_t ctx, int32_t space, int64_t n_elems, double *send_low,
                                       double *send_high, double *recv_low, double *recv_high)
 {

@@ -260,6 +260,10 @@ struct HipHandle
 {
   hipStream_t stream = nullptr;
   bool owns_stream = false;
+  // second stream of the overlapped halo exchange (created at first use) and its two events
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_unpacked = nullptr;
+  bool overlap_exchange = true;
   // scratch for two-stage deterministic reductions
   DeviceBuffer<double> reduce_partials;
   DeviceBuffer<double> reduce_result;
@@ -291,6 +295,51 @@ struct HipHandle
       MFMG_HIP_CHECK(hipMemcpyAsync(v + (s.owned_begin + s.owned_count) * s.layer_elems, s.recv_high, bytes,
                                     hipMemcpyDeviceToDevice, stream));
   }
+  // The same exchange split in two, so that work which does not read the ghost layers can run in between
+  // (north_star: "halo exchange ... overlapped with interior smoothing on a second HIP stream"):
+  //   begin: the boundary layers are packed on `stream`; `comm_stream` waits for the packing, runs the
+  //          transport and unpacks into the ghost layers;
+  //   end:   `stream` waits for the unpacking.
+  // Between the two calls `stream` must not read the ghost layers of `v` nor write its boundary layers.
+  void exchange_begin(int space, double *v)
+  {
+    if (!comm.enabled() || space <= 0)
+      return;
+    HaloSpace &s = comm.spaces[space];
+    if (!s.configured())
+      throw std::runtime_error("halo exchange requested for an unconfigured vector space");
+    if (s.staging_elems < s.layer_elems || comm.exchange_fn == nullptr)
+      throw std::runtime_error("halo staging buffers / transport were not registered");
+    if (comm_stream == nullptr)
+    {
+      MFMG_HIP_CHECK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+      MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming));
+      MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_unpacked, hipEventDisableTiming));
+    }
+    const size_t bytes = (size_t)s.layer_elems * sizeof(double);
+    if (s.has_low)
+      MFMG_HIP_CHECK(hipMemcpyAsync(s.send_low, v + s.owned_begin * s.layer_elems, bytes, hipMemcpyDeviceToDevice, stream));
+    if (s.has_high)
+      MFMG_HIP_CHECK(hipMemcpyAsync(s.send_high, v + (s.owned_begin + s.owned_count - 1) * s.layer_elems, bytes,
+                                    hipMemcpyDeviceToDevice, stream));
+    MFMG_HIP_CHECK(hipEventRecord(ev_packed, stream));
+    MFMG_HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_packed, 0));
+    if (comm.exchange_fn(comm.user, space, comm_stream) != 0)
+      throw std::runtime_error("halo exchange transport failed");
+    if (s.has_low)
+      MFMG_HIP_CHECK(hipMemcpyAsync(v + (s.owned_begin - 1) * s.layer_elems, s.recv_low, bytes, hipMemcpyDeviceToDevice,
+                                    comm_stream));
+    if (s.has_high)
+      MFMG_HIP_CHECK(hipMemcpyAsync(v + (s.owned_begin + s.owned_count) * s.layer_elems, s.recv_high, bytes,
+                                    hipMemcpyDeviceToDevice, comm_stream));
+    MFMG_HIP_CHECK(hipEventRecord(ev_unpacked, comm_stream));
+  }
+  void exchange_end(int space)
+  {
+    if (!comm.enabled() || space <= 0)
+      return;
+    MFMG_HIP_CHECK(hipStreamWaitEvent(stream, ev_unpacked, 0));
+  }
   double allreduce_sum(double v)
   {
     if (!comm.enabled())
@@ -317,6 +366,13 @@ struct HipHandle
   }
   ~HipHandle()
   {
+    if (comm_stream)
+    {
+      (void)hipStreamSynchronize(comm_stream);
+      (void)hipEventDestroy(ev_packed);
+      (void)hipEventDestroy(ev_unpacked);
+      (void)hipStreamDestroy(comm_stream);
+    }
     if (host_result)
       (void)hipHostFree(host_result);
     if (owns_stream && stream)

@@ -384,10 +384,53 @@ HipMatrixFreeOperator::HipMatrixFreeOperator(std::shared_ptr<HipMatrixFreeMeshEv
   ASSERT_THROW(_mesh_evaluator != nullptr, "downcasting failed");
 }
 
+// One operator application of a distributed run: the tiles that do not read a ghost plane run while the
+// boundary planes travel on the second stream; the (at most four) z-tiles next to the ghost planes follow.
+void HipMatrixFreeOperator::apply_mode(MfMode mode, double const *x, double const *b, double const *x_prev,
+                                       double alpha, double beta, double *out) const
+{
+  HipHandle &handle = get_hip_handle();
+  auto op = _mesh_evaluator->get_device_operator();
+  auto whole = [&] {
+    if (mode == MfMode::apply)
+      op->vmult(x, out);
+    else if (mode == MfMode::residual)
+      op->residual(x, b, out);
+    else
+      op->smoother_step(b, x, x_prev, alpha, beta, out);
+  };
+  if (!handle.comm.enabled())
+  {
+    whole();
+    return;
+  }
+  HaloSpace const &s = handle.comm.spaces[1];
+  const int n_tiles = op->n_z_tiles(), tz = op->tile_layers();
+  // tile t reads the DoF planes [t tz - 1, (t + 1) tz]; the received ghost planes are owned_begin - 1 (low)
+  // and owned_begin + owned_count (high)
+  // => plane g is read by the tiles ceil(g / tz) - 1 ... floor((g + 1) / tz)
+  int lo_end = 0, hi_begin = n_tiles;
+  if (s.has_low)
+    lo_end = (int)std::min<int64_t>(n_tiles, (s.owned_begin - 1 + 1) / tz + 1);
+  if (s.has_high)
+    hi_begin = (int)std::max<int64_t>(0, (s.owned_begin + s.owned_count + tz - 1) / tz - 1);
+  if (!handle.overlap_exchange || lo_end >= hi_begin)
+  {
+    handle.exchange(1, const_cast<double *>(x));
+    whole();
+    return;
+  }
+  handle.exchange_begin(1, const_cast<double *>(x));
+  op->launch_z_range(mode, x, b, x_prev, alpha, beta, out, lo_end, hi_begin);
+  handle.exchange_end(1);
+  op->launch_z_range(mode, x, b, x_prev, alpha, beta, out, 0, lo_end);
+  op->launch_z_range(mode, x, b, x_prev, alpha, beta, out, hi_begin, n_tiles);
+}
+
 void HipMatrixFreeOperator::vmult(DVector &dst, DVector const &src) const
 {
-  get_hip_handle().exchange(1, const_cast<double *>(src.get_values()));
-  _mesh_evaluator->matrix_free_evaluate_global(src, dst);
+  ASSERT_THROW(dst.size() == src.size(), "vector sizes do not match the operator");
+  apply_mode(MfMode::apply, src.get_values(), nullptr, nullptr, 0., 0., dst.get_values());
 }
 
 void HipMatrixFreeOperator::apply(DVector const &x, DVector &y, OperatorMode mode) const
@@ -438,17 +481,14 @@ size_t HipMatrixFreeOperator::operator_complexity() const
 
 void HipMatrixFreeOperator::residual(DVector const &x, DVector const &b, DVector &res) const
 {
-  get_hip_handle().exchange(1, const_cast<double *>(x.get_values()));
-  _mesh_evaluator->get_device_operator()->residual(x.get_values(), b.get_values(), res.get_values());
+  apply_mode(MfMode::residual, x.get_values(), b.get_values(), nullptr, 0., 0., res.get_values());
 }
 
 void HipMatrixFreeOperator::smoother_step(DVector const &b, DVector const &x, DVector const *x_prev, double alpha,
                                           double beta, DVector &out) const
 {
-  get_hip_handle().exchange(1, const_cast<double *>(x.get_values()));
-  _mesh_evaluator->get_device_operator()->smoother_step(b.get_values(), x.get_values(),
-                                                        x_prev ? x_prev->get_values() : nullptr, alpha, beta,
-                                                        out.get_values());
+  apply_mode((x_prev == nullptr || alpha == 0.) ? MfMode::first : MfMode::next, x.get_values(), b.get_values(),
+             x_prev ? x_prev->get_values() : nullptr, alpha, beta, out.get_values());
 }
 
 double const *HipMatrixFreeOperator::get_diagonal_inverse() const

@@ -76,7 +76,8 @@ struct MfArgs
   T *out;
   int Nx, Ny, Nz;
   int TY, TZ;
-  unsigned int ncols, ntiles_y, ntiles_z;
+  unsigned int ncols, ntiles_y, ntiles_z; // ntiles_z: z-tiles of THIS launch, the first one is tile z_tile0
+  unsigned int z_tile0;
   T fx, fy, fz;
   T alpha, beta;
   int mode;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
   }
   const int tc = w % a.ncols;
   const int tyi = (w / a.ncols) % a.ntiles_y;
-  const int tzi = w / (a.ncols * a.ntiles_y);
+  const int tzi = a.z_tile0 + w / (a.ncols * a.ntiles_y);
   const int ci = tc * 63 - 1 + lane;                     // cell / DoF column of this lane
   const int Yb = tyi * (NW * a.TY - 1) - 1 + wv * a.TY; // first cell row of this wavefront
   const int Z0 = tzi * a.TZ;
@@ -854,7 +855,7 @@ void MatrixFreeLaplaceDevice<T>::choose_tile(int &nw, int &ty, int &tz) const
 
 template <typename T>
 void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out,
-                                     int nw, int ty, int tz) const
+                                     int nw, int ty, int tz, int z_tile_begin, int z_tile_end) const
 {
   ASSERT_THROW(nw >= 1 && nw <= 8, "1..8 wavefronts per workgroup");
   ASSERT_THROW(ty >= 1 && tz >= 1 && nw * ty >= 2, "operator tile too small");
@@ -881,7 +882,14 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
   a.ncols = _ncols;
   // ty cell rows per wavefront, nw ty - 1 owned DoF rows per workgroup
   a.ntiles_y = (_N[1] + nw * ty - 2) / (nw * ty - 1);
-  a.ntiles_z = (_N[2] + tz - 1) / tz;
+  const int all_z = (_N[2] + tz - 1) / tz;
+  if (z_tile_end < 0)
+    z_tile_end = all_z;
+  ASSERT_THROW(z_tile_begin >= 0 && z_tile_end <= all_z, "z-tile range outside the tiling");
+  if (z_tile_begin >= z_tile_end)
+    return;
+  a.z_tile0 = (unsigned int)z_tile_begin;
+  a.ntiles_z = (unsigned int)(z_tile_end - z_tile_begin);
   const size_t lds = ((size_t)nw * 2 * ty + (size_t)2 * nw * 2) * 64 * sizeof(T) + (size_t)nw * ty * 64 * sizeof(int2);
   ASSERT_THROW(lds <= 160 * 1024, "operator tile too large for the LDS");
   static bool lds_attr_set = false; // (one flag per instantiation of this member)
@@ -900,8 +908,7 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
 }
 
 template <typename T>
-void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha,
-                                        T beta, T *out) const
+void MatrixFreeLaplaceDevice<T>::check_vectors(MfMode mode, T const *x, T const *b, T const *x_prev, T const *out) const
 {
   ASSERT_THROW(x != nullptr && out != nullptr, "null vector");
   ASSERT_THROW(x != out, "the operator kernel cannot run in place (out aliases x)");
@@ -909,6 +916,49 @@ void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T c
     ASSERT_THROW(b != nullptr, "null right-hand side");
   if (mode == MfMode::next)
     ASSERT_THROW(x_prev != nullptr, "null x_prev");
+}
+
+template <typename T>
+int MatrixFreeLaplaceDevice<T>::tile_layers() const
+{
+  int nw, ty, tz;
+  choose_tile(nw, ty, tz);
+  return tz;
+}
+
+template <typename T>
+int MatrixFreeLaplaceDevice<T>::n_z_tiles() const
+{
+  const int tz = tile_layers();
+  return (_N[2] + tz - 1) / tz;
+}
+
+template <typename T>
+void MatrixFreeLaplaceDevice<T>::launch_z_range(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta,
+                                                T *out, int z_tile_begin, int z_tile_end) const
+{
+  check_vectors(mode, x, b, x_prev, out);
+  if (mode == MfMode::next && (x_prev == nullptr || alpha == T(0)))
+    mode = MfMode::first;
+  int nw, ty, tz;
+  choose_tile(nw, ty, tz);
+  const int all_z = (_N[2] + tz - 1) / tz;
+  if (z_tile_begin >= z_tile_end)
+    return;
+  const double extra = (mode == MfMode::apply) ? 0. : (mode == MfMode::residual) ? 1. : (mode == MfMode::first) ? 2. : 3.;
+  const double share = double(z_tile_end - z_tile_begin) / double(all_z);
+  hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel",
+                                           share * (algorithmic_bytes_apply() + extra * sizeof(T) * double(_n_dofs)),
+                                           _handle.stream);
+  run(mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, z_tile_begin, z_tile_end);
+  KernelProfiler::end(stop, _handle.stream);
+}
+
+template <typename T>
+void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha,
+                                        T beta, T *out) const
+{
+  check_vectors(mode, x, b, x_prev, out);
   int nw, ty, tz;
   choose_tile(nw, ty, tz);
   // algorithmic bytes per launch: x + out + 8 idx + 8 coef, plus b / D^-1 / x_prev reads

@@ -47,6 +47,15 @@ public:
       launch(MfMode::next, x, b, x_prev, alpha, beta, out);
   }
 
+  // The same operations restricted to the z-tiles [z_tile_begin, z_tile_end) of the current tiling (every
+  // DoF is owned by exactly one tile, so ranges that cover all tiles once give the full result): tiles
+  // [0, n_z_tiles()) ; tile t owns the DoF layers [t tile_layers(), (t+1) tile_layers()) and reads the layers
+  // one below and one above them.
+  int n_z_tiles() const;
+  int tile_layers() const;
+  void launch_z_range(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out, int z_tile_begin,
+                      int z_tile_end) const;
+
   T const *diagonal() const { return _diag.data(); }
   T const *diagonal_inverse() const { return _dinv.data(); }
 
@@ -69,8 +78,9 @@ public:
 
 private:
   void launch(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out) const;
-  void run(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out, int nw, int ty,
-           int tz) const;
+  void run(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out, int nw, int ty, int tz,
+           int z_tile_begin = 0, int z_tile_end = -1) const;
+  void check_vectors(MfMode mode, T const *x, T const *b, T const *x_prev, T const *out) const;
   void choose_tile(int &nw, int &ty, int &tz) const;
 
   HipHandle &_handle;

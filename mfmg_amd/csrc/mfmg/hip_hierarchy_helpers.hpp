@@ -161,6 +161,8 @@ public:
   double const *get_diagonal_inverse() const override;
   HipHandle &get_hip_handle() const override { return _mesh_evaluator->get_hip_handle(); }
   std::shared_ptr<HipMatrixFreeMeshEvaluator> get_mesh_evaluator() const { return _mesh_evaluator; }
+  void apply_mode(MfMode mode, double const *x, double const *b, double const *x_prev, double alpha, double beta,
+                  double *out) const;
   int domain_space() const override { return 1; }
   int range_space() const override { return 1; }
 

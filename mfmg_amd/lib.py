@@ -84,6 +84,7 @@ def load() -> C.CDLL:
         "mfmg_hip_context_stream": (vp, [vp]),
         "mfmg_hip_context_set_communicator": (C.c_int, [vp, i32, i32, i32, i32, vp, vp, vp]),
         "mfmg_hip_context_set_halo_buffers": (C.c_int, [vp, i32, i64, vp, vp, vp, vp]),
+        "mfmg_hip_context_set_overlap_exchange": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_context_halo_layout": (C.c_int, [vp, i32, P(i64), P(i64), P(i64), P(i64)]),
         "mfmg_hip_profile_enable": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_profile_query": (C.c_int, [vp, C.c_char_p, P(i64), P(dbl), P(dbl)]),

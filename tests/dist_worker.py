@@ -157,6 +157,15 @@ def mode_gpu(args):
     xl = dev(local(xg)); xs = dev(xg)
     h.smoother_apply(0, dev(local(bg, False)), xl); hg.smoother_apply(0, dev(bg), xs)
     check(xl, xs, "smoother")
+    # the same two with the exchange NOT overlapped with the interior tiles: identical bits
+    ctx.set_overlap_exchange(False)
+    yl2 = torch.zeros(nl, dtype=torch.float64, device="cuda")
+    h.operator_apply(0, dev(local(xg)), yl2)
+    xl2 = dev(local(xg))
+    h.smoother_apply(0, dev(local(bg, False)), xl2)
+    sl = part.owned_slice()
+    assert torch.equal(yl2[sl], yl[sl]) and torch.equal(xl2[sl], xl[sl]), "overlapped exchange changed the result"
+    ctx.set_overlap_exchange(True)
     # restriction / prolongation / coarse operator
     lay, nlay, cb, cc = tr.layout(2)
     ncl, ncg = lay * nlay, hg.level_size(1)
