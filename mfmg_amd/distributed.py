@@ -93,6 +93,7 @@ class HaloTransport:
             b = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(4)]  # send_low/high, recv_low/high
             self.bufs[space] = b
         self._host = {s: [t.cpu().pin_memory() for t in b] for s, b in self.bufs.items()} if self.backend != "nccl" else None
+        self._ops, self._streams = {}, {}
         self._exchange_cb = _EXCHANGE_FN(self._exchange)
         self._allreduce_cb = _ALLREDUCE_FN(self._allreduce)
         check(self._lib.mfmg_hip_context_set_communicator(
@@ -115,12 +116,18 @@ class HaloTransport:
             send_low, send_high, recv_low, recv_high = self.bufs[space]
             lo, hi = self.rank - 1, self.rank + 1
             if self.backend == "nccl":
-                stream = torch.cuda.ExternalStream(stream_ptr) if stream_ptr else torch.cuda.default_stream()
-                ops = []
-                if lo >= 0:
-                    ops += [dist.P2POp(dist.isend, send_low, lo, self.group), dist.P2POp(dist.irecv, recv_low, lo, self.group)]
-                if hi < self.n_ranks:
-                    ops += [dist.P2POp(dist.isend, send_high, hi, self.group), dist.P2POp(dist.irecv, recv_high, hi, self.group)]
+                stream = self._streams.get(stream_ptr)
+                if stream is None:
+                    stream = torch.cuda.ExternalStream(stream_ptr) if stream_ptr else torch.cuda.default_stream()
+                    self._streams[stream_ptr] = stream
+                ops = self._ops.get(space)
+                if ops is None:      # the staging buffers never move: build the operation list once
+                    ops = []
+                    if lo >= 0:
+                        ops += [dist.P2POp(dist.isend, send_low, lo, self.group), dist.P2POp(dist.irecv, recv_low, lo, self.group)]
+                    if hi < self.n_ranks:
+                        ops += [dist.P2POp(dist.isend, send_high, hi, self.group), dist.P2POp(dist.irecv, recv_high, hi, self.group)]
+                    self._ops[space] = ops
                 if ops:
                     with torch.cuda.stream(stream):
                         for req in dist.batch_isend_irecv(ops):
