@@ -362,3 +362,64 @@ def test_single_level_hierarchy_is_coarse_solve(ctx):
     x = dev(np.zeros(125))
     h.apply(dev(b), x)
     np.testing.assert_allclose(x.cpu().numpy(), np.linalg.solve(A.toarray(), b), rtol=1e-10)
+
+
+def test_full_size_hierarchy_properties(ctx):
+    """BASELINE.json's per-GPU size (256^3 cells = 257^3 DoFs, Chebyshev(3), AMG coarse solve), where the numpy
+    oracle does not finish in seconds: size-independent properties of every operator on the path --
+    symmetry of A and A_c, adjointness of restriction and prolongation, R (weights) partition of unity on the
+    interior, the smoother as an affine map, contraction of the cycle -- and the kernel variants in use."""
+    n = (256, 256, 256)
+    prob = M.LaplaceProblem(n, "constant", device="cuda")
+    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0},
+                         solver={"type": "amg"})
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    nf, nc = h.level_size(0), h.level_size(1)
+    assert nf == 257 ** 3 and nc == 2 * 128 ** 3
+    g = torch.Generator(device="cuda").manual_seed(3)
+    free = (prob.constrained == 0).to(torch.float64)
+    rnd = lambda m: torch.rand(m, dtype=torch.float64, device="cuda", generator=g)
+    x, y = rnd(nf) * free, rnd(nf) * free
+    u, v = rnd(nc), rnd(nc)
+    ax, ay = torch.empty_like(x), torch.empty_like(x)
+    h.operator_apply(0, x, ax)
+    h.operator_apply(0, y, ay)
+    assert abs(ctx.dot(ax, y) - ctx.dot(x, ay)) < 1e-11 * abs(ctx.dot(ax, y))           # A symmetric
+    au, av = torch.empty_like(u), torch.empty_like(u)
+    h.operator_apply(1, u, au)
+    h.operator_apply(1, v, av)
+    assert abs(ctx.dot(au, v) - ctx.dot(u, av)) < 1e-11 * abs(ctx.dot(au, v))           # A_c symmetric
+    assert ctx.dot(au, u) > 0.0                                                          # ... and positive
+    rx, rtu = torch.empty_like(u), torch.empty_like(x)
+    h.restrictor_apply(1, x, rx)
+    h.restrictor_apply(1, u, rtu, L.TRANS)
+    assert abs(ctx.dot(rx, u) - ctx.dot(x, rtu)) < 1e-11 * abs(ctx.dot(rx, u))          # <R x, u> = <x, R^T u>
+    # Galerkin: <R A R^T u, v> = <A_c u, v>
+    t1, t2, t3 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(u)
+    h.restrictor_apply(1, u, t1, L.TRANS)
+    h.operator_apply(0, t1, t2)
+    h.restrictor_apply(1, t2, t3)
+    assert abs(ctx.dot(t3, v) - ctx.dot(au, v)) < 1e-9 * abs(ctx.dot(au, v))
+    # smoother: S(b, x) is affine in (b, x): S(b, x) - S(0, 0) linear
+    b1, b2 = rnd(nf) * free, rnd(nf) * free
+    def smooth(b, x0):
+        xx = x0.clone()
+        h.smoother_apply(0, b, xx)
+        return xx
+    s1, s2 = smooth(b1, x), smooth(b2, y)
+    s12 = smooth((2.0 * b1 - 3.0 * b2).contiguous(), (2.0 * x - 3.0 * y).contiguous())
+    ctx.synchronize()
+    assert (s12 - (2.0 * s1 - 3.0 * s2)).abs().max().item() < 1e-11 * s1.abs().max().item()
+    # cycle: contraction of the residual for b = 0
+    xx = x.clone()
+    b = torch.zeros_like(xx)
+    r = torch.empty_like(xx)
+    norms = []
+    for _ in range(5):
+        h.operator_apply(0, xx, r)
+        norms.append(ctx.l2_norm(r))
+        h.apply(b, xx)
+    assert all(norms[i + 1] < 0.4 * norms[i] for i in range(4)), norms
+    # the layouts the design relies on were actually chosen at this size
+    assert h.coarse_operator().get_kernel()[1] == 2          # block diagonals for A_c
+    assert h.operator_tile() == (4, 3, 8)

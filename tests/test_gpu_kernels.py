@@ -134,6 +134,35 @@ def test_mf_fp32_instance(ctx):
     assert relerr(out.cpu().numpy().astype(float), ref.vmult(x) - b) < 1e-4
 
 
+@pytest.mark.parametrize("n", [(1, 1, 1), (2, 1, 3), (1, 5, 1), (63, 1, 1), (64, 2, 1), (126, 1, 2)])
+def test_mf_degenerate_meshes(ctx, n):
+    """One-cell-thick meshes and chunk-boundary widths (63 owned columns per chunk): every mode against the oracle."""
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "linear")
+    ref = O.MatrixFreeLaplace(mesh, coef)
+    op = M.MatrixFreeLaplace(ctx, M.LaplaceProblem(n, "linear", device="cuda"))
+    rng = np.random.default_rng(21)
+    x, b, xp = rng.random(mesh.n_dofs), rng.random(mesh.n_dofs), rng.random(mesh.n_dofs)
+    out = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
+    op.vmult(out, dev(x))
+    assert relerr(host(out, ctx), ref.vmult(x)) < TOL
+    dinv = ref.diagonal_inverse()
+    op.smoother_step(dev(b), dev(x), dev(xp), 0.3, 0.45, out)
+    assert relerr(host(out, ctx), x + 0.3 * (x - xp) - 0.45 * dinv * (ref.vmult(x) - b)) < TOL
+
+
+def test_csr_degenerate_shapes(ctx):
+    """Empty matrix rows, a matrix without entries, single row / column."""
+    import scipy.sparse as sp
+    for A in (sp.csr_matrix((5, 7)), sp.csr_matrix(np.array([[0.0, 2.0, 0.0]])), sp.csr_matrix(np.array([[3.0], [0.0], [1.0]]))):
+        Ad = M.SparseMatrixDevice(ctx, A)
+        x = np.arange(1, A.shape[1] + 1, dtype=np.float64)
+        y = torch.full((A.shape[0],), np.nan, dtype=torch.float64, device="cuda")
+        Ad.vmult(y, dev(x))
+        np.testing.assert_array_equal(host(y, ctx), A @ x)
+        assert Ad.transpose().shape == (A.shape[1], A.shape[0])
+
+
 def test_mf_rejects_bad_input(ctx):
     with pytest.raises(L.MfmgNotImplementedError):
         M.MatrixFreeLaplace(ctx, M.LaplaceProblem((8, 8), device="cuda"))        # dim = 2
