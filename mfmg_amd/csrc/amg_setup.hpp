@@ -15,7 +15,7 @@ namespace mfmg
 struct AmgOptions
 {
   int max_levels = 10;
-  int64_t coarsest_size = 400;  // dense LU below this many rows (the one-workgroup triangular solves cost ~n barriers)
+  int64_t coarsest_size = 1100; // dense solve below this many rows (two SpMV launches over inverted triangular factors)
   double strength = 0.08;       // |a_ij| > strength * sqrt(a_ii a_jj) is a strong connection
   bool smooth_prolongator = true;
   double omega = 4. / 3.;

@@ -102,7 +102,7 @@ void dense_lu_factor(int n, std::vector<double> &A, std::vector<int32_t> &perm);
 // in place: the column-major packed L\\U of dense_lu_factor -> L^{-1} below the diagonal (unit diagonal implied),
 // U^{-1} on and above it; used for small systems, where two dense products beat the substitution sweeps
 void dense_triangular_inverses(int n, std::vector<double> &lu);
-constexpr int kTriangularInverseLimit = 1024;
+constexpr int kTriangularInverseLimit = 2048;
 
 // Host threads the setup may use: min(affinity mask, cgroup cpu.max quota); applied to OpenMP once
 // (an over-subscribed quota-limited container is what makes a 256-thread default pathological).

@@ -962,7 +962,7 @@ int mfmg_hip_host_amg_build(int64_t n_rows, int64_t nnz, const int32_t *row_ptr,
     ptree params = ptree::parse_info(params_info ? params_info : "");
     AmgOptions opts;
     opts.max_levels = params.get("solver.amg.max_levels", 10);
-    opts.coarsest_size = params.get("solver.amg.coarsest_size", 400);
+    opts.coarsest_size = params.get("solver.amg.coarsest_size", 1100);
     opts.strength = params.get("solver.amg.strength", 0.08);
     opts.smooth_prolongator = params.get("solver.amg.smooth_prolongator", true);
     AmgGridHint grid;

@@ -47,34 +47,6 @@ __global__ void dense_lu_solve_kernel(int n, double const *lu, int32_t const *pe
     x[i] = y[i];
 }
 
-// Small systems (n <= kTriangularInverseLimit): the factors are stored inverted, the solve is two dense
-// triangular products x = U^{-1} (L^{-1} (P b)) -- no dependent sweeps, thread i owns entry i.
-__global__ void dense_tri_inverse_solve_kernel(int n, double const *inv, int32_t const *perm, double const *b,
-                                               double *x)
-{
-  __shared__ double y[kTriangularInverseLimit];
-  __shared__ double z[kTriangularInverseLimit];
-  const int i = threadIdx.x;
-  if (i < n)
-    y[i] = b[perm[i]];
-  __syncthreads();
-  if (i < n)
-  {
-    double s = y[i];
-    for (int j = 0; j < i; ++j)
-      s += inv[(size_t)j * n + i] * y[j];
-    z[i] = s;
-  }
-  __syncthreads();
-  if (i < n)
-  {
-    double s = 0.;
-    for (int j = i; j < n; ++j)
-      s += inv[(size_t)j * n + i] * z[j];
-    x[i] = s;
-  }
-}
-
 std::shared_ptr<SparseMatrixDevice<double>> upload(HipHandle &handle, HostCsr &&m)
 {
   return std::make_shared<SparseMatrixDevice<double>>(handle, m.n_rows, m.n_cols, std::move(m.row_ptr),
@@ -121,13 +93,6 @@ void dense_lu_solve(HipHandle &handle, int n, double const *lu, int32_t const *p
 {
   if (n <= 0)
     return;
-  if (n <= kTriangularInverseLimit)
-  {
-    hipLaunchKernelGGL(dense_tri_inverse_solve_kernel, dim3(1), dim3(((n + 63) / 64) * 64), 0, handle.stream, n, lu,
-                       perm, b, x);
-    MFMG_HIP_CHECK(hipGetLastError());
-    return;
-  }
   const int threads = n >= 1024 ? 1024 : (n >= 256 ? 256 : 64);
   static bool attr_set = false;
   if (!attr_set)
@@ -694,10 +659,10 @@ void HipSmoother::apply_zero_guess(DVector const &b, DVector &x) const
 }
 
 // ---- HipSolver -----------------------------------------------------------------
-void HipSolver::setup_direct(std::shared_ptr<SparseMatrixDevice<double>> matrix, DeviceBuffer<double> &lu,
-                             DeviceBuffer<int32_t> &perm_dev) const
+void HipSolver::setup_direct(std::shared_ptr<SparseMatrixDevice<double>> matrix, DenseLu &f) const
 {
   const int64_t n = matrix->m();
+  f.n = n;
   std::vector<int32_t> rp, cl;
   std::vector<double> vl;
   matrix->download(rp, cl, vl);
@@ -707,10 +672,66 @@ void HipSolver::setup_direct(std::shared_ptr<SparseMatrixDevice<double>> matrix,
       dense[(size_t)r * n + cl[p]] += vl[p];
   std::vector<int32_t> perm;
   dense_lu_factor((int)n, dense, perm);
-  if (n <= kTriangularInverseLimit)
-    dense_triangular_inverses((int)n, dense);
-  lu.upload(dense.data(), dense.size(), _handle.stream);
-  perm_dev.upload(perm.data(), perm.size(), _handle.stream);
+  if (n > kTriangularInverseLimit)
+  {
+    f.lu.upload(dense.data(), dense.size(), _handle.stream);
+    f.perm.upload(perm.data(), perm.size(), _handle.stream);
+    return;
+  }
+  dense_triangular_inverses((int)n, dense); // column-major: L^-1 below the diagonal (unit diagonal), U^-1 above
+  // (L^-1 P): entry (i, perm[j]) = L^-1(i, j), j <= i ;  U^-1: entry (i, j), j >= i.  Rows of a dense
+  // triangle are long, the SpMV takes 64 lanes per row
+  HostCsr L, U;
+  L.n_rows = L.n_cols = U.n_rows = U.n_cols = n;
+  L.row_ptr.assign(n + 1, 0);
+  U.row_ptr.assign(n + 1, 0);
+  for (int64_t i = 0; i < n; ++i)
+  {
+    L.row_ptr[i + 1] = L.row_ptr[i] + (int32_t)(i + 1);
+    U.row_ptr[i + 1] = U.row_ptr[i] + (int32_t)(n - i);
+  }
+  L.col.resize(L.row_ptr[n]);
+  L.val.resize(L.row_ptr[n]);
+  U.col.resize(U.row_ptr[n]);
+  U.val.resize(U.row_ptr[n]);
+  for (int64_t i = 0; i < n; ++i)
+  {
+    // columns sorted within the row (the permutation scatters them)
+    std::vector<std::pair<int32_t, double>> row(i + 1);
+    for (int64_t j = 0; j <= i; ++j)
+      row[j] = {perm[j], j == i ? 1. : dense[(size_t)j * n + i]};
+    std::sort(row.begin(), row.end());
+    for (int64_t j = 0; j <= i; ++j)
+    {
+      L.col[L.row_ptr[i] + j] = row[j].first;
+      L.val[L.row_ptr[i] + j] = row[j].second;
+    }
+    for (int64_t j = i; j < n; ++j)
+    {
+      U.col[U.row_ptr[i] + (j - i)] = (int32_t)j;
+      U.val[U.row_ptr[i] + (j - i)] = dense[(size_t)j * n + i];
+    }
+  }
+  f.l_inv_p = std::make_shared<SparseMatrixDevice<double>>(_handle, n, n, std::move(L.row_ptr), std::move(L.col),
+                                                          std::move(L.val), false);
+  f.u_inv = std::make_shared<SparseMatrixDevice<double>>(_handle, n, n, std::move(U.row_ptr), std::move(U.col),
+                                                        std::move(U.val), false);
+  f.l_inv_p->set_kernel(64, 0);
+  f.u_inv->set_kernel(64, 0);
+  f.tmp.resize(n);
+}
+
+void HipSolver::solve_direct(DenseLu const &f, double const *b, double *x) const
+{
+  if (f.n <= 0)
+    return;
+  if (f.l_inv_p)
+  {
+    f.l_inv_p->vmult(f.tmp.data(), b);
+    f.u_inv->vmult(x, f.tmp.data());
+    return;
+  }
+  dense_lu_solve(_handle, (int)f.n, f.lu.data(), f.perm.data(), b, x);
 }
 
 HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const> op,
@@ -734,14 +755,14 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
     const int64_t limit = std::min(this->_params->get("solver.dense_limit", 8192), 16384);
     ASSERT_THROW(n <= limit, "The coarse problem (" + std::to_string(n) +
                                  " rows) is too large for the dense direct solver; use solver.type pcg");
-    setup_direct(matrix, _dense_lu, _dense_perm);
+    setup_direct(matrix, _dense);
   }
   else if (_solver == "amg")
   {
     // smoothed-aggregation hierarchy on the host (the role of ML / AMGx upstream), V-cycle on the device
     AmgOptions opts;
     opts.max_levels = this->_params->get("solver.amg.max_levels", 10);
-    opts.coarsest_size = this->_params->get("solver.amg.coarsest_size", 400);
+    opts.coarsest_size = this->_params->get("solver.amg.coarsest_size", 1100);
     opts.strength = this->_params->get("solver.amg.strength", 0.08);
     opts.smooth_prolongator = this->_params->get("solver.amg.smooth_prolongator", true);
     _amg_cycles = this->_params->get("solver.amg.n_cycles", 1);
@@ -845,7 +866,7 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
     auto last = _amg.back().a->get_matrix();
     ASSERT_THROW(last->m() <= 16384, "the coarsest level of the multilevel solver is too large for the dense LU (" +
                                          std::to_string(last->m()) + " rows)");
-    setup_direct(last, _amg_lu, _amg_perm);
+    setup_direct(last, _amg_bottom);
   }
   else if (_solver == "pcg")
   {
@@ -918,7 +939,7 @@ void HipSolver::apply(DVector const &b, DVector &x) const
   else
   {
     ASSERT_THROW(b.get_values() != x.get_values(), "the coarse solve cannot run in place");
-    dense_lu_solve(_handle, (int)n, _dense_lu.data(), _dense_perm.data(), b.get_values(), x.get_values());
+    solve_direct(_dense, b.get_values(), x.get_values());
   }
 }
 
@@ -930,8 +951,7 @@ void HipSolver::amg_cycle(size_t level, DVector const &b, DVector &x) const
   AmgLevel const &L = _amg[level];
   if (level + 1 == _amg.size())
   {
-    dense_lu_solve(_handle, (int)L.a->get_matrix()->m(), _amg_lu.data(), _amg_perm.data(), b.get_values(),
-                   x.get_values());
+    solve_direct(_amg_bottom, b.get_values(), x.get_values());
     return;
   }
   if (!L.res)

@@ -265,20 +265,28 @@ public:
 
 private:
   void amg_cycle(size_t level, DVector const &b, DVector &x) const;
-  void setup_direct(std::shared_ptr<SparseMatrixDevice<double>> matrix, DeviceBuffer<double> &lu,
-                    DeviceBuffer<int32_t> &perm) const;
+  // Dense LU with partial pivoting, factored ONCE at setup (the reference re-factorises in every apply,
+  // source/cuda/dealii_operator_device_helpers.cu:169-228).  Up to kTriangularInverseLimit rows the factors are
+  // stored inverted as two dense triangular matrices and the solve is two SpMV launches over the whole chip
+  // (x = U^-1 (L^-1 P) b); above, one workgroup sweeps the packed factors column by column.
+  struct DenseLu
+  {
+    int64_t n = 0;
+    std::shared_ptr<SparseMatrixDevice<double>> l_inv_p, u_inv; // n <= kTriangularInverseLimit
+    mutable DeviceBuffer<double> tmp;
+    DeviceBuffer<double> lu;                                       // column-major L\\U otherwise
+    DeviceBuffer<int32_t> perm;
+  };
+  void setup_direct(std::shared_ptr<SparseMatrixDevice<double>> matrix, DenseLu &f) const;
+  void solve_direct(DenseLu const &f, double const *b, double *x) const;
   std::vector<AmgLevel> _amg;
   int _amg_cycles = 1;
-  DeviceBuffer<double> _amg_lu;
-  DeviceBuffer<int32_t> _amg_perm;
+  DenseLu _amg_bottom;
 
   HipHandle &_handle;
   std::string _solver;
   std::shared_ptr<HipMatrixOperator const> _matrix_operator;
-  // direct: dense LU with partial pivoting, factored ONCE at setup (the reference re-factorises in
-  // every apply, source/cuda/dealii_operator_device_helpers.cu:169-228); apply = two triangular solves
-  DeviceBuffer<double> _dense_lu; // column-major L\\U
-  DeviceBuffer<int32_t> _dense_perm;
+  DenseLu _dense; // solver.type lu_dense | cholesky | lu_sparse_host
   // pcg
   int _n_iterations = 0;
   mutable DeviceBuffer<double> _scal;
