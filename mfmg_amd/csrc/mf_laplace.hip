@@ -606,7 +606,7 @@ __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coeffic
 // chunk and lane of cell / DoF (i,j,k) (the copy owned by its column)
 __device__ __forceinline__ size_t chunk_of(int i, int j, int k, int Ny, int ncols, int &lane)
 {
-  const int c = (i + 1) / 63;
+  const int c = i / 63; // chunk c owns the columns 63c .. 63c+62 in its lanes 1 .. 63 (lane 0 repeats column 63c-1)
   lane = i + 1 - 63 * c;
   return ((size_t)k * Ny + j) * ncols + c;
 }

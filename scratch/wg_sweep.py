@@ -40,9 +40,7 @@ def apply():
     op.smoother_step(b, x, None, coefs[0][0], coefs[0][1], s2)
     op.smoother_step(b, s2, x, coefs[1][0], coefs[1][1], s1)
     op.smoother_step(b, s1, s2, coefs[2][0], coefs[2][1], x)
-cfgs = [(4, 3, 8), (4, 4, 8), (4, 3, 16), (4, 4, 16), (2, 4, 8), (1, 4, 8), (4, 2, 8), (8, 2, 8), (8, 3, 8), (4, 3, 12), (4, 3, 6), (4, 3, 8)]
-if os.environ.get("SKIP_CHECK"):
-    pass
+cfgs = [(4, 3, 8), (4, 4, 8), (4, 3, 8), (4, 4, 16)]
 for (nw, ty, tz) in cfgs:
     op.set_tile(ty, tz, nw)
     apply(); ctx.synchronize()
@@ -51,4 +49,4 @@ for (nw, ty, tz) in cfgs:
     for _ in range(8): apply()
     e1.record(); e1.synchronize()
     ms = e0.elapsed_time(e1) / 8
-    print(f"n={n} waves={nw} ty={ty} tz={tz} smoother {ms:.3f} ms  {N*400/ms/1e6:.0f} GB/s  frac {N*400/ms/1e6/8000:.3f}", flush=True)
+    print(f"n={n} waves={nw} ty={ty} tz={tz} smoother {ms:.3f} ms  {N*400/ms/1e6:.0f} GB/s  frac {N*400/ms/1e6/8000:.3f}  ns/kDoF {ms*1e6/N*1e3:.2f}", flush=True)

@@ -134,7 +134,7 @@ def test_mf_fp32_instance(ctx):
     assert relerr(out.cpu().numpy().astype(float), ref.vmult(x) - b) < 1e-4
 
 
-@pytest.mark.parametrize("n", [(1, 1, 1), (2, 1, 3), (1, 5, 1), (63, 1, 1), (64, 2, 1), (126, 1, 2)])
+@pytest.mark.parametrize("n", [(1, 1, 1), (2, 1, 3), (1, 5, 1), (62, 1, 1), (63, 1, 1), (64, 2, 1), (125, 2, 1), (126, 1, 2)])
 def test_mf_degenerate_meshes(ctx, n):
     """One-cell-thick meshes and chunk-boundary widths (63 owned columns per chunk): every mode against the oracle."""
     mesh = O.StructuredMesh(n)
