@@ -843,6 +843,8 @@ int mfmg_hip_hierarchy_timer_report(mfmg_hip_hierarchy_t h, char *buf, size_t bu
 }
 
 // ---- host-side setup pieces -------------------------------------------------------------
+extern "C++"
+{
 namespace
 {
 StructuredMesh host_mesh(const mfmg_hip_mesh_desc *mesh)
@@ -852,6 +854,7 @@ StructuredMesh host_mesh(const mfmg_hip_mesh_desc *mesh)
   return StructuredMesh::from_desc(*mesh, nullptr);
 }
 } // namespace
+}
 
 int mfmg_hip_host_csr_shape(mfmg_hip_host_csr_t m, int64_t *n_rows, int64_t *n_cols, int64_t *nnz)
 {
