@@ -206,6 +206,14 @@ int mfmg_hip_hierarchy_destroy(mfmg_hip_hierarchy_t h);
 int mfmg_hip_hierarchy_apply(mfmg_hip_hierarchy_t h, const double *b, double *x);
 /* Hierarchy::vmult(x, b)     (hierarchy.hpp:238-244) */
 int mfmg_hip_hierarchy_vmult(mfmg_hip_hierarchy_t h, double *x, const double *b);
+/* Outer Krylov driver of tests/hierarchy_driver.cc:103-116: dealii::SolverCG on the fine-level operator with
+ * Hierarchy::vmult as preconditioner, SolverControl(max_iterations, tolerance) on the absolute l2 norm of the
+ * residual.  x holds the initial guess on entry.  residual_history (may be NULL) receives ||r_0||, ||r_1||, ... as
+ * far as history_len reaches.  Returns MFMG_HIP_ERROR when max_iterations is reached without convergence
+ * (SolverControl::NoConvergence upstream), with the outputs filled. */
+int mfmg_hip_hierarchy_solve_cg(mfmg_hip_hierarchy_t h, const double *b, double *x, double tolerance,
+                                int32_t max_iterations, int32_t *n_iterations, double *final_residual,
+                                double *residual_history, int32_t history_len);
 int mfmg_hip_hierarchy_n_levels(mfmg_hip_hierarchy_t h, int32_t *n_levels);
 int mfmg_hip_hierarchy_level_size(mfmg_hip_hierarchy_t h, int32_t level, int64_t *n);
 /* Level::get_operator()->apply (level.hpp:30-33) */

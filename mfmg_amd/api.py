@@ -421,6 +421,18 @@ class Hierarchy:
         check(self._lib.mfmg_hip_hierarchy_smoother_info(self.handle, C.byref(d), C.byref(lo), C.byref(hi)))
         return d.value, lo.value, hi.value
 
+    def solve_cg(self, b, x, tolerance: float = 1e-6, max_iterations: int = 1000):
+        """tests/hierarchy_driver.cc:103-116: CG on the fine operator preconditioned by this hierarchy
+        (build it with "is preconditioner" true).  Returns (iterations, residual history)."""
+        import numpy as np
+        n = self.level_size(0)
+        it, res = C.c_int32(), C.c_double()
+        hist = np.zeros(max_iterations + 1)
+        check(self._lib.mfmg_hip_hierarchy_solve_cg(self.handle, _dev_ptr(b, n), _dev_ptr(x, n), tolerance, max_iterations,
+                                                    C.byref(it), C.byref(res), hist.ctypes.data_as(C.POINTER(C.c_double)),
+                                                    len(hist)))
+        return it.value, hist[: it.value + 1]
+
     def operator_tile(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         check(self._lib.mfmg_hip_hierarchy_operator_tile(self.handle, C.byref(a), C.byref(b), C.byref(c)))

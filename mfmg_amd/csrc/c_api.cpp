@@ -628,6 +628,61 @@ int mfmg_hip_hierarchy_vmult(mfmg_hip_hierarchy_t h, double *x, const double *b)
   });
 }
 
+int mfmg_hip_hierarchy_solve_cg(mfmg_hip_hierarchy_t h, const double *b, double *x, double tolerance,
+                                int32_t max_iterations, int32_t *n_iterations, double *final_residual,
+                                double *residual_history, int32_t history_len)
+{
+  return guarded([&] {
+    require(h && b && x, "null argument");
+    require(tolerance >= 0. && max_iterations >= 0, "bad stopping criterion");
+    // preconditioned CG as dealii::SolverCG runs it (third-party, restated): r = b - A x, z = M^-1 r, p = z;
+    // alpha = (r,z)/(p,Ap); x += alpha p; r -= alpha Ap; stop on ||r||_2 <= tolerance; beta = (r,z)_new/(r,z)_old
+    HipHandle &handle = *h->handle;
+    const int64_t n = level_size(h, 0);
+    auto op = h->hierarchy->levels()[0].get_operator();
+    auto hop = std::dynamic_pointer_cast<HipOperator const>(op);
+    const int space = hop ? hop->domain_space() : 0;
+    DVector bv(handle, n, const_cast<double *>(b)), xv(handle, n, x);
+    DVector r(handle, n), z(handle, n), p(handle, n), ap(handle, n);
+    auto dot = [&](DVector const &u, DVector const &v) { return distributed_dot(handle, space, u, v); };
+    op->apply(xv, r);
+    r.sadd(-1., 1., bv); // r = b - A x
+    double res = std::sqrt(dot(r, r));
+    int it = 0;
+    auto record = [&](int k, double v) {
+      if (residual_history && k < history_len)
+        residual_history[k] = v;
+    };
+    record(0, res);
+    double rz = 0.;
+    bool converged = res <= tolerance;
+    while (!converged && it < max_iterations)
+    {
+      h->hierarchy->vmult(z, r);
+      const double rz_new = dot(r, z);
+      if (it == 0)
+        p = z;
+      else
+        p.sadd(rz_new / rz, 1., z); // p = z + beta p
+      rz = rz_new;
+      op->apply(p, ap);
+      const double alpha = rz / dot(p, ap);
+      xv.add(alpha, p);
+      r.add(-alpha, ap);
+      res = std::sqrt(dot(r, r));
+      ++it;
+      record(it, res);
+      converged = res <= tolerance;
+    }
+    if (n_iterations)
+      *n_iterations = it;
+    if (final_residual)
+      *final_residual = res;
+    if (!converged)
+      throw std::runtime_error("CG did not reach the tolerance within max_iterations (SolverControl::NoConvergence)");
+  });
+}
+
 int mfmg_hip_hierarchy_n_levels(mfmg_hip_hierarchy_t h, int32_t *n_levels)
 {
   return guarded([&] {

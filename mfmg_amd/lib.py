@@ -131,6 +131,7 @@ def load() -> C.CDLL:
         "mfmg_hip_hierarchy_destroy": (C.c_int, [vp]),
         "mfmg_hip_hierarchy_apply": (C.c_int, [vp, vp, vp]),
         "mfmg_hip_hierarchy_vmult": (C.c_int, [vp, vp, vp]),
+        "mfmg_hip_hierarchy_solve_cg": (C.c_int, [vp, vp, vp, C.c_double, C.c_int32, P(C.c_int32), P(C.c_double), P(C.c_double), C.c_int32]),
         "mfmg_hip_hierarchy_n_levels": (C.c_int, [vp, P(i32)]),
         "mfmg_hip_hierarchy_level_size": (C.c_int, [vp, i32, P(i64)]),
         "mfmg_hip_hierarchy_operator_apply": (C.c_int, [vp, i32, vp, vp, C.c_int]),

@@ -815,6 +815,32 @@ def vcycle_history(h: TwoLevelHierarchy, apply_A_monitor, b, x0, n_cycles=20):
     return np.array(res), res[-1] / res[-2], x
 
 
+def pcg_solve(apply_A, precondition, b, x0, tolerance=1e-6, max_iterations=None):
+    """The outer solve of tests/hierarchy_driver.cc:103-116: dealii::SolverCG (third party, restated: standard
+    preconditioned CG) with SolverControl(max_iterations, tolerance) on the absolute l2 norm of the residual and
+    `precondition(r)` = Hierarchy::vmult.  Returns (x, [||r_0||, ||r_1||, ...])."""
+    x = x0.copy()
+    r = b - apply_A(x)
+    hist = [np.linalg.norm(r)]
+    if max_iterations is None:
+        max_iterations = b.size
+    rz = 0.0
+    p = None
+    it = 0
+    while hist[-1] > tolerance and it < max_iterations:
+        z = precondition(r)
+        rz_new = r @ z
+        p = z.copy() if it == 0 else z + (rz_new / rz) * p
+        rz = rz_new
+        ap = apply_A(p)
+        alpha = rz / (p @ ap)
+        x = x + alpha * p
+        r = r - alpha * ap
+        hist.append(np.linalg.norm(r))
+        it += 1
+    return x, np.array(hist)
+
+
 def random_initial_guess(n: int, constrained: Optional[np.ndarray], order=None,
                          zero_constrained=True) -> np.ndarray:
     """x0 of tests/test_hierarchy.cc:76-87 (CPU: constrained entries 0 and the

@@ -423,3 +423,43 @@ def test_full_size_hierarchy_properties(ctx):
     # the layouts the design relies on were actually chosen at this size
     assert h.coarse_operator().get_kernel()[1] == 2          # block diagonals for A_c
     assert h.operator_tile() == (4, 3, 8)
+
+
+def test_outer_cg_driver_matches_oracle(ctx):
+    """tests/hierarchy_driver.cc:103-116: CG on the matrix-free operator preconditioned by Hierarchy::vmult
+    ("is preconditioner" true) -- iteration count and residual history against the oracle's CG with the
+    oracle's V-cycle as preconditioner."""
+    n = (12, 10, 8)
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "linear")
+    con = mesh.constrained_mask()
+    mf = O.MatrixFreeLaplace(mesh, coef)
+    prob = M.LaplaceProblem(n, "linear", device="cuda")
+    params = base_params(smoother={"type": "Chebyshev", "degree": 2, "smoothing_range": 20.0})
+    params["is preconditioner"] = True
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    deg, lmin, lmax = h.smoother_info()
+    R = h.restrictor().to_scipy()
+    Ac = O.galerkin_coarse_matrix(mf.vmult, R)
+    p = O.ChebyshevParams(degree=2, lambda_max=lmax, lambda_min=lmin)
+    dinv = mf.diagonal_inverse()
+    smoother = lambda b, x: O.chebyshev_smoother_apply(mf.vmult, dinv, p, b, x)
+    ho = O.TwoLevelHierarchy(mf.vmult, smoother, R, O.direct_coarse_solver(Ac), 1, True)
+    rng = np.random.default_rng(5)
+    b = np.where(con, 0.0, rng.random(mesh.n_dofs))
+    x0 = np.zeros(mesh.n_dofs)
+    tol = 1e-9 * np.linalg.norm(b)
+    xo, hist_o = O.pcg_solve(mf.vmult, lambda r: ho.apply(r, np.zeros_like(r)), b, x0, tol, 100)
+    x = dev(x0)
+    iters, hist_g = h.solve_cg(dev(b), x, tol, 100)
+    ctx.synchronize()
+    assert iters == len(hist_o) - 1 and 3 <= iters <= 25
+    np.testing.assert_allclose(hist_g, hist_o, rtol=1e-7, atol=1e-3 * tol)
+    assert relerr(x.cpu().numpy(), xo) < 1e-9
+    # without enough iterations the driver reports no convergence, like SolverControl::NoConvergence
+    with pytest.raises(L.MfmgError, match="did not reach"):
+        h.solve_cg(dev(b), dev(x0), tol, 2)
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
