@@ -255,18 +255,21 @@ __device__ __forceinline__ T mf_epilogue(MfArgs<T> const &a, int id0, T x0, T yv
   return (a.mode == 2) ? fmadd<T>(wgt, r, x0) : fmadd<T>(wgt, r, fmadd<T>(a.alpha, x0 - lxp, x0));
 }
 
-template <typename T>
+// TYC > 0: rows per wavefront known at compile time (the row loop is fully unrolled: no loop-carried register
+// moves, constant LDS offsets); TYC = 0: taken from the arguments.
+template <typename T, int TYC>
 __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
 {
 #pragma clang fp contract(off)
+  const int TY = TYC > 0 ? TYC : a.TY;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, keep it scalar
   const int NW = blockDim.x >> 6;
-  T *pt = reinterpret_cast<T *>(smem_raw) + (size_t)wv * 2 * a.TY * 64;   // [TY][64] z-carry of the partial sums
-  T *xz = pt + a.TY * 64;                                                  // [TY][64] z-carry of x
-  T *xport = reinterpret_cast<T *>(smem_raw) + (size_t)NW * 2 * a.TY * 64; // [2][NW][2][64] hand-over rows
-  int2 *idz = reinterpret_cast<int2 *>(xport + (size_t)2 * NW * 2 * 64) + (size_t)wv * a.TY * 64; // [TY][64] z-carry of the ids
+  T *pt = reinterpret_cast<T *>(smem_raw) + (size_t)wv * 2 * TY * 64;   // [TY][64] z-carry of the partial sums
+  T *xz = pt + TY * 64;                                                  // [TY][64] z-carry of x
+  T *xport = reinterpret_cast<T *>(smem_raw) + (size_t)NW * 2 * TY * 64; // [2][NW][2][64] hand-over rows
+  int2 *idz = reinterpret_cast<int2 *>(xport + (size_t)2 * NW * 2 * 64) + (size_t)wv * TY * 64; // [TY][64] z-carry of the ids
 
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8,
   // observed, speed only); give every XCD a contiguous run of the tile list.
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
   const int tyi = (w / a.ncols) % a.ntiles_y;
   const int tzi = a.z_tile0 + w / (a.ncols * a.ntiles_y);
   const int ci = tc * 63 - 1 + lane;                     // cell / DoF column of this lane
-  const int Yb = tyi * (NW * a.TY - 1) - 1 + wv * a.TY; // first cell row of this wavefront
+  const int Yb = tyi * (NW * TY - 1) - 1 + wv * TY; // first cell row of this wavefront
   const int Z0 = tzi * a.TZ;
   const bool col_ok = ci >= 0 && ci < a.Nx;
   const bool col_cell = col_ok && ci < a.Nx - 1;
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
     const size_t r0 = ((size_t)max(k, 0) * a.Ny + (size_t)j) * a.ncols + (size_t)tc; // uniform
     unsigned char const *recp = a.rec + r0 * Rec<T>::kBytes;
     int4 const *fb0p = a.fb0 + r0 * 64;
-    bool slot = col_ok && kin && (j < a.Ny) && (jj0 < a.TY);
+    bool slot = col_ok && kin && (j < a.Ny) && (jj0 < TY);
     bool cell = slot && col_cell && (j < a.Ny - 1) && kcell;
     int4 pf0 = make_int4(0, 0, 0, 0);
     // own ids of row j+1 in layer k (A) and k+1 (B); x: the same for column ci+1 where it lies in the next chunk
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
     if (slot)
       pf0 = fb0p[lane];
     {
-      const bool nodes = col_ok && kcell && (j + 1 < a.Ny) && (jj0 < a.TY);
+      const bool nodes = col_ok && kcell && (j + 1 < a.Ny) && (jj0 < TY);
       if (nodes)
       {
         pfB = reinterpret_cast<int const *>(recp + rec_row + rec_layer)[lane];
@@ -342,11 +345,12 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
       }
     }
 
-    for (int jj = jj0; jj < a.TY; ++jj, ++j)
+#pragma unroll
+    for (int jj = jj0; jj < TY; ++jj, ++j)
     {
       if (j >= a.Ny)
         break;
-      const bool rown = (jj + 1 < a.TY) && (j + 1 < a.Ny);
+      const bool rown = (jj + 1 < TY) && (j + 1 < a.Ny);
       const bool slotn = col_ok && kin && rown;
       const bool celln = slotn && col_cell && (j + 1 < a.Ny - 1) && kcell;
       unsigned char const *recn = recp + rec_row;
@@ -895,7 +899,11 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
   static bool lds_attr_set = false; // (one flag per instantiation of this member)
   if (!lds_attr_set)
   {
-    MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mf_laplace_kernel<T>),
+    MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mf_laplace_kernel<T, 0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mf_laplace_kernel<T, 3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mf_laplace_kernel<T, 4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     lds_attr_set = true;
   }
@@ -903,7 +911,12 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
   ASSERT_THROW(n_tiles < (1ull << 31), "operator tile too small for this mesh (grid size limit)");
   // rounded up to a multiple of 8 for the XCD-contiguous tile order
   dim3 grid((unsigned int)(n_tiles >= 64 ? ((n_tiles + 7) / 8) * 8 : n_tiles));
-  hipLaunchKernelGGL(mf_laplace_kernel<T>, grid, dim3(64 * nw), lds, _handle.stream, a);
+  if (ty == 3)
+    hipLaunchKernelGGL((mf_laplace_kernel<T, 3>), grid, dim3(64 * nw), lds, _handle.stream, a);
+  else if (ty == 4)
+    hipLaunchKernelGGL((mf_laplace_kernel<T, 4>), grid, dim3(64 * nw), lds, _handle.stream, a);
+  else
+    hipLaunchKernelGGL((mf_laplace_kernel<T, 0>), grid, dim3(64 * nw), lds, _handle.stream, a);
   MFMG_HIP_CHECK(hipGetLastError());
 }
 
