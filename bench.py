@@ -318,7 +318,10 @@ def main():
     mf_tile = (0, 0, 0) if assembled else h.operator_tile()
     for _ in range(args.warmup):
         h.apply(b, x)
-    ctx.profile_enable(True)
+    # HIP events around the launches of the dominant kernel only: an event pair costs ~5 us on the stream, and the
+    # cycle has ~45 launches; the other kernel family is timed in a separate pass after the timed region
+    dominant = "csr_spmv_kernel" if assembled else "mf_laplace_kernel"
+    ctx.profile_enable(True, only=dominant)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -333,6 +336,16 @@ def main():
     launches, k_ms, k_bytes = ctx.profile_query("mf_laplace_kernel")
     c_launches, c_ms, c_bytes = ctx.profile_query("csr_spmv_kernel")
     ctx.profile_enable(False)
+    other_cycles = 0
+    if not assembled:
+        # second pass, outside the timed region: the SpMV family (x and b keep converging; timings do not depend on it)
+        other_cycles = 3
+        ctx.profile_enable(True, only="csr_spmv_kernel")
+        for _ in range(other_cycles):
+            h.apply(b, x)
+        torch.cuda.synchronize()
+        c_launches, c_ms, c_bytes = ctx.profile_query("csr_spmv_kernel")
+        ctx.profile_enable(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -390,7 +403,9 @@ def main():
             "other_kernels": {
                 "csr_spmv_kernel": {"launches": c_launches, "total_ms": c_ms,
                                     "achieved_GBs": (c_bytes / (c_ms * 1e-3) / 1e9) if c_ms else None,
-                                    "share_of_step_time": c_ms / (ms_per_step * args.steps) if c_ms else None},
+                                    "share_of_step_time": (c_ms / (ms_per_step * (other_cycles or args.steps))) if c_ms else None,
+                                    "timed_in": (f"{other_cycles} extra cycles after the timed region" if other_cycles
+                                                 else "the timed region")},
             },
         }
         tile = tuple(int(v) for v in args.tile.split(",")) if args.tile else None

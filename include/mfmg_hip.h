@@ -89,6 +89,8 @@ int mfmg_hip_context_halo_layout(mfmg_hip_context_t ctx, int32_t space, int64_t 
  * wall-clock dealii::TimerOutput sections, include/mfmg/common/hierarchy.hpp:36-47).  Kernel names:
  * "mf_laplace_kernel", "csr_spmv_kernel".  `algorithmic_bytes` sums SURVEY.md 8d's per-launch figures. */
 int mfmg_hip_profile_enable(mfmg_hip_context_t ctx, int enabled);
+/* restrict the timing to launches of one kernel name (NULL or "" = all); every timed launch costs two event records */
+int mfmg_hip_profile_select(mfmg_hip_context_t ctx, const char *kernel_name);
 int mfmg_hip_profile_query(mfmg_hip_context_t ctx, const char *kernel_name, int64_t *n_launches, double *total_ms,
                            double *algorithmic_bytes);
 

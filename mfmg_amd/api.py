@@ -78,7 +78,10 @@ class Context:
         """Distributed runs: overlap the fine-level halo exchange with interior operator tiles (default on)."""
         check(self._lib.mfmg_hip_context_set_overlap_exchange(self.handle, int(bool(enable))))
 
-    def profile_enable(self, enabled: bool = True):
+    def profile_enable(self, enabled: bool = True, only: str = ""):
+        """HIP-event timing per kernel name; `only` restricts it to one name (every timed launch costs two
+        event records on the stream)."""
+        check(self._lib.mfmg_hip_profile_select(self.handle, only.encode() if only else None))
         check(self._lib.mfmg_hip_profile_enable(self.handle, 1 if enabled else 0))
 
     def profile_query(self, kernel: str):

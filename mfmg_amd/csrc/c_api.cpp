@@ -198,6 +198,14 @@ int mfmg_hip_context_halo_layout(mfmg_hip_context_t ctx, int32_t space, int64_t 
 }
 
 // ---- per-kernel HIP-event timing (bench.py roofline leg) ---------------------------
+int mfmg_hip_profile_select(mfmg_hip_context_t ctx, const char *kernel_name)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    ctx->handle->profiler.only = kernel_name ? kernel_name : "";
+  });
+}
+
 int mfmg_hip_profile_enable(mfmg_hip_context_t ctx, int enabled)
 {
   return guarded([&] {

@@ -87,6 +87,7 @@ def load() -> C.CDLL:
         "mfmg_hip_context_set_overlap_exchange": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_context_halo_layout": (C.c_int, [vp, i32, P(i64), P(i64), P(i64), P(i64)]),
         "mfmg_hip_profile_enable": (C.c_int, [vp, C.c_int]),
+        "mfmg_hip_profile_select": (C.c_int, [vp, C.c_char_p]),
         "mfmg_hip_profile_query": (C.c_int, [vp, C.c_char_p, P(i64), P(dbl), P(dbl)]),
         "mfmg_hip_malloc": (C.c_int, [P(vp), sz]),
         "mfmg_hip_free": (C.c_int, [vp]),
