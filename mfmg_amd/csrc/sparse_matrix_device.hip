@@ -264,9 +264,12 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
   if (avg < 3.)
     lpr = avg < 1.5 ? 1 : 2;
   _lanes_per_row = lpr;
+  // ---- block-diagonal storage (see bdia_spmv_kernel); when it applies the LDS lists are not needed
+  if (n_rows == n_cols && n_rows >= 32768 && avg >= 8.)
+    build_block_diagonals(row_ptr, col, val);
   // ---- block-local column compression for the LDS-cached kernel
   // (a 128-row block per workgroup: below ~256 blocks the plain kernel fills the chip better)
-  if (n_rows >= 256 * kRowsPerBlock && avg >= 4.)
+  if (!_use_bdia && n_rows >= 256 * kRowsPerBlock && avg >= 4.)
   {
     const int64_t nb = (n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
     std::vector<int32_t> blk_ptr(nb + 1, 0);
@@ -310,9 +313,6 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
       _lds_max_cols = max_cols;
     }
   }
-  // ---- block-diagonal storage (see bdia_spmv_kernel)
-  if (n_rows == n_cols && n_rows >= 32768 && avg >= 8.)
-    build_block_diagonals(row_ptr, col, val);
   _val.upload(val.data(), val.size(), handle.stream);
   _col.upload(col.data(), col.size(), handle.stream);
   _row_ptr.upload(row_ptr.data(), row_ptr.size(), handle.stream);

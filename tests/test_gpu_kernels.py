@@ -314,6 +314,17 @@ def test_csr_kernel_variants_on_stencil_matrix(ctx, comps):
         assert relerr(host(out, ctx), x + 0.25 * (x - xp) - 0.6 * dinv * (ref - b)) < TOL
         Ad.smoother_step(dev(dinv), dev(b), dev(x), None, 0.0, 0.6, out)
         assert relerr(host(out, ctx), x - 0.6 * dinv * (ref - b)) < TOL
+    # a rectangular matrix with the same local column reuse (a prolongator-like shape): LDS-cached CSR
+    if comps == 1:
+        Bw = sp.hstack([A, 0.5 * A]).tocsr()
+        Bd = M.SparseMatrixDevice(ctx, Bw)
+        assert Bd.get_kernel()[1] == 1, "LDS-cached kernel expected"
+        xw = rng.random(Bw.shape[1])
+        Bd.vmult(out, dev(xw))
+        assert relerr(host(out, ctx), Bw @ xw) < TOL
+        Bd.set_kernel(0, 0)
+        Bd.vmult(out, dev(xw))
+        assert relerr(host(out, ctx), Bw @ xw) < TOL
     # an unstructured matrix of the same size keeps the CSR kernels
     cols = rng.integers(0, n, size=(n, 20))
     B = sp.csr_matrix((rng.random(n * 20), cols.ravel(), np.arange(0, 20 * n + 1, 20)), shape=(n, n))
