@@ -63,7 +63,7 @@ def smoother_coefficients(degree, lmin, lmax):
     return out
 
 
-def committed_traffic(args):
+def committed_traffic(args, compact):
     """HBM bytes per launch of the operator kernel from the PMC passes committed under profiles/ (2 x FETCH_SIZE
     + WRITE_SIZE, MI355X_MICROARCH.md): counters need rocprofv3 around the process, so this is not a live
     reading; it only applies to the workload it was collected on (256^3 cells per GPU, degree 3)."""
@@ -71,7 +71,9 @@ def committed_traffic(args):
     if args.cells != 256 or args.degree != 3 or not os.path.exists(path):
         return None
     with open(path) as f:
-        return json.load(f)["traffic_bytes_per_launch"]
+        d = json.load(f)
+    key = "cell_constant" if compact else "general"
+    return d.get(key, {}).get("traffic_bytes_per_launch")
 
 
 def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3):
@@ -95,11 +97,12 @@ def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3):
             "n_dofs": n, "ms_per_step": dt * 1e3, "value": n / dt, "unit": "DoF/s"}
 
 
-def measure_smoother_f32(ctx, torch, M, cells, degree, reps=5):
+def measure_smoother_f32(ctx, torch, M, cells, degree, reps=5, material="linear"):
     """BASELINE.json configs[4] (FP32): smoother apply with the FP32 instance of the operator kernel (vector
     ALU: at ~11 flop/B the cell kernel sits below the FP32-MFMA ridge)."""
-    prob = M.LaplaceProblem((cells,) * 3, "constant", device="cuda")
+    prob = M.LaplaceProblem((cells,) * 3, material, device="cuda")
     op = M.MatrixFreeLaplaceF32(ctx, prob)
+    compact = op.cell_constant_layout()
     N = prob.n_dofs
     del prob
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -126,16 +129,20 @@ def measure_smoother_f32(ctx, torch, M, cells, degree, reps=5):
     ev1.synchronize()
     ms = ev0.elapsed_time(ev1) / reps
     # FP32: x 4 + out 4 + 8 idx 32 + 8 coef 32 = 72, + b + D^-1 (+ x_prev from the second term on)
-    per_dof = sum(72 + 8 + (4 if k > 0 else 0) for k in range(len(coefs)))
-    return {"n_dofs": N, "degree": degree, "dtype": "f32", "ms_per_apply": ms, "algorithmic_bytes_per_dof": per_dof,
+    b_op = 44 if compact else 72
+    per_dof = sum(b_op + 8 + (4 if k > 0 else 0) for k in range(len(coefs)))
+    return {"n_dofs": N, "degree": degree, "dtype": "f32", "material": material,
+            "coefficient_layout": "one value per cell" if compact else "eight values per cell",
+            "ms_per_apply": ms, "algorithmic_bytes_per_dof": per_dof,
             "achieved_GBs": N * per_dof / (ms * 1e-3) / 1e9, "frac_of_8TBs": N * per_dof / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
-def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=5, tile=None):
+def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=5, tile=None, material="constant"):
     """Fine-level smoother apply (degree fused operator kernels) on its own: ms per apply from HIP
     events on the kernels' stream, algorithmic GB/s."""
-    prob = M.LaplaceProblem((n_dofs_per_dim - 1,) * 3, "constant", device="cuda")
+    prob = M.LaplaceProblem((n_dofs_per_dim - 1,) * 3, material, device="cuda")
     op = M.MatrixFreeLaplace(ctx, prob)
+    compact = op.cell_constant_layout()
     if tile:
         op.set_tile(*tile)
     N = prob.n_dofs
@@ -167,9 +174,13 @@ def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=5, tile=None):
     ms = ev0.elapsed_time(ev1) / reps
     # exact algorithmic bytes per DoF: operator 112 (x, out, 8 idx, 8 coef) + b + D^-1 (+ x_prev from the
     # second term on); A x is never stored
-    bytes_per_dof = (112 + 16) + (len(coefs) - 1) * (112 + 24)
+    # (one coefficient per cell when the material is cell-wise constant: 112 - 64 + 8 = 56)
+    b_op = 56 if compact else 112
+    bytes_per_dof = (b_op + 16) + (len(coefs) - 1) * (b_op + 24)
     gbs = N * bytes_per_dof / (ms * 1e-3) / 1e9
-    return {"n_dofs": N, "degree": degree, "ms_per_apply": ms, "algorithmic_bytes_per_dof": bytes_per_dof,
+    return {"n_dofs": N, "degree": degree, "material": material,
+            "coefficient_layout": "one value per cell" if compact else "eight values per cell",
+            "ms_per_apply": ms, "algorithmic_bytes_per_dof": bytes_per_dof,
             "achieved_GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS}
 
 
@@ -298,6 +309,7 @@ def main():
     # residual norms around the run: a bench of a cycle that does not contract would be meaningless
     assembled = args.evaluator == "assembled"
     op_monitor = None if assembled else M.MatrixFreeLaplace(ctx, prob)
+    compact = (not assembled) and op_monitor.cell_constant_layout()   # same detection as inside the hierarchy
     r = torch.empty_like(x)
 
     def residual_norm():
@@ -375,6 +387,10 @@ def main():
                             f"(the mesh deal.II's refine_global gives; BASELINE.json configs[3] '512^3 on 8 GPUs' "
                             f"is this workload at N=8), spectral AMGe (2x2x2 agglomerates, 2 eigenvectors), "
                             f"Chebyshev({degree}) smoother, coarse level {n_coarse} DoFs: " + coarse_desc + ", FP64",
+                "material": args.material,
+                "coefficient_layout": (None if assembled else
+                                       ("one value per cell (the eight quadrature coefficients of every cell are equal)"
+                                        if compact else "eight values per cell")),
                 "fine_dofs_per_gpu": n_fine,
                 "coarse_dofs_per_gpu": n_coarse,
                 "coarse_amg_levels_rows_nnzA_nnzP": (h.coarse_amg_shapes() if args.coarse == "amg" else None),
@@ -394,7 +410,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": committed_traffic(args),
+                "traffic": committed_traffic(args, compact),
+                "algorithmic_bytes_per_dof_operator": (None if assembled else (56 if compact else 112)),
                 "launches_in_timed_region": launches, "tile_waves_ty_tz": list(mf_tile),
                 "avg_launch_ms": k_ms / launches if launches else None,
                 "algorithmic_bytes_per_launch": k_bytes / launches if launches else None,
@@ -424,6 +441,8 @@ def main():
             try:
                 out["vcycle_128cubed_config1"] = measure_vcycle_small(ctx, torch, M, 128, params)
                 out["smoother_apply_256cubed_f32_config5"] = measure_smoother_f32(ctx, torch, M, 256, args.degree)
+                out["smoother_apply_257cubed_general_coefficient"] = measure_smoother(ctx, torch, M, 257, args.degree,
+                                                                                        material="linear")
             except Exception as e:  # noqa: BLE001 - report, do not hide the main result
                 out["extras_error"] = str(e)
         if world == 1 and not args.no_smoother_512:

@@ -81,6 +81,10 @@ int mfmg_hip_context_set_halo_buffers(mfmg_hip_context_t ctx, int32_t space, int
 /* Distributed runs: overlap the exchange of the fine-level ghost planes with the operator tiles that do not read
  * them (second HIP stream; default on).  Off: exchange first, then one launch over all tiles.  Same results. */
 int mfmg_hip_context_set_overlap_exchange(mfmg_hip_context_t ctx, int enable);
+/* Matrix-free operators created afterwards: when the eight quadrature coefficients of every cell are equal
+ * (material_property constant, the reference's default, or any cell-wise constant material) keep ONE value per
+ * cell (20 instead of 76 bytes per cell in FP64; default on).  Off forces the general eight-value layout. */
+int mfmg_hip_context_set_cell_constant_layout(mfmg_hip_context_t ctx, int enable);
 /* layout of a distributed space after the hierarchy was built: entries per layer, local layers, owned range */
 int mfmg_hip_context_halo_layout(mfmg_hip_context_t ctx, int32_t space, int64_t *layer_elems, int64_t *n_layers,
                                  int64_t *owned_begin, int64_t *owned_count);
@@ -179,6 +183,7 @@ int mfmg_hip_mf_laplace_smoother_step(mfmg_hip_mf_laplace_t op, const double *b,
 typedef struct mfmg_hip_mf_laplace_f32_s *mfmg_hip_mf_laplace_f32_t;
 int mfmg_hip_mf_laplace_f32_create(mfmg_hip_context_t ctx, const mfmg_hip_mesh_desc *mesh, mfmg_hip_mf_laplace_f32_t *out);
 int mfmg_hip_mf_laplace_f32_destroy(mfmg_hip_mf_laplace_f32_t op);
+int mfmg_hip_mf_laplace_f32_cell_constant_layout(mfmg_hip_mf_laplace_f32_t op, int *in_use);
 int mfmg_hip_mf_laplace_f32_vmult(mfmg_hip_mf_laplace_f32_t op, const float *x, float *y);
 int mfmg_hip_mf_laplace_f32_diagonal_inverse(mfmg_hip_mf_laplace_f32_t op, float *dinv);
 int mfmg_hip_mf_laplace_f32_residual(mfmg_hip_mf_laplace_f32_t op, const float *x, const float *b, float *res);
@@ -188,6 +193,8 @@ int mfmg_hip_mf_laplace_f32_smoother_step(mfmg_hip_mf_laplace_f32_t op, const fl
 int mfmg_hip_mf_laplace_set_tile(mfmg_hip_mf_laplace_t op, int tile_y, int tile_z);
 /* wavefronts per workgroup (1..8) stacked in y that hand their boundary sums on through LDS (0 = heuristic) */
 int mfmg_hip_mf_laplace_set_tile_waves(mfmg_hip_mf_laplace_t op, int n_waves);
+/* 1 when the operator keeps one coefficient per cell (see mfmg_hip_context_set_cell_constant_layout) */
+int mfmg_hip_mf_laplace_cell_constant_layout(mfmg_hip_mf_laplace_t op, int *in_use);
 /* the tile in use */
 int mfmg_hip_mf_laplace_get_tile(mfmg_hip_mf_laplace_t op, int *n_waves, int *tile_y, int *tile_z);
 

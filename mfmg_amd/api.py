@@ -74,6 +74,10 @@ class Context:
     def torch_stream(self) -> "torch.cuda.ExternalStream":
         return torch.cuda.ExternalStream(self.stream)
 
+    def set_cell_constant_layout(self, enable: bool):
+        """Operators created afterwards keep one coefficient per cell when a cell's eight are equal (default on)."""
+        check(self._lib.mfmg_hip_context_set_cell_constant_layout(self.handle, int(bool(enable))))
+
     def set_overlap_exchange(self, enable: bool):
         """Distributed runs: overlap the fine-level halo exchange with interior operator tiles (default on)."""
         check(self._lib.mfmg_hip_context_set_overlap_exchange(self.handle, int(bool(enable))))
@@ -258,6 +262,11 @@ class MatrixFreeLaplace:
         self.ctx.synchronize()
         return out
 
+    def cell_constant_layout(self) -> bool:
+        v = C.c_int()
+        check(self._lib.mfmg_hip_mf_laplace_cell_constant_layout(self.handle, C.byref(v)))
+        return bool(v.value)
+
     def get_tile(self):
         """(waves, ty, tz) of the next launch."""
         a, b, c = C.c_int(), C.c_int(), C.c_int()
@@ -303,6 +312,11 @@ class MatrixFreeLaplaceF32:
         check(self._lib.mfmg_hip_mf_laplace_f32_smoother_step(self.handle, self._p(b), self._p(x),
                                                               self._p(x_prev) if x_prev is not None else None,
                                                               alpha, beta, self._p(out)))
+
+    def cell_constant_layout(self) -> bool:
+        v = C.c_int()
+        check(self._lib.mfmg_hip_mf_laplace_f32_cell_constant_layout(self.handle, C.byref(v)))
+        return bool(v.value)
 
     def diagonal_inverse(self) -> torch.Tensor:
         out = torch.empty(self.n_dofs, dtype=torch.float32, device="cuda")

@@ -155,6 +155,30 @@ int mfmg_hip_context_set_communicator(mfmg_hip_context_t ctx, int32_t rank, int3
   });
 }
 
+int mfmg_hip_context_set_cell_constant_layout(mfmg_hip_context_t ctx, int enable)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    ctx->handle->allow_cell_constant = enable != 0;
+  });
+}
+
+int mfmg_hip_mf_laplace_cell_constant_layout(mfmg_hip_mf_laplace_t op, int *in_use)
+{
+  return guarded([&] {
+    require(op && in_use, "null argument");
+    *in_use = op->op->cell_constant_layout() ? 1 : 0;
+  });
+}
+
+int mfmg_hip_mf_laplace_f32_cell_constant_layout(mfmg_hip_mf_laplace_f32_t op, int *in_use)
+{
+  return guarded([&] {
+    require(op && in_use, "null argument");
+    *in_use = op->op->cell_constant_layout() ? 1 : 0;
+  });
+}
+
 int mfmg_hip_context_set_overlap_exchange(mfmg_hip_context_t ctx, int enable)
 {
   return guarded([&] {
@@ -442,7 +466,7 @@ int mfmg_hip_mf_laplace_create(mfmg_hip_context_t ctx, const mfmg_hip_mesh_desc 
     auto h = new mfmg_hip_mf_laplace_s;
     try
     {
-      h->op = std::make_shared<MatrixFreeLaplaceDevice<double>>(*ctx->handle, *mesh);
+      h->op = std::make_shared<MatrixFreeLaplaceDevice<double>>(*ctx->handle, *mesh, ctx->handle->allow_cell_constant);
     }
     catch (...)
     {
@@ -513,7 +537,7 @@ int mfmg_hip_mf_laplace_f32_create(mfmg_hip_context_t ctx, const mfmg_hip_mesh_d
   return guarded([&] {
     require(ctx && mesh && out, "null argument");
     std::unique_ptr<mfmg_hip_mf_laplace_f32_s> h(new mfmg_hip_mf_laplace_f32_s);
-    h->op = std::make_shared<MatrixFreeLaplaceDevice<float>>(*ctx->handle, *mesh);
+    h->op = std::make_shared<MatrixFreeLaplaceDevice<float>>(*ctx->handle, *mesh, ctx->handle->allow_cell_constant);
     *out = h.release();
   });
 }

@@ -265,6 +265,8 @@ struct HipHandle
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_packed = nullptr, ev_unpacked = nullptr;
   bool overlap_exchange = true;
+  // matrix-free operators built from this handle may keep one coefficient per cell when a cell's eight are equal
+  bool allow_cell_constant = true;
   // scratch for two-stage deterministic reductions
   DeviceBuffer<double> reduce_partials;
   DeviceBuffer<double> reduce_result;

@@ -154,7 +154,7 @@ RestrictorOptions HipMeshEvaluator::agglomerate_options(ptree const &params) con
 HipMatrixFreeMeshEvaluator::HipMatrixFreeMeshEvaluator(HipHandle &handle, mfmg_hip_mesh_desc const &mesh)
     : HipMeshEvaluator(handle, mesh)
 {
-  _op = std::make_shared<MatrixFreeLaplaceDevice<double>>(handle, _desc);
+  _op = std::make_shared<MatrixFreeLaplaceDevice<double>>(handle, _desc, handle.allow_cell_constant);
   HaloCommunicator &c = handle.comm;
   if (c.enabled())
   {

@@ -44,6 +44,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace mfmg
 {
@@ -53,15 +54,18 @@ constexpr unsigned int kFlag = 0x80000000u;  // bit 31: Dirichlet-constrained Do
 constexpr unsigned int kGhost = 0x40000000u; // bit 30: DoF owned by another rank (read normally, never written)
 constexpr unsigned int kIdMask = ~(kFlag | kGhost);
 
-// geometry of one chunk record
-template <typename T>
+// geometry of one chunk record.  CC ("cell constant"): the eight quadrature coefficients of every cell are
+// equal (a constant or cell-wise constant material: the reference's default `material_property constant`), and
+// ONE value per cell is stored instead of eight -- 76 -> 20 bytes per cell in FP64.
+template <typename T, bool CC>
 struct Rec
 {
   static constexpr int W = 16 / sizeof(T);                           // values per 16-byte vector
   static constexpr int NP = 8 / W;                                    // coefficient vectors per slot
   static constexpr size_t kCoefOff = 256;                             // after the own ids
-  static constexpr size_t kDinvOff = kCoefOff + (size_t)NP * 1024;    // after the coefficients
-  static constexpr size_t kBytes = kDinvOff + 64 * sizeof(T);         // 4864 (FP64) / 2560 (FP32)
+  static constexpr size_t kCoefBytes = CC ? 64 * sizeof(T) : (size_t)NP * 1024;
+  static constexpr size_t kDinvOff = kCoefOff + kCoefBytes;           // after the coefficients
+  static constexpr size_t kBytes = kDinvOff + 64 * sizeof(T);         // FP64: 4864 general, 1280 cell-constant
 };
 
 template <typename T>
@@ -155,6 +159,59 @@ __device__ __forceinline__ void direction_apply(T d00, T d10, T d01, T d11, T c0
   X11 = f * x11;
 }
 
+// The same with one coefficient per cell: the flux is a uniform scaling, so interpolation to the Gauss points
+// and back collapses into the 1-D mass matrix M = S^T S = [[A^2 + B^2, 2AB], [2AB, A^2 + B^2]] (= [[2/3, 1/3],
+// [1/3, 2/3]], the two-point rule is exact here) applied once per transverse direction: half the work.
+template <typename T>
+__device__ __forceinline__ void direction_apply_cc(T d00, T d10, T d01, T d11, T fw, T &X00, T &X10, T &X01, T &X11)
+{
+#pragma clang fp contract(off)
+  const T A = T(MFMG_GA * MFMG_GA + MFMG_GB * MFMG_GB), B = T(2. * MFMG_GA * MFMG_GB);
+  MFMG_INTERP(t00, t10, d00, d10) // mass matrix over p, r = 0
+  MFMG_INTERP(t01, t11, d01, d11) // r = 1
+  MFMG_INTERP(x00, x01, t00, t01) // mass matrix over r, p = 0
+  MFMG_INTERP(x10, x11, t10, t11) // p = 1
+  X00 = fw * x00;
+  X10 = fw * x10;
+  X01 = fw * x01;
+  X11 = fw * x11;
+}
+
+template <typename T>
+__device__ __forceinline__ void cell_apply_cc(T const u[8], T cv, T fx, T fy, T fz, T v[8])
+{
+#pragma clang fp contract(off)
+  T X00, X10, X01, X11;
+  const T w2 = cv + cv; // the two Gauss points of the differentiated direction
+  direction_apply_cc<T>(u[1] - u[0], u[3] - u[2], u[5] - u[4], u[7] - u[6], fx * w2, X00, X10, X01, X11);
+  v[0] = -X00;
+  v[1] = X00;
+  v[2] = -X10;
+  v[3] = X10;
+  v[4] = -X01;
+  v[5] = X01;
+  v[6] = -X11;
+  v[7] = X11;
+  direction_apply_cc<T>(u[2] - u[0], u[3] - u[1], u[6] - u[4], u[7] - u[5], fy * w2, X00, X10, X01, X11);
+  v[0] -= X00;
+  v[2] += X00;
+  v[1] -= X10;
+  v[3] += X10;
+  v[4] -= X01;
+  v[6] += X01;
+  v[5] -= X11;
+  v[7] += X11;
+  direction_apply_cc<T>(u[4] - u[0], u[5] - u[1], u[6] - u[2], u[7] - u[3], fz * w2, X00, X10, X01, X11);
+  v[0] -= X00;
+  v[4] += X00;
+  v[1] -= X10;
+  v[5] += X10;
+  v[2] -= X01;
+  v[6] += X01;
+  v[3] -= X11;
+  v[7] += X11;
+}
+
 template <typename T>
 __device__ __forceinline__ void cell_apply(T const u[8], T const c[8], T fx, T fy, T fz, T v[8])
 {
@@ -213,30 +270,29 @@ __device__ __forceinline__ unsigned int id_off(int id)
   return ((unsigned int)id & kIdMask) * (unsigned int)sizeof(T);
 }
 
-template <typename T>
-__device__ __forceinline__ void load_coef(unsigned char const *rec, int lane, T c[8]);
-template <>
-__device__ __forceinline__ void load_coef<double>(unsigned char const *rec, int lane, double c[8])
+template <typename T, bool CC>
+__device__ __forceinline__ void load_coef(unsigned char const *rec, int lane, T c[8])
 {
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
+  if constexpr (CC)
   {
-    const double2 v = reinterpret_cast<double2 const *>(rec + Rec<double>::kCoefOff + q * 1024)[lane];
-    c[2 * q] = v.x;
-    c[2 * q + 1] = v.y;
+    const T v = reinterpret_cast<T const *>(rec + Rec<T, true>::kCoefOff)[lane];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      c[q] = v;
   }
-}
-template <>
-__device__ __forceinline__ void load_coef<float>(unsigned char const *rec, int lane, float c[8])
-{
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
+  else
   {
-    const float4 v = reinterpret_cast<float4 const *>(rec + Rec<float>::kCoefOff + q * 1024)[lane];
-    c[4 * q] = v.x;
-    c[4 * q + 1] = v.y;
-    c[4 * q + 2] = v.z;
-    c[4 * q + 3] = v.w;
+    constexpr int W = Rec<T, false>::W;
+    using vec_t = typename std::conditional<sizeof(T) == 8, double2, float4>::type;
+#pragma unroll
+    for (int p = 0; p < Rec<T, false>::NP; ++p)
+    {
+      const vec_t v = reinterpret_cast<vec_t const *>(rec + Rec<T, false>::kCoefOff + p * 1024)[lane];
+      T const *e = reinterpret_cast<T const *>(&v);
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+        c[p * W + w] = e[w];
+    }
   }
 }
 
@@ -257,8 +313,8 @@ __device__ __forceinline__ T mf_epilogue(MfArgs<T> const &a, int id0, T x0, T yv
 
 // TYC > 0: rows per wavefront known at compile time (the row loop is fully unrolled: no loop-carried register
 // moves, constant LDS offsets); TYC = 0: taken from the arguments.
-template <typename T, int TYC>
-__global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
+template <typename T, int TYC, bool CC>
+__device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a)
 {
 #pragma clang fp contract(off)
   const int TY = TYC > 0 ? TYC : a.TY;
@@ -294,7 +350,7 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
   // the lane whose a=1 corners are not the a=0 corners of lane+1 inside this wavefront
   const bool no_next = (lane == 63) || (ci + 1 >= a.Nx);
   const int jj0 = (Yb < 0) ? 1 : 0; // cell row -1 does not exist (its sums are the zero initial carries)
-  const size_t rec_row = (size_t)a.ncols * Rec<T>::kBytes;
+  const size_t rec_row = (size_t)a.ncols * Rec<T, CC>::kBytes;
   const size_t rec_layer = (size_t)a.Ny * rec_row;
   const bool next_chunk = (lane == 63) && (ci + 1 < a.Nx); // its a=1 corners are lane 1 of the next chunk
   const size_t fb0_row = (size_t)a.ncols * 64;
@@ -320,7 +376,7 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
     // ids of the first row of the layer
     int j = Yb + jj0;
     const size_t r0 = ((size_t)max(k, 0) * a.Ny + (size_t)j) * a.ncols + (size_t)tc; // uniform
-    unsigned char const *recp = a.rec + r0 * Rec<T>::kBytes;
+    unsigned char const *recp = a.rec + r0 * Rec<T, CC>::kBytes;
     int4 const *fb0p = a.fb0 + r0 * 64;
     bool slot = col_ok && kin && (j < a.Ny) && (jj0 < TY);
     bool cell = slot && col_cell && (j < a.Ny - 1) && kcell;
@@ -338,9 +394,9 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
           pfA = reinterpret_cast<int const *>(recp + rec_row)[lane];
         if (next_chunk)
         {
-          pfBx = reinterpret_cast<int const *>(recp + rec_row + rec_layer + Rec<T>::kBytes)[1];
+          pfBx = reinterpret_cast<int const *>(recp + rec_row + rec_layer + Rec<T, CC>::kBytes)[1];
           if (!layer_carry)
-            pfAx = reinterpret_cast<int const *>(recp + rec_row + Rec<T>::kBytes)[1];
+            pfAx = reinterpret_cast<int const *>(recp + rec_row + Rec<T, CC>::kBytes)[1];
         }
       }
     }
@@ -356,7 +412,7 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
       unsigned char const *recn = recp + rec_row;
       int4 const *fb0n = fb0p + fb0_row;
       T v[8];
-      T c[8];
+      T c[CC ? 1 : 8];
       T n0 = T(0), n2 = T(0), n1x = T(0), n3x = T(0);
       T lb = T(0), ld = T(0), lxp = T(0);
       int4 f1;
@@ -401,7 +457,10 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
         }
         if (cell)
         {
-          load_coef<T>(recp, lane, c);
+          if constexpr (CC)
+            c[0] = reinterpret_cast<T const *>(recp + Rec<T, true>::kCoefOff)[lane];
+          else
+            load_coef<T, false>(recp, lane, c);
           n2 = ld_off<T>(a.x, id_off<T>(f1.z));                                     // x(ci, j+1, k+1)
           n0 = layer_carry ? xz[jj * 64 + lane] : ld_off<T>(a.x, id_off<T>(f1.x)); // x(ci, j+1, k)
           if (no_next)
@@ -415,7 +474,7 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
           const unsigned int g = id_off<T>(id0);
           lb = ld_off<T>(a.b, g);
           if (a.mode >= 2)
-            ld = reinterpret_cast<T const *>(recp + Rec<T>::kDinvOff)[lane];
+            ld = reinterpret_cast<T const *>(recp + Rec<T, CC>::kDinvOff)[lane];
           if (a.mode == 3)
             lxp = ld_off<T>(a.xprev, g);
         }
@@ -429,9 +488,9 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
           pfAn = reinterpret_cast<int const *>(recn + rec_row)[lane];
         if (next_chunk)
         {
-          pfBxn = reinterpret_cast<int const *>(recn + rec_row + rec_layer + Rec<T>::kBytes)[1];
+          pfBxn = reinterpret_cast<int const *>(recn + rec_row + rec_layer + Rec<T, CC>::kBytes)[1];
           if (!layer_carry)
-            pfAxn = reinterpret_cast<int const *>(recn + rec_row + Rec<T>::kBytes)[1];
+            pfAxn = reinterpret_cast<int const *>(recn + rec_row + Rec<T, CC>::kBytes)[1];
         }
       }
       if (slotn && !celln)
@@ -459,7 +518,10 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
         u[3] = (f1.y < 0) ? T(0) : n1;
         u[6] = (f1.z < 0) ? T(0) : n2;
         u[7] = (f1.w < 0) ? T(0) : n3;
-        cell_apply<T>(u, c, a.fx, a.fy, a.fz, v);
+        if constexpr (CC)
+          cell_apply_cc<T>(u, c[0], a.fx, a.fy, a.fz, v);
+        else
+          cell_apply<T>(u, c, a.fx, a.fy, a.fz, v);
         cx[0] = n0;
         cx[1] = n1;
         cx[2] = n2;
@@ -548,16 +610,30 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
   }
 }
 
+// The cell-constant variant with three rows per wavefront needs 97 VGPRs: asking for five wavefronts per SIMD
+// costs it one spilled register and buys a fifth resident wavefront (measured 513^3: 6.15 -> 5.65 ms per sweep;
+// with four rows three registers spill and it loses).  The general variant (113-121 VGPRs) stays at four.
+template <typename T, int TYC, bool CC>
+__global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
+{
+  mf_laplace_body<T, TYC, CC>(a);
+}
+template <typename T, int TYC>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) void mf_laplace_cc5_kernel(MfArgs<T> a)
+{
+  mf_laplace_body<T, TYC, true>(a);
+}
+
 // ---- setup kernels -----------------------------------------------------------
-template <typename T>
+template <typename T, bool CC>
 __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coefficient,
                                  uint8_t const *constrained, int Nx, int Ny, int Nz, int ncols, int4 *fb0,
                                  unsigned char *rec)
 {
   const int64_t n_slots = (int64_t)ncols * Nz * Ny * 64;
   const int nx = Nx - 1, ny = Ny - 1, nz = Nz - 1;
-  constexpr int W = Rec<T>::W;
-  constexpr int NP = Rec<T>::NP;
+  constexpr int W = Rec<T, CC>::W;
+  constexpr int NP = Rec<T, CC>::NP;
   for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n_slots;
        s += (int64_t)gridDim.x * blockDim.x)
   {
@@ -598,12 +674,15 @@ __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coeffic
       }
     }
     fb0[s] = make_int4(id[0], id[1], id[4], id[5]);
-    unsigned char *r = rec + (size_t)chunk * Rec<T>::kBytes;
+    unsigned char *r = rec + (size_t)chunk * Rec<T, CC>::kBytes;
     reinterpret_cast<int *>(r)[lane] = id[0];
-    for (int p = 0; p < NP; ++p)
-      for (int w = 0; w < W; ++w)
-        reinterpret_cast<T *>(r + Rec<T>::kCoefOff + p * 1024)[lane * W + w] = cf[p * W + w];
-    reinterpret_cast<T *>(r + Rec<T>::kDinvOff)[lane] = T(0);
+    if constexpr (CC)
+      reinterpret_cast<T *>(r + Rec<T, CC>::kCoefOff)[lane] = cf[0];
+    else
+      for (int p = 0; p < NP; ++p)
+        for (int w = 0; w < W; ++w)
+          reinterpret_cast<T *>(r + Rec<T, CC>::kCoefOff + p * 1024)[lane * W + w] = cf[p * W + w];
+    reinterpret_cast<T *>(r + Rec<T, CC>::kDinvOff)[lane] = T(0);
   }
 }
 
@@ -660,7 +739,7 @@ struct DiagTable
 
 // compute_diagonal (tests/laplace_matrix_free.hpp:75-98,158-199): per-cell
 // unit-vector applies summed per DoF; constrained entries set to one.
-template <typename T>
+template <typename T, bool CC>
 __global__ void mf_diagonal_kernel(int4 const *fb0, unsigned char const *rec, int Nx, int Ny, int Nz, int ncols,
                                    DiagTable tab, T *diag, T *dinv)
 {
@@ -683,7 +762,7 @@ __global__ void mf_diagonal_kernel(int4 const *fb0, unsigned char const *rec, in
       T c[8];
       int cl;
       const size_t cr = chunk_of(ci, cj, ck, Ny, ncols, cl);
-      load_coef<T>(rec + cr * Rec<T>::kBytes, cl, c);
+      load_coef<T, CC>(rec + cr * Rec<T, CC>::kBytes, cl, c);
       for (int q = 0; q < 8; ++q)
         sum += (double)c[q] * tab.K[q][m];
     }
@@ -694,8 +773,22 @@ __global__ void mf_diagonal_kernel(int4 const *fb0, unsigned char const *rec, in
   }
 }
 
+// are the eight quadrature coefficients of every cell equal?
+__global__ void mf_cell_constant_kernel(double const *coefficient, int64_t n_cells, int *n_varying)
+{
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < n_cells; c += (int64_t)gridDim.x * blockDim.x)
+  {
+    const double v = coefficient[c * 8];
+    bool same = true;
+    for (int q = 1; q < 8; ++q)
+      same = same && (coefficient[c * 8 + q] == v);
+    if (!same)
+      atomicAdd(n_varying, 1);
+  }
+}
+
 // copy of D^-1 in slot order inside the records (every slot of a real DoF, the duplicated halo slots too)
-template <typename T>
+template <typename T, bool CC>
 __global__ void mf_fill_dinv_kernel(int4 const *fb0, T const *dinv, int Nx, int ncols, int64_t n_slots,
                                     unsigned char *rec)
 {
@@ -708,13 +801,13 @@ __global__ void mf_fill_dinv_kernel(int4 const *fb0, T const *dinv, int Nx, int 
     if (i < 0 || i >= Nx)
       continue;
     const unsigned int g = (unsigned int)fb0[s].x & kIdMask;
-    reinterpret_cast<T *>(rec + (size_t)chunk * Rec<T>::kBytes + Rec<T>::kDinvOff)[lane] = dinv[g];
+    reinterpret_cast<T *>(rec + (size_t)chunk * Rec<T, CC>::kBytes + Rec<T, CC>::kDinvOff)[lane] = dinv[g];
   }
 }
 } // namespace
 
 template <typename T>
-MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_mesh_desc const &mesh)
+MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_mesh_desc const &mesh, bool allow_compact)
     : _handle(handle)
 {
   if (mesh.dim != 3)
@@ -761,20 +854,30 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   const size_t n_slots = (size_t)_ncols * _N[2] * _N[1] * 64;
   _n_slots = n_slots;
   _fb0.resize(n_slots);
-  _rec.resize((n_slots / 64) * Rec<T>::kBytes);
   _diag.resize(nd);
   _dinv.resize(nd);
 
   // range check of the ids comes first: the repack kernel dereferences constrained[id]
   DeviceBuffer<int> bad(1);
+  // cell-wise constant coefficient: one value per cell is kept (unless the caller asked for the general layout)
+  MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
+  hipLaunchKernelGGL(mf_cell_constant_kernel, dim3(n_blocks_for(nc, 256, 1 << 16)), dim3(256), 0, st, co, nc,
+                     bad.data());
+  MFMG_HIP_CHECK(hipGetLastError());
+  _compact = allow_compact && bad.download(st)[0] == 0;
+  _rec.resize((n_slots / 64) * (_compact ? Rec<T, true>::kBytes : Rec<T, false>::kBytes));
   MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
   hipLaunchKernelGGL(mf_range_kernel, dim3(n_blocks_for(nc * 8, 256, 1 << 16)), dim3(256), 0, st, cd, nc * 8, nd,
                      bad.data());
   MFMG_HIP_CHECK(hipGetLastError());
   ASSERT_THROW(bad.download(st)[0] == 0, "cell_dofs is not a logically structured hex mesh in lexicographic cell "
                                          "order (DoF ids out of range)");
-  hipLaunchKernelGGL(mf_repack_kernel<T>, dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, cd,
-                     co, cn, _N[0], _N[1], _N[2], _ncols, _fb0.data(), _rec.data());
+  if (_compact)
+    hipLaunchKernelGGL((mf_repack_kernel<T, true>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, cd,
+                       co, cn, _N[0], _N[1], _N[2], _ncols, _fb0.data(), _rec.data());
+  else
+    hipLaunchKernelGGL((mf_repack_kernel<T, false>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, cd,
+                       co, cn, _N[0], _N[1], _N[2], _ncols, _fb0.data(), _rec.data());
   MFMG_HIP_CHECK(hipGetLastError());
 
   MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
@@ -810,11 +913,20 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
       }
       tab.K[q][m] = sum;
     }
-  hipLaunchKernelGGL(mf_diagonal_kernel<T>, dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
-                     _fb0.data(), _rec.data(), _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
-  MFMG_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(mf_fill_dinv_kernel<T>, dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st,
-                     _fb0.data(), _dinv.data(), _N[0], _ncols, (int64_t)n_slots, _rec.data());
+  if (_compact)
+  {
+    hipLaunchKernelGGL((mf_diagonal_kernel<T, true>), dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
+                       _fb0.data(), _rec.data(), _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
+    hipLaunchKernelGGL((mf_fill_dinv_kernel<T, true>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st,
+                       _fb0.data(), _dinv.data(), _N[0], _ncols, (int64_t)n_slots, _rec.data());
+  }
+  else
+  {
+    hipLaunchKernelGGL((mf_diagonal_kernel<T, false>), dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
+                       _fb0.data(), _rec.data(), _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
+    hipLaunchKernelGGL((mf_fill_dinv_kernel<T, false>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st,
+                       _fb0.data(), _dinv.data(), _N[0], _ncols, (int64_t)n_slots, _rec.data());
+  }
   MFMG_HIP_CHECK(hipGetLastError());
   MFMG_HIP_CHECK(hipStreamSynchronize(st));
 }
@@ -834,8 +946,11 @@ void MatrixFreeLaplaceDevice<T>::choose_tile(int &nw, int &ty, int &tz) const
   tz = _tile_z;
   if (nw > 0 && ty > 0 && tz > 0)
     return;
-  static const int pref[][3] = {{4, 4, 16}, {4, 4, 8}, {4, 3, 8}, {4, 2, 8}, {2, 2, 8}, {2, 2, 4}, {1, 2, 4}};
-  constexpr int n_pref = sizeof(pref) / sizeof(pref[0]);
+  // (the cell-constant variant is fastest with three rows per wavefront, where it fits five wavefronts per SIMD)
+  static const int pref_general[][3] = {{4, 4, 16}, {4, 4, 8}, {4, 3, 8}, {4, 2, 8}, {2, 2, 8}, {2, 2, 4}, {1, 2, 4}};
+  static const int pref_compact[][3] = {{4, 3, 16}, {4, 3, 8}, {4, 3, 8}, {4, 2, 8}, {2, 2, 8}, {2, 2, 4}, {1, 2, 4}};
+  const int(*pref)[3] = _compact ? pref_compact : pref_general;
+  constexpr int n_pref = 7;
   int pick = n_pref - 1;
   for (int c = 0; c < n_pref; ++c)
   {
@@ -897,26 +1012,43 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
   const size_t lds = ((size_t)nw * 2 * ty + (size_t)2 * nw * 2) * 64 * sizeof(T) + (size_t)nw * ty * 64 * sizeof(int2);
   ASSERT_THROW(lds <= 160 * 1024, "operator tile too large for the LDS");
   static bool lds_attr_set = false; // (one flag per instantiation of this member)
+  auto set_lds = [](const void *f) {
+    MFMG_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  };
   if (!lds_attr_set)
   {
-    MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mf_laplace_kernel<T, 0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mf_laplace_kernel<T, 3>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mf_laplace_kernel<T, 4>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    set_lds(reinterpret_cast<const void *>(mf_laplace_kernel<T, 0, false>));
+    set_lds(reinterpret_cast<const void *>(mf_laplace_kernel<T, 3, false>));
+    set_lds(reinterpret_cast<const void *>(mf_laplace_kernel<T, 4, false>));
+    set_lds(reinterpret_cast<const void *>(mf_laplace_kernel<T, 0, true>));
+    set_lds(reinterpret_cast<const void *>(mf_laplace_cc5_kernel<T, 3>));
+    set_lds(reinterpret_cast<const void *>(mf_laplace_kernel<T, 4, true>));
     lds_attr_set = true;
   }
   const uint64_t n_tiles = (uint64_t)a.ncols * a.ntiles_y * a.ntiles_z;
   ASSERT_THROW(n_tiles < (1ull << 31), "operator tile too small for this mesh (grid size limit)");
   // rounded up to a multiple of 8 for the XCD-contiguous tile order
   dim3 grid((unsigned int)(n_tiles >= 64 ? ((n_tiles + 7) / 8) * 8 : n_tiles));
-  if (ty == 3)
-    hipLaunchKernelGGL((mf_laplace_kernel<T, 3>), grid, dim3(64 * nw), lds, _handle.stream, a);
-  else if (ty == 4)
-    hipLaunchKernelGGL((mf_laplace_kernel<T, 4>), grid, dim3(64 * nw), lds, _handle.stream, a);
+  const dim3 block(64 * nw);
+  hipStream_t st = _handle.stream;
+  if (_compact)
+  {
+    if (ty == 3)
+      hipLaunchKernelGGL((mf_laplace_cc5_kernel<T, 3>), grid, block, lds, st, a);
+    else if (ty == 4)
+      hipLaunchKernelGGL((mf_laplace_kernel<T, 4, true>), grid, block, lds, st, a);
+    else
+      hipLaunchKernelGGL((mf_laplace_kernel<T, 0, true>), grid, block, lds, st, a);
+  }
   else
-    hipLaunchKernelGGL((mf_laplace_kernel<T, 0>), grid, dim3(64 * nw), lds, _handle.stream, a);
+  {
+    if (ty == 3)
+      hipLaunchKernelGGL((mf_laplace_kernel<T, 3, false>), grid, block, lds, st, a);
+    else if (ty == 4)
+      hipLaunchKernelGGL((mf_laplace_kernel<T, 4, false>), grid, block, lds, st, a);
+    else
+      hipLaunchKernelGGL((mf_laplace_kernel<T, 0, false>), grid, block, lds, st, a);
+  }
   MFMG_HIP_CHECK(hipGetLastError());
 }
 

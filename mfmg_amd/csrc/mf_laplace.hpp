@@ -26,7 +26,10 @@ template <typename T>
 class MatrixFreeLaplaceDevice
 {
 public:
-  MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_mesh_desc const &mesh);
+  // allow_compact: keep ONE coefficient per cell when the eight quadrature values of every cell are equal
+  // (detected on the device); false forces the general eight-value layout
+  MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_mesh_desc const &mesh, bool allow_compact = true);
+  bool cell_constant_layout() const { return _compact; }
 
   int64_t n_dofs() const { return _n_dofs; }
   int dof_grid(int d) const { return _N[d]; }
@@ -70,10 +73,11 @@ public:
   void get_tile(int &nw, int &ty, int &tz) const { choose_tile(nw, ty, tz); }
   HipHandle &handle() const { return _handle; }
 
-  // algorithmic bytes of one operator application (112 B/DoF in FP64)
+  // algorithmic bytes of one operator application (112 B/DoF in FP64: x, y, 8 ids, 8 coefficients;
+  // with one coefficient per cell the coefficient term is 8 B and the figure 56 B/DoF)
   double algorithmic_bytes_apply() const
   {
-    return double(_n_dofs) * (2.0 * sizeof(T) + 8 * 4 + 8 * sizeof(T));
+    return double(_n_dofs) * (2.0 * sizeof(T) + 8 * 4 + (_compact ? 1 : 8) * sizeof(T));
   }
 
 private:
@@ -96,5 +100,6 @@ private:
   DeviceBuffer<unsigned char> _rec;
   DeviceBuffer<T> _diag, _dinv;
   int _tile_y = 0, _tile_z = 0, _tile_waves = 0;
+  bool _compact = false;
 };
 } // namespace mfmg

@@ -85,6 +85,8 @@ def load() -> C.CDLL:
         "mfmg_hip_context_set_communicator": (C.c_int, [vp, i32, i32, i32, i32, vp, vp, vp]),
         "mfmg_hip_context_set_halo_buffers": (C.c_int, [vp, i32, i64, vp, vp, vp, vp]),
         "mfmg_hip_context_set_overlap_exchange": (C.c_int, [vp, C.c_int]),
+        "mfmg_hip_context_set_cell_constant_layout": (C.c_int, [vp, C.c_int]),
+        "mfmg_hip_mf_laplace_cell_constant_layout": (C.c_int, [vp, P(C.c_int)]),
         "mfmg_hip_context_halo_layout": (C.c_int, [vp, i32, P(i64), P(i64), P(i64), P(i64)]),
         "mfmg_hip_profile_enable": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_profile_select": (C.c_int, [vp, C.c_char_p]),
@@ -124,6 +126,7 @@ def load() -> C.CDLL:
         "mfmg_hip_mf_laplace_get_tile": (C.c_int, [vp, P(C.c_int), P(C.c_int), P(C.c_int)]),
         "mfmg_hip_mf_laplace_f32_create": (C.c_int, [vp, P(MeshDesc), P(vp)]),
         "mfmg_hip_mf_laplace_f32_destroy": (C.c_int, [vp]),
+        "mfmg_hip_mf_laplace_f32_cell_constant_layout": (C.c_int, [vp, P(C.c_int)]),
         "mfmg_hip_mf_laplace_f32_vmult": (C.c_int, [vp, vp, vp]),
         "mfmg_hip_mf_laplace_f32_diagonal_inverse": (C.c_int, [vp, vp]),
         "mfmg_hip_mf_laplace_f32_residual": (C.c_int, [vp, vp, vp, vp]),

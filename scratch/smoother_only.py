@@ -5,7 +5,7 @@ import mfmg_amd as M
 from bench import smoother_coefficients
 n, ty, tz, reps = (int(v) for v in sys.argv[1:5])
 ctx = M.Context()
-prob = M.LaplaceProblem((n-1,)*3, device='cuda')
+prob = M.LaplaceProblem((n-1,)*3, os.environ.get('MATERIAL', 'constant'), device='cuda')
 op = M.MatrixFreeLaplace(ctx, prob)
 N = prob.n_dofs
 del prob; torch.cuda.empty_cache()

@@ -163,6 +163,45 @@ def test_csr_degenerate_shapes(ctx):
         assert Ad.transpose().shape == (A.shape[1], A.shape[0])
 
 
+@pytest.mark.parametrize("material,expect", [("constant", True), ("linear", False), ("cellwise", True)])
+def test_mf_cell_constant_layout(ctx, material, expect):
+    """One coefficient per cell where a cell's eight quadrature values are equal: chosen automatically, same
+    operator as the general layout to rounding, every fused mode against the oracle."""
+    n = (70, 11, 9)
+    mesh = O.StructuredMesh(n)
+    rng = np.random.default_rng(17)
+    if material == "cellwise":
+        coef = np.repeat(1.0 + rng.random((mesh.n_cells, 1)), 8, axis=1)       # piecewise constant, varies by cell
+        prob = M.LaplaceProblem(n, "constant", device="cuda")
+        prob.coefficient = torch.from_numpy(coef).cuda()
+    else:
+        coef = O.coefficient_table(mesh, material)
+        prob = M.LaplaceProblem(n, material, device="cuda")
+    ref = O.MatrixFreeLaplace(mesh, coef)
+    op = M.MatrixFreeLaplace(ctx, prob)
+    assert op.cell_constant_layout() == expect
+    ctx.set_cell_constant_layout(False)
+    try:
+        op_general = M.MatrixFreeLaplace(ctx, prob)
+    finally:
+        ctx.set_cell_constant_layout(True)
+    assert not op_general.cell_constant_layout()
+    x, b, xp = rng.random(mesh.n_dofs), rng.random(mesh.n_dofs), rng.random(mesh.n_dofs)
+    dinv = ref.diagonal_inverse()
+    np.testing.assert_allclose(host(op.diagonal_inverse(), ctx), dinv, rtol=1e-13)
+    outs = []
+    for o in (op, op_general):
+        out = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
+        o.vmult(out, dev(x))
+        assert relerr(host(out, ctx), ref.vmult(x)) < TOL
+        o.residual(dev(x), dev(b), out)
+        assert relerr(host(out, ctx), ref.vmult(x) - b) < TOL
+        o.smoother_step(dev(b), dev(x), dev(xp), 0.3, 0.45, out)
+        assert relerr(host(out, ctx), x + 0.3 * (x - xp) - 0.45 * dinv * (ref.vmult(x) - b)) < TOL
+        outs.append(host(out, ctx).copy())
+    assert relerr(outs[0], outs[1]) < 1e-13
+
+
 def test_mf_rejects_bad_input(ctx):
     with pytest.raises(L.MfmgNotImplementedError):
         M.MatrixFreeLaplace(ctx, M.LaplaceProblem((8, 8), device="cuda"))        # dim = 2
