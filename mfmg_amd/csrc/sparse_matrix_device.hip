@@ -222,6 +222,74 @@ __global__ __launch_bounds__(256) void bdia_spmv_kernel(CsrArgs<T> a, T const *v
   a.out[row] = o;
 }
 
+// Symmetric matrices keep only the block diagonals with offset >= 0 (half the bytes from HBM): the entry
+// A[(n,c)][(n-o,cc)] of a lower diagonal is read as its transpose A[(n-o,cc)][(n,c)] = val[o][c][(n-o) C + cc],
+// i.e. the same plane a lower-numbered row streams as its upper part -- a second read of data that passed
+// through the caches o rows earlier.  One thread per row, fixed summation order (upper part, then lower part).
+template <typename T, int C>
+__global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, T const *val, int32_t const *offs, int D)
+{
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= a.n_rows)
+    return;
+  const int64_t n_nodes = a.n_rows / C;
+  const int64_t node = r / C;
+  const int c = (int)(r - node * C);
+  const size_t stride = (size_t)a.n_rows;
+  T const *vp = val + r;
+  T sum = T(0);
+#pragma unroll 4
+  for (int d = 0; d < D; ++d) // offs[0] = 0 < offs[1] < ...
+  {
+    const int64_t nb = node + offs[d];
+    if (nb < n_nodes)
+    {
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc)
+        sum += vp[(size_t)(d * C + cc) * stride] * a.x[nb * C + cc];
+    }
+  }
+#pragma unroll 4
+  for (int d = 1; d < D; ++d)
+  {
+    const int64_t nb = node - offs[d];
+    if (nb >= 0)
+    {
+      T const *vq = val + (size_t)(d * C + c) * stride + nb * C;
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc)
+        sum += vq[cc] * a.x[nb * C + cc];
+    }
+  }
+  const int64_t row = r;
+  T o;
+  switch (a.mode)
+  {
+  case 0:
+    o = sum;
+    break;
+  case 1:
+    o = sum - a.b[row];
+    break;
+  case 2:
+    o = a.x[row] - a.beta * a.dinv[row] * (sum - a.b[row]);
+    break;
+  case 3:
+  {
+    const T xr = a.x[row];
+    o = xr + a.alpha * (xr - a.xprev[row]) - a.beta * a.dinv[row] * (sum - a.b[row]);
+    break;
+  }
+  case 4:
+    o = a.out[row] - sum;
+    break;
+  default:
+    o = a.out[row] + sum;
+    break;
+  }
+  a.out[row] = o;
+}
+
 template <typename T, int LPR>
 void launch_lds(CsrArgs<T> const &a, hipStream_t st, int32_t const *blk_ptr, int32_t const *l2g, uint16_t const *lcol,
                 int rows_per_block, int max_cols)
@@ -388,10 +456,56 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
     }
   if (!ok)
     return;
-  _bdia_val.upload(dv.data(), dv.size(), _handle.stream);
-  _bdia_offs.upload(best_offs.data(), best_offs.size(), _handle.stream);
+  // symmetric (to rounding)?  then the diagonals with a negative offset are the transposes of the positive ones
+  bool symmetric = (D % 2 == 1);
+  const int zero = D / 2;
+  if (symmetric)
+    for (int d = 0; d <= zero; ++d)
+      symmetric = symmetric && (best_offs[zero + d] == -best_offs[zero - d]);
+  if (symmetric)
+  {
+    double scale = 0.;
+    for (int64_t r = 0; r < n; r += std::max<int64_t>(1, n / 4096))
+      scale = std::max(scale, std::abs((double)dv[((size_t)zero * c + (size_t)(r % c)) * n + r]));
+    const double tol = 1e-13 * std::max(scale, 1e-300);
+    bool sym = true;
+#pragma omp parallel for schedule(static) reduction(&& : sym)
+    for (int64_t r = 0; r < n; ++r)
+    {
+      const int64_t node = r / c;
+      const int rc = (int)(r % c);
+      for (int d = zero; d < D; ++d)
+      {
+        const int64_t nb = node + best_offs[d];
+        if (nb >= n / c)
+          continue;
+        for (int cc = 0; cc < c; ++cc)
+        {
+          const double up = (double)dv[((size_t)d * c + cc) * n + r];                                // A[(node,rc)][(nb,cc)]
+          const double lo = (double)dv[((size_t)(2 * zero - d) * c + rc) * n + (nb * c + cc)];      // A[(nb,cc)][(node,rc)]
+          if (std::abs(up - lo) > tol)
+            sym = false;
+        }
+      }
+    }
+    symmetric = sym;
+  }
+  if (symmetric)
+  {
+    const int Dh = D - zero; // offsets 0 and the positive ones
+    std::vector<int32_t> offs_h(best_offs.begin() + zero, best_offs.end());
+    _bdia_val.upload(dv.data() + (size_t)zero * c * n, (size_t)Dh * c * n, _handle.stream);
+    _bdia_offs.upload(offs_h.data(), offs_h.size(), _handle.stream);
+    _bdia_d = Dh;
+    _bdia_sym = true;
+  }
+  else
+  {
+    _bdia_val.upload(dv.data(), dv.size(), _handle.stream);
+    _bdia_offs.upload(best_offs.data(), best_offs.size(), _handle.stream);
+    _bdia_d = D;
+  }
   _bdia_c = c;
-  _bdia_d = D;
   _use_bdia = true;
 }
 
@@ -425,6 +539,27 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
     const dim3 grid((unsigned int)((_n_rows + 255) / 256));
     T const *dv = _bdia_val.data();
     int32_t const *of = _bdia_offs.data();
+    if (_bdia_sym)
+    {
+      switch (_bdia_c)
+      {
+      case 1:
+        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 1>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+        break;
+      case 2:
+        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 2>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+        break;
+      case 3:
+        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 3>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+        break;
+      default:
+        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 4>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+        break;
+      }
+      KernelProfiler::end(stop, st);
+      MFMG_HIP_CHECK(hipGetLastError());
+      return;
+    }
     switch (_bdia_c)
     {
     case 1:

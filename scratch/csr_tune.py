@@ -16,7 +16,7 @@ def bench(name, A):
     x = torch.rand(k, dtype=torch.float64, device='cuda'); y = torch.empty(m, dtype=torch.float64, device='cuda')
     lpr0, kind0 = A.get_kernel()
     print(f"{name}: {m} x {k}, nnz {nnz} ({nnz/m:.1f}/row)  default lpr={lpr0} kind={kind0}", flush=True)
-    for kind in (2, 1, 0):
+    for kind in (kind0 if kind0 >= 2 else 2, 1, 0):
         for lpr in ((4, 8, 16, 32, 64) if kind != 2 else (0,)):
             A.set_kernel(lpr, kind)
             if A.get_kernel()[1] != kind:

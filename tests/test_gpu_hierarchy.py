@@ -421,7 +421,7 @@ def test_full_size_hierarchy_properties(ctx):
         h.apply(b, xx)
     assert all(norms[i + 1] < 0.4 * norms[i] for i in range(4)), norms
     # the layouts the design relies on were actually chosen at this size
-    assert h.coarse_operator().get_kernel()[1] == 2          # block diagonals for A_c
+    assert h.coarse_operator().get_kernel()[1] == 3          # block diagonals for A_c, upper half stored
     assert h.operator_tile() == (4, 3, 8)
 
 

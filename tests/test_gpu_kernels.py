@@ -315,8 +315,8 @@ def test_csr_fused_modes_27pt(ctx):
                                    np.array([1.0, 1.0]), (1, 3))).shape
 
 
-@pytest.mark.parametrize("comps", [1, 2, 3])
-def test_csr_kernel_variants_on_stencil_matrix(ctx, comps):
+@pytest.mark.parametrize("comps,symmetric", [(1, False), (2, False), (3, False), (1, True), (2, True), (4, True)])
+def test_csr_kernel_variants_on_stencil_matrix(ctx, comps, symmetric):
     """A stencil matrix with `comps` unknowns per grid node (the shape of the AMGe coarse operators): the
     block-diagonal storage is chosen and every kernel variant / fused mode agrees with the CPU SpMV."""
     import scipy.sparse as sp
@@ -331,18 +331,22 @@ def test_csr_kernel_variants_on_stencil_matrix(ctx, comps):
     # a few rows lose entries (boundary-like irregularity stays inside the stencil)
     A.data[rng.integers(0, A.nnz, 500)] = 0.0
     A.eliminate_zeros()
+    if symmetric:                            # the coarse operators are: half of the diagonals is stored
+        A = (0.5 * (A + A.T)).tocsr()
     A = (A + sp.diags(np.full(A.shape[0], 30.0))).tocsr()
     A.sort_indices()
     n = A.shape[0]
     Ad = M.SparseMatrixDevice(ctx, A)
     lpr, kind = Ad.get_kernel()
-    assert kind == 2, "block-diagonal storage expected for a stencil matrix"
+    assert kind == (3 if symmetric else 2), "block-diagonal storage expected for a stencil matrix"
     x, b, xp = rng.random(n), rng.random(n), rng.random(n)
     dinv = 1.0 / A.diagonal()
     out = torch.empty(n, dtype=torch.float64, device="cuda")
     ref = O.csr_spmv(A.indptr, A.indices, A.data, x)
     for k in (2, 1, 0):
         Ad.set_kernel(0, k)
+        if k == 2:
+            assert Ad.get_kernel()[1] == kind
         if k == 1 and Ad.get_kernel()[1] != 1:
             continue                         # LDS lists are only built for large matrices
         Ad.vmult(out, dev(x))
