@@ -121,7 +121,7 @@ int mfmg_hip_csr_destroy(mfmg_hip_csr_t a);
 int mfmg_hip_csr_shape(mfmg_hip_csr_t a, int64_t *n_rows, int64_t *n_cols, int64_t *nnz); /* m(), n(), n_nonzero_elements() */
 /* tuning knob of the SpMV kernel: lanes of a wavefront per row (power of two 1..64, 0 = keep) and the storage
  * variant (0 plain CSR, 1 LDS-cached CSR, 2 block-diagonal (get reports 3 when only the upper half of a symmetric
- * matrix is stored), -1 = keep; a variant is only taken where its data was
+ * matrix is stored), 4 row-base storage of rectangular stencil-like matrices, -1 = keep; a variant is only taken where its data was
  * built at construction); the summation order, hence the last bits of the result, follows both */
 int mfmg_hip_csr_set_kernel(mfmg_hip_csr_t a, int lanes_per_row, int use_lds);
 int mfmg_hip_csr_get_kernel(mfmg_hip_csr_t a, int *lanes_per_row, int *use_lds);

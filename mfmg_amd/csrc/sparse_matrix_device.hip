@@ -222,6 +222,57 @@ __global__ __launch_bounds__(256) void bdia_spmv_kernel(CsrArgs<T> a, T const *v
   a.out[row] = o;
 }
 
+// Row-base storage for rectangular stencil-like matrices (the smoothed prolongators: every fine row couples to
+// the same small box of coarse unknowns, placed relative to a per-row base column): val[s n_rows + row] for the
+// slots s of a shared offset list, column = base[row] + offs[s].  4 B of index per ROW instead of per entry,
+// coalesced value planes, one thread per row, fixed summation order.
+template <typename T>
+__global__ __launch_bounds__(256) void rowbase_spmv_kernel(CsrArgs<T> a, T const *val, int32_t const *base,
+                                                           int32_t const *offs, int S, int64_t n_cols)
+{
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= a.n_rows)
+    return;
+  const int64_t b0 = base[r];
+  T const *vp = val + r;
+  const size_t stride = (size_t)a.n_rows;
+  T sum = T(0);
+#pragma unroll 4
+  for (int sidx = 0; sidx < S; ++sidx)
+  {
+    const int64_t c = b0 + offs[sidx];
+    if (c >= 0 && c < n_cols)
+      sum += vp[(size_t)sidx * stride] * a.x[c];
+  }
+  const int64_t row = r;
+  T o;
+  switch (a.mode)
+  {
+  case 0:
+    o = sum;
+    break;
+  case 1:
+    o = sum - a.b[row];
+    break;
+  case 2:
+    o = a.x[row] - a.beta * a.dinv[row] * (sum - a.b[row]);
+    break;
+  case 3:
+  {
+    const T xr = a.x[row];
+    o = xr + a.alpha * (xr - a.xprev[row]) - a.beta * a.dinv[row] * (sum - a.b[row]);
+    break;
+  }
+  case 4:
+    o = a.out[row] - sum;
+    break;
+  default:
+    o = a.out[row] + sum;
+    break;
+  }
+  a.out[row] = o;
+}
+
 // Symmetric matrices keep only the block diagonals with offset >= 0 (half the bytes from HBM): the entry
 // A[(n,c)][(n-o,cc)] of a lower diagonal is read as its transpose A[(n-o,cc)][(n,c)] = val[o][c][(n-o) C + cc],
 // i.e. the same plane a lower-numbered row streams as its upper part -- a second read of data that passed
@@ -335,9 +386,13 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
   // ---- block-diagonal storage (see bdia_spmv_kernel); when it applies the LDS lists are not needed
   if (n_rows == n_cols && n_rows >= 32768 && avg >= 8.)
     build_block_diagonals(row_ptr, col, val);
+  // ---- row-base storage (see rowbase_spmv_kernel) for matrices the block diagonals do not fit
+  // (one thread per row: below ~1000 workgroups the CSR kernels with several lanes per row fill the chip better)
+  if (!_use_bdia && n_rows >= 200000 && avg >= 4. && avg <= 160.)
+    build_row_base(row_ptr, col, val);
   // ---- block-local column compression for the LDS-cached kernel
   // (a 128-row block per workgroup: below ~256 blocks the plain kernel fills the chip better)
-  if (!_use_bdia && n_rows >= 256 * kRowsPerBlock && avg >= 4.)
+  if (!_use_bdia && !_use_rowbase && n_rows >= 256 * kRowsPerBlock && avg >= 4.)
   {
     const int64_t nb = (n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
     std::vector<int32_t> blk_ptr(nb + 1, 0);
@@ -510,6 +565,77 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
 }
 
 template <typename T>
+void SparseMatrixDevice<T>::build_row_base(std::vector<int32_t> const &row_ptr, std::vector<int32_t> const &col,
+                                           std::vector<T> const &val)
+{
+  const int64_t n = _n_rows;
+  // the offset list of the fullest rows (columns are sorted inside a row)
+  int max_len = 0;
+  for (int64_t r = 0; r < n; ++r)
+    max_len = std::max(max_len, row_ptr[r + 1] - row_ptr[r]);
+  if (max_len < 2 || max_len > 192)
+    return;
+  std::vector<int32_t> offs;
+  for (int64_t r = 0; r < n; ++r)
+    if (row_ptr[r + 1] - row_ptr[r] == max_len)
+    {
+      for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
+        offs.push_back(col[p] - col[row_ptr[r]]);
+      break;
+    }
+  const int S = (int)offs.size();
+  if (double(_nnz) < 0.8 * double(n) * S)
+    return;
+  // every row: a base such that all its columns fall on slots (rows at a boundary miss the low slots)
+  std::vector<int32_t> base(n, 0);
+  std::vector<T> dv((size_t)n * S, T(0));
+  bool ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : ok)
+  for (int64_t r = 0; r < n; ++r)
+  {
+    const int p0 = row_ptr[r], p1 = row_ptr[r + 1];
+    if (p0 == p1)
+    {
+      base[r] = -(1 << 30); // no column in range
+      continue;
+    }
+    bool placed = false;
+    for (int s0 = 0; s0 < S && !placed; ++s0)
+    {
+      const int64_t b = (int64_t)col[p0] - offs[s0];
+      int sidx = s0;
+      bool fit = true;
+      for (int p = p0; p < p1 && fit; ++p)
+      {
+        while (sidx < S && b + offs[sidx] < col[p])
+          ++sidx;
+        fit = sidx < S && b + offs[sidx] == col[p];
+      }
+      if (!fit || b < -(int64_t(1) << 30) || b > (int64_t(1) << 30))
+        continue;
+      base[r] = (int32_t)b;
+      sidx = s0;
+      for (int p = p0; p < p1; ++p)
+      {
+        while (b + offs[sidx] < col[p])
+          ++sidx;
+        dv[(size_t)sidx * n + r] += val[p];
+      }
+      placed = true;
+    }
+    if (!placed)
+      ok = false;
+  }
+  if (!ok)
+    return;
+  _rb_val.upload(dv.data(), dv.size(), _handle.stream);
+  _rb_base.upload(base.data(), base.size(), _handle.stream);
+  _rb_offs.upload(offs.data(), offs.size(), _handle.stream);
+  _rb_slots = S;
+  _use_rowbase = true;
+}
+
+template <typename T>
 void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const *dinv, T const *x_prev,
                                    T alpha, T beta, T *out) const
 {
@@ -534,6 +660,14 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
   const double extra = (mode == CsrMode::apply) ? 0. : (mode == CsrMode::first) ? 3. : (mode == CsrMode::next) ? 4. : 1.;
   hipEvent_t stop =
       _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes_apply() + extra * sizeof(T) * double(_n_rows), st);
+  if (_use_rowbase)
+  {
+    hipLaunchKernelGGL(rowbase_spmv_kernel<T>, dim3((unsigned int)((_n_rows + 255) / 256)), dim3(256), 0, st, a,
+                       _rb_val.data(), _rb_base.data(), _rb_offs.data(), _rb_slots, _n_cols);
+    KernelProfiler::end(stop, st);
+    MFMG_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (_use_bdia)
   {
     const dim3 grid((unsigned int)((_n_rows + 255) / 256));

@@ -85,7 +85,7 @@ public:
   // tuning knob: lanes of a wavefront that share a row (power of two, 1..64; 0 keeps the choice) and whether
   // the LDS-cached kernel is used (only where the block-local column lists were built)
   // use_lds: 0 plain, 1 LDS-cached, 2 / 3 block-diagonal storage (3 is reported when only the upper half of a
-  // symmetric matrix is stored; each variant only where its data was built)
+  // symmetric matrix is stored), 4 row-base storage; each variant only where its data was built
   void set_kernel(int lanes_per_row, int use_lds)
   {
     if (lanes_per_row > 0)
@@ -93,10 +93,11 @@ public:
     if (use_lds >= 0)
     {
       _use_bdia = (use_lds == 2 || use_lds == 3) && _bdia_val.size() > 0;
+      _use_rowbase = (use_lds == 4) && _rb_val.size() > 0;
       _use_lds = (use_lds == 1) && _lcol.size() > 0;
     }
   }
-  int kernel_kind() const { return _use_bdia ? (_bdia_sym ? 3 : 2) : (_use_lds ? 1 : 0); }
+  int kernel_kind() const { return _use_rowbase ? 4 : _use_bdia ? (_bdia_sym ? 3 : 2) : (_use_lds ? 1 : 0); }
   int block_diagonals() const { return _use_bdia ? _bdia_d : 0; }
   bool symmetric_storage() const { return _use_bdia && _bdia_sym; }
   // algorithmic bytes of one y = A x (12 B/nnz + 4 B/row ptr + x + y)
@@ -124,6 +125,12 @@ private:
   // block-diagonal storage (chosen at construction for stencil-like square matrices, see the .hip file)
   void build_block_diagonals(std::vector<int32_t> const &row_ptr, std::vector<int32_t> const &col,
                              std::vector<T> const &val);
+  // row-base storage (rectangular stencil-like matrices: the smoothed prolongators), see the .hip file
+  void build_row_base(std::vector<int32_t> const &row_ptr, std::vector<int32_t> const &col, std::vector<T> const &val);
+  bool _use_rowbase = false;
+  int _rb_slots = 0;
+  DeviceBuffer<T> _rb_val;
+  DeviceBuffer<int32_t> _rb_base, _rb_offs;
   bool _use_bdia = false;
   bool _bdia_sym = false; // symmetric matrix: only the block diagonals with offset >= 0 are stored
   int _bdia_c = 0, _bdia_d = 0;

@@ -357,17 +357,23 @@ def test_csr_kernel_variants_on_stencil_matrix(ctx, comps, symmetric):
         assert relerr(host(out, ctx), x + 0.25 * (x - xp) - 0.6 * dinv * (ref - b)) < TOL
         Ad.smoother_step(dev(dinv), dev(b), dev(x), None, 0.0, 0.6, out)
         assert relerr(host(out, ctx), x - 0.6 * dinv * (ref - b)) < TOL
-    # a rectangular matrix with the same local column reuse (a prolongator-like shape): LDS-cached CSR
+    # a rectangular matrix with the same stencil in every row (a prolongator-like shape): row-base storage;
+    # with entries missing at random the fill is too low for it and the LDS-cached CSR kernel takes over
     if comps == 1:
-        Bw = sp.hstack([A, 0.5 * A]).tocsr()
-        Bd = M.SparseMatrixDevice(ctx, Bw)
-        assert Bd.get_kernel()[1] == 1, "LDS-cached kernel expected"
-        xw = rng.random(Bw.shape[1])
-        Bd.vmult(out, dev(xw))
-        assert relerr(host(out, ctx), Bw @ xw) < TOL
-        Bd.set_kernel(0, 0)
-        Bd.vmult(out, dev(xw))
-        assert relerr(host(out, ctx), Bw @ xw) < TOL
+        Bw = sp.vstack([sp.hstack([A, 0.5 * A])] * 6).tocsr()       # 212 k rows: above the row-base threshold
+        out = torch.empty(Bw.shape[0], dtype=torch.float64, device="cuda")
+        keep = rng.random(Bw.nnz) > 0.45
+        Bs = sp.csr_matrix((Bw.data[keep], Bw.indices[keep], np.concatenate([[0], np.cumsum(
+            np.add.reduceat(keep.astype(np.int64), Bw.indptr[:-1]))])), shape=Bw.shape)
+        for Bm, want in ((Bw, 4), (Bs, 1)):
+            Bd = M.SparseMatrixDevice(ctx, Bm)
+            assert Bd.get_kernel()[1] == want
+            xw = rng.random(Bm.shape[1])
+            Bd.vmult(out, dev(xw))
+            assert relerr(host(out, ctx), Bm @ xw) < TOL
+            Bd.set_kernel(0, 0)
+            Bd.vmult(out, dev(xw))
+            assert relerr(host(out, ctx), Bm @ xw) < TOL
     # an unstructured matrix of the same size keeps the CSR kernels
     cols = rng.integers(0, n, size=(n, 20))
     B = sp.csr_matrix((rng.random(n * 20), cols.ravel(), np.arange(0, 20 * n + 1, 20)), shape=(n, n))
