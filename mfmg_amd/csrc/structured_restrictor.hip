@@ -49,6 +49,37 @@ __global__ __launch_bounds__(256) void sr_restrict_kernel(SrArgs s, double const
   y[r] = sum;
 }
 
+// two eigenvectors per agglomerate: one thread per agglomerate, both rows at once (the x values of the patch are
+// fetched once, the two plane entries in one 16-byte request); the sums are formed as in the row kernel
+__global__ __launch_bounds__(256) void sr_restrict_pair_kernel(SrArgs s, double const *x, double *y)
+{
+  const int64_t ag = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (2 * ag >= s.n_coarse)
+    return;
+  const int ai = ag % s.na[0], aj = (ag / s.na[0]) % s.na[1], ak = ag / ((int64_t)s.na[0] * s.na[1]);
+  const int64_t base = (int64_t)ai * s.a[0] + (int64_t)s.N[0] * ((int64_t)aj * s.a[1] + (int64_t)s.N[1] * ((int64_t)ak * s.a[2]));
+  double2 const *p = reinterpret_cast<double2 const *>(s.planes) + ag;
+  const size_t stride = (size_t)s.n_coarse / 2;
+  double sum0 = 0., sum1 = 0.;
+  int m = 0;
+  for (int mz = 0; mz <= s.a[2]; ++mz)
+    for (int my = 0; my <= s.a[1]; ++my)
+    {
+      const int64_t row = base + (int64_t)s.N[0] * (my + (int64_t)s.N[1] * mz);
+#pragma unroll 3
+      for (int mx = 0; mx <= s.a[0]; ++mx, ++m)
+      {
+        const int64_t node = row + mx;
+        const int64_t id = s.node_dof ? (int64_t)s.node_dof[node] : node;
+        const double2 pv = p[(size_t)m * stride];
+        const double xv = x[id];
+        sum0 += pv.x * xv;
+        sum1 += pv.y * xv;
+      }
+    }
+  reinterpret_cast<double2 *>(y)[ag] = make_double2(sum0, sum1);
+}
+
 __global__ __launch_bounds__(256) void sr_prolong_kernel(SrArgs s, double const *y, double *out, int subtract)
 {
   const int64_t node = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -87,8 +118,16 @@ __global__ __launch_bounds__(256) void sr_prolong_kernel(SrArgs s, double const 
         const int m = mx[cx] + px * (my[cy] + py * mz[cz]);
         double const *p = s.planes + (size_t)m * s.n_coarse + ag * s.n_eig;
         double const *yy = y + ag * s.n_eig;
-        for (int e = 0; e < s.n_eig; ++e)
-          sum += p[e] * yy[e];
+        if (s.n_eig == 2)
+        {
+          // both eigenvectors of the agglomerate in one 16-byte request (rows 2 ag, 2 ag + 1 are adjacent)
+          const double2 pv = *reinterpret_cast<double2 const *>(p), yv = *reinterpret_cast<double2 const *>(yy);
+          sum += pv.x * yv.x;
+          sum += pv.y * yv.y;
+        }
+        else
+          for (int e = 0; e < s.n_eig; ++e)
+            sum += p[e] * yy[e];
       }
     }
   }
@@ -213,8 +252,12 @@ void StructuredRestrictorDevice::restrict_to_coarse(double const *x, double *y) 
   SrArgs s = make_args(_planes.data(), _identity_numbering ? nullptr : _node_dof.data(), _n_coarse, _N, _na, _a,
                        _n_eig, _patch);
   hipEvent_t stop = _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes(), _handle.stream);
-  hipLaunchKernelGGL(sr_restrict_kernel, dim3((unsigned int)((_n_coarse + 255) / 256)), dim3(256), 0,
-                     _handle.stream, s, x, y);
+  if (_n_eig == 2)
+    hipLaunchKernelGGL(sr_restrict_pair_kernel, dim3((unsigned int)((_n_coarse / 2 + 255) / 256)), dim3(256), 0,
+                       _handle.stream, s, x, y);
+  else
+    hipLaunchKernelGGL(sr_restrict_kernel, dim3((unsigned int)((_n_coarse + 255) / 256)), dim3(256), 0,
+                       _handle.stream, s, x, y);
   KernelProfiler::end(stop, _handle.stream);
   MFMG_HIP_CHECK(hipGetLastError());
 }
