@@ -125,6 +125,12 @@ int mfmg_hip_csr_shape(mfmg_hip_csr_t a, int64_t *n_rows, int64_t *n_cols, int64
  * built at construction); the summation order, hence the last bits of the result, follows both */
 int mfmg_hip_csr_set_kernel(mfmg_hip_csr_t a, int lanes_per_row, int use_lds);
 int mfmg_hip_csr_get_kernel(mfmg_hip_csr_t a, int *lanes_per_row, int *use_lds);
+/* Rows of a symmetric block-diagonal matrix that repeat one stencil bit for bit (interior rows of the coarse operators
+ * of a constant-coefficient problem on a uniform mesh) are evaluated from a table of constants instead of stored
+ * values.  in_use: whether such rows were found and the path is on; enable = 0 switches it off (same results to
+ * rounding). */
+int mfmg_hip_csr_regular_rows(mfmg_hip_csr_t a, int *in_use);
+int mfmg_hip_csr_set_regular_rows(mfmg_hip_csr_t a, int enable);
 /* SparseMatrixDevice::vmult  (…templates.cuh:351-371): y = A x */
 int mfmg_hip_csr_vmult(mfmg_hip_csr_t a, const double *x, double *y);
 /* CudaMatrixOperator::apply (source/cuda/cuda_matrix_operator.cu:80-91); TRANS uses the

@@ -167,6 +167,14 @@ class SparseMatrixDevice:
     def set_kernel(self, lanes_per_row: int = 0, use_lds: int = -1):
         check(self._lib.mfmg_hip_csr_set_kernel(self.handle, lanes_per_row, use_lds))
 
+    def regular_rows(self) -> bool:
+        v = C.c_int()
+        check(self._lib.mfmg_hip_csr_regular_rows(self.handle, C.byref(v)))
+        return bool(v.value)
+
+    def set_regular_rows(self, enable: bool):
+        check(self._lib.mfmg_hip_csr_set_regular_rows(self.handle, int(bool(enable))))
+
     def get_kernel(self):
         a, b = C.c_int(), C.c_int()
         check(self._lib.mfmg_hip_csr_get_kernel(self.handle, C.byref(a), C.byref(b)))

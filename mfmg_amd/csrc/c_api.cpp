@@ -352,6 +352,20 @@ int mfmg_hip_csr_set_kernel(mfmg_hip_csr_t a, int lanes_per_row, int use_lds)
     a->op->get_matrix()->set_kernel(lanes_per_row, use_lds);
   });
 }
+int mfmg_hip_csr_regular_rows(mfmg_hip_csr_t a, int *in_use)
+{
+  return guarded([&] {
+    require(a && in_use, "null argument");
+    *in_use = a->op->get_matrix()->regular_rows() ? 1 : 0;
+  });
+}
+int mfmg_hip_csr_set_regular_rows(mfmg_hip_csr_t a, int enable)
+{
+  return guarded([&] {
+    require(a != nullptr, "null matrix");
+    a->op->get_matrix()->set_regular_rows(enable != 0);
+  });
+}
 int mfmg_hip_csr_get_kernel(mfmg_hip_csr_t a, int *lanes_per_row, int *use_lds)
 {
   return guarded([&] {

@@ -277,8 +277,87 @@ __global__ __launch_bounds__(256) void rowbase_spmv_kernel(CsrArgs<T> a, T const
 // A[(n,c)][(n-o,cc)] of a lower diagonal is read as its transpose A[(n-o,cc)][(n,c)] = val[o][c][(n-o) C + cc],
 // i.e. the same plane a lower-numbered row streams as its upper part -- a second read of data that passed
 // through the caches o rows earlier.  One thread per row, fixed summation order (upper part, then lower part).
+// regular rows (see build_block_diagonals): the stencil comes from a table, only x is read
+template <typename T>
+struct BdiaRegular
+{
+  uint8_t const *exc; // nullptr: no regular rows
+  T const *table;     // [C][Df][C]
+  int32_t const *offs;
+  int Df;
+};
+
+// One thread per NODE whose C rows are all regular: the x values of a neighbour node are fetched once for the C
+// rows (one 16-byte request for C = 2), the stencil constants are wave-uniform (scalar loads).
 template <typename T, int C>
-__global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, T const *val, int32_t const *offs, int D)
+__global__ __launch_bounds__(256) void bdia_regular_node_kernel(CsrArgs<T> a, BdiaRegular<T> g)
+{
+  const int64_t node = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (node * C >= a.n_rows || g.exc[node * C] != 0)
+    return; // (the flag is set for every row of a node as soon as one of them is not regular)
+  T sum[C];
+#pragma unroll
+  for (int rc = 0; rc < C; ++rc)
+    sum[rc] = T(0);
+#pragma unroll 2
+  for (int d = 0; d < g.Df; ++d)
+  {
+    const int64_t nb = node + g.offs[d];
+    T xv[C];
+    if constexpr (C == 2 && sizeof(T) == 8)
+    {
+      const double2 v = reinterpret_cast<double2 const *>(a.x)[nb];
+      xv[0] = v.x;
+      xv[1] = v.y;
+    }
+    else
+    {
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc)
+        xv[cc] = a.x[nb * C + cc];
+    }
+#pragma unroll
+    for (int rc = 0; rc < C; ++rc)
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc)
+        sum[rc] += g.table[((size_t)rc * g.Df + d) * C + cc] * xv[cc];
+  }
+#pragma unroll
+  for (int rc = 0; rc < C; ++rc)
+  {
+    const int64_t row = node * C + rc;
+    T o;
+    switch (a.mode)
+    {
+    case 0:
+      o = sum[rc];
+      break;
+    case 1:
+      o = sum[rc] - a.b[row];
+      break;
+    case 2:
+      o = a.x[row] - a.beta * a.dinv[row] * (sum[rc] - a.b[row]);
+      break;
+    case 3:
+    {
+      const T xr = a.x[row];
+      o = xr + a.alpha * (xr - a.xprev[row]) - a.beta * a.dinv[row] * (sum[rc] - a.b[row]);
+      break;
+    }
+    case 4:
+      o = a.out[row] - sum[rc];
+      break;
+    default:
+      o = a.out[row] + sum[rc];
+      break;
+    }
+    a.out[row] = o;
+  }
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, T const *val, int32_t const *offs, int D,
+                                                            BdiaRegular<T> g)
 {
   const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (r >= a.n_rows)
@@ -289,6 +368,8 @@ __global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, T cons
   const size_t stride = (size_t)a.n_rows;
   T const *vp = val + r;
   T sum = T(0);
+  if (g.exc != nullptr && g.exc[r] == 0)
+    return; // a regular row: bdia_regular_node_kernel has it
 #pragma unroll 4
   for (int d = 0; d < D; ++d) // offs[0] = 0 < offs[1] < ...
   {
@@ -511,6 +592,80 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
     }
   if (!ok)
     return;
+  // Translation invariance: on a uniform mesh with a constant coefficient every interior row of a coarse
+  // operator repeats the same stencil, bit for bit.  Rows equal to a reference row (one per position inside a
+  // node) are flagged regular and evaluated from a table of D C C constants -- no matrix values are read
+  // for them; the others (boundary shells, variable coefficients: all rows) use the stored planes.
+  {
+    std::vector<T> table((size_t)c * D * c, T(0));
+    // reference node: of a few candidates spread over the matrix the one whose stencil a sample of rows repeats most
+    const int64_t n_nodes = n / c;
+    auto row_equals = [&](int64_t node, int rc, int64_t ref) {
+      for (int d = 0; d < D; ++d)
+        for (int cc = 0; cc < c; ++cc)
+          if (dv[((size_t)d * c + cc) * n + node * c + rc] != dv[((size_t)d * c + cc) * n + ref * c + rc])
+            return false;
+      return true;
+    };
+    int64_t ref_node = n_nodes / 2;
+    {
+      int64_t best = -1;
+      const double frac[] = {0.5, 0.377, 0.613, 0.431, 0.569, 0.289, 0.711, 0.457};
+      for (double f : frac)
+      {
+        const int64_t cand = std::min<int64_t>(n_nodes - 1, (int64_t)(f * n_nodes) + 12345 % std::max<int64_t>(n_nodes / 7, 1));
+        int64_t hits = 0;
+        for (int64_t t = 0; t < 2048; ++t)
+          hits += row_equals((t * 2654435761ll) % n_nodes, 0, cand) ? 1 : 0;
+        if (hits > best)
+        {
+          best = hits;
+          ref_node = cand;
+        }
+      }
+    }
+    for (int rc = 0; rc < c; ++rc)
+      for (int d = 0; d < D; ++d)
+        for (int cc = 0; cc < c; ++cc)
+          table[((size_t)rc * D + d) * c + cc] = dv[((size_t)d * c + cc) * n + ref_node * c + rc];
+    std::vector<uint8_t> exc(n, 0);
+    int64_t n_regular = 0;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r)
+    {
+      const int rc = (int)(r % c);
+      const int64_t node = r / c;
+      bool same = true;
+      for (int d = 0; d < D && same; ++d)
+      {
+        const int64_t nb = node + best_offs[d];
+        if (nb < 0 || nb >= n / c)
+          same = false; // a regular row has its whole stencil inside the matrix
+        for (int cc = 0; cc < c && same; ++cc)
+          same = dv[((size_t)d * c + cc) * n + r] == table[((size_t)rc * D + d) * c + cc];
+      }
+      exc[r] = same ? 0 : 1;
+    }
+    // a node is regular only if all its rows are
+#pragma omp parallel for schedule(static) reduction(+ : n_regular)
+    for (int64_t nd = 0; nd < n / c; ++nd)
+    {
+      uint8_t any = 0;
+      for (int rc = 0; rc < c; ++rc)
+        any |= exc[nd * c + rc];
+      for (int rc = 0; rc < c; ++rc)
+        exc[nd * c + rc] = any;
+      n_regular += any ? 0 : c;
+    }
+    if (n_regular * 2 >= n)
+    {
+      _bdia_table.upload(table.data(), table.size(), _handle.stream);
+      _bdia_exc.upload(exc.data(), exc.size(), _handle.stream);
+      _bdia_full_offs.upload(best_offs.data(), best_offs.size(), _handle.stream);
+      _bdia_full_d = D;
+      _bdia_regular = true;
+    }
+  }
   // symmetric (to rounding)?  then the diagonals with a negative offset are the transposes of the positive ones
   bool symmetric = (D % 2 == 1);
   const int zero = D / 2;
@@ -675,19 +830,43 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
     int32_t const *of = _bdia_offs.data();
     if (_bdia_sym)
     {
+      BdiaRegular<T> g;
+      g.exc = (_bdia_regular && _use_regular) ? _bdia_exc.data() : nullptr;
+      g.table = _bdia_table.data();
+      g.offs = _bdia_full_offs.data();
+      g.Df = _bdia_full_d;
+      if (g.exc != nullptr)
+      {
+        const dim3 ngrid((unsigned int)((_n_rows / _bdia_c + 255) / 256));
+        switch (_bdia_c)
+        {
+        case 1:
+          hipLaunchKernelGGL((bdia_regular_node_kernel<T, 1>), ngrid, dim3(256), 0, st, a, g);
+          break;
+        case 2:
+          hipLaunchKernelGGL((bdia_regular_node_kernel<T, 2>), ngrid, dim3(256), 0, st, a, g);
+          break;
+        case 3:
+          hipLaunchKernelGGL((bdia_regular_node_kernel<T, 3>), ngrid, dim3(256), 0, st, a, g);
+          break;
+        default:
+          hipLaunchKernelGGL((bdia_regular_node_kernel<T, 4>), ngrid, dim3(256), 0, st, a, g);
+          break;
+        }
+      }
       switch (_bdia_c)
       {
       case 1:
-        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 1>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 1>), grid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
         break;
       case 2:
-        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 2>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 2>), grid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
         break;
       case 3:
-        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 3>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 3>), grid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
         break;
       default:
-        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 4>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 4>), grid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
         break;
       }
       KernelProfiler::end(stop, st);

@@ -100,6 +100,8 @@ public:
   int kernel_kind() const { return _use_rowbase ? 4 : _use_bdia ? (_bdia_sym ? 3 : 2) : (_use_lds ? 1 : 0); }
   int block_diagonals() const { return _use_bdia ? _bdia_d : 0; }
   bool symmetric_storage() const { return _use_bdia && _bdia_sym; }
+  bool regular_rows() const { return _use_bdia && _bdia_sym && _bdia_regular && _use_regular; }
+  void set_regular_rows(bool on) { _use_regular = on; }
   // algorithmic bytes of one y = A x (12 B/nnz + 4 B/row ptr + x + y)
   double algorithmic_bytes_apply() const
   {
@@ -132,7 +134,13 @@ private:
   DeviceBuffer<T> _rb_val;
   DeviceBuffer<int32_t> _rb_base, _rb_offs;
   bool _use_bdia = false;
-  bool _bdia_sym = false; // symmetric matrix: only the block diagonals with offset >= 0 are stored
+  bool _bdia_sym = false;
+  // regular rows of a translation-invariant operator: stencil table instead of stored values (see the .hip file)
+  bool _bdia_regular = false, _use_regular = true;
+  int _bdia_full_d = 0;
+  DeviceBuffer<T> _bdia_table;
+  DeviceBuffer<uint8_t> _bdia_exc;
+  DeviceBuffer<int32_t> _bdia_full_offs; // symmetric matrix: only the block diagonals with offset >= 0 are stored
   int _bdia_c = 0, _bdia_d = 0;
   DeviceBuffer<T> _bdia_val;
   DeviceBuffer<int32_t> _bdia_offs;

@@ -381,6 +381,47 @@ def test_csr_kernel_variants_on_stencil_matrix(ctx, comps, symmetric):
     assert M.SparseMatrixDevice(ctx, B).get_kernel()[1] != 2
 
 
+@pytest.mark.parametrize("comps", [1, 2])
+def test_csr_regular_rows_of_translation_invariant_operator(ctx, comps):
+    """A symmetric stencil matrix whose interior rows repeat one stencil (what the coarse operators of a
+    constant-coefficient problem look like): interior rows come from the stencil table, boundary rows and a
+    few perturbed rows from the stored planes; every fused mode against scipy, and against the path switched off."""
+    import scipy.sparse as sp
+    dims = (37, 33, 29)
+    rng = np.random.default_rng(23)
+
+    def t1(n, a, b):
+        return sp.diags([np.full(n - 1, b), np.full(n, a), np.full(n - 1, b)], [-1, 0, 1])
+    pattern = sp.kron(t1(dims[2], 2.0, -0.3), sp.kron(t1(dims[1], 1.5, -0.25), t1(dims[0], 1.0, -0.2))).tocsr()
+    blk = np.array([[3.0, 0.4], [0.4, 2.0]])[:comps, :comps]
+    A = sp.kron(pattern, blk).tocsr()
+    A.sort_indices()
+    # a few interior rows differ (made symmetric): they must take the stored-value path
+    A = A.tolil()
+    for r in rng.integers(A.shape[0] // 3, 2 * A.shape[0] // 3, 20):
+        A[r, r] = A[r, r] * 1.5
+    A = A.tocsr()
+    n = A.shape[0]
+    Ad = M.SparseMatrixDevice(ctx, A)
+    assert Ad.get_kernel()[1] == 3 and Ad.regular_rows()
+    x, b, xp = rng.random(n), rng.random(n), rng.random(n)
+    dinv = 1.0 / A.diagonal()
+    ref = A @ x
+    res = {}
+    for on in (True, False):
+        Ad.set_regular_rows(on)
+        assert Ad.regular_rows() == on
+        out = torch.empty(n, dtype=torch.float64, device="cuda")
+        Ad.vmult(out, dev(x))
+        assert relerr(host(out, ctx), ref) < TOL
+        Ad.residual(dev(x), dev(b), out)
+        assert relerr(host(out, ctx), ref - b) < TOL
+        Ad.smoother_step(dev(dinv), dev(b), dev(x), dev(xp), 0.25, 0.6, out)
+        assert relerr(host(out, ctx), x + 0.25 * (x - xp) - 0.6 * dinv * (ref - b)) < TOL
+        res[on] = host(out, ctx).copy()
+    assert relerr(res[True], res[False]) < 1e-13
+
+
 def test_vector_kernels(ctx):
     rng = np.random.default_rng(9)
     for n in (1, 63, 64, 1000, 1 << 20):
