@@ -21,6 +21,11 @@ struct SrArgs
   int64_t n_coarse;
   int N[3], na[3], a[3];
   int n_eig, patch;
+  // agglomerates whose n_eig x patch block repeats a reference block bit for bit (interior agglomerates of a
+  // constant-coefficient problem) are evaluated from `table[m * n_eig + e]`; nullptr: none
+  uint8_t const *exc;
+  uint8_t const *exc_node; // per fine node: 0 = every agglomerate it lies in is regular
+  double const *table;
 };
 
 __global__ __launch_bounds__(256) void sr_restrict_kernel(SrArgs s, double const *x, double *y)
@@ -60,6 +65,7 @@ __global__ __launch_bounds__(256) void sr_restrict_pair_kernel(SrArgs s, double 
   const int64_t base = (int64_t)ai * s.a[0] + (int64_t)s.N[0] * ((int64_t)aj * s.a[1] + (int64_t)s.N[1] * ((int64_t)ak * s.a[2]));
   double2 const *p = reinterpret_cast<double2 const *>(s.planes) + ag;
   const size_t stride = (size_t)s.n_coarse / 2;
+  const bool regular = s.exc != nullptr && s.exc[ag] == 0;
   double sum0 = 0., sum1 = 0.;
   int m = 0;
   for (int mz = 0; mz <= s.a[2]; ++mz)
@@ -71,7 +77,11 @@ __global__ __launch_bounds__(256) void sr_restrict_pair_kernel(SrArgs s, double 
       {
         const int64_t node = row + mx;
         const int64_t id = s.node_dof ? (int64_t)s.node_dof[node] : node;
-        const double2 pv = p[(size_t)m * stride];
+        double2 pv;
+        if (regular)
+          pv = make_double2(s.table[2 * m], s.table[2 * m + 1]); // wave-uniform address
+        else
+          pv = p[(size_t)m * stride];
         const double xv = x[id];
         sum0 += pv.x * xv;
         sum1 += pv.y * xv;
@@ -101,6 +111,7 @@ __global__ __launch_bounds__(256) void sr_prolong_kernel(SrArgs s, double const 
   candidates(j, s.a[1], s.na[1], ay, my);
   candidates(k, s.a[2], s.na[2], az, mz);
   const int px = s.a[0] + 1, py = s.a[1] + 1;
+  const bool table = s.exc_node != nullptr && s.exc_node[node] == 0; // all agglomerates around regular (n_eig = 2)
   double sum = 0.;
   for (int cz = 0; cz < 2; ++cz)
   {
@@ -121,7 +132,9 @@ __global__ __launch_bounds__(256) void sr_prolong_kernel(SrArgs s, double const 
         if (s.n_eig == 2)
         {
           // both eigenvectors of the agglomerate in one 16-byte request (rows 2 ag, 2 ag + 1 are adjacent)
-          const double2 pv = *reinterpret_cast<double2 const *>(p), yv = *reinterpret_cast<double2 const *>(yy);
+          const double2 yv = *reinterpret_cast<double2 const *>(yy);
+          const double2 pv = table ? *reinterpret_cast<double2 const *>(s.table + 2 * m)
+                                   : *reinterpret_cast<double2 const *>(p);
           sum += pv.x * yv.x;
           sum += pv.y * yv.y;
         }
@@ -214,6 +227,70 @@ StructuredRestrictorDevice::create(HipHandle &handle, StructuredMesh const &mesh
   s->_nnz = R.row_ptr[R.n_rows];
   s->_identity_numbering = identity;
   s->_planes.upload(planes.data(), planes.size(), handle.stream);
+  if (n_eig == 2)
+  {
+    // reference agglomerate: of a few candidates the one a sample of agglomerates repeats most
+    auto same = [&](int64_t a1, int64_t a2) {
+      for (int m = 0; m < patch; ++m)
+        for (int e = 0; e < n_eig; ++e)
+          if (planes[(size_t)m * R.n_rows + a1 * n_eig + e] != planes[(size_t)m * R.n_rows + a2 * n_eig + e])
+            return false;
+      return true;
+    };
+    int64_t ref = n_agg / 2, best = -1;
+    const double frac[] = {0.5, 0.377, 0.613, 0.431, 0.569, 0.289, 0.711, 0.457};
+    for (double f : frac)
+    {
+      const int64_t cand = std::min<int64_t>(n_agg - 1, (int64_t)(f * n_agg) + 12345 % std::max<int64_t>(n_agg / 7, 1));
+      int64_t hits = 0;
+      for (int64_t t = 0; t < 2048; ++t)
+        hits += same((t * 2654435761ll) % n_agg, cand) ? 1 : 0;
+      if (hits > best)
+      {
+        best = hits;
+        ref = cand;
+      }
+    }
+    std::vector<uint8_t> exc(n_agg);
+    int64_t n_regular = 0;
+#pragma omp parallel for schedule(static) reduction(+ : n_regular)
+    for (int64_t ag = 0; ag < n_agg; ++ag)
+    {
+      exc[ag] = same(ag, ref) ? 0 : 1;
+      n_regular += exc[ag] ? 0 : 1;
+    }
+    if (n_regular * 2 >= n_agg)
+    {
+      std::vector<double> table((size_t)patch * n_eig);
+      for (int m = 0; m < patch; ++m)
+        for (int e = 0; e < n_eig; ++e)
+          table[(size_t)m * n_eig + e] = planes[(size_t)m * R.n_rows + ref * n_eig + e];
+      // per fine node: is one of the (at most eight) agglomerates it lies in not regular?
+      std::vector<uint8_t> exc_node(n_nodes, 0);
+#pragma omp parallel for schedule(static)
+      for (int64_t nd = 0; nd < n_nodes; ++nd)
+      {
+        const int ijk[3] = {(int)(nd % mesh.N[0]), (int)((nd / mesh.N[0]) % mesh.N[1]),
+                            (int)(nd / ((int64_t)mesh.N[0] * mesh.N[1]))};
+        int lo[3], hi[3];
+        for (int d = 0; d < 3; ++d)
+        {
+          const int q = ijk[d] / agglomerate[d];
+          hi[d] = std::min(q, agg_dims[d] - 1);
+          lo[d] = (ijk[d] % agglomerate[d] == 0 && q >= 1) ? q - 1 : std::min(q, agg_dims[d] - 1);
+        }
+        uint8_t any = 0;
+        for (int c2 = lo[2]; c2 <= hi[2]; ++c2)
+          for (int c1 = lo[1]; c1 <= hi[1]; ++c1)
+            for (int c0 = lo[0]; c0 <= hi[0]; ++c0)
+              any |= exc[c0 + (int64_t)agg_dims[0] * (c1 + (int64_t)agg_dims[1] * c2)];
+        exc_node[nd] = any;
+      }
+      s->_exc.upload(exc.data(), exc.size(), handle.stream);
+      s->_exc_node.upload(exc_node.data(), exc_node.size(), handle.stream);
+      s->_table.upload(table.data(), table.size(), handle.stream);
+    }
+  }
   if (!identity)
     s->_node_dof.upload(mesh.node_dof.data(), mesh.node_dof.size(), handle.stream);
   MFMG_HIP_CHECK(hipStreamSynchronize(handle.stream));
@@ -228,7 +305,7 @@ double StructuredRestrictorDevice::algorithmic_bytes() const
 namespace
 {
 SrArgs make_args(double const *planes, int32_t const *node_dof, int64_t n_coarse, int const N[3], int const na[3],
-                 int const a[3], int n_eig, int patch)
+                 int const a[3], int n_eig, int patch, uint8_t const *exc, uint8_t const *exc_node, double const *table)
 {
   SrArgs s;
   s.planes = planes;
@@ -242,6 +319,9 @@ SrArgs make_args(double const *planes, int32_t const *node_dof, int64_t n_coarse
   }
   s.n_eig = n_eig;
   s.patch = patch;
+  s.exc = exc;
+  s.exc_node = exc_node;
+  s.table = table;
   return s;
 }
 } // namespace
@@ -250,7 +330,7 @@ void StructuredRestrictorDevice::restrict_to_coarse(double const *x, double *y) 
 {
   ASSERT_THROW(x != nullptr && y != nullptr && x != y, "bad vectors");
   SrArgs s = make_args(_planes.data(), _identity_numbering ? nullptr : _node_dof.data(), _n_coarse, _N, _na, _a,
-                       _n_eig, _patch);
+                       _n_eig, _patch, _exc.size() ? _exc.data() : nullptr, _exc_node.size() ? _exc_node.data() : nullptr, _table.data());
   hipEvent_t stop = _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes(), _handle.stream);
   if (_n_eig == 2)
     hipLaunchKernelGGL(sr_restrict_pair_kernel, dim3((unsigned int)((_n_coarse / 2 + 255) / 256)), dim3(256), 0,
@@ -266,7 +346,7 @@ void StructuredRestrictorDevice::prolongate(double const *y, double *out, bool s
 {
   ASSERT_THROW(y != nullptr && out != nullptr && y != out, "bad vectors");
   SrArgs s = make_args(_planes.data(), _identity_numbering ? nullptr : _node_dof.data(), _n_coarse, _N, _na, _a,
-                       _n_eig, _patch);
+                       _n_eig, _patch, _exc.size() ? _exc.data() : nullptr, _exc_node.size() ? _exc_node.data() : nullptr, _table.data());
   hipEvent_t stop = _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes() + (subtract ? 8. * double(_n_fine) : 0.),
                                            _handle.stream);
   hipLaunchKernelGGL(sr_prolong_kernel, dim3((unsigned int)((_n_fine + 255) / 256)), dim3(256), 0, _handle.stream, s,

@@ -42,6 +42,9 @@ private:
   int64_t _n_coarse = 0, _n_fine = 0, _nnz = 0;
   bool _identity_numbering = false;
   DeviceBuffer<double> _planes;   // [patch][n_coarse]
+  DeviceBuffer<uint8_t> _exc;     // per agglomerate: 0 = its block equals the reference block `_table`
+  DeviceBuffer<uint8_t> _exc_node; // per fine node: 0 = all agglomerates around it are regular
+  DeviceBuffer<double> _table;    // [patch][n_eig]
   DeviceBuffer<int32_t> _node_dof; // DoF id of lexicographic node (empty when the numbering is lexicographic)
 };
 } // namespace mfmg
