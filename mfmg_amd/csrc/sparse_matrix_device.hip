@@ -282,6 +282,8 @@ template <typename T>
 struct BdiaRegular
 {
   uint8_t const *exc; // nullptr: no regular rows
+  int32_t const *exc_rows; // the rows that are NOT regular, ascending (what the row kernel works on)
+  int64_t n_exc;
   T const *table;     // [C][Df][C]
   int32_t const *offs;
   int Df;
@@ -359,17 +361,17 @@ template <typename T, int C>
 __global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, T const *val, int32_t const *offs, int D,
                                                             BdiaRegular<T> g)
 {
-  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (r >= a.n_rows)
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  // with regular rows in the matrix (bdia_regular_node_kernel has them) only the listed rows are left
+  if (t >= (g.exc != nullptr ? g.n_exc : a.n_rows))
     return;
+  const int64_t r = g.exc != nullptr ? (int64_t)g.exc_rows[t] : t;
   const int64_t n_nodes = a.n_rows / C;
   const int64_t node = r / C;
   const int c = (int)(r - node * C);
   const size_t stride = (size_t)a.n_rows;
   T const *vp = val + r;
   T sum = T(0);
-  if (g.exc != nullptr && g.exc[r] == 0)
-    return; // a regular row: bdia_regular_node_kernel has it
 #pragma unroll 4
   for (int d = 0; d < D; ++d) // offs[0] = 0 < offs[1] < ...
   {
@@ -660,6 +662,12 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
     if (n_regular * 2 >= n)
     {
       _bdia_table.upload(table.data(), table.size(), _handle.stream);
+      std::vector<int32_t> exc_rows;
+      exc_rows.reserve((size_t)(n - n_regular));
+      for (int64_t r = 0; r < n; ++r)
+        if (exc[r])
+          exc_rows.push_back((int32_t)r);
+      _bdia_exc_rows.upload(exc_rows.data(), exc_rows.size(), _handle.stream);
       _bdia_exc.upload(exc.data(), exc.size(), _handle.stream);
       _bdia_full_offs.upload(best_offs.data(), best_offs.size(), _handle.stream);
       _bdia_full_d = D;
@@ -835,6 +843,8 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
       g.table = _bdia_table.data();
       g.offs = _bdia_full_offs.data();
       g.Df = _bdia_full_d;
+      g.exc_rows = _bdia_exc_rows.data();
+      g.n_exc = (int64_t)_bdia_exc_rows.size();
       if (g.exc != nullptr)
       {
         const dim3 ngrid((unsigned int)((_n_rows / _bdia_c + 255) / 256));
@@ -854,19 +864,21 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
           break;
         }
       }
+      const dim3 rgrid((unsigned int)(((g.exc != nullptr ? g.n_exc : _n_rows) + 255) / 256));
+      if (rgrid.x > 0)
       switch (_bdia_c)
       {
       case 1:
-        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 1>), grid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
+        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 1>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
         break;
       case 2:
-        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 2>), grid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
+        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 2>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
         break;
       case 3:
-        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 3>), grid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
+        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 3>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
         break;
       default:
-        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 4>), grid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
+        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 4>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
         break;
       }
       KernelProfiler::end(stop, st);

@@ -140,7 +140,7 @@ private:
   int _bdia_full_d = 0;
   DeviceBuffer<T> _bdia_table;
   DeviceBuffer<uint8_t> _bdia_exc;
-  DeviceBuffer<int32_t> _bdia_full_offs; // symmetric matrix: only the block diagonals with offset >= 0 are stored
+  DeviceBuffer<int32_t> _bdia_full_offs, _bdia_exc_rows; // symmetric matrix: only the block diagonals with offset >= 0 are stored
   int _bdia_c = 0, _bdia_d = 0;
   DeviceBuffer<T> _bdia_val;
   DeviceBuffer<int32_t> _bdia_offs;
