@@ -48,6 +48,26 @@
 
 namespace mfmg
 {
+template <typename T>
+struct MfArgs
+{
+  unsigned char const *rec;
+  int4 const *fb0;
+  T const *x;
+  T const *b;
+  T const *dinv; // by DoF id (the rows handed over between wavefronts)
+  T const *xprev;
+  T *out;
+  int Nx, Ny, Nz;
+  int TY, TZ;
+  unsigned int ncols, ntiles_y, ntiles_z; // ntiles_z: z-tiles of THIS launch, the first one is tile z_tile0
+  unsigned int ncols_active;              // chunk columns that get workgroups (the last one may go to the tail slab)
+  unsigned int z_tile0;
+  T fx, fy, fz;
+  T alpha, beta;
+  int mode;
+};
+
 namespace
 {
 constexpr unsigned int kFlag = 0x80000000u;  // bit 31: Dirichlet-constrained DoF (read as zero, row = identity)
@@ -68,24 +88,6 @@ struct Rec
   static constexpr size_t kBytes = kDinvOff + 64 * sizeof(T);         // FP64: 4864 general, 1280 cell-constant
 };
 
-template <typename T>
-struct MfArgs
-{
-  unsigned char const *rec;
-  int4 const *fb0;
-  T const *x;
-  T const *b;
-  T const *dinv; // by DoF id (the rows handed over between wavefronts)
-  T const *xprev;
-  T *out;
-  int Nx, Ny, Nz;
-  int TY, TZ;
-  unsigned int ncols, ntiles_y, ntiles_z; // ntiles_z: z-tiles of THIS launch, the first one is tile z_tile0
-  unsigned int z_tile0;
-  T fx, fy, fz;
-  T alpha, beta;
-  int mode;
-};
 
 // Gauss points of QGauss<1>(2) on [0,1]: interpolation weights S[p][i]
 #define MFMG_GA 0.78867513459481288225 // 1 - g0
@@ -314,7 +316,7 @@ __device__ __forceinline__ T mf_epilogue(MfArgs<T> const &a, int id0, T x0, T yv
 // TYC > 0: rows per wavefront known at compile time (the row loop is fully unrolled: no loop-carried register
 // moves, constant LDS offsets); TYC = 0: taken from the arguments.
 template <typename T, int TYC, bool CC>
-__device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a)
+__device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int bid)
 {
 #pragma clang fp contract(off)
   const int TY = TYC > 0 ? TYC : a.TY;
@@ -329,18 +331,18 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a)
 
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8,
   // observed, speed only); give every XCD a contiguous run of the tile list.
-  const unsigned int n_tiles = a.ncols * a.ntiles_y * a.ntiles_z;
-  unsigned int w = blockIdx.x;
+  const unsigned int n_tiles = a.ncols_active * a.ntiles_y * a.ntiles_z;
+  unsigned int w = bid;
   if (n_tiles >= 64)
   {
     const unsigned int per_xcd = (n_tiles + 7) / 8;
-    w = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    w = (bid % 8) * per_xcd + bid / 8;
     if (w >= n_tiles)
       return; // the whole workgroup leaves: no barrier is left waiting
   }
-  const int tc = w % a.ncols;
-  const int tyi = (w / a.ncols) % a.ntiles_y;
-  const int tzi = a.z_tile0 + w / (a.ncols * a.ntiles_y);
+  const int tc = w % a.ncols_active;
+  const int tyi = (w / a.ncols_active) % a.ntiles_y;
+  const int tzi = a.z_tile0 + w / (a.ncols_active * a.ntiles_y);
   const int ci = tc * 63 - 1 + lane;                     // cell / DoF column of this lane
   const int Yb = tyi * (NW * TY - 1) - 1 + wv * TY; // first cell row of this wavefront
   const int Z0 = tzi * a.TZ;
@@ -610,18 +612,24 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a)
   }
 }
 
+// One launch can carry two meshes: the first `n_tail_blocks` workgroups work on `at` (the rotated slab of the
+// tail columns, see the constructor), the others on `am`.  Both share the tile shape (NW, TY, TZ).
+//
 // The cell-constant variant with three rows per wavefront needs 97 VGPRs: asking for five wavefronts per SIMD
 // costs it one spilled register and buys a fifth resident wavefront (measured 513^3: 6.15 -> 5.65 ms per sweep;
 // with four rows three registers spill and it loses).  The general variant (113-121 VGPRs) stays at four.
 template <typename T, int TYC, bool CC>
-__global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> a)
+__global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> am, MfArgs<T> at, unsigned int n_tail_blocks)
 {
-  mf_laplace_body<T, TYC, CC>(a);
+  const bool tail = blockIdx.x < n_tail_blocks;
+  mf_laplace_body<T, TYC, CC>(tail ? at : am, tail ? blockIdx.x : blockIdx.x - n_tail_blocks);
 }
 template <typename T, int TYC>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) void mf_laplace_cc5_kernel(MfArgs<T> a)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) void
+mf_laplace_cc5_kernel(MfArgs<T> am, MfArgs<T> at, unsigned int n_tail_blocks)
 {
-  mf_laplace_body<T, TYC, true>(a);
+  const bool tail = blockIdx.x < n_tail_blocks;
+  mf_laplace_body<T, TYC, true>(tail ? at : am, tail ? blockIdx.x : blockIdx.x - n_tail_blocks);
 }
 
 // ---- setup kernels -----------------------------------------------------------
@@ -661,7 +669,7 @@ __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coeffic
         const int64_t cidx = ic + (int64_t)nx * (jc + (int64_t)ny * kc);
         const int g = cell_dofs[cidx * 8 + (ii - ic) + 2 * (jj - jc) + 4 * (kk - kc)];
         const int c = constrained[g];
-        return g | (c == 1 ? (int)kFlag : (c == 2 ? (int)kGhost : 0));
+        return g | ((c & 1) ? (int)kFlag : 0) | ((c & 2) ? (int)kGhost : 0);
       };
       const bool real = (i < nx) && (j < ny) && (k < nz);
       const int own = node(i, j, k);
@@ -806,8 +814,39 @@ __global__ void mf_fill_dinv_kernel(int4 const *fb0, T const *dinv, int Nx, int 
 }
 } // namespace
 
+namespace
+{
+// Mesh description of the slab of node columns i0 .. Nx-1 seen with x and y exchanged (x' = y, y' = x - i0):
+// cells in the lexicographic order of the rotated frame, corners and quadrature points re-indexed
+// (a <-> b), the DoFs of node column i0 flagged as not-to-be-written (they belong to the main launch).
+__global__ void mf_slab_desc_kernel(int32_t const *cell_dofs, double const *coefficient, uint8_t const *constrained,
+                                    int nx, int ny, int nz, int i0, int32_t *s_cell_dofs, double *s_coefficient,
+                                    uint8_t *s_constrained)
+{
+  const int sc = nx - i0; // cell columns of the slab
+  const int64_t n = (int64_t)ny * sc * nz;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int j = t % ny;
+    const int ip = (t / ny) % sc;
+    const int k = t / ((int64_t)ny * sc);
+    const int64_t src = (i0 + ip) + (int64_t)nx * (j + (int64_t)ny * k);
+    for (int m = 0; m < 8; ++m)
+    {
+      const int ms = ((m >> 1) & 1) | ((m & 1) << 1) | (m & 4); // a' = b, b' = a
+      const int32_t g = cell_dofs[src * 8 + ms];
+      s_cell_dofs[t * 8 + m] = g;
+      s_coefficient[t * 8 + m] = coefficient[src * 8 + ms];
+      if (ip == 0 && (ms & 1) == 0) // corner on node column i0
+        s_constrained[g] = constrained[g] | 2;
+    }
+  }
+}
+} // namespace
+
 template <typename T>
-MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_mesh_desc const &mesh, bool allow_compact)
+MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_mesh_desc const &mesh, bool allow_compact,
+                                                    bool sub_mesh)
     : _handle(handle)
 {
   if (mesh.dim != 3)
@@ -825,7 +864,11 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
     nd *= _N[d];
     nc *= _n[d];
   }
-  ASSERT_THROW(nd == mesh.n_dofs, "n_dofs does not match the cell grid (Q1: (n+1)^dim)");
+  if (sub_mesh) // a sub-box of a larger numbering: the vectors are longer than the node count
+    ASSERT_THROW(nd <= mesh.n_dofs, "sub-mesh larger than the numbering");
+  else
+    ASSERT_THROW(nd == mesh.n_dofs, "n_dofs does not match the cell grid (Q1: (n+1)^dim)");
+  nd = mesh.n_dofs;
   ASSERT_THROW(nd < (int64_t(1) << 30), "DoF ids must fit 30 bits (bits 30/31 carry the ghost / constraint flags)");
   ASSERT_THROW((uint64_t)nd * sizeof(T) <= (uint64_t(1) << 32),
                "vectors are addressed with 32-bit byte offsets: at most 2^32 bytes per vector and rank");
@@ -929,6 +972,41 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   }
   MFMG_HIP_CHECK(hipGetLastError());
   MFMG_HIP_CHECK(hipStreamSynchronize(st));
+
+  // ---- nearly empty last chunk: hand its columns to a rotated slab operator
+  // A row of 2^k + 1 DoFs needs one chunk more than 2^k columns fill (257 = 4 * 63 + 5); the wavefronts of that
+  // chunk issue the full instruction stream for 5 of 63 columns, which costs where the kernel is bound by
+  // instruction issue (the cell-constant variant).  Those columns (plus the last column of the previous chunk as
+  // a halo that is read, not written) form a thin slab whose LONG direction is y: the same kernel runs on it
+  // with x and y exchanged, lanes along y, inside the same launch, and the main part skips the last chunk.
+  const int tail_cols = _N[0] - 63 * (_ncols - 1); // DoF columns owned by the last chunk
+  if (!sub_mesh && _compact && _ncols >= 2 && tail_cols <= 16 && _N[1] >= 64)
+  {
+    const int i0 = 63 * (_ncols - 1) - 1; // halo column of the last chunk = last column of the chunk before
+    const int sc = _n[0] - i0;            // cell columns of the slab
+    const int64_t s_cells = (int64_t)_n[1] * sc * _n[2];
+    DeviceBuffer<int32_t> s_cd((size_t)s_cells * 8);
+    DeviceBuffer<double> s_co((size_t)s_cells * 8);
+    DeviceBuffer<uint8_t> s_cn((size_t)nd);
+    MFMG_HIP_CHECK(hipMemcpyAsync(s_cn.data(), cn, (size_t)nd, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(mf_slab_desc_kernel, dim3(n_blocks_for(s_cells, 256, 1 << 16)), dim3(256), 0, st, cd, co, cn,
+                       _n[0], _n[1], _n[2], i0, s_cd.data(), s_co.data(), s_cn.data());
+    MFMG_HIP_CHECK(hipGetLastError());
+    mfmg_hip_mesh_desc sd = mesh;
+    sd.n_cells[0] = _n[1];
+    sd.n_cells[1] = sc;
+    sd.n_cells[2] = _n[2];
+    sd.cell_size[0] = _h[1];
+    sd.cell_size[1] = _h[0];
+    sd.cell_size[2] = _h[2];
+    sd.cell_dofs = s_cd.data();
+    sd.coefficient = s_co.data();
+    sd.constrained = s_cn.data();
+    sd.arrays_on_device = 1;
+    _tail.reset(new MatrixFreeLaplaceDevice<T>(handle, sd, allow_compact, true));
+    if (!_tail->cell_constant_layout())
+      _tail.reset(); // (cannot happen: a sub-set of cell-constant cells) both parts must run the same kernel
+  }
 }
 
 // ---- tile choice ---------------------------------------------------------------------------------
@@ -973,12 +1051,10 @@ void MatrixFreeLaplaceDevice<T>::choose_tile(int &nw, int &ty, int &tz) const
 }
 
 template <typename T>
-void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out,
-                                     int nw, int ty, int tz, int z_tile_begin, int z_tile_end) const
+bool MatrixFreeLaplaceDevice<T>::make_args(MfArgs<T> &a, unsigned int &n_blocks, MfMode mode, T const *x, T const *b,
+                                           T const *x_prev, T alpha, T beta, T *out, int nw, int ty, int tz,
+                                           int z_tile_begin, int z_tile_end) const
 {
-  ASSERT_THROW(nw >= 1 && nw <= 8, "1..8 wavefronts per workgroup");
-  ASSERT_THROW(ty >= 1 && tz >= 1 && nw * ty >= 2, "operator tile too small");
-  MfArgs<T> a;
   a.rec = _rec.data();
   a.fb0 = _fb0.data();
   a.x = x;
@@ -999,16 +1075,38 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
   a.beta = beta;
   a.mode = static_cast<int>(mode);
   a.ncols = _ncols;
+  a.ncols_active = _tail ? _ncols - 1 : _ncols;
   // ty cell rows per wavefront, nw ty - 1 owned DoF rows per workgroup
   a.ntiles_y = (_N[1] + nw * ty - 2) / (nw * ty - 1);
   const int all_z = (_N[2] + tz - 1) / tz;
   if (z_tile_end < 0)
     z_tile_end = all_z;
   ASSERT_THROW(z_tile_begin >= 0 && z_tile_end <= all_z, "z-tile range outside the tiling");
+  n_blocks = 0;
   if (z_tile_begin >= z_tile_end)
-    return;
+    return false;
   a.z_tile0 = (unsigned int)z_tile_begin;
   a.ntiles_z = (unsigned int)(z_tile_end - z_tile_begin);
+  const uint64_t n_tiles = (uint64_t)a.ncols_active * a.ntiles_y * a.ntiles_z;
+  ASSERT_THROW(n_tiles < (1ull << 30), "operator tile too small for this mesh (grid size limit)");
+  // rounded up to a multiple of 8 for the XCD-contiguous tile order
+  n_blocks = (unsigned int)(n_tiles >= 64 ? ((n_tiles + 7) / 8) * 8 : n_tiles);
+  return true;
+}
+
+template <typename T>
+void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out,
+                                     int nw, int ty, int tz, int z_tile_begin, int z_tile_end) const
+{
+  ASSERT_THROW(nw >= 1 && nw <= 8, "1..8 wavefronts per workgroup");
+  ASSERT_THROW(ty >= 1 && tz >= 1 && nw * ty >= 2, "operator tile too small");
+  MfArgs<T> am, at;
+  unsigned int main_blocks = 0, tail_blocks = 0;
+  if (!make_args(am, main_blocks, mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, z_tile_begin, z_tile_end))
+    return;
+  at = am;
+  if (_tail) // the columns of the last chunk: same tile shape, same layers, first in the grid
+    _tail->make_args(at, tail_blocks, mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, z_tile_begin, z_tile_end);
   const size_t lds = ((size_t)nw * 2 * ty + (size_t)2 * nw * 2) * 64 * sizeof(T) + (size_t)nw * ty * 64 * sizeof(int2);
   ASSERT_THROW(lds <= 160 * 1024, "operator tile too large for the LDS");
   static bool lds_attr_set = false; // (one flag per instantiation of this member)
@@ -1025,29 +1123,26 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
     set_lds(reinterpret_cast<const void *>(mf_laplace_kernel<T, 4, true>));
     lds_attr_set = true;
   }
-  const uint64_t n_tiles = (uint64_t)a.ncols * a.ntiles_y * a.ntiles_z;
-  ASSERT_THROW(n_tiles < (1ull << 31), "operator tile too small for this mesh (grid size limit)");
-  // rounded up to a multiple of 8 for the XCD-contiguous tile order
-  dim3 grid((unsigned int)(n_tiles >= 64 ? ((n_tiles + 7) / 8) * 8 : n_tiles));
+  const dim3 grid(main_blocks + tail_blocks);
   const dim3 block(64 * nw);
   hipStream_t st = _handle.stream;
   if (_compact)
   {
     if (ty == 3)
-      hipLaunchKernelGGL((mf_laplace_cc5_kernel<T, 3>), grid, block, lds, st, a);
+      hipLaunchKernelGGL((mf_laplace_cc5_kernel<T, 3>), grid, block, lds, st, am, at, tail_blocks);
     else if (ty == 4)
-      hipLaunchKernelGGL((mf_laplace_kernel<T, 4, true>), grid, block, lds, st, a);
+      hipLaunchKernelGGL((mf_laplace_kernel<T, 4, true>), grid, block, lds, st, am, at, tail_blocks);
     else
-      hipLaunchKernelGGL((mf_laplace_kernel<T, 0, true>), grid, block, lds, st, a);
+      hipLaunchKernelGGL((mf_laplace_kernel<T, 0, true>), grid, block, lds, st, am, at, tail_blocks);
   }
   else
   {
     if (ty == 3)
-      hipLaunchKernelGGL((mf_laplace_kernel<T, 3, false>), grid, block, lds, st, a);
+      hipLaunchKernelGGL((mf_laplace_kernel<T, 3, false>), grid, block, lds, st, am, at, tail_blocks);
     else if (ty == 4)
-      hipLaunchKernelGGL((mf_laplace_kernel<T, 4, false>), grid, block, lds, st, a);
+      hipLaunchKernelGGL((mf_laplace_kernel<T, 4, false>), grid, block, lds, st, am, at, tail_blocks);
     else
-      hipLaunchKernelGGL((mf_laplace_kernel<T, 0, false>), grid, block, lds, st, a);
+      hipLaunchKernelGGL((mf_laplace_kernel<T, 0, false>), grid, block, lds, st, am, at, tail_blocks);
   }
   MFMG_HIP_CHECK(hipGetLastError());
 }

@@ -11,6 +11,8 @@
 
 #include "common.hpp"
 
+#include <memory>
+
 namespace mfmg
 {
 // Fused epilogues of the operator kernel.
@@ -23,12 +25,17 @@ enum class MfMode : int
 };
 
 template <typename T>
+struct MfArgs; // kernel arguments (mf_laplace.hip)
+
+template <typename T>
 class MatrixFreeLaplaceDevice
 {
 public:
   // allow_compact: keep ONE coefficient per cell when the eight quadrature values of every cell are equal
   // (detected on the device); false forces the general eight-value layout
-  MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_mesh_desc const &mesh, bool allow_compact = true);
+  // sub_mesh (internal, the tail slab): the cells are a sub-box of a larger numbering, n_dofs is the vector length
+  MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_mesh_desc const &mesh, bool allow_compact = true,
+                          bool sub_mesh = false);
   bool cell_constant_layout() const { return _compact; }
 
   int64_t n_dofs() const { return _n_dofs; }
@@ -84,6 +91,8 @@ private:
   void launch(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out) const;
   void run(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out, int nw, int ty, int tz,
            int z_tile_begin = 0, int z_tile_end = -1) const;
+  bool make_args(MfArgs<T> &a, unsigned int &n_blocks, MfMode mode, T const *x, T const *b, T const *x_prev, T alpha,
+                 T beta, T *out, int nw, int ty, int tz, int z_tile_begin, int z_tile_end) const;
   void check_vectors(MfMode mode, T const *x, T const *b, T const *x_prev, T const *out) const;
   void choose_tile(int &nw, int &ty, int &tz) const;
 
@@ -96,6 +105,8 @@ private:
   // halo cell); one record per chunk with the b=1 face ids, the coefficients and D^-1, plus the b=0 face ids
   int _ncols = 0;
   size_t _n_slots = 0;
+  // columns of a nearly empty last chunk, as a slab operator with x and y exchanged (mf_laplace.hip)
+  std::unique_ptr<MatrixFreeLaplaceDevice<T>> _tail;
   DeviceBuffer<int4> _fb0;
   DeviceBuffer<unsigned char> _rec;
   DeviceBuffer<T> _diag, _dinv;

@@ -29,7 +29,10 @@ def relerr(a, b):
 
 # ---- matrix-free operator --------------------------------------------------------------
 CASES = [((4, 4, 4), "constant"), ((7, 5, 6), "linear"), ((16, 16, 16), "discontinuous"),
-         ((64, 9, 11), "linear_x"), ((70, 12, 10), "linear"), ((130, 8, 7), "constant")]
+         ((64, 9, 11), "linear_x"), ((70, 12, 10), "linear"), ((130, 8, 7), "constant"),
+         # rows with a nearly empty last chunk and >= 64 node rows, one coefficient per cell: the tail columns run
+         # as a rotated slab inside the same launch
+         ((65, 70, 5), "constant"), ((64, 64, 2), "constant"), ((141, 63, 3), "constant"), ((128, 65, 4), "constant")]
 
 
 @pytest.mark.parametrize("n,material", CASES)
@@ -200,6 +203,45 @@ def test_mf_cell_constant_layout(ctx, material, expect):
         assert relerr(host(out, ctx), x + 0.3 * (x - xp) - 0.45 * dinv * (ref.vmult(x) - b)) < TOL
         outs.append(host(out, ctx).copy())
     assert relerr(outs[0], outs[1]) < 1e-13
+
+
+@pytest.mark.parametrize("nw,ty,tz", [(0, 0, 0), (1, 2, 1), (4, 3, 8), (2, 5, 2), (4, 4, 3)])
+def test_mf_tail_slab_all_modes_and_renumbering(ctx, nw, ty, tz):
+    """The rotated slab of the tail columns (cell-wise constant coefficient, 67 node columns = 63 + 4): every fused
+    mode, a random DoF numbering, Dirichlet and interior nodes, tile independence."""
+    n = (66, 67, 4)
+    mesh = O.StructuredMesh(n)
+    rng = np.random.default_rng(31)
+    coef = np.repeat(1.0 + rng.random((mesh.n_cells, 1)), 8, axis=1)
+    ref = O.MatrixFreeLaplace(mesh, coef)
+    perm = rng.permutation(mesh.n_dofs)
+    prob = M.LaplaceProblem(n, "constant", device="cuda", dof_numbering=torch.from_numpy(perm))
+    prob.coefficient = torch.from_numpy(coef).cuda()
+    op = M.MatrixFreeLaplace(ctx, prob)
+    assert op.cell_constant_layout()
+    op.set_tile(ty, tz, nw)
+    x, b, xp = rng.random(mesh.n_dofs), rng.random(mesh.n_dofs), rng.random(mesh.n_dofs)
+
+    def to_dof(v):                        # value of node i lives at DoF perm[i]
+        o = np.empty_like(v)
+        o[perm] = v
+        return o
+
+    out = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
+    op.vmult(out, dev(to_dof(x)))
+    assert relerr(host(out, ctx)[perm], ref.vmult(x)) < TOL
+    dinv = ref.diagonal_inverse()
+    np.testing.assert_allclose(host(op.diagonal_inverse(), ctx)[perm], dinv, rtol=1e-13)
+    op.residual(dev(to_dof(x)), dev(to_dof(b)), out)
+    assert relerr(host(out, ctx)[perm], ref.vmult(x) - b) < TOL
+    op.smoother_step(dev(to_dof(b)), dev(to_dof(x)), dev(to_dof(xp)), 0.3, 0.45, out)
+    assert relerr(host(out, ctx)[perm], x + 0.3 * (x - xp) - 0.45 * dinv * (ref.vmult(x) - b)) < TOL
+    op.smoother_step(dev(to_dof(b)), dev(to_dof(x)), None, 0.0, 0.45, out)
+    first = host(out, ctx).copy()
+    assert relerr(first[perm], x - 0.45 * dinv * (ref.vmult(x) - b)) < TOL
+    op.set_tile(3, 2, 2)
+    op.smoother_step(dev(to_dof(b)), dev(to_dof(x)), None, 0.0, 0.45, out)
+    assert np.array_equal(host(out, ctx), first)
 
 
 def test_mf_rejects_bad_input(ctx):
