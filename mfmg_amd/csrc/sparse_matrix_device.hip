@@ -226,23 +226,52 @@ __global__ __launch_bounds__(256) void bdia_spmv_kernel(CsrArgs<T> a, T const *v
 // the same small box of coarse unknowns, placed relative to a per-row base column): val[s n_rows + row] for the
 // slots s of a shared offset list, column = base[row] + offs[s].  4 B of index per ROW instead of per entry,
 // coalesced value planes, one thread per row, fixed summation order.
+// Rows whose S values repeat one of a few value tuples bit for bit (the prolongators of a translation-invariant
+// problem: one tuple per parity class of the fine node and component) carry a class id instead: their values
+// come from table[class][slot], only the class byte, the base and x are read for them.
 template <typename T>
 __global__ __launch_bounds__(256) void rowbase_spmv_kernel(CsrArgs<T> a, T const *val, int32_t const *base,
-                                                           int32_t const *offs, int S, int64_t n_cols)
+                                                           int32_t const *offs, int S, int64_t n_cols,
+                                                           uint8_t const *cls, T const *table, int table_len)
 {
+  // the class table sits in LDS: lanes of different classes read different entries (a gather from global
+  // memory costs one transaction per distinct address)
+  extern __shared__ __align__(16) unsigned char rb_smem[];
+  T *tab = reinterpret_cast<T *>(rb_smem);
+  if (cls != nullptr)
+  {
+    for (int i = threadIdx.x; i < table_len; i += blockDim.x)
+      tab[i] = table[i];
+    __syncthreads();
+  }
   const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (r >= a.n_rows)
     return;
   const int64_t b0 = base[r];
-  T const *vp = val + r;
-  const size_t stride = (size_t)a.n_rows;
+  const int cl = cls != nullptr ? (int)cls[r] : 255;
   T sum = T(0);
-#pragma unroll 4
-  for (int sidx = 0; sidx < S; ++sidx)
+  if (cl != 255)
   {
-    const int64_t c = b0 + offs[sidx];
-    if (c >= 0 && c < n_cols)
-      sum += vp[(size_t)sidx * stride] * a.x[c];
+    T const *tp = tab + (size_t)cl * S;
+#pragma unroll 4
+    for (int sidx = 0; sidx < S; ++sidx)
+    {
+      const int64_t c = b0 + offs[sidx];
+      if (c >= 0 && c < n_cols)
+        sum += tp[sidx] * a.x[c];
+    }
+  }
+  else
+  {
+    T const *vp = val + r;
+    const size_t stride = (size_t)a.n_rows;
+#pragma unroll 4
+    for (int sidx = 0; sidx < S; ++sidx)
+    {
+      const int64_t c = b0 + offs[sidx];
+      if (c >= 0 && c < n_cols)
+        sum += vp[(size_t)sidx * stride] * a.x[c];
+    }
   }
   const int64_t row = r;
   T o;
@@ -791,6 +820,93 @@ void SparseMatrixDevice<T>::build_row_base(std::vector<int32_t> const &row_ptr, 
   }
   if (!ok)
     return;
+  // value tuples that many rows repeat bit for bit -> classes
+  {
+    auto row_hash = [&](int64_t r) {
+      uint64_t h = 1469598103934665603ull;
+      for (int sidx = 0; sidx < S; ++sidx)
+      {
+        uint64_t bits;
+        const double v = (double)dv[(size_t)sidx * n + r];
+        std::memcpy(&bits, &v, sizeof(bits));
+        h = (h ^ bits) * 1099511628211ull;
+      }
+      return h;
+    };
+    auto rows_equal = [&](int64_t r1, int64_t r2) {
+      for (int sidx = 0; sidx < S; ++sidx)
+        if (dv[(size_t)sidx * n + r1] != dv[(size_t)sidx * n + r2])
+          return false;
+      return true;
+    };
+    // candidates from a sample, most frequent first
+    std::vector<std::pair<uint64_t, int64_t>> seen; // (hash, representative row)
+    std::vector<int64_t> count;
+    const int64_t n_sample = std::min<int64_t>(n, 65536);
+    for (int64_t t = 0; t < n_sample; ++t)
+    {
+      const int64_t r = (t * 2654435761ll) % n;
+      const uint64_t h = row_hash(r);
+      size_t k = 0;
+      while (k < seen.size() && seen[k].first != h)
+        ++k;
+      if (k == seen.size())
+      {
+        if (seen.size() >= 512)
+          continue;
+        seen.emplace_back(h, r);
+        count.push_back(0);
+      }
+      ++count[k];
+    }
+    std::vector<size_t> order(seen.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](size_t x1, size_t x2) { return count[x1] > count[x2]; });
+    std::vector<int64_t> reps;
+    for (size_t k = 0; k < order.size() && reps.size() < 64; ++k)
+      if (count[order[k]] * 512 >= n_sample) // at least ~0.2 % of the rows
+        reps.push_back(seen[order[k]].second);
+    if (!reps.empty())
+    {
+      std::vector<uint64_t> rep_hash(reps.size());
+      for (size_t k = 0; k < reps.size(); ++k)
+        rep_hash[k] = row_hash(reps[k]);
+      std::vector<uint8_t> cls(n, 255);
+      int64_t n_regular = 0;
+#pragma omp parallel for schedule(static) reduction(+ : n_regular)
+      for (int64_t r = 0; r < n; ++r)
+      {
+        const uint64_t h = row_hash(r);
+        for (size_t k = 0; k < reps.size(); ++k)
+          if (rep_hash[k] == h && rows_equal(r, reps[k]))
+          {
+            cls[r] = (uint8_t)k;
+            ++n_regular;
+            break;
+          }
+      }
+      // a wavefront with both kinds of rows walks both paths: the table only pays where most wavefronts
+      // (64 consecutive rows) are regular throughout
+      int64_t full_waves = 0;
+#pragma omp parallel for schedule(static) reduction(+ : full_waves)
+      for (int64_t w0 = 0; w0 < n; w0 += 64)
+      {
+        bool all = true;
+        for (int64_t r = w0; r < std::min<int64_t>(n, w0 + 64); ++r)
+          all = all && cls[r] != 255;
+        full_waves += all ? 1 : 0;
+      }
+      if (full_waves * 64 * 10 >= n * 6 && reps.size() * (size_t)S * sizeof(T) <= 32 * 1024)
+      {
+        std::vector<T> table(reps.size() * (size_t)S);
+        for (size_t k = 0; k < reps.size(); ++k)
+          for (int sidx = 0; sidx < S; ++sidx)
+            table[k * S + sidx] = dv[(size_t)sidx * n + reps[k]];
+        _rb_cls.upload(cls.data(), cls.size(), _handle.stream);
+        _rb_table.upload(table.data(), table.size(), _handle.stream);
+      }
+    }
+  }
   _rb_val.upload(dv.data(), dv.size(), _handle.stream);
   _rb_base.upload(base.data(), base.size(), _handle.stream);
   _rb_offs.upload(offs.data(), offs.size(), _handle.stream);
@@ -825,8 +941,11 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
       _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes_apply() + extra * sizeof(T) * double(_n_rows), st);
   if (_use_rowbase)
   {
-    hipLaunchKernelGGL(rowbase_spmv_kernel<T>, dim3((unsigned int)((_n_rows + 255) / 256)), dim3(256), 0, st, a,
-                       _rb_val.data(), _rb_base.data(), _rb_offs.data(), _rb_slots, _n_cols);
+    const bool classes = _rb_cls.size() && _use_regular;
+    hipLaunchKernelGGL(rowbase_spmv_kernel<T>, dim3((unsigned int)((_n_rows + 255) / 256)), dim3(256),
+                       classes ? _rb_table.size() * sizeof(T) : 0, st, a, _rb_val.data(), _rb_base.data(),
+                       _rb_offs.data(), _rb_slots, _n_cols, classes ? _rb_cls.data() : nullptr, _rb_table.data(),
+                       (int)_rb_table.size());
     KernelProfiler::end(stop, st);
     MFMG_HIP_CHECK(hipGetLastError());
     return;

@@ -100,7 +100,10 @@ public:
   int kernel_kind() const { return _use_rowbase ? 4 : _use_bdia ? (_bdia_sym ? 3 : 2) : (_use_lds ? 1 : 0); }
   int block_diagonals() const { return _use_bdia ? _bdia_d : 0; }
   bool symmetric_storage() const { return _use_bdia && _bdia_sym; }
-  bool regular_rows() const { return _use_bdia && _bdia_sym && _bdia_regular && _use_regular; }
+  bool regular_rows() const
+  {
+    return _use_regular && ((_use_bdia && _bdia_sym && _bdia_regular) || (_use_rowbase && _rb_cls.size() > 0));
+  }
   void set_regular_rows(bool on) { _use_regular = on; }
   // algorithmic bytes of one y = A x (12 B/nnz + 4 B/row ptr + x + y)
   double algorithmic_bytes_apply() const
@@ -133,6 +136,8 @@ private:
   int _rb_slots = 0;
   DeviceBuffer<T> _rb_val;
   DeviceBuffer<int32_t> _rb_base, _rb_offs;
+  DeviceBuffer<uint8_t> _rb_cls; // class of a row whose values repeat a table entry, 255 = stored values
+  DeviceBuffer<T> _rb_table;     // [n_classes][slots]
   bool _use_bdia = false;
   bool _bdia_sym = false;
   // regular rows of a translation-invariant operator: stencil table instead of stored values (see the .hip file)

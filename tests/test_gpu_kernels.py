@@ -464,6 +464,34 @@ def test_csr_regular_rows_of_translation_invariant_operator(ctx, comps):
     assert relerr(res[True], res[False]) < 1e-13
 
 
+def test_csr_row_classes_of_translation_invariant_prolongator(ctx):
+    """A rectangular stencil matrix whose rows repeat a few value tuples (what the smoothed prolongators of a
+    constant-coefficient problem look like): class table for those rows, stored values for the others."""
+    import scipy.sparse as sp
+    dims = (37, 33, 29)
+    rng = np.random.default_rng(29)
+
+    def t1(n, a, b):
+        return sp.diags([np.full(n - 1, b), np.full(n, a), np.full(n - 1, b)], [-1, 0, 1])
+    pattern = sp.kron(t1(dims[2], 2.0, -0.3), sp.kron(t1(dims[1], 1.5, -0.25), t1(dims[0], 1.0, -0.2))).tocsr()
+    P = sp.vstack([sp.hstack([pattern, 0.5 * pattern])] * 6).tolil()      # 212 k rows x 71 k columns
+    for r in rng.integers(0, P.shape[0], 30):                             # a few rows of their own
+        P[r, P.rows[r][0]] = 7.5
+    P = P.tocsr()
+    Pd = M.SparseMatrixDevice(ctx, P)
+    assert Pd.get_kernel()[1] == 4 and Pd.regular_rows()
+    x = rng.random(P.shape[1])
+    y0 = rng.random(P.shape[0])
+    res = {}
+    for on in (True, False):
+        Pd.set_regular_rows(on)
+        out = torch.empty(P.shape[0], dtype=torch.float64, device="cuda")
+        Pd.vmult(out, dev(x))
+        assert relerr(host(out, ctx), P @ x) < TOL
+        res[on] = host(out, ctx).copy()
+    assert relerr(res[True], res[False]) < 1e-13
+
+
 def test_vector_kernels(ctx):
     rng = np.random.default_rng(9)
     for n in (1, 63, 64, 1000, 1 << 20):
