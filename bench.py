@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument("--no-smoother-512", action="store_true",
                     help="skip the extra fine-level smoother measurement at 512^3 (north_star target config)")
     ap.add_argument("--amg-block", type=int, default=2, help="nodes per direction of one aggregate of the coarse AMG")
+    ap.add_argument("--amg-deep", type=str, default="", help="level,block: bigger geometric aggregates from that AMG level on")
     ap.add_argument("--amg-degree", type=int, default=1, help="Chebyshev degree of the coarse AMG smoothers")
     ap.add_argument("--evaluator", default="matrix_free", choices=["matrix_free", "assembled"],
                     help="fine-level operator: matrix-free (BASELINE configs[1]/[3]) or assembled CSR (configs[2])")
@@ -284,7 +285,9 @@ def main():
         "smoother": {"type": "Chebyshev", "degree": args.degree, "smoothing_range": 20.0, "n_smoothing_steps": 1},
         "solver": ({"type": "pcg", "n_iterations": args.coarse_iters} if args.coarse == "pcg" else
                    {"type": "amg", "amg": {"smoother_degree": args.amg_degree, "smoothing_range": 4.0, "n_cycles": 1,
-                                           "aggregate_block": args.amg_block}}),
+                                           "aggregate_block": args.amg_block,
+                                           **({"deep_level": int(args.amg_deep.split(",")[0]),
+                                               "deep_block": int(args.amg_deep.split(",")[1])} if args.amg_deep else {})}}),
         "is preconditioner": False,
         "max levels": 2,
     }

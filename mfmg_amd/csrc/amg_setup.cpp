@@ -209,7 +209,7 @@ std::vector<AmgLevelHost> build_aggregation_hierarchy(HostCsr A0, std::vector<do
       for (int d = 0; d < 3; ++d)
       {
         next.dims[d] = cdims[d];
-        next.block[d] = grid.block[d];
+        next.block[d] = ((int)levels.size() >= opts.deep_level) ? opts.deep_block : grid.block[d];
       }
       const int ncomp = std::max(grid.n_components, 1);
       next.n_components = ncomp;

@@ -19,6 +19,10 @@ struct AmgOptions
   double strength = 0.08;       // |a_ij| > strength * sqrt(a_ii a_jj) is a strong connection
   bool smooth_prolongator = true;
   double omega = 4. / 3.;
+  // geometric aggregates: from level `deep_level` on (0 = the operator handed in) blocks of `deep_block` nodes per
+  // direction instead of the hint's block (the small levels are bound by launch latency, not by their size)
+  int deep_level = 1 << 30;
+  int deep_block = 2;
 };
 
 // Optional geometric information: row i of the operator lives on node `node_of_row[i]` of a structured

@@ -765,6 +765,8 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
     opts.coarsest_size = this->_params->get("solver.amg.coarsest_size", 1100);
     opts.strength = this->_params->get("solver.amg.strength", 0.08);
     opts.smooth_prolongator = this->_params->get("solver.amg.smooth_prolongator", true);
+    opts.deep_level = this->_params->get("solver.amg.deep_level", 1 << 30);
+    opts.deep_block = this->_params->get("solver.amg.deep_block", 2);
     _amg_cycles = this->_params->get("solver.amg.n_cycles", 1);
     ASSERT_THROW(opts.coarsest_size <= 16384, "solver.amg.coarsest_size is limited by the dense LU (16384)");
     HostCsr A0;
