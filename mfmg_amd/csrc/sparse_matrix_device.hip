@@ -172,11 +172,14 @@ __global__ void csr_inv_diag_kernel(T const *val, int32_t const *col, int32_t co
 // matrix stream carries no column indices at all (8 B per stored entry instead of 10-12); x is read
 // through L1/L2 (consecutive rows read consecutive entries).  One thread per row, fixed summation order.
 template <typename T, int C>
-__global__ __launch_bounds__(256) void bdia_spmv_kernel(CsrArgs<T> a, T const *val, int32_t const *offs, int D)
+__global__ __launch_bounds__(256) void bdia_spmv_kernel(CsrArgs<T> a, T const *val, int32_t const *offs, int D,
+                                                        int32_t const *rows, int64_t n_listed)
 {
-  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (r >= a.n_rows)
+  // rows != nullptr: only the listed rows (the others are regular, bdia_regular_node_kernel has them)
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= (rows != nullptr ? n_listed : a.n_rows))
     return;
+  const int64_t r = rows != nullptr ? (int64_t)rows[t] : t;
   const int64_t n_nodes = a.n_rows / C;
   const int64_t node = r / C;
   T const *vp = val + r;
@@ -952,18 +955,16 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
   }
   if (_use_bdia)
   {
-    const dim3 grid((unsigned int)((_n_rows + 255) / 256));
     T const *dv = _bdia_val.data();
     int32_t const *of = _bdia_offs.data();
-    if (_bdia_sym)
+    BdiaRegular<T> g;
+    g.exc = (_bdia_regular && _use_regular) ? _bdia_exc.data() : nullptr;
+    g.table = _bdia_table.data();
+    g.offs = _bdia_full_offs.data();
+    g.Df = _bdia_full_d;
+    g.exc_rows = _bdia_exc_rows.data();
+    g.n_exc = (int64_t)_bdia_exc_rows.size();
     {
-      BdiaRegular<T> g;
-      g.exc = (_bdia_regular && _use_regular) ? _bdia_exc.data() : nullptr;
-      g.table = _bdia_table.data();
-      g.offs = _bdia_full_offs.data();
-      g.Df = _bdia_full_d;
-      g.exc_rows = _bdia_exc_rows.data();
-      g.n_exc = (int64_t)_bdia_exc_rows.size();
       if (g.exc != nullptr)
       {
         const dim3 ngrid((unsigned int)((_n_rows / _bdia_c + 255) / 256));
@@ -983,7 +984,10 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
           break;
         }
       }
-      const dim3 rgrid((unsigned int)(((g.exc != nullptr ? g.n_exc : _n_rows) + 255) / 256));
+    }
+    const dim3 rgrid((unsigned int)(((g.exc != nullptr ? g.n_exc : _n_rows) + 255) / 256));
+    if (_bdia_sym)
+    {
       if (rgrid.x > 0)
       switch (_bdia_c)
       {
@@ -1004,19 +1008,21 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
       MFMG_HIP_CHECK(hipGetLastError());
       return;
     }
+    int32_t const *rows = g.exc != nullptr ? g.exc_rows : nullptr;
+    if (rgrid.x > 0)
     switch (_bdia_c)
     {
     case 1:
-      hipLaunchKernelGGL((bdia_spmv_kernel<T, 1>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+      hipLaunchKernelGGL((bdia_spmv_kernel<T, 1>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, rows, g.n_exc);
       break;
     case 2:
-      hipLaunchKernelGGL((bdia_spmv_kernel<T, 2>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+      hipLaunchKernelGGL((bdia_spmv_kernel<T, 2>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, rows, g.n_exc);
       break;
     case 3:
-      hipLaunchKernelGGL((bdia_spmv_kernel<T, 3>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+      hipLaunchKernelGGL((bdia_spmv_kernel<T, 3>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, rows, g.n_exc);
       break;
     default:
-      hipLaunchKernelGGL((bdia_spmv_kernel<T, 4>), grid, dim3(256), 0, st, a, dv, of, _bdia_d);
+      hipLaunchKernelGGL((bdia_spmv_kernel<T, 4>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, rows, g.n_exc);
       break;
     }
     KernelProfiler::end(stop, st);

@@ -102,7 +102,7 @@ public:
   bool symmetric_storage() const { return _use_bdia && _bdia_sym; }
   bool regular_rows() const
   {
-    return _use_regular && ((_use_bdia && _bdia_sym && _bdia_regular) || (_use_rowbase && _rb_cls.size() > 0));
+    return _use_regular && ((_use_bdia && _bdia_regular) || (_use_rowbase && _rb_cls.size() > 0));
   }
   void set_regular_rows(bool on) { _use_regular = on; }
   // algorithmic bytes of one y = A x (12 B/nnz + 4 B/row ptr + x + y)
