@@ -116,9 +116,12 @@ def mode_cpu(args):
 def mode_gpu(args):
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
-    cells = (16, 12, 8 * world)
-    material = "linear"
-    part = M.SlabPartition(cells, rank, world, length=tuple(c / 16.0 for c in cells))   # cubic cells
+    # "wide": 67 node columns = 63 + 4 and 65 node rows with a constant material: the operator runs its
+    # one-coefficient-per-cell variant with the tail columns as a rotated slab, here split into z-tile ranges
+    wide = getattr(args, "mesh", "small") == "wide"
+    cells = (66, 64, 8 * world) if wide else (16, 12, 8 * world)
+    material = "constant" if wide else "linear"
+    part = M.SlabPartition(cells, rank, world, length=tuple(c / float(cells[0]) for c in cells))   # cubic cells
     params = dict(PRM)
     params.update({"smoother": {"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0},
                    "solver": {"type": "amg", "amg": {"coarsest_size": 300}}, "is preconditioner": False})
@@ -207,6 +210,7 @@ def mode_gpu(args):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="cpu")
+    ap.add_argument("--mesh", default="small")
     a = ap.parse_args()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")

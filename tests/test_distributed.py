@@ -20,10 +20,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(mode, world, timeout=600):
+def _run(mode, world, timeout=600, mesh="small"):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode]
+           os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--mesh", mesh]
     env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
@@ -56,6 +56,6 @@ def test_distributed_construction_cpu_gloo(mfmg_lib, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_distributed_library_path_shared_gpu(mfmg_lib, world):
-    assert "gpu distributed checks passed" in _run("gpu", world)
+@pytest.mark.parametrize("world,mesh", [(2, "small"), (3, "small"), (2, "wide")])
+def test_distributed_library_path_shared_gpu(mfmg_lib, world, mesh):
+    assert "gpu distributed checks passed" in _run("gpu", world, mesh=mesh)
