@@ -90,12 +90,11 @@ __global__ __launch_bounds__(256) void sr_restrict_pair_kernel(SrArgs s, double 
   reinterpret_cast<double2 *>(y)[ag] = make_double2(sum0, sum1);
 }
 
-__global__ __launch_bounds__(256) void sr_prolong_kernel(SrArgs s, double const *y, double *out, int subtract)
+// (R^T y) at fine node `node`: a node lies in at most two agglomerates per direction, the one it starts
+// (position m = i mod a) and, on an agglomerate boundary, the previous one (position m = a); fixed order
+// (z, y, x candidates, then eigenvectors)
+__device__ __forceinline__ double sr_node_value(SrArgs const &s, double const *y, int64_t node)
 {
-  const int64_t node = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int64_t n_nodes = (int64_t)s.N[0] * s.N[1] * s.N[2];
-  if (node >= n_nodes)
-    return;
   const int i = node % s.N[0], j = (node / s.N[0]) % s.N[1], k = node / ((int64_t)s.N[0] * s.N[1]);
   // candidate agglomerates per direction: c = 0 the one the node starts, c = 1 the previous one
   int ax[2], mx[2], ay[2], my[2], az[2], mz[2];
@@ -144,6 +143,88 @@ __global__ __launch_bounds__(256) void sr_prolong_kernel(SrArgs s, double const 
       }
     }
   }
+  return sum;
+}
+
+// one thread per fine node (any agglomerate size, any numbering)
+__global__ __launch_bounds__(256) void sr_prolong_kernel(SrArgs s, double const *y, double *out, int subtract)
+{
+  const int64_t node = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t n_nodes = (int64_t)s.N[0] * s.N[1] * s.N[2];
+  if (node >= n_nodes)
+    return;
+  const double sum = sr_node_value(s, y, node);
+  const int64_t id = s.node_dof ? (int64_t)s.node_dof[node] : node;
+  out[id] = subtract ? out[id] - sum : sum;
+}
+
+// 2 x 2 x 2 agglomerates, two eigenvectors, lexicographic numbering, table-driven blocks: one thread per
+// agglomerate position (na + 1 per direction) finishes the 2 x 2 x 2 nodes at the low corner of its agglomerate.
+// The y pairs of the (at most) eight agglomerates around are fetched once for the eight nodes, the table
+// entries are wave-uniform; every sum is formed in the order of sr_node_value (same bits).
+__global__ __launch_bounds__(256) void sr_prolong_block222_kernel(SrArgs s, double const *y, double *out, int subtract,
+                                                                  uint8_t const *blk_exc)
+{
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int vx = s.na[0] + 1, vy = s.na[1] + 1, vz = s.na[2] + 1;
+  if (t >= (int64_t)vx * vy * vz || blk_exc[t] != 0)
+    return;
+  const int vi = t % vx, vj = (t / vx) % vy, vk = t / ((int64_t)vx * vy);
+  double2 yv[8];
+  bool has[8];
+#pragma unroll
+  for (int sidx = 0; sidx < 8; ++sidx)
+  {
+    const int qi = vi - (sidx & 1), qj = vj - ((sidx >> 1) & 1), qk = vk - (sidx >> 2);
+    has[sidx] = qi >= 0 && qi < s.na[0] && qj >= 0 && qj < s.na[1] && qk >= 0 && qk < s.na[2];
+    yv[sidx] = has[sidx] ? reinterpret_cast<double2 const *>(y)[qi + (int64_t)s.na[0] * (qj + (int64_t)s.na[1] * qk)]
+                         : make_double2(0., 0.);
+  }
+#pragma unroll
+  for (int d = 0; d < 8; ++d)
+  {
+    const int dx = d & 1, dy = (d >> 1) & 1, dz = d >> 2;
+    const int i = 2 * vi + dx, j = 2 * vj + dy, k = 2 * vk + dz;
+    if (i >= s.N[0] || j >= s.N[1] || k >= s.N[2])
+      continue;
+    double sum = 0.;
+#pragma unroll
+    for (int sz = 0; sz < 2; ++sz)
+#pragma unroll
+      for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+        {
+          if ((sx && dx) || (sy && dy) || (sz && dz))
+            continue; // the previous agglomerate holds the node only on the shared boundary
+          const int sidx = sx + 2 * sy + 4 * sz;
+          if (!has[sidx])
+            continue;
+          const int m = (sx ? 2 : dx) + 3 * ((sy ? 2 : dy) + 3 * (sz ? 2 : dz));
+          sum += s.table[2 * m] * yv[sidx].x;
+          sum += s.table[2 * m + 1] * yv[sidx].y;
+        }
+    const int64_t node = i + (int64_t)s.N[0] * (j + (int64_t)s.N[1] * k);
+    out[node] = subtract ? out[node] - sum : sum;
+  }
+}
+
+// the nodes of the listed agglomerate positions (the blocks the kernel above leaves out), one thread per node
+__global__ __launch_bounds__(256) void sr_prolong_listed_kernel(SrArgs s, double const *y, double *out, int subtract,
+                                                                int32_t const *blocks, int64_t n_blocks)
+{
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= 8 * n_blocks)
+    return;
+  const int64_t v = blocks[t >> 3];
+  const int d = (int)(t & 7);
+  const int vx = s.na[0] + 1, vy = s.na[1] + 1;
+  const int i = 2 * (int)(v % vx) + (d & 1), j = 2 * (int)((v / vx) % vy) + ((d >> 1) & 1),
+            k = 2 * (int)(v / ((int64_t)vx * vy)) + (d >> 2);
+  if (i >= s.N[0] || j >= s.N[1] || k >= s.N[2])
+    return;
+  const int64_t node = i + (int64_t)s.N[0] * (j + (int64_t)s.N[1] * k);
+  const double sum = sr_node_value(s, y, node);
   const int64_t id = s.node_dof ? (int64_t)s.node_dof[node] : node;
   out[id] = subtract ? out[id] - sum : sum;
 }
@@ -286,6 +367,31 @@ StructuredRestrictorDevice::create(HipHandle &handle, StructuredMesh const &mesh
               any |= exc[c0 + (int64_t)agg_dims[0] * (c1 + (int64_t)agg_dims[1] * c2)];
         exc_node[nd] = any;
       }
+      if (identity && agglomerate[0] == 2 && agglomerate[1] == 2 && agglomerate[2] == 2)
+      {
+        // agglomerate positions all of whose (existing) agglomerates around are regular -> block kernel
+        const int64_t vx = agg_dims[0] + 1, vy = agg_dims[1] + 1, vz = agg_dims[2] + 1;
+        std::vector<uint8_t> blk_exc((size_t)(vx * vy * vz), 0);
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < vx * vy * vz; ++t)
+        {
+          const int vi = (int)(t % vx), vj = (int)((t / vx) % vy), vk = (int)(t / (vx * vy));
+          uint8_t any = 0;
+          for (int sidx = 0; sidx < 8; ++sidx)
+          {
+            const int qi = vi - (sidx & 1), qj = vj - ((sidx >> 1) & 1), qk = vk - (sidx >> 2);
+            if (qi >= 0 && qi < agg_dims[0] && qj >= 0 && qj < agg_dims[1] && qk >= 0 && qk < agg_dims[2])
+              any |= exc[qi + (int64_t)agg_dims[0] * (qj + (int64_t)agg_dims[1] * qk)];
+          }
+          blk_exc[t] = any;
+        }
+        std::vector<int32_t> exc_blocks;
+        for (int64_t t = 0; t < vx * vy * vz; ++t)
+          if (blk_exc[t])
+            exc_blocks.push_back((int32_t)t);
+        s->_blk_exc.upload(blk_exc.data(), blk_exc.size(), handle.stream);
+        s->_exc_blocks.upload(exc_blocks.data(), exc_blocks.size(), handle.stream);
+      }
       s->_exc.upload(exc.data(), exc.size(), handle.stream);
       s->_exc_node.upload(exc_node.data(), exc_node.size(), handle.stream);
       s->_table.upload(table.data(), table.size(), handle.stream);
@@ -349,8 +455,18 @@ void StructuredRestrictorDevice::prolongate(double const *y, double *out, bool s
                        _n_eig, _patch, _exc.size() ? _exc.data() : nullptr, _exc_node.size() ? _exc_node.data() : nullptr, _table.data());
   hipEvent_t stop = _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes() + (subtract ? 8. * double(_n_fine) : 0.),
                                            _handle.stream);
-  hipLaunchKernelGGL(sr_prolong_kernel, dim3((unsigned int)((_n_fine + 255) / 256)), dim3(256), 0, _handle.stream, s,
-                     y, out, subtract ? 1 : 0);
+  if (_blk_exc.size() > 0)
+  {
+    const int64_t n_pos = (int64_t)_blk_exc.size(), n_listed = (int64_t)_exc_blocks.size();
+    hipLaunchKernelGGL(sr_prolong_block222_kernel, dim3((unsigned int)((n_pos + 255) / 256)), dim3(256), 0,
+                       _handle.stream, s, y, out, subtract ? 1 : 0, _blk_exc.data());
+    if (n_listed > 0)
+      hipLaunchKernelGGL(sr_prolong_listed_kernel, dim3((unsigned int)((8 * n_listed + 255) / 256)), dim3(256), 0,
+                         _handle.stream, s, y, out, subtract ? 1 : 0, _exc_blocks.data(), n_listed);
+  }
+  else
+    hipLaunchKernelGGL(sr_prolong_kernel, dim3((unsigned int)((_n_fine + 255) / 256)), dim3(256), 0, _handle.stream,
+                       s, y, out, subtract ? 1 : 0);
   KernelProfiler::end(stop, _handle.stream);
   MFMG_HIP_CHECK(hipGetLastError());
 }

@@ -44,6 +44,8 @@ private:
   DeviceBuffer<double> _planes;   // [patch][n_coarse]
   DeviceBuffer<uint8_t> _exc;     // per agglomerate: 0 = its block equals the reference block `_table`
   DeviceBuffer<uint8_t> _exc_node; // per fine node: 0 = all agglomerates around it are regular
+  DeviceBuffer<uint8_t> _blk_exc;  // per agglomerate position (na + 1 per direction): 0 = table-driven block kernel
+  DeviceBuffer<int32_t> _exc_blocks; // the other positions
   DeviceBuffer<double> _table;    // [patch][n_eig]
   DeviceBuffer<int32_t> _node_dof; // DoF id of lexicographic node (empty when the numbering is lexicographic)
 };
