@@ -112,14 +112,15 @@ def test_mf_fused_epilogues(ctx):
         op.vmult(xd, xd)
 
 
-def test_mf_fp32_instance(ctx):
-    """BASELINE.json configs[4] (FP32): same kernels instantiated for float; tolerance 1e-4 relative
-     against the FP64 oracle."""
-    n = (20, 12, 9)
+@pytest.mark.parametrize("n,material", [((20, 12, 9), "linear"), ((20, 12, 9), "constant"), ((66, 67, 4), "constant")])
+def test_mf_fp32_instance(ctx, n, material):
+    """BASELINE.json configs[4] (FP32): same kernels instantiated for float (eight coefficients per cell, one per
+    cell, one per cell with the tail columns as a slab); tolerance 1e-4 relative against the FP64 oracle."""
     mesh = O.StructuredMesh(n)
-    coef = O.coefficient_table(mesh, "linear")
+    coef = O.coefficient_table(mesh, material)
     ref = O.MatrixFreeLaplace(mesh, coef)
-    op = M.MatrixFreeLaplaceF32(ctx, M.LaplaceProblem(n, "linear", device="cuda"))
+    op = M.MatrixFreeLaplaceF32(ctx, M.LaplaceProblem(n, material, device="cuda"))
+    assert op.cell_constant_layout() == (material == "constant")
     rng = np.random.default_rng(8)
     x, b, xp = rng.random(mesh.n_dofs), rng.random(mesh.n_dofs), rng.random(mesh.n_dofs)
     f = lambda a: torch.from_numpy(a.astype(np.float32)).cuda()
