@@ -47,6 +47,8 @@ def parse_args():
                     help="fine-level operator: matrix-free (BASELINE configs[1]/[3]) or assembled CSR (configs[2])")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra single-GPU lines (configs[1] 128^3 V-cycle, configs[4] FP32 smoother apply)")
+    ap.add_argument("--box", type=str, default="", help="gx,gy,gz: global cells of a distributed run instead of the "
+                    "weak-scaling box (rehearsals of the slab shapes of larger runs on fewer ranks)")
     ap.add_argument("--tile", type=str, default="", help="ty,tz[,waves] override of the operator tile (default: timed choice)")
     return ap.parse_args()
 
@@ -270,6 +272,8 @@ def main():
             gy *= 2
         else:
             gx *= 2
+    if args.box:
+        gx, gy, gz = (int(v) for v in args.box.split(","))
     part = transport = None
     if world > 1:
         if world & (world - 1):

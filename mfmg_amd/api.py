@@ -172,6 +172,12 @@ class SparseMatrixDevice:
         check(self._lib.mfmg_hip_csr_regular_rows(self.handle, C.byref(v)))
         return bool(v.value)
 
+    def stencil_classes(self):
+        """(classes of non-regular nodes sharing a stencil, rows left to the stored values)."""
+        k, r = C.c_int(), C.c_int64()
+        check(self._lib.mfmg_hip_csr_stencil_classes(self.handle, C.byref(k), C.byref(r)))
+        return k.value, r.value
+
     def set_regular_rows(self, enable: bool):
         check(self._lib.mfmg_hip_csr_set_regular_rows(self.handle, int(bool(enable))))
 

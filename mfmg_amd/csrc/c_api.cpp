@@ -359,6 +359,14 @@ int mfmg_hip_csr_regular_rows(mfmg_hip_csr_t a, int *in_use)
     *in_use = a->op->get_matrix()->regular_rows() ? 1 : 0;
   });
 }
+int mfmg_hip_csr_stencil_classes(mfmg_hip_csr_t a, int *n_classes, int64_t *listed_rows)
+{
+  return guarded([&] {
+    require(a && n_classes && listed_rows, "null argument");
+    *n_classes = a->op->get_matrix()->stencil_classes();
+    *listed_rows = a->op->get_matrix()->listed_rows();
+  });
+}
 int mfmg_hip_csr_set_regular_rows(mfmg_hip_csr_t a, int enable)
 {
   return guarded([&] {

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <type_traits>
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256) void bdia_regular_node_kernel(CsrArgs<T> a, Bd
 #pragma unroll
   for (int rc = 0; rc < C; ++rc)
     sum[rc] = T(0);
-#pragma unroll 2
+#pragma unroll 8
   for (int d = 0; d < g.Df; ++d)
   {
     const int64_t nb = node + g.offs[d];
@@ -387,6 +388,218 @@ __global__ __launch_bounds__(256) void bdia_regular_node_kernel(CsrArgs<T> a, Bd
     }
     a.out[row] = o;
   }
+}
+
+// Non-regular nodes that repeat one stencil among themselves (the nodes at the same distance from the faces of a
+// box: boundary shells of a translation-invariant problem) are sorted by class, every class padded to whole
+// wavefronts (node -1): the class of a wavefront is uniform, its stencil constants are scalar loads like the
+// regular ones, and only the node list and x are read.  Neighbours outside the matrix carry the constant 0 and
+// are read at a clamped position.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void bdia_class_node_kernel(CsrArgs<T> a, BdiaRegular<T> g, int32_t const *nodes,
+                                                              int32_t const *class_of_wave, T const *class_table,
+                                                              int64_t n_slots)
+{
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= n_slots)
+    return;
+  const int cls = __builtin_amdgcn_readfirstlane(class_of_wave[t >> 6]);
+  const int64_t node = nodes[t];
+  if (node < 0)
+    return;
+  const int64_t last = a.n_rows / C - 1;
+  T const *tab = class_table + (size_t)cls * (size_t)(C * g.Df * C);
+  T sum[C];
+#pragma unroll
+  for (int rc = 0; rc < C; ++rc)
+    sum[rc] = T(0);
+#pragma unroll 8
+  for (int d = 0; d < g.Df; ++d)
+  {
+    int64_t nb = node + g.offs[d];
+    nb = nb < 0 ? 0 : (nb > last ? last : nb);
+    T xv[C];
+    if constexpr (C == 2 && sizeof(T) == 8)
+    {
+      const double2 v = reinterpret_cast<double2 const *>(a.x)[nb];
+      xv[0] = v.x;
+      xv[1] = v.y;
+    }
+    else
+    {
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc)
+        xv[cc] = a.x[nb * C + cc];
+    }
+#pragma unroll
+    for (int rc = 0; rc < C; ++rc)
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc)
+        sum[rc] += tab[((size_t)rc * g.Df + d) * C + cc] * xv[cc];
+  }
+#pragma unroll
+  for (int rc = 0; rc < C; ++rc)
+  {
+    const int64_t row = node * C + rc;
+    T o;
+    switch (a.mode)
+    {
+    case 0:
+      o = sum[rc];
+      break;
+    case 1:
+      o = sum[rc] - a.b[row];
+      break;
+    case 2:
+      o = a.x[row] - a.beta * a.dinv[row] * (sum[rc] - a.b[row]);
+      break;
+    case 3:
+    {
+      const T xr = a.x[row];
+      o = xr + a.alpha * (xr - a.xprev[row]) - a.beta * a.dinv[row] * (sum[rc] - a.b[row]);
+      break;
+    }
+    case 4:
+      o = a.out[row] - sum[rc];
+      break;
+    default:
+      o = a.out[row] + sum[rc];
+      break;
+    }
+    a.out[row] = o;
+  }
+}
+
+// The same two node kernels for wide stencils (the second level of the aggregation hierarchy couples 125 nodes):
+// few nodes, long dependent gather chains -- the four wavefronts of a workgroup take a quarter of the stencil each
+// for the same 64 nodes and wavefront 0 adds the parts in a fixed order.
+template <typename T>
+__device__ __forceinline__ void bdia_store_row(CsrArgs<T> const &a, int64_t row, T sum)
+{
+  T o;
+  switch (a.mode)
+  {
+  case 0:
+    o = sum;
+    break;
+  case 1:
+    o = sum - a.b[row];
+    break;
+  case 2:
+    o = a.x[row] - a.beta * a.dinv[row] * (sum - a.b[row]);
+    break;
+  case 3:
+  {
+    const T xr = a.x[row];
+    o = xr + a.alpha * (xr - a.xprev[row]) - a.beta * a.dinv[row] * (sum - a.b[row]);
+    break;
+  }
+  case 4:
+    o = a.out[row] - sum;
+    break;
+  default:
+    o = a.out[row] + sum;
+    break;
+  }
+  a.out[row] = o;
+}
+
+template <typename T, int C, bool CLASSES, int P>
+__global__ __launch_bounds__(1024) void bdia_node_split_kernel(CsrArgs<T> a, BdiaRegular<T> g, int32_t const *nodes,
+                                                               int32_t const *class_of_wave, T const *class_table,
+                                                               int64_t n_slots)
+{
+  // NB = 1024 / P consecutive nodes per workgroup (their stencils share cache lines), P parts of the stencil (4, or
+  // 16 on the small levels where even that leaves most of the chip idle)
+  constexpr int NB = 1024 / P;
+  __shared__ T part[P - 1][C][NB];
+  // (the part is the same for a whole wavefront: kept in a scalar register so that the stencil loads are scalar)
+  const int q = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / NB)), lane = threadIdx.x % NB;
+  const int64_t slot = (int64_t)blockIdx.x * NB + lane;
+  int64_t node = -1;
+  T const *tab = g.table;
+  if constexpr (CLASSES)
+  {
+    // (n_slots is a multiple of 64: one class per wavefront, its table pointer stays in scalar registers)
+    const int64_t ws = slot < n_slots ? slot : n_slots - 1;
+    tab = class_table + (size_t)__builtin_amdgcn_readfirstlane(class_of_wave[ws >> 6]) * (size_t)(C * g.Df * C);
+    node = slot < n_slots ? (int64_t)nodes[ws] : -1;
+  }
+  else if (slot * C < a.n_rows && g.exc[slot * C] == 0)
+    node = slot;
+  const int64_t last = a.n_rows / C - 1;
+  const int d0 = (g.Df * q) / P, d1 = (g.Df * (q + 1)) / P;
+  T sum[C];
+#pragma unroll
+  for (int rc = 0; rc < C; ++rc)
+    sum[rc] = T(0);
+  if (node >= 0)
+  {
+#pragma unroll 8
+    for (int d = d0; d < d1; ++d)
+    {
+      int64_t nb = node + g.offs[d];
+      if constexpr (CLASSES)
+        nb = nb < 0 ? 0 : (nb > last ? last : nb);
+      T xv[C];
+      if constexpr (C == 2 && sizeof(T) == 8)
+      {
+        const double2 v = reinterpret_cast<double2 const *>(a.x)[nb];
+        xv[0] = v.x;
+        xv[1] = v.y;
+      }
+      else
+      {
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc)
+          xv[cc] = a.x[nb * C + cc];
+      }
+#pragma unroll
+      for (int rc = 0; rc < C; ++rc)
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc)
+          sum[rc] += tab[((size_t)rc * g.Df + d) * C + cc] * xv[cc];
+    }
+  }
+  if (q > 0)
+  {
+#pragma unroll
+    for (int rc = 0; rc < C; ++rc)
+      part[q - 1][rc][lane] = sum[rc];
+  }
+  __syncthreads();
+  if (q == 0 && node >= 0)
+  {
+#pragma unroll
+    for (int rc = 0; rc < C; ++rc)
+    {
+      T total = sum[rc];
+#pragma unroll
+      for (int k = 0; k < P - 1; ++k)
+        total += part[k][rc][lane];
+      bdia_store_row(a, node * C + rc, total);
+    }
+  }
+}
+
+// The few rows that are neither regular nor in a class: one wavefront per listed row over its CSR entries (a
+// thread per row would walk the diagonals one dependent load after the other).
+template <typename T>
+__global__ __launch_bounds__(256) void csr_listed_rows_kernel(CsrArgs<T> a, int32_t const *rows, int64_t n_listed)
+{
+  const int64_t w = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (w >= n_listed)
+    return;
+  const int64_t row = rows[w];
+  T sum = T(0);
+  for (int p = a.row_ptr[row] + lane, e = a.row_ptr[row + 1]; p < e; p += 64)
+    sum += a.val[p] * a.x[a.col[p]];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    sum += __shfl_xor(sum, off);
+  if (lane == 0)
+    bdia_store_row(a, row, sum);
 }
 
 template <typename T, int C>
@@ -455,6 +668,10 @@ __global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, T cons
   }
   a.out[row] = o;
 }
+
+constexpr size_t kMaxBlockDiagonals = 400; // (343: the third level of the aggregation hierarchy of a Q1 problem)
+constexpr int kSplitStencil = 48;        // block diagonals from which a node's stencil is split over four wavefronts
+constexpr int64_t kListedWaveRows = 32768; // listed rows up to which each gets a wavefront of its own
 
 template <typename T, int LPR>
 void launch_lds(CsrArgs<T> const &a, hipStream_t st, int32_t const *blk_ptr, int32_t const *l2g, uint16_t const *lcol,
@@ -588,7 +805,7 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
         if (it == offs.end() || *it != o)
         {
           offs.insert(it, o);
-          if (offs.size() > 160)
+          if (offs.size() > kMaxBlockDiagonals)
           {
             too_many = true;
             break;
@@ -608,6 +825,8 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
   if (best_c == 0 || best_fill < 0.8)
     return;
   const int c = best_c, D = (int)best_offs.size();
+  if (double(n) * D * c * sizeof(T) > 6e9) // the planes are built on the host
+    return;
   std::vector<T> dv((size_t)n * D * c, T(0));
   bool ok = true;
 #pragma omp parallel for schedule(static) reduction(&& : ok)
@@ -691,14 +910,114 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
         exc[nd * c + rc] = any;
       n_regular += any ? 0 : c;
     }
-    if (n_regular * 2 >= n)
+    bool regular_found = false;
+    std::vector<int32_t> exc_rows;
+    {
+      // classes among the other nodes: same stencil bit for bit (hash, then an exact comparison with the first
+      // node of the class); classes of a few nodes and nodes that match nothing stay with the stored values
+      std::vector<int64_t> enodes;
+      for (int64_t nd = 0; nd < n_nodes; ++nd)
+        if (exc[nd * c])
+          enodes.push_back(nd);
+      const size_t tuple = (size_t)c * D * c;
+      bool look_for_classes = true;
+      auto node_value = [&](int64_t nd, size_t k) { // k = (rc D + d) c + cc
+        const int cc = (int)(k % c), d = (int)((k / c) % D), rc = (int)(k / ((size_t)c * D));
+        return dv[((size_t)d * c + cc) * n + nd * c + rc];
+      };
+      auto node_hash = [&](int64_t nd) {
+        uint64_t h = 1469598103934665603ull;
+        for (size_t k = 0; k < tuple; ++k)
+        {
+          const double v = (double)node_value(nd, k);
+          uint64_t bits;
+          std::memcpy(&bits, &v, 8);
+          h = (h ^ bits) * 1099511628211ull;
+          h ^= h >> 29;
+        }
+        return h;
+      };
+      if (enodes.size() > 65536)
+      {
+        // a sample first: with a variable coefficient every node has a stencil of its own
+        std::vector<uint64_t> sample;
+        for (size_t e = 0; e < enodes.size(); e += enodes.size() / 2048)
+          sample.push_back(node_hash(enodes[e]));
+        std::sort(sample.begin(), sample.end());
+        const size_t distinct = std::unique(sample.begin(), sample.end()) - sample.begin();
+        look_for_classes = distinct * 2 < sample.size();
+      }
+      if (!look_for_classes)
+        enodes.clear();
+      std::vector<uint64_t> hash(enodes.size());
+#pragma omp parallel for schedule(static)
+      for (int64_t e = 0; e < (int64_t)enodes.size(); ++e)
+        hash[e] = node_hash(enodes[e]);
+      std::vector<int64_t> order(enodes.size());
+      std::iota(order.begin(), order.end(), (int64_t)0);
+      std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return hash[x] != hash[y] ? hash[x] < hash[y] : x < y; });
+      constexpr int64_t kMinClass = 8;
+      constexpr int kMaxClasses = 4096;
+      std::vector<int32_t> cls_nodes, cls_of_wave;
+      std::vector<T> cls_table;
+      std::vector<uint8_t> classed(n_nodes, 0);
+      int n_classes = 0;
+      for (size_t g0 = 0; g0 < order.size() && n_classes < kMaxClasses;)
+      {
+        size_t g1 = g0;
+        while (g1 < order.size() && hash[order[g1]] == hash[order[g0]])
+          ++g1;
+        if ((int64_t)(g1 - g0) >= kMinClass)
+        {
+          const int64_t rep = enodes[order[g0]];
+          std::vector<int64_t> members;
+          for (size_t q = g0; q < g1; ++q)
+          {
+            const int64_t nd = enodes[order[q]];
+            bool same = true;
+            for (size_t k = 0; k < tuple && same; ++k)
+              same = node_value(nd, k) == node_value(rep, k);
+            if (same)
+              members.push_back(nd);
+          }
+          if ((int64_t)members.size() >= kMinClass)
+          {
+            for (size_t k = 0; k < tuple; ++k)
+              cls_table.push_back(node_value(rep, k));
+            for (size_t q = 0; q < members.size(); ++q)
+            {
+              if (q % 64 == 0)
+                cls_of_wave.push_back(n_classes);
+              cls_nodes.push_back((int32_t)members[q]);
+              classed[members[q]] = 1;
+            }
+            while (cls_nodes.size() % 64 != 0)
+              cls_nodes.push_back(-1);
+            ++n_classes;
+          }
+        }
+        g0 = g1;
+      }
+      int64_t n_classed = 0;
+      for (int64_t nd = 0; nd < n_nodes; ++nd)
+        n_classed += classed[nd] ? c : 0;
+      if ((n_regular + n_classed) * 2 < n)
+        n_classes = 0;
+      if (n_classes > 0)
+      {
+        _bdia_cls_nodes.upload(cls_nodes.data(), cls_nodes.size(), _handle.stream);
+        _bdia_cls_of_wave.upload(cls_of_wave.data(), cls_of_wave.size(), _handle.stream);
+        _bdia_cls_table.upload(cls_table.data(), cls_table.size(), _handle.stream);
+        _bdia_n_classes = n_classes;
+      }
+      regular_found = n_regular * 2 >= n || n_classes > 0;
+      for (int64_t r = 0; r < n && regular_found; ++r)
+        if (exc[r] && !(n_classes > 0 && classed[r / c]))
+          exc_rows.push_back((int32_t)r);
+    }
+    if (regular_found)
     {
       _bdia_table.upload(table.data(), table.size(), _handle.stream);
-      std::vector<int32_t> exc_rows;
-      exc_rows.reserve((size_t)(n - n_regular));
-      for (int64_t r = 0; r < n; ++r)
-        if (exc[r])
-          exc_rows.push_back((int32_t)r);
       _bdia_exc_rows.upload(exc_rows.data(), exc_rows.size(), _handle.stream);
       _bdia_exc.upload(exc.data(), exc.size(), _handle.stream);
       _bdia_full_offs.upload(best_offs.data(), best_offs.size(), _handle.stream);
@@ -964,25 +1283,59 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
     g.Df = _bdia_full_d;
     g.exc_rows = _bdia_exc_rows.data();
     g.n_exc = (int64_t)_bdia_exc_rows.size();
+    if (g.exc != nullptr)
     {
-      if (g.exc != nullptr)
+      // regular nodes, then the classes of the others; wide stencils split over the wavefronts of a workgroup
+      const bool split = g.Df >= kSplitStencil;
+      const bool many_parts = g.Df >= 4 * kSplitStencil && _n_rows / _bdia_c <= 131072;
+      const int64_t n_nodes = _n_rows / _bdia_c;
+      const int64_t n_slots = (int64_t)_bdia_cls_nodes.size();
+      int32_t const *cn = _bdia_cls_nodes.data(), *cw = _bdia_cls_of_wave.data();
+      T const *ct = _bdia_cls_table.data();
+      auto launch_nodes = [&](auto cc) {
+        constexpr int C = decltype(cc)::value;
+        if (split && many_parts)
+          hipLaunchKernelGGL((bdia_node_split_kernel<T, C, false, 16>), dim3((unsigned int)((n_nodes + 63) / 64)),
+                             dim3(1024), 0, st, a, g, nullptr, nullptr, nullptr, 0);
+        else if (split)
+          hipLaunchKernelGGL((bdia_node_split_kernel<T, C, false, 4>), dim3((unsigned int)((n_nodes + 255) / 256)),
+                             dim3(1024), 0, st, a, g, nullptr, nullptr, nullptr, 0);
+        else
+          hipLaunchKernelGGL((bdia_regular_node_kernel<T, C>), dim3((unsigned int)((n_nodes + 255) / 256)), dim3(256), 0,
+                             st, a, g);
+        if (_bdia_n_classes > 0 && split && many_parts)
+          hipLaunchKernelGGL((bdia_node_split_kernel<T, C, true, 16>), dim3((unsigned int)((n_slots + 63) / 64)),
+                             dim3(1024), 0, st, a, g, cn, cw, ct, n_slots);
+        else if (_bdia_n_classes > 0 && split)
+          hipLaunchKernelGGL((bdia_node_split_kernel<T, C, true, 4>), dim3((unsigned int)((n_slots + 255) / 256)),
+                             dim3(1024), 0, st, a, g, cn, cw, ct, n_slots);
+        else if (_bdia_n_classes > 0)
+          hipLaunchKernelGGL((bdia_class_node_kernel<T, C>), dim3((unsigned int)((n_slots + 255) / 256)), dim3(256), 0,
+                             st, a, g, cn, cw, ct, n_slots);
+      };
+      switch (_bdia_c)
       {
-        const dim3 ngrid((unsigned int)((_n_rows / _bdia_c + 255) / 256));
-        switch (_bdia_c)
-        {
-        case 1:
-          hipLaunchKernelGGL((bdia_regular_node_kernel<T, 1>), ngrid, dim3(256), 0, st, a, g);
-          break;
-        case 2:
-          hipLaunchKernelGGL((bdia_regular_node_kernel<T, 2>), ngrid, dim3(256), 0, st, a, g);
-          break;
-        case 3:
-          hipLaunchKernelGGL((bdia_regular_node_kernel<T, 3>), ngrid, dim3(256), 0, st, a, g);
-          break;
-        default:
-          hipLaunchKernelGGL((bdia_regular_node_kernel<T, 4>), ngrid, dim3(256), 0, st, a, g);
-          break;
-        }
+      case 1:
+        launch_nodes(std::integral_constant<int, 1>());
+        break;
+      case 2:
+        launch_nodes(std::integral_constant<int, 2>());
+        break;
+      case 3:
+        launch_nodes(std::integral_constant<int, 3>());
+        break;
+      default:
+        launch_nodes(std::integral_constant<int, 4>());
+        break;
+      }
+      if (g.n_exc <= kListedWaveRows)
+      {
+        if (g.n_exc > 0)
+          hipLaunchKernelGGL(csr_listed_rows_kernel<T>, dim3((unsigned int)((g.n_exc + 3) / 4)), dim3(256), 0, st, a,
+                             g.exc_rows, g.n_exc);
+        KernelProfiler::end(stop, st);
+        MFMG_HIP_CHECK(hipGetLastError());
+        return;
       }
     }
     const dim3 rgrid((unsigned int)(((g.exc != nullptr ? g.n_exc : _n_rows) + 255) / 256));

@@ -105,6 +105,9 @@ public:
     return _use_regular && ((_use_bdia && _bdia_regular) || (_use_rowbase && _rb_cls.size() > 0));
   }
   void set_regular_rows(bool on) { _use_regular = on; }
+  // rows evaluated from stored values although the matrix has regular rows, and the stencil classes next to the regular one
+  int64_t listed_rows() const { return (int64_t)_bdia_exc_rows.size(); }
+  int stencil_classes() const { return _bdia_n_classes; }
   // algorithmic bytes of one y = A x (12 B/nnz + 4 B/row ptr + x + y)
   double algorithmic_bytes_apply() const
   {
@@ -146,6 +149,10 @@ private:
   DeviceBuffer<T> _bdia_table;
   DeviceBuffer<uint8_t> _bdia_exc;
   DeviceBuffer<int32_t> _bdia_full_offs, _bdia_exc_rows; // symmetric matrix: only the block diagonals with offset >= 0 are stored
+  // classes of non-regular nodes that repeat one stencil among themselves (the shells next to the boundary)
+  DeviceBuffer<int32_t> _bdia_cls_nodes, _bdia_cls_of_wave;
+  DeviceBuffer<T> _bdia_cls_table; // [n_classes][C][Df][C]
+  int _bdia_n_classes = 0;
   int _bdia_c = 0, _bdia_d = 0;
   DeviceBuffer<T> _bdia_val;
   DeviceBuffer<int32_t> _bdia_offs;

@@ -424,34 +424,43 @@ def test_csr_kernel_variants_on_stencil_matrix(ctx, comps, symmetric):
     assert M.SparseMatrixDevice(ctx, B).get_kernel()[1] != 2
 
 
-@pytest.mark.parametrize("comps,symmetric", [(1, True), (2, True), (2, False)])
-def test_csr_regular_rows_of_translation_invariant_operator(ctx, comps, symmetric):
+@pytest.mark.parametrize("comps,symmetric,reach", [(1, True, 1), (2, True, 1), (2, False, 1), (2, True, 2), (1, False, 2)])
+def test_csr_regular_rows_of_translation_invariant_operator(ctx, comps, symmetric, reach):
     """A symmetric stencil matrix whose interior rows repeat one stencil (what the coarse operators of a
     constant-coefficient problem look like): interior rows come from the stencil table, boundary rows and a
-    few perturbed rows from the stored planes; every fused mode against scipy, and against the path switched off."""
+    few perturbed rows from the stored planes; every fused mode against scipy, and against the path switched off.
+    reach 2: 125 block diagonals (the second level of the aggregation hierarchy), stencils split over wavefronts."""
     import scipy.sparse as sp
-    dims = (37, 33, 29)
+    dims = (37, 33, 29) if reach == 1 else (35, 33, 31)
     rng = np.random.default_rng(23)
 
     def t1(n, a, b):
+        if reach == 2:
+            return sp.diags([np.full(n - 2, 0.3 * b), np.full(n - 1, b), np.full(n, a), np.full(n - 1, b),
+                             np.full(n - 2, 0.3 * b)], [-2, -1, 0, 1, 2])
         return sp.diags([np.full(n - 1, b), np.full(n, a), np.full(n - 1, b)], [-1, 0, 1])
     pattern = sp.kron(t1(dims[2], 2.0, -0.3), sp.kron(t1(dims[1], 1.5, -0.25), t1(dims[0], 1.0, -0.2))).tocsr()
     blk = np.array([[3.0, 0.4], [0.4, 2.0]])[:comps, :comps]
     A = sp.kron(pattern, blk).tocsr()
     A.sort_indices()
-    # a few interior rows differ (made symmetric): they must take the stored-value path
-    A = A.tolil()
-    for r in rng.integers(A.shape[0] // 3, 2 * A.shape[0] // 3, 20):
-        A[r, r] = A[r, r] * 1.5
+    # a few interior rows differ (on the diagonal: still symmetric): they must take the stored-value path
+    n = A.shape[0]
+    bump = np.zeros(n)
+    rows = rng.integers(n // 3, 2 * n // 3, 20)
+    bump[rows] = 0.5 * A.diagonal()[rows]
+    A = (A + sp.diags(bump)).tocsr()
     if not symmetric:                        # e.g. the coarse operator of one rank: rows of the neighbours emptied
-        for r in range(0, 400):
-            A[r, :] = 0.0
-            A[r, r] = 1.0
-    A = A.tocsr()
+        keep = np.ones(n)
+        keep[:400] = 0.0
+        A = (sp.diags(keep) @ A + sp.diags(1.0 - keep)).tocsr()
     A.eliminate_zeros()
+    A.sort_indices()
     n = A.shape[0]
     Ad = M.SparseMatrixDevice(ctx, A)
     assert Ad.get_kernel()[1] == (3 if symmetric else 2) and Ad.regular_rows()
+    # faces and edges of the box are stencil classes of their own; the corners and the perturbed rows stay listed
+    n_classes, listed = Ad.stencil_classes()
+    assert n_classes >= (18 if reach == 1 else 60) and listed <= (100 if reach == 1 else 600)
     x, b, xp = rng.random(n), rng.random(n), rng.random(n)
     dinv = 1.0 / A.diagonal()
     ref = A @ x
