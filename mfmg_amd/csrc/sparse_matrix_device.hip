@@ -11,7 +11,10 @@
 #include "amge_structured.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <numeric>
 #include <type_traits>
 
@@ -226,58 +229,10 @@ __global__ __launch_bounds__(256) void bdia_spmv_kernel(CsrArgs<T> a, T const *v
   a.out[row] = o;
 }
 
-// Row-base storage for rectangular stencil-like matrices (the smoothed prolongators: every fine row couples to
-// the same small box of coarse unknowns, placed relative to a per-row base column): val[s n_rows + row] for the
-// slots s of a shared offset list, column = base[row] + offs[s].  4 B of index per ROW instead of per entry,
-// coalesced value planes, one thread per row, fixed summation order.
-// Rows whose S values repeat one of a few value tuples bit for bit (the prolongators of a translation-invariant
-// problem: one tuple per parity class of the fine node and component) carry a class id instead: their values
-// come from table[class][slot], only the class byte, the base and x are read for them.
+// the fused epilogues of a row (the modes of CsrMode)
 template <typename T>
-__global__ __launch_bounds__(256) void rowbase_spmv_kernel(CsrArgs<T> a, T const *val, int32_t const *base,
-                                                           int32_t const *offs, int S, int64_t n_cols,
-                                                           uint8_t const *cls, T const *table, int table_len)
+__device__ __forceinline__ void bdia_store_row(CsrArgs<T> const &a, int64_t row, T sum)
 {
-  // the class table sits in LDS: lanes of different classes read different entries (a gather from global
-  // memory costs one transaction per distinct address)
-  extern __shared__ __align__(16) unsigned char rb_smem[];
-  T *tab = reinterpret_cast<T *>(rb_smem);
-  if (cls != nullptr)
-  {
-    for (int i = threadIdx.x; i < table_len; i += blockDim.x)
-      tab[i] = table[i];
-    __syncthreads();
-  }
-  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (r >= a.n_rows)
-    return;
-  const int64_t b0 = base[r];
-  const int cl = cls != nullptr ? (int)cls[r] : 255;
-  T sum = T(0);
-  if (cl != 255)
-  {
-    T const *tp = tab + (size_t)cl * S;
-#pragma unroll 4
-    for (int sidx = 0; sidx < S; ++sidx)
-    {
-      const int64_t c = b0 + offs[sidx];
-      if (c >= 0 && c < n_cols)
-        sum += tp[sidx] * a.x[c];
-    }
-  }
-  else
-  {
-    T const *vp = val + r;
-    const size_t stride = (size_t)a.n_rows;
-#pragma unroll 4
-    for (int sidx = 0; sidx < S; ++sidx)
-    {
-      const int64_t c = b0 + offs[sidx];
-      if (c >= 0 && c < n_cols)
-        sum += vp[(size_t)sidx * stride] * a.x[c];
-    }
-  }
-  const int64_t row = r;
   T o;
   switch (a.mode)
   {
@@ -306,6 +261,32 @@ __global__ __launch_bounds__(256) void rowbase_spmv_kernel(CsrArgs<T> a, T const
   a.out[row] = o;
 }
 
+// Row-base storage for rectangular stencil-like matrices whose values do not repeat (prolongators of a problem with a
+// variable coefficient; with repeating values build_node_classes has them): every row couples to the same small box
+// of unknowns, placed relative to a per-row base column: val[s n_rows + row] for the slots s of a shared offset
+// list, column = base[row] + offs[s].  4 B of index per ROW instead of per entry, coalesced value planes, one
+// thread per row, fixed summation order.
+template <typename T>
+__global__ __launch_bounds__(256) void rowbase_spmv_kernel(CsrArgs<T> a, T const *val, int32_t const *base,
+                                                           int32_t const *offs, int S, int64_t n_cols)
+{
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= a.n_rows)
+    return;
+  const int64_t b0 = base[r];
+  T const *vp = val + r;
+  const size_t stride = (size_t)a.n_rows;
+  T sum = T(0);
+#pragma unroll 4
+  for (int sidx = 0; sidx < S; ++sidx)
+  {
+    const int64_t c = b0 + offs[sidx];
+    if (c >= 0 && c < n_cols)
+      sum += vp[(size_t)sidx * stride] * a.x[c];
+  }
+  bdia_store_row(a, r, sum);
+}
+
 // Symmetric matrices keep only the block diagonals with offset >= 0 (half the bytes from HBM): the entry
 // A[(n,c)][(n-o,cc)] of a lower diagonal is read as its transpose A[(n-o,cc)][(n,c)] = val[o][c][(n-o) C + cc],
 // i.e. the same plane a lower-numbered row streams as its upper part -- a second read of data that passed
@@ -320,6 +301,8 @@ struct BdiaRegular
   T const *table;     // [C][Df][C]
   int32_t const *offs;
   int Df;
+  int32_t const *base = nullptr; // rectangular matrices (node classes): first column node of a row node
+  int64_t n_col_nodes = 0;
 };
 
 // One thread per NODE whose C rows are all regular: the x values of a neighbour node are fetched once for the C
@@ -407,7 +390,8 @@ __global__ __launch_bounds__(256) void bdia_class_node_kernel(CsrArgs<T> a, Bdia
   const int64_t node = nodes[t];
   if (node < 0)
     return;
-  const int64_t last = a.n_rows / C - 1;
+  const int64_t last = g.n_col_nodes - 1;
+  const int64_t first = g.base != nullptr ? (int64_t)g.base[node] : node;
   T const *tab = class_table + (size_t)cls * (size_t)(C * g.Df * C);
   T sum[C];
 #pragma unroll
@@ -416,7 +400,7 @@ __global__ __launch_bounds__(256) void bdia_class_node_kernel(CsrArgs<T> a, Bdia
 #pragma unroll 8
   for (int d = 0; d < g.Df; ++d)
   {
-    int64_t nb = node + g.offs[d];
+    int64_t nb = first + g.offs[d];
     nb = nb < 0 ? 0 : (nb > last ? last : nb);
     T xv[C];
     if constexpr (C == 2 && sizeof(T) == 8)
@@ -473,37 +457,6 @@ __global__ __launch_bounds__(256) void bdia_class_node_kernel(CsrArgs<T> a, Bdia
 // The same two node kernels for wide stencils (the second level of the aggregation hierarchy couples 125 nodes):
 // few nodes, long dependent gather chains -- the four wavefronts of a workgroup take a quarter of the stencil each
 // for the same 64 nodes and wavefront 0 adds the parts in a fixed order.
-template <typename T>
-__device__ __forceinline__ void bdia_store_row(CsrArgs<T> const &a, int64_t row, T sum)
-{
-  T o;
-  switch (a.mode)
-  {
-  case 0:
-    o = sum;
-    break;
-  case 1:
-    o = sum - a.b[row];
-    break;
-  case 2:
-    o = a.x[row] - a.beta * a.dinv[row] * (sum - a.b[row]);
-    break;
-  case 3:
-  {
-    const T xr = a.x[row];
-    o = xr + a.alpha * (xr - a.xprev[row]) - a.beta * a.dinv[row] * (sum - a.b[row]);
-    break;
-  }
-  case 4:
-    o = a.out[row] - sum;
-    break;
-  default:
-    o = a.out[row] + sum;
-    break;
-  }
-  a.out[row] = o;
-}
-
 template <typename T, int C, bool CLASSES, int P>
 __global__ __launch_bounds__(1024) void bdia_node_split_kernel(CsrArgs<T> a, BdiaRegular<T> g, int32_t const *nodes,
                                                                int32_t const *class_of_wave, T const *class_table,
@@ -527,7 +480,8 @@ __global__ __launch_bounds__(1024) void bdia_node_split_kernel(CsrArgs<T> a, Bdi
   }
   else if (slot * C < a.n_rows && g.exc[slot * C] == 0)
     node = slot;
-  const int64_t last = a.n_rows / C - 1;
+  const int64_t last = g.n_col_nodes - 1;
+  const int64_t first = (CLASSES && g.base != nullptr && node >= 0) ? (int64_t)g.base[node] : node;
   const int d0 = (g.Df * q) / P, d1 = (g.Df * (q + 1)) / P;
   T sum[C];
 #pragma unroll
@@ -538,7 +492,7 @@ __global__ __launch_bounds__(1024) void bdia_node_split_kernel(CsrArgs<T> a, Bdi
 #pragma unroll 8
     for (int d = d0; d < d1; ++d)
     {
-      int64_t nb = node + g.offs[d];
+      int64_t nb = first + g.offs[d];
       if constexpr (CLASSES)
         nb = nb < 0 ? 0 : (nb > last ? last : nb);
       T xv[C];
@@ -720,11 +674,14 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
     build_block_diagonals(row_ptr, col, val);
   // ---- row-base storage (see rowbase_spmv_kernel) for matrices the block diagonals do not fit
   // (one thread per row: below ~1000 workgroups the CSR kernels with several lanes per row fill the chip better)
-  if (!_use_bdia && n_rows >= 200000 && avg >= 4. && avg <= 160.)
+  // ---- node classes (see build_node_classes) for the rectangular operators of a translation-invariant problem
+  if (!_use_bdia && n_rows >= 32768 && avg >= 4.)
+    build_node_classes(row_ptr, col, val);
+  if (!_use_bdia && !_use_nodecls && n_rows >= 200000 && avg >= 4. && avg <= 160.)
     build_row_base(row_ptr, col, val);
   // ---- block-local column compression for the LDS-cached kernel
   // (a 128-row block per workgroup: below ~256 blocks the plain kernel fills the chip better)
-  if (!_use_bdia && !_use_rowbase && n_rows >= 256 * kRowsPerBlock && avg >= 4.)
+  if (!_use_bdia && !_use_rowbase && !_use_nodecls && n_rows >= 256 * kRowsPerBlock && avg >= 4.)
   {
     const int64_t nb = (n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
     std::vector<int32_t> blk_ptr(nb + 1, 0);
@@ -768,6 +725,13 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
       _lds_max_cols = max_cols;
     }
   }
+  if (std::getenv("MFMG_HIP_VERBOSE") != nullptr)
+    std::fprintf(stderr,
+                 "[mfmg_hip] matrix %lld x %lld, %.1f entries per row: kernel kind %d (lanes per row %d; block diagonals %d x "
+                 "%d components%s, regular rows %d, stencil classes %d, listed rows %lld; row-base slots %d; node classes %d of %d x %d components, %lld rows listed)\n",
+                 (long long)_n_rows, (long long)_n_cols, avg, kernel_kind(), _lanes_per_row, _bdia_d, _bdia_c,
+                 _bdia_sym ? " (symmetric half)" : "", (int)_bdia_regular, _bdia_n_classes,
+                 (long long)_bdia_exc_rows.size(), _rb_slots, _nc_classes, _nc_d, _nc_c, (long long)_nc_listed.size());
   _val.upload(val.data(), val.size(), handle.stream);
   _col.upload(col.data(), col.size(), handle.stream);
   _row_ptr.upload(row_ptr.data(), row_ptr.size(), handle.stream);
@@ -1078,6 +1042,204 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
   _use_bdia = true;
 }
 
+// Node classes for rectangular stencil-like matrices (the smoothed prolongators of the aggregation hierarchy and
+// their transposes, the restrictor): a row node (C rows) couples to the column nodes base[node] + offs[d]; on a
+// translation-invariant problem its C D C values repeat one of a few tuples (the position of the node inside its
+// aggregate, the distance to the boundary).  Nodes are sorted by (tile of 8192 nodes, class), every run padded to
+// whole wavefronts, and evaluated by bdia_class_node_kernel / bdia_node_split_kernel: 4 B of node id and 4 B of base
+// per node instead of 12 B per entry.  Rows of nodes that match no class go through csr_listed_rows_kernel.  The
+// format is used when at least 90 % of the rows are in classes.
+template <typename T>
+void SparseMatrixDevice<T>::build_node_classes(std::vector<int32_t> const &row_ptr, std::vector<int32_t> const &col,
+                                               std::vector<T> const &val)
+{
+  const int64_t n = _n_rows, m = _n_cols;
+  int best_c = 0;
+  std::vector<int32_t> best_offs;
+  double best_fill = 0.;
+  auto node_base = [&](int64_t nd, int c) {
+    int64_t b = std::numeric_limits<int64_t>::max();
+    for (int64_t r = nd * c; r < (nd + 1) * c; ++r)
+      for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
+        b = std::min<int64_t>(b, col[p] / c);
+    return b;
+  };
+  for (int c = 1; c <= 4; ++c)
+  {
+    if (n % c != 0 || m % c != 0)
+      continue;
+    const int64_t n_nodes = n / c;
+    std::vector<int32_t> offs;
+    bool too_many = false;
+    int64_t step = std::max<int64_t>(1, n_nodes / 65536);
+    while (step % 2 == 0 || step % 3 == 0)
+      ++step;
+    for (int64_t nd = 0; nd < n_nodes && !too_many; nd += step)
+    {
+      const int64_t b = node_base(nd, c);
+      for (int64_t r = nd * c; r < (nd + 1) * c && !too_many; ++r)
+        for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
+        {
+          const int32_t o = (int32_t)(col[p] / c - b);
+          auto it = std::lower_bound(offs.begin(), offs.end(), o);
+          if (it == offs.end() || *it != o)
+          {
+            offs.insert(it, o);
+            if (offs.size() > kMaxBlockDiagonals)
+            {
+              too_many = true;
+              break;
+            }
+          }
+        }
+    }
+    if (too_many || offs.empty())
+      continue;
+    const double fill = double(_nnz) / (double(n_nodes) * double(offs.size()) * c * c);
+    if (fill > 0.98 * best_fill) // (several unknowns per node: one wide load instead of several narrow ones)
+    {
+      best_fill = fill;
+      best_c = c;
+      best_offs = offs;
+    }
+  }
+  if (best_c == 0 || best_fill < 0.6)
+    return;
+  const int c = best_c, D = (int)best_offs.size();
+  const int64_t n_nodes = n / c;
+  const size_t tuple = (size_t)c * D * c;
+  if (double(n_nodes) * tuple * sizeof(T) > 6e9)
+    return;
+  std::vector<T> tv((size_t)n_nodes * tuple, T(0)); // [node][rc][d][cc]
+  std::vector<int32_t> base(n_nodes, 0);
+  bool ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : ok)
+  for (int64_t nd = 0; nd < n_nodes; ++nd)
+  {
+    const int64_t b = node_base(nd, c);
+    if (b == std::numeric_limits<int64_t>::max())
+      continue; // a node without entries: all zeros
+    base[nd] = (int32_t)b;
+    for (int rc = 0; rc < c; ++rc)
+      for (int p = row_ptr[nd * c + rc]; p < row_ptr[nd * c + rc + 1]; ++p)
+      {
+        const int32_t o = (int32_t)(col[p] / c - b);
+        auto it = std::lower_bound(best_offs.begin(), best_offs.end(), o);
+        if (it == best_offs.end() || *it != o)
+        {
+          ok = false;
+          continue;
+        }
+        tv[(size_t)nd * tuple + ((size_t)rc * D + (size_t)(it - best_offs.begin())) * c + (size_t)(col[p] % c)] += val[p];
+      }
+  }
+  if (!ok)
+    return;
+  std::vector<uint64_t> hash(n_nodes);
+#pragma omp parallel for schedule(static)
+  for (int64_t nd = 0; nd < n_nodes; ++nd)
+  {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t k = 0; k < tuple; ++k)
+    {
+      const double v = (double)tv[(size_t)nd * tuple + k];
+      uint64_t bits;
+      std::memcpy(&bits, &v, 8);
+      h = (h ^ bits) * 1099511628211ull;
+      h ^= h >> 29;
+    }
+    hash[nd] = h;
+  }
+  std::vector<int64_t> order(n_nodes);
+  std::iota(order.begin(), order.end(), (int64_t)0);
+  std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return hash[x] != hash[y] ? hash[x] < hash[y] : x < y; });
+  constexpr int64_t kMinClass = 8, kTile = 8192;
+  constexpr int kMaxClasses = 4096;
+  std::vector<int32_t> cls_of_node(n_nodes, -1);
+  std::vector<T> table;
+  int n_classes = 0;
+  int64_t n_classed = 0;
+  for (int64_t g0 = 0; g0 < n_nodes && n_classes < kMaxClasses;)
+  {
+    int64_t g1 = g0;
+    while (g1 < n_nodes && hash[order[g1]] == hash[order[g0]])
+      ++g1;
+    if (g1 - g0 >= kMinClass)
+    {
+      const int64_t rep = order[g0];
+      int64_t members = 0;
+      for (int64_t q = g0; q < g1; ++q)
+        if (std::memcmp(&tv[(size_t)order[q] * tuple], &tv[(size_t)rep * tuple], tuple * sizeof(T)) == 0)
+        {
+          cls_of_node[order[q]] = n_classes;
+          ++members;
+        }
+      if (members >= kMinClass)
+      {
+        table.insert(table.end(), tv.begin() + (size_t)rep * tuple, tv.begin() + (size_t)(rep + 1) * tuple);
+        n_classed += members;
+        ++n_classes;
+      }
+      else
+        for (int64_t q = g0; q < g1; ++q)
+          if (cls_of_node[order[q]] == n_classes)
+            cls_of_node[order[q]] = -1;
+    }
+    g0 = g1;
+  }
+  if (n_classes == 0 || n_classed * 10 < n_nodes * 9)
+    return;
+  // (tile, class, node) order, runs padded to whole wavefronts; tiles keep the rows of a wavefront close together
+  // (partial cache lines of the output are completed by wavefronts of other classes of the same tile), the whole
+  // matrix as one tile where small tiles would mostly hold padding
+  std::vector<int32_t> nodes, class_of_wave, listed;
+  for (int64_t nd = 0; nd < n_nodes; ++nd)
+    if (cls_of_node[nd] < 0)
+      for (int rc = 0; rc < c; ++rc)
+        listed.push_back((int32_t)(nd * c + rc));
+  std::vector<std::pair<int32_t, int32_t>> in_tile; // (class, node)
+  bool done = false;
+  for (int64_t tile : {kTile, 8 * kTile, n_nodes})
+  {
+    if (done)
+      break;
+    nodes.clear();
+    class_of_wave.clear();
+    for (int64_t t0 = 0; t0 < n_nodes; t0 += tile)
+    {
+      in_tile.clear();
+      for (int64_t nd = t0; nd < std::min(n_nodes, t0 + tile); ++nd)
+        if (cls_of_node[nd] >= 0)
+          in_tile.emplace_back(cls_of_node[nd], (int32_t)nd);
+      std::sort(in_tile.begin(), in_tile.end());
+      for (size_t q = 0; q < in_tile.size(); ++q)
+      {
+        if (q > 0 && in_tile[q].first != in_tile[q - 1].first)
+          while (nodes.size() % 64 != 0)
+            nodes.push_back(-1);
+        if (nodes.size() % 64 == 0)
+          class_of_wave.push_back(in_tile[q].first);
+        nodes.push_back(in_tile[q].second);
+      }
+      while (nodes.size() % 64 != 0)
+        nodes.push_back(-1);
+    }
+    done = (double)nodes.size() <= 1.25 * (double)n_classed || tile >= n_nodes;
+  }
+  if ((double)nodes.size() > 2. * (double)n_classed)
+    return; // mostly padding: the CSR kernels do better
+  _nc_base.upload(base.data(), base.size(), _handle.stream);
+  _nc_offs.upload(best_offs.data(), best_offs.size(), _handle.stream);
+  _nc_nodes.upload(nodes.data(), nodes.size(), _handle.stream);
+  _nc_class_of_wave.upload(class_of_wave.data(), class_of_wave.size(), _handle.stream);
+  _nc_listed.upload(listed.data(), listed.size(), _handle.stream);
+  _nc_table.upload(table.data(), table.size(), _handle.stream);
+  _nc_c = c;
+  _nc_d = D;
+  _nc_classes = n_classes;
+  _use_nodecls = true;
+}
+
 template <typename T>
 void SparseMatrixDevice<T>::build_row_base(std::vector<int32_t> const &row_ptr, std::vector<int32_t> const &col,
                                            std::vector<T> const &val)
@@ -1142,93 +1304,6 @@ void SparseMatrixDevice<T>::build_row_base(std::vector<int32_t> const &row_ptr, 
   }
   if (!ok)
     return;
-  // value tuples that many rows repeat bit for bit -> classes
-  {
-    auto row_hash = [&](int64_t r) {
-      uint64_t h = 1469598103934665603ull;
-      for (int sidx = 0; sidx < S; ++sidx)
-      {
-        uint64_t bits;
-        const double v = (double)dv[(size_t)sidx * n + r];
-        std::memcpy(&bits, &v, sizeof(bits));
-        h = (h ^ bits) * 1099511628211ull;
-      }
-      return h;
-    };
-    auto rows_equal = [&](int64_t r1, int64_t r2) {
-      for (int sidx = 0; sidx < S; ++sidx)
-        if (dv[(size_t)sidx * n + r1] != dv[(size_t)sidx * n + r2])
-          return false;
-      return true;
-    };
-    // candidates from a sample, most frequent first
-    std::vector<std::pair<uint64_t, int64_t>> seen; // (hash, representative row)
-    std::vector<int64_t> count;
-    const int64_t n_sample = std::min<int64_t>(n, 65536);
-    for (int64_t t = 0; t < n_sample; ++t)
-    {
-      const int64_t r = (t * 2654435761ll) % n;
-      const uint64_t h = row_hash(r);
-      size_t k = 0;
-      while (k < seen.size() && seen[k].first != h)
-        ++k;
-      if (k == seen.size())
-      {
-        if (seen.size() >= 512)
-          continue;
-        seen.emplace_back(h, r);
-        count.push_back(0);
-      }
-      ++count[k];
-    }
-    std::vector<size_t> order(seen.size());
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](size_t x1, size_t x2) { return count[x1] > count[x2]; });
-    std::vector<int64_t> reps;
-    for (size_t k = 0; k < order.size() && reps.size() < 64; ++k)
-      if (count[order[k]] * 512 >= n_sample) // at least ~0.2 % of the rows
-        reps.push_back(seen[order[k]].second);
-    if (!reps.empty())
-    {
-      std::vector<uint64_t> rep_hash(reps.size());
-      for (size_t k = 0; k < reps.size(); ++k)
-        rep_hash[k] = row_hash(reps[k]);
-      std::vector<uint8_t> cls(n, 255);
-      int64_t n_regular = 0;
-#pragma omp parallel for schedule(static) reduction(+ : n_regular)
-      for (int64_t r = 0; r < n; ++r)
-      {
-        const uint64_t h = row_hash(r);
-        for (size_t k = 0; k < reps.size(); ++k)
-          if (rep_hash[k] == h && rows_equal(r, reps[k]))
-          {
-            cls[r] = (uint8_t)k;
-            ++n_regular;
-            break;
-          }
-      }
-      // a wavefront with both kinds of rows walks both paths: the table only pays where most wavefronts
-      // (64 consecutive rows) are regular throughout
-      int64_t full_waves = 0;
-#pragma omp parallel for schedule(static) reduction(+ : full_waves)
-      for (int64_t w0 = 0; w0 < n; w0 += 64)
-      {
-        bool all = true;
-        for (int64_t r = w0; r < std::min<int64_t>(n, w0 + 64); ++r)
-          all = all && cls[r] != 255;
-        full_waves += all ? 1 : 0;
-      }
-      if (full_waves * 64 * 10 >= n * 6 && reps.size() * (size_t)S * sizeof(T) <= 32 * 1024)
-      {
-        std::vector<T> table(reps.size() * (size_t)S);
-        for (size_t k = 0; k < reps.size(); ++k)
-          for (int sidx = 0; sidx < S; ++sidx)
-            table[k * S + sidx] = dv[(size_t)sidx * n + reps[k]];
-        _rb_cls.upload(cls.data(), cls.size(), _handle.stream);
-        _rb_table.upload(table.data(), table.size(), _handle.stream);
-      }
-    }
-  }
   _rb_val.upload(dv.data(), dv.size(), _handle.stream);
   _rb_base.upload(base.data(), base.size(), _handle.stream);
   _rb_offs.upload(offs.data(), offs.size(), _handle.stream);
@@ -1261,13 +1336,61 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
   const double extra = (mode == CsrMode::apply) ? 0. : (mode == CsrMode::first) ? 3. : (mode == CsrMode::next) ? 4. : 1.;
   hipEvent_t stop =
       _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes_apply() + extra * sizeof(T) * double(_n_rows), st);
+  if (_use_nodecls && _use_regular)
+  {
+    BdiaRegular<T> g;
+    g.exc = nullptr;
+    g.exc_rows = nullptr;
+    g.n_exc = 0;
+    g.table = nullptr;
+    g.offs = _nc_offs.data();
+    g.Df = _nc_d;
+    g.base = _nc_base.data();
+    g.n_col_nodes = _n_cols / _nc_c;
+    const int64_t n_slots = (int64_t)_nc_nodes.size();
+    int32_t const *cn = _nc_nodes.data(), *cw = _nc_class_of_wave.data();
+    T const *ct = _nc_table.data();
+    const bool split = g.Df >= kSplitStencil;
+    const bool many_parts = g.Df >= 4 * kSplitStencil && _n_rows / _nc_c <= 131072;
+    auto launch_nodes = [&](auto cc) {
+      constexpr int C = decltype(cc)::value;
+      if (split && many_parts)
+        hipLaunchKernelGGL((bdia_node_split_kernel<T, C, true, 16>), dim3((unsigned int)((n_slots + 63) / 64)), dim3(1024),
+                           0, st, a, g, cn, cw, ct, n_slots);
+      else if (split)
+        hipLaunchKernelGGL((bdia_node_split_kernel<T, C, true, 4>), dim3((unsigned int)((n_slots + 255) / 256)),
+                           dim3(1024), 0, st, a, g, cn, cw, ct, n_slots);
+      else
+        hipLaunchKernelGGL((bdia_class_node_kernel<T, C>), dim3((unsigned int)((n_slots + 255) / 256)), dim3(256), 0, st,
+                           a, g, cn, cw, ct, n_slots);
+    };
+    switch (_nc_c)
+    {
+    case 1:
+      launch_nodes(std::integral_constant<int, 1>());
+      break;
+    case 2:
+      launch_nodes(std::integral_constant<int, 2>());
+      break;
+    case 3:
+      launch_nodes(std::integral_constant<int, 3>());
+      break;
+    default:
+      launch_nodes(std::integral_constant<int, 4>());
+      break;
+    }
+    const int64_t n_listed = (int64_t)_nc_listed.size();
+    if (n_listed > 0)
+      hipLaunchKernelGGL(csr_listed_rows_kernel<T>, dim3((unsigned int)((n_listed + 3) / 4)), dim3(256), 0, st, a,
+                         _nc_listed.data(), n_listed);
+    KernelProfiler::end(stop, st);
+    MFMG_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (_use_rowbase)
   {
-    const bool classes = _rb_cls.size() && _use_regular;
-    hipLaunchKernelGGL(rowbase_spmv_kernel<T>, dim3((unsigned int)((_n_rows + 255) / 256)), dim3(256),
-                       classes ? _rb_table.size() * sizeof(T) : 0, st, a, _rb_val.data(), _rb_base.data(),
-                       _rb_offs.data(), _rb_slots, _n_cols, classes ? _rb_cls.data() : nullptr, _rb_table.data(),
-                       (int)_rb_table.size());
+    hipLaunchKernelGGL(rowbase_spmv_kernel<T>, dim3((unsigned int)((_n_rows + 255) / 256)), dim3(256), 0, st, a,
+                       _rb_val.data(), _rb_base.data(), _rb_offs.data(), _rb_slots, _n_cols);
     KernelProfiler::end(stop, st);
     MFMG_HIP_CHECK(hipGetLastError());
     return;
@@ -1283,6 +1406,7 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
     g.Df = _bdia_full_d;
     g.exc_rows = _bdia_exc_rows.data();
     g.n_exc = (int64_t)_bdia_exc_rows.size();
+    g.n_col_nodes = _n_rows / _bdia_c;
     if (g.exc != nullptr)
     {
       // regular nodes, then the classes of the others; wide stencils split over the wavefronts of a workgroup

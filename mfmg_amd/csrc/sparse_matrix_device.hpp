@@ -85,7 +85,7 @@ public:
   // tuning knob: lanes of a wavefront that share a row (power of two, 1..64; 0 keeps the choice) and whether
   // the LDS-cached kernel is used (only where the block-local column lists were built)
   // use_lds: 0 plain, 1 LDS-cached, 2 / 3 block-diagonal storage (3 is reported when only the upper half of a
-  // symmetric matrix is stored), 4 row-base storage; each variant only where its data was built
+  // symmetric matrix is stored), 4 row-base storage, 5 node classes; each variant only where its data was built
   void set_kernel(int lanes_per_row, int use_lds)
   {
     if (lanes_per_row > 0)
@@ -94,20 +94,24 @@ public:
     {
       _use_bdia = (use_lds == 2 || use_lds == 3) && _bdia_val.size() > 0;
       _use_rowbase = (use_lds == 4) && _rb_val.size() > 0;
+      _use_nodecls = (use_lds == 5) && _nc_nodes.size() > 0;
       _use_lds = (use_lds == 1) && _lcol.size() > 0;
     }
   }
-  int kernel_kind() const { return _use_rowbase ? 4 : _use_bdia ? (_bdia_sym ? 3 : 2) : (_use_lds ? 1 : 0); }
+  int kernel_kind() const
+  {
+    return _use_nodecls ? 5 : _use_rowbase ? 4 : _use_bdia ? (_bdia_sym ? 3 : 2) : (_use_lds ? 1 : 0);
+  }
   int block_diagonals() const { return _use_bdia ? _bdia_d : 0; }
   bool symmetric_storage() const { return _use_bdia && _bdia_sym; }
   bool regular_rows() const
   {
-    return _use_regular && ((_use_bdia && _bdia_regular) || (_use_rowbase && _rb_cls.size() > 0));
+    return _use_regular && ((_use_bdia && _bdia_regular) || _use_nodecls);
   }
   void set_regular_rows(bool on) { _use_regular = on; }
   // rows evaluated from stored values although the matrix has regular rows, and the stencil classes next to the regular one
-  int64_t listed_rows() const { return (int64_t)_bdia_exc_rows.size(); }
-  int stencil_classes() const { return _bdia_n_classes; }
+  int64_t listed_rows() const { return (int64_t)(_use_nodecls ? _nc_listed.size() : _bdia_exc_rows.size()); }
+  int stencil_classes() const { return _use_nodecls ? _nc_classes : _bdia_n_classes; }
   // algorithmic bytes of one y = A x (12 B/nnz + 4 B/row ptr + x + y)
   double algorithmic_bytes_apply() const
   {
@@ -139,8 +143,13 @@ private:
   int _rb_slots = 0;
   DeviceBuffer<T> _rb_val;
   DeviceBuffer<int32_t> _rb_base, _rb_offs;
-  DeviceBuffer<uint8_t> _rb_cls; // class of a row whose values repeat a table entry, 255 = stored values
-  DeviceBuffer<T> _rb_table;     // [n_classes][slots]
+  // node classes (rectangular stencil-like matrices of a translation-invariant problem: the prolongators and
+  // their transposes), see the .hip file
+  void build_node_classes(std::vector<int32_t> const &row_ptr, std::vector<int32_t> const &col, std::vector<T> const &val);
+  bool _use_nodecls = false;
+  int _nc_c = 0, _nc_d = 0, _nc_classes = 0;
+  DeviceBuffer<int32_t> _nc_base, _nc_offs, _nc_nodes, _nc_class_of_wave, _nc_listed;
+  DeviceBuffer<T> _nc_table;
   bool _use_bdia = false;
   bool _bdia_sym = false;
   // regular rows of a translation-invariant operator: stencil table instead of stored values (see the .hip file)

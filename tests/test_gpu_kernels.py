@@ -481,7 +481,8 @@ def test_csr_regular_rows_of_translation_invariant_operator(ctx, comps, symmetri
 
 def test_csr_row_classes_of_translation_invariant_prolongator(ctx):
     """A rectangular stencil matrix whose rows repeat a few value tuples (what the smoothed prolongators of a
-    constant-coefficient problem look like): class table for those rows, stored values for the others."""
+    constant-coefficient problem look like): nodes sorted by class and evaluated from per-class tables, the rows of
+    their own one wavefront each over the CSR entries; every fused mode, and against the plain CSR kernel."""
     import scipy.sparse as sp
     dims = (37, 33, 29)
     rng = np.random.default_rng(29)
@@ -494,16 +495,21 @@ def test_csr_row_classes_of_translation_invariant_prolongator(ctx):
         P[r, P.rows[r][0]] = 7.5
     P = P.tocsr()
     Pd = M.SparseMatrixDevice(ctx, P)
-    assert Pd.get_kernel()[1] == 4 and Pd.regular_rows()
+    assert Pd.get_kernel()[1] == 5 and Pd.regular_rows()
+    n_classes, listed = Pd.stencil_classes()
+    assert n_classes >= 19 and 30 <= listed <= 400          # interior, faces, edges; corners and the 30 rows listed
     x = rng.random(P.shape[1])
     y0 = rng.random(P.shape[0])
     res = {}
     for on in (True, False):
         Pd.set_regular_rows(on)
+        assert Pd.regular_rows() == on
         out = torch.empty(P.shape[0], dtype=torch.float64, device="cuda")
         Pd.vmult(out, dev(x))
         assert relerr(host(out, ctx), P @ x) < TOL
         res[on] = host(out, ctx).copy()
+        Pd.residual(dev(x), dev(y0), out)
+        assert relerr(host(out, ctx), P @ x - y0) < TOL
     assert relerr(res[True], res[False]) < 1e-13
 
 
