@@ -658,6 +658,18 @@ void HipSmoother::apply_zero_guess(DVector const &b, DVector &x) const
                                 _hip_operator->get_diagonal_inverse(), b.get_values(), x.get_values());
 }
 
+void HipSmoother::apply_to(DVector const &b, DVector const &x_in, DVector &x_out) const
+{
+  ASSERT_THROW(x_in.get_values() != x_out.get_values(), "apply_to needs two vectors");
+  if (_coefficients.size() == 1)
+  {
+    _hip_operator->smoother_step(b, x_in, nullptr, 0., _coefficients[0].second, x_out);
+    return;
+  }
+  x_out = x_in;
+  apply(b, x_out);
+}
+
 // ---- HipSolver -----------------------------------------------------------------
 void HipSolver::setup_direct(std::shared_ptr<SparseMatrixDevice<double>> matrix, DenseLu &f) const
 {
@@ -961,13 +973,15 @@ void HipSolver::amg_cycle(size_t level, DVector const &b, DVector &x) const
     L.res = L.a->build_range_vector();
     L.b_coarse = _amg[level + 1].a->build_range_vector();
     L.x_coarse = _amg[level + 1].a->build_range_vector();
+    L.x_work = L.a->build_range_vector();
   }
-  L.smoother->apply_zero_guess(b, x); // x = 0 on entry by construction
-  L.a->residual(x, b, *L.res);
+  // the iterate lives in x_work until the post-smoother writes its result into x
+  L.smoother->apply_zero_guess(b, *L.x_work); // zero initial guess by construction
+  L.a->residual(*L.x_work, b, *L.res);
   L.restrictor->apply(*L.res, *L.b_coarse);
   amg_cycle(level + 1, *L.b_coarse, *L.x_coarse);
-  L.prolongator->apply_subtract(*L.x_coarse, x, OperatorMode::NO_TRANS);
-  L.smoother->apply(b, x);
+  L.prolongator->apply_subtract(*L.x_coarse, *L.x_work, OperatorMode::NO_TRANS);
+  L.smoother->apply_to(b, *L.x_work, x);
 }
 
 // ---- HipHierarchyHelpers ---------------------------------------------------------

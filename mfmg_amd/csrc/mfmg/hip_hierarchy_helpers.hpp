@@ -220,6 +220,8 @@ public:
   void apply(DVector const &b, DVector &x) const override;
   // same update when x is known to be zero on entry (content of x ignored); saves one operator application
   void apply_zero_guess(DVector const &b, DVector &x) const;
+  // same update from x_in into a different vector x_out (one polynomial term: no copy back from the scratch vector)
+  void apply_to(DVector const &b, DVector const &x_in, DVector &x_out) const;
 
   int degree() const { return (int)_coefficients.size(); }
   double lambda_min() const { return _lambda_min; }
@@ -259,7 +261,7 @@ public:
     std::shared_ptr<HipMatrixOperator> restrictor; // P^T as a matrix; its (lazy) transpose is P
     std::shared_ptr<HipMatrixOperator> prolongator;
     std::shared_ptr<HipSmoother> smoother;
-    mutable std::shared_ptr<DVector> res, b_coarse, x_coarse;
+    mutable std::shared_ptr<DVector> res, b_coarse, x_coarse, x_work;
   };
   std::vector<AmgLevel> const &amg_levels() const { return _amg; }
 

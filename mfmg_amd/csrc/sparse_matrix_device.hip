@@ -373,6 +373,25 @@ __global__ __launch_bounds__(256) void bdia_regular_node_kernel(CsrArgs<T> a, Bd
   }
 }
 
+// One wavefront over the CSR entries of one listed row (rows that are neither regular nor in a class): a thread per
+// row would walk the diagonals one dependent load after the other.
+template <typename T>
+__device__ __forceinline__ void listed_row_wave(CsrArgs<T> const &a, int32_t const *rows, int64_t n_listed, int64_t w,
+                                                int lane)
+{
+  if (w >= n_listed)
+    return;
+  const int64_t row = rows[w];
+  T sum = T(0);
+  for (int p = a.row_ptr[row] + lane, e = a.row_ptr[row + 1]; p < e; p += 64)
+    sum += a.val[p] * a.x[a.col[p]];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    sum += __shfl_xor(sum, off);
+  if (lane == 0)
+    bdia_store_row(a, row, sum);
+}
+
 // Non-regular nodes that repeat one stencil among themselves (the nodes at the same distance from the faces of a
 // box: boundary shells of a translation-invariant problem) are sorted by class, every class padded to whole
 // wavefronts (node -1): the class of a wavefront is uniform, its stencil constants are scalar loads like the
@@ -381,8 +400,15 @@ __global__ __launch_bounds__(256) void bdia_regular_node_kernel(CsrArgs<T> a, Bd
 template <typename T, int C>
 __global__ __launch_bounds__(256) void bdia_class_node_kernel(CsrArgs<T> a, BdiaRegular<T> g, int32_t const *nodes,
                                                               int32_t const *class_of_wave, T const *class_table,
-                                                              int64_t n_slots)
+                                                              int64_t n_slots, int32_t const *listed, int64_t n_listed)
 {
+  // the workgroups behind the class lists take the listed rows (a launch of their own would cost more than they do)
+  const int64_t class_blocks = (n_slots + 255) / 256;
+  if ((int64_t)blockIdx.x >= class_blocks)
+  {
+    listed_row_wave(a, listed, n_listed, ((int64_t)blockIdx.x - class_blocks) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+    return;
+  }
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= n_slots)
     return;
@@ -460,8 +486,18 @@ __global__ __launch_bounds__(256) void bdia_class_node_kernel(CsrArgs<T> a, Bdia
 template <typename T, int C, bool CLASSES, int P>
 __global__ __launch_bounds__(1024) void bdia_node_split_kernel(CsrArgs<T> a, BdiaRegular<T> g, int32_t const *nodes,
                                                                int32_t const *class_of_wave, T const *class_table,
-                                                               int64_t n_slots)
+                                                               int64_t n_slots, int32_t const *listed, int64_t n_listed)
 {
+  if constexpr (CLASSES)
+  {
+    const int64_t class_blocks = (n_slots + 1024 / P - 1) / (1024 / P);
+    if ((int64_t)blockIdx.x >= class_blocks) // (whole workgroups: nobody is left at the barrier below)
+    {
+      listed_row_wave(a, listed, n_listed, ((int64_t)blockIdx.x - class_blocks) * 16 + (threadIdx.x >> 6),
+                      threadIdx.x & 63);
+      return;
+    }
+  }
   // NB = 1024 / P consecutive nodes per workgroup (their stencils share cache lines), P parts of the stencil (4, or
   // 16 on the small levels where even that leaves most of the chip idle)
   constexpr int NB = 1024 / P;
@@ -536,24 +572,11 @@ __global__ __launch_bounds__(1024) void bdia_node_split_kernel(CsrArgs<T> a, Bdi
   }
 }
 
-// The few rows that are neither regular nor in a class: one wavefront per listed row over its CSR entries (a
-// thread per row would walk the diagonals one dependent load after the other).
+// the listed rows of a matrix without classes
 template <typename T>
 __global__ __launch_bounds__(256) void csr_listed_rows_kernel(CsrArgs<T> a, int32_t const *rows, int64_t n_listed)
 {
-  const int64_t w = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (w >= n_listed)
-    return;
-  const int64_t row = rows[w];
-  T sum = T(0);
-  for (int p = a.row_ptr[row] + lane, e = a.row_ptr[row + 1]; p < e; p += 64)
-    sum += a.val[p] * a.x[a.col[p]];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1)
-    sum += __shfl_xor(sum, off);
-  if (lane == 0)
-    bdia_store_row(a, row, sum);
+  listed_row_wave(a, rows, n_listed, (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, threadIdx.x & 63);
 }
 
 template <typename T, int C>
@@ -1352,17 +1375,21 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
     T const *ct = _nc_table.data();
     const bool split = g.Df >= kSplitStencil;
     const bool many_parts = g.Df >= 4 * kSplitStencil && _n_rows / _nc_c <= 131072;
+    int32_t const *ls = _nc_listed.data();
+    const int64_t n_listed = (int64_t)_nc_listed.size();
     auto launch_nodes = [&](auto cc) {
       constexpr int C = decltype(cc)::value;
       if (split && many_parts)
-        hipLaunchKernelGGL((bdia_node_split_kernel<T, C, true, 16>), dim3((unsigned int)((n_slots + 63) / 64)), dim3(1024),
-                           0, st, a, g, cn, cw, ct, n_slots);
+        hipLaunchKernelGGL((bdia_node_split_kernel<T, C, true, 16>),
+                           dim3((unsigned int)((n_slots + 63) / 64 + (n_listed + 15) / 16)), dim3(1024), 0, st, a, g, cn, cw,
+                           ct, n_slots, ls, n_listed);
       else if (split)
-        hipLaunchKernelGGL((bdia_node_split_kernel<T, C, true, 4>), dim3((unsigned int)((n_slots + 255) / 256)),
-                           dim3(1024), 0, st, a, g, cn, cw, ct, n_slots);
+        hipLaunchKernelGGL((bdia_node_split_kernel<T, C, true, 4>),
+                           dim3((unsigned int)((n_slots + 255) / 256 + (n_listed + 15) / 16)), dim3(1024), 0, st, a, g, cn,
+                           cw, ct, n_slots, ls, n_listed);
       else
-        hipLaunchKernelGGL((bdia_class_node_kernel<T, C>), dim3((unsigned int)((n_slots + 255) / 256)), dim3(256), 0, st,
-                           a, g, cn, cw, ct, n_slots);
+        hipLaunchKernelGGL((bdia_class_node_kernel<T, C>), dim3((unsigned int)((n_slots + 255) / 256 + (n_listed + 3) / 4)),
+                           dim3(256), 0, st, a, g, cn, cw, ct, n_slots, ls, n_listed);
     };
     switch (_nc_c)
     {
@@ -1379,10 +1406,6 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
       launch_nodes(std::integral_constant<int, 4>());
       break;
     }
-    const int64_t n_listed = (int64_t)_nc_listed.size();
-    if (n_listed > 0)
-      hipLaunchKernelGGL(csr_listed_rows_kernel<T>, dim3((unsigned int)((n_listed + 3) / 4)), dim3(256), 0, st, a,
-                         _nc_listed.data(), n_listed);
     KernelProfiler::end(stop, st);
     MFMG_HIP_CHECK(hipGetLastError());
     return;
@@ -1416,26 +1439,30 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
       const int64_t n_slots = (int64_t)_bdia_cls_nodes.size();
       int32_t const *cn = _bdia_cls_nodes.data(), *cw = _bdia_cls_of_wave.data();
       T const *ct = _bdia_cls_table.data();
+      // few listed rows ride at the end of the class launch, one wavefront each
+      const int64_t n_tail = (_bdia_n_classes > 0 && g.n_exc <= kListedWaveRows) ? g.n_exc : 0;
       auto launch_nodes = [&](auto cc) {
         constexpr int C = decltype(cc)::value;
         if (split && many_parts)
           hipLaunchKernelGGL((bdia_node_split_kernel<T, C, false, 16>), dim3((unsigned int)((n_nodes + 63) / 64)),
-                             dim3(1024), 0, st, a, g, nullptr, nullptr, nullptr, 0);
+                             dim3(1024), 0, st, a, g, nullptr, nullptr, nullptr, 0, nullptr, 0);
         else if (split)
           hipLaunchKernelGGL((bdia_node_split_kernel<T, C, false, 4>), dim3((unsigned int)((n_nodes + 255) / 256)),
-                             dim3(1024), 0, st, a, g, nullptr, nullptr, nullptr, 0);
+                             dim3(1024), 0, st, a, g, nullptr, nullptr, nullptr, 0, nullptr, 0);
         else
           hipLaunchKernelGGL((bdia_regular_node_kernel<T, C>), dim3((unsigned int)((n_nodes + 255) / 256)), dim3(256), 0,
                              st, a, g);
         if (_bdia_n_classes > 0 && split && many_parts)
-          hipLaunchKernelGGL((bdia_node_split_kernel<T, C, true, 16>), dim3((unsigned int)((n_slots + 63) / 64)),
-                             dim3(1024), 0, st, a, g, cn, cw, ct, n_slots);
+          hipLaunchKernelGGL((bdia_node_split_kernel<T, C, true, 16>),
+                             dim3((unsigned int)((n_slots + 63) / 64 + (n_tail + 15) / 16)), dim3(1024), 0, st, a, g, cn, cw,
+                             ct, n_slots, g.exc_rows, n_tail);
         else if (_bdia_n_classes > 0 && split)
-          hipLaunchKernelGGL((bdia_node_split_kernel<T, C, true, 4>), dim3((unsigned int)((n_slots + 255) / 256)),
-                             dim3(1024), 0, st, a, g, cn, cw, ct, n_slots);
+          hipLaunchKernelGGL((bdia_node_split_kernel<T, C, true, 4>),
+                             dim3((unsigned int)((n_slots + 255) / 256 + (n_tail + 15) / 16)), dim3(1024), 0, st, a, g, cn,
+                             cw, ct, n_slots, g.exc_rows, n_tail);
         else if (_bdia_n_classes > 0)
-          hipLaunchKernelGGL((bdia_class_node_kernel<T, C>), dim3((unsigned int)((n_slots + 255) / 256)), dim3(256), 0,
-                             st, a, g, cn, cw, ct, n_slots);
+          hipLaunchKernelGGL((bdia_class_node_kernel<T, C>), dim3((unsigned int)((n_slots + 255) / 256 + (n_tail + 3) / 4)),
+                             dim3(256), 0, st, a, g, cn, cw, ct, n_slots, g.exc_rows, n_tail);
       };
       switch (_bdia_c)
       {
@@ -1454,7 +1481,7 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
       }
       if (g.n_exc <= kListedWaveRows)
       {
-        if (g.n_exc > 0)
+        if (g.n_exc > 0 && n_tail == 0)
           hipLaunchKernelGGL(csr_listed_rows_kernel<T>, dim3((unsigned int)((g.n_exc + 3) / 4)), dim3(256), 0, st, a,
                              g.exc_rows, g.n_exc);
         KernelProfiler::end(stop, st);
