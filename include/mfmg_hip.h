@@ -119,10 +119,12 @@ int mfmg_hip_csr_create(mfmg_hip_context_t ctx, int64_t n_rows, int64_t n_cols, 
                         const double *val_host, mfmg_hip_csr_t *out);
 int mfmg_hip_csr_destroy(mfmg_hip_csr_t a);
 int mfmg_hip_csr_shape(mfmg_hip_csr_t a, int64_t *n_rows, int64_t *n_cols, int64_t *nnz); /* m(), n(), n_nonzero_elements() */
-/* tuning knob of the SpMV kernel: lanes of a wavefront per row (power of two 1..64, 0 = keep) and the storage
- * variant (0 plain CSR, 1 LDS-cached CSR, 2 block-diagonal (get reports 3 when only the upper half of a symmetric
- * matrix is stored), 4 row-base storage of rectangular stencil-like matrices, -1 = keep; a variant is only taken where its data was
- * built at construction); the summation order, hence the last bits of the result, follows both */
+/* tuning knob of the SpMV kernel: lanes of a wavefront per row (power of two 1..64; 256 = a workgroup per row, the
+ * choice for at most 4096 rows of 256 entries or more; 0 = keep) and the storage variant (0 plain CSR, 1 LDS-cached
+ * CSR, 2 block-diagonal (get reports 3 when only the upper half of a symmetric matrix is stored), 4 row-base storage
+ * of rectangular stencil-like matrices, 5 node classes (rectangular matrices whose rows repeat a few stencils: per-class
+ * tables instead of stored values), -1 = keep; a variant is only taken where its data was built at construction);
+ * the summation order, hence the last bits of the result, follows both */
 int mfmg_hip_csr_set_kernel(mfmg_hip_csr_t a, int lanes_per_row, int use_lds);
 int mfmg_hip_csr_get_kernel(mfmg_hip_csr_t a, int *lanes_per_row, int *use_lds);
 /* Rows of a symmetric block-diagonal matrix that repeat one stencil bit for bit (interior rows of the coarse operators

@@ -347,8 +347,9 @@ int mfmg_hip_csr_set_kernel(mfmg_hip_csr_t a, int lanes_per_row, int use_lds)
 {
   return guarded([&] {
     require(a != nullptr, "null matrix");
-    require(lanes_per_row >= 0 && lanes_per_row <= 64 && (lanes_per_row & (lanes_per_row - 1)) == 0,
-            "lanes_per_row must be 0 or a power of two up to 64");
+    require(lanes_per_row >= 0 && (lanes_per_row <= 64 || lanes_per_row == 256) &&
+                (lanes_per_row & (lanes_per_row - 1)) == 0,
+            "lanes_per_row must be 0, a power of two up to 64, or 256 (a workgroup per row)");
     a->op->get_matrix()->set_kernel(lanes_per_row, use_lds);
   });
 }

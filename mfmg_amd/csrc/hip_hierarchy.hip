@@ -728,8 +728,9 @@ void HipSolver::setup_direct(std::shared_ptr<SparseMatrixDevice<double>> matrix,
                                                           std::move(L.val), false);
   f.u_inv = std::make_shared<SparseMatrixDevice<double>>(_handle, n, n, std::move(U.row_ptr), std::move(U.col),
                                                         std::move(U.val), false);
-  f.l_inv_p->set_kernel(64, 0);
-  f.u_inv->set_kernel(64, 0);
+  // (triangular rows: half of them are long enough for a workgroup each)
+  f.l_inv_p->set_kernel(n >= 512 ? 256 : 64, 0);
+  f.u_inv->set_kernel(n >= 512 ? 256 : 64, 0);
   f.tmp.resize(n);
 }
 

@@ -125,13 +125,14 @@ public:
     auto &level_fine = _levels[level_index];
     auto a = level_fine.get_operator();
 
-    if (level_index > 0 || _is_preconditioner)
+    const bool coarsest = level_index == static_cast<int>(num_levels) - 1;
+    if ((level_index > 0 || _is_preconditioner) && !(coarsest && level_fine.get_solver()->ignores_initial_guess()))
     {
-      // Zero out any garbage in x (hierarchy.hpp:253-259).
+      // Zero out any garbage in x (hierarchy.hpp:253-259); a solver that does not read x needs no pass over it.
       x = 0.;
     }
 
-    if (level_index == static_cast<int>(num_levels) - 1)
+    if (coarsest)
     {
       timer_enter_subsection(_timer, "Apply: coarsest level");
       auto coarse_solver = level_fine.get_solver();

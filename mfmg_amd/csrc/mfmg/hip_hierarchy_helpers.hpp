@@ -251,6 +251,7 @@ public:
             std::vector<double> const *near_null = nullptr, AmgGridHint const *grid = nullptr);
 
   void apply(DVector const &b, DVector &x) const override;
+  bool ignores_initial_guess() const override { return true; } // every variant starts from zero by itself
   std::string const &type() const { return _solver; }
   int n_iterations() const { return _n_iterations; }
 

@@ -20,6 +20,9 @@ public:
   virtual ~Solver() = default;
 
   virtual void apply(vector_type const &b, vector_type &x) const = 0;
+  // true when apply() overwrites x without reading it: the hierarchy then skips its x = 0 (hierarchy.hpp:253-259)
+  // in front of the coarsest-level solve
+  virtual bool ignores_initial_guess() const { return false; }
 
 protected:
   std::shared_ptr<operator_type const> _operator;

@@ -42,6 +42,38 @@ struct CsrArgs
   int mode;
 };
 
+// the fused epilogues of a row (the modes of CsrMode)
+template <typename T>
+__device__ __forceinline__ void store_row(CsrArgs<T> const &a, int64_t row, T sum)
+{
+  T o;
+  switch (a.mode)
+  {
+  case 0:
+    o = sum;
+    break;
+  case 1:
+    o = sum - a.b[row];
+    break;
+  case 2:
+    o = a.x[row] - a.beta * a.dinv[row] * (sum - a.b[row]);
+    break;
+  case 3:
+  {
+    const T xr = a.x[row];
+    o = xr + a.alpha * (xr - a.xprev[row]) - a.beta * a.dinv[row] * (sum - a.b[row]);
+    break;
+  }
+  case 4:
+    o = a.out[row] - sum;
+    break;
+  default:
+    o = a.out[row] + sum;
+    break;
+  }
+  a.out[row] = o;
+}
+
 template <typename T, int LPR>
 __global__ void csr_spmv_kernel(CsrArgs<T> a)
 {
@@ -87,6 +119,27 @@ __global__ void csr_spmv_kernel(CsrArgs<T> a)
     }
     a.out[row] = o;
   }
+}
+
+// Few, long rows (the transfer operators and the triangular inverses at the bottom of the aggregation hierarchy:
+// about a thousand rows of about a thousand entries): a workgroup of four wavefronts per row, so that the chip is not
+// left with one wavefront per SIMD walking a long row; the four partial sums are added in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void csr_spmv_row_block_kernel(CsrArgs<T> a)
+{
+  __shared__ T part[4];
+  const int64_t row = blockIdx.x;
+  T sum = T(0);
+  for (int p = a.row_ptr[row] + (int)threadIdx.x, e = a.row_ptr[row + 1]; p < e; p += 256)
+    sum += a.val[p] * a.x[a.col[p]];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    sum += __shfl_xor(sum, off);
+  if ((threadIdx.x & 63) == 0)
+    part[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    store_row(a, row, ((part[0] + part[1]) + part[2]) + part[3]);
 }
 
 // LDS-cached SpMV: the x entries a block of rows touches are gathered once (coalesced through the sorted
@@ -229,38 +282,6 @@ __global__ __launch_bounds__(256) void bdia_spmv_kernel(CsrArgs<T> a, T const *v
   a.out[row] = o;
 }
 
-// the fused epilogues of a row (the modes of CsrMode)
-template <typename T>
-__device__ __forceinline__ void bdia_store_row(CsrArgs<T> const &a, int64_t row, T sum)
-{
-  T o;
-  switch (a.mode)
-  {
-  case 0:
-    o = sum;
-    break;
-  case 1:
-    o = sum - a.b[row];
-    break;
-  case 2:
-    o = a.x[row] - a.beta * a.dinv[row] * (sum - a.b[row]);
-    break;
-  case 3:
-  {
-    const T xr = a.x[row];
-    o = xr + a.alpha * (xr - a.xprev[row]) - a.beta * a.dinv[row] * (sum - a.b[row]);
-    break;
-  }
-  case 4:
-    o = a.out[row] - sum;
-    break;
-  default:
-    o = a.out[row] + sum;
-    break;
-  }
-  a.out[row] = o;
-}
-
 // Row-base storage for rectangular stencil-like matrices whose values do not repeat (prolongators of a problem with a
 // variable coefficient; with repeating values build_node_classes has them): every row couples to the same small box
 // of unknowns, placed relative to a per-row base column: val[s n_rows + row] for the slots s of a shared offset
@@ -284,7 +305,7 @@ __global__ __launch_bounds__(256) void rowbase_spmv_kernel(CsrArgs<T> a, T const
     if (c >= 0 && c < n_cols)
       sum += vp[(size_t)sidx * stride] * a.x[c];
   }
-  bdia_store_row(a, r, sum);
+  store_row(a, r, sum);
 }
 
 // Symmetric matrices keep only the block diagonals with offset >= 0 (half the bytes from HBM): the entry
@@ -389,7 +410,7 @@ __device__ __forceinline__ void listed_row_wave(CsrArgs<T> const &a, int32_t con
   for (int off = 32; off > 0; off >>= 1)
     sum += __shfl_xor(sum, off);
   if (lane == 0)
-    bdia_store_row(a, row, sum);
+    store_row(a, row, sum);
 }
 
 // Non-regular nodes that repeat one stencil among themselves (the nodes at the same distance from the faces of a
@@ -567,7 +588,7 @@ __global__ __launch_bounds__(1024) void bdia_node_split_kernel(CsrArgs<T> a, Bdi
 #pragma unroll
       for (int k = 0; k < P - 1; ++k)
         total += part[k][rc][lane];
-      bdia_store_row(a, node * C + rc, total);
+      store_row(a, node * C + rc, total);
     }
   }
 }
@@ -691,6 +712,8 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
     lpr *= 2;
   if (avg < 3.)
     lpr = avg < 1.5 ? 1 : 2;
+  if (n_rows <= 4096 && avg >= 256.)
+    lpr = 256; // a workgroup per row (csr_spmv_row_block_kernel)
   _lanes_per_row = lpr;
   // ---- block-diagonal storage (see bdia_spmv_kernel); when it applies the LDS lists are not needed
   if (n_rows == n_cols && n_rows >= 32768 && avg >= 8.)
@@ -1563,6 +1586,9 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
   }
   switch (_lanes_per_row)
   {
+  case 256:
+    hipLaunchKernelGGL(csr_spmv_row_block_kernel<T>, dim3((unsigned int)_n_rows), dim3(256), 0, st, a);
+    break;
   case 1:
     launch_lpr<T, 1>(a, st);
     break;

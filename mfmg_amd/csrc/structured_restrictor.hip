@@ -10,6 +10,10 @@
 //            every sector.
 #include "structured_restrictor.hpp"
 
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
 namespace mfmg
 {
 namespace
@@ -26,6 +30,9 @@ struct SrArgs
   uint8_t const *exc;
   uint8_t const *exc_node; // per fine node: 0 = every agglomerate it lies in is regular
   double const *table;
+  // the other agglomerates: class of the block they repeat (0xffff: a block of their own, read from the planes)
+  uint16_t const *cls;
+  double const *class_table; // [class][patch][n_eig]
 };
 
 __global__ __launch_bounds__(256) void sr_restrict_kernel(SrArgs s, double const *x, double *y)
@@ -58,7 +65,10 @@ __global__ __launch_bounds__(256) void sr_restrict_kernel(SrArgs s, double const
 // fetched once, the two plane entries in one 16-byte request); the sums are formed as in the row kernel
 __global__ __launch_bounds__(256) void sr_restrict_pair_kernel(SrArgs s, double const *x, double *y)
 {
-  const int64_t ag = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  // workgroups are dealt to the 8 XCDs in turn: give every XCD a contiguous run of agglomerates, so that the node
+  // planes two layers of agglomerates share stay in one L2 (the grid is a multiple of 8)
+  const int64_t bid = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t ag = bid * (int64_t)blockDim.x + threadIdx.x;
   if (2 * ag >= s.n_coarse)
     return;
   const int ai = ag % s.na[0], aj = (ag / s.na[0]) % s.na[1], ak = ag / ((int64_t)s.na[0] * s.na[1]);
@@ -66,6 +76,9 @@ __global__ __launch_bounds__(256) void sr_restrict_pair_kernel(SrArgs s, double 
   double2 const *p = reinterpret_cast<double2 const *>(s.planes) + ag;
   const size_t stride = (size_t)s.n_coarse / 2;
   const bool regular = s.exc != nullptr && s.exc[ag] == 0;
+  // a block shared with other agglomerates comes from the class table (cached) instead of the planes (HBM)
+  const unsigned int cl = (!regular && s.cls != nullptr) ? s.cls[ag] : 0xffffu;
+  double2 const *ct = reinterpret_cast<double2 const *>(s.class_table) + (size_t)(cl == 0xffffu ? 0 : cl) * s.patch;
   double sum0 = 0., sum1 = 0.;
   int m = 0;
   for (int mz = 0; mz <= s.a[2]; ++mz)
@@ -80,6 +93,8 @@ __global__ __launch_bounds__(256) void sr_restrict_pair_kernel(SrArgs s, double 
         double2 pv;
         if (regular)
           pv = make_double2(s.table[2 * m], s.table[2 * m + 1]); // wave-uniform address
+        else if (cl != 0xffffu)
+          pv = ct[m];
         else
           pv = p[(size_t)m * stride];
         const double xv = x[id];
@@ -132,8 +147,15 @@ __device__ __forceinline__ double sr_node_value(SrArgs const &s, double const *y
         {
           // both eigenvectors of the agglomerate in one 16-byte request (rows 2 ag, 2 ag + 1 are adjacent)
           const double2 yv = *reinterpret_cast<double2 const *>(yy);
-          const double2 pv = table ? *reinterpret_cast<double2 const *>(s.table + 2 * m)
-                                   : *reinterpret_cast<double2 const *>(p);
+          double2 pv;
+          if (table)
+            pv = *reinterpret_cast<double2 const *>(s.table + 2 * m);
+          else
+          {
+            const unsigned int cl = s.cls != nullptr ? s.cls[ag] : 0xffffu;
+            pv = cl != 0xffffu ? reinterpret_cast<double2 const *>(s.class_table)[(size_t)cl * s.patch + m]
+                               : *reinterpret_cast<double2 const *>(p);
+          }
           sum += pv.x * yv.x;
           sum += pv.y * yv.y;
         }
@@ -342,6 +364,72 @@ StructuredRestrictorDevice::create(HipHandle &handle, StructuredMesh const &mesh
     }
     if (n_regular * 2 >= n_agg)
     {
+      // classes among the others (hash of the block, exact comparison with the first agglomerate of the class)
+      {
+        std::vector<int64_t> others;
+        for (int64_t ag = 0; ag < n_agg; ++ag)
+          if (exc[ag])
+            others.push_back(ag);
+        std::vector<uint64_t> hash(others.size());
+#pragma omp parallel for schedule(static)
+        for (int64_t q = 0; q < (int64_t)others.size(); ++q)
+        {
+          uint64_t h = 1469598103934665603ull;
+          for (int m = 0; m < patch; ++m)
+            for (int e = 0; e < n_eig; ++e)
+            {
+              uint64_t bits;
+              std::memcpy(&bits, &planes[(size_t)m * R.n_rows + others[q] * n_eig + e], 8);
+              h = (h ^ bits) * 1099511628211ull;
+              h ^= h >> 29;
+            }
+          hash[q] = h;
+        }
+        std::vector<int64_t> order(others.size());
+        std::iota(order.begin(), order.end(), (int64_t)0);
+        std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return hash[x] != hash[y] ? hash[x] < hash[y] : x < y; });
+        std::vector<uint16_t> cls(n_agg, kNoClass);
+        std::vector<double> class_table;
+        auto push_block = [&](int64_t ag) {
+          for (int m = 0; m < patch; ++m)
+            for (int e = 0; e < n_eig; ++e)
+              class_table.push_back(planes[(size_t)m * R.n_rows + ag * n_eig + e]);
+        };
+        push_block(ref); // class 0: the reference block
+        for (int64_t ag = 0; ag < n_agg; ++ag)
+          if (!exc[ag])
+            cls[ag] = 0;
+        int n_classes = 1;
+        for (size_t g0 = 0; g0 < order.size() && n_classes < 0xfff0;)
+        {
+          size_t g1 = g0;
+          while (g1 < order.size() && hash[order[g1]] == hash[order[g0]])
+            ++g1;
+          if (g1 - g0 >= 4)
+          {
+            const int64_t rep = others[order[g0]];
+            int64_t members = 0;
+            for (size_t q = g0; q < g1; ++q)
+              if (same(others[order[q]], rep))
+              {
+                cls[others[order[q]]] = (uint16_t)n_classes;
+                ++members;
+              }
+            if (members > 0)
+            {
+              push_block(rep);
+              ++n_classes;
+            }
+          }
+          g0 = g1;
+        }
+        if (n_classes > 1)
+        {
+          s->_cls.upload(cls.data(), cls.size(), handle.stream);
+          s->_class_table.upload(class_table.data(), class_table.size(), handle.stream);
+          s->_n_classes = n_classes - 1;
+        }
+      }
       std::vector<double> table((size_t)patch * n_eig);
       for (int m = 0; m < patch; ++m)
         for (int e = 0; e < n_eig; ++e)
@@ -411,7 +499,8 @@ double StructuredRestrictorDevice::algorithmic_bytes() const
 namespace
 {
 SrArgs make_args(double const *planes, int32_t const *node_dof, int64_t n_coarse, int const N[3], int const na[3],
-                 int const a[3], int n_eig, int patch, uint8_t const *exc, uint8_t const *exc_node, double const *table)
+                 int const a[3], int n_eig, int patch, uint8_t const *exc, uint8_t const *exc_node, double const *table,
+                 uint16_t const *cls, double const *class_table)
 {
   SrArgs s;
   s.planes = planes;
@@ -428,6 +517,8 @@ SrArgs make_args(double const *planes, int32_t const *node_dof, int64_t n_coarse
   s.exc = exc;
   s.exc_node = exc_node;
   s.table = table;
+  s.cls = cls;
+  s.class_table = class_table;
   return s;
 }
 } // namespace
@@ -436,11 +527,12 @@ void StructuredRestrictorDevice::restrict_to_coarse(double const *x, double *y) 
 {
   ASSERT_THROW(x != nullptr && y != nullptr && x != y, "bad vectors");
   SrArgs s = make_args(_planes.data(), _identity_numbering ? nullptr : _node_dof.data(), _n_coarse, _N, _na, _a,
-                       _n_eig, _patch, _exc.size() ? _exc.data() : nullptr, _exc_node.size() ? _exc_node.data() : nullptr, _table.data());
+                       _n_eig, _patch, _exc.size() ? _exc.data() : nullptr, _exc_node.size() ? _exc_node.data() : nullptr, _table.data(),
+                       _cls.size() ? _cls.data() : nullptr, _class_table.data());
   hipEvent_t stop = _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes(), _handle.stream);
   if (_n_eig == 2)
-    hipLaunchKernelGGL(sr_restrict_pair_kernel, dim3((unsigned int)((_n_coarse / 2 + 255) / 256)), dim3(256), 0,
-                       _handle.stream, s, x, y);
+    hipLaunchKernelGGL(sr_restrict_pair_kernel, dim3((unsigned int)(((_n_coarse / 2 + 255) / 256 + 7) / 8 * 8)),
+                       dim3(256), 0, _handle.stream, s, x, y);
   else
     hipLaunchKernelGGL(sr_restrict_kernel, dim3((unsigned int)((_n_coarse + 255) / 256)), dim3(256), 0,
                        _handle.stream, s, x, y);
@@ -452,7 +544,8 @@ void StructuredRestrictorDevice::prolongate(double const *y, double *out, bool s
 {
   ASSERT_THROW(y != nullptr && out != nullptr && y != out, "bad vectors");
   SrArgs s = make_args(_planes.data(), _identity_numbering ? nullptr : _node_dof.data(), _n_coarse, _N, _na, _a,
-                       _n_eig, _patch, _exc.size() ? _exc.data() : nullptr, _exc_node.size() ? _exc_node.data() : nullptr, _table.data());
+                       _n_eig, _patch, _exc.size() ? _exc.data() : nullptr, _exc_node.size() ? _exc_node.data() : nullptr, _table.data(),
+                       _cls.size() ? _cls.data() : nullptr, _class_table.data());
   hipEvent_t stop = _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes() + (subtract ? 8. * double(_n_fine) : 0.),
                                            _handle.stream);
   if (_blk_exc.size() > 0)

@@ -47,6 +47,17 @@ private:
   DeviceBuffer<uint8_t> _blk_exc;  // per agglomerate position (na + 1 per direction): 0 = table-driven block kernel
   DeviceBuffer<int32_t> _exc_blocks; // the other positions
   DeviceBuffer<double> _table;    // [patch][n_eig]
+  // the other agglomerates that repeat a block among themselves (at the same distance from the faces of the box):
+  // class per agglomerate (0 = the reference block, kNoClass = a block of its own -> planes) and the class blocks
+  static constexpr uint16_t kNoClass = 0xffff;
+  DeviceBuffer<uint16_t> _cls;
+  DeviceBuffer<double> _class_table; // [class][patch][n_eig]
+  int _n_classes = 0;
+
+public:
+  int block_classes() const { return _n_classes; }
+
+private:
   DeviceBuffer<int32_t> _node_dof; // DoF id of lexicographic node (empty when the numbering is lexicographic)
 };
 } // namespace mfmg

@@ -167,6 +167,42 @@ def test_csr_degenerate_shapes(ctx):
         assert Ad.transpose().shape == (A.shape[1], A.shape[0])
 
 
+def test_csr_few_long_rows(ctx):
+    """About a thousand rows of about a thousand entries (the bottom of the aggregation hierarchy: transfer operators,
+    dense triangular inverses): a workgroup per row; every fused mode, and against a wavefront per row."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(41)
+    n = 700
+    A = sp.random(n, n, density=0.6, random_state=np.random.default_rng(5), format="csr") + sp.diags(np.full(n, 50.0))
+    A = A.tocsr()
+    A[13, :] = 0.0                                          # an empty row and a short one
+    A[14, :] = 0.0
+    A[14, 3] = 2.0
+    A.eliminate_zeros()
+    A.sort_indices()
+    Ad = M.SparseMatrixDevice(ctx, A)
+    assert Ad.get_kernel() == (256, 0)
+    x, b, xp = rng.random(n), rng.random(n), rng.random(n)
+    dinv = rng.random(n)
+    ref = A @ x
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    for lanes in (256, 64):
+        Ad.set_kernel(lanes, -1)
+        Ad.vmult(out, dev(x))
+        assert relerr(host(out, ctx), ref) < TOL
+        Ad.residual(dev(x), dev(b), out)
+        assert relerr(host(out, ctx), ref - b) < TOL
+        Ad.smoother_step(dev(dinv), dev(b), dev(x), dev(xp), 0.25, 0.6, out)
+        assert relerr(host(out, ctx), x + 0.25 * (x - xp) - 0.6 * dinv * (ref - b)) < TOL
+    T = sp.random(900, 5000, density=0.1, random_state=np.random.default_rng(6), format="csr")   # rectangular
+    Td = M.SparseMatrixDevice(ctx, T)
+    assert Td.get_kernel()[0] == 256
+    xw = rng.random(5000)
+    yw = torch.empty(900, dtype=torch.float64, device="cuda")
+    Td.vmult(yw, dev(xw))
+    assert relerr(host(yw, ctx), T @ xw) < TOL
+
+
 @pytest.mark.parametrize("material,expect", [("constant", True), ("linear", False), ("cellwise", True)])
 def test_mf_cell_constant_layout(ctx, material, expect):
     """One coefficient per cell where a cell's eight quadrature values are equal: chosen automatically, same
