@@ -11,6 +11,7 @@
 #include "amge_structured.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -706,6 +707,7 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
   for (int64_t p = 0; p < _nnz; ++p)
     ASSERT_THROW(col[p] >= 0 && col[p] < n_cols, "column index out of range");
   const double avg = n_rows > 0 ? double(_nnz) / double(n_rows) : 0.;
+  const auto t_begin = std::chrono::steady_clock::now();
   // lanes per row: about 3-6 entries per lane (measured on R, R^T, A_c and the prolongators, profiles/)
   int lpr = 4;
   while (lpr < 64 && lpr * 2 <= avg / 3.3)
@@ -774,10 +776,11 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
   if (std::getenv("MFMG_HIP_VERBOSE") != nullptr)
     std::fprintf(stderr,
                  "[mfmg_hip] matrix %lld x %lld, %.1f entries per row: kernel kind %d (lanes per row %d; block diagonals %d x "
-                 "%d components%s, regular rows %d, stencil classes %d, listed rows %lld; row-base slots %d; node classes %d of %d x %d components, %lld rows listed)\n",
+                 "%d components%s, regular rows %d, stencil classes %d, listed rows %lld; row-base slots %d; node classes %d of %d x %d components, %lld rows listed), %.2f s\n",
                  (long long)_n_rows, (long long)_n_cols, avg, kernel_kind(), _lanes_per_row, _bdia_d, _bdia_c,
                  _bdia_sym ? " (symmetric half)" : "", (int)_bdia_regular, _bdia_n_classes,
-                 (long long)_bdia_exc_rows.size(), _rb_slots, _nc_classes, _nc_d, _nc_c, (long long)_nc_listed.size());
+                 (long long)_bdia_exc_rows.size(), _rb_slots, _nc_classes, _nc_d, _nc_c, (long long)_nc_listed.size(),
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
   _val.upload(val.data(), val.size(), handle.stream);
   _col.upload(col.data(), col.size(), handle.stream);
   _row_ptr.upload(row_ptr.data(), row_ptr.size(), handle.stream);
