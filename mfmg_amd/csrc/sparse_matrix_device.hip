@@ -669,6 +669,7 @@ __global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, T cons
 }
 
 constexpr size_t kMaxBlockDiagonals = 400; // (343: the third level of the aggregation hierarchy of a Q1 problem)
+constexpr int kMaxStoredBlockDiagonals = 160;
 constexpr int kSplitStencil = 48;        // block diagonals from which a node's stencil is split over four wavefronts
 constexpr int64_t kListedWaveRows = 32768; // listed rows up to which each gets a wavefront of its own
 
@@ -1038,6 +1039,10 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
       _bdia_regular = true;
     }
   }
+  // stored planes pay up to ~160 block diagonals (one thread walks a row: with more the LDS-cached CSR kernel,
+  // several lanes per row, is faster); wider stencils are kept only for their tables
+  if (D > kMaxStoredBlockDiagonals && !_bdia_regular)
+    return;
   // symmetric (to rounding)?  then the diagonals with a negative offset are the transposes of the positive ones
   bool symmetric = (D % 2 == 1);
   const int zero = D / 2;
