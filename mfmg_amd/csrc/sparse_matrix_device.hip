@@ -601,6 +601,50 @@ __global__ __launch_bounds__(256) void csr_listed_rows_kernel(CsrArgs<T> a, int3
   listed_row_wave(a, rows, n_listed, (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, threadIdx.x & 63);
 }
 
+// The same sums for a whole matrix with the block diagonals dealt to the four quarters of a 1024-thread workgroup
+// (256 consecutive rows): four times the wavefronts, each with a quarter of the dependent loads; no branches
+// around the loads (a neighbour outside the matrix is read at a clamped position and its entry replaced by 0), the
+// quarters are added in a fixed order through LDS.
+template <typename T, int C>
+__global__ __launch_bounds__(1024) void bdia_sym_split_kernel(CsrArgs<T> a, T const *val, int32_t const *offs, int D)
+{
+  __shared__ T part[3][256];
+  const int q = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)), lane = threadIdx.x & 255;
+  const int64_t r = (int64_t)blockIdx.x * 256 + lane;
+  const bool active = r < a.n_rows;
+  const int64_t rr = active ? r : a.n_rows - 1;
+  const int64_t last = a.n_rows / C - 1;
+  const int64_t node = rr / C;
+  const int c = (int)(rr - node * C);
+  const size_t stride = (size_t)a.n_rows;
+  T const *vp = val + rr;
+  const int d0 = (D * q) / 4, d1 = (D * (q + 1)) / 4;
+  T sum = T(0);
+#pragma unroll 4
+  for (int d = d0; d < d1; ++d) // offs[0] = 0 < offs[1] < ...; the entry of a neighbour behind the last node is 0
+  {
+    const int64_t nb = min(node + offs[d], last);
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc)
+      sum += vp[(size_t)(d * C + cc) * stride] * a.x[nb * C + cc];
+  }
+#pragma unroll 4
+  for (int d = max(d0, 1); d < d1; ++d)
+  {
+    const int64_t nbu = node - offs[d];
+    const int64_t nb = max(nbu, (int64_t)0);
+    T const *vq = val + (size_t)(d * C + c) * stride + nb * C;
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc)
+      sum += (nbu >= 0 ? vq[cc] : T(0)) * a.x[nb * C + cc];
+  }
+  if (q > 0)
+    part[q - 1][lane] = sum;
+  __syncthreads();
+  if (q == 0 && active)
+    store_row(a, r, ((sum + part[0][lane]) + part[1][lane]) + part[2][lane]);
+}
+
 template <typename T, int C>
 __global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, T const *val, int32_t const *offs, int D,
                                                             BdiaRegular<T> g)
@@ -1521,6 +1565,28 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
       }
     }
     const dim3 rgrid((unsigned int)(((g.exc != nullptr ? g.n_exc : _n_rows) + 255) / 256));
+    if (_bdia_sym && g.exc == nullptr)
+    {
+      const dim3 sgrid((unsigned int)((_n_rows + 255) / 256));
+      switch (_bdia_c)
+      {
+      case 1:
+        hipLaunchKernelGGL((bdia_sym_split_kernel<T, 1>), sgrid, dim3(1024), 0, st, a, dv, of, _bdia_d);
+        break;
+      case 2:
+        hipLaunchKernelGGL((bdia_sym_split_kernel<T, 2>), sgrid, dim3(1024), 0, st, a, dv, of, _bdia_d);
+        break;
+      case 3:
+        hipLaunchKernelGGL((bdia_sym_split_kernel<T, 3>), sgrid, dim3(1024), 0, st, a, dv, of, _bdia_d);
+        break;
+      default:
+        hipLaunchKernelGGL((bdia_sym_split_kernel<T, 4>), sgrid, dim3(1024), 0, st, a, dv, of, _bdia_d);
+        break;
+      }
+      KernelProfiler::end(stop, st);
+      MFMG_HIP_CHECK(hipGetLastError());
+      return;
+    }
     if (_bdia_sym)
     {
       if (rgrid.x > 0)
