@@ -63,8 +63,12 @@ __global__ __launch_bounds__(256) void sr_restrict_kernel(SrArgs s, double const
 
 // two eigenvectors per agglomerate: one thread per agglomerate, both rows at once (the x values of the patch are
 // fetched once, the two plane entries in one 16-byte request); the sums are formed as in the row kernel
+// A = 2: 2 x 2 x 2 agglomerates with the loops unrolled, so that the 27 independent requests of a thread are in
+// flight together (with run-time bounds they went out three at a time: latency, not bytes); A = 0: any size
+template <int A>
 __global__ __launch_bounds__(256) void sr_restrict_pair_kernel(SrArgs s, double const *x, double *y)
 {
+  const int a0 = A > 0 ? A : s.a[0], a1 = A > 0 ? A : s.a[1], a2 = A > 0 ? A : s.a[2];
   // workgroups are dealt to the 8 XCDs in turn: give every XCD a contiguous run of agglomerates, so that the node
   // planes two layers of agglomerates share stay in one L2 (the grid is a multiple of 8)
   const int64_t bid = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256) void sr_restrict_pair_kernel(SrArgs s, double 
   if (2 * ag >= s.n_coarse)
     return;
   const int ai = ag % s.na[0], aj = (ag / s.na[0]) % s.na[1], ak = ag / ((int64_t)s.na[0] * s.na[1]);
-  const int64_t base = (int64_t)ai * s.a[0] + (int64_t)s.N[0] * ((int64_t)aj * s.a[1] + (int64_t)s.N[1] * ((int64_t)ak * s.a[2]));
+  const int64_t base = (int64_t)ai * a0 + (int64_t)s.N[0] * ((int64_t)aj * a1 + (int64_t)s.N[1] * ((int64_t)ak * a2));
   double2 const *p = reinterpret_cast<double2 const *>(s.planes) + ag;
   const size_t stride = (size_t)s.n_coarse / 2;
   const bool regular = s.exc != nullptr && s.exc[ag] == 0;
@@ -80,28 +84,71 @@ __global__ __launch_bounds__(256) void sr_restrict_pair_kernel(SrArgs s, double 
   const unsigned int cl = (!regular && s.cls != nullptr) ? s.cls[ag] : 0xffffu;
   double2 const *ct = reinterpret_cast<double2 const *>(s.class_table) + (size_t)(cl == 0xffffu ? 0 : cl) * s.patch;
   double sum0 = 0., sum1 = 0.;
-  int m = 0;
-  for (int mz = 0; mz <= s.a[2]; ++mz)
-    for (int my = 0; my <= s.a[1]; ++my)
+  if constexpr (A == 2)
+  {
+    // all 27 x requests first (they do not depend on where the weights come from), then one loop per source
+    double xv[27];
+#pragma unroll
+    for (int m = 0; m < 27; ++m)
     {
-      const int64_t row = base + (int64_t)s.N[0] * (my + (int64_t)s.N[1] * mz);
-#pragma unroll 3
-      for (int mx = 0; mx <= s.a[0]; ++mx, ++m)
+      const int64_t node = base + (m % 3) + (int64_t)s.N[0] * ((m / 3) % 3 + (int64_t)s.N[1] * (m / 9));
+      xv[m] = x[s.node_dof ? (int64_t)s.node_dof[node] : node];
+    }
+    if (regular)
+    {
+#pragma unroll
+      for (int m = 0; m < 27; ++m)
       {
-        const int64_t node = row + mx;
-        const int64_t id = s.node_dof ? (int64_t)s.node_dof[node] : node;
-        double2 pv;
-        if (regular)
-          pv = make_double2(s.table[2 * m], s.table[2 * m + 1]); // wave-uniform address
-        else if (cl != 0xffffu)
-          pv = ct[m];
-        else
-          pv = p[(size_t)m * stride];
-        const double xv = x[id];
-        sum0 += pv.x * xv;
-        sum1 += pv.y * xv;
+        sum0 += s.table[2 * m] * xv[m]; // wave-uniform addresses
+        sum1 += s.table[2 * m + 1] * xv[m];
       }
     }
+    else if (cl != 0xffffu)
+    {
+#pragma unroll
+      for (int m = 0; m < 27; ++m)
+      {
+        const double2 pv = ct[m];
+        sum0 += pv.x * xv[m];
+        sum1 += pv.y * xv[m];
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int m = 0; m < 27; ++m)
+      {
+        const double2 pv = p[(size_t)m * stride];
+        sum0 += pv.x * xv[m];
+        sum1 += pv.y * xv[m];
+      }
+    }
+  }
+  else
+  {
+    int m = 0;
+    for (int mz = 0; mz <= a2; ++mz)
+      for (int my = 0; my <= a1; ++my)
+      {
+        const int64_t row = base + (int64_t)s.N[0] * (my + (int64_t)s.N[1] * mz);
+#pragma unroll 3
+        for (int mx = 0; mx <= a0; ++mx, ++m)
+        {
+          const int64_t node = row + mx;
+          const int64_t id = s.node_dof ? (int64_t)s.node_dof[node] : node;
+          double2 pv;
+          if (regular)
+            pv = make_double2(s.table[2 * m], s.table[2 * m + 1]); // wave-uniform address
+          else if (cl != 0xffffu)
+            pv = ct[m];
+          else
+            pv = p[(size_t)m * stride];
+          const double xv = x[id];
+          sum0 += pv.x * xv;
+          sum1 += pv.y * xv;
+        }
+      }
+  }
   reinterpret_cast<double2 *>(y)[ag] = make_double2(sum0, sum1);
 }
 
@@ -531,8 +578,13 @@ void StructuredRestrictorDevice::restrict_to_coarse(double const *x, double *y) 
                        _cls.size() ? _cls.data() : nullptr, _class_table.data());
   hipEvent_t stop = _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes(), _handle.stream);
   if (_n_eig == 2)
-    hipLaunchKernelGGL(sr_restrict_pair_kernel, dim3((unsigned int)(((_n_coarse / 2 + 255) / 256 + 7) / 8 * 8)),
-                       dim3(256), 0, _handle.stream, s, x, y);
+  {
+    const dim3 grid((unsigned int)(((_n_coarse / 2 + 255) / 256 + 7) / 8 * 8));
+    if (_a[0] == 2 && _a[1] == 2 && _a[2] == 2)
+      hipLaunchKernelGGL(sr_restrict_pair_kernel<2>, grid, dim3(256), 0, _handle.stream, s, x, y);
+    else
+      hipLaunchKernelGGL(sr_restrict_pair_kernel<0>, grid, dim3(256), 0, _handle.stream, s, x, y);
+  }
   else
     hipLaunchKernelGGL(sr_restrict_kernel, dim3((unsigned int)((_n_coarse + 255) / 256)), dim3(256), 0,
                        _handle.stream, s, x, y);
