@@ -252,8 +252,9 @@ int mfmg_hip_hierarchy_set_restrictor(mfmg_hip_hierarchy_t h, int64_t n_rows, in
 /* restrictor / coarse operator download for inspection: query sizes with *_shape first */
 int mfmg_hip_hierarchy_get_restrictor(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *r_borrowed);
 int mfmg_hip_hierarchy_get_coarse_operator(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *ac_borrowed);
-/* levels of the multilevel coarse solver (0 when the coarse solver is direct / pcg): operator A_l,
- * prolongator P_l (which = 0 / 1, borrowed handles) and the Chebyshev bounds of its smoother */
+/* levels of the multilevel coarse solver (0 when the coarse solver is direct / pcg): operator A_l, prolongator P_l,
+ * its transpose as stored for the restriction (which = 0 / 1 / 2; a borrowed handle, valid until the next call) and the
+ * Chebyshev bounds of its smoother */
 int mfmg_hip_hierarchy_coarse_amg_levels(mfmg_hip_hierarchy_t h, int32_t *n_levels);
 int mfmg_hip_hierarchy_coarse_amg_get(mfmg_hip_hierarchy_t h, int32_t level, int32_t which, mfmg_hip_csr_t *borrowed);
 int mfmg_hip_hierarchy_coarse_amg_smoother(mfmg_hip_hierarchy_t h, int32_t level, int32_t *degree, double *lambda_min,

@@ -430,6 +430,25 @@ class Hierarchy:
             out.append((A, P, cheb))
         return out
 
+    def coarse_amg_kernels(self, regular_rows=None):
+        """[(level, which, rows, kernel kind, stencil classes, listed rows)] of the matrices of the multilevel coarse
+        solver (which: 0 A_l, 1 P_l, 2 its stored transpose); regular_rows True / False switches the table-driven paths
+        of all of them on / off first (tests: both must give the same cycle to rounding)."""
+        n = C.c_int32()
+        check(self._lib.mfmg_hip_hierarchy_coarse_amg_levels(self.handle, C.byref(n)))
+        out = []
+        for l in range(n.value):
+            for which in (0, 1, 2):
+                if which > 0 and l + 1 == n.value:
+                    continue
+                h = C.c_void_p()                              # (one borrowed view at a time)
+                check(self._lib.mfmg_hip_hierarchy_coarse_amg_get(self.handle, l, which, C.byref(h)))
+                m = SparseMatrixDevice(self.ctx, _handle=h, _borrowed=True, _keepalive=self)
+                if regular_rows is not None:
+                    m.set_regular_rows(regular_rows)
+                out.append((l, which, m.shape[0], m.get_kernel()[1]) + tuple(m.stencil_classes()))
+        return out
+
     def coarse_amg_shapes(self):
         """[(rows, nnz(A_l), nnz(P_l) or 0)] of the multilevel coarse solver (no download)."""
         n = C.c_int32()

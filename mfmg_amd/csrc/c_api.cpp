@@ -879,9 +879,9 @@ int mfmg_hip_hierarchy_coarse_amg_get(mfmg_hip_hierarchy_t h, int32_t level, int
     require(borrowed != nullptr, "null argument");
     auto const &lv = coarse_solver_of(h)->amg_levels();
     require(level >= 0 && level < (int)lv.size(), "level out of range");
-    require(which == 0 || which == 1, "which must be 0 (A) or 1 (P)");
-    auto op = which == 0 ? lv[level].a : lv[level].prolongator;
-    require(op != nullptr, "the last level has no prolongator");
+    require(which >= 0 && which <= 2, "which must be 0 (A), 1 (P) or 2 (P^T as stored for the restriction)");
+    auto op = which == 0 ? lv[level].a : which == 1 ? lv[level].prolongator : lv[level].restrictor;
+    require(op != nullptr, "the last level has no transfer operators");
     h->amg_view.op = op;
     h->amg_view.borrowed = true;
     *borrowed = &h->amg_view;

@@ -423,6 +423,23 @@ def test_full_size_hierarchy_properties(ctx):
     # the layouts the design relies on were actually chosen at this size
     assert h.coarse_operator().get_kernel()[1] == 3          # block diagonals for A_c, upper half stored
     assert h.operator_tile() == (4, 3, 8)
+    kernels = {(l, w): (rows, kind, classes, listed) for l, w, rows, kind, classes, listed in h.coarse_amg_kernels()}
+    for l in (0, 1, 2):                                      # A_c and the two levels below: tables for >= 99.9 % of the rows
+        rows, kind, classes, listed = kernels[(l, 0)]
+        assert kind == 3 and classes >= 50 and listed <= 0.02 * rows, kernels[(l, 0)]
+    for key in ((0, 1), (0, 2), (1, 1), (1, 2)):             # the first two prolongators and their transposes: node classes
+        rows, kind, classes, listed = kernels[key]
+        assert kind == 5 and classes >= 10 and listed <= 0.02 * rows, (key, kernels[key])
+    # the table-driven paths against the stored values / plain CSR kernels of the same matrices: same cycle to rounding
+    h.coarse_amg_kernels(regular_rows=False)
+    xx2 = x.clone()
+    norms2 = []
+    for _ in range(5):
+        h.operator_apply(0, xx2, r)
+        norms2.append(ctx.l2_norm(r))
+        h.apply(b, xx2)
+    h.coarse_amg_kernels(regular_rows=True)
+    np.testing.assert_allclose(norms2, norms, rtol=1e-10)
 
 
 def test_outer_cg_driver_matches_oracle(ctx):
