@@ -295,11 +295,13 @@ def test_smoother_bounds_cover_the_spectrum_at_row_length_128(ctx):
     assert norms[3] < norms[2] < norms[1] < norms[0]
 
 
-@pytest.mark.parametrize("n_cycles", [1, 2])
-def test_amg_coarse_solver_parity(ctx, n_cycles):
+@pytest.mark.parametrize("n_cycles,cells", [(1, 32), (2, 32), (1, 64), (1, 128)])
+def test_amg_coarse_solver_parity(ctx, n_cycles, cells):
     """solver.type amg: the V-cycle over the aggregation hierarchy on the GPU against its oracle restatement,
-    run on the level matrices downloaded from the product."""
-    n = (32, 32, 32)
+    run on the level matrices downloaded from the product.  64 cells per direction: A_c (65536 rows) in block-diagonal
+    storage with regular rows, stencil classes and listed rows, its prolongator in node classes, the restrictor with
+    block classes -- the table-driven kernels against the oracle's scipy products of the same matrices."""
+    n = (cells,) * 3
     mesh = O.StructuredMesh(n)
     coef = O.coefficient_table(mesh, "constant")
     con = mesh.constrained_mask()
@@ -309,7 +311,10 @@ def test_amg_coarse_solver_parity(ctx, n_cycles):
                          solver={"type": "amg", "amg": {"coarsest_size": 600, "n_cycles": n_cycles}})
     h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
     levels = h.coarse_amg_levels()
-    assert [A.shape[0] for A, _, _ in levels] == [8192, 1024, 128]
+    assert [A.shape[0] for A, _, _ in levels] == {32: [8192, 1024, 128], 64: [65536, 8192, 1024, 128], 128: [524288, 65536, 8192, 1024, 128]}[cells]
+    if cells >= 64:
+        kernels = {(l, w): (kind, classes) for l, w, _, kind, classes, _ in h.coarse_amg_kernels()}
+        assert kernels[(0, 0)][0] == 3 and kernels[(0, 0)][1] >= 20 and kernels[(0, 1)][0] == 5
     deg, lmin, lmax = h.smoother_info()
     R = h.restrictor().to_scipy()
     # coarse solve alone
@@ -325,9 +330,10 @@ def test_amg_coarse_solver_parity(ctx, n_cycles):
     ho = O.TwoLevelHierarchy(mf.vmult, smoother, R, solve, 1, False)
     x0 = O.random_initial_guess(mesh.n_dofs, con)
     b = np.zeros(mesh.n_dofs)
-    res_o, rate, _ = O.vcycle_history(ho, mf.vmult, b, x0, n_cycles=10)
+    n_hist = 10 if cells <= 64 else 4          # (the numpy operator takes a second per application at 129^3 DoFs)
+    res_o, rate, _ = O.vcycle_history(ho, mf.vmult, b, x0, n_cycles=n_hist)
     op = M.MatrixFreeLaplace(ctx, prob)
-    res_g, _ = gpu_history(ctx, h, lambda y, x: op.vmult(y, x), b, x0, n_cycles=10)
+    res_g, _ = gpu_history(ctx, h, lambda y, x: op.vmult(y, x), b, x0, n_cycles=n_hist)
     np.testing.assert_allclose(res_g, res_o, rtol=1e-9, atol=HIST_ATOL)
     assert rate < 0.35
 
