@@ -443,6 +443,11 @@ def main():
                        "avg_launch_ms": c_ms / c_launches if c_launches else None,
                        "algorithmic_bytes_per_launch": c_bytes / c_launches if c_launches else None,
                        "share_of_step_time": c_ms / (ms_per_step * args.steps) if c_ms else None})
+            if ach > HBM_PEAK_GBS:
+                rf["note"] = ("priced at the CSR figure of SURVEY.md 8(d) (12 B per entry + vectors); with a constant coefficient "
+                              "the rows of the fine matrix and of the coarse operators repeat a few stencils and are evaluated "
+                              "from tables (no matrix values or column indices are read), so this rate is not a fraction of "
+                              "the HBM peak -- see --material linear for stored values")
         if world == 1 and not args.no_cpu_baseline and not assembled:
             out["cpu_baseline"] = cpu_baseline(args, M, h, prob, lmin, lmax, torch)
         if world == 1 and not args.no_extras:
