@@ -416,7 +416,7 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
       T v[8];
       T c[CC ? 1 : 8];
       T n0 = T(0), n2 = T(0), n1x = T(0), n3x = T(0);
-      T lb = T(0), ld = T(0), lxp = T(0);
+      T lb, ld, lxp; // (only read where `stores` holds and the mode asks for them)
       int4 f1;
       {
         const int bn = dpp_from_next(pfB);
