@@ -101,6 +101,42 @@ def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, mater
             "n_dofs": n, "ms_per_step": dt * 1e3, "value": n / dt, "unit": "DoF/s"}
 
 
+def measure_vcycle_f32(ctx, torch, M, h, prob, op_monitor_factory, steps=10, warmup=3):
+    """BASELINE.json configs[4] (FP32) as a whole cycle: the fine level (smoother, residual) in FP32 through the FP32
+    instance of the operator kernel, restriction / coarse solve / prolongation in FP64 (`Hierarchy.apply_f32`, the
+    hierarchy of the headline measurement built with "fine level precision" float)."""
+    n = h.level_size(0)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand(n, dtype=torch.float32, device="cuda", generator=g)
+    x *= (prob.constrained != 1).to(torch.float32)
+    b = torch.zeros(n, dtype=torch.float32, device="cuda")
+    op = op_monitor_factory()
+    r = torch.empty(n, dtype=torch.float64, device="cuda")
+
+    def norm():
+        op.vmult(r, x.double())
+        return ctx.l2_norm(r)
+    r0 = norm()
+    for _ in range(warmup):
+        h.apply_f32(b, x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        h.apply_f32(b, x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # contraction over the first cycles only: a float iterate stalls at ~1e-7 of the start residual
+    x = torch.rand(n, dtype=torch.float32, device="cuda", generator=g) * (prob.constrained != 1).to(torch.float32)
+    r0 = norm()
+    for _ in range(4):
+        h.apply_f32(b, x)
+    contraction = (norm() / r0) ** 0.25
+    return {"workload": "the headline hierarchy with the fine level in FP32 (operator kernel, Chebyshev(3) smoother and "
+                        "residual on float vectors; restriction, coarse solve and prolongation in FP64)",
+            "n_dofs": n, "dtype": "f32 fine level / f64 coarse levels", "ms_per_step": dt * 1e3, "value": n / dt,
+            "unit": "DoF/s", "mean_residual_contraction_per_cycle_first_4": contraction}
+
+
 def measure_smoother_f32(ctx, torch, M, cells, degree, reps=5, material="linear"):
     """BASELINE.json configs[4] (FP32): smoother apply with the FP32 instance of the operator kernel (vector
     ALU: at ~11 flop/B the cell kernel sits below the FP32-MFMA ridge)."""
@@ -296,7 +332,10 @@ def main():
         "max levels": 2,
     }
     evaluator = "HipMatrixFreeMeshEvaluator" if args.evaluator == "matrix_free" else "HipMeshEvaluator"
-    h = M.Hierarchy(ctx, evaluator, prob, params)
+    # (the FP32 instance of the fine operator rides along for the extra line `vcycle_fp32_fine_level_config5`;
+    # the headline cycle below is the FP64 `apply`)
+    with_f32 = world == 1 and args.evaluator == "matrix_free" and not args.no_extras
+    h = M.Hierarchy(ctx, evaluator, prob, dict(params, **{"fine level precision": "float"}) if with_f32 else params)
     ctx.synchronize()
     t_setup = time.perf_counter() - t_setup
     degree, lmin, lmax = h.smoother_info()
@@ -452,6 +491,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, M, h, prob, lmin, lmax, torch)
         if world == 1 and not args.no_extras:
             try:
+                if with_f32:
+                    out["vcycle_fp32_fine_level_config5"] = measure_vcycle_f32(ctx, torch, M, h, prob,
+                                                                              lambda: M.MatrixFreeLaplace(ctx, prob))
                 out["vcycle_128cubed_config1"] = measure_vcycle_small(ctx, torch, M, 128, params)
                 out["smoother_apply_256cubed_f32_config5"] = measure_smoother_f32(ctx, torch, M, 256, args.degree)
                 out["smoother_apply_257cubed_general_coefficient"] = measure_smoother(ctx, torch, M, 257, args.degree,

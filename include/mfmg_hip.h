@@ -226,6 +226,11 @@ int mfmg_hip_hierarchy_destroy(mfmg_hip_hierarchy_t h);
 /* Hierarchy::apply(b, x, 0)  (hierarchy.hpp:246-309) */
 int mfmg_hip_hierarchy_apply(mfmg_hip_hierarchy_t h, const double *b, double *x);
 /* Hierarchy::vmult(x, b)     (hierarchy.hpp:238-244) */
+/* The same cycle with the fine level in FP32 (BASELINE.json configs[4]): float device vectors; pre-smoother,
+ * residual and post-smoother through the FP32 instance of the matrix-free operator, restriction, coarse solve and
+ * prolongation in FP64.  Needs the parameter "fine level precision" float at creation (matrix-free evaluator, two
+ * levels, one process). */
+int mfmg_hip_hierarchy_apply_f32(mfmg_hip_hierarchy_t h, const float *b, float *x);
 int mfmg_hip_hierarchy_vmult(mfmg_hip_hierarchy_t h, double *x, const double *b);
 /* Outer Krylov driver of tests/hierarchy_driver.cc:103-116: dealii::SolverCG on the fine-level operator with
  * Hierarchy::vmult as preconditioner, SolverControl(max_iterations, tolerance) on the absolute l2 norm of the

@@ -375,6 +375,11 @@ class Hierarchy:
         n = self.level_size(0)
         check(self._lib.mfmg_hip_hierarchy_apply(self.handle, _dev_ptr(b, n), _dev_ptr(x, n)))
 
+    def apply_f32(self, b: torch.Tensor, x: torch.Tensor):
+        """The same cycle on float32 vectors with the fine level in FP32 (parameter "fine level precision": "float")."""
+        n = self.level_size(0)
+        check(self._lib.mfmg_hip_hierarchy_apply_f32(self.handle, _dev_ptr(b, n, torch.float32), _dev_ptr(x, n, torch.float32)))
+
     def vmult(self, x: torch.Tensor, b: torch.Tensor):
         n = self.level_size(0)
         check(self._lib.mfmg_hip_hierarchy_vmult(self.handle, _dev_ptr(x, n), _dev_ptr(b, n)))

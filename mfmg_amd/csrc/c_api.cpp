@@ -92,6 +92,10 @@ struct mfmg_hip_hierarchy_s
   std::shared_ptr<TimerOutput> timer;
   std::unique_ptr<Hierarchy<DVector>> hierarchy;
   mfmg_hip_csr_s restrictor_view, coarse_view, amg_view;
+  // "fine level precision" float: the matrix-free operator and its smoother in FP32 around the FP64 coarse levels
+  std::shared_ptr<MatrixFreeLaplaceDevice<float>> fine_f32;
+  DeviceBuffer<float> f32_a, f32_b, f32_res;
+  std::shared_ptr<DVector> f32_res64, f32_bc, f32_xc, f32_corr64;
 };
 
 extern "C" {
@@ -640,6 +644,17 @@ int mfmg_hip_hierarchy_create(mfmg_hip_context_t ctx, const char *evaluator_type
       ASSERT_THROW_NOT_IMPLEMENTED("mesh evaluator type \"" + type + "\" is not available in the HIP build");
     h->timer = std::make_shared<TimerOutput>();
     h->hierarchy.reset(new Hierarchy<DVector>(nullptr, h->evaluator, params, h->timer));
+    const std::string precision = params->get("fine level precision", "double");
+    if (precision == "float")
+    {
+      // built here: the mesh arrays of the caller need not outlive this call
+      require(type == "HipMatrixFreeMeshEvaluator", "\"fine level precision\" float needs the matrix-free evaluator");
+      require(h->hierarchy->levels().size() == 2, "\"fine level precision\" float needs the two-level hierarchy");
+      require(!ctx->handle->comm.enabled(), "\"fine level precision\" float is not available in a distributed run");
+      h->fine_f32 = std::make_shared<MatrixFreeLaplaceDevice<float>>(*ctx->handle, *mesh, ctx->handle->allow_cell_constant);
+    }
+    else
+      require(precision == "double", "\"fine level precision\" must be double or float");
     MFMG_HIP_CHECK(hipStreamSynchronize(ctx->handle->stream));
     *out = h.release();
   });
@@ -670,6 +685,70 @@ int mfmg_hip_hierarchy_apply(mfmg_hip_hierarchy_t h, const double *b, double *x)
     const int64_t n = level_size(h, 0);
     DVector bv(*h->handle, n, const_cast<double *>(b)), xv(*h->handle, n, x);
     h->hierarchy->apply(bv, xv);
+  });
+}
+
+// Hierarchy::apply (hierarchy.hpp:246-309) with the fine level in FP32: pre-smoother, residual and post-smoother run
+// on float vectors through the FP32 instance of the matrix-free operator (same polynomial coefficients as the FP64
+// smoother), the residual is widened, restricted, solved for and prolongated in FP64, and the correction is
+// subtracted from the float iterate.
+int mfmg_hip_hierarchy_apply_f32(mfmg_hip_hierarchy_t h, const float *b, float *x)
+{
+  return guarded([&] {
+    require(h && b && x, "null argument");
+    require(h->fine_f32 != nullptr, "the hierarchy was not built with \"fine level precision\" float");
+    HipHandle &hd = *h->handle;
+    auto const &levels = h->hierarchy->levels();
+    const int64_t n = level_size(h, 0), nc = level_size(h, 1);
+    auto smoother = std::dynamic_pointer_cast<HipSmoother const>(levels[0].get_smoother());
+    require(smoother != nullptr, "unexpected smoother type");
+    auto const &coef = smoother->coefficients();
+    const int d = (int)coef.size();
+    if (h->f32_a.size() == 0)
+    {
+      h->f32_a.resize(n);
+      h->f32_b.resize(n);
+      h->f32_res.resize(n);
+      h->f32_res64 = levels[0].get_operator()->build_range_vector();
+      h->f32_corr64 = levels[0].get_operator()->build_range_vector();
+      h->f32_bc = levels[1].get_operator()->build_range_vector();
+      h->f32_xc = levels[1].get_operator()->build_range_vector();
+    }
+    auto const &op = *h->fine_f32;
+    // x <- x - B^-1 (A x - b), one fused kernel per polynomial term, targets alternating so that the last lands in x
+    auto smooth = [&]() {
+      if (d == 1)
+      {
+        op.smoother_step(b, x, nullptr, 0.f, (float)coef[0].second, h->f32_a.data());
+        MFMG_HIP_CHECK(hipMemcpyAsync(x, h->f32_a.data(), sizeof(float) * n, hipMemcpyDeviceToDevice, hd.stream));
+        return;
+      }
+      std::vector<float *> target(d);
+      target[d - 1] = x;
+      for (int k = d - 2, flip = 0; k >= 0; --k, flip ^= 1)
+        target[k] = flip ? h->f32_b.data() : h->f32_a.data();
+      float const *cur = x, *prev = nullptr;
+      for (int k = 0; k < d; ++k)
+      {
+        op.smoother_step(b, cur, prev, (float)coef[k].first, (float)coef[k].second, target[k]);
+        prev = cur;
+        cur = target[k];
+      }
+    };
+    if (h->hierarchy->is_preconditioner())
+      MFMG_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(float) * n, hd.stream));
+    for (unsigned int i = 0; i < h->hierarchy->n_smoothing_steps(); ++i)
+      smooth();
+    op.residual(x, b, h->f32_res.data());
+    vec::widen(hd, n, h->f32_res.data(), h->f32_res64->get_values());
+    auto restrictor = levels[1].get_restrictor();
+    restrictor->apply(*h->f32_res64, *h->f32_bc);
+    h->hierarchy->apply(*h->f32_bc, *h->f32_xc, 1);
+    restrictor->apply(*h->f32_xc, *h->f32_corr64, OperatorMode::TRANS);
+    vec::subtract_narrowed(hd, n, h->f32_corr64->get_values(), x);
+    for (unsigned int i = 0; i < h->hierarchy->n_smoothing_steps(); ++i)
+      smooth();
+    (void)nc;
   });
 }
 

@@ -191,6 +191,8 @@ public:
   double operator_complexity() const { return 0; }
 
   std::vector<Level<VectorType>> const &levels() const { return _levels; }
+  bool is_preconditioner() const { return _is_preconditioner; }
+  unsigned int n_smoothing_steps() const { return _n_smoothing_steps; }
   std::shared_ptr<TimerOutput> timer() const { return _timer; }
 
 private:

@@ -224,6 +224,8 @@ public:
   void apply_to(DVector const &b, DVector const &x_in, DVector &x_out) const;
 
   int degree() const { return (int)_coefficients.size(); }
+  // (alpha_k, beta_k) of the polynomial terms: x_{k+1} = x_k + alpha_k (x_k - x_{k-1}) - beta_k D^-1 (A x_k - b)
+  std::vector<std::pair<double, double>> const &coefficients() const { return _coefficients; }
   double lambda_min() const { return _lambda_min; }
   double lambda_max() const { return _lambda_max; }
   std::string const &type() const { return _type; }

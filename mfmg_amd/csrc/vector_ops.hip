@@ -48,6 +48,18 @@ __global__ void scaled_pointwise_kernel(int64_t n, T s, T const *d, T const *v, 
     out[i] = (s * d[i]) * v[i];
 }
 
+__global__ void widen_kernel(int64_t n, float const *in, double *out)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (double)in[i];
+}
+
+__global__ void subtract_narrowed_kernel(int64_t n, double const *c, float *x)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = (float)((double)x[i] - c[i]);
+}
+
 __device__ __forceinline__ double block_reduce_sum(double v)
 {
   __shared__ double wsum[16];
@@ -167,6 +179,22 @@ void scaled_pointwise(HipHandle &h, int64_t n, T s, T const *d, T const *v, T *o
     return;
   hipLaunchKernelGGL(scaled_pointwise_kernel<T>, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, n, s, d,
                      v, out);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+void widen(HipHandle &h, int64_t n, float const *in, double *out)
+{
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(widen_kernel, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, n, in, out);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+void subtract_narrowed(HipHandle &h, int64_t n, double const *correction, float *x)
+{
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(subtract_narrowed_kernel, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, n, correction, x);
   MFMG_HIP_CHECK(hipGetLastError());
 }
 

@@ -23,6 +23,10 @@ void scale_pointwise(HipHandle &h, int64_t n, T const *d, T const *v, T *out); /
 template <typename T>
 void scaled_pointwise(HipHandle &h, int64_t n, T s, T const *d, T const *v, T *out); // out = (s d) .* v
 
+// fine level in FP32 around an FP64 coarse hierarchy: out = (double) in, and x -= (float) correction
+void widen(HipHandle &h, int64_t n, float const *in, double *out);
+void subtract_narrowed(HipHandle &h, int64_t n, double const *correction, float *x);
+
 // Deterministic two-stage dot product; the result lands in device slot
 // `result_dev[slot]` (no host synchronisation).
 template <typename T>

@@ -137,6 +137,7 @@ def load() -> C.CDLL:
         "mfmg_hip_hierarchy_create": (C.c_int, [vp, C.c_char_p, P(MeshDesc), C.c_char_p, P(vp)]),
         "mfmg_hip_hierarchy_destroy": (C.c_int, [vp]),
         "mfmg_hip_hierarchy_apply": (C.c_int, [vp, vp, vp]),
+        "mfmg_hip_hierarchy_apply_f32": (C.c_int, [vp, vp, vp]),
         "mfmg_hip_hierarchy_vmult": (C.c_int, [vp, vp, vp]),
         "mfmg_hip_hierarchy_solve_cg": (C.c_int, [vp, vp, vp, C.c_double, C.c_int32, P(C.c_int32), P(C.c_double), P(C.c_double), C.c_int32]),
         "mfmg_hip_hierarchy_n_levels": (C.c_int, [vp, P(i32)]),

@@ -75,6 +75,52 @@ def test_matrix_free_chebyshev_vcycle_history(ctx, n, material, degree):
     assert rate_o < 0.5
 
 
+@pytest.mark.parametrize("n,material,degree", [((16, 16, 16), "constant", 3), ((12, 10, 6), "linear", 2), ((66, 8, 6), "constant", 3)])
+def test_fine_level_in_fp32_against_the_fp64_oracle(ctx, n, material, degree):
+    """BASELINE.json configs[4] (FP32): the cycle with the fine level in float (operator, smoother and residual through
+    the FP32 instance of the matrix-free kernel, coarse levels in FP64) against the FP64 oracle with the same R and
+    the same polynomial: residual history to 1e-4 relative, down to the rounding floor of a float iterate."""
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, material)
+    con = mesh.constrained_mask()
+    mf = O.MatrixFreeLaplace(mesh, coef)
+    prob = M.LaplaceProblem(n, material, device="cuda")
+    params = base_params(smoother={"type": "Chebyshev", "degree": degree, "smoothing_range": 20.0})
+    params["fine level precision"] = "float"
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    deg, lmin, lmax = h.smoother_info()
+    R = h.restrictor().to_scipy()
+    Ac = O.galerkin_coarse_matrix(mf.vmult, R)
+    p = O.ChebyshevParams(degree=degree, lambda_max=lmax, lambda_min=lmin)
+    dinv = mf.diagonal_inverse()
+    ho = O.TwoLevelHierarchy(mf.vmult, lambda b, x: O.chebyshev_smoother_apply(mf.vmult, dinv, p, b, x), R,
+                             O.direct_coarse_solver(Ac), 1, False)
+    x0 = O.random_initial_guess(mesh.n_dofs, con).astype(np.float32).astype(np.float64)   # representable in float
+    b = np.zeros(mesh.n_dofs)
+    res_o, _, _ = O.vcycle_history(ho, mf.vmult, b, x0, n_cycles=8)
+    # the float cycle, residual monitored in FP64
+    op = M.MatrixFreeLaplace(ctx, prob)
+    xf = torch.from_numpy(x0.astype(np.float32)).cuda()
+    bf = torch.zeros_like(xf)
+    r = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
+
+    def norm():
+        op.vmult(r, xf.double())
+        return ctx.l2_norm(r)
+    r0 = norm()
+    res_f = [1.0]
+    for _ in range(8):
+        h.apply_f32(bf, xf)
+        res_f.append(norm() / r0)
+    np.testing.assert_allclose(res_f, res_o, rtol=1e-4, atol=2e-6)
+    assert res_f[-1] < 1e-2                                          # and it does converge
+    # the FP64 cycle of the same hierarchy object is untouched
+    res_g, _ = gpu_history(ctx, h, lambda y, x: op.vmult(y, x), b, x0, n_cycles=8)
+    np.testing.assert_allclose(res_g, res_o, rtol=HIST_TOL, atol=HIST_ATOL)
+    with pytest.raises(L.MfmgInvalidArgument, match="fine level precision"):
+        M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, base_params()).apply_f32(bf, xf)
+
+
 @pytest.mark.parametrize("n,numbering", [((8, 6, 4), "lexicographic"), ((6, 6, 6), "random"), ((10, 4, 2), "lexicographic")])
 def test_agglomerate_wise_restrictor_equals_csr(ctx, n, numbering):
     """The agglomerate-wise evaluation of R and R^T (structured_restrictor.hpp) against the CSR kernels and
