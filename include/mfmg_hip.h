@@ -85,6 +85,11 @@ int mfmg_hip_context_set_overlap_exchange(mfmg_hip_context_t ctx, int enable);
  * (material_property constant, the reference's default, or any cell-wise constant material) keep ONE value per
  * cell (20 instead of 76 bytes per cell in FP64; default on).  Off forces the general eight-value layout. */
 int mfmg_hip_context_set_cell_constant_layout(mfmg_hip_context_t ctx, int enable);
+/* Hierarchies created afterwards form the coarse operator R A R^T of a matrix-free A on the device by probing
+ * (27 n_eig applications of R^T, A and R over colour classes of agglomerates; the reference's fast_ap idea,
+ * source/dealii/dealii_matrix_free_hierarchy_helpers.cc:77-288) -- the default where the restrictor has the block
+ * structure and the run is not distributed; 0: the host triple product.  Same matrix to rounding. */
+int mfmg_hip_context_set_galerkin_on_device(mfmg_hip_context_t ctx, int enable);
 /* layout of a distributed space after the hierarchy was built: entries per layer, local layers, owned range */
 int mfmg_hip_context_halo_layout(mfmg_hip_context_t ctx, int32_t space, int64_t *layer_elems, int64_t *n_layers,
                                  int64_t *owned_begin, int64_t *owned_count);

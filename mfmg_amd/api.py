@@ -78,6 +78,10 @@ class Context:
         """Operators created afterwards keep one coefficient per cell when a cell's eight are equal (default on)."""
         check(self._lib.mfmg_hip_context_set_cell_constant_layout(self.handle, int(bool(enable))))
 
+    def set_galerkin_on_device(self, enable: bool):
+        """Hierarchies created afterwards form R A R^T of a matrix-free A by probing on the device (default) or on the host."""
+        check(self._lib.mfmg_hip_context_set_galerkin_on_device(self.handle, int(bool(enable))))
+
     def set_overlap_exchange(self, enable: bool):
         """Distributed runs: overlap the fine-level halo exchange with interior operator tiles (default on)."""
         check(self._lib.mfmg_hip_context_set_overlap_exchange(self.handle, int(bool(enable))))

@@ -166,6 +166,13 @@ int mfmg_hip_context_set_cell_constant_layout(mfmg_hip_context_t ctx, int enable
     ctx->handle->allow_cell_constant = enable != 0;
   });
 }
+int mfmg_hip_context_set_galerkin_on_device(mfmg_hip_context_t ctx, int enable)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    ctx->handle->galerkin_on_device = enable != 0;
+  });
+}
 
 int mfmg_hip_mf_laplace_cell_constant_layout(mfmg_hip_mf_laplace_t op, int *in_use)
 {

@@ -267,6 +267,9 @@ struct HipHandle
   bool overlap_exchange = true;
   // matrix-free operators built from this handle may keep one coefficient per cell when a cell's eight are equal
   bool allow_cell_constant = true;
+  // R A R^T of a matrix-free A by probing on the device (hip_hierarchy.hip, HipMatrixOperator::multiply) instead of
+  // the host triple product
+  bool galerkin_on_device = true;
   // scratch for two-stage deterministic reductions
   DeviceBuffer<double> reduce_partials;
   DeviceBuffer<double> reduce_result;

@@ -276,6 +276,85 @@ std::shared_ptr<Operator<DVector>> HipMatrixOperator::multiply(std::shared_ptr<O
   {
     ASSERT_THROW(half->get_r()->get_matrix() == _matrix, "the Galerkin product needs the same restrictor on both sides");
     auto evaluator = half->get_a()->get_mesh_evaluator();
+    HipHandle &hd = _matrix->handle();
+    if (_structured && !hd.comm.enabled() && hd.galerkin_on_device)
+    {
+      // On device, by probing (the reference's fast_ap idea,
+      // source/dealii/dealii_matrix_free_hierarchy_helpers.cc:77-288): R A R^T couples an agglomerate only to its 26
+      // neighbours, so the columns of all agglomerates with the same index mod 3 in every direction (and the same
+      // eigenvector) can be applied at once -- u = their indicator, y = R (A (R^T u)) with the kernels of the apply
+      // path -- and row (a, e) of y is the entry towards the one agglomerate of that class next to a:
+      // 27 n_eig operator applications instead of one per coarse column.
+      const int ne = _structured->n_eigenvectors();
+      const int na[3] = {_structured->agglomerates(0), _structured->agglomerates(1), _structured->agglomerates(2)};
+      const int k[3] = {std::min(3, na[0]), std::min(3, na[1]), std::min(3, na[2])};
+      const int64_t n_agg = (int64_t)na[0] * na[1] * na[2], nc = n_agg * ne;
+      ASSERT_THROW(nc == _matrix->m(), "agglomerate grid does not match the restrictor");
+      const int n_colors = k[0] * k[1] * k[2] * ne;
+      std::vector<std::vector<double>> Y(n_colors, std::vector<double>(nc));
+      {
+        auto u = this->build_range_vector();
+        auto y = this->build_range_vector();
+        auto w = half->build_range_vector();
+        for (int color = 0; color < n_colors; ++color)
+        {
+          const int e0 = color % ne, oc = color / ne;
+          const int o[3] = {oc % k[0], (oc / k[0]) % k[1], oc / (k[0] * k[1])};
+          vec::probing_vector(hd, na, ne, k, o, e0, u->get_values());
+          half->apply(*u, *w);
+          this->apply(*w, *y);
+          MFMG_HIP_CHECK(hipMemcpyAsync(Y[color].data(), y->get_values(), sizeof(double) * nc, hipMemcpyDeviceToHost,
+                                        hd.stream));
+        }
+        MFMG_HIP_CHECK(hipStreamSynchronize(hd.stream));
+      }
+      HostCsr Ac;
+      Ac.n_rows = Ac.n_cols = nc;
+      Ac.row_ptr.assign(nc + 1, 0);
+      auto neighbours = [&](int64_t a, auto &&visit) {
+        const int ax = (int)(a % na[0]), ay = (int)((a / na[0]) % na[1]), az = (int)(a / ((int64_t)na[0] * na[1]));
+        for (int dz = -1; dz <= 1; ++dz)
+          for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx)
+            {
+              const int bx = ax + dx, by = ay + dy, bz = az + dz;
+              if (bx < 0 || bx >= na[0] || by < 0 || by >= na[1] || bz < 0 || bz >= na[2])
+                continue;
+              visit(bx + (int64_t)na[0] * (by + (int64_t)na[1] * bz), (bx % k[0]) + k[0] * ((by % k[1]) + k[1] * (bz % k[2])));
+            }
+      };
+      for (int64_t a = 0; a < n_agg; ++a)
+      {
+        int count = 0;
+        neighbours(a, [&](int64_t, int) { ++count; });
+        for (int e = 0; e < ne; ++e)
+          Ac.row_ptr[a * ne + e + 1] = count * ne;
+      }
+      for (int64_t r = 0; r < nc; ++r)
+      {
+        ASSERT_THROW((int64_t)Ac.row_ptr[r] + Ac.row_ptr[r + 1] < (int64_t(1) << 31), "coarse operator exceeds int32 entries");
+        Ac.row_ptr[r + 1] += Ac.row_ptr[r];
+      }
+      Ac.col.resize(Ac.row_ptr[nc]);
+      Ac.val.resize(Ac.row_ptr[nc]);
+#pragma omp parallel for schedule(static)
+      for (int64_t a = 0; a < n_agg; ++a)
+        for (int e = 0; e < ne; ++e)
+        {
+          const int64_t r = a * ne + e;
+          int p = Ac.row_ptr[r];
+          neighbours(a, [&](int64_t b, int oc) {
+            for (int e2 = 0; e2 < ne; ++e2, ++p)
+            {
+              Ac.col[p] = (int32_t)(b * ne + e2);
+              Ac.val[p] = Y[oc * ne + e2][r];
+            }
+          });
+        }
+      auto coarse = std::make_shared<HipMatrixOperator>(upload(hd, std::move(Ac)));
+      coarse->set_spaces(_range_space, _range_space);
+      return coarse;
+    }
     HostCsr R, Rt;
     R.n_rows = _matrix->m();
     R.n_cols = _matrix->n();

@@ -25,6 +25,8 @@ public:
 
   int64_t n_coarse() const { return _n_coarse; }
   int64_t n_fine() const { return _n_fine; }
+  int agglomerates(int d) const { return _na[d]; }
+  int n_eigenvectors() const { return _n_eig; }
   // y_c = R x
   void restrict_to_coarse(double const *x, double *y) const;
   // out = R^T y (subtract = false) or out -= R^T y (subtract = true)

@@ -23,6 +23,10 @@ void scale_pointwise(HipHandle &h, int64_t n, T const *d, T const *v, T *out); /
 template <typename T>
 void scaled_pointwise(HipHandle &h, int64_t n, T s, T const *d, T const *v, T *out); // out = (s d) .* v
 
+// probing vector of the Galerkin product on device: u[(a, e)] = 1 where e == e0 and the agglomerate a (x fastest on a
+// grid na) has a_d mod k_d == o_d in every direction, else 0
+void probing_vector(HipHandle &h, int const na[3], int n_eig, int const k[3], int const o[3], int e0, double *u);
+
 // fine level in FP32 around an FP64 coarse hierarchy: out = (double) in, and x -= (float) correction
 void widen(HipHandle &h, int64_t n, float const *in, double *out);
 void subtract_narrowed(HipHandle &h, int64_t n, double const *correction, float *x);

@@ -86,6 +86,7 @@ def load() -> C.CDLL:
         "mfmg_hip_context_set_halo_buffers": (C.c_int, [vp, i32, i64, vp, vp, vp, vp]),
         "mfmg_hip_context_set_overlap_exchange": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_context_set_cell_constant_layout": (C.c_int, [vp, C.c_int]),
+        "mfmg_hip_context_set_galerkin_on_device": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_mf_laplace_cell_constant_layout": (C.c_int, [vp, P(C.c_int)]),
         "mfmg_hip_context_halo_layout": (C.c_int, [vp, i32, P(i64), P(i64), P(i64), P(i64)]),
         "mfmg_hip_profile_enable": (C.c_int, [vp, C.c_int]),

@@ -121,6 +121,35 @@ def test_fine_level_in_fp32_against_the_fp64_oracle(ctx, n, material, degree):
         M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, base_params()).apply_f32(bf, xf)
 
 
+@pytest.mark.parametrize("n,material,numbering", [((12, 10, 6), "linear", "lexicographic"), ((8, 6, 4), "discontinuous", "lexicographic"),
+                                                  ((8, 8, 2), "constant", "lexicographic"), ((6, 8, 10), "linear", "random")])
+def test_galerkin_product_on_device_equals_host(ctx, n, material, numbering):
+    """R A R^T of the matrix-free operator by probing on the device (27 n_eig applications of R^T, A, R over colour
+    classes of agglomerates; fewer colours where a direction has fewer than three agglomerates) against the host
+    triple product and the oracle's Galerkin matrix."""
+    nd = int(np.prod([v + 1 for v in n]))
+    perm = torch.from_numpy(np.random.default_rng(3).permutation(nd)) if numbering == "random" else None
+    params = base_params(smoother={"type": "Chebyshev", "degree": 2})
+    mats = {}
+    try:
+        for on_device in (True, False):
+            ctx.set_galerkin_on_device(on_device)
+            prob = M.LaplaceProblem(n, material, device="cuda", dof_numbering=perm)
+            mats[on_device] = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params).coarse_operator().to_scipy()
+    finally:
+        ctx.set_galerkin_on_device(True)
+    scale = abs(mats[False]).max()
+    assert abs(mats[True] - mats[False]).max() < 1e-12 * scale
+    assert mats[True].shape == mats[False].shape and mats[True].nnz >= mats[False].nnz - 0
+    if numbering == "lexicographic":
+        mesh = O.StructuredMesh(n)
+        coef = O.coefficient_table(mesh, material)
+        mf = O.MatrixFreeLaplace(mesh, coef)
+        R = O.build_restrictor(mesh, coef, mf.diagonal(), n_eig=2, variant="mf", eig_mode="krylov").csr
+        Ac = O.galerkin_coarse_matrix(mf.vmult, R)
+        assert abs(mats[True] - Ac).max() < 1e-11 * abs(Ac).max()
+
+
 @pytest.mark.parametrize("n,numbering", [((8, 6, 4), "lexicographic"), ((6, 6, 6), "random"), ((10, 4, 2), "lexicographic")])
 def test_agglomerate_wise_restrictor_equals_csr(ctx, n, numbering):
     """The agglomerate-wise evaluation of R and R^T (structured_restrictor.hpp) against the CSR kernels and
