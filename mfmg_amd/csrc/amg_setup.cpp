@@ -2,12 +2,23 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 
 #include "sparse_matrix_device.hpp"
 
 namespace mfmg
 {
+namespace
+{
+double wall_seconds()
+{
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+} // namespace
+
 int64_t aggregate_rows(HostCsr const &A, double strength, std::vector<int32_t> &agg)
 {
   const int64_t n = A.n_rows;
@@ -112,6 +123,8 @@ std::vector<AmgLevelHost> build_aggregation_hierarchy(HostCsr A0, std::vector<do
     HostCsr const &A = levels.back().A;
     std::vector<double> const &B = levels.back().near_null;
     const int64_t n = A.n_rows;
+    const bool verbose = std::getenv("MFMG_HIP_VERBOSE") != nullptr;
+    const double t_level = wall_seconds();
     ASSERT_THROW((int64_t)B.size() == n, "near-null-space vector has the wrong size");
     std::vector<int32_t> agg;
     int64_t n_agg = 0;
@@ -191,13 +204,23 @@ std::vector<AmgLevelHost> build_aggregation_hierarchy(HostCsr A0, std::vector<do
       for (int64_t i = 0; i < n; ++i)
         for (int p = S.row_ptr[i]; p < S.row_ptr[i + 1]; ++p)
           S.val[p] = ((S.col[p] == i) ? 1. : 0.) - w * dinv[i] * S.val[p];
+      const double t0 = wall_seconds();
       P = multiply(S, Pt);
+      if (verbose)
+        std::fprintf(stderr, "[mfmg_hip] amg level %d (%lld rows): smoothing matrix %.2f s, P = S P_tent %.2f s\n",
+                     (int)levels.size() - 1, (long long)n, t0 - t_level, wall_seconds() - t0);
     }
     else
       P = Pt;
+    const double t1 = wall_seconds();
     HostCsr AP = multiply(A, P);
+    const double t2 = wall_seconds();
     HostCsr PT = transpose(P);
+    const double t3 = wall_seconds();
     HostCsr Ac = multiply(PT, AP);
+    if (verbose)
+      std::fprintf(stderr, "[mfmg_hip] amg level %d: A P %.2f s, transpose %.2f s, P^T (A P) %.2f s\n", (int)levels.size() - 1,
+                   t2 - t1, t3 - t2, wall_seconds() - t3);
     levels.back().P = std::move(P);
     levels.emplace_back();
     levels.back().A = std::move(Ac);
