@@ -714,6 +714,7 @@ __global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, T cons
 
 constexpr size_t kMaxBlockDiagonals = 400; // (343: the third level of the aggregation hierarchy of a Q1 problem)
 constexpr int kMaxStoredBlockDiagonals = 160;
+constexpr int64_t kRegularAsClassNodes = 300000; // nodes up to which regular nodes are evaluated as one more class
 constexpr int kSplitStencil = 48;        // block diagonals from which a node's stencil is split over four wavefronts
 constexpr int64_t kListedWaveRows = 32768; // listed rows up to which each gets a wavefront of its own
 
@@ -1061,6 +1062,31 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
         n_classed += classed[nd] ? c : 0;
       if ((n_regular + n_classed) * 2 < n)
         n_classes = 0;
+      // small levels are bound by the latency of a launch, not by their rows: there the regular nodes join the lists
+      // as one more class (their table is the reference stencil; a regular node has its whole stencil inside the
+      // matrix, so the clamping of the class kernel never acts) and the launch of their own is dropped
+      if (n_classes > 0 && n_classes < kMaxClasses && n_nodes <= kRegularAsClassNodes && n_regular > 0)
+      {
+        for (int rc = 0; rc < c; ++rc)
+          for (int d = 0; d < D; ++d)
+            for (int cc = 0; cc < c; ++cc)
+              cls_table.push_back(table[((size_t)rc * D + d) * c + cc]);
+        int64_t q = 0;
+        for (int64_t nd = 0; nd < n_nodes; ++nd)
+          if (!exc[nd * c])
+          {
+            if (q++ % 64 == 0)
+              cls_of_wave.push_back(n_classes);
+            cls_nodes.push_back((int32_t)nd);
+            classed[nd] = 1;
+            for (int rc = 0; rc < c; ++rc)
+              exc[nd * c + rc] = 1;
+          }
+        while (cls_nodes.size() % 64 != 0)
+          cls_nodes.push_back(-1);
+        ++n_classes;
+        _bdia_all_in_classes = true;
+      }
       if (n_classes > 0)
       {
         _bdia_cls_nodes.upload(cls_nodes.data(), cls_nodes.size(), _handle.stream);
@@ -1518,7 +1544,9 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
       const int64_t n_tail = (_bdia_n_classes > 0 && g.n_exc <= kListedWaveRows) ? g.n_exc : 0;
       auto launch_nodes = [&](auto cc) {
         constexpr int C = decltype(cc)::value;
-        if (split && many_parts)
+        if (_bdia_all_in_classes)
+          ; // (the regular nodes are one of the classes)
+        else if (split && many_parts)
           hipLaunchKernelGGL((bdia_node_split_kernel<T, C, false, 16>), dim3((unsigned int)((n_nodes + 63) / 64)),
                              dim3(1024), 0, st, a, g, nullptr, nullptr, nullptr, 0, nullptr, 0);
         else if (split)

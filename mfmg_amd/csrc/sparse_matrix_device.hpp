@@ -162,6 +162,7 @@ private:
   DeviceBuffer<int32_t> _bdia_cls_nodes, _bdia_cls_of_wave;
   DeviceBuffer<T> _bdia_cls_table; // [n_classes][C][Df][C]
   int _bdia_n_classes = 0;
+  bool _bdia_all_in_classes = false; // small matrices: the regular nodes are one of the classes (no launch of their own)
   int _bdia_c = 0, _bdia_d = 0;
   DeviceBuffer<T> _bdia_val;
   DeviceBuffer<int32_t> _bdia_offs;
