@@ -760,7 +760,7 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
     lpr *= 2;
   if (avg < 3.)
     lpr = avg < 1.5 ? 1 : 2;
-  if (n_rows <= 4096 && avg >= 256.)
+  if ((n_rows <= 4096 && avg >= 256.) || (n_rows <= 16384 && avg >= 512.))
     lpr = 256; // a workgroup per row (csr_spmv_row_block_kernel)
   _lanes_per_row = lpr;
   // ---- block-diagonal storage (see bdia_spmv_kernel); when it applies the LDS lists are not needed
