@@ -448,8 +448,8 @@ __global__ __launch_bounds__(256) void bdia_class_node_kernel(CsrArgs<T> a, Bdia
 #pragma unroll 8
   for (int d = 0; d < g.Df; ++d)
   {
-    int64_t nb = first + g.offs[d];
-    nb = nb < 0 ? 0 : (nb > last ? last : nb);
+    // (node indices are int32 in every layout: the clamp is two 32-bit instructions instead of 64-bit selects)
+    const int64_t nb = max(0, min((int)first + g.offs[d], (int)last));
     T xv[C];
     if constexpr (C == 2 && sizeof(T) == 8)
     {
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(1024) void bdia_node_split_kernel(CsrArgs<T> a, Bdi
     {
       int64_t nb = first + g.offs[d];
       if constexpr (CLASSES)
-        nb = nb < 0 ? 0 : (nb > last ? last : nb);
+        nb = max(0, min((int)first + g.offs[d], (int)last)); // (int32 node indices: a 32-bit clamp)
       T xv[C];
       if constexpr (C == 2 && sizeof(T) == 8)
       {
