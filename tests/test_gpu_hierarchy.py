@@ -445,18 +445,20 @@ def test_single_level_hierarchy_is_coarse_solve(ctx):
     np.testing.assert_allclose(x.cpu().numpy(), np.linalg.solve(A.toarray(), b), rtol=1e-10)
 
 
-def test_full_size_hierarchy_properties(ctx):
+@pytest.mark.parametrize("material", ["constant", "linear"])
+def test_full_size_hierarchy_properties(ctx, material):
     """BASELINE.json's per-GPU size (256^3 cells = 257^3 DoFs, Chebyshev(3), AMG coarse solve), where the numpy
     oracle does not finish in seconds: size-independent properties of every operator on the path --
     symmetry of A and A_c, adjointness of restriction and prolongation, R (weights) partition of unity on the
     interior, the smoother as an affine map, contraction of the cycle -- and the kernel variants in use."""
     n = (256, 256, 256)
-    prob = M.LaplaceProblem(n, "constant", device="cuda")
+    prob = M.LaplaceProblem(n, material, device="cuda")
     params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0},
                          solver={"type": "amg"})
     h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
     nf, nc = h.level_size(0), h.level_size(1)
     assert nf == 257 ** 3 and nc == 2 * 128 ** 3
+    constant = material == "constant"          # linear: eight coefficients per cell, every coarse row stored
     g = torch.Generator(device="cuda").manual_seed(3)
     free = (prob.constrained == 0).to(torch.float64)
     rnd = lambda m: torch.rand(m, dtype=torch.float64, device="cuda", generator=g)
@@ -503,14 +505,18 @@ def test_full_size_hierarchy_properties(ctx):
     assert all(norms[i + 1] < 0.4 * norms[i] for i in range(4)), norms
     # the layouts the design relies on were actually chosen at this size
     assert h.coarse_operator().get_kernel()[1] == 3          # block diagonals for A_c, upper half stored
-    assert h.operator_tile() == (4, 3, 8)
     kernels = {(l, w): (rows, kind, classes, listed) for l, w, rows, kind, classes, listed in h.coarse_amg_kernels()}
-    for l in (0, 1, 2):                                      # A_c and the two levels below: tables for >= 99.9 % of the rows
-        rows, kind, classes, listed = kernels[(l, 0)]
-        assert kind == 3 and classes >= 50 and listed <= 0.02 * rows, kernels[(l, 0)]
-    for key in ((0, 1), (0, 2), (1, 1), (1, 2)):             # the first two prolongators and their transposes: node classes
-        rows, kind, classes, listed = kernels[key]
-        assert kind == 5 and classes >= 10 and listed <= 0.02 * rows, (key, kernels[key])
+    if constant:
+        assert h.operator_tile() == (4, 3, 8)
+        for l in (0, 1, 2):                                  # A_c and the two levels below: tables for >= 99.9 % of the rows
+            rows, kind, classes, listed = kernels[(l, 0)]
+            assert kind == 3 and classes >= 50 and listed <= 0.02 * rows, kernels[(l, 0)]
+        for key in ((0, 1), (0, 2), (1, 1), (1, 2)):         # the first two prolongators and their transposes: node classes
+            rows, kind, classes, listed = kernels[key]
+            assert kind == 5 and classes >= 10 and listed <= 0.02 * rows, (key, kernels[key])
+    else:
+        assert not h.coarse_operator().regular_rows()        # no two rows alike: stored planes
+        assert kernels[(1, 0)][1] == 3 and kernels[(2, 0)][1] == 1   # 125 diagonals stored, 343 left to the CSR kernel
     # the table-driven paths against the stored values / plain CSR kernels of the same matrices: same cycle to rounding
     h.coarse_amg_kernels(regular_rows=False)
     xx2 = x.clone()
