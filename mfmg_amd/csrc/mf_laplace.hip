@@ -1040,6 +1040,7 @@ void MatrixFreeLaplaceDevice<T>::choose_tile(int &nw, int &ty, int &tz) const
       break;
     }
   }
+  const bool tz_free = tz <= 0;
   if (nw <= 0)
     nw = pref[pick][0];
   if (ty <= 0)
@@ -1048,6 +1049,44 @@ void MatrixFreeLaplaceDevice<T>::choose_tile(int &nw, int &ty, int &tz) const
     tz = pref[pick][2];
   if (nw * ty < 2)
     ty = 2;
+  // Layers per tile of the cell-constant variant (bound by instruction issue, measured 257^3: 7 or 11 layers
+  // 0.244 ms per launch, 8: 0.264, 10: 0.268, 16: 0.292, 21: 0.332): all workgroups cost the same, 5 wavefronts per SIMD
+  // are resident, so the launch runs in ceil(workgroups / resident slots) rounds of (layers + 1) layer passes each --
+  // choose the layer count that minimises rounds x (layers + 1) with at least two rounds (a single round pays its ramp
+  // up and down in full).  The general variant is bound by bytes and does not follow this model (8 layers measured
+  // best there).
+  if (_compact && tz_free && nw == 4 && ty == 3)
+  {
+    static const int n_cus = [] {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        v = 256;
+      return v > 0 ? v : 256;
+    }();
+    const double slots = 0.98 * n_cus * 5.; // 5 workgroups of 4 wavefronts per CU
+    auto blocks = [&](MatrixFreeLaplaceDevice<T> const &op, int layers) {
+      const int64_t cols = op._tail ? op._ncols - 1 : op._ncols;
+      const int64_t t = cols * ((op._N[1] + nw * ty - 2) / (nw * ty - 1)) * ((op._N[2] + layers - 1) / layers);
+      return t >= 64 ? ((t + 7) / 8) * 8 : t;
+    };
+    double best = 0.;
+    int best_tz = 0;
+    for (int layers = 6; layers <= 16; ++layers)
+    {
+      const int64_t w = blocks(*this, layers) + (_tail ? blocks(*_tail, layers) : 0);
+      const double rounds = std::ceil((double)w / slots);
+      if (rounds < 2.)
+        continue;
+      const double cost = rounds * (layers + 1);
+      if (best_tz == 0 || cost < best)
+      {
+        best = cost;
+        best_tz = layers;
+      }
+    }
+    if (best_tz > 0)
+      tz = best_tz;
+  }
 }
 
 template <typename T>
