@@ -277,7 +277,17 @@ std::shared_ptr<Operator<DVector>> HipMatrixOperator::multiply(std::shared_ptr<O
     ASSERT_THROW(half->get_r()->get_matrix() == _matrix, "the Galerkin product needs the same restrictor on both sides");
     auto evaluator = half->get_a()->get_mesh_evaluator();
     HipHandle &hd = _matrix->handle();
-    if (_structured && !hd.comm.enabled() && hd.galerkin_on_device)
+    // (ghost nodes -- flag 2, the local mesh of one rank of a distributed run -- are rows the device operator does not
+    // form: those meshes keep the host product, which builds the rows of the owned agglomerates from the cell data)
+    bool ghosts = hd.comm.enabled();
+    if (!ghosts)
+      for (uint8_t f : evaluator->get_mesh().constrained)
+        if (f == 2)
+        {
+          ghosts = true;
+          break;
+        }
+    if (_structured && !ghosts && hd.galerkin_on_device)
     {
       // On device, by probing (the reference's fast_ap idea,
       // source/dealii/dealii_matrix_free_hierarchy_helpers.cc:77-288): R A R^T couples an agglomerate only to its 26

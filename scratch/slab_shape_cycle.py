@@ -16,6 +16,13 @@ h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
 ctx.synchronize()
 print("setup s", time.perf_counter() - t, "tile", h.operator_tile(), "local dofs", h.level_size(0), h.level_size(1))
 x = torch.rand(h.level_size(0), dtype=torch.float64, device="cuda"); b = torch.zeros_like(x)
+for tz in [int(v) for v in sys.argv[6:]]:       # optional: layers per operator tile to compare with the default choice
+    h.set_operator_tile(4, 3, tz)
+    for _ in range(3): h.apply(b, x)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(10): h.apply(b, x)
+    torch.cuda.synchronize(); print(f"tz {tz}: ms/cycle {(time.perf_counter() - t) / 10 * 1e3:.3f}")
+h.set_operator_tile(0, 0, 0)
 for _ in range(3): h.apply(b, x)
 torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(10): h.apply(b, x)
