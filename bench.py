@@ -79,6 +79,23 @@ def committed_traffic(args, compact):
     return d.get(key, {}).get("traffic_bytes_per_launch")
 
 
+def operator_bytes_per_dof(word, compact, survey):
+    """Bytes per fine DoF of one operator application y = A x.
+    survey=True : SURVEY.md 8(d)'s indexed form -- x + y + 8 index ints + 8 coefficients (112 B in FP64); with one
+                  coefficient per cell 8 indices + 1 coefficient.
+    survey=False: what the chunk-record layout makes the kernel read at least -- x + y + ONE id (each slot stores
+                  its own DoF id, the other seven corners are neighbours' own ids) + the coefficients (8, or 1 for a
+                  cell-wise constant material).  Halo re-reads of the tiling are NOT in this figure: they are waste."""
+    coef = (1 if compact else 8) * word
+    return 2 * word + (32 if survey else 4) + coef
+
+
+def smoother_bytes_per_dof(n_terms, word, compact, survey):
+    """Chebyshev smoother apply = n_terms fused operator launches: + b + D^-1 each, + x_prev from the second on."""
+    b_op = operator_bytes_per_dof(word, compact, survey)
+    return (b_op + 2 * word) + (n_terms - 1) * (b_op + 3 * word)
+
+
 def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, material="constant"):
     """BASELINE.json configs[1]: the same V-cycle on a `cells`^3 mesh, wall clock around `steps` cycles."""
     prob = M.LaplaceProblem((cells,) * 3, material, device="cuda")
@@ -177,9 +194,11 @@ def measure_smoother_f32(ctx, torch, M, cells, degree, reps=5, material="linear"
             "achieved_GBs": N * per_dof / (ms * 1e-3) / 1e9, "frac_of_8TBs": N * per_dof / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
-def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=5, tile=None, material="constant"):
-    """Fine-level smoother apply (degree fused operator kernels) on its own: ms per apply from HIP
-    events on the kernels' stream, algorithmic GB/s."""
+def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=20, warmup=3, tile=None, material="constant"):
+    """Fine-level smoother apply (degree fused operator kernels) on its own: one HIP event pair per apply on the
+    kernels' stream, `warmup` untimed applies, then `reps` timed ones; reported: median (the quoted figure), min,
+    max.  Rates: `required_GBs` on the bytes the layout makes the kernel read at least (see
+    required_bytes_per_dof), `survey_GBs` on the SURVEY.md 8(d) figure (8 index ints and 8 coefficients per DoF)."""
     prob = M.LaplaceProblem((n_dofs_per_dim - 1,) * 3, material, device="cuda")
     op = M.MatrixFreeLaplace(ctx, prob)
     compact = op.cell_constant_layout()
@@ -203,25 +222,26 @@ def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=5, tile=None, m
             op.smoother_step(b, cur, prev, al, be, tgt)
             prev, cur = cur, tgt
 
-    apply()
-    ctx.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for _ in range(reps):
+    for _ in range(warmup):
         apply()
-    ev1.record()
-    ev1.synchronize()
-    ms = ev0.elapsed_time(ev1) / reps
-    # exact algorithmic bytes per DoF: operator 112 (x, out, 8 idx, 8 coef) + b + D^-1 (+ x_prev from the
-    # second term on); A x is never stored
-    # (one coefficient per cell when the material is cell-wise constant: 112 - 64 + 8 = 56)
-    b_op = 56 if compact else 112
-    bytes_per_dof = (b_op + 16) + (len(coefs) - 1) * (b_op + 24)
-    gbs = N * bytes_per_dof / (ms * 1e-3) / 1e9
+    ctx.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for r in range(reps):
+        apply()
+        ev[r + 1].record()
+    ev[-1].synchronize()
+    ts = sorted(ev[r].elapsed_time(ev[r + 1]) for r in range(reps))
+    ms = ts[len(ts) // 2]
+    survey = smoother_bytes_per_dof(len(coefs), 8, compact, survey=True)
+    required = smoother_bytes_per_dof(len(coefs), 8, compact, survey=False)
     return {"n_dofs": N, "degree": degree, "material": material,
             "coefficient_layout": "one value per cell" if compact else "eight values per cell",
-            "ms_per_apply": ms, "algorithmic_bytes_per_dof": bytes_per_dof,
-            "achieved_GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS}
+            "tile_waves_ty_tz": list(op.get_tile()),
+            "ms_per_apply": ms, "ms_min": ts[0], "ms_max": ts[-1], "reps": reps, "warmup": warmup,
+            "required_bytes_per_dof": required, "required_GBs": N * required / (ms * 1e-3) / 1e9,
+            "frac_of_8TBs": N * required / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "survey_8d_bytes_per_dof": survey, "survey_8d_GBs": N * survey / (ms * 1e-3) / 1e9}
 
 
 def cpu_baseline(args, M, h, prob, lmin, lmax, torch):
