@@ -1,27 +1,26 @@
 // gfx950 kernel of the matrix-free Q1 Laplace operator.
 //
 // Data layout in HBM ("one cell slot per DoF", rows cut into aligned 64-slot chunks): the DoF
-// columns are cut into runs of 63; chunk c of row (j,k) holds the 64 cell slots of the cells
-// i = 63c-1 .. 63c+62 (the low halo cell is stored again, +1.6 % memory).  Everything the steady
-// state of the kernel needs for one chunk sits in ONE contiguous record, so that a wavefront streams
+// columns are cut into runs of 62; chunk c of row (j,k) holds the 64 slots of the node columns
+// i = 62c-1 .. 62c+62: lanes 1 .. 62 are the columns the chunk owns, lanes 0 and 63 repeat the last / first
+// column of the neighbouring chunks (+3.2 % memory), so that a wavefront needs nothing from another chunk.
+// Everything the kernel reads for one chunk sits in ONE contiguous record, so that a wavefront streams
 // a single run of memory per row instead of one run per array:
 //   chunk r(c,j,k) = (k Ny + j) ncols + c
 //   rec  [r]  : own   int  [64]      DoF id of the slot's own DoF (corner (0,0,0) of its cell)
-//               coef  16 B [NP][64]  the 8 quadrature coefficients of the cell (NP = 8 sizeof(T) / 16)
+//               coef  16 B [NP][64]  the 8 quadrature coefficients of the cell (NP = 8 sizeof(T) / 16);
+//                                    ONE value T[64] when the eight are equal in every cell
 //               dinv  T    [64]      1 / diagonal entry of the slot's own DoF
-//   fb0  [r]  : int4 [64]            DoF ids of the b=0 face: corners (0,0,0) (1,0,0) (0,0,1) (1,0,1)
-//                                    (read for the first row of a tile and by lanes without a cell only)
 // Slot (i,j,k) holds the cell whose lowest corner is DoF (i,j,k); cells that stick out of the
-// mesh on a high face are phantoms with zero coefficient.  The ids are the caller's global DoF
-// ids (any numbering); bit 31 carries the Dirichlet flag, so the constrained-read-as-zero rule
-// costs no extra load, bit 30 marks DoFs owned by another rank (read, never written).
-// The seven other corner ids of a cell are the own ids of neighbouring slots: the b=1 face of row j is
-// read as the own ids of row j+1 in layers k and k+1 (the lane+1 corners by a DPP shift, the layer-k pair
-// from an LDS column written one layer earlier), so the steady state fetches 4 B of ids per cell, not 32.
+// mesh on a high face are phantoms with zero coefficient, slots outside the mesh carry id 0 and coefficient 0.
+// The ids are the caller's global DoF ids (any numbering); bit 31 carries the Dirichlet flag, so the
+// constrained-read-as-zero rule costs no extra load, bit 30 marks DoFs owned by another rank (read, never
+// written).  The seven other corner ids of a cell are the own ids of neighbouring slots, so 4 B of ids are read
+// per cell, not 32.
 //
 // Work decomposition (owner computes, no atomics, results independent of the tiling bit for bit):
-// a workgroup of NW wavefronts marches over a tile of 64 cell columns x NW TY cell rows x (TZ+1)
-// cell layers and owns the 63 x (NW TY - 1) x TZ DoFs whose eight cells all lie inside (one halo
+// a workgroup of NW wavefronts marches over a tile of 64 node columns x NW TY cell rows x (TZ+1)
+// cell layers and owns the 62 x (NW TY - 1) x TZ DoFs whose eight cells all lie inside (one halo
 // column / row / layer on the low side is recomputed).  Wavefront w computes the TY cell rows
 // [Yb + w TY, Yb + (w+1) TY) and hands the b=1 partial sums of its last row to wavefront w+1 through
 // LDS (one barrier per layer) instead of letting w+1 recompute that row.
@@ -30,15 +29,13 @@
 //   in y : a register carried from the previous cell row (LDS hand-over between wavefronts),
 //   in z : a per-lane column in LDS carried from the previous cell layer,
 // so every DoF value is complete exactly when its own slot is visited and the smoother
-// epilogue (b, D^-1, x_prev) is fused there: A x is never stored.  x is read once per tile: the
-// b=0 face of a cell is the b=1 face of the previous row (registers), the d=0 edge is the d=1 edge
+// epilogue (b, D^-1, x_prev) is fused there: A x is never stored.  x is read once per wavefront and layer pass:
+// the b=0 face of a cell is the b=1 face of the previous row (registers), the d=0 edge is the d=1 edge
 // of the previous layer (a second per-lane LDS column), the a=1 corners are the a=0 corners of the
-// next lane; the steady state reads one record and gathers ONE x value per cell.
+// next lane (DPP).
 //
-// Memory pipeline: a wavefront pays one memory round trip per row.  The ids of row j+1 are fetched
-// while row j is computed, and the operands of the epilogue (which depend only on the id of the row's
-// own DoF, known one row ahead) are requested together with the coefficients at the top of the row.
-// Vector accesses use a uniform (SGPR) base and a 32-bit per-lane byte offset.
+// Memory pipeline (see mf_laplace_body): one memory round trip per layer pass of a wavefront; vector accesses
+// use a uniform (SGPR) base and a 32-bit per-lane byte offset.
 #include "mf_laplace.hpp"
 
 #include <algorithm>
@@ -52,7 +49,6 @@ template <typename T>
 struct MfArgs
 {
   unsigned char const *rec;
-  int4 const *fb0;
   T const *x;
   T const *b;
   T const *dinv; // by DoF id (the rows handed over between wavefronts)
@@ -64,6 +60,7 @@ struct MfArgs
   unsigned int ncols_active;              // chunk columns that get workgroups (the last one may go to the tail slab)
   unsigned int z_tile0;
   T fx, fy, fz;
+  T fax, fbx, fay, fby, faz, fbz; // one coefficient per cell: 2 f M00, 2 f M01 per direction (M = [[2/3, 1/3], [1/3, 2/3]])
   T alpha, beta;
   int mode;
 };
@@ -73,6 +70,7 @@ namespace
 constexpr unsigned int kFlag = 0x80000000u;  // bit 31: Dirichlet-constrained DoF (read as zero, row = identity)
 constexpr unsigned int kGhost = 0x40000000u; // bit 30: DoF owned by another rank (read normally, never written)
 constexpr unsigned int kIdMask = ~(kFlag | kGhost);
+constexpr int kOwn = 62; // DoF columns a chunk owns (lanes 1 .. 62; lanes 0 and 63 repeat the neighbours' columns)
 
 // geometry of one chunk record.  CC ("cell constant"): the eight quadrature coefficients of every cell are
 // equal (a constant or cell-wise constant material: the reference's default `material_property constant`), and
@@ -132,126 +130,113 @@ __device__ __forceinline__ float from_next_lane(float v)
   return __int_as_float(dpp_from_next(__float_as_int(v)));
 }
 
-// out[p][.] = S[p][0] in0 + S[p][1] in1 with S = [[A, B], [B, A]]
-#define MFMG_INTERP(o0, o1, i0, i1)                                                                          \
-  T o0 = fmadd<T>(A, i0, B * (i1));                                                                          \
-  T o1 = fmadd<T>(B, i0, A * (i1));
+// out[p][.] = S[p][0] in0 + S[p][1] in1 with S = [[A, B], [B, A]] and A + B = 1 (true for the Gauss
+// interpolation weights and for the 1-D mass matrix S^T S):  out0 = in1 + A (in0 - in1),  out1 = in0 - A (in0 - in1)
+// -- three instructions instead of four.
+#define MFMG_INTERP(o0, o1, i0, i1, A)                                                                       \
+  T o0, o1;                                                                                                  \
+  {                                                                                                          \
+    const T dlt = (i0) - (i1);                                                                               \
+    o0 = fmadd<T>(A, dlt, i1);                                                                               \
+    o1 = fmadd<T>(-(A), dlt, i0);                                                                            \
+  }
+// the same with both outputs scaled by a factor folded into the constants: fa = f A, fb = f B
+#define MFMG_INTERP_SCALED(o0, o1, i0, i1, fa, fb)                                                           \
+  const T o0 = fmadd<T>(fa, i0, (fb) * (i1));                                                                \
+  const T o1 = fmadd<T>(fb, i0, (fa) * (i1));
 
 template <typename T>
 __device__ __forceinline__ void direction_apply(T d00, T d10, T d01, T d11, T c00, T c10, T c01, T c11, T f,
                                                 T &X00, T &X10, T &X01, T &X11)
 {
 #pragma clang fp contract(off)
-  const T A = T(MFMG_GA), B = T(MFMG_GB);
+  const T A = T(MFMG_GA);
   // interpolate the one-sided differences d[p][r] to the 2x2 Gauss points of the two other directions
-  MFMG_INTERP(t00, t10, d00, d10) // t[qp][r=0]
-  MFMG_INTERP(t01, t11, d01, d11) // t[qp][r=1]
-  MFMG_INTERP(g00, g01, t00, t01) // g[qp=0][qr]
-  MFMG_INTERP(g10, g11, t10, t11) // g[qp=1][qr]
-  // flux, already summed over the two Gauss points of the differentiated direction
-  const T s00 = g00 * c00, s10 = g10 * c10, s01 = g01 * c01, s11 = g11 * c11;
+  MFMG_INTERP(t00, t10, d00, d10, A) // t[qp][r=0]
+  MFMG_INTERP(t01, t11, d01, d11, A) // t[qp][r=1]
+  MFMG_INTERP(g00, g01, t00, t01, A) // g[qp=0][qr]
+  MFMG_INTERP(g10, g11, t10, t11, A) // g[qp=1][qr]
+  // flux, already summed over the two Gauss points of the differentiated direction; the direction factor rides along
+  const T s00 = g00 * (f * c00), s10 = g10 * (f * c10), s01 = g01 * (f * c01), s11 = g11 * (f * c11);
   // transposed interpolation back to the corners
-  MFMG_INTERP(w00, w01, s00, s01) // w[qp=0][r]
-  MFMG_INTERP(w10, w11, s10, s11) // w[qp=1][r]
-  MFMG_INTERP(x00, x10, w00, w10) // x[p][r=0]
-  MFMG_INTERP(x01, x11, w01, w11) // x[p][r=1]
-  X00 = f * x00;
-  X10 = f * x10;
-  X01 = f * x01;
-  X11 = f * x11;
+  MFMG_INTERP(w00, w01, s00, s01, A) // w[qp=0][r]
+  MFMG_INTERP(w10, w11, s10, s11, A) // w[qp=1][r]
+  MFMG_INTERP(x00, x10, w00, w10, A) // x[p][r=0]
+  MFMG_INTERP(x01, x11, w01, w11, A) // x[p][r=1]
+  X00 = x00;
+  X10 = x10;
+  X01 = x01;
+  X11 = x11;
 }
 
 // The same with one coefficient per cell: the flux is a uniform scaling, so interpolation to the Gauss points
 // and back collapses into the 1-D mass matrix M = S^T S = [[A^2 + B^2, 2AB], [2AB, A^2 + B^2]] (= [[2/3, 1/3],
-// [1/3, 2/3]], the two-point rule is exact here) applied once per transverse direction: half the work.
+// [1/3, 2/3]], the two-point rule is exact here) applied once per transverse direction.  The direction factor
+// (and the 2 of the two Gauss points of the differentiated direction) is folded into the constants of the second
+// pass (fa = 2 f 2/3, fb = 2 f 1/3, computed on the host); the coefficient multiplies the eight corner sums at the end.
 template <typename T>
-__device__ __forceinline__ void direction_apply_cc(T d00, T d10, T d01, T d11, T fw, T &X00, T &X10, T &X01, T &X11)
+__device__ __forceinline__ void direction_apply_cc(T d00, T d10, T d01, T d11, T fa, T fb, T &X00, T &X10, T &X01, T &X11)
 {
 #pragma clang fp contract(off)
-  const T A = T(MFMG_GA * MFMG_GA + MFMG_GB * MFMG_GB), B = T(2. * MFMG_GA * MFMG_GB);
-  MFMG_INTERP(t00, t10, d00, d10) // mass matrix over p, r = 0
-  MFMG_INTERP(t01, t11, d01, d11) // r = 1
-  MFMG_INTERP(x00, x01, t00, t01) // mass matrix over r, p = 0
-  MFMG_INTERP(x10, x11, t10, t11) // p = 1
-  X00 = fw * x00;
-  X10 = fw * x10;
-  X01 = fw * x01;
-  X11 = fw * x11;
+  const T A = T(MFMG_GA * MFMG_GA + MFMG_GB * MFMG_GB);
+  MFMG_INTERP(t00, t10, d00, d10, A)            // mass matrix over p, r = 0
+  MFMG_INTERP(t01, t11, d01, d11, A)            // r = 1
+  MFMG_INTERP_SCALED(x00, x01, t00, t01, fa, fb) // mass matrix over r, p = 0
+  MFMG_INTERP_SCALED(x10, x11, t10, t11, fa, fb) // p = 1
+  X00 = x00;
+  X10 = x10;
+  X01 = x01;
+  X11 = x11;
 }
 
 template <typename T>
-__device__ __forceinline__ void cell_apply_cc(T const u[8], T cv, T fx, T fy, T fz, T v[8])
+struct CellFactors
+{
+  T fx, fy, fz;             // h-scaling of the three directions (eight coefficients per cell)
+  T fax, fbx, fay, fby, faz, fbz; // 2 f M00, 2 f M01 per direction (one coefficient per cell)
+};
+
+template <typename T>
+__device__ __forceinline__ void cell_apply_cc(T const u[8], T cv, CellFactors<T> const &f, T v[8])
 {
 #pragma clang fp contract(off)
-  T X00, X10, X01, X11;
-  const T w2 = cv + cv; // the two Gauss points of the differentiated direction
-  direction_apply_cc<T>(u[1] - u[0], u[3] - u[2], u[5] - u[4], u[7] - u[6], fx * w2, X00, X10, X01, X11);
-  v[0] = -X00;
-  v[1] = X00;
-  v[2] = -X10;
-  v[3] = X10;
-  v[4] = -X01;
-  v[5] = X01;
-  v[6] = -X11;
-  v[7] = X11;
-  direction_apply_cc<T>(u[2] - u[0], u[3] - u[1], u[6] - u[4], u[7] - u[5], fy * w2, X00, X10, X01, X11);
-  v[0] -= X00;
-  v[2] += X00;
-  v[1] -= X10;
-  v[3] += X10;
-  v[4] -= X01;
-  v[6] += X01;
-  v[5] -= X11;
-  v[7] += X11;
-  direction_apply_cc<T>(u[4] - u[0], u[5] - u[1], u[6] - u[2], u[7] - u[3], fz * w2, X00, X10, X01, X11);
-  v[0] -= X00;
-  v[4] += X00;
-  v[1] -= X10;
-  v[5] += X10;
-  v[2] -= X01;
-  v[6] += X01;
-  v[3] -= X11;
-  v[7] += X11;
+  T X00, X10, X01, X11, Y00, Y10, Y01, Y11, Z00, Z10, Z01, Z11;
+  direction_apply_cc<T>(u[1] - u[0], u[3] - u[2], u[5] - u[4], u[7] - u[6], f.fax, f.fbx, X00, X10, X01, X11);
+  direction_apply_cc<T>(u[2] - u[0], u[3] - u[1], u[6] - u[4], u[7] - u[5], f.fay, f.fby, Y00, Y10, Y01, Y11);
+  direction_apply_cc<T>(u[4] - u[0], u[5] - u[1], u[6] - u[2], u[7] - u[3], f.faz, f.fbz, Z00, Z10, Z01, Z11);
+  // corner m = a + 2b + 4d: x pairs (a): X[b][d]; y pairs (b): Y[a][d]; z pairs (d): Z[a][b]
+  v[0] = cv * ((-X00 - Y00) - Z00);
+  v[1] = cv * ((X00 - Y10) - Z10);
+  v[2] = cv * ((Y00 - X10) - Z01);
+  v[3] = cv * ((X10 + Y10) - Z11);
+  v[4] = cv * ((Z00 - X01) - Y01);
+  v[5] = cv * ((X01 - Y11) + Z10);
+  v[6] = cv * ((Y01 - X11) + Z01);
+  v[7] = cv * ((X11 + Y11) + Z11);
 }
 
 template <typename T>
-__device__ __forceinline__ void cell_apply(T const u[8], T const c[8], T fx, T fy, T fz, T v[8])
+__device__ __forceinline__ void cell_apply(T const u[8], T const c[8], CellFactors<T> const &f, T v[8])
 {
 #pragma clang fp contract(off)
-  T X00, X10, X01, X11;
+  T X00, X10, X01, X11, Y00, Y10, Y01, Y11, Z00, Z10, Z01, Z11;
   // x: differences along a, (p, r) = (b, d); coefficient pairs summed over qa
   direction_apply<T>(u[1] - u[0], u[3] - u[2], u[5] - u[4], u[7] - u[6], c[0] + c[1], c[2] + c[3], c[4] + c[5],
-                     c[6] + c[7], fx, X00, X10, X01, X11);
-  v[0] = -X00;
-  v[1] = X00;
-  v[2] = -X10;
-  v[3] = X10;
-  v[4] = -X01;
-  v[5] = X01;
-  v[6] = -X11;
-  v[7] = X11;
+                     c[6] + c[7], f.fx, X00, X10, X01, X11);
   // y: differences along b, (p, r) = (a, d); summed over qb
   direction_apply<T>(u[2] - u[0], u[3] - u[1], u[6] - u[4], u[7] - u[5], c[0] + c[2], c[1] + c[3], c[4] + c[6],
-                     c[5] + c[7], fy, X00, X10, X01, X11);
-  v[0] -= X00;
-  v[2] += X00;
-  v[1] -= X10;
-  v[3] += X10;
-  v[4] -= X01;
-  v[6] += X01;
-  v[5] -= X11;
-  v[7] += X11;
+                     c[5] + c[7], f.fy, Y00, Y10, Y01, Y11);
   // z: differences along d, (p, r) = (a, b); summed over qc
   direction_apply<T>(u[4] - u[0], u[5] - u[1], u[6] - u[2], u[7] - u[3], c[0] + c[4], c[1] + c[5], c[2] + c[6],
-                     c[3] + c[7], fz, X00, X10, X01, X11);
-  v[0] -= X00;
-  v[4] += X00;
-  v[1] -= X10;
-  v[5] += X10;
-  v[2] -= X01;
-  v[6] += X01;
-  v[3] -= X11;
-  v[7] += X11;
+                     c[3] + c[7], f.fz, Z00, Z10, Z01, Z11);
+  v[0] = (-X00 - Y00) - Z00;
+  v[1] = (X00 - Y10) - Z10;
+  v[2] = (Y00 - X10) - Z01;
+  v[3] = (X10 + Y10) - Z11;
+  v[4] = (Z00 - X01) - Y01;
+  v[5] = (X01 - Y11) + Z10;
+  v[6] = (Y01 - X11) + Z01;
+  v[7] = (X11 + Y11) + Z11;
 }
 
 // 32-bit byte offsets from a uniform base: the global_load takes the base from SGPRs and one VGPR per
@@ -270,6 +255,12 @@ template <typename T>
 __device__ __forceinline__ unsigned int id_off(int id)
 {
   return ((unsigned int)id & kIdMask) * (unsigned int)sizeof(T);
+}
+// constrained DoFs read as zero (bit 31 of the id)
+template <typename T>
+__device__ __forceinline__ T masked(T x, int id)
+{
+  return (id < 0) ? T(0) : x;
 }
 
 template <typename T, bool CC>
@@ -298,7 +289,7 @@ __device__ __forceinline__ void load_coef(unsigned char const *rec, int lane, T 
   }
 }
 
-// fused epilogue of one DoF: ax = (A x)_g, x0 = x_g
+// fused epilogue of one DoF: yv = (A x)_g for an unconstrained row, x0 = x_g
 template <typename T>
 __device__ __forceinline__ T mf_epilogue(MfArgs<T> const &a, int id0, T x0, T yv, T lb, T ld, T lxp)
 {
@@ -313,21 +304,41 @@ __device__ __forceinline__ T mf_epilogue(MfArgs<T> const &a, int id0, T x0, T yv
   return (a.mode == 2) ? fmadd<T>(wgt, r, x0) : fmadd<T>(wgt, r, fmadd<T>(a.alpha, x0 - lxp, x0));
 }
 
+// The tile body.  There is no per-lane control flow around the cell arithmetic: every lane of every row computes a
+// cell.  What makes that legal is the data, not branches:
+//   * slots without a real cell (the halo lanes past the last column, the last DoF row and layer) are stored with
+//     coefficient zero and valid ids, so they contribute exact zeros; lane 63 is a halo NODE column only (its cell
+//     would need column 64: it is computed on shifted garbage and nothing reads the result);
+//   * the halo layer k = -1 of the first z-tile is evaluated at the clamped layer 0 with the coefficient forced to
+//     zero (a wave-uniform select); the b = 1 face of the last DoF row is read at the clamped row Ny - 1 (its cells
+//     are phantoms with coefficient zero);
+//   * Dirichlet DoFs are zeroed ONCE, when a value enters the tile (one value per lane and node row), not at each
+//     of the eight corners of each cell; the unmasked value of the row's own DoF rides along for the epilogue.
+// Memory pipeline: ONE round trip per layer pass of a wavefront.  All requests of the pass -- the x values of the
+// b=1 faces of its rows in layer k+1 (their ids were fetched during the previous pass), the coefficients, the
+// epilogue operands of the rows it completes (their ids sit in LDS since the previous pass) and the ids of the
+// next pass -- are issued before the first row is computed; the values of layer k come from LDS / registers.
 // TYC > 0: rows per wavefront known at compile time (the row loop is fully unrolled: no loop-carried register
-// moves, constant LDS offsets); TYC = 0: taken from the arguments.
-template <typename T, int TYC, bool CC>
+// moves, constant LDS offsets, the whole pass is one request batch for TYC <= 4); TYC = 0: rows from the
+// arguments, one request batch per row.
+template <typename T, int TYC, bool CC, int BATCH>
 __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int bid)
 {
 #pragma clang fp contract(off)
+  constexpr int B = TYC > 0 ? BATCH : 1; // cell rows per request batch (divides TYC)
+  constexpr bool XP = TYC > 0;           // ids of the next pass are prefetched across the barrier
+  static_assert(TYC == 0 || TYC % B == 0, "the batch must divide the rows per wavefront");
   const int TY = TYC > 0 ? TYC : a.TY;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, keep it scalar
   const int NW = blockDim.x >> 6;
-  T *pt = reinterpret_cast<T *>(smem_raw) + (size_t)wv * 2 * TY * 64;   // [TY][64] z-carry of the partial sums
-  T *xz = pt + TY * 64;                                                  // [TY][64] z-carry of x
-  T *xport = reinterpret_cast<T *>(smem_raw) + (size_t)NW * 2 * TY * 64; // [2][NW][2][64] hand-over rows
-  int2 *idz = reinterpret_cast<int2 *>(xport + (size_t)2 * NW * 2 * 64) + (size_t)wv * TY * 64; // [TY][64] z-carry of the ids
+  // LDS: per wavefront pt[TY] (z-carry of the partial sums), xz[TY+1] (z-carry of x, one slot per node row),
+  // then the hand-over rows of all wavefronts, then per wavefront idz[TY+1] (z-carry of the ids)
+  T *pt = reinterpret_cast<T *>(smem_raw) + (size_t)wv * (2 * TY + 1) * 64;
+  T *xz = pt + TY * 64;
+  T *xport = reinterpret_cast<T *>(smem_raw) + (size_t)NW * (2 * TY + 1) * 64; // [2][NW][2][64]
+  int *idz = reinterpret_cast<int *>(xport + (size_t)2 * NW * 2 * 64) + (size_t)wv * (TY + 1) * 64;
 
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8,
   // observed, speed only); give every XCD a contiguous run of the tile list.
@@ -343,241 +354,237 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
   const int tc = w % a.ncols_active;
   const int tyi = (w / a.ncols_active) % a.ntiles_y;
   const int tzi = a.z_tile0 + w / (a.ncols_active * a.ntiles_y);
-  const int ci = tc * 63 - 1 + lane;                     // cell / DoF column of this lane
+  const int ci = tc * kOwn - 1 + lane;              // cell / DoF column of this lane
   const int Yb = tyi * (NW * TY - 1) - 1 + wv * TY; // first cell row of this wavefront
   const int Z0 = tzi * a.TZ;
-  const bool col_ok = ci >= 0 && ci < a.Nx;
-  const bool col_cell = col_ok && ci < a.Nx - 1;
-  const bool col_owned = lane >= 1 && ci < a.Nx;
-  // the lane whose a=1 corners are not the a=0 corners of lane+1 inside this wavefront
-  const bool no_next = (lane == 63) || (ci + 1 >= a.Nx);
+  const bool col_owned = lane >= 1 && lane <= kOwn && ci < a.Nx;
   const int jj0 = (Yb < 0) ? 1 : 0; // cell row -1 does not exist (its sums are the zero initial carries)
   const size_t rec_row = (size_t)a.ncols * Rec<T, CC>::kBytes;
   const size_t rec_layer = (size_t)a.Ny * rec_row;
-  const bool next_chunk = (lane == 63) && (ci + 1 < a.Nx); // its a=1 corners are lane 1 of the next chunk
-  const size_t fb0_row = (size_t)a.ncols * 64;
+  unsigned char const *rec_col = a.rec + (size_t)tc * Rec<T, CC>::kBytes;
+  const bool have_rows = (jj0 < TY) && (Yb + jj0 < a.Ny);
+  CellFactors<T> fac;
+  fac.fx = a.fx;
+  fac.fy = a.fy;
+  fac.fz = a.fz;
+  fac.fax = a.fax;
+  fac.fbx = a.fbx;
+  fac.fay = a.fay;
+  fac.fby = a.fby;
+  fac.faz = a.faz;
+  fac.fbz = a.fbz;
+  // own id of node row `jrow` (clamped into the mesh) in the layer whose records start at `layer`
+  auto own_id = [&](unsigned char const *layer, int jrow) {
+    return reinterpret_cast<int const *>(layer + (size_t)min(max(jrow, 0), a.Ny - 1) * rec_row)[lane];
+  };
+  int pf[XP ? TYC + 1 : 1]; // own ids of the node rows Yb .. Yb + TY in the layer after next
+#pragma unroll
+  for (int r = 0; r < (XP ? TYC + 1 : 1); ++r)
+    pf[r] = 0;
 
   for (int kk = 0; kk <= a.TZ; ++kk)
   {
     const int k = Z0 - 1 + kk;
     if (k >= a.Nz)
       break; // uniform over the workgroup
-    const bool kin = k >= 0;
-    const bool kcell = kin && (k < a.Nz - 1);
-    const bool layer_carry = (kk > 0) && (k >= 1); // xz holds x(., ., k) written by layer k-1
+    const int kc = max(k, 0);            // layer the records of "layer k" are read from
+    const int kn = min(k + 1, a.Nz - 1); // ... and those of layer k + 1
+    const bool no_cells = k < 0;         // the halo layer below the mesh: coefficient forced to zero
+    const bool layer_carry = kk > 0;     // xz / idz hold x and the ids of layer k, written by the pass of layer k - 1
+    unsigned char const *rec_k = rec_col + (size_t)kc * rec_layer;
+    unsigned char const *rec_kn = rec_col + (size_t)kn * rec_layer;
+    unsigned char const *rec_kn2 = rec_col + (size_t)min(k + 2, a.Nz - 1) * rec_layer;
     T ry0 = T(0), ry1 = T(0);
-    // b=0 face carried from the previous cell row: raw x values, ids (flag in bit 31)
-    T cx[4] = {T(0), T(0), T(0), T(0)};
-    int cid[4] = {0, 0, 0, 0};
-    bool carried = false;
-    // first DoF row of a wavefront w > 0, finished after the barrier
-    T d00 = T(0), d01 = T(0), dx0 = T(0);
+    // b=0 face carried from the previous cell row: Dirichlet-masked x values of the four corners, the raw value
+    // and the id of the own DoF
+    T cxm[4] = {T(0), T(0), T(0), T(0)};
+    T cx0 = T(0);
+    int id0 = 0;
+    // first DoF row of a wavefront w > 0, finished after the barrier: sums, raw x, id, epilogue operands
+    T d00 = T(0), d01 = T(0), dx0 = T(0), dlb = T(0), dld = T(0), dlx = T(0);
     int did0 = 0;
-    bool dlive = false;
 
-    // ids of the first row of the layer
-    int j = Yb + jj0;
-    const size_t r0 = ((size_t)max(k, 0) * a.Ny + (size_t)j) * a.ncols + (size_t)tc; // uniform
-    unsigned char const *recp = a.rec + r0 * Rec<T, CC>::kBytes;
-    int4 const *fb0p = a.fb0 + r0 * 64;
-    bool slot = col_ok && kin && (j < a.Ny) && (jj0 < TY);
-    bool cell = slot && col_cell && (j < a.Ny - 1) && kcell;
-    int4 pf0 = make_int4(0, 0, 0, 0);
-    // own ids of row j+1 in layer k (A) and k+1 (B); x: the same for column ci+1 where it lies in the next chunk
-    int pfA = 0, pfB = 0, pfAx = 0, pfBx = 0;
-    if (slot)
-      pf0 = fb0p[lane];
+    // ---- first node row of the pass (the b=0 face of its first cell row)
+    if (have_rows)
     {
-      const bool nodes = col_ok && kcell && (j + 1 < a.Ny) && (jj0 < TY);
-      if (nodes)
+      const int jf = Yb + jj0;
+      int idBf, idAf;
+      T xAf;
+      if (layer_carry)
       {
-        pfB = reinterpret_cast<int const *>(recp + rec_row + rec_layer)[lane];
-        if (!layer_carry)
-          pfA = reinterpret_cast<int const *>(recp + rec_row)[lane];
-        if (next_chunk)
-        {
-          pfBx = reinterpret_cast<int const *>(recp + rec_row + rec_layer + Rec<T, CC>::kBytes)[1];
-          if (!layer_carry)
-            pfAx = reinterpret_cast<int const *>(recp + rec_row + Rec<T, CC>::kBytes)[1];
-        }
+        idAf = idz[jj0 * 64 + lane];
+        xAf = xz[jj0 * 64 + lane];
+        if constexpr (XP)
+          idBf = jj0 ? pf[XP ? 1 : 0] : pf[0]; // (no run-time index into the register array)
+        else
+          idBf = own_id(rec_kn, jf);
       }
+      else
+      {
+        idAf = own_id(rec_k, jf);
+        idBf = own_id(rec_kn, jf);
+        xAf = ld_off<T>(a.x, id_off<T>(idAf));
+      }
+      const T xBf = ld_off<T>(a.x, id_off<T>(idBf));
+      if (wv > 0 && kk > 0 && a.mode != 0)
+      {
+        // epilogue operands of the deferred row (its id has been in LDS since the previous pass)
+        const unsigned int g = id_off<T>(idAf);
+        dlb = ld_off<T>(a.b, g);
+        if (a.mode >= 2)
+          dld = reinterpret_cast<T const *>(rec_k + (size_t)jf * rec_row + Rec<T, CC>::kDinvOff)[lane];
+        if (a.mode == 3)
+          dlx = ld_off<T>(a.xprev, g);
+      }
+      xz[jj0 * 64 + lane] = xBf;
+      idz[jj0 * 64 + lane] = idBf;
+      id0 = idAf;
+      cx0 = xAf;
+      cxm[0] = masked<T>(xAf, idAf);
+      cxm[2] = masked<T>(xBf, idBf);
+      cxm[1] = from_next_lane(cxm[0]);
+      cxm[3] = from_next_lane(cxm[2]);
     }
 
 #pragma unroll
-    for (int jj = jj0; jj < TY; ++jj, ++j)
+    for (int g = 0; g < TY; g += B)
     {
-      if (j >= a.Ny)
-        break;
-      const bool rown = (jj + 1 < TY) && (j + 1 < a.Ny);
-      const bool slotn = col_ok && kin && rown;
-      const bool celln = slotn && col_cell && (j + 1 < a.Ny - 1) && kcell;
-      unsigned char const *recn = recp + rec_row;
-      int4 const *fb0n = fb0p + fb0_row;
-      T v[8];
-      T c[CC ? 1 : 8];
-      T n0 = T(0), n2 = T(0), n1x = T(0), n3x = T(0);
-      T lb, ld, lxp; // (only read where `stores` holds and the mode asks for them)
-      int4 f1;
+      // ---- every request of the batch: node rows g+1 .. g+B (the b=1 faces of the cell rows g .. g+B-1)
+      bool ok[B];
+      int idA[B], idB[B];
+      T xA[B], xB[B], lb[B], ld[B], lxp[B];
+      T c[B][CC ? 1 : 8];
+#pragma unroll
+      for (int b = 0; b < B; ++b)
       {
-        const int bn = dpp_from_next(pfB);
-        f1.z = pfB;
-        f1.w = next_chunk ? pfBx : bn;
+        const int jj = g + b, j = Yb + jj;
+        ok[b] = jj >= jj0 && jj < TY && j < a.Ny;
+        idA[b] = idB[b] = 0;
+        xA[b] = xB[b] = lb[b] = ld[b] = lxp[b] = T(0);
+        if (!ok[b])
+          continue;
         if (layer_carry)
         {
-          const int2 c2 = cell ? idz[jj * 64 + lane] : make_int2(0, 0);
-          f1.x = c2.x;
-          f1.y = c2.y;
-        }
-        else
-        {
-          const int an = dpp_from_next(pfA);
-          f1.x = pfA;
-          f1.y = next_chunk ? pfAx : an;
-        }
-      }
-      if (slot && !carried)
-      {
-        cid[0] = pf0.x;
-        cid[1] = pf0.y;
-        cid[2] = pf0.z;
-        cid[3] = pf0.w;
-      }
-      const int id0 = cid[0];
-      const bool stores = slot && col_owned && jj > 0 && kk > 0 && !((unsigned int)id0 & kGhost);
-      // ---- every request of this row, and the ids of the next one
-      if (slot)
-      {
-        if (!carried)
-        {
-          cx[0] = ld_off<T>(a.x, id_off<T>(cid[0]));
-          if (cell)
-          {
-            cx[1] = ld_off<T>(a.x, id_off<T>(cid[1]));
-            cx[2] = ld_off<T>(a.x, id_off<T>(cid[2]));
-            cx[3] = ld_off<T>(a.x, id_off<T>(cid[3]));
-          }
-        }
-        if (cell)
-        {
-          if constexpr (CC)
-            c[0] = reinterpret_cast<T const *>(recp + Rec<T, true>::kCoefOff)[lane];
+          idA[b] = idz[(jj + 1) * 64 + lane];
+          xA[b] = xz[(jj + 1) * 64 + lane];
+          if constexpr (XP)
+            idB[b] = pf[XP ? g + b + 1 : 0];
           else
-            load_coef<T, false>(recp, lane, c);
-          n2 = ld_off<T>(a.x, id_off<T>(f1.z));                                     // x(ci, j+1, k+1)
-          n0 = layer_carry ? xz[jj * 64 + lane] : ld_off<T>(a.x, id_off<T>(f1.x)); // x(ci, j+1, k)
-          if (no_next)
-          {
-            n1x = ld_off<T>(a.x, id_off<T>(f1.y));
-            n3x = ld_off<T>(a.x, id_off<T>(f1.w));
-          }
+            idB[b] = own_id(rec_kn, j + 1);
         }
-        if (stores && a.mode != 0)
-        {
-          const unsigned int g = id_off<T>(id0);
-          lb = ld_off<T>(a.b, g);
-          if (a.mode >= 2)
-            ld = reinterpret_cast<T const *>(recp + Rec<T, CC>::kDinvOff)[lane];
-          if (a.mode == 3)
-            lxp = ld_off<T>(a.xprev, g);
-        }
-      }
-      int pfAn = 0, pfBn = 0, pfAxn = 0, pfBxn = 0;
-      int pf0n = 0;
-      if (col_ok && kcell && rown && (j + 2 < a.Ny))
-      {
-        pfBn = reinterpret_cast<int const *>(recn + rec_row + rec_layer)[lane];
-        if (!layer_carry)
-          pfAn = reinterpret_cast<int const *>(recn + rec_row)[lane];
-        if (next_chunk)
-        {
-          pfBxn = reinterpret_cast<int const *>(recn + rec_row + rec_layer + Rec<T, CC>::kBytes)[1];
-          if (!layer_carry)
-            pfAxn = reinterpret_cast<int const *>(recn + rec_row + Rec<T, CC>::kBytes)[1];
-        }
-      }
-      if (slotn && !celln)
-        pf0n = reinterpret_cast<int const *>(fb0n)[4 * lane];
-
-      const T x0 = cx[0];
-      // a=1 corners: the a=0 corners of the next lane (every lane takes part in the shift)
-      T n1 = from_next_lane(n0), n3 = from_next_lane(n2);
-      if (cell)
-      {
-        if (no_next)
-        {
-          n1 = n1x;
-          n3 = n3x;
-        }
-        xz[jj * 64 + lane] = n2;
-        idz[jj * 64 + lane] = make_int2(f1.z, f1.w);
-        T u[8];
-        // constrained DoFs read as zero
-        u[0] = (cid[0] < 0) ? T(0) : cx[0];
-        u[1] = (cid[1] < 0) ? T(0) : cx[1];
-        u[4] = (cid[2] < 0) ? T(0) : cx[2];
-        u[5] = (cid[3] < 0) ? T(0) : cx[3];
-        u[2] = (f1.x < 0) ? T(0) : n0;
-        u[3] = (f1.y < 0) ? T(0) : n1;
-        u[6] = (f1.z < 0) ? T(0) : n2;
-        u[7] = (f1.w < 0) ? T(0) : n3;
-        if constexpr (CC)
-          cell_apply_cc<T>(u, c[0], a.fx, a.fy, a.fz, v);
         else
-          cell_apply<T>(u, c, a.fx, a.fy, a.fz, v);
-        cx[0] = n0;
-        cx[1] = n1;
-        cx[2] = n2;
-        cx[3] = n3;
-        cid[0] = f1.x;
-        cid[1] = f1.y;
-        cid[2] = f1.z;
-        cid[3] = f1.w;
+        {
+          idA[b] = own_id(rec_k, j + 1);
+          idB[b] = own_id(rec_kn, j + 1);
+        }
       }
-      else
-      {
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
-          v[m] = T(0);
+      for (int b = 0; b < B; ++b)
+      {
+        if (!ok[b])
+          continue;
+        const int jj = g + b, j = Yb + jj;
+        unsigned char const *recp = rec_k + (size_t)j * rec_row;
+        xB[b] = ld_off<T>(a.x, id_off<T>(idB[b]));
+        if (!layer_carry)
+          xA[b] = ld_off<T>(a.x, id_off<T>(idA[b]));
+        if constexpr (CC)
+          c[b][0] = reinterpret_cast<T const *>(recp + Rec<T, true>::kCoefOff)[lane];
+        else
+          load_coef<T, false>(recp, lane, c[b]);
+        if (jj > 0 && kk > 0 && a.mode != 0)
+        {
+          // the DoF row this cell row completes: node row jj, id = the layer-k id of the previous node row
+          const unsigned int gid = id_off<T>((b == 0 || !ok[b > 0 ? b - 1 : 0]) ? id0 : idA[b > 0 ? b - 1 : 0]);
+          lb[b] = ld_off<T>(a.b, gid);
+          if (a.mode >= 2)
+            ld[b] = reinterpret_cast<T const *>(recp + Rec<T, CC>::kDinvOff)[lane];
+          if (a.mode == 3)
+            lxp[b] = ld_off<T>(a.xprev, gid);
+        }
       }
-      carried = cell;
+      if constexpr (XP)
+      {
+        // ids of the next pass (layer k + 2): the node rows whose current ids this batch has just consumed
+        if (have_rows)
+        {
+          if (g == 0)
+            pf[0] = own_id(rec_kn2, Yb);
+#pragma unroll
+          for (int b = 0; b < B; ++b)
+            pf[XP ? g + b + 1 : 0] = own_id(rec_kn2, Yb + g + b + 1);
+        }
+      }
 
-      // ---- x combine: DoF column ci gets the a=0 corners of its own cell and the a=1 corners of
-      //      the cell of the lane to the left (lane 0 is the halo column: its sum is never used)
-      const T s00 = v[0] + from_prev_lane(v[1]); // s[b][d]: b=0,d=0
-      const T s10 = v[2] + from_prev_lane(v[3]); // b=1,d=0
-      const T s01 = v[4] + from_prev_lane(v[5]); // b=0,d=1
-      const T s11 = v[6] + from_prev_lane(v[7]); // b=1,d=1
-      if (jj == 0 && wv > 0)
+      // ---- the rows of the batch
+#pragma unroll
+      for (int b = 0; b < B; ++b)
       {
-        // the b=1 sums of the row below arrive from wavefront w-1 after the barrier
-        d00 = s00;
-        d01 = s01;
-        dx0 = x0;
-        did0 = id0;
-        dlive = slot && col_owned && kk > 0 && !((unsigned int)id0 & kGhost);
+        if (!ok[b])
+          continue;
+        const int jj = g + b;
+        xz[(jj + 1) * 64 + lane] = xB[b];
+        idz[(jj + 1) * 64 + lane] = idB[b];
+        const T n0m = masked<T>(xA[b], idA[b]), n2m = masked<T>(xB[b], idB[b]);
+        const T n1m = from_next_lane(n0m), n3m = from_next_lane(n2m);
+        T u[8], v[8];
+        u[0] = cxm[0];
+        u[1] = cxm[1];
+        u[4] = cxm[2];
+        u[5] = cxm[3];
+        u[2] = n0m;
+        u[3] = n1m;
+        u[6] = n2m;
+        u[7] = n3m;
+        if constexpr (CC)
+          cell_apply_cc<T>(u, no_cells ? T(0) : c[b][0], fac, v);
+        else
+        {
+          if (no_cells)
+          {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              c[b][q] = T(0);
+          }
+          cell_apply<T>(u, c[b], fac, v);
+        }
+        const T x0 = cx0;
+        const int idr = id0;
+        cxm[0] = n0m;
+        cxm[1] = n1m;
+        cxm[2] = n2m;
+        cxm[3] = n3m;
+        cx0 = xA[b];
+        id0 = idA[b];
+
+        // ---- x combine: DoF column ci gets the a=0 corners of its own cell and the a=1 corners of
+        //      the cell of the lane to the left (lane 0 is the halo column: its sum is never used)
+        const T s00 = v[0] + from_prev_lane(v[1]); // s[b][d]: b=0,d=0
+        const T s10 = v[2] + from_prev_lane(v[3]); // b=1,d=0
+        const T s01 = v[4] + from_prev_lane(v[5]); // b=0,d=1
+        const T s11 = v[6] + from_prev_lane(v[7]); // b=1,d=1
+        if (jj == 0 && wv > 0)
+        {
+          // the b=1 sums of the row below arrive from wavefront w-1 after the barrier
+          d00 = s00;
+          d01 = s01;
+          dx0 = x0;
+          did0 = idr;
+        }
+        else
+        {
+          // ---- y combine (register carry), z combine (LDS column carry)
+          const T t0 = s00 + ry0;
+          const T t1 = s01 + ry1;
+          T *ptj = pt + jj * 64 + lane;
+          const T yv = t0 + *ptj; // (layer kk = 0 reads what an earlier tile left there: never stored)
+          *ptj = t1;
+          if (jj > 0 && kk > 0 && col_owned && !((unsigned int)idr & kGhost))
+            st_off<T>(a.out, id_off<T>(idr), mf_epilogue<T>(a, idr, x0, yv, lb[b], ld[b], lxp[b]));
+        }
+        ry0 = s10;
+        ry1 = s11;
       }
-      else
-      {
-        // ---- y combine (register carry), z combine (LDS column carry)
-        const T t0 = s00 + ry0;
-        const T t1 = s01 + ry1;
-        T *ptj = pt + jj * 64 + lane;
-        const T yv = (kk > 0) ? (t0 + *ptj) : T(0);
-        *ptj = t1;
-        if (stores)
-          st_off<T>(a.out, id_off<T>(id0), mf_epilogue<T>(a, id0, x0, yv, lb, ld, lxp));
-      }
-      ry0 = s10;
-      ry1 = s11;
-      pfA = pfAn;
-      pfB = pfBn;
-      pfAx = pfAxn;
-      pfBx = pfBxn;
-      pf0.x = pf0n;
-      slot = slotn;
-      cell = celln;
-      recp = recn;
-      fb0p = fb0n;
     }
     if (NW > 1)
     {
@@ -593,20 +600,10 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
         const T t0 = d00 + ip[0];
         const T t1 = d01 + ip[64];
         T *ptj = pt + lane;
-        const T yv = (kk > 0) ? (t0 + *ptj) : T(0);
+        const T yv = t0 + *ptj;
         *ptj = t1;
-        if (dlive)
-        {
-          const unsigned int g = id_off<T>(did0);
-          T lb = T(0), ld = T(0), lxp = T(0);
-          if (a.mode != 0)
-            lb = ld_off<T>(a.b, g);
-          if (a.mode >= 2)
-            ld = ld_off<T>(a.dinv, g);
-          if (a.mode == 3)
-            lxp = ld_off<T>(a.xprev, g);
-          st_off<T>(a.out, g, mf_epilogue<T>(a, did0, dx0, yv, lb, ld, lxp));
-        }
+        if (kk > 0 && have_rows && col_owned && !((unsigned int)did0 & kGhost))
+          st_off<T>(a.out, id_off<T>(did0), mf_epilogue<T>(a, did0, dx0, yv, dlb, dld, dlx));
       }
     }
   }
@@ -614,28 +611,19 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
 
 // One launch can carry two meshes: the first `n_tail_blocks` workgroups work on `at` (the rotated slab of the
 // tail columns, see the constructor), the others on `am`.  Both share the tile shape (NW, TY, TZ).
-//
-// The cell-constant variant with three rows per wavefront needs 97 VGPRs: asking for five wavefronts per SIMD
-// costs it one spilled register and buys a fifth resident wavefront (measured 513^3: 6.15 -> 5.65 ms per sweep;
-// with four rows three registers spill and it loses).  The general variant (113-121 VGPRs) stays at four.
-template <typename T, int TYC, bool CC>
+// BATCH = cell rows whose requests are issued together (one memory round trip per batch): the whole pass for the
+// cell-constant variant, fewer for eight coefficients per cell (16 VGPRs of coefficients per row in FP64).
+template <typename T, int TYC, bool CC, int BATCH>
 __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> am, MfArgs<T> at, unsigned int n_tail_blocks)
 {
   const bool tail = blockIdx.x < n_tail_blocks;
-  mf_laplace_body<T, TYC, CC>(tail ? at : am, tail ? blockIdx.x : blockIdx.x - n_tail_blocks);
-}
-template <typename T, int TYC>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) void
-mf_laplace_cc5_kernel(MfArgs<T> am, MfArgs<T> at, unsigned int n_tail_blocks)
-{
-  const bool tail = blockIdx.x < n_tail_blocks;
-  mf_laplace_body<T, TYC, true>(tail ? at : am, tail ? blockIdx.x : blockIdx.x - n_tail_blocks);
+  mf_laplace_body<T, TYC, CC, BATCH>(tail ? at : am, tail ? blockIdx.x : blockIdx.x - n_tail_blocks);
 }
 
 // ---- setup kernels -----------------------------------------------------------
 template <typename T, bool CC>
 __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coefficient,
-                                 uint8_t const *constrained, int Nx, int Ny, int Nz, int ncols, int4 *fb0,
+                                 uint8_t const *constrained, int Nx, int Ny, int Nz, int ncols,
                                  unsigned char *rec)
 {
   const int64_t n_slots = (int64_t)ncols * Nz * Ny * 64;
@@ -650,7 +638,7 @@ __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coeffic
     const int c = chunk % ncols;
     const int j = (chunk / ncols) % Ny;
     const int k = chunk / ((int64_t)ncols * Ny);
-    const int i = c * 63 - 1 + lane;
+    const int i = c * kOwn - 1 + lane;
     int id[8];
     T cf[8];
     if (i < 0 || i >= Nx)
@@ -681,7 +669,6 @@ __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coeffic
         cf[m] = real ? T(coefficient[(i + (int64_t)nx * (j + (int64_t)ny * k)) * 8 + m]) : T(0);
       }
     }
-    fb0[s] = make_int4(id[0], id[1], id[4], id[5]);
     unsigned char *r = rec + (size_t)chunk * Rec<T, CC>::kBytes;
     reinterpret_cast<int *>(r)[lane] = id[0];
     if constexpr (CC)
@@ -697,8 +684,8 @@ __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coeffic
 // chunk and lane of cell / DoF (i,j,k) (the copy owned by its column)
 __device__ __forceinline__ size_t chunk_of(int i, int j, int k, int Ny, int ncols, int &lane)
 {
-  const int c = i / 63; // chunk c owns the columns 63c .. 63c+62 in its lanes 1 .. 63 (lane 0 repeats column 63c-1)
-  lane = i + 1 - 63 * c;
+  const int c = i / kOwn; // chunk c owns the columns kOwn c .. kOwn c + kOwn - 1 in its lanes 1 .. kOwn
+  lane = i + 1 - kOwn * c;
   return ((size_t)k * Ny + j) * ncols + c;
 }
 
@@ -711,7 +698,7 @@ __global__ void mf_range_kernel(int32_t const *cell_dofs, int64_t n, int64_t n_d
 
 // Every corner (a,b,d) of real cell (i,j,k) as read from cell_dofs must be corner 0 of slot
 // (i+a,j+b,k+d): the logical-structure precondition of the tiled kernel.  Also checks the id range.
-__global__ void mf_validate_kernel(int32_t const *cell_dofs, int4 const *fb0, int Nx, int Ny, int Nz, int ncols,
+__global__ void mf_validate_kernel(int32_t const *cell_dofs, unsigned char const *rec, size_t rec_bytes, int Nx, int Ny, int Nz, int ncols,
                                    int64_t n_dofs, int *n_bad)
 {
   const int nx = Nx - 1, ny = Ny - 1, nz = Nz - 1;
@@ -732,7 +719,7 @@ __global__ void mf_validate_kernel(int32_t const *cell_dofs, int4 const *fb0, in
       }
       int lane;
       const size_t r = chunk_of(i + (m & 1), j + ((m >> 1) & 1), k + (m >> 2), Ny, ncols, lane);
-      if ((int)((unsigned int)fb0[r * 64 + lane].x & kIdMask) != g)
+      if ((int)((unsigned int)reinterpret_cast<int const *>(rec + r * rec_bytes)[lane] & kIdMask) != g)
         bad = true;
     }
     if (bad)
@@ -748,7 +735,7 @@ struct DiagTable
 // compute_diagonal (tests/laplace_matrix_free.hpp:75-98,158-199): per-cell
 // unit-vector applies summed per DoF; constrained entries set to one.
 template <typename T, bool CC>
-__global__ void mf_diagonal_kernel(int4 const *fb0, unsigned char const *rec, int Nx, int Ny, int Nz, int ncols,
+__global__ void mf_diagonal_kernel(unsigned char const *rec, int Nx, int Ny, int Nz, int ncols,
                                    DiagTable tab, T *diag, T *dinv)
 {
   const int64_t n = (int64_t)Nx * Ny * Nz;
@@ -760,7 +747,7 @@ __global__ void mf_diagonal_kernel(int4 const *fb0, unsigned char const *rec, in
     const int k = t / ((int64_t)Nx * Ny);
     int lane;
     const size_t r = chunk_of(i, j, k, Ny, ncols, lane);
-    const int id0 = fb0[r * 64 + lane].x;
+    const int id0 = reinterpret_cast<int const *>(rec + r * Rec<T, CC>::kBytes)[lane];
     double sum = 0.;
     for (int m = 0; m < 8; ++m)
     {
@@ -797,7 +784,7 @@ __global__ void mf_cell_constant_kernel(double const *coefficient, int64_t n_cel
 
 // copy of D^-1 in slot order inside the records (every slot of a real DoF, the duplicated halo slots too)
 template <typename T, bool CC>
-__global__ void mf_fill_dinv_kernel(int4 const *fb0, T const *dinv, int Nx, int ncols, int64_t n_slots,
+__global__ void mf_fill_dinv_kernel(T const *dinv, int Nx, int ncols, int64_t n_slots,
                                     unsigned char *rec)
 {
   for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n_slots;
@@ -805,11 +792,12 @@ __global__ void mf_fill_dinv_kernel(int4 const *fb0, T const *dinv, int Nx, int 
   {
     const int lane = s & 63;
     const int64_t chunk = s >> 6;
-    const int i = (int)(chunk % ncols) * 63 - 1 + lane;
+    const int i = (int)(chunk % ncols) * kOwn - 1 + lane;
     if (i < 0 || i >= Nx)
       continue;
-    const unsigned int g = (unsigned int)fb0[s].x & kIdMask;
-    reinterpret_cast<T *>(rec + (size_t)chunk * Rec<T, CC>::kBytes + Rec<T, CC>::kDinvOff)[lane] = dinv[g];
+    unsigned char *r = rec + (size_t)chunk * Rec<T, CC>::kBytes;
+    const unsigned int g = (unsigned int)reinterpret_cast<int const *>(r)[lane] & kIdMask;
+    reinterpret_cast<T *>(r + Rec<T, CC>::kDinvOff)[lane] = dinv[g];
   }
 }
 } // namespace
@@ -893,10 +881,9 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
     co = co_tmp.data();
     cn = cn_tmp.data();
   }
-  _ncols = (_N[0] + 62) / 63;
+  _ncols = (_N[0] + kOwn - 1) / kOwn;
   const size_t n_slots = (size_t)_ncols * _N[2] * _N[1] * 64;
   _n_slots = n_slots;
-  _fb0.resize(n_slots);
   _diag.resize(nd);
   _dinv.resize(nd);
 
@@ -917,15 +904,16 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
                                          "order (DoF ids out of range)");
   if (_compact)
     hipLaunchKernelGGL((mf_repack_kernel<T, true>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, cd,
-                       co, cn, _N[0], _N[1], _N[2], _ncols, _fb0.data(), _rec.data());
+                       co, cn, _N[0], _N[1], _N[2], _ncols, _rec.data());
   else
     hipLaunchKernelGGL((mf_repack_kernel<T, false>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, cd,
-                       co, cn, _N[0], _N[1], _N[2], _ncols, _fb0.data(), _rec.data());
+                       co, cn, _N[0], _N[1], _N[2], _ncols, _rec.data());
   MFMG_HIP_CHECK(hipGetLastError());
 
   MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
   hipLaunchKernelGGL(mf_validate_kernel, dim3(n_blocks_for(nc, 256, 1 << 16)), dim3(256), 0, st, cd,
-                     _fb0.data(), _N[0], _N[1], _N[2], _ncols, _n_dofs, bad.data());
+                     _rec.data(), _compact ? Rec<T, true>::kBytes : Rec<T, false>::kBytes, _N[0], _N[1], _N[2], _ncols, _n_dofs,
+                     bad.data());
   MFMG_HIP_CHECK(hipGetLastError());
   int n_bad = bad.download(st)[0];
   ASSERT_THROW(n_bad == 0, "cell_dofs is not a logically structured hex mesh in lexicographic cell order (" +
@@ -959,16 +947,16 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   if (_compact)
   {
     hipLaunchKernelGGL((mf_diagonal_kernel<T, true>), dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
-                       _fb0.data(), _rec.data(), _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
+                       _rec.data(), _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
     hipLaunchKernelGGL((mf_fill_dinv_kernel<T, true>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st,
-                       _fb0.data(), _dinv.data(), _N[0], _ncols, (int64_t)n_slots, _rec.data());
+                       _dinv.data(), _N[0], _ncols, (int64_t)n_slots, _rec.data());
   }
   else
   {
     hipLaunchKernelGGL((mf_diagonal_kernel<T, false>), dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
-                       _fb0.data(), _rec.data(), _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
+                       _rec.data(), _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
     hipLaunchKernelGGL((mf_fill_dinv_kernel<T, false>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st,
-                       _fb0.data(), _dinv.data(), _N[0], _ncols, (int64_t)n_slots, _rec.data());
+                       _dinv.data(), _N[0], _ncols, (int64_t)n_slots, _rec.data());
   }
   MFMG_HIP_CHECK(hipGetLastError());
   MFMG_HIP_CHECK(hipStreamSynchronize(st));
@@ -979,10 +967,10 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   // instruction issue (the cell-constant variant).  Those columns (plus the last column of the previous chunk as
   // a halo that is read, not written) form a thin slab whose LONG direction is y: the same kernel runs on it
   // with x and y exchanged, lanes along y, inside the same launch, and the main part skips the last chunk.
-  const int tail_cols = _N[0] - 63 * (_ncols - 1); // DoF columns owned by the last chunk
-  if (!sub_mesh && _compact && _ncols >= 2 && tail_cols <= 16 && _N[1] >= 64)
+  const int tail_cols = _N[0] - kOwn * (_ncols - 1); // DoF columns owned by the last chunk
+  if (!sub_mesh && _compact && _ncols >= 2 && tail_cols <= 24 && _N[1] >= 64)
   {
-    const int i0 = 63 * (_ncols - 1) - 1; // halo column of the last chunk = last column of the chunk before
+    const int i0 = kOwn * (_ncols - 1) - 1; // halo column of the last chunk = last column of the chunk before
     const int sc = _n[0] - i0;            // cell columns of the slab
     const int64_t s_cells = (int64_t)_n[1] * sc * _n[2];
     DeviceBuffer<int32_t> s_cd((size_t)s_cells * 8);
@@ -1010,12 +998,12 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
 }
 
 // ---- tile choice ---------------------------------------------------------------------------------
-// The result does not depend on the tile (bit for bit), only the speed does.  Measured inside the V-cycle
-// on MI355X (profiles/README.md): the largest tile wins as long as the launch still has about three
-// workgroups of four wavefronts per CU and XCD round; below that the shorter tiles win (257^3 DoFs:
-// (4,3,8) 0.450 ms, (4,4,8) 0.457, (4,4,16) 0.500; 513^3 DoFs: (4,4,16) 3.26 ms, (4,3,8) 3.43).  A timed
-// choice at first use was tried and dropped: timings outside the cycle did not rank the tiles the way
-// the cycle does, and the pick changed from run to run.
+// The result does not depend on the tile (bit for bit), only the speed does.  With one memory round trip per
+// layer pass the kernel runs at the rate the memory system sustains for its access mix (about 5 TB/s of HBM
+// traffic on MI355X, profiles/README.md), and the tile only decides how many halo rows, columns and layers are
+// read twice: measured at 257^3 and 512^3 DoFs all reasonable tiles lie within 3 % of each other.  The largest
+// tile of the list that still gives every CU two rounds of wavefronts is taken (large tiles re-read less halo,
+// but a launch of fewer than two rounds pays its ramp up and down in full).
 template <typename T>
 void MatrixFreeLaplaceDevice<T>::choose_tile(int &nw, int &ty, int &tz) const
 {
@@ -1024,23 +1012,28 @@ void MatrixFreeLaplaceDevice<T>::choose_tile(int &nw, int &ty, int &tz) const
   tz = _tile_z;
   if (nw > 0 && ty > 0 && tz > 0)
     return;
-  // (the cell-constant variant is fastest with three rows per wavefront, where it fits five wavefronts per SIMD)
-  static const int pref_general[][3] = {{4, 4, 16}, {4, 4, 8}, {4, 3, 8}, {4, 2, 8}, {2, 2, 8}, {2, 2, 4}, {1, 2, 4}};
-  static const int pref_compact[][3] = {{4, 3, 16}, {4, 3, 8}, {4, 3, 8}, {4, 2, 8}, {2, 2, 8}, {2, 2, 4}, {1, 2, 4}};
+  static const int pref_general[][3] = {{8, 2, 16}, {4, 3, 8}, {4, 2, 8}, {2, 2, 8}, {2, 2, 4}, {1, 2, 4}};
+  static const int pref_compact[][3] = {{8, 4, 16}, {4, 3, 10}, {4, 3, 8}, {4, 2, 8}, {2, 2, 4}, {1, 2, 4}};
   const int(*pref)[3] = _compact ? pref_compact : pref_general;
-  constexpr int n_pref = 7;
+  constexpr int n_pref = 6;
+  static const int n_cus = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      v = 256;
+    return v > 0 ? v : 256;
+  }();
+  const int64_t waves_wanted = (int64_t)2 * 16 * n_cus; // two rounds of 4 wavefronts per SIMD
   int pick = n_pref - 1;
   for (int c = 0; c < n_pref; ++c)
   {
     const int64_t wgs = (int64_t)_ncols * ((_N[1] + pref[c][0] * pref[c][1] - 2) / (pref[c][0] * pref[c][1] - 1)) *
                         ((_N[2] + pref[c][2] - 1) / pref[c][2]);
-    if (wgs >= 3 * 1024)
+    if (wgs * pref[c][0] >= waves_wanted)
     {
       pick = c;
       break;
     }
   }
-  const bool tz_free = tz <= 0;
   if (nw <= 0)
     nw = pref[pick][0];
   if (ty <= 0)
@@ -1049,44 +1042,6 @@ void MatrixFreeLaplaceDevice<T>::choose_tile(int &nw, int &ty, int &tz) const
     tz = pref[pick][2];
   if (nw * ty < 2)
     ty = 2;
-  // Layers per tile of the cell-constant variant (bound by instruction issue, measured 257^3: 7 or 11 layers
-  // 0.244 ms per launch, 8: 0.264, 10: 0.268, 16: 0.292, 21: 0.332): all workgroups cost the same, 5 wavefronts per SIMD
-  // are resident, so the launch runs in ceil(workgroups / resident slots) rounds of (layers + 1) layer passes each --
-  // choose the layer count that minimises rounds x (layers + 1) with at least two rounds (a single round pays its ramp
-  // up and down in full).  The general variant is bound by bytes and does not follow this model (8 layers measured
-  // best there).
-  if (_compact && tz_free && nw == 4 && ty == 3)
-  {
-    static const int n_cus = [] {
-      int dev = 0, v = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        v = 256;
-      return v > 0 ? v : 256;
-    }();
-    const double slots = 0.98 * n_cus * 5.; // 5 workgroups of 4 wavefronts per CU
-    auto blocks = [&](MatrixFreeLaplaceDevice<T> const &op, int layers) {
-      const int64_t cols = op._tail ? op._ncols - 1 : op._ncols;
-      const int64_t t = cols * ((op._N[1] + nw * ty - 2) / (nw * ty - 1)) * ((op._N[2] + layers - 1) / layers);
-      return t >= 64 ? ((t + 7) / 8) * 8 : t;
-    };
-    double best = 0.;
-    int best_tz = 0;
-    for (int layers = 6; layers <= 16; ++layers)
-    {
-      const int64_t w = blocks(*this, layers) + (_tail ? blocks(*_tail, layers) : 0);
-      const double rounds = std::ceil((double)w / slots);
-      if (rounds < 2.)
-        continue;
-      const double cost = rounds * (layers + 1);
-      if (best_tz == 0 || cost < best)
-      {
-        best = cost;
-        best_tz = layers;
-      }
-    }
-    if (best_tz > 0)
-      tz = best_tz;
-  }
 }
 
 template <typename T>
@@ -1095,7 +1050,6 @@ bool MatrixFreeLaplaceDevice<T>::make_args(MfArgs<T> &a, unsigned int &n_blocks,
                                            int z_tile_begin, int z_tile_end) const
 {
   a.rec = _rec.data();
-  a.fb0 = _fb0.data();
   a.x = x;
   a.b = b;
   a.dinv = _dinv.data();
@@ -1110,6 +1064,16 @@ bool MatrixFreeLaplaceDevice<T>::make_args(MfArgs<T> &a, unsigned int &n_blocks,
   a.fx = T(vol / 8. / (_h[0] * _h[0]));
   a.fy = T(vol / 8. / (_h[1] * _h[1]));
   a.fz = T(vol / 8. / (_h[2] * _h[2]));
+  {
+    const double m00 = MFMG_GA * MFMG_GA + MFMG_GB * MFMG_GB, m01 = 2. * MFMG_GA * MFMG_GB;
+    const double f[3] = {vol / 8. / (_h[0] * _h[0]), vol / 8. / (_h[1] * _h[1]), vol / 8. / (_h[2] * _h[2])};
+    a.fax = T(2. * f[0] * m00);
+    a.fbx = T(2. * f[0] * m01);
+    a.fay = T(2. * f[1] * m00);
+    a.fby = T(2. * f[1] * m01);
+    a.faz = T(2. * f[2] * m00);
+    a.fbz = T(2. * f[2] * m01);
+  }
   a.alpha = alpha;
   a.beta = beta;
   a.mode = static_cast<int>(mode);
@@ -1146,42 +1110,53 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
   at = am;
   if (_tail) // the columns of the last chunk: same tile shape, same layers, first in the grid
     _tail->make_args(at, tail_blocks, mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, z_tile_begin, z_tile_end);
-  const size_t lds = ((size_t)nw * 2 * ty + (size_t)2 * nw * 2) * 64 * sizeof(T) + (size_t)nw * ty * 64 * sizeof(int2);
+  const size_t lds = ((size_t)nw * (2 * ty + 1) + (size_t)2 * nw * 2) * 64 * sizeof(T) + (size_t)nw * (ty + 1) * 64 * sizeof(int);
   ASSERT_THROW(lds <= 160 * 1024, "operator tile too large for the LDS");
-  static bool lds_attr_set = false; // (one flag per instantiation of this member)
-  auto set_lds = [](const void *f) {
-    MFMG_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  };
-  if (!lds_attr_set)
-  {
-    set_lds(reinterpret_cast<const void *>(mf_laplace_kernel<T, 0, false>));
-    set_lds(reinterpret_cast<const void *>(mf_laplace_kernel<T, 3, false>));
-    set_lds(reinterpret_cast<const void *>(mf_laplace_kernel<T, 4, false>));
-    set_lds(reinterpret_cast<const void *>(mf_laplace_kernel<T, 0, true>));
-    set_lds(reinterpret_cast<const void *>(mf_laplace_cc5_kernel<T, 3>));
-    set_lds(reinterpret_cast<const void *>(mf_laplace_kernel<T, 4, true>));
-    lds_attr_set = true;
-  }
   const dim3 grid(main_blocks + tail_blocks);
   const dim3 block(64 * nw);
   hipStream_t st = _handle.stream;
+  auto go = [&](auto kernel) {
+    // (the attribute is per kernel and device: set it whenever the device of the calling thread changes)
+    static int lds_attr_device = -1;
+    int dev = 0;
+    MFMG_HIP_CHECK(hipGetDevice(&dev));
+    if (lds_attr_device != dev)
+    {
+      MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024));
+      lds_attr_device = dev;
+    }
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, am, at, tail_blocks);
+  };
   if (_compact)
   {
-    if (ty == 3)
-      hipLaunchKernelGGL((mf_laplace_cc5_kernel<T, 3>), grid, block, lds, st, am, at, tail_blocks);
+    if (ty == 2)
+      go(mf_laplace_kernel<T, 2, true, 2>);
+    else if (ty == 3)
+      go(mf_laplace_kernel<T, 3, true, 3>);
     else if (ty == 4)
-      hipLaunchKernelGGL((mf_laplace_kernel<T, 4, true>), grid, block, lds, st, am, at, tail_blocks);
+      go(mf_laplace_kernel<T, 4, true, 4>);
     else
-      hipLaunchKernelGGL((mf_laplace_kernel<T, 0, true>), grid, block, lds, st, am, at, tail_blocks);
+      go(mf_laplace_kernel<T, 0, true, 1>);
   }
   else
   {
-    if (ty == 3)
-      hipLaunchKernelGGL((mf_laplace_kernel<T, 3, false>), grid, block, lds, st, am, at, tail_blocks);
+    // (experiments: MFMG_MF_BATCH=n asks for n rows per request batch where that instance exists)
+    static const int batch_env = std::getenv("MFMG_MF_BATCH") ? std::atoi(std::getenv("MFMG_MF_BATCH")) : 0;
+    if (ty == 2 && batch_env == 2)
+      go(mf_laplace_kernel<T, 2, false, 2>);
+    else if (ty == 3 && batch_env == 3)
+      go(mf_laplace_kernel<T, 3, false, 3>);
+    else if (ty == 4 && batch_env == 2)
+      go(mf_laplace_kernel<T, 4, false, 2>);
+    else if (ty == 2)
+      go(mf_laplace_kernel<T, 2, false, 1>);
+    else if (ty == 3)
+      go(mf_laplace_kernel<T, 3, false, 1>);
     else if (ty == 4)
-      hipLaunchKernelGGL((mf_laplace_kernel<T, 4, false>), grid, block, lds, st, am, at, tail_blocks);
+      go(mf_laplace_kernel<T, 4, false, 1>);
     else
-      hipLaunchKernelGGL((mf_laplace_kernel<T, 0, false>), grid, block, lds, st, am, at, tail_blocks);
+      go(mf_laplace_kernel<T, 0, false, 1>);
   }
   MFMG_HIP_CHECK(hipGetLastError());
 }
@@ -1227,7 +1202,7 @@ void MatrixFreeLaplaceDevice<T>::launch_z_range(MfMode mode, T const *x, T const
   const double extra = (mode == MfMode::apply) ? 0. : (mode == MfMode::residual) ? 1. : (mode == MfMode::first) ? 2. : 3.;
   const double share = double(z_tile_end - z_tile_begin) / double(all_z);
   hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel",
-                                           share * (algorithmic_bytes_apply() + extra * sizeof(T) * double(_n_dofs)),
+                                           share * (required_bytes_apply() + extra * sizeof(T) * double(_n_dofs)),
                                            _handle.stream);
   run(mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, z_tile_begin, z_tile_end);
   KernelProfiler::end(stop, _handle.stream);
@@ -1240,9 +1215,9 @@ void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T c
   check_vectors(mode, x, b, x_prev, out);
   int nw, ty, tz;
   choose_tile(nw, ty, tz);
-  // algorithmic bytes per launch: x + out + 8 idx + 8 coef, plus b / D^-1 / x_prev reads
+  // bytes the layout requires per launch (mf_laplace.hpp), plus the b / D^-1 / x_prev reads of the epilogue
   const double extra = (mode == MfMode::apply) ? 0. : (mode == MfMode::residual) ? 1. : (mode == MfMode::first) ? 2. : 3.;
-  hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel", algorithmic_bytes_apply() + extra * sizeof(T) * double(_n_dofs),
+  hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel", required_bytes_apply() + extra * sizeof(T) * double(_n_dofs),
                                            _handle.stream);
   run(mode, x, b, x_prev, alpha, beta, out, nw, ty, tz);
   KernelProfiler::end(stop, _handle.stream);

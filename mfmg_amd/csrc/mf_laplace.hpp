@@ -80,11 +80,19 @@ public:
   void get_tile(int &nw, int &ty, int &tz) const { choose_tile(nw, ty, tz); }
   HipHandle &handle() const { return _handle; }
 
-  // algorithmic bytes of one operator application (112 B/DoF in FP64: x, y, 8 ids, 8 coefficients;
-  // with one coefficient per cell the coefficient term is 8 B and the figure 56 B/DoF)
-  double algorithmic_bytes_apply() const
+  // Bytes of one operator application y = A x.
+  // survey: the indexed form of SURVEY.md 8(d) -- x, y, 8 index ints, 8 coefficients (112 B/DoF in FP64; one
+  //         coefficient per cell: 56);
+  // required: what the chunk-record layout makes the kernel move at least -- x, y, ONE id (each slot stores its own
+  //         DoF id, the other seven corners are neighbours' own ids) and the coefficients (84 / 28 B/DoF in FP64);
+  //         halo re-reads of the tiling are not in this figure.
+  double survey_bytes_apply() const
   {
     return double(_n_dofs) * (2.0 * sizeof(T) + 8 * 4 + (_compact ? 1 : 8) * sizeof(T));
+  }
+  double required_bytes_apply() const
+  {
+    return double(_n_dofs) * (2.0 * sizeof(T) + 4 + (_compact ? 1 : 8) * sizeof(T));
   }
 
 private:
@@ -101,13 +109,12 @@ private:
   int _n[3]; // cells
   double _h[3];
   int64_t _n_dofs;
-  // internal layout (mf_laplace.hip): rows cut into aligned chunks of 64 cell slots (63 owned DoFs + the low
+  // internal layout (mf_laplace.hip): rows cut into aligned chunks of 64 cell slots (62 owned DoFs + the
   // halo cell); one record per chunk with the b=1 face ids, the coefficients and D^-1, plus the b=0 face ids
   int _ncols = 0;
   size_t _n_slots = 0;
   // columns of a nearly empty last chunk, as a slab operator with x and y exchanged (mf_laplace.hip)
   std::unique_ptr<MatrixFreeLaplaceDevice<T>> _tail;
-  DeviceBuffer<int4> _fb0;
   DeviceBuffer<unsigned char> _rec;
   DeviceBuffer<T> _diag, _dinv;
   int _tile_y = 0, _tile_z = 0, _tile_waves = 0;

@@ -507,7 +507,8 @@ def test_full_size_hierarchy_properties(ctx, material):
     assert h.coarse_operator().get_kernel()[1] == 3          # block diagonals for A_c, upper half stored
     kernels = {(l, w): (rows, kind, classes, listed) for l, w, rows, kind, classes, listed in h.coarse_amg_kernels()}
     if constant:
-        assert h.operator_tile()[:2] == (4, 3) and h.operator_tile()[2] in (7, 11)   # two full rounds of workgroups
+        nw_, ty_, tz_ = h.operator_tile()                      # a compiled row count, at least two wavefronts
+        assert ty_ in (2, 3, 4) and nw_ * ty_ >= 2 and tz_ >= 1
         for l in (0, 1, 2):                                  # A_c and the two levels below: tables for >= 99.9 % of the rows
             rows, kind, classes, listed = kernels[(l, 0)]
             assert kind == 3 and classes >= 50 and listed <= 0.02 * rows, kernels[(l, 0)]

@@ -87,13 +87,20 @@ def test_mf_vmult_host_arrays_and_renumbered_dofs(ctx):
     assert relerr(host(y, ctx)[perm], ref.vmult(x_lex)) < TOL
 
 
-def test_mf_fused_epilogues(ctx):
-    n = (12, 10, 9)
+@pytest.mark.parametrize("n,material,tile", [((12, 10, 9), "discontinuous", None), ((12, 10, 9), "constant", None),
+                                             ((70, 30, 12), "constant", (3, 4, 4)), ((70, 30, 12), "linear", (3, 4, 4)),
+                                             ((20, 13, 9), "constant", (4, 2, 2)), ((20, 13, 9), "constant", (2, 3, 2)),
+                                             ((66, 67, 6), "constant", (3, 2, 4))])
+def test_mf_fused_epilogues(ctx, n, material, tile):
+    """Every epilogue of the operator kernel, for both coefficient layouts, with one and several wavefronts per
+    workgroup (the hand-over row between wavefronts has its own epilogue path) and with the tail slab."""
     mesh = O.StructuredMesh(n)
-    coef = O.coefficient_table(mesh, "discontinuous")
+    coef = O.coefficient_table(mesh, material)
     ref = O.MatrixFreeLaplace(mesh, coef)
     dinv = ref.diagonal_inverse()
-    op = M.MatrixFreeLaplace(ctx, M.LaplaceProblem(n, "discontinuous", device="cuda"))
+    op = M.MatrixFreeLaplace(ctx, M.LaplaceProblem(n, material, device="cuda"))
+    if tile:
+        op.set_tile(*tile)
     rng = np.random.default_rng(3)
     x, b, xp = rng.random(mesh.n_dofs), rng.random(mesh.n_dofs), rng.random(mesh.n_dofs)
     out = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
