@@ -1,10 +1,17 @@
 #!/usr/bin/env python3
 """bench.py -- V-cycle throughput of the MI355X-native mfmg hot path.
 
-One "step" = one `Hierarchy::apply` (V-cycle: Chebyshev(3) pre-smooth, residual, restriction,
-coarse Jacobi-PCG, prolongation, Chebyshev(3) post-smooth) on the matrix-free Q1 Laplace of a
-synthetic 3-D hyper-cube, FP64, inputs resident in HBM.  Metric (BASELINE.json): fine-DoFs/sec per
-V-cycle.  One process per GPU; rank 0 prints ONE JSON line.
+One "step" = one `Hierarchy::apply` (V-cycle: Chebyshev(3) pre-smooth, residual, restriction, coarse
+solve = one V-cycle of the smoothed-aggregation hierarchy below the first coarse level, prolongation,
+Chebyshev(3) post-smooth) on the matrix-free Q1 Laplace of a synthetic 3-D hyper-cube, FP64, inputs
+resident in HBM.  Metric (BASELINE.json): fine-DoFs/sec per V-cycle.  One process per GPU; rank 0
+prints ONE JSON line.
+
+Byte accounting of the roofline block: `achieved` = bytes the data layout REQUIRES per launch of the
+operator kernel (x, out, one id, the coefficients, the epilogue operands; halo re-reads excluded) / the
+average launch time from HIP events on the launch stream; `traffic` = HBM bytes per launch from the
+rocprofv3 PMC passes committed under profiles/ for exactly this workload and tile (null otherwise);
+the SURVEY.md 8(d) figure (8 index ints + 8 coefficients per DoF) is printed beside it, named as such.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -66,17 +73,18 @@ def smoother_coefficients(degree, lmin, lmax):
     return out
 
 
-def committed_traffic(args, compact):
+def committed_traffic(cells, degree, compact, tile):
     """HBM bytes per launch of the operator kernel from the PMC passes committed under profiles/ (2 x FETCH_SIZE
-    + WRITE_SIZE, MI355X_MICROARCH.md): counters need rocprofv3 around the process, so this is not a live
-    reading; it only applies to the workload it was collected on (256^3 cells per GPU, degree 3)."""
+    + WRITE_SIZE, MI355X_MICROARCH.md): counters need rocprofv3 around the process, so this is not a live reading.
+    The file is keyed on the workload AND the tile; anything else returns None."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "mf_kernel_traffic.json")
-    if args.cells != 256 or args.degree != 3 or not os.path.exists(path):
+    if not os.path.exists(path):
         return None
     with open(path) as f:
         d = json.load(f)
-    key = "cell_constant" if compact else "general"
-    return d.get(key, {}).get("traffic_bytes_per_launch")
+    key = f"cells{cells}_degree{degree}_{'cell_constant' if compact else 'general'}_tile{'x'.join(str(v) for v in tile)}"
+    e = d.get(key)
+    return e.get("traffic_bytes_per_launch") if e else None
 
 
 def operator_bytes_per_dof(word, compact, survey):
@@ -96,10 +104,14 @@ def smoother_bytes_per_dof(n_terms, word, compact, survey):
     return (b_op + 2 * word) + (n_terms - 1) * (b_op + 3 * word)
 
 
-def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, material="constant"):
+def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, material="constant",
+                         evaluator="HipMatrixFreeMeshEvaluator"):
     """BASELINE.json configs[1]: the same V-cycle on a `cells`^3 mesh, wall clock around `steps` cycles."""
     prob = M.LaplaceProblem((cells,) * 3, material, device="cuda")
-    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    t_setup = time.perf_counter()
+    h = M.Hierarchy(ctx, evaluator, prob, params)
+    ctx.synchronize()
+    t_setup = time.perf_counter() - t_setup
     n = h.level_size(0)
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
@@ -113,9 +125,10 @@ def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, mater
         h.apply(b, x)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"workload": f"{cells}^3 cells = {cells + 1}^3 DoFs, matrix-free, material {material}, Chebyshev(3), same "
+    kind = "matrix-free" if evaluator == "HipMatrixFreeMeshEvaluator" else "assembled CSR fine operator"
+    return {"workload": f"{cells}^3 cells = {cells + 1}^3 DoFs, {kind}, material {material}, Chebyshev(3), same "
                         f"hierarchy parameters",
-            "n_dofs": n, "ms_per_step": dt * 1e3, "value": n / dt, "unit": "DoF/s"}
+            "n_dofs": n, "ms_per_step": dt * 1e3, "value": n / dt, "unit": "DoF/s", "setup_seconds": t_setup}
 
 
 def measure_vcycle_f32(ctx, torch, M, h, prob, op_monitor_factory, steps=10, warmup=3):
@@ -185,13 +198,12 @@ def measure_smoother_f32(ctx, torch, M, cells, degree, reps=5, material="linear"
     ev1.record()
     ev1.synchronize()
     ms = ev0.elapsed_time(ev1) / reps
-    # FP32: x 4 + out 4 + 8 idx 32 + 8 coef 32 = 72, + b + D^-1 (+ x_prev from the second term on)
-    b_op = 44 if compact else 72
-    per_dof = sum(b_op + 8 + (4 if k > 0 else 0) for k in range(len(coefs)))
+    # bytes the layout requires in FP32: x 4 + out 4 + one id 4 + 8 (or 1) coefficients, + b + D^-1 (+ x_prev)
+    per_dof = smoother_bytes_per_dof(len(coefs), 4, compact, survey=False)
     return {"n_dofs": N, "degree": degree, "dtype": "f32", "material": material,
             "coefficient_layout": "one value per cell" if compact else "eight values per cell",
-            "ms_per_apply": ms, "algorithmic_bytes_per_dof": per_dof,
-            "achieved_GBs": N * per_dof / (ms * 1e-3) / 1e9, "frac_of_8TBs": N * per_dof / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            "ms_per_apply": ms, "required_bytes_per_dof": per_dof,
+            "required_GBs": N * per_dof / (ms * 1e-3) / 1e9, "frac_of_8TBs": N * per_dof / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
 def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=20, warmup=3, tile=None, material="constant"):
@@ -435,7 +447,9 @@ def main():
     coarse_desc = (f"{args.coarse_iters} Jacobi-PCG steps" if args.coarse == "pcg" else
                    "one V-cycle of a smoothed-aggregation hierarchy (Chebyshev(1) = damped-Jacobi smoothers, dense LU at the bottom)")
     if rank == 0:
+        # bytes the layout requires per launch (library accounting: x, out, one id, coefficients + epilogue operands)
         achieved = (k_bytes / launches) / (k_ms / launches * 1e-3) / 1e9 if launches else 0.0
+        word = 8
         out = {
             "metric": "fine-DoFs/sec per V-cycle (3D Laplace)",
             "value": value,
@@ -463,9 +477,8 @@ def main():
                 "coarse_amg_levels_rows_nnzA_nnzP": (h.coarse_amg_shapes() if args.coarse == "amg" else None),
                 "smoother": {"type": "Chebyshev", "degree": degree, "lambda_min": lmin, "lambda_max": lmax},
                 "parallelism": "1 GPU" if world == 1 else
-                               f"{world} GPUs, z-slab domain decomposition of a {gx}x{gy}x{gz}-cell box, one-plane halo "
-                               f"exchange per operator application (RCCL send/recv), levels below the first coarse "
-                               f"level rank-local",
+                               f"{world} GPUs, z-slab domain decomposition of a {gx}x{gy}x{gz}-cell box, halo "
+                               f"exchange per operator application on every level of the cycle",
                 "global_dofs": n_global,
                 "setup_seconds": t_setup,
                 "mean_residual_contraction_per_cycle": contraction,
@@ -477,16 +490,23 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": committed_traffic(args, compact),
-                "algorithmic_bytes_per_dof_operator": (None if assembled else (56 if compact else 112)),
+                "traffic": (None if assembled else committed_traffic(args.cells, args.degree, compact, mf_tile)),
+                "priced_on": "bytes the data layout requires per launch (x, out, one id, coefficients, b, D^-1, x_prev); "
+                             "halo re-reads of the tiling are waste and not counted",
+                "required_bytes_per_dof_operator": (None if assembled else operator_bytes_per_dof(word, compact, False)),
+                "survey_8d_bytes_per_dof_operator": (None if assembled else operator_bytes_per_dof(word, compact, True)),
+                "survey_8d_GBs": (None if assembled or not launches else      # + the 7 index ints the layout does not read
+                                  (k_bytes / launches + 28.0 * n_local) / (k_ms / launches * 1e-3) / 1e9),
                 "launches_in_timed_region": launches, "tile_waves_ty_tz": list(mf_tile),
                 "avg_launch_ms": k_ms / launches if launches else None,
-                "algorithmic_bytes_per_launch": k_bytes / launches if launches else None,
+                "required_bytes_per_launch": k_bytes / launches if launches else None,
                 "share_of_step_time": k_ms / (ms_per_step * args.steps) if launches else None,
             },
             "other_kernels": {
-                "csr_spmv_kernel": {"launches": c_launches, "total_ms": c_ms,
-                                    "GBs_priced_as_csr": (c_bytes / (c_ms * 1e-3) / 1e9) if c_ms else None,
+                "csr_spmv_kernel": {"what": "coarse-level family: A_c and the levels below, R, R^T, prolongators (table-driven "
+                                            "layouts read no matrix values, so no byte rate is quoted; HBM bytes per launch "
+                                            "from the PMC passes: profiles/r01_k_cycle_hbm_bytes_per_launch.txt)",
+                                    "launches": c_launches, "total_ms": c_ms,
                                     "share_of_step_time": (c_ms / (ms_per_step * (other_cycles or args.steps))) if c_ms else None,
                                     "timed_in": (f"{other_cycles} extra cycles after the timed region" if other_cycles
                                                  else "the timed region")},
@@ -494,19 +514,30 @@ def main():
         }
         tile = tuple(int(v) for v in args.tile.split(",")) if args.tile else None
         if assembled:
-            # the dominant kernel of the assembled path is the SpMV family
+            # the dominant kernel of the assembled path is the SpMV family, priced at SURVEY.md 8(d)'s CSR figure
             rf = out["roofline"]
             ach = (c_bytes / (c_ms * 1e-3) / 1e9) if c_ms else 0.0
             rf.update({"kernel": "csr_spmv_kernel family (fine operator with fused smoother epilogues, R, R^T, coarse levels)",
-                       "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches_in_timed_region": c_launches,
+                       "launches_in_timed_region": c_launches,
                        "avg_launch_ms": c_ms / c_launches if c_launches else None,
-                       "algorithmic_bytes_per_launch": c_bytes / c_launches if c_launches else None,
-                       "share_of_step_time": c_ms / (ms_per_step * args.steps) if c_ms else None})
+                       "share_of_step_time": c_ms / (ms_per_step * args.steps) if c_ms else None,
+                       "priced_on": "SURVEY.md 8(d) CSR figure: 12 B per entry + 4 B per row + vectors"})
             if ach > HBM_PEAK_GBS:
-                rf["note"] = ("priced at the CSR figure of SURVEY.md 8(d) (12 B per entry + vectors); with a constant coefficient "
-                              "the rows of the fine matrix and of the coarse operators repeat a few stencils and are evaluated "
-                              "from tables (no matrix values or column indices are read), so this rate is not a fraction of "
-                              "the HBM peak -- see --material linear for stored values")
+                rf.update({"achieved": None, "frac": None,
+                           "note": "with a constant coefficient the rows of the fine matrix and of the coarse operators "
+                                   "repeat a few stencils and are evaluated from tables (no matrix values or column "
+                                   "indices are read): the CSR-priced rate would exceed the HBM peak and is not a "
+                                   "fraction of it -- see --material linear for stored values"})
+            else:
+                rf.update({"achieved": ach, "frac": ach / HBM_PEAK_GBS})
+        # ---- north_star target legs first (GPU warm, allocator state of the headline run): fine-level smoother
+        #      apply at 512^3 DoFs, both coefficient layouts
+        if world == 1 and not args.no_smoother_512:
+            for mat, key in (("constant", "smoother_apply_512cubed"), ("linear", "smoother_apply_512cubed_general_coefficient")):
+                try:
+                    out[key] = measure_smoother(ctx, torch, M, 512, args.degree, tile=tile, material=mat)
+                except Exception as e:  # noqa: BLE001 - report, do not hide the main result
+                    out[key] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline and not assembled:
             out["cpu_baseline"] = cpu_baseline(args, M, h, prob, lmin, lmax, torch)
         if world == 1 and not args.no_extras:
@@ -514,23 +545,20 @@ def main():
                 if with_f32:
                     out["vcycle_fp32_fine_level_config5"] = measure_vcycle_f32(ctx, torch, M, h, prob,
                                                                               lambda: M.MatrixFreeLaplace(ctx, prob))
+                del h, x, b
+                torch.cuda.empty_cache()
+                # the same cycle and smoother without the redundancies of the constant material (eight coefficients per
+                # cell, every coarse-operator row and restrictor block stored): what a variable coefficient gets
+                gen = measure_vcycle_small(ctx, torch, M, args.cells, params, material="linear")
+                gen["smoother_apply"] = measure_smoother(ctx, torch, M, args.cells + 1, args.degree, material="linear")
+                out["general_coefficient"] = gen
                 out["vcycle_128cubed_config1"] = measure_vcycle_small(ctx, torch, M, 128, params)
                 out["smoother_apply_256cubed_f32_config5"] = measure_smoother_f32(ctx, torch, M, 256, args.degree)
-                out["smoother_apply_257cubed_general_coefficient"] = measure_smoother(ctx, torch, M, 257, args.degree,
-                                                                                        material="linear")
-                # the whole cycle without the redundancies of the constant material (eight coefficients per cell,
-                # every coarse-operator row and restrictor block stored)
-                out["vcycle_256cubed_general_coefficient"] = measure_vcycle_small(ctx, torch, M, args.cells, params,
-                                                                                material="linear")
+                if not assembled:
+                    out["vcycle_256cubed_assembled_config2"] = measure_vcycle_small(
+                        ctx, torch, M, args.cells, params, evaluator="HipMeshEvaluator")
             except Exception as e:  # noqa: BLE001 - report, do not hide the main result
                 out["extras_error"] = str(e)
-        if world == 1 and not args.no_smoother_512:
-            del h, x, b
-            torch.cuda.empty_cache()
-            try:
-                out["smoother_apply_512cubed"] = measure_smoother(ctx, torch, M, 512, args.degree, tile=tile)
-            except Exception as e:  # noqa: BLE001 - report, do not hide the main result
-                out["smoother_apply_512cubed"] = {"error": str(e)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -1028,7 +1028,8 @@ void MatrixFreeLaplaceDevice<T>::choose_tile(int &nw, int &ty, int &tz) const
   {
     const int64_t wgs = (int64_t)_ncols * ((_N[1] + pref[c][0] * pref[c][1] - 2) / (pref[c][0] * pref[c][1] - 1)) *
                         ((_N[2] + pref[c][2] - 1) / pref[c][2]);
-    if (wgs * pref[c][0] >= waves_wanted)
+    // (the eight-wavefront tiles need four rounds: below that the shorter workgroups fill the chip better)
+    if (wgs * pref[c][0] >= (pref[c][0] >= 8 ? 2 : 1) * waves_wanted)
     {
       pick = c;
       break;
