@@ -66,18 +66,39 @@ void *mfmg_hip_context_stream(mfmg_hip_context_t ctx);
  * include/mfmg/cuda/sparse_matrix_device.templates.cuh:104-138).  The local mesh of a rank is its owned
  * cell slab plus `ghost_cells_low/high` (0 or 2 = one agglomerate) cell layers of its neighbours; local DoF
  * numbering must be lexicographic; ghost (not owned) DoFs carry the value 2 in mfmg_hip_mesh_desc.constrained.
- * Before every operator application the library copies the boundary layers of the input vector into the
- * registered device staging buffers, calls `exchange(user, space, hip_stream)` -- which must enqueue, on that
- * stream, send_low -> rank-1, send_high -> rank+1 and the matching receives into recv_low / recv_high -- and
- * copies the received layers into the ghost layers.  space 1 = fine DoFs (one plane), 2 = first coarse level
- * (one layer of agglomerates).  `allreduce` sums `n` doubles over all ranks in place (setup and norms only). */
-typedef int (*mfmg_hip_exchange_fn)(void *user, int space, void *hip_stream);
-typedef int (*mfmg_hip_allreduce_fn)(void *user, double *values, int n);
+ * Every level of the V-cycle is coupled across the ranks: before an operator application the library refreshes
+ * the ghost layers of its input (owner -> ghost), after a transposed prolongator it returns the partial sums in
+ * the ghost layers to their owners (ghost -> owner, added); the levels of the aggregation hierarchy whose global
+ * size is small are gathered and solved redundantly on every rank.  The distributed cycle is the same
+ * preconditioner as the single-process one (same matrices to rounding).
+ * Transport, one of:
+ *   mfmg_hip_context_use_rccl            ncclSend / ncclRecv between slab neighbours on the library's HIP stream
+ *                                        (RCCL over xGMI); the 128-byte id comes from mfmg_hip_rccl_unique_id on
+ *                                        rank 0 and must reach every rank through the caller's own channel;
+ *   mfmg_hip_context_use_host_transport  the library stages the layers through pinned host memory and calls the
+ *                                        callbacks with HOST pointers (tests: gloo, several ranks on one card).
+ * `sendrecv` exchanges n_low doubles with rank - 1 and n_high with rank + 1 (a count of 0: no such neighbour);
+ * `allreduce` combines `n` doubles over all ranks in place (op 0: sum, 1: max); `allgather` collects `n` doubles of
+ * every rank into `out` (n * n_ranks, rank order). */
+typedef int (*mfmg_hip_host_sendrecv_fn)(void *user, const double *send_low, double *recv_low, int64_t n_low,
+                                         const double *send_high, double *recv_high, int64_t n_high);
+typedef int (*mfmg_hip_host_allreduce_fn)(void *user, double *values, int n, int op);
+typedef int (*mfmg_hip_host_allgather_fn)(void *user, const double *in, int64_t n, double *out);
 int mfmg_hip_context_set_communicator(mfmg_hip_context_t ctx, int32_t rank, int32_t n_ranks, int32_t ghost_cells_low,
-                                      int32_t ghost_cells_high, mfmg_hip_exchange_fn exchange,
-                                      mfmg_hip_allreduce_fn allreduce, void *user);
-int mfmg_hip_context_set_halo_buffers(mfmg_hip_context_t ctx, int32_t space, int64_t n_elems, double *send_low,
-                                      double *send_high, double *recv_low, double *recv_high);
+                                      int32_t ghost_cells_high);
+int mfmg_hip_rccl_unique_id(unsigned char out[128]);
+int mfmg_hip_context_use_rccl(mfmg_hip_context_t ctx, const unsigned char unique_id[128]);
+int mfmg_hip_context_use_host_transport(mfmg_hip_context_t ctx, mfmg_hip_host_sendrecv_fn sendrecv,
+                                        mfmg_hip_host_allreduce_fn allreduce, mfmg_hip_host_allgather_fn allgather, void *user);
+/* "rccl", "host" or "" (none) */
+int mfmg_hip_context_transport_name(mfmg_hip_context_t ctx, char *buffer, size_t buffer_size);
+/* point-to-point exchanges issued through the context so far (diagnostics) */
+int mfmg_hip_context_exchange_count(mfmg_hip_context_t ctx, int64_t *n_exchanges);
+/* one halo exchange of a device vector of `space` (1 fine DoFs, 2 first coarse level, 3.. aggregation levels):
+ * reverse = 0 owner -> ghost, 1 ghost -> owner (added).  The cycle does this by itself; exposed for tests. */
+int mfmg_hip_context_exchange(mfmg_hip_context_t ctx, int32_t space, double *vector, int reverse);
+/* sum over the ranks of the dot product over the owned entries of two vectors of `space` */
+int mfmg_hip_context_owned_dot(mfmg_hip_context_t ctx, int32_t space, const double *x, const double *y, double *result);
 /* Distributed runs: overlap the exchange of the fine-level ghost planes with the operator tiles that do not read
  * them (second HIP stream; default on).  Off: exchange first, then one launch over all tiles.  Same results. */
 int mfmg_hip_context_set_overlap_exchange(mfmg_hip_context_t ctx, int enable);
@@ -90,9 +111,11 @@ int mfmg_hip_context_set_cell_constant_layout(mfmg_hip_context_t ctx, int enable
  * source/dealii/dealii_matrix_free_hierarchy_helpers.cc:77-288) -- the default where the restrictor has the block
  * structure and the run is not distributed; 0: the host triple product.  Same matrix to rounding. */
 int mfmg_hip_context_set_galerkin_on_device(mfmg_hip_context_t ctx, int enable);
-/* layout of a distributed space after the hierarchy was built: entries per layer, local layers, owned range */
+/* layout of a distributed space after the hierarchy was built: entries per layer, local layers, owned range;
+ * mfmg_hip_context_halo_space adds {global index of local layer 0, global layers, exchange width, number of spaces} */
 int mfmg_hip_context_halo_layout(mfmg_hip_context_t ctx, int32_t space, int64_t *layer_elems, int64_t *n_layers,
                                  int64_t *owned_begin, int64_t *owned_count);
+int mfmg_hip_context_halo_space(mfmg_hip_context_t ctx, int32_t space, int64_t out[8]);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (the reference only has the
  * wall-clock dealii::TimerOutput sections, include/mfmg/common/hierarchy.hpp:36-47).  Kernel names:

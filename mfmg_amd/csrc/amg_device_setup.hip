@@ -1,0 +1,518 @@
+// Setup of the smoothed-aggregation hierarchy below the first coarse level ON THE DEVICE, by probing, for runs
+// where the levels are coupled across the ranks of a slab decomposition (and, on request, for one rank).
+//
+// The reference delegates the coarse problem to ML / AMGx (source/dealii/dealii_solver.cc:48-66,
+// source/cuda/cuda_solver.cu:204-445) and forms its Galerkin products with host / cuSPARSE SpGEMM
+// (source/cuda/cuda_matrix_operator.cu:132-225, include/mfmg/cuda/sparse_matrix_device.templates.cuh:373-434).  Here the
+// aggregates are 2x2x2 blocks of nodes of a structured grid, so the sparsity of every matrix of the hierarchy is a
+// box stencil of known reach, and a matrix can be read off from a few applications of operators that already exist
+// on the device:
+//   P_l     = (I - omega/rho D^-1 A_l) P_tent     columns of aggregates (1 + r_l) apart never overlap:
+//                                                  (1 + r_l)^3 n_comp applications of A_l;
+//   A_{l+1} = P_l^T A_l P_l                        columns 2 r_{l+1} + 1 apart never meet in a row:
+//                                                  (2 r_{l+1} + 1)^3 n_comp applications of P_l, A_l, P_l^T
+// with r_l the reach of A_l in nodes (r_0 = 1 for the AMGe coarse operator, r_{l+1} = floor((1 + 3 r_l) / 2)).
+// Nothing but vectors crosses between ranks: the probing vectors are defined on global coordinates, A_l reads its
+// ghost layers after a forward halo exchange and P_l^T returns the partial sums of ghost aggregates to their owners
+// by a reverse (adding) exchange -- exactly the exchanges of the cycle itself.  No sparse rows are communicated.
+// Below `solver.amg.replicate_rows` global rows (or where a slab can no longer be halved) the level is gathered and
+// the rest of the hierarchy is built and applied redundantly on every rank by the host code path of one rank.
+#include "mfmg/hip_hierarchy_helpers.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+
+namespace mfmg
+{
+namespace
+{
+double wall_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct LevelGeom
+{
+  int dims[3] = {0, 0, 0}; // local nodes (x, y, z incl. ghost layers)
+  int n_comp = 1;
+  int space = 0;             // halo space of the level's vectors (0: one rank)
+  int64_t owned_begin = 0, owned_count = 0; // owned z layers of the local box
+  int64_t global_begin = 0, global_layers = 0;
+  int reach = 1;             // stencil reach of the level's operator in nodes
+  int64_t layer_elems() const { return (int64_t)dims[0] * dims[1] * n_comp; }
+  int64_t n_rows() const { return layer_elems() * dims[2]; }
+  int64_t owned_row_begin() const { return owned_begin * layer_elems(); }
+  int64_t owned_rows() const { return owned_count * layer_elems(); }
+};
+
+std::vector<double> download_range(HipHandle &h, double const *dev, int64_t begin, int64_t n)
+{
+  std::vector<double> out((size_t)n);
+  if (n > 0)
+  {
+    MFMG_HIP_CHECK(hipMemcpyAsync(out.data(), dev + begin, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h.stream));
+    MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
+  }
+  return out;
+}
+
+std::shared_ptr<SparseMatrixDevice<double>> upload_csr(HipHandle &handle, HostCsr &&m, bool keep_host = true)
+{
+  return std::make_shared<SparseMatrixDevice<double>>(handle, m.n_rows, m.n_cols, std::move(m.row_ptr), std::move(m.col),
+                                                      std::move(m.val), keep_host);
+}
+} // namespace
+
+// Builds `_amg` for an operator whose rows live on a structured node grid (node-major, component-minor).
+void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> matrix, std::vector<double> const &near_null,
+                                    AmgGridHint const &grid, AmgOptions const &opts, std::shared_ptr<ptree> smoother_params)
+{
+  HipHandle &h = _handle;
+  HaloCommunicator &comm = h.comm;
+  const int op_space = _matrix_operator->domain_space();
+  const bool distributed = comm.enabled() && op_space > 0;
+  const bool verbose = std::getenv("MFMG_HIP_VERBOSE") != nullptr;
+  const int64_t replicate_rows = this->_params->get("solver.amg.replicate_rows", 200000);
+  const int C = std::max(grid.n_components, 1);
+
+  LevelGeom g;
+  for (int d = 0; d < 3; ++d)
+    g.dims[d] = std::max(grid.dims[d], 1);
+  g.n_comp = C;
+  g.reach = 1;
+  if (distributed)
+  {
+    HaloSpace const &s = comm.spaces[op_space];
+    ASSERT_THROW(s.layer_elems == g.layer_elems() && s.n_layers == g.dims[2], "internal: coarse space does not match the agglomerate grid");
+    g.space = op_space;
+    g.owned_begin = s.owned_begin;
+    g.owned_count = s.owned_count;
+    g.global_begin = s.global_begin;
+    g.global_layers = s.global_layers;
+  }
+  else
+  {
+    g.owned_begin = 0;
+    g.owned_count = g.dims[2];
+    g.global_begin = 0;
+    g.global_layers = g.dims[2];
+  }
+  ASSERT_THROW(matrix->m() == g.n_rows(), "internal: operator rows do not match the agglomerate grid");
+  for (int64_t r = 0; r < (int64_t)grid.node_of_row.size(); r += std::max<int64_t>(1, (int64_t)grid.node_of_row.size() / 8191))
+    ASSERT_THROW(grid.node_of_row[r] == r / C && (grid.component_of_row.empty() ? 0 : grid.component_of_row[r]) == r % C,
+                 "the device setup of the aggregation hierarchy needs node-major rows with a fixed number of components");
+
+  // host copy of the current level: owned rows of A (local column ids), near-null vector (local, owned part valid)
+  HostCsr A;
+  A.n_rows = A.n_cols = g.n_rows();
+  matrix->download(A.row_ptr, A.col, A.val);
+  std::vector<double> B = near_null;
+  ASSERT_THROW((int64_t)B.size() == g.n_rows(), "near-null-space vector has the wrong size");
+  std::shared_ptr<HipMatrixOperator> a_op = std::const_pointer_cast<HipMatrixOperator>(_matrix_operator);
+
+  _amg.clear();
+  _amg_gather_level = -1;
+  for (;;)
+  {
+    const int level = (int)_amg.size();
+    const int64_t global_rows = g.layer_elems() * g.global_layers;
+    // ---- can the next level be built distributed?
+    LevelGeom c;
+    for (int d = 0; d < 2; ++d)
+      c.dims[d] = (g.dims[d] + 1) / 2;
+    c.n_comp = C;
+    c.reach = (1 + 3 * g.reach) / 2;
+    bool coarsen_here = global_rows > std::max<int64_t>(replicate_rows, opts.coarsest_size) && level + 1 < opts.max_levels;
+    if (coarsen_here)
+    {
+      if (distributed)
+      {
+        HaloSpace const &s = comm.spaces[g.space];
+        // whole aggregates per rank, aligned globally; the ghost layers of the coarse level must come from the
+        // immediate neighbour
+        double ok = (g.owned_count % 2 == 0 && (g.global_begin + g.owned_begin) % 2 == 0 && g.owned_count / 2 >= c.reach) ? 1. : 0.;
+        ok = -h.allreduce_max(-ok); // min over the ranks
+        coarsen_here = ok > 0.5;
+        c.owned_count = g.owned_count / 2;
+        c.owned_begin = s.has_low ? c.reach : 0;
+        c.dims[2] = (int)(c.owned_begin + c.owned_count + (s.has_high ? c.reach : 0));
+        c.global_begin = (g.global_begin + g.owned_begin) / 2 - c.owned_begin;
+        c.global_layers = g.global_layers / 2;
+        ASSERT_THROW(!coarsen_here || g.global_layers % 2 == 0, "internal: odd number of layers on a distributed level");
+      }
+      else
+      {
+        c.dims[2] = (g.dims[2] + 1) / 2;
+        c.owned_begin = 0;
+        c.owned_count = c.dims[2];
+        c.global_begin = 0;
+        c.global_layers = c.dims[2];
+      }
+    }
+    if (!coarsen_here)
+    {
+      // ---- gather this level; the rest of the hierarchy is replicated (host setup of one rank)
+      finish_amg_replicated(a_op, std::move(A), std::move(B), g.space, g.owned_begin, g.owned_count, g.global_begin, g.global_layers,
+                            g.dims, C, opts, smoother_params);
+      break;
+    }
+    const double t0 = wall_now();
+    if (distributed)
+    {
+      HaloSpace s;
+      s.layer_elems = c.layer_elems();
+      s.n_layers = c.dims[2];
+      s.owned_begin = c.owned_begin;
+      s.owned_count = c.owned_count;
+      s.global_begin = c.global_begin;
+      s.global_layers = c.global_layers;
+      s.width = c.reach;
+      s.has_low = comm.spaces[g.space].has_low;
+      s.has_high = comm.spaces[g.space].has_high;
+      c.space = comm.add_space(s);
+      // the fine level of this pair exchanges as many layers as its operator reaches
+      comm.spaces[g.space].width = std::max(comm.spaces[g.space].width, g.reach);
+      ASSERT_THROW(comm.spaces[g.space].width <= std::min<int64_t>(s.has_low ? comm.spaces[g.space].ghost_low() : 1 << 30,
+                                                                    s.has_high ? comm.spaces[g.space].ghost_high() : 1 << 30),
+                   "internal: not enough ghost layers for the stencil of this level");
+    }
+    const int64_t n_f = g.n_rows(), n_c = c.n_rows();
+    const int64_t row0 = g.owned_row_begin(), n_own = g.owned_rows();
+
+    // ---- diagonal, rho = max_i sum_j |a_ij| / |a_ii| over the owned rows of all ranks
+    std::vector<double> dinv((size_t)n_f, 0.);
+    double rho = 0.;
+    for (int64_t i = row0; i < row0 + n_own; ++i)
+    {
+      double d = 0., sum = 0.;
+      for (int p = A.row_ptr[i]; p < A.row_ptr[i + 1]; ++p)
+      {
+        sum += std::abs(A.val[p]);
+        if (A.col[p] == i)
+          d = A.val[p];
+      }
+      ASSERT_THROW(d != 0., "zero diagonal in the multilevel coarse solver setup");
+      dinv[i] = 1. / d;
+      rho = std::max(rho, sum / std::abs(d));
+    }
+    rho = h.allreduce_max(rho);
+    const double w = opts.omega / rho;
+
+    // ---- tentative prolongator: t = B / |B|_aggregate on the owned nodes, exchanged to the ghosts; B_c = |B|_aggregate
+    auto agg_of_row = [&](int64_t row, int &I, int &J, int &K, int &comp) {
+      comp = (int)(row % C);
+      const int64_t nd = row / C;
+      const int i = (int)(nd % g.dims[0]), j = (int)((nd / g.dims[0]) % g.dims[1]), k = (int)(nd / ((int64_t)g.dims[0] * g.dims[1]));
+      I = i / 2;
+      J = j / 2;
+      K = (int)((k + g.global_begin) / 2 - c.global_begin); // local coarse layer
+    };
+    std::vector<double> norm2((size_t)n_c, 0.), t((size_t)n_f, 0.), Bc((size_t)n_c, 0.);
+    for (int64_t i = row0; i < row0 + n_own; ++i)
+    {
+      int I, J, K, comp;
+      agg_of_row(i, I, J, K, comp);
+      norm2[(((int64_t)K * c.dims[1] + J) * c.dims[0] + I) * C + comp] += B[i] * B[i];
+    }
+    for (int64_t i = row0; i < row0 + n_own; ++i)
+    {
+      int I, J, K, comp;
+      agg_of_row(i, I, J, K, comp);
+      const double nn = norm2[(((int64_t)K * c.dims[1] + J) * c.dims[0] + I) * C + comp];
+      ASSERT_THROW(nn > 0., "the device setup of the aggregation hierarchy needs a near-null-space vector without zero aggregates");
+      t[i] = B[i] / std::sqrt(nn);
+    }
+    for (int64_t r = c.owned_row_begin(); r < c.owned_row_begin() + c.owned_rows(); ++r)
+      Bc[r] = std::sqrt(norm2[r]);
+    DVector t_dev(h, n_f), y_f(h, n_f), z_f(h, n_f), u_c(h, n_c), y_c(h, n_c);
+    MFMG_HIP_CHECK(hipMemcpyAsync(t_dev.get_values(), t.data(), (size_t)n_f * sizeof(double), hipMemcpyHostToDevice, h.stream));
+    h.exchange(g.space, t_dev.get_values());
+    t = download_range(h, t_dev.get_values(), 0, n_f);
+
+    // ---- P = (I - w D^-1 A) P_tent by probing: aggregates (1 + reach) apart have disjoint columns
+    const int gdims_c[3] = {c.dims[0], c.dims[1], (int)c.global_layers};
+    int period_p[3];
+    for (int d = 0; d < 3; ++d)
+      period_p[d] = std::max(1, std::min(1 + g.reach, gdims_c[d]));
+    const int n_col_p = period_p[0] * period_p[1] * period_p[2] * C;
+    std::vector<std::vector<double>> Z((size_t)n_col_p);
+    for (int col = 0; col < n_col_p; ++col)
+    {
+      const int comp = col % C, oc = col / C;
+      const int phase[3] = {oc % period_p[0], (oc / period_p[0]) % period_p[1], oc / (period_p[0] * period_p[1])};
+      vec::select_rows(h, g.dims, C, 2, (int)g.global_begin, period_p, phase, comp, t_dev.get_values(), y_f.get_values());
+      a_op->get_matrix()->vmult(z_f.get_values(), y_f.get_values()); // ghosts of y are set locally: no exchange
+      Z[col] = download_range(h, z_f.get_values(), row0, n_own);
+    }
+    HostCsr P;
+    P.n_rows = n_f;
+    P.n_cols = n_c;
+    P.row_ptr.assign(n_f + 1, 0);
+    {
+      // two passes: count, fill.  Candidates of owned row i: aggregates whose nodes lie within `reach` of its node
+      auto visit = [&](int64_t i, auto &&emit) {
+        const int64_t nd = i / C;
+        const int x = (int)(nd % g.dims[0]), y = (int)((nd / g.dims[0]) % g.dims[1]), zl = (int)(nd / ((int64_t)g.dims[0] * g.dims[1]));
+        const int64_t zg = zl + g.global_begin;
+        const int lo[3] = {std::max(0, (x - g.reach) >> 1), std::max(0, (y - g.reach) >> 1),
+                           (int)std::max<int64_t>(0, (zg - g.reach) >> 1)};
+        const int hi[3] = {std::min(gdims_c[0] - 1, (x + g.reach) >> 1), std::min(gdims_c[1] - 1, (y + g.reach) >> 1),
+                           (int)std::min<int64_t>(gdims_c[2] - 1, (zg + g.reach) >> 1)};
+        for (int K = lo[2]; K <= hi[2]; ++K)
+          for (int J = lo[1]; J <= hi[1]; ++J)
+            for (int I = lo[0]; I <= hi[0]; ++I)
+            {
+              const int oc = (I % period_p[0]) + period_p[0] * ((J % period_p[1]) + period_p[1] * (K % period_p[2]));
+              const int64_t Kl = K - c.global_begin;
+              ASSERT_THROW(Kl >= 0 && Kl < c.dims[2], "internal: prolongator column outside the local coarse box");
+              // own aggregate of the node, for the identity part of S
+              const bool own_agg = (I == (x >> 1)) && (J == (y >> 1)) && (K == (int)(zg >> 1));
+              for (int comp = 0; comp < C; ++comp)
+              {
+                const double ay = Z[(size_t)(oc * C + comp)][(size_t)(i - row0)];
+                const double yi = (own_agg && comp == (int)(i % C)) ? t[i] : 0.;
+                const double v = yi - w * dinv[i] * ay;
+                if (v != 0.)
+                  emit((((int64_t)Kl * c.dims[1] + J) * c.dims[0] + I) * C + comp, v);
+              }
+            }
+      };
+#pragma omp parallel for schedule(static)
+      for (int64_t i = row0; i < row0 + n_own; ++i)
+      {
+        int cnt = 0;
+        visit(i, [&](int64_t, double) { ++cnt; });
+        P.row_ptr[i + 1] = cnt;
+      }
+      for (int64_t i = 0; i < n_f; ++i)
+      {
+        ASSERT_THROW((int64_t)P.row_ptr[i] + P.row_ptr[i + 1] < (int64_t(1) << 31), "prolongator exceeds int32 entries");
+        P.row_ptr[i + 1] += P.row_ptr[i];
+      }
+      P.col.resize(P.row_ptr[n_f]);
+      P.val.resize(P.row_ptr[n_f]);
+#pragma omp parallel for schedule(static)
+      for (int64_t i = row0; i < row0 + n_own; ++i)
+      {
+        int p = P.row_ptr[i];
+        visit(i, [&](int64_t col, double v) {
+          P.col[p] = (int32_t)col;
+          P.val[p] = v;
+          ++p;
+        });
+      }
+    }
+    Z.clear();
+    Z.shrink_to_fit();
+    auto p_mat = upload_csr(h, std::move(P));
+    auto pt_mat = p_mat->transpose();
+    const double t1 = wall_now();
+
+    // ---- A_c = P^T A P by probing: coarse nodes (2 reach_c + 1) apart never meet in a row
+    int period_a[3];
+    for (int d = 0; d < 3; ++d)
+      period_a[d] = std::max(1, std::min(2 * c.reach + 1, gdims_c[d]));
+    const int n_col_a = period_a[0] * period_a[1] * period_a[2] * C;
+    const int64_t crow0 = c.owned_row_begin(), cn_own = c.owned_rows();
+    std::vector<std::vector<double>> Y((size_t)n_col_a);
+    for (int col = 0; col < n_col_a; ++col)
+    {
+      const int comp = col % C, oc = col / C;
+      const int phase[3] = {oc % period_a[0], (oc / period_a[0]) % period_a[1], oc / (period_a[0] * period_a[1])};
+      vec::select_rows(h, c.dims, C, 1, (int)c.global_begin, period_a, phase, comp, nullptr, u_c.get_values());
+      p_mat->vmult(y_f.get_values(), u_c.get_values());
+      h.exchange(g.space, y_f.get_values());
+      a_op->get_matrix()->vmult(z_f.get_values(), y_f.get_values());
+      pt_mat->vmult(y_c.get_values(), z_f.get_values());
+      h.exchange_reverse_add(c.space, y_c.get_values());
+      Y[col] = download_range(h, y_c.get_values(), crow0, cn_own);
+    }
+    HostCsr Ac;
+    Ac.n_rows = Ac.n_cols = n_c;
+    Ac.row_ptr.assign(n_c + 1, 0);
+    {
+      auto visit = [&](int64_t r, auto &&emit) {
+        const int64_t nd = r / C;
+        const int X = (int)(nd % c.dims[0]), Yc = (int)((nd / c.dims[0]) % c.dims[1]), Zl = (int)(nd / ((int64_t)c.dims[0] * c.dims[1]));
+        const int64_t Zg = Zl + c.global_begin;
+        for (int64_t K = std::max<int64_t>(0, Zg - c.reach); K <= std::min<int64_t>(gdims_c[2] - 1, Zg + c.reach); ++K)
+          for (int J = std::max(0, Yc - c.reach); J <= std::min(gdims_c[1] - 1, Yc + c.reach); ++J)
+            for (int I = std::max(0, X - c.reach); I <= std::min(gdims_c[0] - 1, X + c.reach); ++I)
+            {
+              const int oc = (I % period_a[0]) + period_a[0] * ((J % period_a[1]) + period_a[1] * (int)(K % period_a[2]));
+              const int64_t Kl = K - c.global_begin;
+              ASSERT_THROW(Kl >= 0 && Kl < c.dims[2], "internal: coarse-operator column outside the local box");
+              for (int comp = 0; comp < C; ++comp)
+              {
+                const double v = Y[(size_t)(oc * C + comp)][(size_t)(r - crow0)];
+                if (v != 0.)
+                  emit((((int64_t)Kl * c.dims[1] + J) * c.dims[0] + I) * C + comp, v);
+              }
+            }
+      };
+#pragma omp parallel for schedule(static)
+      for (int64_t r = crow0; r < crow0 + cn_own; ++r)
+      {
+        int cnt = 0;
+        visit(r, [&](int64_t, double) { ++cnt; });
+        Ac.row_ptr[r + 1] = cnt;
+      }
+      for (int64_t r = 0; r < n_c; ++r)
+      {
+        ASSERT_THROW((int64_t)Ac.row_ptr[r] + Ac.row_ptr[r + 1] < (int64_t(1) << 31), "coarse operator exceeds int32 entries");
+        Ac.row_ptr[r + 1] += Ac.row_ptr[r];
+      }
+      Ac.col.resize(Ac.row_ptr[n_c]);
+      Ac.val.resize(Ac.row_ptr[n_c]);
+#pragma omp parallel for schedule(static)
+      for (int64_t r = crow0; r < crow0 + cn_own; ++r)
+      {
+        int p = Ac.row_ptr[r];
+        visit(r, [&](int64_t col, double v) {
+          Ac.col[p] = (int32_t)col;
+          Ac.val[p] = v;
+          ++p;
+        });
+      }
+    }
+    Y.clear();
+    Y.shrink_to_fit();
+    if (verbose)
+      std::fprintf(stderr, "[mfmg_hip] amg level %d on the device (%lld local rows, reach %d): P %d probes %.2f s, A_c %d probes %.2f s\n",
+                   level, (long long)n_f, g.reach, n_col_p, t1 - t0, n_col_a, wall_now() - t1);
+
+    // ---- the level's operators
+    AmgLevel L;
+    L.a = a_op;
+    L.prolongator = std::make_shared<HipMatrixOperator>(p_mat);
+    L.prolongator->set_spaces(c.space, 0); // x -= P x_c reads the ghost aggregates of x_c
+    L.restrictor = std::make_shared<HipMatrixOperator>(pt_mat);
+    L.restrictor->set_spaces(0, 0);        // P^T has entries in owned fine rows only ...
+    L.restrictor->set_reverse_range_space(c.space); // ... and returns the sums of ghost aggregates to their owners
+    L.smoother = std::make_shared<HipSmoother>(L.a, smoother_params);
+    _amg.push_back(std::move(L));
+
+    // ---- next level
+    HostCsr Ac_copy = Ac;
+    auto ac_mat = upload_csr(h, std::move(Ac_copy));
+    a_op = std::make_shared<HipMatrixOperator>(ac_mat);
+    a_op->set_spaces(c.space, c.space);
+    A = std::move(Ac);
+    B = std::move(Bc);
+    g = c;
+  }
+}
+
+// The level `a_op` (owned rows in `A`, local numbering) becomes the first replicated level: its operator and near-null
+// vector are gathered, the remaining hierarchy is built by the host code of one rank, identically on every rank.
+void HipSolver::finish_amg_replicated(std::shared_ptr<HipMatrixOperator> a_op, HostCsr A, std::vector<double> B, int space,
+                                      int64_t owned_begin, int64_t owned_count, int64_t global_begin, int64_t global_layers,
+                                      int const dims[3], int n_comp, AmgOptions const &opts, std::shared_ptr<ptree> smoother_params)
+{
+  HipHandle &h = _handle;
+  const bool distributed = h.comm.enabled() && space > 0;
+  const int64_t le = (int64_t)dims[0] * dims[1] * n_comp;
+  HostCsr Ag;
+  std::vector<double> Bg;
+  if (!distributed)
+  {
+    Ag = std::move(A);
+    Bg = std::move(B);
+  }
+  else
+  {
+    const int n_ranks = h.comm.n_ranks;
+    const int64_t row0 = owned_begin * le, n_own = owned_count * le, n_glob = global_layers * le;
+    ASSERT_THROW(n_own * n_ranks == n_glob, "internal: the slabs of a gathered level must have equal size");
+    const int64_t shift = global_begin * le; // local column -> global column
+    double nnz_max = (double)(A.row_ptr[row0 + n_own] - A.row_ptr[row0]);
+    nnz_max = h.allreduce_max(nnz_max);
+    const int64_t pad = (int64_t)nnz_max;
+    // [row lengths | near-null | columns (as doubles, exact) | values], padded to the same length on every rank
+    const int64_t each = 2 * n_own + 2 * pad;
+    std::vector<double> send((size_t)each, 0.);
+    for (int64_t r = 0; r < n_own; ++r)
+    {
+      send[r] = (double)(A.row_ptr[row0 + r + 1] - A.row_ptr[row0 + r]);
+      send[n_own + r] = B[row0 + r];
+    }
+    const int p0 = A.row_ptr[row0];
+    for (int p = p0; p < A.row_ptr[row0 + n_own]; ++p)
+    {
+      send[2 * n_own + (p - p0)] = (double)(A.col[p] + shift);
+      send[2 * n_own + pad + (p - p0)] = A.val[p];
+    }
+    DeviceBuffer<double> d_in((size_t)each), d_out((size_t)each * n_ranks);
+    MFMG_HIP_CHECK(hipMemcpyAsync(d_in.data(), send.data(), (size_t)each * sizeof(double), hipMemcpyHostToDevice, h.stream));
+    h.comm.transport->allgather(d_in.data(), each, d_out.data(), h.stream);
+    std::vector<double> all = d_out.download(h.stream);
+    Ag.n_rows = Ag.n_cols = n_glob;
+    Ag.row_ptr.assign(n_glob + 1, 0);
+    Bg.assign((size_t)n_glob, 0.);
+    for (int rk = 0; rk < n_ranks; ++rk)
+      for (int64_t r = 0; r < n_own; ++r)
+      {
+        Ag.row_ptr[rk * n_own + r + 1] = (int32_t)all[(size_t)rk * each + r];
+        Bg[rk * n_own + r] = all[(size_t)rk * each + n_own + r];
+      }
+    for (int64_t r = 0; r < n_glob; ++r)
+    {
+      ASSERT_THROW((int64_t)Ag.row_ptr[r] + Ag.row_ptr[r + 1] < (int64_t(1) << 31), "gathered operator exceeds int32 entries");
+      Ag.row_ptr[r + 1] += Ag.row_ptr[r];
+    }
+    Ag.col.resize(Ag.row_ptr[n_glob]);
+    Ag.val.resize(Ag.row_ptr[n_glob]);
+    for (int rk = 0; rk < n_ranks; ++rk)
+    {
+      const int64_t base = Ag.row_ptr[rk * n_own];
+      const int64_t cnt = Ag.row_ptr[(rk + 1) * n_own] - base;
+      for (int64_t q = 0; q < cnt; ++q)
+      {
+        Ag.col[base + q] = (int32_t)all[(size_t)rk * each + 2 * n_own + q];
+        Ag.val[base + q] = all[(size_t)rk * each + 2 * n_own + pad + q];
+      }
+    }
+    _amg_gather_level = (int)_amg.size();
+    _gather_space = space;
+    _gather_in.resize((size_t)n_own);
+    _gather_b = std::make_shared<DVector>(h, n_glob);
+    _gather_x = std::make_shared<DVector>(h, n_glob);
+  }
+  // geometric hint of the (global) level: the same blocks of nodes the distributed levels use
+  AmgGridHint hint;
+  hint.dims[0] = dims[0];
+  hint.dims[1] = dims[1];
+  hint.dims[2] = (int)global_layers;
+  hint.n_components = n_comp;
+  hint.node_of_row.resize((size_t)Ag.n_rows);
+  hint.component_of_row.resize((size_t)Ag.n_rows);
+  for (int64_t r = 0; r < Ag.n_rows; ++r)
+  {
+    hint.node_of_row[r] = (int32_t)(r / n_comp);
+    hint.component_of_row[r] = (int32_t)(r % n_comp);
+  }
+  const int blk = this->_params->get("solver.amg.aggregate_block", 2);
+  for (int d = 0; d < 3; ++d)
+    hint.block[d] = blk;
+  auto host_levels = build_aggregation_hierarchy(std::move(Ag), std::move(Bg), opts, &hint);
+  const size_t first = _amg.size();
+  _amg.resize(first + host_levels.size());
+  for (size_t l = 0; l < host_levels.size(); ++l)
+  {
+    AmgLevel &L = _amg[first + l];
+    if (l == 0 && !distributed)
+      L.a = a_op; // the operator the caller handed in (local = global)
+    else
+      L.a = std::make_shared<HipMatrixOperator>(upload_csr(h, std::move(host_levels[l].A)));
+    if (l + 1 < host_levels.size())
+    {
+      L.prolongator = std::make_shared<HipMatrixOperator>(upload_csr(h, std::move(host_levels[l].P)));
+      L.restrictor = std::dynamic_pointer_cast<HipMatrixOperator>(L.prolongator->transpose());
+      L.smoother = std::make_shared<HipSmoother>(L.a, smoother_params);
+    }
+  }
+  auto last = _amg.back().a->get_matrix();
+  ASSERT_THROW(last->m() <= 16384, "the coarsest level of the multilevel solver is too large for the dense LU (" +
+                                       std::to_string(last->m()) + " rows)");
+  setup_direct(last, _amg_bottom);
+}
+} // namespace mfmg

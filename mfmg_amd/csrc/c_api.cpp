@@ -4,6 +4,7 @@
 #include <exception>
 #include <string>
 
+#include "halo_transport.hpp"
 #include "mfmg/hierarchy.hpp"
 
 using namespace mfmg;
@@ -136,26 +137,91 @@ void *mfmg_hip_context_stream(mfmg_hip_context_t ctx) { return ctx ? ctx->handle
 
 // ---- distributed runs -----------------------------------------------------------------
 int mfmg_hip_context_set_communicator(mfmg_hip_context_t ctx, int32_t rank, int32_t n_ranks, int32_t ghost_cells_low,
-                                      int32_t ghost_cells_high, mfmg_hip_exchange_fn exchange,
-                                      mfmg_hip_allreduce_fn allreduce, void *user)
+                                      int32_t ghost_cells_high)
 {
   return guarded([&] {
     require(ctx != nullptr, "null context");
     require(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "rank out of range");
     require((ghost_cells_low == 0 || ghost_cells_low == 2) && (ghost_cells_high == 0 || ghost_cells_high == 2),
             "ghost cell layers must be 0 or 2 (one agglomerate layer)");
-    require(n_ranks == 1 || (exchange && allreduce), "null transport callbacks");
     require((ghost_cells_low == 2) == (rank > 0) && (ghost_cells_high == 2) == (rank + 1 < n_ranks),
             "ghost layers must be present exactly towards existing neighbours");
     HaloCommunicator &c = ctx->handle->comm;
+    auto transport = c.transport;
     c = HaloCommunicator();
+    c.transport = transport;
     c.rank = rank;
     c.n_ranks = n_ranks;
     c.ghost_cells_low = ghost_cells_low;
     c.ghost_cells_high = ghost_cells_high;
-    c.exchange_fn = exchange;
-    c.allreduce_fn = allreduce;
-    c.user = user;
+  });
+}
+
+int mfmg_hip_rccl_unique_id(unsigned char out[128])
+{
+  return guarded([&] {
+    require(out != nullptr, "null output");
+    rccl_unique_id(out);
+  });
+}
+
+int mfmg_hip_context_use_rccl(mfmg_hip_context_t ctx, const unsigned char unique_id[128])
+{
+  return guarded([&] {
+    require(ctx != nullptr && unique_id != nullptr, "null argument");
+    HaloCommunicator &c = ctx->handle->comm;
+    c.transport = make_rccl_transport(c.rank, c.n_ranks, unique_id);
+  });
+}
+
+int mfmg_hip_context_use_host_transport(mfmg_hip_context_t ctx, mfmg_hip_host_sendrecv_fn sendrecv,
+                                        mfmg_hip_host_allreduce_fn allreduce, mfmg_hip_host_allgather_fn allgather, void *user)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    require(sendrecv && allreduce && allgather, "null transport callbacks");
+    HaloCommunicator &c = ctx->handle->comm;
+    c.transport = make_host_transport(c.rank, c.n_ranks, sendrecv, allreduce, allgather, user);
+  });
+}
+
+int mfmg_hip_context_transport_name(mfmg_hip_context_t ctx, char *buffer, size_t buffer_size)
+{
+  return guarded([&] {
+    require(ctx != nullptr && buffer != nullptr && buffer_size > 0, "null argument");
+    std::string name = ctx->handle->comm.transport ? ctx->handle->comm.transport->name() : "";
+    std::snprintf(buffer, buffer_size, "%s", name.c_str());
+  });
+}
+
+int mfmg_hip_context_exchange_count(mfmg_hip_context_t ctx, int64_t *n_exchanges)
+{
+  return guarded([&] {
+    require(ctx != nullptr && n_exchanges != nullptr, "null argument");
+    *n_exchanges = ctx->handle->comm.n_exchanges;
+  });
+}
+
+int mfmg_hip_context_exchange(mfmg_hip_context_t ctx, int32_t space, double *vector, int reverse)
+{
+  return guarded([&] {
+    require(ctx != nullptr && vector != nullptr, "null argument");
+    if (reverse)
+      ctx->handle->exchange_reverse_add(space, vector);
+    else
+      ctx->handle->exchange(space, vector);
+  });
+}
+
+int mfmg_hip_context_owned_dot(mfmg_hip_context_t ctx, int32_t space, const double *x, const double *y, double *result)
+{
+  return guarded([&] {
+    require(ctx != nullptr && x && y && result, "null argument");
+    HipHandle &h = *ctx->handle;
+    require(space > 0 && space < (int)h.comm.spaces.size() && h.comm.spaces[space].configured(), "unknown vector space");
+    HaloSpace const &s = h.comm.spaces[space];
+    const int64_t off = s.owned_begin * s.layer_elems, n = s.owned_count * s.layer_elems;
+    *result = h.allreduce_sum(vec::dot<double>(h, n, x + off, y + off));
   });
 }
 
@@ -198,28 +264,12 @@ int mfmg_hip_context_set_overlap_exchange(mfmg_hip_context_t ctx, int enable)
   });
 }
 
-int mfmg_hip_context_set_halo_buffers(mfmg_hip_context_t ctx, int32_t space, int64_t n_elems, double *send_low,
-                                      double *send_high, double *recv_low, double *recv_high)
-{
-  return guarded([&] {
-    require(ctx != nullptr, "null context");
-    require(space == 1 || space == 2, "space must be 1 (fine) or 2 (coarse)");
-    require(n_elems > 0 && send_low && send_high && recv_low && recv_high, "null staging buffer");
-    HaloSpace &s = ctx->handle->comm.spaces[space];
-    s.send_low = send_low;
-    s.send_high = send_high;
-    s.recv_low = recv_low;
-    s.recv_high = recv_high;
-    s.staging_elems = n_elems;
-  });
-}
-
 int mfmg_hip_context_halo_layout(mfmg_hip_context_t ctx, int32_t space, int64_t *layer_elems, int64_t *n_layers,
                                  int64_t *owned_begin, int64_t *owned_count)
 {
   return guarded([&] {
     require(ctx != nullptr, "null context");
-    require(space == 1 || space == 2, "space must be 1 (fine) or 2 (coarse)");
+    require(space >= 1 && space < (int)ctx->handle->comm.spaces.size(), "unknown vector space");
     HaloSpace const &s = ctx->handle->comm.spaces[space];
     if (layer_elems)
       *layer_elems = s.layer_elems;
@@ -229,6 +279,23 @@ int mfmg_hip_context_halo_layout(mfmg_hip_context_t ctx, int32_t space, int64_t 
       *owned_begin = s.owned_begin;
     if (owned_count)
       *owned_count = s.owned_count;
+  });
+}
+
+int mfmg_hip_context_halo_space(mfmg_hip_context_t ctx, int32_t space, int64_t out[8])
+{
+  return guarded([&] {
+    require(ctx != nullptr && out != nullptr, "null argument");
+    require(space >= 1 && space < (int)ctx->handle->comm.spaces.size(), "unknown vector space");
+    HaloSpace const &s = ctx->handle->comm.spaces[space];
+    out[0] = s.layer_elems;
+    out[1] = s.n_layers;
+    out[2] = s.owned_begin;
+    out[3] = s.owned_count;
+    out[4] = s.global_begin;
+    out[5] = s.global_layers;
+    out[6] = s.width;
+    out[7] = (int64_t)ctx->handle->comm.spaces.size();
   });
 }
 

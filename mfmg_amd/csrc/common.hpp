@@ -230,30 +230,59 @@ struct KernelProfiler
 // The reference gets its ghost exchange from deal.II's distributed::Vector inside
 // MatrixFree::cell_loop / Epetra Import (and all-gathers the whole vector on the CUDA path,
 // source/cuda/utils.cu:363-482).  Here a rank's vector is [ghost layers | owned layers | ghost layers],
-// layers contiguous; exchange() refreshes the one ghost layer on each side that operator applications
-// read, through staging buffers and a caller-provided transport (RCCL send/recv via torch.distributed).
+// layers contiguous and the local layers a contiguous run of the global ones.  Every level of the cycle has
+// its own space (fine DoF planes, agglomerate layers, the node layers of the aggregation levels):
+//   forward exchange     owner -> ghost: the `width` owned layers next to each neighbour refresh that
+//                        neighbour's nearest `width` ghost layers (before an operator reads them);
+//   reverse-add exchange ghost -> owner: the `width` ghost layers are sent back and ADDED to the owner's
+//                        boundary layers (after a transposed prolongator scattered partial sums into them).
 struct HaloSpace
 {
-  int64_t layer_elems = 0;   // entries per layer (a DoF plane, or a layer of agglomerates)
-  int64_t n_layers = 0;      // layers of the local vector
-  int64_t owned_begin = 0;   // first owned layer
-  int64_t owned_count = 0;   // owned layers
+  int64_t layer_elems = 0;  // entries per layer (a DoF plane, a layer of agglomerates / aggregates)
+  int64_t n_layers = 0;     // layers of the local vector
+  int64_t owned_begin = 0;  // first owned layer
+  int64_t owned_count = 0;  // owned layers
+  int64_t global_begin = 0; // global index of local layer 0
+  int64_t global_layers = 0;
+  int width = 1;            // layers moved per side by an exchange (<= the ghost layers present on that side)
   bool has_low = false, has_high = false;
-  double *send_low = nullptr, *send_high = nullptr, *recv_low = nullptr, *recv_high = nullptr; // device staging
-  int64_t staging_elems = 0;
   bool configured() const { return layer_elems > 0; }
+  int64_t ghost_low() const { return owned_begin; }
+  int64_t ghost_high() const { return n_layers - owned_begin - owned_count; }
+};
+
+// Point-to-point transport between slab neighbours + the few collectives of the setup.  Two implementations:
+// RCCL send/recv over xGMI on the caller's stream (one process per GPU), and host callbacks (the library stages
+// through pinned host buffers; gloo in the tests, where several ranks share one card).
+struct HaloTransport
+{
+  virtual ~HaloTransport() = default;
+  // exchange n_low doubles with rank - 1 and n_high with rank + 1 (device pointers; a count of 0 = no neighbour);
+  // enqueued on `stream` (the host transport synchronises the stream around its callbacks)
+  virtual void sendrecv(double const *send_low, double *recv_low, int64_t n_low, double const *send_high, double *recv_high,
+                        int64_t n_high, hipStream_t stream) = 0;
+  virtual void allreduce(double *host_values, int n, int op /* 0 sum, 1 max */, hipStream_t stream) = 0;
+  // every rank contributes n doubles (device), `out` (device) receives n * n_ranks in rank order
+  virtual void allgather(double const *in, int64_t n, double *out, hipStream_t stream) = 0;
+  virtual char const *name() const = 0;
 };
 
 struct HaloCommunicator
 {
   int rank = 0, n_ranks = 1;
   int ghost_cells_low = 0, ghost_cells_high = 0; // ghost cell layers of the local mesh along z
-  int (*exchange_fn)(void *user, int space, void *stream) = nullptr;
-  int (*allreduce_fn)(void *user, double *values, int n) = nullptr;
-  void *user = nullptr;
-  HaloSpace spaces[3]; // [1] fine DoFs, [2] first coarse level
+  std::shared_ptr<HaloTransport> transport;
+  std::vector<HaloSpace> spaces = std::vector<HaloSpace>(3); // [0] rank-local, [1] fine DoFs, [2] first coarse level, then the aggregation levels
+  int64_t n_exchanges = 0; // (diagnostics) point-to-point exchanges issued so far
   bool enabled() const { return n_ranks > 1; }
+  int add_space(HaloSpace const &s)
+  {
+    spaces.push_back(s);
+    return (int)spaces.size() - 1;
+  }
 };
+
+void halo_add_layers(double *dst, double const *src, int64_t n, hipStream_t stream); // dst += src (vector_ops.hip)
 
 // ---- HipHandle: stream + reduction scratch; twin of CudaHandle
 //      (include/mfmg/cuda/cuda_handle.cuh:25-48): borrowed by every object built from it ----
@@ -276,30 +305,61 @@ struct HipHandle
   double *host_result = nullptr; // pinned
   KernelProfiler profiler;
   HaloCommunicator comm;
+  // staging of the halo exchanges: [send_low | send_high | recv_low | recv_high], grown on demand
+  DeviceBuffer<double> halo_staging;
+  int64_t halo_staging_each = 0;
 
+  HaloSpace &space_checked(int space)
+  {
+    if (space <= 0 || space >= (int)comm.spaces.size() || !comm.spaces[space].configured())
+      throw std::runtime_error("halo exchange requested for an unconfigured vector space");
+    if (!comm.transport)
+      throw std::runtime_error("no halo transport was registered with the context");
+    return comm.spaces[space];
+  }
+  void staging_reserve(int64_t each)
+  {
+    if (each > halo_staging_each)
+    {
+      MFMG_HIP_CHECK(hipStreamSynchronize(stream));
+      if (comm_stream)
+        MFMG_HIP_CHECK(hipStreamSynchronize(comm_stream));
+      halo_staging.resize((size_t)4 * each);
+      halo_staging_each = each;
+    }
+  }
+  // forward exchange on `st`: pack, transport, unpack
+  void exchange_on(HaloSpace const &s, double *v, hipStream_t pack_stream, hipStream_t st, bool split)
+  {
+    const int64_t n = (int64_t)s.width * s.layer_elems;
+    staging_reserve(n);
+    double *send_low = halo_staging.data(), *send_high = send_low + halo_staging_each, *recv_low = send_high + halo_staging_each,
+           *recv_high = recv_low + halo_staging_each;
+    const size_t bytes = (size_t)n * sizeof(double);
+    if (s.has_low)
+      MFMG_HIP_CHECK(hipMemcpyAsync(send_low, v + s.owned_begin * s.layer_elems, bytes, hipMemcpyDeviceToDevice, pack_stream));
+    if (s.has_high)
+      MFMG_HIP_CHECK(hipMemcpyAsync(send_high, v + (s.owned_begin + s.owned_count - s.width) * s.layer_elems, bytes,
+                                    hipMemcpyDeviceToDevice, pack_stream));
+    if (split)
+    {
+      MFMG_HIP_CHECK(hipEventRecord(ev_packed, pack_stream));
+      MFMG_HIP_CHECK(hipStreamWaitEvent(st, ev_packed, 0));
+    }
+    comm.transport->sendrecv(send_low, recv_low, s.has_low ? n : 0, send_high, recv_high, s.has_high ? n : 0, st);
+    ++comm.n_exchanges;
+    if (s.has_low)
+      MFMG_HIP_CHECK(hipMemcpyAsync(v + (s.owned_begin - s.width) * s.layer_elems, recv_low, bytes, hipMemcpyDeviceToDevice, st));
+    if (s.has_high)
+      MFMG_HIP_CHECK(hipMemcpyAsync(v + (s.owned_begin + s.owned_count) * s.layer_elems, recv_high, bytes,
+                                    hipMemcpyDeviceToDevice, st));
+  }
   // refresh the ghost layers of a distributed vector (no-op on one rank / for local spaces)
   void exchange(int space, double *v)
   {
     if (!comm.enabled() || space <= 0)
       return;
-    HaloSpace &s = comm.spaces[space];
-    if (!s.configured())
-      throw std::runtime_error("halo exchange requested for an unconfigured vector space");
-    if (s.staging_elems < s.layer_elems || comm.exchange_fn == nullptr)
-      throw std::runtime_error("halo staging buffers / transport were not registered");
-    const size_t bytes = (size_t)s.layer_elems * sizeof(double);
-    if (s.has_low)
-      MFMG_HIP_CHECK(hipMemcpyAsync(s.send_low, v + s.owned_begin * s.layer_elems, bytes, hipMemcpyDeviceToDevice, stream));
-    if (s.has_high)
-      MFMG_HIP_CHECK(hipMemcpyAsync(s.send_high, v + (s.owned_begin + s.owned_count - 1) * s.layer_elems, bytes,
-                                    hipMemcpyDeviceToDevice, stream));
-    if (comm.exchange_fn(comm.user, space, stream) != 0)
-      throw std::runtime_error("halo exchange transport failed");
-    if (s.has_low)
-      MFMG_HIP_CHECK(hipMemcpyAsync(v + (s.owned_begin - 1) * s.layer_elems, s.recv_low, bytes, hipMemcpyDeviceToDevice, stream));
-    if (s.has_high)
-      MFMG_HIP_CHECK(hipMemcpyAsync(v + (s.owned_begin + s.owned_count) * s.layer_elems, s.recv_high, bytes,
-                                    hipMemcpyDeviceToDevice, stream));
+    exchange_on(space_checked(space), v, stream, stream, false);
   }
   // The same exchange split in two, so that work which does not read the ghost layers can run in between
   // (north_star: "halo exchange ... overlapped with interior smoothing on a second HIP stream"):
@@ -311,33 +371,14 @@ struct HipHandle
   {
     if (!comm.enabled() || space <= 0)
       return;
-    HaloSpace &s = comm.spaces[space];
-    if (!s.configured())
-      throw std::runtime_error("halo exchange requested for an unconfigured vector space");
-    if (s.staging_elems < s.layer_elems || comm.exchange_fn == nullptr)
-      throw std::runtime_error("halo staging buffers / transport were not registered");
+    HaloSpace &s = space_checked(space);
     if (comm_stream == nullptr)
     {
       MFMG_HIP_CHECK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
       MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming));
       MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_unpacked, hipEventDisableTiming));
     }
-    const size_t bytes = (size_t)s.layer_elems * sizeof(double);
-    if (s.has_low)
-      MFMG_HIP_CHECK(hipMemcpyAsync(s.send_low, v + s.owned_begin * s.layer_elems, bytes, hipMemcpyDeviceToDevice, stream));
-    if (s.has_high)
-      MFMG_HIP_CHECK(hipMemcpyAsync(s.send_high, v + (s.owned_begin + s.owned_count - 1) * s.layer_elems, bytes,
-                                    hipMemcpyDeviceToDevice, stream));
-    MFMG_HIP_CHECK(hipEventRecord(ev_packed, stream));
-    MFMG_HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_packed, 0));
-    if (comm.exchange_fn(comm.user, space, comm_stream) != 0)
-      throw std::runtime_error("halo exchange transport failed");
-    if (s.has_low)
-      MFMG_HIP_CHECK(hipMemcpyAsync(v + (s.owned_begin - 1) * s.layer_elems, s.recv_low, bytes, hipMemcpyDeviceToDevice,
-                                    comm_stream));
-    if (s.has_high)
-      MFMG_HIP_CHECK(hipMemcpyAsync(v + (s.owned_begin + s.owned_count) * s.layer_elems, s.recv_high, bytes,
-                                    hipMemcpyDeviceToDevice, comm_stream));
+    exchange_on(s, v, stream, comm_stream, true);
     MFMG_HIP_CHECK(hipEventRecord(ev_unpacked, comm_stream));
   }
   void exchange_end(int space)
@@ -346,12 +387,45 @@ struct HipHandle
       return;
     MFMG_HIP_CHECK(hipStreamWaitEvent(stream, ev_unpacked, 0));
   }
+  // ghost -> owner: the ghost layers hold partial sums that belong to the neighbours' boundary layers
+  void exchange_reverse_add(int space, double *v)
+  {
+    if (!comm.enabled() || space <= 0)
+      return;
+    HaloSpace &s = space_checked(space);
+    const int64_t n = (int64_t)s.width * s.layer_elems;
+    staging_reserve(n);
+    double *send_low = halo_staging.data(), *send_high = send_low + halo_staging_each, *recv_low = send_high + halo_staging_each,
+           *recv_high = recv_low + halo_staging_each;
+    const size_t bytes = (size_t)n * sizeof(double);
+    if (s.has_low)
+      MFMG_HIP_CHECK(hipMemcpyAsync(send_low, v + (s.owned_begin - s.width) * s.layer_elems, bytes, hipMemcpyDeviceToDevice, stream));
+    if (s.has_high)
+      MFMG_HIP_CHECK(hipMemcpyAsync(send_high, v + (s.owned_begin + s.owned_count) * s.layer_elems, bytes,
+                                    hipMemcpyDeviceToDevice, stream));
+    comm.transport->sendrecv(send_low, recv_low, s.has_low ? n : 0, send_high, recv_high, s.has_high ? n : 0, stream);
+    ++comm.n_exchanges;
+    if (s.has_low)
+      halo_add_layers(v + s.owned_begin * s.layer_elems, recv_low, n, stream);
+    if (s.has_high)
+      halo_add_layers(v + (s.owned_begin + s.owned_count - s.width) * s.layer_elems, recv_high, n, stream);
+  }
   double allreduce_sum(double v)
   {
     if (!comm.enabled())
       return v;
-    if (comm.allreduce_fn == nullptr || comm.allreduce_fn(comm.user, &v, 1) != 0)
-      throw std::runtime_error("all-reduce transport failed");
+    if (!comm.transport)
+      throw std::runtime_error("no halo transport was registered with the context");
+    comm.transport->allreduce(&v, 1, 0, stream);
+    return v;
+  }
+  double allreduce_max(double v)
+  {
+    if (!comm.enabled())
+      return v;
+    if (!comm.transport)
+      throw std::runtime_error("no halo transport was registered with the context");
+    comm.transport->allreduce(&v, 1, 1, stream);
     return v;
   }
 

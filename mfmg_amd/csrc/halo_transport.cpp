@@ -1,0 +1,225 @@
+#include "halo_transport.hpp"
+
+#include <dlfcn.h>
+
+#include <cstring>
+
+namespace mfmg
+{
+namespace
+{
+// ---- the handful of RCCL entry points used, resolved with dlsym (rccl/rccl.h, NCCL 2.x ABI) ----
+struct ncclComm;
+typedef ncclComm *ncclComm_t;
+struct ncclUniqueId
+{
+  char internal[128];
+};
+constexpr int ncclSuccess = 0;
+constexpr int ncclFloat64 = 8; // ncclDataType_t
+constexpr int ncclSum = 0, ncclMax = 2;
+
+struct RcclApi
+{
+  int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  void *lib = nullptr;
+};
+
+RcclApi &rccl()
+{
+  static RcclApi api = [] {
+    RcclApi a;
+    // the copy already in the process (torch ships its own librccl.so) comes first: two RCCL instances in one
+    // process would each bring their own topology state
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names)
+      if ((a.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) != nullptr)
+        break;
+    if (!a.lib)
+      for (const char *n : names)
+        if ((a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr)
+          break;
+    if (!a.lib)
+      throw std::runtime_error("RCCL transport: librccl.so could not be loaded");
+    auto sym = [&](const char *name) {
+      void *p = dlsym(a.lib, name);
+      if (!p)
+        throw std::runtime_error(std::string("RCCL transport: missing symbol ") + name);
+      return p;
+    };
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    return a;
+  }();
+  return api;
+}
+
+void rccl_check(int status, const char *what)
+{
+  if (status != ncclSuccess)
+    throw std::runtime_error(std::string("RCCL error in ") + what + ": " + rccl().GetErrorString(status));
+}
+
+class RcclTransport : public HaloTransport
+{
+public:
+  RcclTransport(int rank, int n_ranks, unsigned char const unique_id[128]) : _rank(rank), _n(n_ranks)
+  {
+    ncclUniqueId id;
+    std::memcpy(id.internal, unique_id, 128);
+    rccl_check(rccl().CommInitRank(&_comm, n_ranks, id, rank), "ncclCommInitRank");
+    _scalars.resize(16);
+  }
+  ~RcclTransport() override
+  {
+    if (_comm)
+      (void)rccl().CommDestroy(_comm);
+  }
+  void sendrecv(double const *send_low, double *recv_low, int64_t n_low, double const *send_high, double *recv_high, int64_t n_high,
+                hipStream_t stream) override
+  {
+    if (n_low <= 0 && n_high <= 0)
+      return;
+    RcclApi &r = rccl();
+    rccl_check(r.GroupStart(), "ncclGroupStart");
+    if (n_low > 0)
+    {
+      rccl_check(r.Send(send_low, (size_t)n_low, ncclFloat64, _rank - 1, _comm, stream), "ncclSend");
+      rccl_check(r.Recv(recv_low, (size_t)n_low, ncclFloat64, _rank - 1, _comm, stream), "ncclRecv");
+    }
+    if (n_high > 0)
+    {
+      rccl_check(r.Send(send_high, (size_t)n_high, ncclFloat64, _rank + 1, _comm, stream), "ncclSend");
+      rccl_check(r.Recv(recv_high, (size_t)n_high, ncclFloat64, _rank + 1, _comm, stream), "ncclRecv");
+    }
+    rccl_check(r.GroupEnd(), "ncclGroupEnd");
+  }
+  void allreduce(double *host_values, int n, int op, hipStream_t stream) override
+  {
+    ASSERT_THROW(n >= 1 && n <= 16, "all-reduce of at most 16 scalars");
+    MFMG_HIP_CHECK(hipMemcpyAsync(_scalars.data(), host_values, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    rccl_check(rccl().AllReduce(_scalars.data(), _scalars.data(), (size_t)n, ncclFloat64, op == 1 ? ncclMax : ncclSum, _comm, stream),
+               "ncclAllReduce");
+    MFMG_HIP_CHECK(hipMemcpyAsync(host_values, _scalars.data(), n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    MFMG_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  void allgather(double const *in, int64_t n, double *out, hipStream_t stream) override
+  {
+    rccl_check(rccl().AllGather(in, out, (size_t)n, ncclFloat64, _comm, stream), "ncclAllGather");
+  }
+  char const *name() const override { return "rccl"; }
+
+private:
+  int _rank, _n;
+  ncclComm_t _comm = nullptr;
+  DeviceBuffer<double> _scalars;
+};
+
+class HostTransport : public HaloTransport
+{
+public:
+  HostTransport(int rank, int n_ranks, mfmg_hip_host_sendrecv_fn sr, mfmg_hip_host_allreduce_fn ar, mfmg_hip_host_allgather_fn ag,
+                void *user)
+      : _rank(rank), _n(n_ranks), _sr(sr), _ar(ar), _ag(ag), _user(user)
+  {
+    ASSERT_THROW(sr && ar && ag, "null transport callbacks");
+  }
+  ~HostTransport() override
+  {
+    if (_host)
+      (void)hipHostFree(_host);
+  }
+  void sendrecv(double const *send_low, double *recv_low, int64_t n_low, double const *send_high, double *recv_high, int64_t n_high,
+                hipStream_t stream) override
+  {
+    if (n_low <= 0 && n_high <= 0)
+      return;
+    const int64_t each = std::max(n_low, n_high);
+    reserve(4 * each);
+    double *h_sl = _host, *h_sh = _host + each, *h_rl = _host + 2 * each, *h_rh = _host + 3 * each;
+    if (n_low > 0)
+      MFMG_HIP_CHECK(hipMemcpyAsync(h_sl, send_low, n_low * sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (n_high > 0)
+      MFMG_HIP_CHECK(hipMemcpyAsync(h_sh, send_high, n_high * sizeof(double), hipMemcpyDeviceToHost, stream));
+    MFMG_HIP_CHECK(hipStreamSynchronize(stream));
+    if (_sr(_user, h_sl, h_rl, n_low, h_sh, h_rh, n_high) != 0)
+      throw std::runtime_error("halo exchange transport failed");
+    if (n_low > 0)
+      MFMG_HIP_CHECK(hipMemcpyAsync(recv_low, h_rl, n_low * sizeof(double), hipMemcpyHostToDevice, stream));
+    if (n_high > 0)
+      MFMG_HIP_CHECK(hipMemcpyAsync(recv_high, h_rh, n_high * sizeof(double), hipMemcpyHostToDevice, stream));
+    MFMG_HIP_CHECK(hipStreamSynchronize(stream)); // the pinned buffers are reused by the next call
+  }
+  void allreduce(double *host_values, int n, int op, hipStream_t) override
+  {
+    if (_ar(_user, host_values, n, op) != 0)
+      throw std::runtime_error("all-reduce transport failed");
+  }
+  void allgather(double const *in, int64_t n, double *out, hipStream_t stream) override
+  {
+    reserve(n * (int64_t)(_n + 1));
+    MFMG_HIP_CHECK(hipMemcpyAsync(_host, in, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    MFMG_HIP_CHECK(hipStreamSynchronize(stream));
+    if (_ag(_user, _host, n, _host + n) != 0)
+      throw std::runtime_error("all-gather transport failed");
+    MFMG_HIP_CHECK(hipMemcpyAsync(out, _host + n, n * _n * sizeof(double), hipMemcpyHostToDevice, stream));
+    MFMG_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  char const *name() const override { return "host"; }
+
+private:
+  void reserve(int64_t n)
+  {
+    if (n <= _host_n)
+      return;
+    if (_host)
+      (void)hipHostFree(_host);
+    MFMG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&_host), (size_t)n * sizeof(double)));
+    _host_n = n;
+  }
+  int _rank, _n;
+  mfmg_hip_host_sendrecv_fn _sr;
+  mfmg_hip_host_allreduce_fn _ar;
+  mfmg_hip_host_allgather_fn _ag;
+  void *_user;
+  double *_host = nullptr;
+  int64_t _host_n = 0;
+};
+} // namespace
+
+void rccl_unique_id(unsigned char out[128])
+{
+  ncclUniqueId id;
+  rccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+  std::memcpy(out, id.internal, 128);
+}
+
+std::shared_ptr<HaloTransport> make_rccl_transport(int rank, int n_ranks, unsigned char const unique_id[128])
+{
+  return std::make_shared<RcclTransport>(rank, n_ranks, unique_id);
+}
+
+std::shared_ptr<HaloTransport> make_host_transport(int rank, int n_ranks, mfmg_hip_host_sendrecv_fn sendrecv,
+                                                   mfmg_hip_host_allreduce_fn allreduce, mfmg_hip_host_allgather_fn allgather,
+                                                   void *user)
+{
+  return std::make_shared<HostTransport>(rank, n_ranks, sendrecv, allreduce, allgather, user);
+}
+} // namespace mfmg

@@ -162,12 +162,18 @@ HipMatrixFreeMeshEvaluator::HipMatrixFreeMeshEvaluator(HipHandle &handle, mfmg_h
     // last rank); the planes below / above belong to the neighbours
     ASSERT_THROW(_mesh.dim == 3, "distributed runs need a 3-D mesh");
     HaloSpace &s = c.spaces[1];
+    s = HaloSpace();
     s.layer_elems = (int64_t)_mesh.N[0] * _mesh.N[1];
     s.n_layers = _mesh.N[2];
     s.has_low = c.ghost_cells_low > 0;
     s.has_high = c.ghost_cells_high > 0;
     s.owned_begin = c.ghost_cells_low;
     s.owned_count = _mesh.N[2] - c.ghost_cells_low - (s.has_high ? c.ghost_cells_high + 1 : 0);
+    s.width = 1; // operator applications read one plane of each neighbour
+    // uniform slabs: every rank owns the same number of cell layers, so the global position follows from the rank
+    const int64_t own_cells = _mesh.n[2] - c.ghost_cells_low - c.ghost_cells_high;
+    s.global_begin = (int64_t)c.rank * own_cells - c.ghost_cells_low;
+    s.global_layers = (int64_t)c.n_ranks * own_cells + 1;
     ASSERT_THROW(s.owned_count >= 2 && s.owned_count % 2 == (s.has_high ? 0 : 1),
                  "the owned slab must hold a whole number of agglomerate layers");
     // local numbering must be lexicographic so that planes are contiguous
@@ -234,6 +240,8 @@ void HipMatrixOperator::apply(DVector const &x, DVector &y, OperatorMode mode) c
       _structured->restrict_to_coarse(x.get_values(), y.get_values());
     else
       _matrix->vmult(y.get_values(), x.get_values());
+    if (_reverse_range_space > 0)
+      _matrix->handle().exchange_reverse_add(_reverse_range_space, y.get_values());
   }
   else
   {
@@ -640,17 +648,34 @@ void HipSmoother::estimate_eigenvalues(int n_iterations, double residual, double
   auto rhs = _hip_operator->build_range_vector();
   const int64_t n = rhs->size();
   {
+    // (distributed spaces: the pattern follows the GLOBAL id -- the local layers are a contiguous run of the
+    // global ones -- and the mean is the global one, so that every rank count estimates the same eigenvalues)
+    const int sp = _hip_operator->domain_space();
+    int64_t id0 = 0, own_begin = 0, own_end = n;
+    double n_global = double(n);
+    if (h.comm.enabled() && sp > 0)
+    {
+      HaloSpace const &hs = h.comm.spaces[sp];
+      id0 = hs.global_begin * hs.layer_elems;
+      own_begin = hs.owned_begin * hs.layer_elems;
+      own_end = own_begin + hs.owned_count * hs.layer_elems;
+      n_global = double(hs.global_layers * hs.layer_elems);
+    }
     std::vector<double> v(n);
     double mean = 0.;
     for (int64_t i = 0; i < n; ++i)
     {
+      const int64_t gi = i + id0;
       if (_eig_start == "dealii")
-        v[i] = double(i % 11);
+        v[i] = double(gi % 11);
       else // Knuth multiplicative hash of the DoF id, in [0, 1)
-        v[i] = double((uint64_t(i) * 2654435761ull) & 0xffffffffull) / 4294967296.0;
-      mean += v[i];
+        v[i] = double((uint64_t(gi) * 2654435761ull) & 0xffffffffull) / 4294967296.0;
+      if (i >= own_begin && i < own_end)
+        mean += v[i];
     }
-    mean /= double(n);
+    if (h.comm.enabled() && sp > 0)
+      mean = h.allreduce_sum(mean); // (a replicated level sums over its own entries only)
+    mean /= n_global;
     for (auto &e : v)
       e -= mean;
     MFMG_HIP_CHECK(hipMemcpyAsync(rhs->get_values(), v.data(), n * sizeof(double), hipMemcpyHostToDevice, h.stream));
@@ -889,69 +914,25 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
       for (int d = 0; d < 3; ++d)
         local_grid.block[d] = blk;
     }
-    int64_t row_off = 0;
-    if (distributed)
-    {
-      // levels below this one are built on the OWNED block (owned rows x owned columns) and stay local to
-      // the rank; the first level itself is applied with halo exchange
-      HaloSpace const &cs = _handle.comm.spaces[op_space];
-      row_off = cs.owned_begin * cs.layer_elems;
-      const int64_t n_own = cs.owned_count * cs.layer_elems;
-      HostCsr Ao;
-      Ao.n_rows = Ao.n_cols = n_own;
-      Ao.row_ptr.assign(n_own + 1, 0);
-      for (int64_t r = 0; r < n_own; ++r)
-      {
-        for (int p = A0.row_ptr[row_off + r]; p < A0.row_ptr[row_off + r + 1]; ++p)
-        {
-          const int64_t cidx = A0.col[p] - row_off;
-          if (cidx >= 0 && cidx < n_own)
-          {
-            Ao.col.push_back((int32_t)cidx);
-            Ao.val.push_back(A0.val[p]);
-          }
-        }
-        Ao.row_ptr[r + 1] = (int32_t)Ao.col.size();
-      }
-      A0 = std::move(Ao);
-      b0 = std::vector<double>(b0.begin() + row_off, b0.begin() + row_off + n_own);
-      if (local_grid.valid(n))
-      {
-        AmgGridHint og = local_grid;
-        const int32_t node_off = (int32_t)(cs.owned_begin * (int64_t)local_grid.dims[0] * local_grid.dims[1]);
-        og.dims[2] = (int)cs.owned_count;
-        og.node_of_row.assign(local_grid.node_of_row.begin() + row_off, local_grid.node_of_row.begin() + row_off + n_own);
-        for (auto &v : og.node_of_row)
-          v -= node_off;
-        if (!local_grid.component_of_row.empty())
-          og.component_of_row.assign(local_grid.component_of_row.begin() + row_off,
-                                     local_grid.component_of_row.begin() + row_off + n_own);
-        local_grid = std::move(og);
-      }
-    }
-    auto host_levels = build_aggregation_hierarchy(std::move(A0), std::move(b0), opts,
-                                                   local_grid.valid(distributed ? _handle.comm.spaces[op_space].owned_count *
-                                                                                      _handle.comm.spaces[op_space].layer_elems
-                                                                                : n)
-                                                       ? &local_grid
-                                                       : nullptr);
-    if (distributed && host_levels.size() > 1)
-    {
-      // embed the first prolongator into the local numbering (ghost rows stay empty)
-      HostCsr &P = host_levels[0].P;
-      std::vector<int32_t> rp(n + 1, 0);
-      for (int64_t r = 0; r < P.n_rows; ++r)
-        rp[row_off + r + 1] = P.row_ptr[r + 1] - P.row_ptr[r];
-      for (int64_t r = 0; r < n; ++r)
-        rp[r + 1] += rp[r];
-      P.row_ptr.swap(rp);
-      P.n_rows = n;
-    }
     auto smoother_params = std::make_shared<ptree>();
     smoother_params->put("smoother.type", "Chebyshev");
     smoother_params->put("smoother.degree", this->_params->get("solver.amg.smoother_degree", 1));
     smoother_params->put("smoother.smoothing_range", this->_params->get("solver.amg.smoothing_range", 4.));
     smoother_params->put("smoother.eig_cg_n_iterations", this->_params->get("solver.amg.eig_cg_n_iterations", 10));
+    // setup "device": matrices of the hierarchy read off from operator applications on the device (probing), the
+    // levels coupled across the ranks of a distributed run; "host": SpGEMM on the host cores (one rank only)
+    std::string const setup = to_lower(this->_params->get("solver.amg.setup", distributed ? "device" : "host"));
+    ASSERT_THROW(setup == "device" || setup == "host", "solver.amg.setup must be device or host");
+    if (distributed || setup == "device")
+    {
+      ASSERT_THROW(setup == "device", "distributed runs build the aggregation hierarchy on the device (solver.amg.setup device)");
+      ASSERT_THROW(local_grid.valid(n) && opts.smooth_prolongator && local_grid.block[0] == 2,
+                   "the device setup of the aggregation hierarchy needs the agglomerate grid of the restrictor, a smoothed "
+                   "prolongator and aggregates of 2 x 2 x 2 nodes");
+      setup_amg_on_device(matrix, b0, local_grid, opts, smoother_params);
+      return;
+    }
+    auto host_levels = build_aggregation_hierarchy(std::move(A0), std::move(b0), opts, local_grid.valid(n) ? &local_grid : nullptr);
     _amg.resize(host_levels.size());
     for (size_t l = 0; l < host_levels.size(); ++l)
     {
@@ -964,7 +945,6 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
         _amg[l].prolongator = std::make_shared<HipMatrixOperator>(upload(_handle, std::move(host_levels[l].P)));
         _amg[l].restrictor = std::dynamic_pointer_cast<HipMatrixOperator>(_amg[l].prolongator->transpose());
         _amg[l].smoother = std::make_shared<HipSmoother>(_amg[l].a, smoother_params);
-        ASSERT_THROW(!distributed || l == 0 || _amg[l].a->domain_space() == 0, "internal: deeper levels are local");
       }
     }
     auto last = _amg.back().a->get_matrix();
@@ -997,7 +977,12 @@ void HipSolver::apply(DVector const &b, DVector &x) const
   ASSERT_THROW(b.size() == n && x.size() == n, "vector sizes do not match the coarse operator");
   if (_solver == "amg")
   {
-    if (_amg_cycles <= 1)
+    if (_amg_gather_level == 0)
+    {
+      ASSERT_THROW(_amg_cycles <= 1, "solver.amg.n_cycles > 1 is not available when the first level is gathered");
+      amg_cycle_gathered(0, b, x);
+    }
+    else if (_amg_cycles <= 1)
       amg_cycle(0, b, x);
     else
     {
@@ -1069,9 +1054,27 @@ void HipSolver::amg_cycle(size_t level, DVector const &b, DVector &x) const
   L.smoother->apply_zero_guess(b, *L.x_work); // zero initial guess by construction
   L.a->residual(*L.x_work, b, *L.res);
   L.restrictor->apply(*L.res, *L.b_coarse);
-  amg_cycle(level + 1, *L.b_coarse, *L.x_coarse);
+  if ((int)level + 1 == _amg_gather_level)
+    amg_cycle_gathered(level + 1, *L.b_coarse, *L.x_coarse);
+  else
+    amg_cycle(level + 1, *L.b_coarse, *L.x_coarse);
   L.prolongator->apply_subtract(*L.x_coarse, *L.x_work, OperatorMode::NO_TRANS);
   L.smoother->apply_to(b, *L.x_work, x);
+}
+
+void HipSolver::amg_cycle_gathered(size_t level, DVector const &b_local, DVector &x_local) const
+{
+  HaloSpace const &s = _handle.comm.spaces[_gather_space];
+  const int64_t n_own = s.owned_count * s.layer_elems;
+  ASSERT_THROW(b_local.size() == s.n_layers * s.layer_elems && x_local.size() == b_local.size(),
+               "vector sizes do not match the gathered level");
+  MFMG_HIP_CHECK(hipMemcpyAsync(_gather_in.data(), b_local.get_values() + s.owned_begin * s.layer_elems,
+                                (size_t)n_own * sizeof(double), hipMemcpyDeviceToDevice, _handle.stream));
+  _handle.comm.transport->allgather(_gather_in.data(), n_own, _gather_b->get_values(), _handle.stream);
+  amg_cycle(level, *_gather_b, *_gather_x);
+  // the local layers (ghost layers included) are a contiguous run of the global ones
+  MFMG_HIP_CHECK(hipMemcpyAsync(x_local.get_values(), _gather_x->get_values() + s.global_begin * s.layer_elems,
+                                (size_t)x_local.size() * sizeof(double), hipMemcpyDeviceToDevice, _handle.stream));
 }
 
 // ---- HipHierarchyHelpers ---------------------------------------------------------
@@ -1126,6 +1129,7 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
     // first coarse level: layers of agglomerates along z, `n_components` unknowns per agglomerate
     ASSERT_THROW(opts.agglomerate[2] == 2, "distributed runs need agglomeration.nz = 2");
     HaloSpace &cs = comm.spaces[2];
+    cs = HaloSpace();
     const int64_t per_layer = (int64_t)_grid_hint.dims[0] * _grid_hint.dims[1] * _grid_hint.n_components;
     ASSERT_THROW(R.n_rows == per_layer * _grid_hint.dims[2],
                  "distributed runs need the same number of eigenvectors on every agglomerate");
@@ -1135,6 +1139,10 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
     cs.has_high = comm.ghost_cells_high > 0;
     cs.owned_begin = comm.ghost_cells_low / 2;
     cs.owned_count = cs.n_layers - comm.ghost_cells_low / 2 - comm.ghost_cells_high / 2;
+    cs.width = 1;
+    cs.global_begin = (int64_t)comm.rank * cs.owned_count - cs.owned_begin;
+    cs.global_layers = (int64_t)comm.n_ranks * cs.owned_count;
+    comm.spaces.resize(3); // the spaces of the aggregation levels belong to the coarse solver built next
     // rows of the neighbours' agglomerates stay: the lower neighbour's top face is my first owned plane
     // (prolongation), and the Galerkin product of my boundary rows couples to both ghost layers
   }

@@ -126,13 +126,17 @@ public:
     _domain_space = domain;
     _range_space = range;
   }
+  // after y = M x (NO_TRANS): return the partial sums in the ghost layers of y to their owners (a transposed
+  // prolongator of a distributed level: its rows of ghost aggregates hold contributions of owned fine rows)
+  void set_reverse_range_space(int space) { _reverse_range_space = space; }
+  int reverse_range_space() const { return _reverse_range_space; }
   // agglomerate-wise evaluation of a restrictor and its transpose (structured_restrictor.hpp); the CSR copy
   // stays for the setup algebra and for get_restrictor
   void set_structured(std::shared_ptr<StructuredRestrictorDevice> s) { _structured = std::move(s); }
   bool has_structured() const { return _structured != nullptr; }
 
 private:
-  int _domain_space = 0, _range_space = 0;
+  int _domain_space = 0, _range_space = 0, _reverse_range_space = 0;
   std::shared_ptr<SparseMatrixDevice<double>> _matrix;
   mutable std::shared_ptr<SparseMatrixDevice<double>> _transposed_matrix; // built lazily (cuda_matrix_operator.cu:93-130)
   std::shared_ptr<StructuredRestrictorDevice> _structured;
@@ -267,9 +271,20 @@ public:
     mutable std::shared_ptr<DVector> res, b_coarse, x_coarse, x_work;
   };
   std::vector<AmgLevel> const &amg_levels() const { return _amg; }
+  // index of the first level that is gathered and solved redundantly on every rank (-1: one rank / none)
+  int amg_gather_level() const { return _amg_gather_level; }
 
 private:
   void amg_cycle(size_t level, DVector const &b, DVector &x) const;
+  // b, x in the local layout of the gathered level's space: all-gather of the owned parts, replicated cycle from
+  // `level` down, the local run of layers copied back (ghost layers included)
+  void amg_cycle_gathered(size_t level, DVector const &b_local, DVector &x_local) const;
+  // aggregation hierarchy by probing on the device, coupled across the ranks (amg_device_setup.hip)
+  void setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> matrix, std::vector<double> const &near_null,
+                           AmgGridHint const &grid, AmgOptions const &opts, std::shared_ptr<ptree> smoother_params);
+  void finish_amg_replicated(std::shared_ptr<HipMatrixOperator> a_op, HostCsr A, std::vector<double> B, int space,
+                             int64_t owned_begin, int64_t owned_count, int64_t global_begin, int64_t global_layers,
+                             int const dims[3], int n_comp, AmgOptions const &opts, std::shared_ptr<ptree> smoother_params);
   // Dense LU with partial pivoting, factored ONCE at setup (the reference re-factorises in every apply,
   // source/cuda/dealii_operator_device_helpers.cu:169-228).  Up to kTriangularInverseLimit rows the factors are
   // stored inverted as two dense triangular matrices and the solve is two SpMV launches over the whole chip
@@ -285,6 +300,10 @@ private:
   void setup_direct(std::shared_ptr<SparseMatrixDevice<double>> matrix, DenseLu &f) const;
   void solve_direct(DenseLu const &f, double const *b, double *x) const;
   std::vector<AmgLevel> _amg;
+  int _amg_gather_level = -1;
+  int _gather_space = 0;
+  mutable DeviceBuffer<double> _gather_in;
+  std::shared_ptr<DVector> _gather_b, _gather_x;
   int _amg_cycles = 1;
   DenseLu _amg_bottom;
 

@@ -61,6 +61,29 @@ __global__ void probing_vector_kernel(int nx, int ny, int nz, int n_eig, int kx,
   }
 }
 
+// out[r] = in[r] (or 1 when `in` is null) where row r = node * n_comp + comp lives on a node whose block
+// coordinates (node coordinates / block, the z coordinate taken globally: z_local + z_offset) are congruent to
+// `phase` modulo `period` and comp == comp0; 0 elsewhere.  Probing vectors of the aggregation-hierarchy setup.
+__global__ void select_rows_kernel(int nx, int ny, int nz, int n_comp, int block, int z_offset, int px, int py, int pz,
+                                   int ox, int oy, int oz, int comp0, double const *in, double *out)
+{
+  const int64_t n = (int64_t)nx * ny * nz * n_comp;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int c = (int)(r % n_comp);
+    const int64_t nd = r / n_comp;
+    const int i = (int)(nd % nx), j = (int)((nd / nx) % ny), k = (int)(nd / ((int64_t)nx * ny));
+    const bool hit = c == comp0 && (i / block) % px == ox && (j / block) % py == oy && ((k + z_offset) / block) % pz == oz;
+    out[r] = hit ? (in ? in[r] : 1.) : 0.;
+  }
+}
+
+__global__ void add_layers_kernel(int64_t n, double const *src, double *dst)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] += src[i];
+}
+
 __global__ void widen_kernel(int64_t n, float const *in, double *out)
 {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -205,6 +228,17 @@ void probing_vector(HipHandle &h, int const na[3], int n_eig, int const k[3], in
   MFMG_HIP_CHECK(hipGetLastError());
 }
 
+void select_rows(HipHandle &h, int const dims[3], int n_comp, int block, int z_offset, int const period[3], int const phase[3],
+                 int comp, double const *in, double *out)
+{
+  const int64_t n = (int64_t)dims[0] * dims[1] * dims[2] * n_comp;
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(select_rows_kernel, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, dims[0], dims[1], dims[2], n_comp,
+                     block, z_offset, period[0], period[1], period[2], phase[0], phase[1], phase[2], comp, in, out);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
 void widen(HipHandle &h, int64_t n, float const *in, double *out)
 {
   if (n <= 0)
@@ -282,4 +316,12 @@ void cg_direction(HipHandle &h, int64_t n, T const *z, T *p, double const *scal,
 MFMG_INSTANTIATE_VEC(double)
 MFMG_INSTANTIATE_VEC(float)
 } // namespace vec
+
+void halo_add_layers(double *dst, double const *src, int64_t n, hipStream_t stream)
+{
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(vec::add_layers_kernel, dim3(n_blocks_for(n, block_size, 4096)), dim3(block_size), 0, stream, n, src, dst);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
 } // namespace mfmg

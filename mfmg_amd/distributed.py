@@ -5,9 +5,9 @@ The reference partitions the mesh with p4est and exchanges ghost DoFs inside dea
 vector in front of every SpMV (source/cuda/utils.cu:363-482).  Here every rank owns a slab of cell
 layers; its local mesh is that slab plus one agglomerate (2 cell layers) of each neighbour, numbered
 lexicographically, so that ghost planes are contiguous and a halo exchange is two sends and two
-receives of one layer -- RCCL point-to-point over xGMI through torch.distributed ("nccl"), issued on
-the library's stream.  With the "gloo" backend (CPU tests, several ranks sharing one GPU) the layers
-are staged through the host."""
+receives of a few layers -- RCCL point-to-point over xGMI, issued by the library itself on its HIP stream
+(include/mfmg_hip.h: mfmg_hip_context_use_rccl).  In the tests (several ranks sharing one GPU) the library
+stages the layers through the host and torch.distributed / gloo carries them."""
 from __future__ import annotations
 
 import ctypes as C
@@ -74,100 +74,94 @@ class SlabPartition:
         return xg[lo: lo + self.n_local_planes * self.plane].clone()
 
 
-_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
-_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+_SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64,
+                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
+_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double))
+
+
+def _host_tensor(ptr, n):
+    """torch view (no copy) of n doubles of host memory owned by the library."""
+    import numpy as np
+    return torch.from_numpy(np.ctypeslib.as_array(ptr, shape=(int(n),)))
 
 
 class HaloTransport:
-    """Registers the communicator of a Context: staging buffers + exchange / all-reduce callbacks."""
+    """Registers the communicator of a Context and its transport.
 
-    def __init__(self, ctx, part: SlabPartition, n_eigenvectors: int, group=None):
+    transport "rccl": the library exchanges the boundary layers itself with ncclSend / ncclRecv on its HIP stream
+    (one process per GPU; this object only carries the 128-byte RCCL id from rank 0 to the other ranks through
+    torch.distributed).  transport "host": the library stages the layers through pinned host memory and calls back
+    into torch.distributed on a gloo group (tests: several ranks on one card).  Default: "rccl" when the default
+    process group is nccl, else "host"."""
+
+    def __init__(self, ctx, part: SlabPartition, n_eigenvectors: int = 2, group=None, transport: str | None = None):
         self._lib = _lib.load()
         self.ctx, self.part, self.group = ctx, part, group
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
         self.rank, self.n_ranks = part.rank, part.n_ranks
-        coarse_layer = (part.cells[0] // 2) * (part.cells[1] // 2) * n_eigenvectors
-        self.sizes = {1: part.plane, 2: coarse_layer}
-        self.bufs = {}
-        for space, n in self.sizes.items():
-            b = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(4)]  # send_low/high, recv_low/high
-            self.bufs[space] = b
-        self._host = {s: [t.cpu().pin_memory() for t in b] for s, b in self.bufs.items()} if self.backend != "nccl" else None
-        self._ops, self._streams = {}, {}
-        self._exchange_cb = _EXCHANGE_FN(self._exchange)
-        self._allreduce_cb = _ALLREDUCE_FN(self._allreduce)
-        check(self._lib.mfmg_hip_context_set_communicator(
-            ctx.handle, self.rank, self.n_ranks, part.ghost_low, part.ghost_high,
-            C.cast(self._exchange_cb, C.c_void_p), C.cast(self._allreduce_cb, C.c_void_p), None))
-        for space, b in self.bufs.items():
-            check(self._lib.mfmg_hip_context_set_halo_buffers(ctx.handle, space, self.sizes[space],
-                                                              b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(),
-                                                              b[3].data_ptr()))
-        ctx._transport = self  # keep the callbacks alive as long as the context
-        if self.backend == "nccl":
-            # RCCL builds its communicators at the first collective: do it here, with every rank present
-            warm = torch.zeros(1, dtype=torch.float64, device="cuda")
-            dist.all_reduce(warm, group=group)
-            torch.cuda.synchronize()
-
-    # -- callbacks (invoked from inside the library, on the calling Python thread) ------------------
-    def _exchange(self, user, space, stream_ptr):
-        try:
-            send_low, send_high, recv_low, recv_high = self.bufs[space]
-            lo, hi = self.rank - 1, self.rank + 1
+        if transport is None:
+            transport = "rccl" if self.backend == "nccl" else "host"
+        assert transport in ("rccl", "host")
+        self.transport = transport
+        check(self._lib.mfmg_hip_context_set_communicator(ctx.handle, self.rank, self.n_ranks, part.ghost_low,
+                                                          part.ghost_high))
+        if transport == "rccl":
+            uid = (C.c_ubyte * 128)()
+            if self.rank == 0:
+                check(self._lib.mfmg_hip_rccl_unique_id(uid))
+            t = torch.tensor(list(uid), dtype=torch.uint8)
             if self.backend == "nccl":
-                stream = self._streams.get(stream_ptr)
-                if stream is None:
-                    stream = torch.cuda.ExternalStream(stream_ptr) if stream_ptr else torch.cuda.default_stream()
-                    self._streams[stream_ptr] = stream
-                ops = self._ops.get(space)
-                if ops is None:      # the staging buffers never move: build the operation list once
-                    ops = []
-                    if lo >= 0:
-                        ops += [dist.P2POp(dist.isend, send_low, lo, self.group), dist.P2POp(dist.irecv, recv_low, lo, self.group)]
-                    if hi < self.n_ranks:
-                        ops += [dist.P2POp(dist.isend, send_high, hi, self.group), dist.P2POp(dist.irecv, recv_high, hi, self.group)]
-                    self._ops[space] = ops
-                if ops:
-                    with torch.cuda.stream(stream):
-                        for req in dist.batch_isend_irecv(ops):
-                            req.wait()      # orders the library's stream behind the transfers (no host wait)
-            else:
-                # gloo: stage through the host
-                self.ctx.synchronize()
-                h = self._host[space]
-                ops = []
-                if lo >= 0:
-                    h[0].copy_(send_low)
-                    ops += [dist.P2POp(dist.isend, h[0], lo, self.group), dist.P2POp(dist.irecv, h[2], lo, self.group)]
-                if hi < self.n_ranks:
-                    h[1].copy_(send_high)
-                    ops += [dist.P2POp(dist.isend, h[1], hi, self.group), dist.P2POp(dist.irecv, h[3], hi, self.group)]
-                if ops:
-                    for req in dist.batch_isend_irecv(ops):
-                        req.wait()
-                if lo >= 0:
-                    recv_low.copy_(h[2])
-                if hi < self.n_ranks:
-                    recv_high.copy_(h[3])
-                torch.cuda.synchronize()
+                t = t.cuda()
+            dist.broadcast(t, src=0, group=group)
+            uid = (C.c_ubyte * 128)(*[int(v) for v in t.cpu().tolist()])
+            check(self._lib.mfmg_hip_context_use_rccl(ctx.handle, uid))
+            self._host_group = None
+        else:
+            # CPU tensors travel over gloo (a second group when the default one is nccl)
+            self._host_group = group if self.backend == "gloo" else dist.new_group(backend="gloo")
+            self._sendrecv_cb = _SENDRECV_FN(self._sendrecv)
+            self._allreduce_cb = _ALLREDUCE_FN(self._allreduce)
+            self._allgather_cb = _ALLGATHER_FN(self._allgather)
+            check(self._lib.mfmg_hip_context_use_host_transport(
+                ctx.handle, C.cast(self._sendrecv_cb, C.c_void_p), C.cast(self._allreduce_cb, C.c_void_p),
+                C.cast(self._allgather_cb, C.c_void_p), None))
+        ctx._transport = self  # keep the callbacks alive as long as the context
+
+    # -- callbacks of the host transport (invoked from inside the library, on the calling Python thread) --------
+    def _sendrecv(self, user, send_low, recv_low, n_low, send_high, recv_high, n_high):
+        try:
+            ops = []
+            if n_low > 0:
+                ops += [dist.P2POp(dist.isend, _host_tensor(send_low, n_low), self.rank - 1, self._host_group),
+                        dist.P2POp(dist.irecv, _host_tensor(recv_low, n_low), self.rank - 1, self._host_group)]
+            if n_high > 0:
+                ops += [dist.P2POp(dist.isend, _host_tensor(send_high, n_high), self.rank + 1, self._host_group),
+                        dist.P2POp(dist.irecv, _host_tensor(recv_high, n_high), self.rank + 1, self._host_group)]
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
             return 0
         except Exception as e:  # noqa: BLE001 - must not propagate through the C frame
             print(f"[mfmg_amd] halo exchange failed on rank {self.rank}: {e!r}", flush=True)
             return 1
 
-    def _allreduce(self, user, values, n):
+    def _allreduce(self, user, values, n, op):
         try:
-            t = torch.tensor([values[i] for i in range(n)], dtype=torch.float64)
-            if self.backend == "nccl":
-                t = t.cuda()
-            dist.all_reduce(t, group=self.group)
-            t = t.cpu()
-            for i in range(n):
-                values[i] = float(t[i])
+            t = _host_tensor(values, n)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM, group=self._host_group)
             return 0
         except Exception as e:  # noqa: BLE001
             print(f"[mfmg_amd] all-reduce failed on rank {self.rank}: {e!r}", flush=True)
+            return 1
+
+    def _allgather(self, user, src, n, out):
+        try:
+            o = _host_tensor(out, n * self.n_ranks)
+            dist.all_gather_into_tensor(o, _host_tensor(src, n).clone(), group=self._host_group)
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print(f"[mfmg_amd] all-gather failed on rank {self.rank}: {e!r}", flush=True)
             return 1
 
     # -- helpers for drivers -----------------------------------------------------------------------
@@ -176,14 +170,30 @@ class HaloTransport:
         check(self._lib.mfmg_hip_context_halo_layout(self.ctx.handle, space, *[C.byref(x) for x in v]))
         return tuple(x.value for x in v)
 
-    def owned_dot(self, x: torch.Tensor, y: torch.Tensor) -> float:
-        sl = self.part.owned_slice()
-        local = self.ctx.dot(x[sl], y[sl])
-        t = torch.tensor([local], dtype=torch.float64)
-        if self.backend == "nccl":
-            t = t.cuda()
-        dist.all_reduce(t, group=self.group)
-        return float(t.item())
+    def space(self, space: int) -> dict:
+        out = (C.c_int64 * 8)()
+        check(self._lib.mfmg_hip_context_halo_space(self.ctx.handle, space, out))
+        keys = ("layer_elems", "n_layers", "owned_begin", "owned_count", "global_begin", "global_layers", "width", "n_spaces")
+        return dict(zip(keys, [int(v) for v in out]))
 
-    def owned_norm(self, x: torch.Tensor) -> float:
-        return self.owned_dot(x, x) ** 0.5
+    def exchange(self, space: int, v: torch.Tensor, reverse: bool = False):
+        """One halo exchange of a vector of `space` (the cycle does this by itself; for tests)."""
+        check(self._lib.mfmg_hip_context_exchange(self.ctx.handle, space, v.data_ptr(), 1 if reverse else 0))
+
+    def n_exchanges(self) -> int:
+        n = C.c_int64()
+        check(self._lib.mfmg_hip_context_exchange_count(self.ctx.handle, C.byref(n)))
+        return n.value
+
+    def name(self) -> str:
+        buf = C.create_string_buffer(32)
+        check(self._lib.mfmg_hip_context_transport_name(self.ctx.handle, buf, 32))
+        return buf.value.decode()
+
+    def owned_dot(self, x: torch.Tensor, y: torch.Tensor, space: int = 1) -> float:
+        r = C.c_double()
+        check(self._lib.mfmg_hip_context_owned_dot(self.ctx.handle, space, x.data_ptr(), y.data_ptr(), C.byref(r)))
+        return r.value
+
+    def owned_norm(self, x: torch.Tensor, space: int = 1) -> float:
+        return self.owned_dot(x, x, space) ** 0.5

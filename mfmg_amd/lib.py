@@ -82,8 +82,15 @@ def load() -> C.CDLL:
         "mfmg_hip_context_destroy": (C.c_int, [vp]),
         "mfmg_hip_context_synchronize": (C.c_int, [vp]),
         "mfmg_hip_context_stream": (vp, [vp]),
-        "mfmg_hip_context_set_communicator": (C.c_int, [vp, i32, i32, i32, i32, vp, vp, vp]),
-        "mfmg_hip_context_set_halo_buffers": (C.c_int, [vp, i32, i64, vp, vp, vp, vp]),
+        "mfmg_hip_context_set_communicator": (C.c_int, [vp, i32, i32, i32, i32]),
+        "mfmg_hip_rccl_unique_id": (C.c_int, [vp]),
+        "mfmg_hip_context_use_rccl": (C.c_int, [vp, vp]),
+        "mfmg_hip_context_use_host_transport": (C.c_int, [vp, vp, vp, vp, vp]),
+        "mfmg_hip_context_transport_name": (C.c_int, [vp, C.c_char_p, sz]),
+        "mfmg_hip_context_exchange_count": (C.c_int, [vp, P(i64)]),
+        "mfmg_hip_context_exchange": (C.c_int, [vp, i32, vp, C.c_int]),
+        "mfmg_hip_context_owned_dot": (C.c_int, [vp, i32, vp, vp, P(dbl)]),
+        "mfmg_hip_context_halo_space": (C.c_int, [vp, i32, vp]),
         "mfmg_hip_context_set_overlap_exchange": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_context_set_cell_constant_layout": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_context_set_galerkin_on_device": (C.c_int, [vp, C.c_int]),

@@ -4,8 +4,9 @@
                local extended slab and applies them with the oracle's numpy kernels + a gloo halo exchange;
                the owned parts must reproduce the global operators (partition correct by construction).
   --mode gpu : the library path on cuda:0 (all ranks share the GPU, layers staged through the host): fine
-               operator / smoother / residual / restriction / prolongation / coarse operator against the
-               single-process global hierarchy, then V-cycles must contract."""
+               operator / smoother / residual / restriction / prolongation / coarse operator / coarse solve against
+               the single-process global hierarchy, then the 20-cycle residual history of the distributed V-cycle
+               against the single-process cycle AND against the oracle's restatement of it, to 1e-10 relative."""
 import argparse
 import os
 import sys
@@ -113,29 +114,41 @@ def mode_cpu(args):
         print("cpu distributed checks passed", flush=True)
 
 
+MESHES = {
+    # name: (cells per rank along z, (cx, cy), material, amg parameters)
+    # small: A_c (768 rows at 2 ranks) is gathered right away: replicated hierarchy behind one all-gather
+    "small": (8, (16, 12), "linear", {"coarsest_size": 300}),
+    # wide: 67 node columns and 65 node rows with a constant material: the operator runs its one-coefficient-per-cell
+    # variant with the tail columns as a rotated slab, split into z-tile ranges by the overlapped exchange
+    "wide": (8, (66, 64), "constant", {"coarsest_size": 300}),
+    # deep: two aggregation levels stay distributed (stencil reach 1 and 2, probing with 16 / 250 and 54 / 686
+    # vectors, reverse exchanges two and three layers wide), the third is gathered
+    "deep": (24, (16, 16), "linear", {"coarsest_size": 40, "replicate_rows": 40}),
+}
+
+
 def mode_gpu(args):
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
-    # "wide": 67 node columns = 63 + 4 and 65 node rows with a constant material: the operator runs its
-    # one-coefficient-per-cell variant with the tail columns as a rotated slab, here split into z-tile ranges
-    wide = getattr(args, "mesh", "small") == "wide"
-    cells = (66, 64, 8 * world) if wide else (16, 12, 8 * world)
-    material = "constant" if wide else "linear"
+    per, (cx, cy), material, amg = MESHES[args.mesh]
+    cells = (cx, cy, per * world)
     part = M.SlabPartition(cells, rank, world, length=tuple(c / float(cells[0]) for c in cells))   # cubic cells
     params = dict(PRM)
     params.update({"smoother": {"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0},
-                   "solver": {"type": "amg", "amg": {"coarsest_size": 300}}, "is preconditioner": False})
+                   "solver": {"type": "amg", "amg": dict(amg)}, "is preconditioner": False})
     ctx = M.Context()
     tr = M.HaloTransport(ctx, part, 2)
+    assert tr.name() == "host"
     h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", part.local_problem(material, "cuda"), params)
     deg, lmin, lmax = h.smoother_info()       # estimated with dot products summed over the ranks
     assert 1.4 < lmax < 2.2, lmax
-    # global single-process reference on the same GPU (rank-local context without communicator), same polynomial
+    # global single-process reference on the same GPU (context without communicator): the SAME parameters -- the
+    # distributed hierarchy must be the same preconditioner, eigenvalue estimates included
     gctx = M.Context()
     gprob = M.LaplaceProblem(cells, material, device="cuda", cell_size=part.h)
-    gparams = dict(params)
-    gparams["smoother"] = {"type": "Chebyshev", "degree": 3, "lambda_max": lmax, "lambda_min": lmin}
-    hg = M.Hierarchy(gctx, "HipMatrixFreeMeshEvaluator", gprob, gparams)
+    hg = M.Hierarchy(gctx, "HipMatrixFreeMeshEvaluator", gprob, params)
+    _, glmin, glmax = hg.smoother_info()
+    assert abs(glmax - lmax) < 1e-9 * lmax and abs(glmin - lmin) < 1e-9 * lmax, (lmin, lmax, glmin, glmax)
     ng, nl = gprob.n_dofs, part.plane * part.n_local_planes
     rng = np.random.default_rng(0)
     xg, bg = rng.random(ng), rng.random(ng)
@@ -159,7 +172,7 @@ def mode_gpu(args):
     # smoother (3 fused steps, 3 exchanges)
     xl = dev(local(xg)); xs = dev(xg)
     h.smoother_apply(0, dev(local(bg, False)), xl); hg.smoother_apply(0, dev(bg), xs)
-    check(xl, xs, "smoother")
+    check(xl, xs, "smoother", 1e-11)
     # the same two with the exchange NOT overlapped with the interior tiles: identical bits
     ctx.set_overlap_exchange(False)
     yl2 = torch.zeros(nl, dtype=torch.float64, device="cuda")
@@ -171,6 +184,8 @@ def mode_gpu(args):
     ctx.set_overlap_exchange(True)
     # restriction / prolongation / coarse operator
     lay, nlay, cb, cc = tr.layout(2)
+    sp = tr.space(2)
+    assert sp["global_begin"] == part.z0 // 2 - cb and sp["global_layers"] == cells[2] // 2
     ncl, ncg = lay * nlay, hg.level_size(1)
     assert h.level_size(1) == ncl
     c_glob0 = (part.z0 // 2 - cb) * lay
@@ -192,19 +207,56 @@ def mode_gpu(args):
     al = torch.zeros(ncl, dtype=torch.float64, device="cuda"); ag = torch.empty(ncg, dtype=torch.float64, device="cuda")
     h.operator_apply(1, dev(xcl), al); hg.operator_apply(1, dev(xcg), ag)
     np.testing.assert_allclose(gather_c(al), ag.cpu().numpy(), rtol=1e-11, atol=1e-13)
-    # V-cycles contract (the levels below the first coarse level are rank-local in a distributed run)
-    con = (part.local_problem(material).constrained == 1).numpy()
-    x = dev(np.where(con, 0.0, local(xg, False)))
-    b = torch.zeros(nl, dtype=torch.float64, device="cuda")
+    # reverse (adding) exchange: every ghost entry returns to its owner exactly once
+    ones = torch.ones(ncl, dtype=torch.float64, device="cuda")
+    tr.exchange(2, ones, reverse=True)
+    expect = np.ones(ncl)
+    if rank > 0:
+        expect[cb * lay:(cb + 1) * lay] += 1.0
+    if rank + 1 < world:
+        expect[(cb + cc - 1) * lay:(cb + cc) * lay] += 1.0
+    np.testing.assert_array_equal(ones.cpu().numpy()[cb * lay:(cb + cc) * lay], expect[cb * lay:(cb + cc) * lay])
+    # the coarse solve: the aggregation hierarchy coupled across the ranks against the single-process one
+    bcg = rng.random(ncg)
+    bcl = bcg[c_glob0: c_glob0 + ncl].copy()
+    scl = torch.zeros(ncl, dtype=torch.float64, device="cuda"); scg = torch.empty(ncg, dtype=torch.float64, device="cuda")
+    h.coarse_apply(dev(bcl), scl); hg.coarse_apply(dev(bcg), scg)
+    np.testing.assert_allclose(gather_c(scl), scg.cpu().numpy(), rtol=1e-9, atol=1e-11 * np.abs(scg.cpu().numpy()).max())
+    # ---- V-cycles: 20-cycle residual history of the distributed cycle == the single-process cycle == the oracle's
+    con_g = (gprob.constrained == 1).cpu().numpy()
+    x0g = np.where(con_g, 0.0, xg)
+    b0 = torch.zeros(nl, dtype=torch.float64, device="cuda")
+    x = dev(local(x0g, False))
     r = torch.empty_like(x)
-    norms = []
-    for _ in range(6):
+    n_cycles = 20
+    hist = []
+    for _ in range(n_cycles + 1):
         h.operator_apply(0, x, r)
-        norms.append(tr.owned_norm(r))
-        h.apply(b, x)
-    assert all(norms[i + 1] < 0.7 * norms[i] for i in range(5)), norms
+        hist.append(tr.owned_norm(r))
+        h.apply(b0, x)
+    xs = dev(x0g); bs = torch.zeros(ng, dtype=torch.float64, device="cuda"); rs = torch.empty_like(xs)
+    hist_g = []
+    for _ in range(n_cycles + 1):
+        hg.operator_apply(0, xs, rs)
+        hist_g.append(gctx.l2_norm(rs))
+        hg.apply(bs, xs)
+    hist, hist_g = np.array(hist), np.array(hist_g)
+    floor = 1e-12 * hist_g[0]          # where b - A x sits on FP64 rounding
+    np.testing.assert_allclose(hist, hist_g, rtol=1e-10, atol=floor)
+    # the oracle's restatement of the cycle (numpy / scipy), built from the single-process level matrices
+    mesh = O.StructuredMesh(cells)
+    mesh.h = part.h
+    mf = O.MatrixFreeLaplace(mesh, gprob.coefficient.cpu().numpy())
+    p = O.ChebyshevParams(deg, glmax, glmin)
+    smoother = lambda b, xx: O.chebyshev_smoother_apply(mf.vmult, mf.diagonal_inverse(), p, b, xx)
+    ho = O.TwoLevelHierarchy(mf.vmult, smoother, hg.restrictor().to_scipy(), O.amg_coarse_solver(hg.coarse_amg_levels(), 1), 1, False)
+    res_o, rate, _ = O.vcycle_history(ho, mf.vmult, np.zeros(ng), x0g, n_cycles=n_cycles)
+    res_o = np.array(res_o)
+    np.testing.assert_allclose(hist / hist[0], res_o[:n_cycles + 1] / res_o[0], rtol=1e-9, atol=1e-12)
+    assert rate < 0.6
     if rank == 0:
-        print("gpu distributed checks passed; residuals", ["%.3e" % v for v in norms], flush=True)
+        print("gpu distributed checks passed; transport", tr.name(), "exchanges", tr.n_exchanges(), "spaces", tr.space(1)["n_spaces"],
+              "residuals", ["%.3e" % v for v in hist[:6]], flush=True)
 
 
 if __name__ == "__main__":
