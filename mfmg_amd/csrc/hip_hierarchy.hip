@@ -1046,8 +1046,9 @@ void HipSolver::amg_cycle(size_t level, DVector const &b, DVector &x) const
   if (!L.res)
   {
     L.res = L.a->build_range_vector();
-    L.b_coarse = _amg[level + 1].a->build_range_vector();
-    L.x_coarse = _amg[level + 1].a->build_range_vector();
+    // (the coarse vectors have the local layout of the restrictor's rows; a gathered next level has global ones)
+    L.b_coarse = L.restrictor->build_range_vector();
+    L.x_coarse = L.restrictor->build_range_vector();
     L.x_work = L.a->build_range_vector();
   }
   // the iterate lives in x_work until the post-smoother writes its result into x
