@@ -50,6 +50,11 @@ def parse_args():
     ap.add_argument("--amg-block", type=int, default=2, help="nodes per direction of one aggregate of the coarse AMG")
     ap.add_argument("--amg-deep", type=str, default="", help="level,block: bigger geometric aggregates from that AMG level on")
     ap.add_argument("--amg-degree", type=int, default=1, help="Chebyshev degree of the coarse AMG smoothers")
+    ap.add_argument("--amg-replicate-rows", type=int, default=0,
+                    help="distributed runs: aggregation levels with at most this many global rows are gathered and solved "
+                         "redundantly on every rank (0: the library's default, 200000)")
+    ap.add_argument("--amg-setup", default="", choices=["", "device", "host"],
+                    help="aggregation hierarchy by probing on the device or by host SpGEMM (default: the library's choice)")
     ap.add_argument("--evaluator", default="matrix_free", choices=["matrix_free", "assembled"],
                     help="fine-level operator: matrix-free (BASELINE configs[1]/[3]) or assembled CSR (configs[2])")
     ap.add_argument("--no-extras", action="store_true",
@@ -347,8 +352,14 @@ def main():
         if world & (world - 1):
             raise SystemExit("--gpus must be a power of two")
         part = M.SlabPartition((gx, gy, gz), rank, world, length=(gx / args.cells, gy / args.cells, gz / args.cells))
-        transport = M.HaloTransport(ctx, part, 2)
+        if backend != "nccl":
+            os.environ.setdefault("MFMG_BENCH_TRANSPORT", "host")
+        transport = M.HaloTransport(ctx, part, 2, transport=os.environ.get("MFMG_BENCH_TRANSPORT") or None)
         prob = part.local_problem(args.material, device="cuda")
+    elif args.box:
+        # one rank on the global box of a distributed run (rehearsals: the distributed cycle must contract identically)
+        prob = M.LaplaceProblem((gx, gy, gz), args.material, device="cuda",
+                                cell_size=(1.0 / args.cells,) * 3)
     else:
         prob = M.LaplaceProblem((args.cells,) * 3, args.material, device="cuda")
     params = {
@@ -358,6 +369,8 @@ def main():
         "solver": ({"type": "pcg", "n_iterations": args.coarse_iters} if args.coarse == "pcg" else
                    {"type": "amg", "amg": {"smoother_degree": args.amg_degree, "smoothing_range": 4.0, "n_cycles": 1,
                                            "aggregate_block": args.amg_block,
+                                           **({"setup": args.amg_setup} if args.amg_setup else {}),
+                                           **({"replicate_rows": args.amg_replicate_rows} if args.amg_replicate_rows else {}),
                                            **({"deep_level": int(args.amg_deep.split(",")[0]),
                                                "deep_block": int(args.amg_deep.split(",")[1])} if args.amg_deep else {})}}),
         "is preconditioner": False,
@@ -376,8 +389,13 @@ def main():
     n_fine = n_local if part is None else part.plane * part.owned_plane_count
     n_global = n_fine if part is None else part.n_global_dofs
 
-    g = torch.Generator(device="cuda").manual_seed(1 + rank)
-    x = torch.rand(n_local, dtype=torch.float64, device="cuda", generator=g)
+    # the same global start vector whatever the number of ranks (a rank cuts its slab out of it)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    if part is None:
+        x = torch.rand(n_local, dtype=torch.float64, device="cuda", generator=g)
+    else:
+        x = part.local_from_global(torch.rand(part.n_global_dofs, dtype=torch.float64, device="cuda", generator=g))
+        torch.cuda.empty_cache()
     x *= (prob.constrained != 1).to(torch.float64)
     b = torch.zeros(n_local, dtype=torch.float64, device="cuda")
 
@@ -413,6 +431,7 @@ def main():
     # cycle has ~45 launches; the other kernel family is timed in a separate pass after the timed region
     dominant = "csr_spmv_kernel" if assembled else "mf_laplace_kernel"
     ctx.profile_enable(True, only=dominant)
+    n_ex0 = transport.n_exchanges() if transport is not None else 0
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -421,6 +440,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    n_exchanges_per_cycle = ((transport.n_exchanges() - n_ex0) / max(args.steps, 1)) if transport is not None else 0.0
     res_end = residual_norm()
     contraction = (res_end / res_start) ** (1.0 / max(args.warmup + args.steps, 1)) if res_start > 0 else 0.0
     del op_monitor, r
@@ -477,8 +497,11 @@ def main():
                 "coarse_amg_levels_rows_nnzA_nnzP": (h.coarse_amg_shapes() if args.coarse == "amg" else None),
                 "smoother": {"type": "Chebyshev", "degree": degree, "lambda_min": lmin, "lambda_max": lmax},
                 "parallelism": "1 GPU" if world == 1 else
-                               f"{world} GPUs, z-slab domain decomposition of a {gx}x{gy}x{gz}-cell box, halo "
-                               f"exchange per operator application on every level of the cycle",
+                               f"{world} GPUs, z-slab domain decomposition of a {gx}x{gy}x{gz}-cell box, halo exchange "
+                               f"per operator application on every level of the cycle (transport: {transport.name()}, "
+                               f"{n_exchanges_per_cycle:.1f} point-to-point exchanges per cycle), aggregation levels coupled "
+                               f"across the ranks, levels below {h.coarse_amg_gather_rows()} rows gathered and solved "
+                               f"redundantly: the same preconditioner as on one GPU",
                 "global_dofs": n_global,
                 "setup_seconds": t_setup,
                 "mean_residual_contraction_per_cycle": contraction,

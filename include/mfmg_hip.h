@@ -92,6 +92,9 @@ int mfmg_hip_context_use_host_transport(mfmg_hip_context_t ctx, mfmg_hip_host_se
                                         mfmg_hip_host_allreduce_fn allreduce, mfmg_hip_host_allgather_fn allgather, void *user);
 /* "rccl", "host" or "" (none) */
 int mfmg_hip_context_transport_name(mfmg_hip_context_t ctx, char *buffer, size_t buffer_size);
+/* exercises the registered transport: `n` doubles sent to this rank itself and back, an all-gather and sum / max
+ * all-reduces over all ranks; returns the largest deviation from the known answers (0 when everything arrived) */
+int mfmg_hip_context_transport_selftest(mfmg_hip_context_t ctx, int64_t n, double *max_error);
 /* point-to-point exchanges issued through the context so far (diagnostics) */
 int mfmg_hip_context_exchange_count(mfmg_hip_context_t ctx, int64_t *n_exchanges);
 /* one halo exchange of a device vector of `space` (1 fine DoFs, 2 first coarse level, 3.. aggregation levels):
@@ -289,6 +292,9 @@ int mfmg_hip_hierarchy_get_coarse_operator(mfmg_hip_hierarchy_t h, mfmg_hip_csr_
  * its transpose as stored for the restriction (which = 0 / 1 / 2; a borrowed handle, valid until the next call) and the
  * Chebyshev bounds of its smoother */
 int mfmg_hip_hierarchy_coarse_amg_levels(mfmg_hip_hierarchy_t h, int32_t *n_levels);
+/* distributed runs: index of the first level of the multilevel coarse solver that is gathered and solved redundantly on
+ * every rank (-1: one rank); the levels before it are coupled across the ranks by halo exchanges */
+int mfmg_hip_hierarchy_coarse_amg_gather_level(mfmg_hip_hierarchy_t h, int32_t *level);
 int mfmg_hip_hierarchy_coarse_amg_get(mfmg_hip_hierarchy_t h, int32_t level, int32_t which, mfmg_hip_csr_t *borrowed);
 int mfmg_hip_hierarchy_coarse_amg_smoother(mfmg_hip_hierarchy_t h, int32_t level, int32_t *degree, double *lambda_min,
                                            double *lambda_max);

@@ -458,6 +458,17 @@ class Hierarchy:
                 out.append((l, which, m.shape[0], m.get_kernel()[1]) + tuple(m.stencil_classes()))
         return out
 
+    def coarse_amg_gather_level(self) -> int:
+        """Index of the first aggregation level that is gathered and solved redundantly on every rank (-1: one rank)."""
+        n = C.c_int32()
+        check(self._lib.mfmg_hip_hierarchy_coarse_amg_gather_level(self.handle, C.byref(n)))
+        return n.value
+
+    def coarse_amg_gather_rows(self) -> int:
+        """Global rows of that level (0 on one rank)."""
+        l = self.coarse_amg_gather_level()
+        return self.coarse_amg_shapes()[l][0] if l >= 0 else 0
+
     def coarse_amg_shapes(self):
         """[(rows, nnz(A_l), nnz(P_l) or 0)] of the multilevel coarse solver (no download)."""
         n = C.c_int32()

@@ -181,6 +181,7 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     // ---- diagonal, rho = max_i sum_j |a_ij| / |a_ii| over the owned rows of all ranks
     std::vector<double> dinv((size_t)n_f, 0.);
     double rho = 0.;
+#pragma omp parallel for schedule(static) reduction(max : rho)
     for (int64_t i = row0; i < row0 + n_own; ++i)
     {
       double d = 0., sum = 0.;
@@ -190,10 +191,10 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
         if (A.col[p] == i)
           d = A.val[p];
       }
-      ASSERT_THROW(d != 0., "zero diagonal in the multilevel coarse solver setup");
-      dinv[i] = 1. / d;
-      rho = std::max(rho, sum / std::abs(d));
+      dinv[i] = d != 0. ? 1. / d : 0.;
+      rho = std::max(rho, d != 0. ? sum / std::abs(d) : HUGE_VAL);
     }
+    ASSERT_THROW(rho < HUGE_VAL, "zero diagonal in the multilevel coarse solver setup");
     rho = h.allreduce_max(rho);
     const double w = opts.omega / rho;
 

@@ -1,5 +1,6 @@
 // extern "C" boundary of libmfmg_hip.so (include/mfmg_hip.h): exceptions of the C++
 // mirror are mapped to status codes; messages are kept per thread.
+#include <cmath>
 #include <cstring>
 #include <exception>
 #include <string>
@@ -191,6 +192,38 @@ int mfmg_hip_context_transport_name(mfmg_hip_context_t ctx, char *buffer, size_t
     require(ctx != nullptr && buffer != nullptr && buffer_size > 0, "null argument");
     std::string name = ctx->handle->comm.transport ? ctx->handle->comm.transport->name() : "";
     std::snprintf(buffer, buffer_size, "%s", name.c_str());
+  });
+}
+
+int mfmg_hip_context_transport_selftest(mfmg_hip_context_t ctx, int64_t n, double *max_error)
+{
+  return guarded([&] {
+    require(ctx != nullptr && max_error != nullptr && n > 0, "bad argument");
+    HipHandle &h = *ctx->handle;
+    require(h.comm.transport != nullptr, "no transport registered");
+    const int nr = h.comm.n_ranks, rk = h.comm.rank;
+    std::vector<double> host((size_t)n);
+    for (int64_t i = 0; i < n; ++i)
+      host[i] = 1000. * rk + double(i % 977);
+    DeviceBuffer<double> a((size_t)n), b((size_t)n), g((size_t)n * nr);
+    MFMG_HIP_CHECK(hipMemcpyAsync(a.data(), host.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, h.stream));
+    MFMG_HIP_CHECK(hipMemsetAsync(b.data(), 0, (size_t)n * sizeof(double), h.stream));
+    double err = 0.;
+    h.comm.transport->loopback(a.data(), b.data(), n, h.stream);
+    std::vector<double> back = b.download(h.stream);
+    for (int64_t i = 0; i < n; ++i)
+      err = std::max(err, std::abs(back[i] - host[i]));
+    h.comm.transport->allgather(a.data(), n, g.data(), h.stream);
+    std::vector<double> all = g.download(h.stream);
+    for (int r = 0; r < nr; ++r)
+      for (int64_t i = 0; i < n; ++i)
+        err = std::max(err, std::abs(all[(size_t)r * n + i] - (1000. * r + double(i % 977))));
+    double v[2] = {double(rk + 1), double(rk + 1)};
+    h.comm.transport->allreduce(v, 1, 0, h.stream);
+    h.comm.transport->allreduce(v + 1, 1, 1, h.stream);
+    err = std::max(err, std::abs(v[0] - 0.5 * nr * (nr + 1)));
+    err = std::max(err, std::abs(v[1] - double(nr)));
+    *max_error = err;
   });
 }
 
@@ -1023,6 +1056,14 @@ int mfmg_hip_hierarchy_coarse_amg_levels(mfmg_hip_hierarchy_t h, int32_t *n_leve
   return guarded([&] {
     require(n_levels != nullptr, "null argument");
     *n_levels = (int32_t)coarse_solver_of(h)->amg_levels().size();
+  });
+}
+
+int mfmg_hip_hierarchy_coarse_amg_gather_level(mfmg_hip_hierarchy_t h, int32_t *level)
+{
+  return guarded([&] {
+    require(level != nullptr, "null argument");
+    *level = (int32_t)coarse_solver_of(h)->amg_gather_level();
   });
 }
 

@@ -264,6 +264,8 @@ struct HaloTransport
   virtual void allreduce(double *host_values, int n, int op /* 0 sum, 1 max */, hipStream_t stream) = 0;
   // every rank contributes n doubles (device), `out` (device) receives n * n_ranks in rank order
   virtual void allgather(double const *in, int64_t n, double *out, hipStream_t stream) = 0;
+  // send n doubles to this rank itself and receive them (exercises the point-to-point path on a single GPU)
+  virtual void loopback(double const *send, double *recv, int64_t n, hipStream_t stream) = 0;
   virtual char const *name() const = 0;
 };
 

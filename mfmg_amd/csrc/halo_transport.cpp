@@ -124,6 +124,14 @@ public:
   {
     rccl_check(rccl().AllGather(in, out, (size_t)n, ncclFloat64, _comm, stream), "ncclAllGather");
   }
+  void loopback(double const *send, double *recv, int64_t n, hipStream_t stream) override
+  {
+    RcclApi &r = rccl();
+    rccl_check(r.GroupStart(), "ncclGroupStart");
+    rccl_check(r.Send(send, (size_t)n, ncclFloat64, _rank, _comm, stream), "ncclSend");
+    rccl_check(r.Recv(recv, (size_t)n, ncclFloat64, _rank, _comm, stream), "ncclRecv");
+    rccl_check(r.GroupEnd(), "ncclGroupEnd");
+  }
   char const *name() const override { return "rccl"; }
 
 private:
@@ -181,6 +189,10 @@ public:
       throw std::runtime_error("all-gather transport failed");
     MFMG_HIP_CHECK(hipMemcpyAsync(out, _host + n, n * _n * sizeof(double), hipMemcpyHostToDevice, stream));
     MFMG_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  void loopback(double const *send, double *recv, int64_t n, hipStream_t stream) override
+  {
+    MFMG_HIP_CHECK(hipMemcpyAsync(recv, send, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
   }
   char const *name() const override { return "host"; }
 

@@ -110,11 +110,12 @@ class HaloTransport:
             uid = (C.c_ubyte * 128)()
             if self.rank == 0:
                 check(self._lib.mfmg_hip_rccl_unique_id(uid))
-            t = torch.tensor(list(uid), dtype=torch.uint8)
-            if self.backend == "nccl":
-                t = t.cuda()
-            dist.broadcast(t, src=0, group=group)
-            uid = (C.c_ubyte * 128)(*[int(v) for v in t.cpu().tolist()])
+            if self.n_ranks > 1:
+                t = torch.tensor(list(uid), dtype=torch.uint8)
+                if self.backend == "nccl":
+                    t = t.cuda()
+                dist.broadcast(t, src=0, group=group)
+                uid = (C.c_ubyte * 128)(*[int(v) for v in t.cpu().tolist()])
             check(self._lib.mfmg_hip_context_use_rccl(ctx.handle, uid))
             self._host_group = None
         else:
@@ -184,6 +185,12 @@ class HaloTransport:
         n = C.c_int64()
         check(self._lib.mfmg_hip_context_exchange_count(self.ctx.handle, C.byref(n)))
         return n.value
+
+    def selftest(self, n: int = 1 << 16) -> float:
+        """Loop-back send/recv, all-gather and all-reduces through the registered transport; largest deviation."""
+        e = C.c_double()
+        check(self._lib.mfmg_hip_context_transport_selftest(self.ctx.handle, n, C.byref(e)))
+        return e.value
 
     def name(self) -> str:
         buf = C.create_string_buffer(32)

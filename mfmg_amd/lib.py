@@ -88,6 +88,7 @@ def load() -> C.CDLL:
         "mfmg_hip_context_use_host_transport": (C.c_int, [vp, vp, vp, vp, vp]),
         "mfmg_hip_context_transport_name": (C.c_int, [vp, C.c_char_p, sz]),
         "mfmg_hip_context_exchange_count": (C.c_int, [vp, P(i64)]),
+        "mfmg_hip_context_transport_selftest": (C.c_int, [vp, i64, P(dbl)]),
         "mfmg_hip_context_exchange": (C.c_int, [vp, i32, vp, C.c_int]),
         "mfmg_hip_context_owned_dot": (C.c_int, [vp, i32, vp, vp, P(dbl)]),
         "mfmg_hip_context_halo_space": (C.c_int, [vp, i32, vp]),
@@ -173,6 +174,7 @@ def load() -> C.CDLL:
         "mfmg_hip_host_amg_get": (C.c_int, [vp, i32, i32, P(vp)]),
         "mfmg_hip_host_amg_destroy": (C.c_int, [vp]),
         "mfmg_hip_hierarchy_coarse_amg_levels": (C.c_int, [vp, P(i32)]),
+        "mfmg_hip_hierarchy_coarse_amg_gather_level": (C.c_int, [vp, P(i32)]),
         "mfmg_hip_hierarchy_coarse_amg_get": (C.c_int, [vp, i32, i32, P(vp)]),
         "mfmg_hip_hierarchy_coarse_amg_smoother": (C.c_int, [vp, i32, P(i32), P(dbl), P(dbl)]),
     }

@@ -423,10 +423,15 @@ def dealii_chebyshev_initial_guess(n: int, first_local: int = 0) -> np.ndarray:
 
 
 def hashed_initial_guess(n: int) -> np.ndarray:
-    """Numbering-independent start vector used by the HIP build by default (Knuth multiplicative hash of
+    """Numbering-independent start vector used by the HIP build by default (splitmix64 finaliser of
     the DoF id, mean-free): deal.II's (i % 11) pattern degenerates to a plane wave for lexicographic
     numberings with row lengths such as 128 or 256 and then under-estimates lambda_max."""
-    v = ((np.arange(n, dtype=np.uint64) * np.uint64(2654435761)) & np.uint64(0xffffffff)).astype(float) / 4294967296.0
+    with np.errstate(over="ignore"):
+        z = np.arange(n, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    v = (z >> np.uint64(11)).astype(float) / 9007199254740992.0
     return v - v.mean()
 
 

@@ -139,6 +139,7 @@ def mode_gpu(args):
     ctx = M.Context()
     tr = M.HaloTransport(ctx, part, 2)
     assert tr.name() == "host"
+    assert tr.selftest(4096) == 0.0          # loop-back, all-gather, sum / max all-reduce through gloo
     h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", part.local_problem(material, "cuda"), params)
     deg, lmin, lmax = h.smoother_info()       # estimated with dot products summed over the ranks
     assert 1.4 < lmax < 2.2, lmax

@@ -59,3 +59,22 @@ def test_distributed_construction_cpu_gloo(mfmg_lib, world):
 @pytest.mark.parametrize("world,mesh", [(2, "small"), (3, "small"), (2, "wide"), (2, "deep"), (4, "deep")])
 def test_distributed_library_path_shared_gpu(mfmg_lib, world, mesh):
     assert "gpu distributed checks passed" in _run("gpu", world, mesh=mesh)
+
+
+@pytest.mark.gpu
+def test_rccl_transport_on_one_gpu(mfmg_lib):
+    """The native transport (ncclSend / ncclRecv / ncclAllGather / ncclAllReduce resolved from librccl at run time) on a
+    one-rank communicator: a loop-back send/recv of 512 KiB, the collectives, and a hierarchy built and applied with
+    the communicator registered (one rank: no neighbours, every exchange a no-op)."""
+    ctx = M.Context()
+    part = M.SlabPartition((8, 8, 8), 0, 1)
+    tr = M.HaloTransport(ctx, part, transport="rccl")
+    assert tr.name() == "rccl"
+    assert tr.selftest(1 << 16) == 0.0
+    params = {"eigensolver": {"number of eigenvectors": 2}, "agglomeration": {"nx": 2, "ny": 2, "nz": 2},
+              "smoother": {"type": "Chebyshev", "degree": 2, "smoothing_range": 20.0}, "solver": {"type": "amg"}}
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", part.local_problem("linear", "cuda"), params)
+    x = torch.rand(h.level_size(0), dtype=torch.float64, device="cuda")
+    h.apply(torch.zeros_like(x), x)
+    ctx.synchronize()
+    assert torch.isfinite(x).all()
