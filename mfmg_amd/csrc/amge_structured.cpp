@@ -1,4 +1,5 @@
 #include "amge_structured.hpp"
+#include "amge_device.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -524,7 +525,7 @@ struct AggKey
 
 HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<double> const &global_diag,
                                     RestrictorOptions const &opts, std::vector<int32_t> *row_agglomerate,
-                                    int *agglomerate_counts)
+                                    int *agglomerate_counts, HipHandle *device)
 {
   const int dim = mesh.dim;
   const int nc = mesh.nc();
@@ -547,6 +548,13 @@ HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<doub
 
   std::vector<std::shared_ptr<AggResult const>> result_of(n_agg);
   std::vector<std::vector<int32_t>> dofs_of(n_agg);
+  // eigenproblems on the device (one wavefront per agglomerate, amge_device.hip) when a handle is given
+  std::vector<double> dev_weights;
+  std::vector<int32_t> dev_n_vec;
+  int dev_nmax = 0;
+  const bool on_device = device != nullptr && amge_device_supported(mesh, opts);
+  if (on_device)
+    amge_device_eigen(*device, mesh, opts, cnt, dev_weights, dev_n_vec, dev_nmax);
   // identical agglomerates (same shape, constraints and local matrix) share one eigen-solve;
   // the table is capped so that a spatially varying coefficient cannot blow up host memory
   // (one table per thread: no lock on the hot path; at most threads x classes eigen-solves)
@@ -587,6 +595,8 @@ HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<doub
             gl[lidx(i, j, k)] = g;
             lcon[lidx(i, j, k)] = (mesh.constrained[g] == 1);
           }
+      if (on_device)
+        continue;
       // local (Neumann) matrix from the cell matrices of the agglomerate
       A.assign((size_t)nloc * nloc, 0.);
       const int lkz = (dim == 3) ? ln[2] : 1;
@@ -757,9 +767,13 @@ HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<doub
   // assemble R (rows: agglomerates in x-fastest order, eigenvectors inside; columns sorted)
   HostCsr R;
   R.n_cols = mesh.n_dofs;
+  auto n_vec_of = [&](int64_t a) { return on_device ? (int)dev_n_vec[a] : result_of[a]->n_vec; };
+  auto weight_of = [&](int64_t a, int e, int l, int nloc) {
+    return on_device ? dev_weights[((size_t)a * opts.n_eigenvectors + e) * dev_nmax + l] : result_of[a]->weights[(size_t)e * nloc + l];
+  };
   std::vector<int64_t> first_row(n_agg + 1, 0);
   for (int64_t a = 0; a < n_agg; ++a)
-    first_row[a + 1] = first_row[a] + result_of[a]->n_vec;
+    first_row[a + 1] = first_row[a] + n_vec_of(a);
   R.n_rows = first_row[n_agg];
   if (row_agglomerate)
   {
@@ -773,7 +787,7 @@ HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<doub
       agglomerate_counts[d] = cnt[d];
   R.row_ptr.assign(R.n_rows + 1, 0);
   for (int64_t a = 0; a < n_agg; ++a)
-    for (int e = 0; e < result_of[a]->n_vec; ++e)
+    for (int e = 0; e < n_vec_of(a); ++e)
       R.row_ptr[first_row[a] + e + 1] = (int32_t)dofs_of[a].size();
   int64_t total = 0;
   for (int64_t r = 0; r < R.n_rows; ++r)
@@ -795,14 +809,14 @@ HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<doub
       perm.resize(nloc);
       std::iota(perm.begin(), perm.end(), 0);
       std::sort(perm.begin(), perm.end(), [&](int x, int y) { return gl[x] < gl[y]; });
-      for (int e = 0; e < result_of[a]->n_vec; ++e)
+      for (int e = 0; e < n_vec_of(a); ++e)
       {
         const int64_t base = R.row_ptr[first_row[a] + e];
         for (int t = 0; t < nloc; ++t)
         {
           const int l = perm[t];
           R.col[base + t] = gl[l];
-          R.val[base + t] = result_of[a]->weights[(size_t)e * nloc + l] / global_diag[gl[l]];
+          R.val[base + t] = weight_of(a, e, l, nloc) / global_diag[gl[l]];
         }
       }
     }

@@ -84,9 +84,11 @@ struct RestrictorOptions
 
 // R as CSR (rows = coarse DoFs: agglomerates x-fastest, eigenvectors inside)
 // `row_agglomerate` (optional): agglomerate index (x fastest) of every row; `agglomerate_counts`: grid
+// `device` (optional): solve the agglomerate eigenproblems on the GPU of that handle (amge_device.hip) instead of
+// on the host cores; same rules, results equal to rounding
 HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<double> const &global_diag,
                                     RestrictorOptions const &opts, std::vector<int32_t> *row_agglomerate = nullptr,
-                                    int *agglomerate_counts = nullptr);
+                                    int *agglomerate_counts = nullptr, HipHandle *device = nullptr);
 
 // A_c = R A R^T without storing A or A R^T: operator rows generated on the fly from the
 // coefficient table.  `Rt` must be the transpose of `R`.

@@ -1121,8 +1121,11 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
   RestrictorOptions opts = hip_mesh_evaluator->agglomerate_options(*params);
   auto global_diag = hip_mesh_evaluator->get_locally_relevant_diag();
   _grid_hint = AmgGridHint();
+  // agglomerate eigenproblems: batched on the device (default) or on the host cores ("restrictor.eigensolver host")
+  std::string const where = params->get("restrictor.eigensolver", "device");
+  ASSERT_THROW(where == "device" || where == "host", "restrictor.eigensolver must be device or host");
   HostCsr R = build_restrictor_structured(hip_mesh_evaluator->get_mesh(), global_diag, opts, &_grid_hint.node_of_row,
-                                          _grid_hint.dims);
+                                          _grid_hint.dims, where == "device" ? &_handle : nullptr);
   // component of a coarse row = its position among the eigenvectors of its agglomerate
   _grid_hint.component_of_row.resize(_grid_hint.node_of_row.size());
   _grid_hint.n_components = 1;
