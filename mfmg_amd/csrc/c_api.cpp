@@ -818,6 +818,9 @@ int mfmg_hip_hierarchy_apply_f32(mfmg_hip_hierarchy_t h, const float *b, float *
       h->f32_res.resize(n);
       h->f32_res64 = levels[0].get_operator()->build_range_vector();
       h->f32_corr64 = levels[0].get_operator()->build_range_vector();
+    }
+    if (!h->f32_bc)
+    {
       h->f32_bc = levels[1].get_operator()->build_range_vector();
       h->f32_xc = levels[1].get_operator()->build_range_vector();
     }
@@ -1002,14 +1005,20 @@ int mfmg_hip_hierarchy_set_restrictor(mfmg_hip_hierarchy_t h, int64_t n_rows, in
 {
   return guarded([&] {
     require(h && row_ptr_host && col_host && val_host, "null argument");
+    require(n_rows >= 1 && n_cols >= 1 && nnz >= 0 && nnz < (int64_t(1) << 31), "matrix shape out of range");
     require(n_cols == level_size(h, 0), "the restrictor must have one column per fine DoF");
+    require(!h->handle->comm.enabled(), "set_restrictor is not available in a distributed run (the restrictor carries "
+                                        "the halo layout of the coarse space)");
+    require(row_ptr_host[0] == 0 && row_ptr_host[n_rows] == nnz, "row_ptr[0] != 0 or row_ptr[n_rows] != nnz");
     std::vector<int32_t> rp(row_ptr_host, row_ptr_host + n_rows + 1);
-    require(rp[n_rows] == nnz, "row_ptr[n_rows] != nnz");
     std::vector<int32_t> cl(col_host, col_host + nnz);
     std::vector<double> vl(val_host, val_host + nnz);
     auto m = std::make_shared<SparseMatrixDevice<double>>(*h->handle, n_rows, n_cols, std::move(rp), std::move(cl),
                                                           std::move(vl));
     h->hierarchy->set_restrictor(std::make_shared<HipMatrixOperator>(m));
+    // scratch vectors of apply_f32 were sized for the old coarse space
+    h->f32_bc.reset();
+    h->f32_xc.reset();
     MFMG_HIP_CHECK(hipStreamSynchronize(h->handle->stream));
   });
 }

@@ -2,7 +2,8 @@
 # usage: pmc.sh tag n ty tz   (env: WAVES, MFMG_MF_VARIANT) ; separate --pmc passes, kernel-trace only
 set -e
 tag=$1; n=$2; ty=$3; tz=$4
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT}
+mkdir -p "$R/gpurun_out/pmc_$tag"
 cd /tmp && export TMPDIR=/tmp
 for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
   name=$(echo $pass | cut -d' ' -f1)

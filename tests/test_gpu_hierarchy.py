@@ -530,6 +530,108 @@ def test_full_size_hierarchy_properties(ctx, material):
     np.testing.assert_allclose(norms2, norms, rtol=1e-10)
 
 
+@pytest.mark.parametrize("material", ["constant", "linear"])
+def test_full_size_assembled_hierarchy_properties(ctx, material):
+    """BASELINE.json configs[2] at size: 256^3 cells with the ASSEMBLED fine operator (HipMeshEvaluator: 17 M rows,
+    27 entries per row in CSR; restriction / prolongation as SpMV).  The numpy oracle does not finish at this size,
+    so the size-independent properties of every operator on the path are checked, and the table-driven variants of
+    the fine and coarse matrices against their stored values / plain CSR kernels."""
+    n = (256, 256, 256)
+    prob = M.LaplaceProblem(n, material, device="cuda")
+    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0, "lambda_max": 1.8, "lambda_min": 0.09},
+                         solver={"type": "amg"})
+    h = M.Hierarchy(ctx, "HipMeshEvaluator", prob, params)
+    nf, nc = h.level_size(0), h.level_size(1)
+    assert nf == 257 ** 3 and nc == 2 * 128 ** 3
+    g = torch.Generator(device="cuda").manual_seed(5)
+    free = (prob.constrained == 0).to(torch.float64)
+    rnd = lambda m: torch.rand(m, dtype=torch.float64, device="cuda", generator=g)
+    x, y = rnd(nf) * free, rnd(nf) * free
+    u, v = rnd(nc), rnd(nc)
+    ax, ay = torch.empty_like(x), torch.empty_like(x)
+    h.operator_apply(0, x, ax)
+    h.operator_apply(0, y, ay)
+    assert abs(ctx.dot(ax, y) - ctx.dot(x, ay)) < 1e-11 * abs(ctx.dot(ax, y))           # A symmetric on the free DoFs
+    # the assembled operator and the matrix-free one agree on vectors that vanish on the Dirichlet DoFs
+    # (tests/test_hierarchy.cc:644-695: matrix-free vs assembled, < 1e-9)
+    mf = M.MatrixFreeLaplace(ctx, prob)
+    amf = torch.empty_like(x)
+    mf.vmult(amf, x)
+    ctx.synchronize()
+    assert ((ax - amf) * free).abs().max().item() < 1e-9 * ax.abs().max().item()
+    del mf, amf
+    au, av = torch.empty_like(u), torch.empty_like(u)
+    h.operator_apply(1, u, au)
+    h.operator_apply(1, v, av)
+    assert abs(ctx.dot(au, v) - ctx.dot(u, av)) < 1e-11 * abs(ctx.dot(au, v))           # A_c symmetric
+    assert ctx.dot(au, u) > 0.0
+    rx, rtu = torch.empty_like(u), torch.empty_like(x)
+    h.restrictor_apply(1, x, rx)
+    h.restrictor_apply(1, u, rtu, L.TRANS)
+    assert abs(ctx.dot(rx, u) - ctx.dot(x, rtu)) < 1e-11 * abs(ctx.dot(rx, u))          # <R x, u> = <x, R^T u>
+    t1, t2, t3 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(u)
+    h.restrictor_apply(1, u, t1, L.TRANS)
+    h.operator_apply(0, t1, t2)
+    h.restrictor_apply(1, t2, t3)
+    assert abs(ctx.dot(t3, v) - ctx.dot(au, v)) < 1e-9 * abs(ctx.dot(au, v))            # Galerkin: R A R^T = A_c
+    # the smoother is an affine map
+    b1, b2 = rnd(nf) * free, rnd(nf) * free
+    def smooth(b, x0):
+        xx = x0.clone()
+        h.smoother_apply(0, b, xx)
+        return xx
+    s1, s2 = smooth(b1, x), smooth(b2, y)
+    s12 = smooth((2.0 * b1 - 3.0 * b2).contiguous(), (2.0 * x - 3.0 * y).contiguous())
+    ctx.synchronize()
+    assert (s12 - (2.0 * s1 - 3.0 * s2)).abs().max().item() < 1e-11 * s1.abs().max().item()
+    del s1, s2, s12, b1, b2, t1, t2, t3
+    # the cycle contracts; the same cycle with every table-driven matrix switched back to its stored values agrees
+    def cycle_norms():
+        xx = x.clone()
+        b = torch.zeros_like(xx)
+        r = torch.empty_like(xx)
+        out = []
+        for _ in range(4):
+            h.operator_apply(0, xx, r)
+            out.append(ctx.l2_norm(r))
+            h.apply(b, xx)
+        return out
+    norms = cycle_norms()
+    assert all(norms[i + 1] < 0.5 * norms[i] for i in range(3)), norms
+    h.coarse_amg_kernels(regular_rows=False)
+    np.testing.assert_allclose(cycle_norms(), norms, rtol=1e-10)
+    h.coarse_amg_kernels(regular_rows=True)
+
+
+@pytest.mark.parametrize("degree", [4, 5])
+@pytest.mark.parametrize("evaluator", ["HipMatrixFreeMeshEvaluator", "HipMeshEvaluator"])
+def test_chebyshev_degree_4_and_5(ctx, evaluator, degree):
+    """Polynomial degrees above three: the fused kernels write a term into the vector that holds x_{k-1} (out aliases
+    x_prev), for the matrix-free and the CSR smoother step alike; one smoother application against the oracle."""
+    n = (10, 9, 8)
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "linear")
+    con = mesh.constrained_mask()
+    prob = M.LaplaceProblem(n, "linear", device="cuda")
+    lmax, lmin = 1.8, 0.09
+    h = M.Hierarchy(ctx, evaluator, prob, base_params(smoother={"type": "Chebyshev", "degree": degree, "lambda_max": lmax,
+                                                                 "lambda_min": lmin}, solver={"type": "lu_dense"}))
+    if evaluator == "HipMatrixFreeMeshEvaluator":
+        mf = O.MatrixFreeLaplace(mesh, coef)
+        apply_a, dinv = mf.vmult, mf.diagonal_inverse()
+    else:
+        A = O.assemble_csr(mesh, coef)
+        apply_a, dinv = (lambda z: A @ z), 1.0 / A.diagonal()
+    rng = np.random.default_rng(11)
+    b = np.where(con, 0.0, rng.random(mesh.n_dofs))
+    x0 = np.where(con, 0.0, rng.random(mesh.n_dofs))
+    ref = O.chebyshev_smoother_apply(apply_a, dinv, O.ChebyshevParams(degree, lmax, lmin), b, x0.copy())
+    x = dev(x0)
+    h.smoother_apply(0, dev(b), x)
+    ctx.synchronize()
+    assert np.abs(x.cpu().numpy() - ref).max() < 1e-12 * np.abs(ref).max()
+
+
 def test_outer_cg_driver_matches_oracle(ctx):
     """tests/hierarchy_driver.cc:103-116: CG on the matrix-free operator preconditioned by Hierarchy::vmult
     ("is preconditioner" true) -- iteration count and residual history against the oracle's CG with the
