@@ -211,6 +211,36 @@ def measure_smoother_f32(ctx, torch, M, cells, degree, reps=5, material="linear"
             "required_GBs": N * per_dof / (ms * 1e-3) / 1e9, "frac_of_8TBs": N * per_dof / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+def measure_cell_contraction(ctx, torch, cells, reps=20):
+    """BASELINE.json configs[4]: the cell-local evaluation as a batched dense contraction V = (K_ref U) diag(c) over
+    cells^3 cells, planar operands, on the vector ALU and on the matrix cores, FP32 and FP64.  17 values move per cell
+    (8 in, 1 coefficient, 8 out): HBM-bound either way; the MFMA issue time is beside it (two 16x16x4 MFMAs per 16 cells,
+    half of each tile is padding: the operator is 8 x 8)."""
+    n = cells ** 3
+    out = {"n_cells": n, "bytes_per_cell": {"f32": 68, "f64": 136}}
+    for dt, name in ((torch.float32, "f32"), (torch.float64, "f64")):
+        u = torch.randn(8, n, dtype=dt, device="cuda")
+        c = torch.rand(n, dtype=dt, device="cuda") + 1.0
+        v = torch.empty_like(u)
+        for variant in ("valu", "mfma"):
+            for _ in range(3):
+                ctx.cell_contraction(u, c, v, (1.0 / cells,) * 3, variant=variant)
+            ctx.synchronize()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+            ev[0].record()
+            for r in range(reps):
+                ctx.cell_contraction(u, c, v, (1.0 / cells,) * 3, variant=variant)
+                ev[r + 1].record()
+            ev[-1].synchronize()
+            ts = sorted(ev[r].elapsed_time(ev[r + 1]) for r in range(reps))
+            ms = ts[len(ts) // 2]
+            gbs = n * 17 * u.element_size() / (ms * 1e-3) / 1e9
+            out[f"{name}_{variant}"] = {"ms": ms, "GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS, "Gcells_per_s": n / (ms * 1e-3) / 1e9}
+        del u, c, v
+        torch.cuda.empty_cache()
+    return out
+
+
 def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=20, warmup=3, tile=None, material="constant"):
     """Fine-level smoother apply (degree fused operator kernels) on its own: one HIP event pair per apply on the
     kernels' stream, `warmup` untimed applies, then `reps` timed ones; reported: median (the quoted figure), min,
@@ -577,6 +607,7 @@ def main():
                 out["general_coefficient"] = gen
                 out["vcycle_128cubed_config1"] = measure_vcycle_small(ctx, torch, M, 128, params)
                 out["smoother_apply_256cubed_f32_config5"] = measure_smoother_f32(ctx, torch, M, 256, args.degree)
+                out["cell_contraction_256cubed_config5"] = measure_cell_contraction(ctx, torch, 256)
                 if not assembled:
                     out["vcycle_256cubed_assembled_config2"] = measure_vcycle_small(
                         ctx, torch, M, args.cells, params, evaluator="HipMeshEvaluator")

@@ -120,6 +120,15 @@ int mfmg_hip_context_halo_layout(mfmg_hip_context_t ctx, int32_t space, int64_t 
                                  int64_t *owned_begin, int64_t *owned_count);
 int mfmg_hip_context_halo_space(mfmg_hip_context_t ctx, int32_t space, int64_t out[8]);
 
+/* BASELINE.json configs[4]: the cell-local evaluation of the Q1 Laplace as a batched dense contraction,
+ * v[m][cell] = c[cell] * sum_k K_ref[m][k] u[k][cell] (K_ref: reference matrix of a Cartesian cell of size `cell_size`,
+ * what LaplaceOperator::local_apply computes per cell for a cell-wise constant coefficient, tests/laplace_matrix_free.hpp:129-156)
+ * on planar device operands u, v: [8][n_cells], c: [n_cells].  fp32 != 0: float operands.  variant 0: vector ALU,
+ * 1: MFMA (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64).  Timed under the kernel names "cell_contraction_valu" /
+ * "cell_contraction_mfma" (17 values moved per cell). */
+int mfmg_hip_cell_contraction(mfmg_hip_context_t ctx, int fp32, int variant, int64_t n_cells, const void *u, const void *c,
+                              void *v, const double cell_size[3]);
+
 /* Per-kernel timing with HIP events recorded on the launch stream (the reference only has the
  * wall-clock dealii::TimerOutput sections, include/mfmg/common/hierarchy.hpp:36-47).  Kernel names:
  * "mf_laplace_kernel", "csr_spmv_kernel".  `algorithmic_bytes` sums SURVEY.md 8d's per-launch figures. */

@@ -117,6 +117,16 @@ class Context:
     def sadd(self, x: torch.Tensor, s: float, a: float, v: torch.Tensor):
         check(self._lib.mfmg_hip_vector_sadd(self.handle, x.numel(), s, a, _dev_ptr(v, x.numel()), _dev_ptr(x)))
 
+    def cell_contraction(self, u: torch.Tensor, c: torch.Tensor, v: torch.Tensor, cell_size, variant: str = "mfma"):
+        """v[m, cell] = c[cell] * sum_k K_ref[m, k] u[k, cell] (BASELINE.json configs[4]); u, v: [8, n] contiguous CUDA
+        tensors, float32 or float64; variant "valu" or "mfma"."""
+        n = c.numel()
+        dt = u.dtype
+        assert dt in (torch.float32, torch.float64) and u.shape == (8, n) and v.shape == (8, n)
+        hs = (C.c_double * 3)(*[float(x) for x in cell_size])
+        check(self._lib.mfmg_hip_cell_contraction(self.handle, 1 if dt == torch.float32 else 0, 1 if variant == "mfma" else 0, n,
+                                                  _dev_ptr(u, 8 * n, dt), _dev_ptr(c, n, dt), _dev_ptr(v, 8 * n, dt), hs))
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):

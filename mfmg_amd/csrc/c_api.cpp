@@ -5,6 +5,7 @@
 #include <exception>
 #include <string>
 
+#include "cell_contraction.hpp"
 #include "halo_transport.hpp"
 #include "mfmg/hierarchy.hpp"
 
@@ -329,6 +330,20 @@ int mfmg_hip_context_halo_space(mfmg_hip_context_t ctx, int32_t space, int64_t o
     out[5] = s.global_layers;
     out[6] = s.width;
     out[7] = (int64_t)ctx->handle->comm.spaces.size();
+  });
+}
+
+int mfmg_hip_cell_contraction(mfmg_hip_context_t ctx, int fp32, int variant, int64_t n_cells, const void *u, const void *c,
+                              void *v, const double cell_size[3])
+{
+  return guarded([&] {
+    require(ctx != nullptr && u && c && v && cell_size, "null argument");
+    if (fp32)
+      cell_contraction<float>(*ctx->handle, variant, n_cells, static_cast<float const *>(u), static_cast<float const *>(c),
+                              static_cast<float *>(v), cell_size);
+    else
+      cell_contraction<double>(*ctx->handle, variant, n_cells, static_cast<double const *>(u), static_cast<double const *>(c),
+                               static_cast<double *>(v), cell_size);
   });
 }
 

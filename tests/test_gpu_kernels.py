@@ -572,3 +572,28 @@ def test_vector_kernels(ctx):
     # deterministic reduction: same bits on repeat
     xd = dev(rng.random(1 << 20))
     assert ctx.dot(xd, xd) == ctx.dot(xd, xd)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float64, 1e-14)])
+@pytest.mark.parametrize("variant", ["valu", "mfma"])
+@pytest.mark.parametrize("n_cells", [1, 15, 64, 1000, 70001])
+def test_cell_contraction_valu_and_mfma(ctx, dtype, tol, variant, n_cells):
+    """BASELINE.json configs[4]: the cell-local evaluation as a batched dense contraction, on the vector ALU and on the
+    matrix cores (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64), against the oracle's cell matrix: the reference
+    matrix K_ref of a Cartesian cell is what the oracle's operator applies per cell for a unit coefficient."""
+    h = (0.25, 0.5, 0.125)       # anisotropic on purpose: K_ref is not symmetric under corner permutations
+    mesh = O.StructuredMesh((1, 1, 1), length=1.0)
+    mesh.h = h
+    Ke = O.cell_matrices(mesh, np.ones((1, 8)))[0]            # 8 x 8, unit coefficient
+    rng = np.random.default_rng(n_cells)
+    U = rng.standard_normal((8, n_cells))                    # asymmetric data: a row/column swap would show
+    c = 1.0 + rng.random(n_cells)
+    ref = (Ke @ U) * c
+    u = torch.from_numpy(U).to(dtype).cuda().contiguous()
+    cc = torch.from_numpy(c).to(dtype).cuda().contiguous()
+    v = torch.full((8, n_cells), float("nan"), dtype=dtype, device="cuda")
+    ctx.cell_contraction(u, cc, v, h, variant=variant)
+    ctx.synchronize()
+    got = v.cpu().numpy().astype(float)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < tol * np.abs(ref).max() * 8
