@@ -78,7 +78,7 @@ def smoother_coefficients(degree, lmin, lmax):
     return out
 
 
-def committed_traffic(cells, degree, compact, tile):
+def committed_traffic(cells, degree, compact, tile, prefix="cells"):
     """HBM bytes per launch of the operator kernel from the PMC passes committed under profiles/ (2 x FETCH_SIZE
     + WRITE_SIZE, MI355X_MICROARCH.md): counters need rocprofv3 around the process, so this is not a live reading.
     The file is keyed on the workload AND the tile; anything else returns None."""
@@ -87,7 +87,7 @@ def committed_traffic(cells, degree, compact, tile):
         return None
     with open(path) as f:
         d = json.load(f)
-    key = f"cells{cells}_degree{degree}_{'cell_constant' if compact else 'general'}_tile{'x'.join(str(v) for v in tile)}"
+    key = f"{prefix}{cells}_degree{degree}_{'cell_constant' if compact else 'general'}_tile{'x'.join(str(v) for v in tile)}"
     e = d.get(key)
     return e.get("traffic_bytes_per_launch") if e else None
 
@@ -282,9 +282,12 @@ def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=20, warmup=3, t
     ms = ts[len(ts) // 2]
     survey = smoother_bytes_per_dof(len(coefs), 8, compact, survey=True)
     required = smoother_bytes_per_dof(len(coefs), 8, compact, survey=False)
+    traffic = committed_traffic(n_dofs_per_dim, degree, compact, op.get_tile(), prefix="dofs")
     return {"n_dofs": N, "degree": degree, "material": material,
             "coefficient_layout": "one value per cell" if compact else "eight values per cell",
             "tile_waves_ty_tz": list(op.get_tile()),
+            "hbm_traffic_bytes_per_launch_pmc": traffic,
+            "hbm_traffic_GBs": (traffic * len(coefs) / (ms * 1e-3) / 1e9) if traffic else None,
             "ms_per_apply": ms, "ms_min": ts[0], "ms_max": ts[-1], "reps": reps, "warmup": warmup,
             "required_bytes_per_dof": required, "required_GBs": N * required / (ms * 1e-3) / 1e9,
             "frac_of_8TBs": N * required / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
