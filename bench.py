@@ -104,9 +104,11 @@ def operator_bytes_per_dof(word, compact, survey):
 
 
 def smoother_bytes_per_dof(n_terms, word, compact, survey):
-    """Chebyshev smoother apply = n_terms fused operator launches: + b + D^-1 each, + x_prev from the second on."""
+    """Chebyshev smoother apply = n_terms fused operator launches: + b + D^-1 each, + x_prev from the second on.  With one
+    coefficient per cell the layout holds no D^-1 (the kernel derives it from the cell coefficients): not required."""
     b_op = operator_bytes_per_dof(word, compact, survey)
-    return (b_op + 2 * word) + (n_terms - 1) * (b_op + 3 * word)
+    dinv = 0 if (compact and not survey) else word
+    return (b_op + word + dinv) + (n_terms - 1) * (b_op + 2 * word + dinv)
 
 
 def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, material="constant",
@@ -547,7 +549,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (None if assembled else committed_traffic(args.cells, args.degree, compact, mf_tile)),
-                "priced_on": "bytes the data layout requires per launch (x, out, one id, coefficients, b, D^-1, x_prev); "
+                "priced_on": "bytes the data layout requires per launch (x, out, one id, coefficients, b, x_prev, and D^-1 where the "
+                             "layout stores it: eight coefficients per cell); "
                              "halo re-reads of the tiling are waste and not counted",
                 "required_bytes_per_dof_operator": (None if assembled else operator_bytes_per_dof(word, compact, False)),
                 "survey_8d_bytes_per_dof_operator": (None if assembled else operator_bytes_per_dof(word, compact, True)),

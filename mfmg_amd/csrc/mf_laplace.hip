@@ -61,6 +61,7 @@ struct MfArgs
   unsigned int z_tile0;
   T fx, fy, fz;
   T fax, fbx, fay, fby, faz, fbz; // one coefficient per cell: 2 f M00, 2 f M01 per direction (M = [[2/3, 1/3], [1/3, 2/3]])
+  T kd;                           // ... and the diagonal entry of the reference cell matrix: diag = kd * sum of the 8 cell coefficients
   T alpha, beta;
   int mode;
 };
@@ -82,8 +83,11 @@ struct Rec
   static constexpr int NP = 8 / W;                                    // coefficient vectors per slot
   static constexpr size_t kCoefOff = 256;                             // after the own ids
   static constexpr size_t kCoefBytes = CC ? 64 * sizeof(T) : (size_t)NP * 1024;
-  static constexpr size_t kDinvOff = kCoefOff + kCoefBytes;           // after the coefficients
-  static constexpr size_t kBytes = kDinvOff + 64 * sizeof(T);         // FP64: 4864 general, 1280 cell-constant
+  static constexpr size_t kDinvOff = kCoefOff + kCoefBytes;           // after the coefficients (general layout only)
+  // FP64: 4864 B general, 768 B cell-constant.  The cell-constant record has no D^-1: with one coefficient per cell the
+  // diagonal of a DoF is kd * (sum of the coefficients of the eight cells around it), and the kernel forms that sum on
+  // the fly with the same lane / row / layer combines that assemble A x (8 bytes per DoF and launch less to read)
+  static constexpr size_t kBytes = CC ? kDinvOff : kDinvOff + 64 * sizeof(T);
 };
 
 
@@ -335,10 +339,13 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
   const int NW = blockDim.x >> 6;
   // LDS: per wavefront pt[TY] (z-carry of the partial sums), xz[TY+1] (z-carry of x, one slot per node row),
   // then the hand-over rows of all wavefronts, then per wavefront idz[TY+1] (z-carry of the ids)
-  T *pt = reinterpret_cast<T *>(smem_raw) + (size_t)wv * (2 * TY + 1) * 64;
+  T *pt = reinterpret_cast<T *>(smem_raw) + (size_t)wv * (3 * TY + 1) * 64;
   T *xz = pt + TY * 64;
-  T *xport = reinterpret_cast<T *>(smem_raw) + (size_t)NW * (2 * TY + 1) * 64; // [2][NW][2][64]
-  int *idz = reinterpret_cast<int *>(xport + (size_t)2 * NW * 2 * 64) + (size_t)wv * (TY + 1) * 64;
+  T *pc = xz + (TY + 1) * 64;                                                  // [TY][64] z-carry of the coefficient sums
+  T *xport = reinterpret_cast<T *>(smem_raw) + (size_t)NW * (3 * TY + 1) * 64; // [2][NW][3][64]
+  int *idz = reinterpret_cast<int *>(xport + (size_t)2 * NW * 3 * 64) + (size_t)wv * (TY + 1) * 64;
+  // D^-1 on the fly (cell-constant layout, smoother modes): diag = kd * sum of the coefficients of the 8 cells of a DoF
+  const bool make_dinv = CC && a.mode >= 2;
 
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8,
   // observed, speed only); give every XCD a contiguous run of the tile list.
@@ -394,14 +401,14 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
     unsigned char const *rec_k = rec_col + (size_t)kc * rec_layer;
     unsigned char const *rec_kn = rec_col + (size_t)kn * rec_layer;
     unsigned char const *rec_kn2 = rec_col + (size_t)min(k + 2, a.Nz - 1) * rec_layer;
-    T ry0 = T(0), ry1 = T(0);
+    T ry0 = T(0), ry1 = T(0), rc = T(0); // (rc: coefficient sum of the previous cell row)
     // b=0 face carried from the previous cell row: Dirichlet-masked x values of the four corners, the raw value
     // and the id of the own DoF
     T cxm[4] = {T(0), T(0), T(0), T(0)};
     T cx0 = T(0);
     int id0 = 0;
     // first DoF row of a wavefront w > 0, finished after the barrier: sums, raw x, id, epilogue operands
-    T d00 = T(0), d01 = T(0), dx0 = T(0), dlb = T(0), dld = T(0), dlx = T(0);
+    T d00 = T(0), d01 = T(0), dx0 = T(0), dlb = T(0), dld = T(0), dlx = T(0), dsc = T(0);
     int did0 = 0;
 
     // ---- first node row of the pass (the b=0 face of its first cell row)
@@ -431,8 +438,9 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
         // epilogue operands of the deferred row (its id has been in LDS since the previous pass)
         const unsigned int g = id_off<T>(idAf);
         dlb = ld_off<T>(a.b, g);
-        if (a.mode >= 2)
-          dld = reinterpret_cast<T const *>(rec_k + (size_t)jf * rec_row + Rec<T, CC>::kDinvOff)[lane];
+        if constexpr (!CC)
+          if (a.mode >= 2)
+            dld = reinterpret_cast<T const *>(rec_k + (size_t)jf * rec_row + Rec<T, CC>::kDinvOff)[lane];
         if (a.mode == 3)
           dlx = ld_off<T>(a.xprev, g);
       }
@@ -497,8 +505,9 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
           // the DoF row this cell row completes: node row jj, id = the layer-k id of the previous node row
           const unsigned int gid = id_off<T>((b == 0 || !ok[b > 0 ? b - 1 : 0]) ? id0 : idA[b > 0 ? b - 1 : 0]);
           lb[b] = ld_off<T>(a.b, gid);
-          if (a.mode >= 2)
-            ld[b] = reinterpret_cast<T const *>(recp + Rec<T, CC>::kDinvOff)[lane];
+          if constexpr (!CC)
+            if (a.mode >= 2)
+              ld[b] = reinterpret_cast<T const *>(recp + Rec<T, CC>::kDinvOff)[lane];
           if (a.mode == 3)
             lxp[b] = ld_off<T>(a.xprev, gid);
         }
@@ -536,8 +545,14 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
         u[3] = n1m;
         u[6] = n2m;
         u[7] = n3m;
+        T sx = T(0); // coefficients of the two cells of this row and layer that touch DoF column ci
         if constexpr (CC)
-          cell_apply_cc<T>(u, no_cells ? T(0) : c[b][0], fac, v);
+        {
+          const T cv = no_cells ? T(0) : c[b][0];
+          cell_apply_cc<T>(u, cv, fac, v);
+          if (make_dinv)
+            sx = cv + from_prev_lane(cv);
+        }
         else
         {
           if (no_cells)
@@ -570,6 +585,7 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
           d01 = s01;
           dx0 = x0;
           did0 = idr;
+          dsc = sx;
         }
         else
         {
@@ -579,29 +595,49 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
           T *ptj = pt + jj * 64 + lane;
           const T yv = t0 + *ptj; // (layer kk = 0 reads what an earlier tile left there: never stored)
           *ptj = t1;
+          T dinv_here = ld[b];
+          if (make_dinv)
+          {
+            // the eight cells of the DoF: two rows of this layer (register carry) + the same of the layer below (LDS)
+            const T tc = sx + rc;
+            T *pcj = pc + jj * 64 + lane;
+            const T sum8 = tc + *pcj;
+            *pcj = tc;
+            dinv_here = (idr < 0) ? T(1) : T(1) / (a.kd * sum8);
+          }
           if (jj > 0 && kk > 0 && col_owned && !((unsigned int)idr & kGhost))
-            st_off<T>(a.out, id_off<T>(idr), mf_epilogue<T>(a, idr, x0, yv, lb[b], ld[b], lxp[b]));
+            st_off<T>(a.out, id_off<T>(idr), mf_epilogue<T>(a, idr, x0, yv, lb[b], dinv_here, lxp[b]));
         }
         ry0 = s10;
         ry1 = s11;
+        rc = sx;
       }
     }
     if (NW > 1)
     {
       // exports are double-buffered by layer parity: a slot written in layer k is read after barrier k
       // and rewritten in layer k+2, i.e. after barrier k+1, which the reader only passes once it has read
-      T *xp = xport + ((size_t)((kk & 1) * NW + wv) * 2) * 64 + lane;
+      T *xp = xport + ((size_t)((kk & 1) * NW + wv) * 3) * 64 + lane;
       xp[0] = ry0;
       xp[64] = ry1;
+      if (make_dinv)
+        xp[128] = rc;
       __syncthreads();
       if (wv > 0)
       {
-        T const *ip = xport + ((size_t)((kk & 1) * NW + wv - 1) * 2) * 64 + lane;
+        T const *ip = xport + ((size_t)((kk & 1) * NW + wv - 1) * 3) * 64 + lane;
         const T t0 = d00 + ip[0];
         const T t1 = d01 + ip[64];
         T *ptj = pt + lane;
         const T yv = t0 + *ptj;
         *ptj = t1;
+        if (make_dinv)
+        {
+          const T tc = dsc + ip[128];
+          const T sum8 = tc + pc[lane];
+          pc[lane] = tc;
+          dld = (did0 < 0) ? T(1) : T(1) / (a.kd * sum8);
+        }
         if (kk > 0 && have_rows && col_owned && !((unsigned int)did0 & kGhost))
           st_off<T>(a.out, id_off<T>(did0), mf_epilogue<T>(a, did0, dx0, yv, dlb, dld, dlx));
       }
@@ -677,7 +713,8 @@ __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coeffic
       for (int p = 0; p < NP; ++p)
         for (int w = 0; w < W; ++w)
           reinterpret_cast<T *>(r + Rec<T, CC>::kCoefOff + p * 1024)[lane * W + w] = cf[p * W + w];
-    reinterpret_cast<T *>(r + Rec<T, CC>::kDinvOff)[lane] = T(0);
+    if constexpr (!CC)
+      reinterpret_cast<T *>(r + Rec<T, CC>::kDinvOff)[lane] = T(0);
   }
 }
 
@@ -797,7 +834,8 @@ __global__ void mf_fill_dinv_kernel(T const *dinv, int Nx, int ncols, int64_t n_
       continue;
     unsigned char *r = rec + (size_t)chunk * Rec<T, CC>::kBytes;
     const unsigned int g = (unsigned int)reinterpret_cast<int const *>(r)[lane] & kIdMask;
-    reinterpret_cast<T *>(r + Rec<T, CC>::kDinvOff)[lane] = dinv[g];
+    if constexpr (!CC)
+      reinterpret_cast<T *>(r + Rec<T, CC>::kDinvOff)[lane] = dinv[g];
   }
 }
 } // namespace
@@ -1013,7 +1051,7 @@ void MatrixFreeLaplaceDevice<T>::choose_tile(int &nw, int &ty, int &tz) const
   if (nw > 0 && ty > 0 && tz > 0)
     return;
   static const int pref_general[][3] = {{8, 2, 16}, {4, 3, 8}, {4, 2, 8}, {2, 2, 8}, {2, 2, 4}, {1, 2, 4}};
-  static const int pref_compact[][3] = {{8, 4, 16}, {4, 3, 10}, {4, 3, 8}, {4, 2, 8}, {2, 2, 4}, {1, 2, 4}};
+  static const int pref_compact[][3] = {{8, 3, 16}, {4, 3, 8}, {4, 3, 8}, {4, 2, 8}, {2, 2, 4}, {1, 2, 4}};
   const int(*pref)[3] = _compact ? pref_compact : pref_general;
   constexpr int n_pref = 6;
   static const int n_cus = [] {
@@ -1074,6 +1112,7 @@ bool MatrixFreeLaplaceDevice<T>::make_args(MfArgs<T> &a, unsigned int &n_blocks,
     a.fby = T(2. * f[1] * m01);
     a.faz = T(2. * f[2] * m00);
     a.fbz = T(2. * f[2] * m01);
+    a.kd = T(2. * m00 * m00 * (f[0] + f[1] + f[2]));
   }
   a.alpha = alpha;
   a.beta = beta;
@@ -1111,7 +1150,7 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
   at = am;
   if (_tail) // the columns of the last chunk: same tile shape, same layers, first in the grid
     _tail->make_args(at, tail_blocks, mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, z_tile_begin, z_tile_end);
-  const size_t lds = ((size_t)nw * (2 * ty + 1) + (size_t)2 * nw * 2) * 64 * sizeof(T) + (size_t)nw * (ty + 1) * 64 * sizeof(int);
+  const size_t lds = ((size_t)nw * (3 * ty + 1) + (size_t)2 * nw * 3) * 64 * sizeof(T) + (size_t)nw * (ty + 1) * 64 * sizeof(int);
   ASSERT_THROW(lds <= 160 * 1024, "operator tile too large for the LDS");
   const dim3 grid(main_blocks + tail_blocks);
   const dim3 block(64 * nw);
@@ -1200,10 +1239,8 @@ void MatrixFreeLaplaceDevice<T>::launch_z_range(MfMode mode, T const *x, T const
   const int all_z = (_N[2] + tz - 1) / tz;
   if (z_tile_begin >= z_tile_end)
     return;
-  const double extra = (mode == MfMode::apply) ? 0. : (mode == MfMode::residual) ? 1. : (mode == MfMode::first) ? 2. : 3.;
   const double share = double(z_tile_end - z_tile_begin) / double(all_z);
-  hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel",
-                                           share * (required_bytes_apply() + extra * sizeof(T) * double(_n_dofs)),
+  hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel", share * (required_bytes_apply() + epilogue_bytes((int)mode)),
                                            _handle.stream);
   run(mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, z_tile_begin, z_tile_end);
   KernelProfiler::end(stop, _handle.stream);
@@ -1217,9 +1254,7 @@ void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T c
   int nw, ty, tz;
   choose_tile(nw, ty, tz);
   // bytes the layout requires per launch (mf_laplace.hpp), plus the b / D^-1 / x_prev reads of the epilogue
-  const double extra = (mode == MfMode::apply) ? 0. : (mode == MfMode::residual) ? 1. : (mode == MfMode::first) ? 2. : 3.;
-  hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel", required_bytes_apply() + extra * sizeof(T) * double(_n_dofs),
-                                           _handle.stream);
+  hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel", required_bytes_apply() + epilogue_bytes((int)mode), _handle.stream);
   run(mode, x, b, x_prev, alpha, beta, out, nw, ty, tz);
   KernelProfiler::end(stop, _handle.stream);
 }

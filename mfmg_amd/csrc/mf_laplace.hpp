@@ -94,6 +94,13 @@ public:
   {
     return double(_n_dofs) * (2.0 * sizeof(T) + 4 + (_compact ? 1 : 8) * sizeof(T));
   }
+  // bytes of the epilogue operands of a fused mode on top of that: b, then D^-1 (NOT read in the cell-constant layout:
+  // the kernel derives it from the cell coefficients), then x_prev
+  double epilogue_bytes(int mode) const
+  {
+    const double w = sizeof(T) * double(_n_dofs);
+    return mode == 0 ? 0. : mode == 1 ? w : (mode == 2 ? 1. : 2.) * w + (_compact ? 0. : w);
+  }
 
 private:
   void launch(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out) const;

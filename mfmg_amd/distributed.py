@@ -107,6 +107,13 @@ class HaloTransport:
         check(self._lib.mfmg_hip_context_set_communicator(ctx.handle, self.rank, self.n_ranks, part.ghost_low,
                                                           part.ghost_high))
         if transport == "rccl":
+            # can this process reach RCCL at all?  (decided identically on every rank: same image, same library)
+            probe = (C.c_ubyte * 128)()
+            if self._lib.mfmg_hip_rccl_unique_id(probe) != 0:
+                print(f"[mfmg_amd] RCCL transport unavailable ({self._lib.mfmg_hip_last_error().decode(errors='replace')}); "
+                      f"falling back to the host transport", flush=True)
+                transport = self.transport = "host"
+        if transport == "rccl":
             uid = (C.c_ubyte * 128)()
             if self.rank == 0:
                 check(self._lib.mfmg_hip_rccl_unique_id(uid))
