@@ -114,6 +114,185 @@ def mode_cpu(args):
         print("cpu distributed checks passed", flush=True)
 
 
+def mode_protocol(args):
+    """CPU restatement of the distributed setup protocol of amg_device_setup.hip: on a z-slab partition of a node grid
+    with two unknowns per node, P = (I - w D^-1 A) P_tent and A_c = P^T A P are READ OFF from operator applications on
+    probing vectors defined on global coordinates -- nothing but vectors crosses between the ranks (forward halo
+    exchange before A, reverse-add exchange after P^T) -- for two levels in a row (stencil reach 1 -> 2 -> 3), and must
+    equal the rows of the globally formed matrices.  numpy / scipy + gloo; no GPU, no library."""
+    import scipy.sparse as sp
+    rank, world = dist.get_rank(), dist.get_world_size()
+    C, nx, ny, per = 2, 6, 4, 12
+    nzg = per * world
+    rng = np.random.default_rng(7)
+
+    def exchange(v, g, reverse=False):
+        """v: local vector [layers][le]; g: level geometry dict."""
+        le, w, ob, oc = g["le"], g["w"], g["ob"], g["oc"]
+        V = v.reshape(-1, le)
+        ops, recv = [], {}
+        for side, peer in (("low", rank - 1), ("high", rank + 1)):
+            if peer < 0 or peer >= world:
+                continue
+            if not reverse:
+                src = V[ob:ob + w] if side == "low" else V[ob + oc - w:ob + oc]
+            else:
+                src = V[ob - w:ob] if side == "low" else V[ob + oc:ob + oc + w]
+            t = torch.from_numpy(np.ascontiguousarray(src).reshape(-1).copy())
+            r = torch.empty_like(t)
+            ops += [dist.P2POp(dist.isend, t, peer), dist.P2POp(dist.irecv, r, peer)]
+            recv[side] = r
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
+        for side, r in recv.items():
+            blk = r.numpy().reshape(w, le)
+            if not reverse:
+                if side == "low":
+                    V[ob - w:ob] = blk
+                else:
+                    V[ob + oc:ob + oc + w] = blk
+            else:
+                if side == "low":
+                    V[ob:ob + w] += blk
+                else:
+                    V[ob + oc - w:ob + oc] += blk
+
+    def geom(dx, dy, oc, reach, gz_total):
+        lo, hi = rank > 0, rank + 1 < world
+        ob = reach if lo else 0
+        nzl = ob + oc + (reach if hi else 0)
+        return {"dx": dx, "dy": dy, "nz": nzl, "ob": ob, "oc": oc, "w": reach, "reach": reach, "le": dx * dy * C,
+                "g0": rank * oc - ob, "gz": gz_total}
+
+    # ---- a global SPD block-stencil operator of reach 1 on the node grid (the role of A_c)
+    def lap1d(n):
+        return sp.diags([-np.ones(n - 1), 2.5 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1])
+    def m1d(n):
+        return sp.diags([np.ones(n - 1), 4 * np.ones(n), np.ones(n - 1)], [-1, 0, 1]) / 6.0
+    Kz, Ky, Kx, Mz, My, Mx = lap1d(nzg), lap1d(ny), lap1d(nx), m1d(nzg), m1d(ny), m1d(nx)
+    S = sp.kron(Kz, sp.kron(My, Mx)) + sp.kron(Mz, sp.kron(Ky, Mx)) + sp.kron(Mz, sp.kron(My, Kx))   # 27-point
+    Ag = sp.kron(S, sp.csr_matrix(np.array([[2.0, 0.5], [0.5, 1.0]]))).tocsr()
+    Bg = 0.5 + rng.random(Ag.shape[0])
+    omega = 4.0 / 3.0
+
+    def global_level(Ag, Bg, dims):
+        dx, dy, dz = dims
+        n = Ag.shape[0]
+        node = np.arange(n) // C
+        comp = np.arange(n) % C
+        i, j, k = node % dx, (node // dx) % dy, node // (dx * dy)
+        cx, cy, cz = (dx + 1) // 2, (dy + 1) // 2, (dz + 1) // 2
+        agg = (((k // 2) * cy + j // 2) * cx + i // 2) * C + comp
+        n_c = cx * cy * cz * C
+        norm = np.sqrt(np.bincount(agg, weights=Bg * Bg, minlength=n_c))
+        Pt = sp.csr_matrix((Bg / norm[agg], (np.arange(n), agg)), shape=(n, n_c))
+        d = Ag.diagonal()
+        rho = (abs(Ag).sum(axis=1).A1 / abs(d)).max()
+        Sm = sp.identity(n) - sp.diags(omega / rho / d) @ Ag
+        P = (Sm @ Pt).tocsr()
+        return P, (P.T @ Ag @ P).tocsr(), norm, (cx, cy, cz), rho
+
+    def local_of(Mg, gf, gc=None):
+        """owned rows of a global matrix in local numbering (rows: level gf, columns: gc or gf)."""
+        gc = gc or gf
+        r0, r1 = (gf["g0"] + gf["ob"]) * gf["le"], (gf["g0"] + gf["ob"] + gf["oc"]) * gf["le"]
+        c0, c1 = gc["g0"] * gc["le"], (gc["g0"] + gc["nz"]) * gc["le"]
+        sub = Mg[r0:r1]
+        assert sub[:, :c0].nnz == 0 and sub[:, c1:].nnz == 0, "ghost layers too thin for this stencil"
+        L = sp.lil_matrix((gf["nz"] * gf["le"], gc["nz"] * gc["le"]))
+        L[gf["ob"] * gf["le"]:(gf["ob"] + gf["oc"]) * gf["le"]] = sub[:, c0:c1]
+        return L.tocsr()
+
+    def select(g, block, period, phase, comp, values=None):
+        n = g["nz"] * g["le"]
+        r = np.arange(n)
+        c = r % C
+        nd = r // C
+        i, j, k = nd % g["dx"], (nd // g["dx"]) % g["dy"], nd // (g["dx"] * g["dy"])
+        hit = (c == comp) & ((i // block) % period[0] == phase[0]) & ((j // block) % period[1] == phase[1]) & \
+              (((k + g["g0"]) // block) % period[2] == phase[2])
+        return np.where(hit, 1.0 if values is None else values, 0.0)
+
+    dims = (nx, ny, nzg)
+    gf = geom(nx, ny, per, 1, nzg)
+    A_loc = local_of(Ag, gf)
+    B_loc = Bg[gf["g0"] * gf["le"]:(gf["g0"] + gf["nz"]) * gf["le"]].copy()
+    for level in range(2):
+        P_ref, Ac_ref, norm_ref, cdims, rho_ref = global_level(Ag, Bg, dims)
+        reach_c = (1 + 3 * gf["reach"]) // 2
+        gc = geom(cdims[0], cdims[1], gf["oc"] // 2, reach_c, cdims[2])
+        own_f = slice(gf["ob"] * gf["le"], (gf["ob"] + gf["oc"]) * gf["le"])
+        own_c = slice(gc["ob"] * gc["le"], (gc["ob"] + gc["oc"]) * gc["le"])
+        # rho: max over the owned rows of all ranks
+        d = np.zeros(A_loc.shape[0]); d[own_f] = A_loc.diagonal()[own_f]
+        rho_t = torch.tensor([(abs(A_loc[own_f]).sum(axis=1).A1 / abs(d[own_f])).max()])
+        dist.all_reduce(rho_t, op=dist.ReduceOp.MAX)
+        rho = float(rho_t)
+        assert abs(rho - rho_ref) < 1e-14 * rho_ref
+        wgt = omega / rho
+        # tentative prolongator: t = B / |B|_aggregate on the owned nodes, exchanged to the ghosts
+        r = np.arange(A_loc.shape[0]); nd = r // C
+        i, j, k = nd % gf["dx"], (nd // gf["dx"]) % gf["dy"], nd // (gf["dx"] * gf["dy"])
+        agg_l = ((((k + gf["g0"]) // 2 - gc["g0"]) * gc["dy"] + j // 2) * gc["dx"] + i // 2) * C + r % C
+        own_mask = np.zeros(A_loc.shape[0], bool); own_mask[own_f] = True
+        n2 = np.bincount(agg_l[own_mask], weights=(B_loc * B_loc)[own_mask], minlength=gc["nz"] * gc["le"])
+        t = np.zeros_like(B_loc); t[own_mask] = B_loc[own_mask] / np.sqrt(n2[agg_l[own_mask]])
+        exchange(t, gf)
+        # ---- P by probing: aggregates (1 + reach) apart have disjoint columns
+        gdc = (gc["dx"], gc["dy"], gc["gz"])
+        per_p = [max(1, min(1 + gf["reach"], gdc[dd])) for dd in range(3)]
+        P_loc = sp.lil_matrix((A_loc.shape[0], gc["nz"] * gc["le"]))
+        for oc in range(per_p[0] * per_p[1] * per_p[2]):
+            ph = (oc % per_p[0], (oc // per_p[0]) % per_p[1], oc // (per_p[0] * per_p[1]))
+            for comp in range(C):
+                y = select(gf, 2, per_p, ph, comp, t)
+                z = y - wgt * np.where(own_mask, (A_loc @ y) / np.where(d != 0, d, 1.0), 0.0)
+                for row in np.nonzero(own_mask & (z != 0))[0]:
+                    x_, y_, zg = i[row], j[row], k[row] + gf["g0"]
+                    # the one aggregate of this colour within reach of the row's node
+                    cand = [(I, J, K) for K in range(max(0, (zg - gf["reach"]) // 2), min(gdc[2] - 1, (zg + gf["reach"]) // 2) + 1)
+                            for J in range(max(0, (y_ - gf["reach"]) // 2), min(gdc[1] - 1, (y_ + gf["reach"]) // 2) + 1)
+                            for I in range(max(0, (x_ - gf["reach"]) // 2), min(gdc[0] - 1, (x_ + gf["reach"]) // 2) + 1)
+                            if (I % per_p[0], J % per_p[1], K % per_p[2]) == ph]
+                    assert len(cand) == 1, (row, cand)
+                    I, J, K = cand[0]
+                    P_loc[row, (((K - gc["g0"]) * gc["dy"] + J) * gc["dx"] + I) * C + comp] = z[row]
+        P_loc = P_loc.tocsr()
+        assert abs(P_loc - local_of(P_ref, gf, gc)).max() < 1e-13
+        # ---- A_c = P^T A P by probing: coarse nodes (2 reach_c + 1) apart never meet in a row
+        per_a = [max(1, min(2 * reach_c + 1, gdc[dd])) for dd in range(3)]
+        Ac_loc = sp.lil_matrix((gc["nz"] * gc["le"],) * 2)
+        rc = np.arange(gc["nz"] * gc["le"]); ndc = rc // C
+        X, Y, Z = ndc % gc["dx"], (ndc // gc["dx"]) % gc["dy"], ndc // (gc["dx"] * gc["dy"]) + gc["g0"]
+        own_c_mask = np.zeros(gc["nz"] * gc["le"], bool); own_c_mask[own_c] = True
+        for oc in range(per_a[0] * per_a[1] * per_a[2]):
+            ph = (oc % per_a[0], (oc // per_a[0]) % per_a[1], oc // (per_a[0] * per_a[1]))
+            for comp in range(C):
+                u = select(gc, 1, per_a, ph, comp)
+                wv = P_loc @ u
+                exchange(wv, gf)                      # A reads its ghost layers
+                v = np.where(own_mask, A_loc @ wv, 0.0)
+                yc = P_loc.T @ v                     # partial sums for the neighbours' aggregates in the ghost layers
+                exchange(yc, gc, reverse=True)
+                for row in np.nonzero(own_c_mask & (yc != 0))[0]:
+                    cand = [(I, J, K) for K in range(max(0, Z[row] - reach_c), min(gdc[2] - 1, Z[row] + reach_c) + 1)
+                            for J in range(max(0, Y[row] - reach_c), min(gdc[1] - 1, Y[row] + reach_c) + 1)
+                            for I in range(max(0, X[row] - reach_c), min(gdc[0] - 1, X[row] + reach_c) + 1)
+                            if (I % per_a[0], J % per_a[1], K % per_a[2]) == ph]
+                    assert len(cand) == 1, (row, cand)
+                    I, J, K = cand[0]
+                    Ac_loc[row, (((K - gc["g0"]) * gc["dy"] + J) * gc["dx"] + I) * C + comp] = yc[row]
+        Ac_loc = Ac_loc.tocsr()
+        assert abs(Ac_loc - local_of(Ac_ref, gc)).max() < 1e-12 * abs(Ac_ref).max()
+        # next level
+        Ag, Bg, dims = Ac_ref, norm_ref, cdims
+        A_loc, gf = Ac_loc, gc
+        B_loc = Bg[gf["g0"] * gf["le"]:(gf["g0"] + gf["nz"]) * gf["le"]].copy()
+    if rank == 0:
+        print("protocol checks passed", flush=True)
+
+
 MESHES = {
     # name: (cells per rank along z, (cx, cy), material, amg parameters)
     # small: A_c (768 rows at 2 ranks) is gathered right away: replicated hierarchy behind one all-gather
@@ -268,6 +447,6 @@ if __name__ == "__main__":
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
     try:
-        (mode_cpu if a.mode == "cpu" else mode_gpu)(a)
+        {"cpu": mode_cpu, "gpu": mode_gpu, "protocol": mode_protocol}[a.mode](a)
     finally:
         dist.destroy_process_group()

@@ -55,6 +55,14 @@ def test_distributed_construction_cpu_gloo(mfmg_lib, world):
     assert "cpu distributed checks passed" in _run("cpu", world)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_setup_protocol_cpu_gloo(mfmg_lib, world):
+    """The probing protocol that couples the aggregation levels across ranks (amg_device_setup.hip), restated in numpy on
+    CPU ranks: prolongator and Galerkin operator of two consecutive levels from operator applications and halo exchanges
+    alone, equal to the rows of the globally formed matrices."""
+    assert "protocol checks passed" in _run("protocol", world)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,mesh", [(2, "small"), (3, "small"), (2, "wide"), (2, "deep"), (4, "deep")])
 def test_distributed_library_path_shared_gpu(mfmg_lib, world, mesh):
