@@ -47,12 +47,22 @@ def exchange_np(v, part, layer, owned_begin, owned_count):
         v[(owned_begin + owned_count) * layer:(owned_begin + owned_count + 1) * layer] = bufs["high"].numpy()
 
 
+def _all_reduce_cpu(t):
+    """Sum of a CPU tensor over the ranks (through the GPU when the process group is nccl)."""
+    if dist.get_backend() == "nccl":
+        g = t.cuda()
+        dist.all_reduce(g)
+        t.copy_(g.cpu())
+    else:
+        dist.all_reduce(t)
+    return t
+
+
 def gather_owned(local, part, n_global, sl_local, sl_global):
     """All ranks end up with the global vector assembled from the owned parts."""
     out = torch.zeros(n_global, dtype=torch.float64)
     out[sl_global] = torch.from_numpy(np.ascontiguousarray(local[sl_local]))
-    dist.all_reduce(out)
-    return out.numpy()
+    return _all_reduce_cpu(out).numpy()
 
 
 def mode_cpu(args):
@@ -308,7 +318,9 @@ MESHES = {
 
 def mode_gpu(args):
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
+    # gloo: all ranks share cuda:0 (host transport); nccl: one GPU per rank, the native RCCL transport
+    native = dist.get_backend() == "nccl"
+    torch.cuda.set_device(rank if native else 0)
     per, (cx, cy), material, amg = MESHES[args.mesh]
     cells = (cx, cy, per * world)
     part = M.SlabPartition(cells, rank, world, length=tuple(c / float(cells[0]) for c in cells))   # cubic cells
@@ -317,8 +329,8 @@ def mode_gpu(args):
                    "solver": {"type": "amg", "amg": dict(amg)}, "is preconditioner": False})
     ctx = M.Context()
     tr = M.HaloTransport(ctx, part, 2)
-    assert tr.name() == "host"
-    assert tr.selftest(4096) == 0.0          # loop-back, all-gather, sum / max all-reduce through gloo
+    assert tr.name() == ("rccl" if native else "host")
+    assert tr.selftest(4096) == 0.0          # loop-back, all-gather, sum / max all-reduce through the transport
     h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", part.local_problem(material, "cuda"), params)
     deg, lmin, lmax = h.smoother_info()       # estimated with dot products summed over the ranks
     assert 1.4 < lmax < 2.2, lmax
@@ -372,8 +384,7 @@ def mode_gpu(args):
     def gather_c(v):
         out = torch.zeros(ncg, dtype=torch.float64)
         out[c_glob0 + cb * lay: c_glob0 + (cb + cc) * lay] = v.cpu()[cb * lay:(cb + cc) * lay]
-        dist.all_reduce(out)
-        return out.numpy()
+        return _all_reduce_cpu(out).numpy()
     rl = torch.zeros(ncl, dtype=torch.float64, device="cuda"); rg = torch.empty(ncg, dtype=torch.float64, device="cuda")
     h.restrictor_apply(1, dev(local(xg)), rl); hg.restrictor_apply(1, dev(xg), rg)
     np.testing.assert_allclose(gather_c(rl), rg.cpu().numpy(), rtol=1e-12, atol=1e-13)
@@ -443,9 +454,15 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="cpu")
     ap.add_argument("--mesh", default="small")
+    ap.add_argument("--backend", default="gloo")
     a = ap.parse_args()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("gloo")
+    if a.backend == "nccl":
+        # before any HIP call of this process: pick the rank's GPU
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+    else:
+        dist.init_process_group("gloo")
     try:
         {"cpu": mode_cpu, "gpu": mode_gpu, "protocol": mode_protocol}[a.mode](a)
     finally:

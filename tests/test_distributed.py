@@ -20,10 +20,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(mode, world, timeout=600, mesh="small"):
+def _run(mode, world, timeout=600, mesh="small", backend="gloo"):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--mesh", mesh]
+           os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--mesh", mesh, "--backend", backend]
     env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
@@ -86,3 +86,15 @@ def test_rccl_transport_on_one_gpu(mfmg_lib):
     h.apply(torch.zeros_like(x), x)
     ctx.synchronize()
     assert torch.isfinite(x).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,mesh", [(2, "deep"), (4, "deep")])
+def test_distributed_rccl_one_gpu_per_rank(mfmg_lib, world, mesh):
+    """The same checks with one GPU per rank and the native transport (ncclSend / ncclRecv over xGMI on the library's
+    stream, ncclAllReduce / ncclAllGather for the setup): needs `world` GPUs in the box, skipped otherwise (the pool's
+    test boxes have one; a multi-GPU node runs it).  The worker never counts devices after HIP is initialised: the
+    count is taken here, in the parent, without touching the GPU."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {torch.cuda.device_count()}")
+    assert "gpu distributed checks passed" in _run("gpu", world, mesh=mesh, backend="nccl")
