@@ -535,7 +535,7 @@ def main():
                                f"{world} GPUs, z-slab domain decomposition of a {gx}x{gy}x{gz}-cell box, halo exchange "
                                f"per operator application on every level of the cycle (transport: {transport.name()}, "
                                f"{n_exchanges_per_cycle:.1f} point-to-point exchanges per cycle), aggregation levels coupled "
-                               f"across the ranks, levels below {h.coarse_amg_gather_rows()} rows gathered and solved "
+                               f"across the ranks, the levels from {h.coarse_amg_gather_rows()} global rows down gathered and solved "
                                f"redundantly: the same preconditioner as on one GPU",
                 "global_dofs": n_global,
                 "setup_seconds": t_setup,
