@@ -94,12 +94,14 @@ void dense_lu_solve(HipHandle &handle, int n, double const *lu, int32_t const *p
   if (n <= 0)
     return;
   const int threads = n >= 1024 ? 1024 : (n >= 256 ? 256 : 64);
-  static bool attr_set = false;
-  if (!attr_set)
+  static int attr_device = -1; // (the attribute is per device)
+  int dev = 0;
+  MFMG_HIP_CHECK(hipGetDevice(&dev));
+  if (attr_device != dev)
   {
     MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(dense_lu_solve_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    attr_set = true;
+    attr_device = dev;
   }
   hipLaunchKernelGGL(dense_lu_solve_kernel, dim3(1), dim3(threads), (size_t)n * sizeof(double), handle.stream, n,
                      lu, perm, b, x);
