@@ -103,11 +103,14 @@ def operator_bytes_per_dof(word, compact, survey):
     return 2 * word + (32 if survey else 4) + coef
 
 
-def smoother_bytes_per_dof(n_terms, word, compact, survey):
+def smoother_bytes_per_dof(n_terms, word, compact, survey, dinv_stored=None):
     """Chebyshev smoother apply = n_terms fused operator launches: + b + D^-1 each, + x_prev from the second on.  With one
-    coefficient per cell the layout holds no D^-1 (the kernel derives it from the cell coefficients): not required."""
+    coefficient per cell the layout holds no D^-1 by default (the kernel derives it from the cell coefficients): then it
+    is not a required byte; `dinv_stored` says what the operator at hand does."""
     b_op = operator_bytes_per_dof(word, compact, survey)
-    dinv = 0 if (compact and not survey) else word
+    if dinv_stored is None:
+        dinv_stored = not compact
+    dinv = word if (survey or dinv_stored) else 0
     return (b_op + word + dinv) + (n_terms - 1) * (b_op + 2 * word + dinv)
 
 
@@ -243,14 +246,18 @@ def measure_cell_contraction(ctx, torch, cells, reps=20):
     return out
 
 
-def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=20, warmup=3, tile=None, material="constant"):
+def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=20, warmup=3, tile=None, material="constant",
+                     stored_diagonal=False):
     """Fine-level smoother apply (degree fused operator kernels) on its own: one HIP event pair per apply on the
     kernels' stream, `warmup` untimed applies, then `reps` timed ones; reported: median (the quoted figure), min,
     max.  Rates: `required_GBs` on the bytes the layout makes the kernel read at least (see
     required_bytes_per_dof), `survey_GBs` on the SURVEY.md 8(d) figure (8 index ints and 8 coefficients per DoF)."""
     prob = M.LaplaceProblem((n_dofs_per_dim - 1,) * 3, material, device="cuda")
+    ctx.set_stored_diagonal(stored_diagonal)
     op = M.MatrixFreeLaplace(ctx, prob)
+    ctx.set_stored_diagonal(False)
     compact = op.cell_constant_layout()
+    dinv_stored = op.diagonal_in_record()
     if tile:
         op.set_tile(*tile)
     N = prob.n_dofs
@@ -283,10 +290,11 @@ def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=20, warmup=3, t
     ts = sorted(ev[r].elapsed_time(ev[r + 1]) for r in range(reps))
     ms = ts[len(ts) // 2]
     survey = smoother_bytes_per_dof(len(coefs), 8, compact, survey=True)
-    required = smoother_bytes_per_dof(len(coefs), 8, compact, survey=False)
-    traffic = committed_traffic(n_dofs_per_dim, degree, compact, op.get_tile(), prefix="dofs")
+    required = smoother_bytes_per_dof(len(coefs), 8, compact, survey=False, dinv_stored=dinv_stored)
+    traffic = committed_traffic(n_dofs_per_dim, degree, compact, op.get_tile(), prefix="dofs") if dinv_stored == (not compact) else None
     return {"n_dofs": N, "degree": degree, "material": material,
             "coefficient_layout": "one value per cell" if compact else "eight values per cell",
+            "diagonal": "D^-1 stored in the chunk records" if dinv_stored else "D^-1 derived in the kernel from the cell coefficients (not read)",
             "tile_waves_ty_tz": list(op.get_tile()),
             "hbm_traffic_bytes_per_launch_pmc": traffic,
             "hbm_traffic_GBs": (traffic * len(coefs) / (ms * 1e-3) / 1e9) if traffic else None,
@@ -592,9 +600,13 @@ def main():
         # ---- north_star target legs first (GPU warm, allocator state of the headline run): fine-level smoother
         #      apply at 512^3 DoFs, both coefficient layouts
         if world == 1 and not args.no_smoother_512:
-            for mat, key in (("constant", "smoother_apply_512cubed"), ("linear", "smoother_apply_512cubed_general_coefficient")):
+            # (the default cell-constant layout derives D^-1 in the kernel: fewer bytes, faster, and a lower byte RATE; the
+            #  variant that keeps D^-1 in the records is measured beside it)
+            for mat, key, stored in (("constant", "smoother_apply_512cubed", False),
+                                     ("constant", "smoother_apply_512cubed_stored_diagonal", True),
+                                     ("linear", "smoother_apply_512cubed_general_coefficient", False)):
                 try:
-                    out[key] = measure_smoother(ctx, torch, M, 512, args.degree, tile=tile, material=mat)
+                    out[key] = measure_smoother(ctx, torch, M, 512, args.degree, tile=tile, material=mat, stored_diagonal=stored)
                 except Exception as e:  # noqa: BLE001 - report, do not hide the main result
                     out[key] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline and not assembled:

@@ -109,6 +109,11 @@ int mfmg_hip_context_set_overlap_exchange(mfmg_hip_context_t ctx, int enable);
  * (material_property constant, the reference's default, or any cell-wise constant material) keep ONE value per
  * cell (20 instead of 76 bytes per cell in FP64; default on).  Off forces the general eight-value layout. */
 int mfmg_hip_context_set_cell_constant_layout(mfmg_hip_context_t ctx, int enable);
+/* With one coefficient per cell the diagonal of a DoF is kd * (sum of the coefficients of its eight cells); by default the
+ * operator kernel derives D^-1 from that on the fly and the chunk records hold no D^-1 (8 bytes per DoF and smoother launch
+ * less to read, 768 instead of 1280 B per chunk).  enable != 0: operators created afterwards keep D^-1 in the records. */
+int mfmg_hip_context_set_stored_diagonal(mfmg_hip_context_t ctx, int enable);
+int mfmg_hip_mf_laplace_diagonal_in_record(mfmg_hip_mf_laplace_t op, int *in_record);
 /* Hierarchies created afterwards form the coarse operator R A R^T of a matrix-free A on the device by probing
  * (27 n_eig applications of R^T, A and R over colour classes of agglomerates; the reference's fast_ap idea,
  * source/dealii/dealii_matrix_free_hierarchy_helpers.cc:77-288) -- the default where the restrictor has the block

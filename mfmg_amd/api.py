@@ -78,6 +78,10 @@ class Context:
         """Operators created afterwards keep one coefficient per cell when a cell's eight are equal (default on)."""
         check(self._lib.mfmg_hip_context_set_cell_constant_layout(self.handle, int(bool(enable))))
 
+    def set_stored_diagonal(self, enable: bool):
+        """Cell-constant operators created afterwards keep D^-1 in their chunk records (default: derived in the kernel)."""
+        check(self._lib.mfmg_hip_context_set_stored_diagonal(self.handle, int(bool(enable))))
+
     def set_galerkin_on_device(self, enable: bool):
         """Hierarchies created afterwards form R A R^T of a matrix-free A by probing on the device (default) or on the host."""
         check(self._lib.mfmg_hip_context_set_galerkin_on_device(self.handle, int(bool(enable))))
@@ -293,6 +297,11 @@ class MatrixFreeLaplace:
     def cell_constant_layout(self) -> bool:
         v = C.c_int()
         check(self._lib.mfmg_hip_mf_laplace_cell_constant_layout(self.handle, C.byref(v)))
+        return bool(v.value)
+
+    def diagonal_in_record(self) -> bool:
+        v = C.c_int()
+        check(self._lib.mfmg_hip_mf_laplace_diagonal_in_record(self.handle, C.byref(v)))
         return bool(v.value)
 
     def get_tile(self):

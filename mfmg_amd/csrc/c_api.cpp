@@ -266,6 +266,20 @@ int mfmg_hip_context_set_cell_constant_layout(mfmg_hip_context_t ctx, int enable
     ctx->handle->allow_cell_constant = enable != 0;
   });
 }
+int mfmg_hip_context_set_stored_diagonal(mfmg_hip_context_t ctx, int enable)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    ctx->handle->stored_diagonal = enable != 0;
+  });
+}
+int mfmg_hip_mf_laplace_diagonal_in_record(mfmg_hip_mf_laplace_t op, int *in_record)
+{
+  return guarded([&] {
+    require(op && in_record, "null argument");
+    *in_record = op->op->diagonal_in_record() ? 1 : 0;
+  });
+}
 int mfmg_hip_context_set_galerkin_on_device(mfmg_hip_context_t ctx, int enable)
 {
   return guarded([&] {

@@ -298,6 +298,9 @@ struct HipHandle
   bool overlap_exchange = true;
   // matrix-free operators built from this handle may keep one coefficient per cell when a cell's eight are equal
   bool allow_cell_constant = true;
+  // ... and then keep D^-1 in the chunk records (8 more bytes per DoF and smoother launch) instead of deriving it
+  // in the kernel from the cell coefficients
+  bool stored_diagonal = false;
   // R A R^T of a matrix-free A by probing on the device (hip_hierarchy.hip, HipMatrixOperator::multiply) instead of
   // the host triple product
   bool galerkin_on_device = true;

@@ -64,6 +64,8 @@ struct MfArgs
   T kd;                           // ... and the diagonal entry of the reference cell matrix: diag = kd * sum of the 8 cell coefficients
   T alpha, beta;
   int mode;
+  unsigned int rec_bytes;  // bytes of one chunk record
+  int dinv_in_record;      // D^-1 is part of the record (always for eight coefficients per cell)
 };
 
 namespace
@@ -84,10 +86,11 @@ struct Rec
   static constexpr size_t kCoefOff = 256;                             // after the own ids
   static constexpr size_t kCoefBytes = CC ? 64 * sizeof(T) : (size_t)NP * 1024;
   static constexpr size_t kDinvOff = kCoefOff + kCoefBytes;           // after the coefficients (general layout only)
-  // FP64: 4864 B general, 768 B cell-constant.  The cell-constant record has no D^-1: with one coefficient per cell the
-  // diagonal of a DoF is kd * (sum of the coefficients of the eight cells around it), and the kernel forms that sum on
-  // the fly with the same lane / row / layer combines that assemble A x (8 bytes per DoF and launch less to read)
-  static constexpr size_t kBytes = CC ? kDinvOff : kDinvOff + 64 * sizeof(T);
+  // FP64: 4864 B general, 768 B cell-constant (1280 with D^-1).  By default the cell-constant record has no D^-1: with
+  // one coefficient per cell the diagonal of a DoF is kd * (sum of the coefficients of the eight cells around it), and the
+  // kernel forms that sum on the fly with the same lane / row / layer combines that assemble A x (8 bytes per DoF and
+  // launch less to read); mfmg_hip_context_set_stored_diagonal keeps the stored form
+  static constexpr size_t bytes(bool with_dinv) { return with_dinv ? kDinvOff + 64 * sizeof(T) : kDinvOff; }
 };
 
 
@@ -345,7 +348,7 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
   T *xport = reinterpret_cast<T *>(smem_raw) + (size_t)NW * (3 * TY + 1) * 64; // [2][NW][3][64]
   int *idz = reinterpret_cast<int *>(xport + (size_t)2 * NW * 3 * 64) + (size_t)wv * (TY + 1) * 64;
   // D^-1 on the fly (cell-constant layout, smoother modes): diag = kd * sum of the coefficients of the 8 cells of a DoF
-  const bool make_dinv = CC && a.mode >= 2;
+  const bool make_dinv = CC && a.mode >= 2 && !a.dinv_in_record;
 
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8,
   // observed, speed only); give every XCD a contiguous run of the tile list.
@@ -366,9 +369,9 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
   const int Z0 = tzi * a.TZ;
   const bool col_owned = lane >= 1 && lane <= kOwn && ci < a.Nx;
   const int jj0 = (Yb < 0) ? 1 : 0; // cell row -1 does not exist (its sums are the zero initial carries)
-  const size_t rec_row = (size_t)a.ncols * Rec<T, CC>::kBytes;
+  const size_t rec_row = (size_t)a.ncols * a.rec_bytes;
   const size_t rec_layer = (size_t)a.Ny * rec_row;
-  unsigned char const *rec_col = a.rec + (size_t)tc * Rec<T, CC>::kBytes;
+  unsigned char const *rec_col = a.rec + (size_t)tc * a.rec_bytes;
   const bool have_rows = (jj0 < TY) && (Yb + jj0 < a.Ny);
   CellFactors<T> fac;
   fac.fx = a.fx;
@@ -438,9 +441,8 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
         // epilogue operands of the deferred row (its id has been in LDS since the previous pass)
         const unsigned int g = id_off<T>(idAf);
         dlb = ld_off<T>(a.b, g);
-        if constexpr (!CC)
-          if (a.mode >= 2)
-            dld = reinterpret_cast<T const *>(rec_k + (size_t)jf * rec_row + Rec<T, CC>::kDinvOff)[lane];
+        if (a.mode >= 2 && a.dinv_in_record)
+          dld = reinterpret_cast<T const *>(rec_k + (size_t)jf * rec_row + Rec<T, CC>::kDinvOff)[lane];
         if (a.mode == 3)
           dlx = ld_off<T>(a.xprev, g);
       }
@@ -505,9 +507,8 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
           // the DoF row this cell row completes: node row jj, id = the layer-k id of the previous node row
           const unsigned int gid = id_off<T>((b == 0 || !ok[b > 0 ? b - 1 : 0]) ? id0 : idA[b > 0 ? b - 1 : 0]);
           lb[b] = ld_off<T>(a.b, gid);
-          if constexpr (!CC)
-            if (a.mode >= 2)
-              ld[b] = reinterpret_cast<T const *>(recp + Rec<T, CC>::kDinvOff)[lane];
+          if (a.mode >= 2 && a.dinv_in_record)
+            ld[b] = reinterpret_cast<T const *>(recp + Rec<T, CC>::kDinvOff)[lane];
           if (a.mode == 3)
             lxp[b] = ld_off<T>(a.xprev, gid);
         }
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> am, MfArgs<T>
 template <typename T, bool CC>
 __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coefficient,
                                  uint8_t const *constrained, int Nx, int Ny, int Nz, int ncols,
-                                 unsigned char *rec)
+                                 unsigned char *rec, size_t rec_bytes, int with_dinv)
 {
   const int64_t n_slots = (int64_t)ncols * Nz * Ny * 64;
   const int nx = Nx - 1, ny = Ny - 1, nz = Nz - 1;
@@ -705,7 +706,7 @@ __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coeffic
         cf[m] = real ? T(coefficient[(i + (int64_t)nx * (j + (int64_t)ny * k)) * 8 + m]) : T(0);
       }
     }
-    unsigned char *r = rec + (size_t)chunk * Rec<T, CC>::kBytes;
+    unsigned char *r = rec + (size_t)chunk * rec_bytes;
     reinterpret_cast<int *>(r)[lane] = id[0];
     if constexpr (CC)
       reinterpret_cast<T *>(r + Rec<T, CC>::kCoefOff)[lane] = cf[0];
@@ -713,7 +714,7 @@ __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coeffic
       for (int p = 0; p < NP; ++p)
         for (int w = 0; w < W; ++w)
           reinterpret_cast<T *>(r + Rec<T, CC>::kCoefOff + p * 1024)[lane * W + w] = cf[p * W + w];
-    if constexpr (!CC)
+    if (with_dinv)
       reinterpret_cast<T *>(r + Rec<T, CC>::kDinvOff)[lane] = T(0);
   }
 }
@@ -772,7 +773,7 @@ struct DiagTable
 // compute_diagonal (tests/laplace_matrix_free.hpp:75-98,158-199): per-cell
 // unit-vector applies summed per DoF; constrained entries set to one.
 template <typename T, bool CC>
-__global__ void mf_diagonal_kernel(unsigned char const *rec, int Nx, int Ny, int Nz, int ncols,
+__global__ void mf_diagonal_kernel(unsigned char const *rec, size_t rec_bytes, int Nx, int Ny, int Nz, int ncols,
                                    DiagTable tab, T *diag, T *dinv)
 {
   const int64_t n = (int64_t)Nx * Ny * Nz;
@@ -784,7 +785,7 @@ __global__ void mf_diagonal_kernel(unsigned char const *rec, int Nx, int Ny, int
     const int k = t / ((int64_t)Nx * Ny);
     int lane;
     const size_t r = chunk_of(i, j, k, Ny, ncols, lane);
-    const int id0 = reinterpret_cast<int const *>(rec + r * Rec<T, CC>::kBytes)[lane];
+    const int id0 = reinterpret_cast<int const *>(rec + r * rec_bytes)[lane];
     double sum = 0.;
     for (int m = 0; m < 8; ++m)
     {
@@ -794,7 +795,7 @@ __global__ void mf_diagonal_kernel(unsigned char const *rec, int Nx, int Ny, int
       T c[8];
       int cl;
       const size_t cr = chunk_of(ci, cj, ck, Ny, ncols, cl);
-      load_coef<T, CC>(rec + cr * Rec<T, CC>::kBytes, cl, c);
+      load_coef<T, CC>(rec + cr * rec_bytes, cl, c);
       for (int q = 0; q < 8; ++q)
         sum += (double)c[q] * tab.K[q][m];
     }
@@ -822,7 +823,7 @@ __global__ void mf_cell_constant_kernel(double const *coefficient, int64_t n_cel
 // copy of D^-1 in slot order inside the records (every slot of a real DoF, the duplicated halo slots too)
 template <typename T, bool CC>
 __global__ void mf_fill_dinv_kernel(T const *dinv, int Nx, int ncols, int64_t n_slots,
-                                    unsigned char *rec)
+                                    unsigned char *rec, size_t rec_bytes)
 {
   for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n_slots;
        s += (int64_t)gridDim.x * blockDim.x)
@@ -832,10 +833,9 @@ __global__ void mf_fill_dinv_kernel(T const *dinv, int Nx, int ncols, int64_t n_
     const int i = (int)(chunk % ncols) * kOwn - 1 + lane;
     if (i < 0 || i >= Nx)
       continue;
-    unsigned char *r = rec + (size_t)chunk * Rec<T, CC>::kBytes;
+    unsigned char *r = rec + (size_t)chunk * rec_bytes;
     const unsigned int g = (unsigned int)reinterpret_cast<int const *>(r)[lane] & kIdMask;
-    if constexpr (!CC)
-      reinterpret_cast<T *>(r + Rec<T, CC>::kDinvOff)[lane] = dinv[g];
+    reinterpret_cast<T *>(r + Rec<T, CC>::kDinvOff)[lane] = dinv[g];
   }
 }
 } // namespace
@@ -933,7 +933,9 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
                      bad.data());
   MFMG_HIP_CHECK(hipGetLastError());
   _compact = allow_compact && bad.download(st)[0] == 0;
-  _rec.resize((n_slots / 64) * (_compact ? Rec<T, true>::kBytes : Rec<T, false>::kBytes));
+  _dinv_in_record = !_compact || handle.stored_diagonal;
+  _rec_bytes = _compact ? Rec<T, true>::bytes(_dinv_in_record) : Rec<T, false>::bytes(true);
+  _rec.resize((n_slots / 64) * _rec_bytes);
   MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
   hipLaunchKernelGGL(mf_range_kernel, dim3(n_blocks_for(nc * 8, 256, 1 << 16)), dim3(256), 0, st, cd, nc * 8, nd,
                      bad.data());
@@ -942,15 +944,15 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
                                          "order (DoF ids out of range)");
   if (_compact)
     hipLaunchKernelGGL((mf_repack_kernel<T, true>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, cd,
-                       co, cn, _N[0], _N[1], _N[2], _ncols, _rec.data());
+                       co, cn, _N[0], _N[1], _N[2], _ncols, _rec.data(), _rec_bytes, _dinv_in_record ? 1 : 0);
   else
     hipLaunchKernelGGL((mf_repack_kernel<T, false>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, cd,
-                       co, cn, _N[0], _N[1], _N[2], _ncols, _rec.data());
+                       co, cn, _N[0], _N[1], _N[2], _ncols, _rec.data(), _rec_bytes, _dinv_in_record ? 1 : 0);
   MFMG_HIP_CHECK(hipGetLastError());
 
   MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
   hipLaunchKernelGGL(mf_validate_kernel, dim3(n_blocks_for(nc, 256, 1 << 16)), dim3(256), 0, st, cd,
-                     _rec.data(), _compact ? Rec<T, true>::kBytes : Rec<T, false>::kBytes, _N[0], _N[1], _N[2], _ncols, _n_dofs,
+                     _rec.data(), _rec_bytes, _N[0], _N[1], _N[2], _ncols, _n_dofs,
                      bad.data());
   MFMG_HIP_CHECK(hipGetLastError());
   int n_bad = bad.download(st)[0];
@@ -985,16 +987,17 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   if (_compact)
   {
     hipLaunchKernelGGL((mf_diagonal_kernel<T, true>), dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
-                       _rec.data(), _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
-    hipLaunchKernelGGL((mf_fill_dinv_kernel<T, true>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st,
-                       _dinv.data(), _N[0], _ncols, (int64_t)n_slots, _rec.data());
+                       _rec.data(), _rec_bytes, _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
+    if (_dinv_in_record)
+      hipLaunchKernelGGL((mf_fill_dinv_kernel<T, true>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st,
+                         _dinv.data(), _N[0], _ncols, (int64_t)n_slots, _rec.data(), _rec_bytes);
   }
   else
   {
     hipLaunchKernelGGL((mf_diagonal_kernel<T, false>), dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
-                       _rec.data(), _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
+                       _rec.data(), _rec_bytes, _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
     hipLaunchKernelGGL((mf_fill_dinv_kernel<T, false>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st,
-                       _dinv.data(), _N[0], _ncols, (int64_t)n_slots, _rec.data());
+                       _dinv.data(), _N[0], _ncols, (int64_t)n_slots, _rec.data(), _rec_bytes);
   }
   MFMG_HIP_CHECK(hipGetLastError());
   MFMG_HIP_CHECK(hipStreamSynchronize(st));
@@ -1117,6 +1120,8 @@ bool MatrixFreeLaplaceDevice<T>::make_args(MfArgs<T> &a, unsigned int &n_blocks,
   a.alpha = alpha;
   a.beta = beta;
   a.mode = static_cast<int>(mode);
+  a.rec_bytes = (unsigned int)_rec_bytes;
+  a.dinv_in_record = _dinv_in_record ? 1 : 0;
   a.ncols = _ncols;
   a.ncols_active = _tail ? _ncols - 1 : _ncols;
   // ty cell rows per wavefront, nw ty - 1 owned DoF rows per workgroup

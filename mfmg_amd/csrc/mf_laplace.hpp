@@ -37,6 +37,7 @@ public:
   MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_mesh_desc const &mesh, bool allow_compact = true,
                           bool sub_mesh = false);
   bool cell_constant_layout() const { return _compact; }
+  bool diagonal_in_record() const { return _dinv_in_record; }
 
   int64_t n_dofs() const { return _n_dofs; }
   int dof_grid(int d) const { return _N[d]; }
@@ -99,7 +100,7 @@ public:
   double epilogue_bytes(int mode) const
   {
     const double w = sizeof(T) * double(_n_dofs);
-    return mode == 0 ? 0. : mode == 1 ? w : (mode == 2 ? 1. : 2.) * w + (_compact ? 0. : w);
+    return mode == 0 ? 0. : mode == 1 ? w : (mode == 2 ? 1. : 2.) * w + (_dinv_in_record ? w : 0.);
   }
 
 private:
@@ -126,5 +127,7 @@ private:
   DeviceBuffer<T> _diag, _dinv;
   int _tile_y = 0, _tile_z = 0, _tile_waves = 0;
   bool _compact = false;
+  bool _dinv_in_record = true; // D^-1 is part of the chunk records (always for eight coefficients per cell)
+  size_t _rec_bytes = 0;
 };
 } // namespace mfmg

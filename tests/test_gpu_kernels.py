@@ -101,6 +101,22 @@ def test_mf_fused_epilogues(ctx, n, material, tile):
     op = M.MatrixFreeLaplace(ctx, M.LaplaceProblem(n, material, device="cuda"))
     if tile:
         op.set_tile(*tile)
+    if material == "constant":
+        # the cell-constant layout derives D^-1 in the kernel by default; the stored form must give the same smoother step
+        assert not op.diagonal_in_record()
+        ctx.set_stored_diagonal(True)
+        op_s = M.MatrixFreeLaplace(ctx, M.LaplaceProblem(n, material, device="cuda"))
+        ctx.set_stored_diagonal(False)
+        assert op_s.diagonal_in_record()
+        if tile:
+            op_s.set_tile(*tile)
+        r0 = np.random.default_rng(4)
+        xs, bs, xps = r0.random(mesh.n_dofs), r0.random(mesh.n_dofs), r0.random(mesh.n_dofs)
+        o1 = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
+        o2 = torch.empty_like(o1)
+        op.smoother_step(dev(bs), dev(xs), dev(xps), 0.3, 0.45, o1)
+        op_s.smoother_step(dev(bs), dev(xs), dev(xps), 0.3, 0.45, o2)
+        assert relerr(host(o1, ctx), host(o2, ctx)) < 1e-14
     rng = np.random.default_rng(3)
     x, b, xp = rng.random(mesh.n_dofs), rng.random(mesh.n_dofs), rng.random(mesh.n_dofs)
     out = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
