@@ -117,7 +117,8 @@ int mfmg_hip_mf_laplace_diagonal_in_record(mfmg_hip_mf_laplace_t op, int *in_rec
 /* Hierarchies created afterwards form the coarse operator R A R^T of a matrix-free A on the device by probing
  * (27 n_eig applications of R^T, A and R over colour classes of agglomerates; the reference's fast_ap idea,
  * source/dealii/dealii_matrix_free_hierarchy_helpers.cc:77-288) -- the default where the restrictor has the block
- * structure and the run is not distributed; 0: the host triple product.  Same matrix to rounding. */
+ * structure, distributed runs included (colours on global coordinates, every rank keeps its own rows); 0: the host
+ * triple product.  Same matrix to rounding. */
 int mfmg_hip_context_set_galerkin_on_device(mfmg_hip_context_t ctx, int enable);
 /* layout of a distributed space after the hierarchy was built: entries per layer, local layers, owned range;
  * mfmg_hip_context_halo_space adds {global index of local layer 0, global layers, exchange width, number of spaces} */

@@ -287,10 +287,12 @@ std::shared_ptr<Operator<DVector>> HipMatrixOperator::multiply(std::shared_ptr<O
     ASSERT_THROW(half->get_r()->get_matrix() == _matrix, "the Galerkin product needs the same restrictor on both sides");
     auto evaluator = half->get_a()->get_mesh_evaluator();
     HipHandle &hd = _matrix->handle();
-    // (ghost nodes -- flag 2, the local mesh of one rank of a distributed run -- are rows the device operator does not
-    // form: those meshes keep the host product, which builds the rows of the owned agglomerates from the cell data)
-    bool ghosts = hd.comm.enabled();
-    if (!ghosts)
+    // Distributed runs: the same probing with the colours taken on GLOBAL agglomerate coordinates; the applications of
+    // R^T, A and R refresh their ghost layers by themselves, and a rank keeps the rows of the agglomerates it owns.
+    // (A mesh with ghost nodes but no communicator -- one rank's local problem run alone -- keeps the host product.)
+    const bool distributed = hd.comm.enabled() && _range_space > 0;
+    bool ghosts = false;
+    if (!hd.comm.enabled())
       for (uint8_t f : evaluator->get_mesh().constrained)
         if (f == 2)
         {
@@ -307,7 +309,17 @@ std::shared_ptr<Operator<DVector>> HipMatrixOperator::multiply(std::shared_ptr<O
       // 27 n_eig operator applications instead of one per coarse column.
       const int ne = _structured->n_eigenvectors();
       const int na[3] = {_structured->agglomerates(0), _structured->agglomerates(1), _structured->agglomerates(2)};
-      const int k[3] = {std::min(3, na[0]), std::min(3, na[1]), std::min(3, na[2])};
+      // z: period and phase on the global layer index (local layer + zoff), rows of the owned layers only
+      int64_t zoff = 0, z_own0 = 0, z_own1 = na[2], z_glob = na[2];
+      if (distributed)
+      {
+        HaloSpace const &cs = hd.comm.spaces[_range_space];
+        zoff = cs.global_begin;
+        z_own0 = cs.owned_begin;
+        z_own1 = cs.owned_begin + cs.owned_count;
+        z_glob = cs.global_layers;
+      }
+      const int k[3] = {std::min(3, na[0]), std::min(3, na[1]), (int)std::min<int64_t>(3, z_glob)};
       const int64_t n_agg = (int64_t)na[0] * na[1] * na[2], nc = n_agg * ne;
       ASSERT_THROW(nc == _matrix->m(), "agglomerate grid does not match the restrictor");
       const int n_colors = k[0] * k[1] * k[2] * ne;
@@ -320,7 +332,7 @@ std::shared_ptr<Operator<DVector>> HipMatrixOperator::multiply(std::shared_ptr<O
         {
           const int e0 = color % ne, oc = color / ne;
           const int o[3] = {oc % k[0], (oc / k[0]) % k[1], oc / (k[0] * k[1])};
-          vec::probing_vector(hd, na, ne, k, o, e0, u->get_values());
+          vec::probing_vector(hd, na, ne, k, o, e0, u->get_values(), (int)zoff);
           half->apply(*u, *w);
           this->apply(*w, *y);
           MFMG_HIP_CHECK(hipMemcpyAsync(Y[color].data(), y->get_values(), sizeof(double) * nc, hipMemcpyDeviceToHost,
@@ -340,13 +352,19 @@ std::shared_ptr<Operator<DVector>> HipMatrixOperator::multiply(std::shared_ptr<O
               const int bx = ax + dx, by = ay + dy, bz = az + dz;
               if (bx < 0 || bx >= na[0] || by < 0 || by >= na[1] || bz < 0 || bz >= na[2])
                 continue;
-              visit(bx + (int64_t)na[0] * (by + (int64_t)na[1] * bz), (bx % k[0]) + k[0] * ((by % k[1]) + k[1] * (bz % k[2])));
+              visit(bx + (int64_t)na[0] * (by + (int64_t)na[1] * bz),
+                    (bx % k[0]) + k[0] * ((by % k[1]) + k[1] * (int)((bz + zoff) % k[2])));
             }
+      };
+      auto owned = [&](int64_t a) {
+        const int64_t az = a / ((int64_t)na[0] * na[1]);
+        return az >= z_own0 && az < z_own1;
       };
       for (int64_t a = 0; a < n_agg; ++a)
       {
         int count = 0;
-        neighbours(a, [&](int64_t, int) { ++count; });
+        if (owned(a)) // (rows of the neighbours' agglomerates stay empty: a rank applies only its own rows)
+          neighbours(a, [&](int64_t, int) { ++count; });
         for (int e = 0; e < ne; ++e)
           Ac.row_ptr[a * ne + e + 1] = count * ne;
       }
@@ -361,6 +379,8 @@ std::shared_ptr<Operator<DVector>> HipMatrixOperator::multiply(std::shared_ptr<O
       for (int64_t a = 0; a < n_agg; ++a)
         for (int e = 0; e < ne; ++e)
         {
+          if (!owned(a))
+            continue;
           const int64_t r = a * ne + e;
           int p = Ac.row_ptr[r];
           neighbours(a, [&](int64_t b, int oc) {

@@ -49,7 +49,7 @@ __global__ void scaled_pointwise_kernel(int64_t n, T s, T const *d, T const *v, 
 }
 
 __global__ void probing_vector_kernel(int nx, int ny, int nz, int n_eig, int kx, int ky, int kz, int ox, int oy, int oz,
-                                      int e0, double *u)
+                                      int e0, double *u, int z_offset)
 {
   const int64_t n = (int64_t)nx * ny * nz * n_eig;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -57,7 +57,7 @@ __global__ void probing_vector_kernel(int nx, int ny, int nz, int n_eig, int kx,
     const int e = (int)(i % n_eig);
     const int64_t ag = i / n_eig;
     const int ax = (int)(ag % nx), ay = (int)((ag / nx) % ny), az = (int)(ag / ((int64_t)nx * ny));
-    u[i] = (e == e0 && ax % kx == ox && ay % ky == oy && az % kz == oz) ? 1. : 0.;
+    u[i] = (e == e0 && ax % kx == ox && ay % ky == oy && (az + z_offset) % kz == oz) ? 1. : 0.;
   }
 }
 
@@ -218,13 +218,13 @@ void scaled_pointwise(HipHandle &h, int64_t n, T s, T const *d, T const *v, T *o
   MFMG_HIP_CHECK(hipGetLastError());
 }
 
-void probing_vector(HipHandle &h, int const na[3], int n_eig, int const k[3], int const o[3], int e0, double *u)
+void probing_vector(HipHandle &h, int const na[3], int n_eig, int const k[3], int const o[3], int e0, double *u, int z_offset)
 {
   const int64_t n = (int64_t)na[0] * na[1] * na[2] * n_eig;
   if (n <= 0)
     return;
   hipLaunchKernelGGL(probing_vector_kernel, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, na[0], na[1], na[2],
-                     n_eig, k[0], k[1], k[2], o[0], o[1], o[2], e0, u);
+                     n_eig, k[0], k[1], k[2], o[0], o[1], o[2], e0, u, z_offset);
   MFMG_HIP_CHECK(hipGetLastError());
 }
 

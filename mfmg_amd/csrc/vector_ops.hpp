@@ -25,7 +25,8 @@ void scaled_pointwise(HipHandle &h, int64_t n, T s, T const *d, T const *v, T *o
 
 // probing vector of the Galerkin product on device: u[(a, e)] = 1 where e == e0 and the agglomerate a (x fastest on a
 // grid na) has a_d mod k_d == o_d in every direction, else 0
-void probing_vector(HipHandle &h, int const na[3], int n_eig, int const k[3], int const o[3], int e0, double *u);
+// (z_offset: global index of the local agglomerate layer 0 in a distributed run)
+void probing_vector(HipHandle &h, int const na[3], int n_eig, int const k[3], int const o[3], int e0, double *u, int z_offset = 0);
 
 // out[r] = in[r] (1 when in is null) on the rows r = node * n_comp + comp of the nodes whose block coordinates
 // (node / block; z taken globally: z_local + z_offset) are congruent to `phase` modulo `period`, with comp == `comp`;
