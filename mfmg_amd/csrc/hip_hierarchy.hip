@@ -952,8 +952,18 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
     // setup "device": matrices of the hierarchy read off from operator applications on the device (probing), the
     // levels coupled across the ranks of a distributed run; "host": SpGEMM on the host cores (one rank only)
     // (default: the device wherever its preconditions hold -- one code path for one and for many ranks)
-    const bool device_ok = local_grid.valid(n) && opts.smooth_prolongator && local_grid.block[0] == 2 &&
-                           opts.deep_level >= (1 << 30) && std::all_of(b0.begin(), b0.end(), [](double v) { return v != 0.; });
+    bool device_ok = local_grid.valid(n) && opts.smooth_prolongator && local_grid.block[0] == 2 &&
+                     opts.deep_level >= (1 << 30) && std::all_of(b0.begin(), b0.end(), [](double v) { return v != 0.; });
+    if (device_ok)
+    {
+      // node-major rows with the same number of components on every node (an agglomerate that yields fewer eigenvectors
+      // breaks the pattern: such hierarchies keep the host setup)
+      const int ncomp = std::max(local_grid.n_components, 1);
+      device_ok = n % ncomp == 0;
+      for (int64_t r = 0; device_ok && r < n; ++r)
+        device_ok = local_grid.node_of_row[r] == r / ncomp &&
+                    (local_grid.component_of_row.empty() ? 0 : local_grid.component_of_row[r]) == r % ncomp;
+    }
     std::string const setup = to_lower(this->_params->get("solver.amg.setup", (distributed || device_ok) ? "device" : "host"));
     ASSERT_THROW(setup == "device" || setup == "host", "solver.amg.setup must be device or host");
     if (distributed || setup == "device")
