@@ -1,0 +1,42 @@
+"""bench.py's byte accounting (no GPU): the figures roofline.achieved is priced on."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_operator_bytes_per_dof():
+    # x + y + 8 index ints + 8 coefficients
+    assert bench.operator_bytes_per_dof(8, False, True) == 112
+    assert bench.operator_bytes_per_dof(8, True, True) == 56
+    assert bench.operator_bytes_per_dof(4, False, True) == 72
+    # what the chunk-record layout requires: one id
+    assert bench.operator_bytes_per_dof(8, False, False) == 84
+    assert bench.operator_bytes_per_dof(8, True, False) == 28
+
+
+def test_smoother_bytes_per_dof():
+    # SURVEY.md 8(d), fused form: B_op + b + D^-1 (+ x_prev from the second term on)
+    assert bench.smoother_bytes_per_dof(3, 8, False, True) == 128 + 136 + 136
+    assert bench.smoother_bytes_per_dof(3, 8, True, True) == 72 + 80 + 80
+    # required: eight coefficients per cell keep D^-1 in the records
+    assert bench.smoother_bytes_per_dof(3, 8, False, False) == 100 + 108 + 108
+    # one coefficient per cell: D^-1 derived in the kernel by default, stored on request
+    assert bench.smoother_bytes_per_dof(3, 8, True, False) == 36 + 44 + 44
+    assert bench.smoother_bytes_per_dof(3, 8, True, False, dinv_stored=True) == 44 + 52 + 52
+    assert bench.smoother_bytes_per_dof(1, 8, True, False) == 36      # Jacobi
+
+
+def test_chebyshev_coefficients_first_term():
+    c = bench.smoother_coefficients(3, 0.09, 1.8)
+    assert len(c) == 3 and c[0][0] == 0.0 and abs(c[0][1] - 1.0 / 0.945) < 1e-15
+    assert len(bench.smoother_coefficients(1, 0.09, 1.8)) == 1
+
+
+def test_traffic_file_is_keyed_on_workload_and_tile():
+    assert bench.committed_traffic(256, 3, True, (4, 3, 8)) is not None
+    assert bench.committed_traffic(256, 3, True, (4, 3, 7)) is None      # another tile: no figure
+    assert bench.committed_traffic(128, 3, True, (4, 3, 8)) is None      # another workload
+    assert bench.committed_traffic(512, 3, False, (8, 2, 16), prefix="dofs") is not None
