@@ -354,7 +354,7 @@ def test_smoother_bounds_on_large_lexicographic_meshes(ctx, cells):
     consecutive ids is a low-discrepancy sequence (smooth in index space): on a 65 x 129 x 129 mesh it gave
     lambda_max = 1.41 where the truth is 1.5, and the cycle contracted at 0.78 instead of 0.2.  The splitmix64 finaliser
     must not under-estimate on such meshes."""
-    prob = M.LaplaceProblem(cells, device="cuda")
+    prob = M.LaplaceProblem(cells, device="cuda", cell_size=(1.0 / 64,) * 3)       # cubic cells: lambda_max(D^-1 A) = 1.5
     op = M.MatrixFreeLaplace(ctx, prob)
     h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob,
                     base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0}, solver={"type": "amg"}))
