@@ -185,11 +185,14 @@ int mfmg_hip_csr_stencil_classes(mfmg_hip_csr_t a, int *n_classes, int64_t *list
 /* SparseMatrixDevice::vmult  (…templates.cuh:351-371): y = A x */
 int mfmg_hip_csr_vmult(mfmg_hip_csr_t a, const double *x, double *y);
 /* CudaMatrixOperator::apply (source/cuda/cuda_matrix_operator.cu:80-91); TRANS uses the
- * explicit transpose built once by transpose() (:93-130) -- here on the host at first use. */
+ * explicit transpose built once by transpose() (:93-130) -- here by device kernels at first use
+ * (csr_algebra.hip; rows of the transpose beyond 4096 entries take the host algorithm). */
 int mfmg_hip_csr_apply(mfmg_hip_csr_t a, const double *x, double *y, int mode);
 /* CudaMatrixOperator::transpose (:93-130) */
 int mfmg_hip_csr_transpose(mfmg_hip_csr_t a, mfmg_hip_csr_t *out);
-/* SparseMatrixDevice::mmult / CudaMatrixOperator::multiply (…templates.cuh:373-434, cuda_matrix_operator.cu:132-149): C = A B (setup, host SpGEMM) */
+/* SparseMatrixDevice::mmult / CudaMatrixOperator::multiply (…templates.cuh:373-434, cuda_matrix_operator.cu:132-149): C = A B
+ * (setup; row-wise hash SpGEMM in LDS, sums in the order of the host product; rows with more than 2048 candidate
+ * columns take the host algorithm; MFMG_CSR_ALGEBRA=host|device|device_only selects) */
 int mfmg_hip_csr_multiply(mfmg_hip_csr_t a, mfmg_hip_csr_t b, mfmg_hip_csr_t *out);
 /* download (copy_from_dev / convert_to_trilinos_matrix, source/cuda/utils.cu:170-204) */
 int mfmg_hip_csr_download(mfmg_hip_csr_t a, int32_t *row_ptr_host, int32_t *col_host, double *val_host);

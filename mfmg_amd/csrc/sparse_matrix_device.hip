@@ -9,6 +9,7 @@
 // order is fixed and the result is bit-reproducible.
 #include "sparse_matrix_device.hpp"
 #include "amge_structured.hpp"
+#include "csr_algebra.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -1826,11 +1827,31 @@ void csr_multiply_host(int64_t a_rows, int64_t a_cols, std::vector<int32_t> cons
   }
 }
 
+// MFMG_CSR_ALGEBRA=host forces the host algorithms (the tests compare the two paths bit for bit); =device_only
+// turns the fall-back for rows beyond the LDS tables into an error (so that a test knows which path it measured)
+static bool csr_algebra_on_device()
+{
+  char const *e = std::getenv("MFMG_CSR_ALGEBRA");
+  return !(e && std::string(e) == "host");
+}
+static void csr_algebra_fell_back(char const *what)
+{
+  char const *e = std::getenv("MFMG_CSR_ALGEBRA");
+  ASSERT_THROW(!(e && std::string(e) == "device_only"),
+               std::string(what) + ": a row exceeds the LDS tables of the device algorithm (MFMG_CSR_ALGEBRA=device_only)");
+}
+
 template <typename T>
 std::shared_ptr<SparseMatrixDevice<T>> SparseMatrixDevice<T>::transpose() const
 {
   std::vector<int32_t> rp, cl, trp, tcl;
   std::vector<T> vl, tvl;
+  const int64_t nnz = (int64_t)_val.size();
+  if (csr_algebra_on_device() && nnz > 0 &&
+      csr_transpose_device<T>(_handle, _n_rows, _n_cols, nnz, _row_ptr.data(), _col.data(), _val.data(), trp, tcl, tvl))
+    return std::make_shared<SparseMatrixDevice<T>>(_handle, _n_cols, _n_rows, std::move(trp), std::move(tcl), std::move(tvl));
+  if (csr_algebra_on_device() && nnz > 0)
+    csr_algebra_fell_back("transpose");
   if (has_host_copy())
     csr_transpose_host<T>(_n_rows, _n_cols, _row_ptr_host, _col_host, _val_host, trp, tcl, tvl);
   else
@@ -1849,6 +1870,12 @@ std::shared_ptr<SparseMatrixDevice<T>> SparseMatrixDevice<T>::mmult(SparseMatrix
                                  "incompatible.");
   std::vector<int32_t> arp, acl, brp, bcl, crp, ccl;
   std::vector<T> avl, bvl, cvl;
+  if (csr_algebra_on_device() && _val.size() > 0 && b._val.size() > 0 &&
+      csr_multiply_device<T>(_handle, _n_rows, _row_ptr.data(), _col.data(), _val.data(), b._row_ptr.data(), b._col.data(),
+                             b._val.data(), crp, ccl, cvl))
+    return std::make_shared<SparseMatrixDevice<T>>(_handle, _n_rows, b.n(), std::move(crp), std::move(ccl), std::move(cvl));
+  if (csr_algebra_on_device() && _val.size() > 0 && b._val.size() > 0)
+    csr_algebra_fell_back("mmult");
   std::vector<int32_t> const *ap = &_row_ptr_host, *ac = &_col_host;
   std::vector<T> const *av = &_val_host;
   if (!has_host_copy())

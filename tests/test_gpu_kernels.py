@@ -367,6 +367,65 @@ def test_csr_fixture_banded_operator(ctx):
     assert abs(C.to_scipy() - A @ A.T).max() == 0.0
 
 
+@pytest.mark.parametrize("shape,density,dense_col", [((300, 211), 0.04, False), ((2000, 1500), 0.01, True),
+                                                      ((64, 5000), 0.02, False), ((1, 1), 1.0, False)])
+def test_csr_transpose_and_product_on_device(ctx, monkeypatch, shape, density, dense_col):
+    """The device setup algebra (csr_algebra.hip) against the host algorithms, BIT FOR BIT: transposed rows longer
+    than a wavefront (the workgroup sort), empty rows, rectangular shapes; the product sums in the
+    order of the host Gustavson product (reference: cusparseDcsrgemm,
+    include/mfmg/cuda/sparse_matrix_device.templates.cuh:373-434, and the Epetra transpose,
+    source/cuda/cuda_matrix_operator.cu:93-130)."""
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    A = sp.random(*shape, density=density, random_state=rng, format="lil", dtype=np.float64)
+    if dense_col:
+        A[:, 3] = rng.standard_normal((shape[0], 1))      # a transposed row of 2000 entries: LDS sort
+        A[5, :] = 0.0                                      # an empty row
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    B = sp.random(shape[1], 97, density=0.05, random_state=rng, format="csr", dtype=np.float64)
+    B.sort_indices()
+
+    def both(fn):
+        out = []
+        for mode in ("device_only", "host"):
+            monkeypatch.setenv("MFMG_CSR_ALGEBRA", mode)
+            out.append(fn())
+        return out
+
+    Ad, Bd = M.SparseMatrixDevice(ctx, A), M.SparseMatrixDevice(ctx, B)
+    t_dev, t_host = both(lambda: Ad.transpose().to_scipy())
+    ref = sp.csr_matrix(A.T)
+    ref.sort_indices()
+    for t in (t_dev, t_host):
+        assert np.array_equal(t.indptr, ref.indptr) and np.array_equal(t.indices, ref.indices)
+        assert np.array_equal(t.data, ref.data)
+    c_dev, c_host = both(lambda: Ad.multiply(Bd).to_scipy())
+    assert np.array_equal(c_dev.indptr, c_host.indptr) and np.array_equal(c_dev.indices, c_host.indices)
+    assert np.array_equal(c_dev.data, c_host.data)          # same summation order: the same bits
+    ref = (A @ B).toarray()
+    np.testing.assert_allclose(c_dev.toarray(), ref, rtol=0, atol=1e-13 * max(1.0, np.abs(ref).max()))
+    for r in range(c_dev.shape[0]):                         # columns strictly increasing within every row
+        assert np.all(np.diff(c_dev.indices[c_dev.indptr[r]:c_dev.indptr[r + 1]]) > 0)
+
+
+def test_csr_algebra_falls_back_for_rows_beyond_lds(ctx, monkeypatch):
+    """Rows with more candidate columns than the LDS hash table holds (or transposed rows beyond the LDS sort) take the
+    host algorithm: the same result, and an error where the test insists on the device path."""
+    n = 5000
+    A = sp.csr_matrix(np.ones((1, n)))
+    B = sp.identity(n, format="csr") * 2.0
+    Ad, Bd = M.SparseMatrixDevice(ctx, A), M.SparseMatrixDevice(ctx, B)
+    monkeypatch.setenv("MFMG_CSR_ALGEBRA", "device")
+    assert np.array_equal(Ad.multiply(Bd).to_scipy().toarray(), 2.0 * np.ones((1, n)))
+    At = M.SparseMatrixDevice(ctx, sp.csr_matrix(np.ones((n, 1)))).transpose().to_scipy()
+    assert np.array_equal(At.toarray(), np.ones((1, n)))
+    monkeypatch.setenv("MFMG_CSR_ALGEBRA", "device_only")
+    with pytest.raises(RuntimeError, match="LDS tables"):
+        Ad.multiply(Bd)
+    with pytest.raises(RuntimeError, match="LDS tables"):
+        M.SparseMatrixDevice(ctx, sp.csr_matrix(np.ones((n, 1)))).transpose()
+
+
 def test_csr_fixture_random_pattern_and_jacobi(ctx):
     from test_oracle_fixtures import random_pattern_matrix
     A = random_pattern_matrix()                      # tests/test_sparse_matrix_device.cu:43-56
