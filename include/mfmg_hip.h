@@ -303,6 +303,13 @@ int mfmg_hip_hierarchy_coarse_apply(mfmg_hip_hierarchy_t h, const double *b, dou
  * from a host CSR so that CPU and GPU runs can share the identical R. */
 int mfmg_hip_hierarchy_set_restrictor(mfmg_hip_hierarchy_t h, int64_t n_rows, int64_t n_cols, int64_t nnz,
                                       const int32_t *row_ptr_host, const int32_t *col_host, const double *val_host);
+/* b_coarse = R (A x - b): the residual of hierarchy.hpp:281-286 and its restriction (:288-290) as the cycle computes them.
+ * Where the rows of R A repeat themselves from agglomerate to agglomerate (constant coefficient) this is ONE kernel
+ * over x and b (residual_restriction.hip; `restrictor.fused_residual false` or MFMG_FUSED_RESIDUAL=0 switch it off);
+ * otherwise the fused residual kernel followed by the restriction.  *_classes: number of agglomerate classes of the
+ * one-pass form, 0 when the two-step form is in use. */
+int mfmg_hip_hierarchy_restrict_residual(mfmg_hip_hierarchy_t h, int32_t level, const double *x, const double *b, double *b_coarse);
+int mfmg_hip_hierarchy_residual_restriction_classes(mfmg_hip_hierarchy_t h, int32_t level, int32_t *n_classes);
 /* restrictor / coarse operator download for inspection: query sizes with *_shape first */
 int mfmg_hip_hierarchy_get_restrictor(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *r_borrowed);
 int mfmg_hip_hierarchy_get_coarse_operator(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *ac_borrowed);

@@ -477,6 +477,19 @@ class Hierarchy:
                 out.append((l, which, m.shape[0], m.get_kernel()[1]) + tuple(m.stencil_classes()))
         return out
 
+    def restrict_residual(self, x: torch.Tensor, b: torch.Tensor, b_coarse: torch.Tensor, level: int = 1):
+        """b_coarse = R (A x - b) as the cycle computes it (hierarchy.hpp:281-290): one kernel where the rows of R A
+        repeat themselves, the fused residual followed by the restriction otherwise."""
+        nf, nc = self.level_size(level - 1), self.level_size(level)
+        check(self._lib.mfmg_hip_hierarchy_restrict_residual(self.handle, level, _dev_ptr(x, nf), _dev_ptr(b, nf),
+                                                             _dev_ptr(b_coarse, nc)))
+
+    def residual_restriction_classes(self, level: int = 1) -> int:
+        """Agglomerate classes of the one-pass residual restriction; 0 when the two-step form is in use."""
+        n = C.c_int32()
+        check(self._lib.mfmg_hip_hierarchy_residual_restriction_classes(self.handle, level, C.byref(n)))
+        return n.value
+
     def coarse_amg_gather_level(self) -> int:
         """Index of the first aggregation level that is gathered and solved redundantly on every rank (-1: one rank)."""
         n = C.c_int32()

@@ -1018,6 +1018,36 @@ int mfmg_hip_hierarchy_restrictor_apply(mfmg_hip_hierarchy_t h, int32_t level, c
   });
 }
 
+int mfmg_hip_hierarchy_residual_restriction_classes(mfmg_hip_hierarchy_t h, int32_t level, int32_t *n_classes)
+{
+  return guarded([&] {
+    require(h && n_classes, "null argument");
+    require(level >= 1 && level < (int)h->hierarchy->levels().size(), "restrictors live on levels >= 1");
+    auto r = std::dynamic_pointer_cast<HipMatrixOperator const>(h->hierarchy->levels()[level].get_restrictor());
+    *n_classes = (r && r->has_residual_restriction()) ? (int32_t)r->residual_restriction_classes() : 0;
+  });
+}
+
+int mfmg_hip_hierarchy_restrict_residual(mfmg_hip_hierarchy_t h, int32_t level, const double *x, const double *b, double *b_coarse)
+{
+  return guarded([&] {
+    require(h && x && b && b_coarse, "null argument");
+    require(level >= 1 && level < (int)h->hierarchy->levels().size(), "restrictors live on levels >= 1");
+    const int64_t n_fine = level_size(h, level - 1), n_coarse = level_size(h, level);
+    auto r = h->hierarchy->levels()[level].get_restrictor();
+    auto a = h->hierarchy->levels()[level - 1].get_operator();
+    DVector xv(*h->handle, n_fine, const_cast<double *>(x)), bv(*h->handle, n_fine, const_cast<double *>(b)),
+        bc(*h->handle, n_coarse, b_coarse);
+    if (!r->restrict_residual(*a, xv, bv, bc))
+    {
+      // the two steps of hierarchy.hpp:281-290
+      DVector res(*h->handle, n_fine);
+      a->residual(xv, bv, res);
+      r->apply(res, bc);
+    }
+  });
+}
+
 int mfmg_hip_hierarchy_coarse_apply(mfmg_hip_hierarchy_t h, const double *b, double *x)
 {
   return guarded([&] {

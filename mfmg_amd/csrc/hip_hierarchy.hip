@@ -274,6 +274,105 @@ void HipMatrixOperator::apply_subtract(DVector const &x, DVector &y, OperatorMod
     get_transposed_matrix()->vmult_subtract(y.get_values(), x.get_values());
 }
 
+bool HipMatrixOperator::prepare_residual_restriction(std::shared_ptr<Operator<DVector> const> a)
+{
+  _rr_operator.reset();
+  HipHandle &hd = _matrix->handle();
+  auto ha = std::dynamic_pointer_cast<HipOperator const>(a);
+  if (!_structured || !ha)
+    return false;
+  const bool distributed = hd.comm.enabled();
+  if (distributed && !(_domain_space == 1 && _range_space == 2))
+    return false;
+  const int64_t n = _matrix->n(), nc = _matrix->m();
+  auto apply_a = [&](double const *v, double *w) {
+    DVector vv(hd, n, const_cast<double *>(v)), ww(hd, n, w);
+    ha->apply_local(vv, ww);
+  };
+  StructuredRestrictorDevice::SlabInfo slab;
+  if (distributed)
+  {
+    HaloSpace const &f = hd.comm.spaces[1], &c = hd.comm.spaces[2];
+    slab.valid_begin = (int)f.owned_begin;
+    slab.valid_end = (int)(f.owned_begin + f.owned_count);
+    slab.has_low = f.has_low;
+    slab.has_high = f.has_high;
+    slab.owned_begin = (int)c.owned_begin;
+    slab.owned_end = (int)(c.owned_begin + c.owned_count);
+  }
+  double ok = _structured->build_residual_restriction(apply_a, slab) ? 1. : 0.;
+  if (distributed)
+  {
+    // all ranks or none (a slab too thin to hold a representative of its classes says no): the path changes the exchanges
+    ok = -hd.allreduce_max(-ok);
+    // the 5 node layers around the top agglomerates of the slab reach one layer further than an operator application
+    HaloSpace const &f = hd.comm.spaces[1];
+    if (ok > 0. && ((f.has_low && f.ghost_low() < 2) || (f.has_high && f.ghost_high() < 2)))
+      ok = 0.;
+  }
+  if (ok == 0.)
+  {
+    _structured->drop_residual_restriction();
+    return false;
+  }
+  if (distributed && _rr_space == 0)
+  {
+    HaloSpace two = hd.comm.spaces[1];
+    two.width = 2;
+    _rr_space = hd.comm.add_space(two);
+  }
+  // the check: a random pair (x, b), the one-pass result against residual + restriction (owned rows, all ranks)
+  std::vector<double> hx(n), hb(n);
+  uint64_t state = 0x9e3779b97f4a7c15ull + (uint64_t)hd.comm.rank * 0x632be59bd9b4e019ull;
+  auto next = [&state] {
+    uint64_t z = (state += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return double((z ^ (z >> 31)) >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+  };
+  for (int64_t i = 0; i < n; ++i)
+  {
+    hx[i] = next();
+    hb[i] = next();
+  }
+  DVector x(hd, n), b(hd, n), res(hd, n), two_step(hd, nc), one_pass(hd, nc);
+  MFMG_HIP_CHECK(hipMemcpyAsync(x.get_values(), hx.data(), n * sizeof(double), hipMemcpyHostToDevice, hd.stream));
+  MFMG_HIP_CHECK(hipMemcpyAsync(b.get_values(), hb.data(), n * sizeof(double), hipMemcpyHostToDevice, hd.stream));
+  a->residual(x, b, res);
+  apply(res, two_step);
+  _rr_operator = a;
+  restrict_residual(*a, x, b, one_pass);
+  _rr_operator.reset();
+  const double scale = std::sqrt(distributed_dot(hd, _range_space, two_step, two_step));
+  one_pass.add(-1., two_step);
+  const double diff = std::sqrt(distributed_dot(hd, _range_space, one_pass, one_pass));
+  if (std::getenv("MFMG_DEBUG_RR"))
+    fprintf(stderr, "[rr] rank %d: %d classes, one pass against two steps: difference %.3e of %.3e\n", hd.comm.rank,
+            _structured->residual_restriction_classes(), diff, scale);
+  if (!(diff <= 1e-12 * scale))
+  {
+    _structured->drop_residual_restriction(); // the operator does not repeat itself the way the classes assume
+    return false;
+  }
+  _rr_operator = a;
+  return true;
+}
+
+bool HipMatrixOperator::restrict_residual(Operator<DVector> const &a, DVector const &x, DVector const &b, DVector &b_coarse) const
+{
+  if (_rr_operator.get() != &a || !_structured || !_structured->has_residual_restriction())
+    return false;
+  ASSERT_THROW(x.size() == _matrix->n() && b.size() == _matrix->n() && b_coarse.size() == _matrix->m(),
+               "vector sizes do not match the operator");
+  HipHandle &hd = _matrix->handle();
+  // distributed runs: two exchanges as in the two-step form (there: x for the residual, the residual for R) -- here x two
+  // layers deep and b one layer deep
+  hd.exchange(_rr_space, const_cast<double *>(x.get_values()));
+  hd.exchange(_domain_space, const_cast<double *>(b.get_values()));
+  _structured->restrict_residual(x.get_values(), b.get_values(), b_coarse.get_values());
+  return true;
+}
+
 std::shared_ptr<Operator<DVector>> HipMatrixOperator::transpose() const
 {
   return std::make_shared<HipMatrixOperator>(get_transposed_matrix());
@@ -509,6 +608,11 @@ void HipMatrixFreeOperator::apply_mode(MfMode mode, double const *x, double cons
   handle.exchange_end(1);
   op->launch_z_range(mode, x, b, x_prev, alpha, beta, out, 0, lo_end);
   op->launch_z_range(mode, x, b, x_prev, alpha, beta, out, hi_begin, n_tiles);
+}
+
+void HipMatrixFreeOperator::apply_local(DVector const &x, DVector &y) const
+{
+  _mesh_evaluator->get_device_operator()->vmult(x.get_values(), y.get_values());
 }
 
 void HipMatrixFreeOperator::vmult(DVector &dst, DVector const &src) const
@@ -1245,6 +1349,20 @@ HipHierarchyHelpers<VectorType>::build_coarse_solver(std::shared_ptr<Operator<Ve
   }
   return std::make_shared<HipSolver>(_handle, op, params, near_null.empty() ? nullptr : &near_null,
                                      own ? &_grid_hint : nullptr);
+}
+
+template <typename VectorType>
+void HipHierarchyHelpers<VectorType>::prepare_residual_restriction(std::shared_ptr<Operator<VectorType> const> a,
+                                                                   std::shared_ptr<Operator<VectorType>> restrictor,
+                                                                   std::shared_ptr<ptree const> params)
+{
+  auto r = std::dynamic_pointer_cast<HipMatrixOperator>(restrictor);
+  if (!r || !r->has_structured())
+    return;
+  char const *env = std::getenv("MFMG_FUSED_RESIDUAL");
+  if ((env && std::string(env) == "0") || (params && !params->get("restrictor.fused_residual", true)))
+    return;
+  r->prepare_residual_restriction(a);
 }
 
 template class HipHierarchyHelpers<DVector>;

@@ -84,6 +84,7 @@ public:
       auto restrictor = hierarchy_helpers->build_restrictor(comm, evaluator, params);
       level_coarse.set_restrictor(restrictor);
       hierarchy_helpers->set_coarse_space_hint(restrictor);
+      hierarchy_helpers->prepare_residual_restriction(a, restrictor, params);
       timer_leave_subsection(_timer);
 
       std::shared_ptr<Operator<VectorType>> ap;
@@ -150,13 +151,15 @@ public:
       for (unsigned int i = 0; i < _n_smoothing_steps; ++i)
         smoother->apply(b, x);
 
-      // negative residual -r = A x - b (one fused kernel)
-      auto res = level_fine.workspace_vector(0);
-      a->residual(x, b, *res);
-
-      // restrict residual
+      // negative residual -r = A x - b and its restriction: one pass where the restrictor holds the rows of R A,
+      // otherwise one fused kernel for the residual and the restriction after it
       auto b_coarse = level_coarse.workspace_vector(1);
-      restrictor->apply(*res, *b_coarse);
+      if (!restrictor->restrict_residual(*a, x, b, *b_coarse))
+      {
+        auto res = level_fine.workspace_vector(0);
+        a->residual(x, b, *res);
+        restrictor->apply(*res, *b_coarse);
+      }
 
       // coarse grid correction
       auto x_coarse = level_coarse.workspace_vector(2);
@@ -179,6 +182,7 @@ public:
     ASSERT_THROW(_levels.size() == 2, "set_restrictor supports the two-level hierarchy only");
     auto a = _levels[0].get_operator();
     _levels[1].set_restrictor(restrictor);
+    _helpers->prepare_residual_restriction(a, restrictor, _params);
     auto ap = a->multiply_transpose(restrictor);
     auto a_coarse = restrictor->multiply(ap);
     _levels[1].set_operator(a_coarse);

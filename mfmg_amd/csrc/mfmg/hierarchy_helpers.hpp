@@ -43,5 +43,11 @@ public:
   // Extension: the restrictor the coarse operator was built with, so that a multilevel coarse solver can
   // derive its near-null-space vector (the coarse image of the constant) from it.  Default: ignored.
   virtual void set_coarse_space_hint(std::shared_ptr<Operator<vector_type> const> /*restrictor*/) {}
+  // Extension: lets a restrictor prepare `restrict_residual` for the operator of its fine level.  Default: nothing.
+  virtual void prepare_residual_restriction(std::shared_ptr<Operator<vector_type> const> /*a*/,
+                                            std::shared_ptr<Operator<vector_type>> /*restrictor*/,
+                                            std::shared_ptr<ptree const> /*params*/)
+  {
+  }
 };
 } // namespace mfmg

@@ -90,6 +90,8 @@ public:
   // distributed vector space of the domain / range (0: rank-local, 1: fine DoFs, 2: first coarse level)
   virtual int domain_space() const { return 0; }
   virtual int range_space() const { return 0; }
+  // y = A x on the rows this rank computes, from the local x as it stands: no exchange, no collective (setup probes)
+  virtual void apply_local(DVector const &x, DVector &y) const { apply(x, y); }
 };
 
 // dot product over the owned entries of a distributed space, summed over the ranks
@@ -111,6 +113,7 @@ public:
   size_t operator_complexity() const override;
   void residual(DVector const &x, DVector const &b, DVector &res) const override;
   void apply_subtract(DVector const &x, DVector &y, OperatorMode mode) const override;
+  void apply_local(DVector const &x, DVector &y) const override { _matrix->vmult(y.get_values(), x.get_values()); }
 
   void smoother_step(DVector const &b, DVector const &x, DVector const *x_prev, double alpha, double beta,
                      DVector &out) const override;
@@ -134,12 +137,20 @@ public:
   // stays for the setup algebra and for get_restrictor
   void set_structured(std::shared_ptr<StructuredRestrictorDevice> s) { _structured = std::move(s); }
   bool has_structured() const { return _structured != nullptr; }
+  // b_c = R (A x - b) in one pass (structured_restrictor.hpp): probes the rows of R A for `a`, checks the result against
+  // residual + restriction on a random pair of vectors and keeps it only if the two agree to rounding
+  bool prepare_residual_restriction(std::shared_ptr<Operator<DVector> const> a);
+  bool has_residual_restriction() const { return _rr_operator != nullptr; }
+  int residual_restriction_classes() const { return _structured ? _structured->residual_restriction_classes() : 0; }
+  bool restrict_residual(Operator<DVector> const &a, DVector const &x, DVector const &b, DVector &b_coarse) const override;
 
 private:
   int _domain_space = 0, _range_space = 0, _reverse_range_space = 0;
   std::shared_ptr<SparseMatrixDevice<double>> _matrix;
   mutable std::shared_ptr<SparseMatrixDevice<double>> _transposed_matrix; // built lazily (cuda_matrix_operator.cu:93-130)
   std::shared_ptr<StructuredRestrictorDevice> _structured;
+  std::shared_ptr<Operator<DVector> const> _rr_operator; // the fine operator the rows of R A were probed for
+  int _rr_space = 0; // distributed runs: the fine space with two ghost layers refreshed per side (the 5 layers of R A)
   mutable DeviceBuffer<double> _dinv;
 };
 
@@ -169,6 +180,7 @@ public:
                   double *out) const;
   int domain_space() const override { return 1; }
   int range_space() const override { return 1; }
+  void apply_local(DVector const &x, DVector &y) const override;
 
 private:
   std::shared_ptr<HipMatrixFreeMeshEvaluator> _mesh_evaluator;
@@ -342,6 +354,10 @@ public:
   {
     _restrictor_hint = restrictor;
   }
+
+  // restrictor.fused_residual (default true): b_c = R (A x - b) in one pass where R A repeats itself
+  void prepare_residual_restriction(std::shared_ptr<Operator<VectorType> const> a, std::shared_ptr<Operator<VectorType>> restrictor,
+                                    std::shared_ptr<ptree const> params) override;
 
 private:
   HipHandle &_handle;

@@ -46,6 +46,13 @@ public:
     apply(x, res);
     res.add(-1., b);
   }
+  // Called on a RESTRICTOR: b_coarse = R (A x - b), the residual and its restriction (hierarchy.hpp:281-290) in one
+  // pass where the restrictor knows the rows of R A (structured_restrictor.hpp).  false: not available, nothing done.
+  virtual bool restrict_residual(operator_type const & /*a*/, vector_type const & /*x*/, vector_type const & /*b*/,
+                                 vector_type & /*b_coarse*/) const
+  {
+    return false;
+  }
   // y -= op(A) x : `restrictor->apply(*x_coarse, *x_correction, TRANS); x.add(-1., *x_correction);`
   // of hierarchy.hpp:297-302
   virtual void apply_subtract(vector_type const &x, vector_type &y, OperatorMode mode) const

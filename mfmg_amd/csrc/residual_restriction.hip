@@ -1,0 +1,395 @@
+// b_c = R (A x - b) in one pass (structured_restrictor.hpp): the residual and its restriction of the V-cycle
+// (include/mfmg/common/hierarchy.hpp:281-290) without the fine residual ever being stored.
+//
+// A row of R lives on the 3 x 3 x 3 nodes of a 2 x 2 x 2-cell agglomerate, a row of a Q1 operator on the 3 x 3 x 3
+// nodes around its node: a row of R A lives on the 5 x 5 x 5 nodes around the agglomerate.  Where the fine operator
+// repeats itself from agglomerate to agglomerate these 125 x 2 weights (two eigenvectors) depend only on the CLASS of
+// the agglomerate (the block of R it repeats and its distance from the faces of the box), so that
+//   b_c[agglomerate] = sum_125 W[class][m] x[node m] - sum_27 R[class][m] b[node m]
+// needs x and b once (16 B per fine DoF + 8 B per coarse row) where residual + restriction move 40 B per fine DoF plus
+// the operator's own data.  The weights are probed: W[class] = A (R^T e_row) for one representative per class.
+//
+// Kernel: a wavefront takes 64 consecutive agglomerates of one row (same j, k); a lane loads its two own x values of a
+// node row as one 16-byte request -- consecutive lanes, consecutive addresses -- and takes the three others of its five
+// from the neighbouring lanes; the weights are wave-uniform (scalar loads).  The first and last agglomerate of a row
+// and rows whose agglomerates do not share a class go to a thread-per-agglomerate part in the same launch.
+#include "structured_restrictor.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+
+namespace mfmg
+{
+namespace
+{
+constexpr int kFoot = 125, kOwn = 27, kTab = kFoot + kOwn; // double2 entries of one class
+constexpr int kRun = 62; // agglomerates of one wavefront of the row-wise part (lanes 1 .. 62)
+
+struct RrArgs
+{
+  double2 const *table;
+  uint16_t const *seg_class;
+  uint16_t const *cls;
+  int32_t const *listed;
+  int64_t n_listed;
+  int64_t n_main_waves;
+  unsigned int main_blocks, listed_blocks;
+  int main_last; // last agglomerate index i of a row the row-wise part takes
+  int N[3], na[3];
+  int segs;
+};
+
+struct __attribute__((aligned(8))) pair8
+{
+  double x, y;
+};
+
+// value held by the previous / next lane of the wavefront (DPP wave shift: a VALU move, no LDS crossbar traffic)
+__device__ __forceinline__ int rr_dpp_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int rr_dpp_next(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ double rr_prev(double v)
+{
+  return __hiloint2double(rr_dpp_prev(__double2hiint(v)), rr_dpp_prev(__double2loint(v)));
+}
+__device__ __forceinline__ double rr_next(double v)
+{
+  return __hiloint2double(rr_dpp_next(__double2hiint(v)), rr_dpp_next(__double2loint(v)));
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void
+residual_restriction_kernel(RrArgs s, double const *__restrict__ x, double const *__restrict__ b, double *__restrict__ y)
+{
+  if (blockIdx.x >= s.listed_blocks)
+  {
+    // workgroups are dealt to the 8 XCDs in turn: a contiguous run of rows per XCD keeps the node rows that
+    // neighbouring agglomerate rows share in one L2 (main_blocks is a multiple of 8)
+    const unsigned int mb = blockIdx.x - s.listed_blocks;
+    const int64_t bid = (int64_t)(mb & 7) * (s.main_blocks >> 3) + (mb >> 3);
+    const int64_t wave = bid * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave >= s.n_main_waves)
+      return;
+    const unsigned int cw = s.seg_class[wave];
+    if (cw == 0xffffu)
+      return; // the agglomerates of this run are in the list
+    const int c = __builtin_amdgcn_readfirstlane((int)cw);
+    // wavefront order (k, run, j), j fastest: the four wavefronts of a workgroup take four consecutive rows j of the same
+    // run, whose 5 node rows per layer overlap (11 distinct of 20: the vector cache serves the rest)
+    const int aj = (int)(wave % s.na[1]);
+    const int seg = (int)((wave / s.na[1]) % s.segs);
+    const int ak = (int)(wave / ((int64_t)s.na[1] * s.segs));
+    const int lane = threadIdx.x & 63;
+    // lanes 1 .. 62 own the agglomerates i0 .. i0 + 61; lane 0 and lane 63 fetch the pair to the left / right of them
+    const int i0 = 1 + seg * kRun, last = min(s.main_last, i0 + kRun - 1);
+    const int ai = i0 + lane - 1;
+    const int aic = min(ai, s.na[0] - 1);
+    // (constant address space: the weights stay scalar loads whatever the compiler assumes about the asm statements below)
+    using const_weights = __attribute__((address_space(4))) const double;
+    const_weights *t = reinterpret_cast<const_weights *>(reinterpret_cast<uintptr_t>(s.table + (size_t)c * kTab));
+    const int N0 = s.N[0], N1 = s.N[1], N2 = s.N[2];
+    // node rows outside the box carry zero weights: their index is clamped instead of branched around, so that the
+    // requests of a layer go out together (a branch per row made every row a dependent round trip); the five rows of
+    // the next layer are requested before the current one is used
+    // (32-bit index arithmetic: the vectors have fewer than 2^31 entries, checked on the host)
+    int zo[5], yo[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m)
+    {
+      zo[m] = min(max(2 * ak - 1 + m, 0), N2 - 1) * N1;
+      yo[m] = min(max(2 * aj - 1 + m, 0), N1 - 1);
+    }
+    double const *xc = x + 2 * aic, *bc = b + 2 * aic;
+    auto load_layer = [&](pair8(&v)[5], int mz) {
+#pragma unroll
+      for (int my = 0; my < 5; ++my)
+        v[my] = *reinterpret_cast<pair8 const *>(xc + (zo[mz] + yo[my]) * N0);
+    };
+    auto load_b = [&](pair8(&v)[3], int mz) {
+#pragma unroll
+      for (int my = 0; my < 3; ++my)
+        v[my] = *reinterpret_cast<pair8 const *>(bc + (zo[mz + 1] + yo[my + 1]) * N0); // (rows 2 ak + mz, 2 aj + my: never clamped)
+    };
+    double s0 = 0., s1 = 0., r0 = 0., r1 = 0.;
+    pair8 cur[5], nxt[5], bcur[3];
+    load_layer(cur, 0);
+#pragma unroll
+    for (int mz = 0; mz < 5; ++mz)
+    {
+      if (mz < 4)
+        load_layer(nxt, mz + 1);
+      if (mz >= 1 && mz <= 3)
+        load_b(bcur, mz - 1);
+      __builtin_amdgcn_sched_barrier(0); // (keeps the scheduler from hoisting every request and every weight to the top)
+#pragma unroll
+      for (int my = 0; my < 5; ++my)
+      {
+        const pair8 own = cur[my];
+        const double xm1 = rr_prev(own.y), xp2 = rr_next(own.x), xp3 = rr_next(own.y);
+        const int m = (mz * 5 + my) * 5;
+        s0 += t[2 * m] * xm1 + t[2 * m + 2] * own.x + t[2 * m + 4] * own.y + t[2 * m + 6] * xp2 + t[2 * m + 8] * xp3;
+        s1 += t[2 * m + 1] * xm1 + t[2 * m + 3] * own.x + t[2 * m + 5] * own.y + t[2 * m + 7] * xp2 + t[2 * m + 9] * xp3;
+        // the sums are stored under a condition at the very end, and the compiler would sink ALL the arithmetic into
+        // that block (every weight parked in a VGPR lane meanwhile): pin them here, one row of weights at a time
+        asm volatile("" : "+v"(s0), "+v"(s1));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (mz >= 1 && mz <= 3)
+      {
+#pragma unroll
+        for (int my = 0; my < 3; ++my)
+        {
+          const pair8 own = bcur[my];
+          const double bp2 = rr_next(own.x);
+          const int m = kFoot + ((mz - 1) * 3 + my) * 3;
+          r0 += t[2 * m] * own.x + t[2 * m + 2] * own.y + t[2 * m + 4] * bp2;
+          r1 += t[2 * m + 1] * own.x + t[2 * m + 3] * own.y + t[2 * m + 5] * bp2;
+          asm volatile("" : "+v"(r0), "+v"(r1));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int my = 0; my < 5; ++my)
+        cur[my] = nxt[my];
+    }
+    if (lane >= 1 && lane <= kRun && ai <= last)
+    {
+      const int64_t ag = ai + (int64_t)s.na[0] * (aj + (int64_t)s.na[1] * ak);
+      reinterpret_cast<double2 *>(y)[ag] = make_double2(s0 - r0, s1 - r1);
+    }
+    return;
+  }
+  // ---- the listed agglomerates (first in the grid: they overlap with the rest): sixteen lanes each, the 125 + 27 nodes
+  // dealt round the lanes, every bound checked; the requests of a lane are in flight together, then a 16-lane reduction ----
+  const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  const bool live = q < s.n_listed;
+  const int64_t ag = s.listed[live ? q : 0];
+  const int ai = (int)(ag % s.na[0]), aj = (int)((ag / s.na[0]) % s.na[1]), ak = (int)(ag / ((int64_t)s.na[0] * s.na[1]));
+  double2 const *t = s.table + (size_t)s.cls[ag] * kTab;
+  double s0 = 0., s1 = 0.;
+#pragma unroll
+  for (int it = 0; it < (kTab + 15) / 16; ++it)
+  {
+    const int m = min(it * 16 + sub, kTab - 1);
+    const bool foot = m < kFoot;
+    const int mm = foot ? m : m - kFoot, n = foot ? 5 : 3, o = foot ? 1 : 0;
+    const int gx = 2 * ai - o + mm % n, gy = 2 * aj - o + (mm / n) % n, gz = 2 * ak - o + mm / (n * n);
+    const bool in = it * 16 + sub < kTab && gx >= 0 && gx < s.N[0] && gy >= 0 && gy < s.N[1] && gz >= 0 && gz < s.N[2];
+    const int64_t node = ((int64_t)min(max(gz, 0), s.N[2] - 1) * s.N[1] + min(max(gy, 0), s.N[1] - 1)) * s.N[0] + min(max(gx, 0), s.N[0] - 1);
+    const double v = foot ? x[node] : -b[node];
+    const double2 w = t[m];
+    s0 += in ? w.x * v : 0.;
+    s1 += in ? w.y * v : 0.;
+  }
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1)
+  {
+    s0 += __shfl_xor(s0, d);
+    s1 += __shfl_xor(s1, d);
+  }
+  if (live && sub == 0)
+    reinterpret_cast<double2 *>(y)[ag] = make_double2(s0, s1);
+}
+
+// table of one (class, eigenvector): the 125 values of w = A R^T e around the representative, the 27 of v = R^T e
+__global__ void rr_gather_kernel(double const *v, double const *w, int N0, int N1, int N2, int ai, int aj, int ak, int e,
+                                 double *table)
+{
+  const int m = threadIdx.x;
+  if (m < kFoot)
+  {
+    const int gx = 2 * ai - 1 + m % 5, gy = 2 * aj - 1 + (m / 5) % 5, gz = 2 * ak - 1 + m / 25;
+    const bool in = gx >= 0 && gx < N0 && gy >= 0 && gy < N1 && gz >= 0 && gz < N2;
+    table[2 * m + e] = in ? w[((int64_t)gz * N1 + gy) * N0 + gx] : 0.;
+  }
+  else if (m < kTab)
+  {
+    const int mm = m - kFoot;
+    const int gx = 2 * ai + mm % 3, gy = 2 * aj + (mm / 3) % 3, gz = 2 * ak + mm / 9;
+    table[2 * m + e] = v[((int64_t)gz * N1 + gy) * N0 + gx];
+  }
+}
+
+__global__ void rr_unit_kernel(double *y, int64_t row) { y[row] = 1.; }
+} // namespace
+
+void StructuredRestrictorDevice::drop_residual_restriction()
+{
+  _rr_table.release();
+  _rr_cls.release();
+  _rr_seg_class.release();
+  _rr_listed.release();
+  _rr_segs = _rr_classes = _rr_main_last = 0;
+}
+
+bool StructuredRestrictorDevice::build_residual_restriction(std::function<void(double const *, double *)> const &apply_a,
+                                                            SlabInfo const &slab)
+{
+  drop_residual_restriction();
+  const int64_t n_agg = (int64_t)_na[0] * _na[1] * _na[2];
+  const bool say = std::getenv("MFMG_DEBUG_RR") != nullptr;
+  if (_n_eig != 2 || _a[0] != 2 || _a[1] != 2 || _a[2] != 2 || !_identity_numbering || (int64_t)_cls_host.size() != n_agg)
+  {
+    if (say)
+      fprintf(stderr, "[rr] not built: n_eig %d, agglomerate %d %d %d, lexicographic %d, blocks classified for %zu of %lld agglomerates\n", _n_eig,
+              _a[0], _a[1], _a[2], (int)_identity_numbering, _cls_host.size(), (long long)n_agg);
+    return false;
+  }
+  // class of an agglomerate for R A: the block of R it repeats and, per direction, which faces of the box its 5 nodes reach
+  auto position = [&](int a, int d) { return (a == 0 ? 1 : 0) + (a == _na[d] - 1 ? 2 : 0); };
+  // a representative must see its whole 5 x 5 x 5 neighbourhood computed by this rank
+  auto can_represent = [&](int ak) {
+    for (int mz = 0; mz < 5; ++mz)
+    {
+      const int gz = 2 * ak - 1 + mz;
+      const bool outside_box = (gz < 0 && !slab.has_low) || (gz >= _N[2] && !slab.has_high);
+      if (!outside_box && !(gz >= slab.valid_begin && gz < std::min(slab.valid_end, _N[2])))
+        return false;
+    }
+    return true;
+  };
+  std::map<uint32_t, int> index;
+  std::vector<int64_t> representative; // -1: none found yet
+  std::vector<char> needed;
+  std::vector<uint16_t> cls(n_agg);
+  for (int64_t ag = 0; ag < n_agg; ++ag)
+  {
+    const int ai = (int)(ag % _na[0]), aj = (int)((ag / _na[0]) % _na[1]), ak = (int)(ag / ((int64_t)_na[0] * _na[1]));
+    const uint32_t key = ((uint32_t)_cls_host[ag] << 6) | (position(ai, 0) | (position(aj, 1) << 2) | (position(ak, 2) << 4));
+    auto it = index.find(key);
+    if (it == index.end())
+    {
+      if (representative.size() >= 4096)
+        return false;
+      it = index.emplace(key, (int)representative.size()).first;
+      representative.push_back(-1);
+      needed.push_back(0);
+    }
+    cls[ag] = (uint16_t)it->second;
+    if (representative[it->second] < 0 && can_represent(ak))
+      representative[it->second] = ag;
+    if (ak >= slab.owned_begin && ak < slab.owned_end)
+      needed[it->second] = 1;
+  }
+  for (size_t c = 0; c < representative.size(); ++c)
+    if (needed[c] && representative[c] < 0)
+    {
+      if (say)
+        fprintf(stderr, "[rr] not built: a class of owned agglomerates has no representative with its neighbourhood on this rank\n");
+      return false;
+    }
+  const int n_classes = (int)representative.size();
+  // wavefronts of the row-wise part: runs of 62 agglomerates i = 1 .. main_last of one row, when they share a class; a
+  // last run shorter than 24 is left to the list together with i = 0 and i = na0 - 1
+  const int interior = std::max(_na[0] - 2, 0);
+  const int segs = interior / kRun + (interior % kRun >= 24 ? 1 : 0);
+  const int main_last = std::min(interior, segs * kRun);
+  const int64_t n_rows = (int64_t)_na[1] * _na[2];
+  std::vector<uint16_t> seg_class((size_t)(segs * n_rows), 0xffff);
+  std::vector<int32_t> listed;
+  for (int64_t row = 0; row < n_rows; ++row)
+  {
+    const int64_t base = row * _na[0];
+    listed.push_back((int32_t)base);
+    for (int sg = 0; sg < segs; ++sg)
+    {
+      const int i0 = 1 + sg * kRun, i1 = std::min(main_last, i0 + kRun - 1);
+      bool uniform = true;
+      for (int i = i0 + 1; i <= i1; ++i)
+        uniform = uniform && cls[base + i] == cls[base + i0];
+      if (uniform)
+        seg_class[((row / _na[1]) * segs + sg) * _na[1] + row % _na[1]] = cls[base + i0];
+      else
+        for (int i = i0; i <= i1; ++i)
+          listed.push_back((int32_t)(base + i));
+    }
+    for (int i = main_last + 1; i < _na[0]; ++i)
+      listed.push_back((int32_t)(base + i));
+  }
+  // the thread-per-agglomerate part is meant for the faces of the box: when it would carry a quarter of a mesh with
+  // full rows of agglomerates, the blocks do not repeat along the rows and the two-step path is the faster one
+  if ((segs > 0 && (int64_t)listed.size() * 4 > n_agg) || (segs == 0 && n_classes > 64))
+  {
+    if (say)
+      fprintf(stderr, "[rr] not built: %zu of %lld agglomerates outside the row-wise part\n", listed.size(), (long long)n_agg);
+    return false;
+  }
+  // probe: W[class] = A (R^T e) on the 5^3 nodes around the representative
+  hipStream_t st = _handle.stream;
+  DeviceBuffer<double> unit((size_t)_n_coarse), v((size_t)_n_fine), w((size_t)_n_fine), table((size_t)n_classes * kTab * 2);
+  MFMG_HIP_CHECK(hipMemsetAsync(table.data(), 0, table.size() * sizeof(double), st));
+  for (int c = 0; c < n_classes; ++c)
+  {
+    const int64_t ag = representative[c];
+    if (ag < 0)
+      continue; // a class of the neighbours' agglomerates only: its rows are never used (the table stays zero)
+    const int ai = (int)(ag % _na[0]), aj = (int)((ag / _na[0]) % _na[1]), ak = (int)(ag / ((int64_t)_na[0] * _na[1]));
+    for (int e = 0; e < 2; ++e)
+    {
+      MFMG_HIP_CHECK(hipMemsetAsync(unit.data(), 0, (size_t)_n_coarse * sizeof(double), st));
+      hipLaunchKernelGGL(rr_unit_kernel, dim3(1), dim3(1), 0, st, unit.data(), 2 * ag + e);
+      prolongate(unit.data(), v.data(), false);
+      apply_a(v.data(), w.data());
+      hipLaunchKernelGGL(rr_gather_kernel, dim3(1), dim3(192), 0, st, v.data(), w.data(), _N[0], _N[1], _N[2], ai, aj, ak, e,
+                         table.data() + (size_t)c * kTab * 2);
+      MFMG_HIP_CHECK(hipGetLastError());
+    }
+  }
+  MFMG_HIP_CHECK(hipStreamSynchronize(st));
+  _rr_table = std::move(table);
+  _rr_cls.upload(cls.data(), cls.size(), st);
+  if (!seg_class.empty())
+    _rr_seg_class.upload(seg_class.data(), seg_class.size(), st);
+  _rr_listed.upload(listed.data(), listed.size(), st);
+  _rr_segs = segs;
+  _rr_main_last = main_last;
+  _rr_classes = n_classes;
+  return true;
+}
+
+void StructuredRestrictorDevice::restrict_residual(double const *x, double const *b, double *y) const
+{
+  ASSERT_THROW(has_residual_restriction(), "the residual restriction has not been built");
+  ASSERT_THROW(x != nullptr && b != nullptr && y != nullptr && x != y && b != y, "bad vectors");
+  ASSERT_THROW(_n_fine < (int64_t(1) << 31), "the residual restriction indexes with 32 bits");
+  RrArgs s;
+  s.table = reinterpret_cast<double2 const *>(_rr_table.data());
+  s.seg_class = _rr_seg_class.data();
+  s.cls = _rr_cls.data();
+  s.listed = _rr_listed.data();
+  s.n_listed = (int64_t)_rr_listed.size();
+  s.n_main_waves = (int64_t)_rr_segs * _na[1] * _na[2];
+  s.main_blocks = (unsigned int)(((s.n_main_waves + 3) / 4 + 7) / 8 * 8);
+  if (s.n_main_waves == 0)
+    s.main_blocks = 0;
+  for (int d = 0; d < 3; ++d)
+  {
+    s.N[d] = _N[d];
+    s.na[d] = _na[d];
+  }
+  s.segs = _rr_segs;
+  s.main_last = _rr_main_last;
+  s.listed_blocks = (unsigned int)((s.n_listed + 15) / 16);
+  hipEvent_t stop = _handle.profiler.begin("residual_restriction", 16. * double(_n_fine) + 8. * double(_n_coarse), _handle.stream);
+  static const int waves = [] {
+    char const *e = std::getenv("MFMG_RR_WAVES");
+    return e ? std::atoi(e) : 4; // (3, 4 and 6 wavefronts per SIMD within 5 % of each other; 1, 2 and 8 slower)
+  }();
+  const dim3 grid(s.main_blocks + s.listed_blocks);
+  if (waves == 1)
+    hipLaunchKernelGGL(residual_restriction_kernel<1>, grid, dim3(256), 0, _handle.stream, s, x, b, y);
+  else if (waves == 3)
+    hipLaunchKernelGGL(residual_restriction_kernel<3>, grid, dim3(256), 0, _handle.stream, s, x, b, y);
+  else if (waves == 4)
+    hipLaunchKernelGGL(residual_restriction_kernel<4>, grid, dim3(256), 0, _handle.stream, s, x, b, y);
+  else if (waves == 6)
+    hipLaunchKernelGGL(residual_restriction_kernel<6>, grid, dim3(256), 0, _handle.stream, s, x, b, y);
+  else if (waves == 8)
+    hipLaunchKernelGGL(residual_restriction_kernel<8>, grid, dim3(256), 0, _handle.stream, s, x, b, y);
+  else
+    hipLaunchKernelGGL(residual_restriction_kernel<2>, grid, dim3(256), 0, _handle.stream, s, x, b, y);
+  KernelProfiler::end(stop, _handle.stream);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+} // namespace mfmg

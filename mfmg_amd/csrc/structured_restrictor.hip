@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <unordered_map>
 
 namespace mfmg
 {
@@ -377,6 +378,62 @@ StructuredRestrictorDevice::create(HipHandle &handle, StructuredMesh const &mesh
   s->_nnz = R.row_ptr[R.n_rows];
   s->_identity_numbering = identity;
   s->_planes.upload(planes.data(), planes.size(), handle.stream);
+  if (n_eig == 2 && identity && agglomerate[0] == 2 && agglomerate[1] == 2 && agglomerate[2] == 2)
+  {
+    // class of EVERY agglomerate by the bits of its block (for the residual restriction, residual_restriction.hip);
+    // given up beyond 4096 classes (a coefficient that varies from cell to cell: no two blocks alike)
+    std::vector<uint64_t> hash(n_agg);
+#pragma omp parallel for schedule(static)
+    for (int64_t ag = 0; ag < n_agg; ++ag)
+    {
+      uint64_t h = 1469598103934665603ull;
+      for (int m = 0; m < patch; ++m)
+        for (int e = 0; e < n_eig; ++e)
+        {
+          uint64_t bits;
+          std::memcpy(&bits, &planes[(size_t)m * R.n_rows + ag * n_eig + e], 8);
+          h = (h ^ bits) * 1099511628211ull;
+          h ^= h >> 29;
+        }
+      hash[ag] = h;
+    }
+    auto same_block = [&](int64_t a1, int64_t a2) {
+      for (int m = 0; m < patch; ++m)
+        for (int e = 0; e < n_eig; ++e)
+          if (planes[(size_t)m * R.n_rows + a1 * n_eig + e] != planes[(size_t)m * R.n_rows + a2 * n_eig + e])
+            return false;
+      return true;
+    };
+    std::unordered_map<uint64_t, std::vector<int>> by_hash; // hash -> classes with that hash
+    std::vector<int64_t> first;
+    std::vector<uint16_t> all(n_agg);
+    bool fits = true;
+    for (int64_t ag = 0; ag < n_agg && fits; ++ag)
+    {
+      auto &cands = by_hash[hash[ag]];
+      int found = -1;
+      for (int c : cands)
+        if (same_block(first[c], ag))
+        {
+          found = c;
+          break;
+        }
+      if (found < 0)
+      {
+        if (first.size() >= 4096)
+        {
+          fits = false;
+          break;
+        }
+        found = (int)first.size();
+        first.push_back(ag);
+        cands.push_back(found);
+      }
+      all[ag] = (uint16_t)found;
+    }
+    if (fits)
+      s->_cls_host = std::move(all);
+  }
   if (n_eig == 2)
   {
     // reference agglomerate: of a few candidates the one a sample of agglomerates repeats most

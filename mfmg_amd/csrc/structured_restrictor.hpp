@@ -11,6 +11,8 @@
 #include "amge_structured.hpp"
 #include "common.hpp"
 
+#include <functional>
+
 namespace mfmg
 {
 class StructuredRestrictorDevice
@@ -32,6 +34,34 @@ public:
   // out = R^T y (subtract = false) or out -= R^T y (subtract = true)
   void prolongate(double const *y, double *out, bool subtract) const;
   double algorithmic_bytes() const; // the CSR figure of SURVEY.md 8d for one application
+
+  // ---- b_c = R (A x - b) in ONE pass over x and b (residual_restriction.hip) ----------------------------------
+  // For a fine operator that repeats its rows from agglomerate to agglomerate (constant coefficient: every
+  // agglomerate at the same distance from the faces of the box sees the same 5 x 5 x 5 rows of R A), the product R A is
+  // a table of 125 x 2 weights per agglomerate class; `hierarchy.hpp:284-290` (residual, then restriction) becomes one
+  // kernel that reads x and b once and never stores the fine residual.  The tables are PROBED (A applied to R^T e for
+  // one representative of every class: apply_a(v, w) must compute w = A v without touching other ranks); the caller
+  // verifies the result against the two-step path before use (HipMatrixOperator::prepare_residual_restriction).
+  // Returns false -- nothing built -- when the blocks of R fall into more than 4096 classes (no two alike), for
+  // agglomerates other than 2 x 2 x 2 cells with two eigenvectors, or for a renumbered mesh.
+  // Distributed runs (slabs along z): rows of A are computed locally only on the node layers [valid_begin, valid_end), and
+  // a layer outside the local mesh is outside the BOX only where no neighbour exists; a class with an agglomerate in the
+  // layers [owned_begin, owned_end) of agglomerates needs a representative whose 5 layers qualify.
+  struct SlabInfo
+  {
+    int valid_begin = 0, valid_end = 1 << 30; // node layers whose rows apply_a computes
+    bool has_low = false, has_high = false;   // neighbours below / above
+    int owned_begin = 0, owned_end = 1 << 30; // agglomerate layers this rank owns
+  };
+  bool build_residual_restriction(std::function<void(double const *, double *)> const &apply_a, SlabInfo const &slab);
+  bool build_residual_restriction(std::function<void(double const *, double *)> const &apply_a)
+  {
+    return build_residual_restriction(apply_a, SlabInfo());
+  }
+  bool has_residual_restriction() const { return _rr_table.size() > 0; }
+  void drop_residual_restriction();
+  int residual_restriction_classes() const { return _rr_classes; }
+  void restrict_residual(double const *x, double const *b, double *y) const;
 
 private:
   StructuredRestrictorDevice(HipHandle &handle) : _handle(handle) {}
@@ -61,5 +91,12 @@ public:
 
 private:
   DeviceBuffer<int32_t> _node_dof; // DoF id of lexicographic node (empty when the numbering is lexicographic)
+  // residual restriction
+  std::vector<uint16_t> _cls_host;       // class of every agglomerate by the bits of its block (empty: > 4096 classes)
+  DeviceBuffer<double> _rr_table;        // [class][125 + 27][2]: weights of R A on the 5^3 nodes around, of R on its 3^3
+  DeviceBuffer<uint16_t> _rr_cls;        // per agglomerate
+  DeviceBuffer<uint16_t> _rr_seg_class;  // per wavefront of the main part (64 agglomerates of one row): its class
+  DeviceBuffer<int32_t> _rr_listed;      // agglomerates left to the thread-per-agglomerate part
+  int _rr_segs = 0, _rr_classes = 0, _rr_main_last = 0;
 };
 } // namespace mfmg

@@ -178,6 +178,8 @@ def load() -> C.CDLL:
         "mfmg_hip_host_amg_destroy": (C.c_int, [vp]),
         "mfmg_hip_hierarchy_coarse_amg_levels": (C.c_int, [vp, P(i32)]),
         "mfmg_hip_hierarchy_coarse_amg_gather_level": (C.c_int, [vp, P(i32)]),
+        "mfmg_hip_hierarchy_restrict_residual": (C.c_int, [vp, i32, vp, vp, vp]),
+        "mfmg_hip_hierarchy_residual_restriction_classes": (C.c_int, [vp, i32, P(i32)]),
         "mfmg_hip_hierarchy_coarse_amg_get": (C.c_int, [vp, i32, i32, P(vp)]),
         "mfmg_hip_hierarchy_coarse_amg_smoother": (C.c_int, [vp, i32, P(i32), P(dbl), P(dbl)]),
     }

@@ -388,6 +388,13 @@ def mode_gpu(args):
     rl = torch.zeros(ncl, dtype=torch.float64, device="cuda"); rg = torch.empty(ncg, dtype=torch.float64, device="cuda")
     h.restrictor_apply(1, dev(local(xg)), rl); hg.restrictor_apply(1, dev(xg), rg)
     np.testing.assert_allclose(gather_c(rl), rg.cpu().numpy(), rtol=1e-12, atol=1e-13)
+    # residual + restriction as the cycle computes them (one pass over x and b where the rows of R A repeat themselves:
+    # x is then needed two ghost layers deep, b one -- both poisoned here, so they must come from the exchanges)
+    if args.mesh == "wide":
+        assert h.residual_restriction_classes() > 0 and hg.residual_restriction_classes() > 0
+    r1 = torch.zeros(ncl, dtype=torch.float64, device="cuda"); r1g = torch.empty(ncg, dtype=torch.float64, device="cuda")
+    h.restrict_residual(dev(local(xg)), dev(local(bg)), r1); hg.restrict_residual(dev(xg), dev(bg), r1g)
+    np.testing.assert_allclose(gather_c(r1), r1g.cpu().numpy(), rtol=1e-11, atol=1e-12 * np.abs(r1g.cpu().numpy()).max())
     xcg = rng.random(ncg)
     xcl = xcg[c_glob0: c_glob0 + ncl].copy()
     xcl[:cb * lay] = 1e30

@@ -731,3 +731,48 @@ def test_restrictor_eigenproblems_on_device(ctx, n, material, evaluator, variant
     for r in range(D.shape[0]):
         e = min(np.abs(D[r] - Oo[r]).max(), np.abs(D[r] + Oo[r]).max())
         assert e < 1e-11 * scale, (r, e)
+
+
+@pytest.mark.parametrize("n,material,evaluator,expect", [
+    ((8, 8, 8), "constant", "HipMatrixFreeMeshEvaluator", None),         # too small for classes of agglomerates
+    ((4, 16, 20), "constant", "HipMatrixFreeMeshEvaluator", None),       # two agglomerates in x: everything in the list
+    ((180, 12, 6), "constant", "HipMatrixFreeMeshEvaluator", True),      # 90 agglomerates in x: a full and a partial run
+    ((132, 10, 8), "constant", "HipMeshEvaluator", True),                # assembled fine operator
+    ((16, 16, 16), "linear", "HipMatrixFreeMeshEvaluator", False),       # every agglomerate its own block: two steps
+    ((12, 10, 6), "discontinuous", "HipMatrixFreeMeshEvaluator", None),  # whatever the classes allow: must agree
+])
+def test_residual_restriction_in_one_pass(ctx, monkeypatch, n, material, evaluator, expect):
+    """b_c = R (A x - b) (include/mfmg/common/hierarchy.hpp:281-290) as one kernel over x and b where the rows of R A
+    repeat themselves (residual_restriction.hip), against the two steps on the same restrictor, and the cycle built on
+    it against the cycle without it."""
+    prob = M.LaplaceProblem(n, material, device="cuda")
+    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0})
+    h = M.Hierarchy(ctx, evaluator, prob, params)
+    classes = h.residual_restriction_classes()
+    if expect is not None:
+        assert (classes > 0) == expect
+    nf, nc = h.level_size(0), h.level_size(1)
+    rng = np.random.default_rng(5)
+    x, b = dev(rng.standard_normal(nf)), dev(rng.standard_normal(nf))
+    one = torch.empty(nc, dtype=torch.float64, device="cuda")
+    h.restrict_residual(x, b, one)
+    res = torch.empty(nf, dtype=torch.float64, device="cuda")
+    h.operator_apply(0, x, res)
+    res -= b
+    two = torch.empty(nc, dtype=torch.float64, device="cuda")
+    h.restrictor_apply(1, res, two)
+    ctx.synchronize()
+    assert (one - two).abs().max().item() <= 1e-12 * two.abs().max().item()
+    # the cycle with and without it
+    x0 = rng.random(nf)
+    hist = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MFMG_FUSED_RESIDUAL", fused)
+        hh = M.Hierarchy(ctx, evaluator, prob, params)
+        assert fused == "1" or hh.residual_restriction_classes() == 0
+        xx, bb = dev(x0), dev(np.zeros(nf))
+        for _ in range(5):
+            hh.apply(bb, xx)
+        ctx.synchronize()
+        hist.append(xx.cpu().numpy())
+    assert np.abs(hist[0] - hist[1]).max() <= 1e-12 * np.abs(x0).max()
