@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, T cons
 
 constexpr size_t kMaxBlockDiagonals = 400; // (343: the third level of the aggregation hierarchy of a Q1 problem)
 constexpr int kMaxStoredBlockDiagonals = 160;
-constexpr int64_t kRegularAsClassNodes = 300000; // nodes up to which regular nodes are evaluated as one more class
+constexpr int64_t kRegularAsClassNodes = 5000000; // nodes up to which regular nodes are evaluated as one more class (one launch instead of two: at 2.1 M nodes 54 against 38 + 23 us)
 constexpr int kSplitStencil = 48;        // block diagonals from which a node's stencil is split over four wavefronts
 constexpr int64_t kListedWaveRows = 32768; // listed rows up to which each gets a wavefront of its own
 
@@ -1066,7 +1066,11 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
       // small levels are bound by the latency of a launch, not by their rows: there the regular nodes join the lists
       // as one more class (their table is the reference stencil; a regular node has its whole stencil inside the
       // matrix, so the clamping of the class kernel never acts) and the launch of their own is dropped
-      if (n_classes > 0 && n_classes < kMaxClasses && n_nodes <= kRegularAsClassNodes && n_regular > 0)
+      static const int64_t regular_as_class_nodes = [] {
+        char const *e = std::getenv("MFMG_REGULAR_AS_CLASS_NODES");
+        return e ? std::atoll(e) : kRegularAsClassNodes;
+      }();
+      if (n_classes > 0 && n_classes < kMaxClasses && n_nodes <= regular_as_class_nodes && n_regular > 0)
       {
         for (int rc = 0; rc < c; ++rc)
           for (int d = 0; d < D; ++d)

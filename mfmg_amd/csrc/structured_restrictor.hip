@@ -232,10 +232,38 @@ __global__ __launch_bounds__(256) void sr_prolong_kernel(SrArgs s, double const 
 // agglomerate position (na + 1 per direction) finishes the 2 x 2 x 2 nodes at the low corner of its agglomerate.
 // The y pairs of the (at most) eight agglomerates around are fetched once for the eight nodes, the table
 // entries are wave-uniform; every sum is formed in the order of sr_node_value (same bits).
-__global__ __launch_bounds__(256) void sr_prolong_block222_kernel(SrArgs s, double const *y, double *out, int subtract,
-                                                                  uint8_t const *blk_exc)
+struct __attribute__((aligned(8))) sr_pair
 {
-  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  double x, y;
+};
+
+// Both parts in ONE launch: the first `listed_blocks` workgroups take the nodes of the listed agglomerate positions (the
+// blocks the table-driven part leaves out: a thread per node, latency-bound, so they start first and run beside the
+// rest), the others one agglomerate position per thread.  The two nodes 2 i, 2 i + 1 of a row are read / written as one
+// 16-byte access: consecutive lanes, consecutive addresses (with 8-byte accesses at a stride of 16 every request used
+// half of what it touched).
+__global__ __launch_bounds__(256) void sr_prolong_block222_kernel(SrArgs s, double const *y, double *out, int subtract,
+                                                                  uint8_t const *blk_exc, int32_t const *blocks, int64_t n_blocks,
+                                                                  unsigned int listed_blocks)
+{
+  if (blockIdx.x < listed_blocks)
+  {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= 8 * n_blocks)
+      return;
+    const int64_t v = blocks[t >> 3];
+    const int d = (int)(t & 7);
+    const int vx = s.na[0] + 1, vy = s.na[1] + 1;
+    const int i = 2 * (int)(v % vx) + (d & 1), j = 2 * (int)((v / vx) % vy) + ((d >> 1) & 1),
+              k = 2 * (int)(v / ((int64_t)vx * vy)) + (d >> 2);
+    if (i >= s.N[0] || j >= s.N[1] || k >= s.N[2])
+      return;
+    const int64_t node = i + (int64_t)s.N[0] * (j + (int64_t)s.N[1] * k);
+    const double sum = sr_node_value(s, y, node);
+    out[node] = subtract ? out[node] - sum : sum;
+    return;
+  }
+  const int64_t t = (int64_t)(blockIdx.x - listed_blocks) * blockDim.x + threadIdx.x;
   const int vx = s.na[0] + 1, vy = s.na[1] + 1, vz = s.na[2] + 1;
   if (t >= (int64_t)vx * vy * vz || blk_exc[t] != 0)
     return;
@@ -250,53 +278,48 @@ __global__ __launch_bounds__(256) void sr_prolong_block222_kernel(SrArgs s, doub
     yv[sidx] = has[sidx] ? reinterpret_cast<double2 const *>(y)[qi + (int64_t)s.na[0] * (qj + (int64_t)s.na[1] * qk)]
                          : make_double2(0., 0.);
   }
+  const bool pair = 2 * vi + 1 < s.N[0];
 #pragma unroll
-  for (int d = 0; d < 8; ++d)
+  for (int dyz = 0; dyz < 4; ++dyz)
   {
-    const int dx = d & 1, dy = (d >> 1) & 1, dz = d >> 2;
-    const int i = 2 * vi + dx, j = 2 * vj + dy, k = 2 * vk + dz;
-    if (i >= s.N[0] || j >= s.N[1] || k >= s.N[2])
+    const int dy = dyz & 1, dz = dyz >> 1;
+    const int j = 2 * vj + dy, k = 2 * vk + dz;
+    if (j >= s.N[1] || k >= s.N[2])
       continue;
-    double sum = 0.;
+    double sums[2];
 #pragma unroll
-    for (int sz = 0; sz < 2; ++sz)
+    for (int dx = 0; dx < 2; ++dx)
+    {
+      double sum = 0.; // (formed in the order of sr_node_value: same bits)
 #pragma unroll
-      for (int sy = 0; sy < 2; ++sy)
+      for (int sz = 0; sz < 2; ++sz)
 #pragma unroll
-        for (int sx = 0; sx < 2; ++sx)
-        {
-          if ((sx && dx) || (sy && dy) || (sz && dz))
-            continue; // the previous agglomerate holds the node only on the shared boundary
-          const int sidx = sx + 2 * sy + 4 * sz;
-          if (!has[sidx])
-            continue;
-          const int m = (sx ? 2 : dx) + 3 * ((sy ? 2 : dy) + 3 * (sz ? 2 : dz));
-          sum += s.table[2 * m] * yv[sidx].x;
-          sum += s.table[2 * m + 1] * yv[sidx].y;
-        }
-    const int64_t node = i + (int64_t)s.N[0] * (j + (int64_t)s.N[1] * k);
-    out[node] = subtract ? out[node] - sum : sum;
+        for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx)
+          {
+            if ((sx && dx) || (sy && dy) || (sz && dz))
+              continue; // the previous agglomerate holds the node only on the shared boundary
+            const int sidx = sx + 2 * sy + 4 * sz;
+            if (!has[sidx])
+              continue;
+            const int m = (sx ? 2 : dx) + 3 * ((sy ? 2 : dy) + 3 * (sz ? 2 : dz));
+            sum += s.table[2 * m] * yv[sidx].x;
+            sum += s.table[2 * m + 1] * yv[sidx].y;
+          }
+      sums[dx] = sum;
+    }
+    double *o = out + 2 * vi + (int64_t)s.N[0] * (j + (int64_t)s.N[1] * k);
+    if (pair)
+    {
+      sr_pair v = subtract ? *reinterpret_cast<sr_pair const *>(o) : sr_pair{0., 0.};
+      v.x = subtract ? v.x - sums[0] : sums[0];
+      v.y = subtract ? v.y - sums[1] : sums[1];
+      *reinterpret_cast<sr_pair *>(o) = v;
+    }
+    else
+      o[0] = subtract ? o[0] - sums[0] : sums[0];
   }
-}
-
-// the nodes of the listed agglomerate positions (the blocks the kernel above leaves out), one thread per node
-__global__ __launch_bounds__(256) void sr_prolong_listed_kernel(SrArgs s, double const *y, double *out, int subtract,
-                                                                int32_t const *blocks, int64_t n_blocks)
-{
-  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (t >= 8 * n_blocks)
-    return;
-  const int64_t v = blocks[t >> 3];
-  const int d = (int)(t & 7);
-  const int vx = s.na[0] + 1, vy = s.na[1] + 1;
-  const int i = 2 * (int)(v % vx) + (d & 1), j = 2 * (int)((v / vx) % vy) + ((d >> 1) & 1),
-            k = 2 * (int)(v / ((int64_t)vx * vy)) + (d >> 2);
-  if (i >= s.N[0] || j >= s.N[1] || k >= s.N[2])
-    return;
-  const int64_t node = i + (int64_t)s.N[0] * (j + (int64_t)s.N[1] * k);
-  const double sum = sr_node_value(s, y, node);
-  const int64_t id = s.node_dof ? (int64_t)s.node_dof[node] : node;
-  out[id] = subtract ? out[id] - sum : sum;
 }
 } // namespace
 
@@ -660,11 +683,9 @@ void StructuredRestrictorDevice::prolongate(double const *y, double *out, bool s
   if (_blk_exc.size() > 0)
   {
     const int64_t n_pos = (int64_t)_blk_exc.size(), n_listed = (int64_t)_exc_blocks.size();
-    hipLaunchKernelGGL(sr_prolong_block222_kernel, dim3((unsigned int)((n_pos + 255) / 256)), dim3(256), 0,
-                       _handle.stream, s, y, out, subtract ? 1 : 0, _blk_exc.data());
-    if (n_listed > 0)
-      hipLaunchKernelGGL(sr_prolong_listed_kernel, dim3((unsigned int)((8 * n_listed + 255) / 256)), dim3(256), 0,
-                         _handle.stream, s, y, out, subtract ? 1 : 0, _exc_blocks.data(), n_listed);
+    const unsigned int listed_blocks = (unsigned int)((8 * n_listed + 255) / 256);
+    hipLaunchKernelGGL(sr_prolong_block222_kernel, dim3(listed_blocks + (unsigned int)((n_pos + 255) / 256)), dim3(256), 0,
+                       _handle.stream, s, y, out, subtract ? 1 : 0, _blk_exc.data(), _exc_blocks.data(), n_listed, listed_blocks);
   }
   else
     hipLaunchKernelGGL(sr_prolong_kernel, dim3((unsigned int)((_n_fine + 255) / 256)), dim3(256), 0, _handle.stream,
