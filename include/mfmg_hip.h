@@ -114,6 +114,11 @@ int mfmg_hip_context_set_cell_constant_layout(mfmg_hip_context_t ctx, int enable
  * less to read, 768 instead of 1280 B per chunk).  enable != 0: operators created afterwards keep D^-1 in the records. */
 int mfmg_hip_context_set_stored_diagonal(mfmg_hip_context_t ctx, int enable);
 int mfmg_hip_mf_laplace_diagonal_in_record(mfmg_hip_mf_laplace_t op, int *in_record);
+/* 1 when the operator kernel COMPUTES the DoF ids instead of reading them from its records: a numbering that is affine
+ * on the node grid (any lexicographic one), Dirichlet DoFs on whole faces of the box, ghost DoFs on whole z-layers,
+ * checked slot by slot at construction; used by the eight-coefficient kernels (where it pays).  MFMG_MF_AFFINE_IDS=0
+ * keeps the ids of the records. */
+int mfmg_hip_mf_laplace_ids_computed(mfmg_hip_mf_laplace_t op, int *computed);
 /* Hierarchies created afterwards form the coarse operator R A R^T of a matrix-free A on the device by probing
  * (27 n_eig applications of R^T, A and R over colour classes of agglomerates; the reference's fast_ap idea,
  * source/dealii/dealii_matrix_free_hierarchy_helpers.cc:77-288) -- the default where the restrictor has the block

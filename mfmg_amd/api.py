@@ -304,6 +304,12 @@ class MatrixFreeLaplace:
         check(self._lib.mfmg_hip_mf_laplace_diagonal_in_record(self.handle, C.byref(v)))
         return bool(v.value)
 
+    def ids_computed(self) -> bool:
+        """The kernel computes the DoF ids from the position instead of reading them from its records."""
+        v = C.c_int()
+        check(self._lib.mfmg_hip_mf_laplace_ids_computed(self.handle, C.byref(v)))
+        return bool(v.value)
+
     def get_tile(self):
         """(waves, ty, tz) of the next launch."""
         a, b, c = C.c_int(), C.c_int(), C.c_int()

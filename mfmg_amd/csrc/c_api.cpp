@@ -280,6 +280,13 @@ int mfmg_hip_mf_laplace_diagonal_in_record(mfmg_hip_mf_laplace_t op, int *in_rec
     *in_record = op->op->diagonal_in_record() ? 1 : 0;
   });
 }
+int mfmg_hip_mf_laplace_ids_computed(mfmg_hip_mf_laplace_t op, int *computed)
+{
+  return guarded([&] {
+    require(op && computed, "null argument");
+    *computed = op->op->ids_computed() ? 1 : 0;
+  });
+}
 int mfmg_hip_context_set_galerkin_on_device(mfmg_hip_context_t ctx, int enable)
 {
   return guarded([&] {

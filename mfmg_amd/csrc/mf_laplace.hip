@@ -66,6 +66,8 @@ struct MfArgs
   int mode;
   unsigned int rec_bytes;  // bytes of one chunk record
   int dinv_in_record;      // D^-1 is part of the record (always for eight coefficients per cell)
+  // structured numbering (AffineIds below): the kernel computes the ids instead of reading them from the records
+  AffineIds aff;
 };
 
 namespace
@@ -328,7 +330,7 @@ __device__ __forceinline__ T mf_epilogue(MfArgs<T> const &a, int id0, T x0, T yv
 // TYC > 0: rows per wavefront known at compile time (the row loop is fully unrolled: no loop-carried register
 // moves, constant LDS offsets, the whole pass is one request batch for TYC <= 4); TYC = 0: rows from the
 // arguments, one request batch per row.
-template <typename T, int TYC, bool CC, int BATCH>
+template <typename T, int TYC, bool CC, int BATCH, bool AFF>
 __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int bid)
 {
 #pragma clang fp contract(off)
@@ -384,8 +386,23 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
   fac.faz = a.faz;
   fac.fbz = a.fbz;
   // own id of node row `jrow` (clamped into the mesh) in the layer whose records start at `layer`
-  auto own_id = [&](unsigned char const *layer, int jrow) {
-    return reinterpret_cast<int const *>(layer + (size_t)min(max(jrow, 0), a.Ny - 1) * rec_row)[lane];
+  const int id_lane = a.aff.base + ci * a.aff.s0; // (AFF) the part of the id that belongs to the lane
+  const bool lane_in = ci >= 0 && ci < a.Nx;
+  const bool lane_face = ((a.aff.faces & 1) && ci == 0) || ((a.aff.faces & 2) && ci == a.Nx - 1);
+  auto own_id = [&](int kz, int jrow) {
+    const int jr = min(max(jrow, 0), a.Ny - 1);
+    if constexpr (AFF)
+    {
+      // wave-uniform: the row and layer part of the id, the faces j and k, the ghost layers
+      const int id_row = jr * a.aff.s1 + kz * a.aff.s2;
+      const bool row_face = ((a.aff.faces & 4) && jr == 0) || ((a.aff.faces & 8) && jr == a.Ny - 1) ||
+                            ((a.aff.faces & 16) && kz == 0) || ((a.aff.faces & 32) && kz == a.Nz - 1);
+      const int ghost = (kz < a.aff.ghost_low || kz >= a.Nz - a.aff.ghost_high) ? (int)kGhost : 0;
+      const int id = (id_lane + id_row) | ((lane_face || row_face) ? (int)kFlag : 0) | ghost;
+      return lane_in ? id : 0; // (lanes outside the mesh carry id 0 in the records too)
+    }
+    else
+      return reinterpret_cast<int const *>(rec_col + (size_t)kz * rec_layer + (size_t)jr * rec_row)[lane];
   };
   int pf[XP ? TYC + 1 : 1]; // own ids of the node rows Yb .. Yb + TY in the layer after next
 #pragma unroll
@@ -402,8 +419,6 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
     const bool no_cells = k < 0;         // the halo layer below the mesh: coefficient forced to zero
     const bool layer_carry = kk > 0;     // xz / idz hold x and the ids of layer k, written by the pass of layer k - 1
     unsigned char const *rec_k = rec_col + (size_t)kc * rec_layer;
-    unsigned char const *rec_kn = rec_col + (size_t)kn * rec_layer;
-    unsigned char const *rec_kn2 = rec_col + (size_t)min(k + 2, a.Nz - 1) * rec_layer;
     T ry0 = T(0), ry1 = T(0), rc = T(0); // (rc: coefficient sum of the previous cell row)
     // b=0 face carried from the previous cell row: Dirichlet-masked x values of the four corners, the raw value
     // and the id of the own DoF
@@ -427,12 +442,12 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
         if constexpr (XP)
           idBf = jj0 ? pf[XP ? 1 : 0] : pf[0]; // (no run-time index into the register array)
         else
-          idBf = own_id(rec_kn, jf);
+          idBf = own_id(kn, jf);
       }
       else
       {
-        idAf = own_id(rec_k, jf);
-        idBf = own_id(rec_kn, jf);
+        idAf = own_id(kc, jf);
+        idBf = own_id(kn, jf);
         xAf = ld_off<T>(a.x, id_off<T>(idAf));
       }
       const T xBf = ld_off<T>(a.x, id_off<T>(idBf));
@@ -480,12 +495,12 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
           if constexpr (XP)
             idB[b] = pf[XP ? g + b + 1 : 0];
           else
-            idB[b] = own_id(rec_kn, j + 1);
+            idB[b] = own_id(kn, j + 1);
         }
         else
         {
-          idA[b] = own_id(rec_k, j + 1);
-          idB[b] = own_id(rec_kn, j + 1);
+          idA[b] = own_id(kc, j + 1);
+          idB[b] = own_id(kn, j + 1);
         }
       }
 #pragma unroll
@@ -519,10 +534,10 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
         if (have_rows)
         {
           if (g == 0)
-            pf[0] = own_id(rec_kn2, Yb);
+            pf[0] = own_id(min(k + 2, a.Nz - 1), Yb);
 #pragma unroll
           for (int b = 0; b < B; ++b)
-            pf[XP ? g + b + 1 : 0] = own_id(rec_kn2, Yb + g + b + 1);
+            pf[XP ? g + b + 1 : 0] = own_id(min(k + 2, a.Nz - 1), Yb + g + b + 1);
         }
       }
 
@@ -650,14 +665,36 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
 // tail columns, see the constructor), the others on `am`.  Both share the tile shape (NW, TY, TZ).
 // BATCH = cell rows whose requests are issued together (one memory round trip per batch): the whole pass for the
 // cell-constant variant, fewer for eight coefficients per cell (16 VGPRs of coefficients per row in FP64).
-template <typename T, int TYC, bool CC, int BATCH>
+// AFF: the ids are computed from the position (AffineIds) instead of read from the records.
+template <typename T, int TYC, bool CC, int BATCH, bool AFF = false>
 __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> am, MfArgs<T> at, unsigned int n_tail_blocks)
 {
   const bool tail = blockIdx.x < n_tail_blocks;
-  mf_laplace_body<T, TYC, CC, BATCH>(tail ? at : am, tail ? blockIdx.x : blockIdx.x - n_tail_blocks);
+  mf_laplace_body<T, TYC, CC, BATCH, AFF>(tail ? at : am, tail ? blockIdx.x : blockIdx.x - n_tail_blocks);
 }
 
 // ---- setup kernels -----------------------------------------------------------
+// *mismatch is raised when a slot of the records does not carry the id AffineIds gives it
+__global__ void mf_affine_check_kernel(unsigned char const *rec, size_t rec_bytes, int64_t n_slots, int Nx, int Ny, int Nz, int ncols,
+                                       AffineIds f, int *mismatch)
+{
+  for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n_slots; s += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int lane = s & 63;
+    const int64_t chunk = s >> 6;
+    const int c = chunk % ncols, j = (chunk / ncols) % Ny, k = chunk / ((int64_t)ncols * Ny);
+    const int i = c * kOwn - 1 + lane;
+    if (i < 0 || i >= Nx)
+      continue;
+    const bool face = ((f.faces & 1) && i == 0) || ((f.faces & 2) && i == Nx - 1) || ((f.faces & 4) && j == 0) ||
+                      ((f.faces & 8) && j == Ny - 1) || ((f.faces & 16) && k == 0) || ((f.faces & 32) && k == Nz - 1);
+    const bool ghost = k < f.ghost_low || k >= Nz - f.ghost_high;
+    const int want = (f.base + i * f.s0 + j * f.s1 + k * f.s2) | (face ? (int)kFlag : 0) | (ghost ? (int)kGhost : 0);
+    if (reinterpret_cast<int const *>(rec + (size_t)chunk * rec_bytes)[lane] != want)
+      atomicOr(mismatch, 1);
+  }
+}
+
 template <typename T, bool CC>
 __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coefficient,
                                  uint8_t const *constrained, int Nx, int Ny, int Nz, int ncols,
@@ -959,6 +996,44 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   ASSERT_THROW(n_bad == 0, "cell_dofs is not a logically structured hex mesh in lexicographic cell order (" +
                                std::to_string(n_bad) + " inconsistent cells)");
 
+  // a numbering the kernel can compute (AffineIds): parameters from a few slots of the records, then every slot checked
+  {
+    char const *env = std::getenv("MFMG_MF_AFFINE_IDS");
+    if (!(env && std::string(env) == "0") && _N[0] >= 3 && _N[1] >= 3 && _N[2] >= 3)
+    {
+      auto slot_id = [&](int i, int j, int k) {
+        const int c = i / kOwn;
+        const int64_t chunk = c + (int64_t)_ncols * (j + (int64_t)_N[1] * k);
+        int v = 0;
+        MFMG_HIP_CHECK(hipMemcpyAsync(&v, _rec.data() + (size_t)chunk * _rec_bytes + (size_t)(i + 1 - kOwn * c) * sizeof(int), sizeof(int),
+                                      hipMemcpyDeviceToHost, st));
+        MFMG_HIP_CHECK(hipStreamSynchronize(st));
+        return (unsigned int)v;
+      };
+      AffineIds f;
+      const int mi = _N[0] / 2, mj = _N[1] / 2, mk = _N[2] / 2;
+      const int g0 = (int)(slot_id(mi, mj, mk) & kIdMask);
+      f.s0 = (int)(slot_id(mi + 1, mj, mk) & kIdMask) - g0;
+      f.s1 = (int)(slot_id(mi, mj + 1, mk) & kIdMask) - g0;
+      f.s2 = (int)(slot_id(mi, mj, mk + 1) & kIdMask) - g0;
+      f.base = g0 - mi * f.s0 - mj * f.s1 - mk * f.s2;
+      f.faces = ((slot_id(0, mj, mk) & kFlag) ? 1 : 0) | ((slot_id(_N[0] - 1, mj, mk) & kFlag) ? 2 : 0) |
+                ((slot_id(mi, 0, mk) & kFlag) ? 4 : 0) | ((slot_id(mi, _N[1] - 1, mk) & kFlag) ? 8 : 0) |
+                ((slot_id(mi, mj, 0) & kFlag) ? 16 : 0) | ((slot_id(mi, mj, _N[2] - 1) & kFlag) ? 32 : 0);
+      f.ghost_low = f.ghost_high = 0;
+      while (f.ghost_low < std::min(_N[2], 4) && (slot_id(mi, mj, f.ghost_low) & kGhost))
+        ++f.ghost_low;
+      while (f.ghost_high < std::min(_N[2], 4) && (slot_id(mi, mj, _N[2] - 1 - f.ghost_high) & kGhost))
+        ++f.ghost_high;
+      MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
+      hipLaunchKernelGGL(mf_affine_check_kernel, dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, _rec.data(), _rec_bytes,
+                         (int64_t)n_slots, _N[0], _N[1], _N[2], _ncols, f, bad.data());
+      MFMG_HIP_CHECK(hipGetLastError());
+      _affine_ids = bad.download(st)[0] == 0;
+      _affine = f;
+    }
+  }
+
   // diagonal: K[q][m] = sum_d f_d (dphi_m/dxi_d)^2 at Gauss point q
   DiagTable tab;
   const double vol = _h[0] * _h[1] * _h[2];
@@ -1122,6 +1197,7 @@ bool MatrixFreeLaplaceDevice<T>::make_args(MfArgs<T> &a, unsigned int &n_blocks,
   a.mode = static_cast<int>(mode);
   a.rec_bytes = (unsigned int)_rec_bytes;
   a.dinv_in_record = _dinv_in_record ? 1 : 0;
+  a.aff = _affine;
   a.ncols = _ncols;
   a.ncols_active = _tail ? _ncols - 1 : _ncols;
   // ty cell rows per wavefront, nw ty - 1 owned DoF rows per workgroup
@@ -1173,6 +1249,8 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
     }
     hipLaunchKernelGGL(kernel, grid, block, lds, st, am, at, tail_blocks);
   };
+  // both parts of the launch must read their ids the same way
+  const bool affine = ids_computed();
   if (_compact)
   {
     if (ty == 2)
@@ -1194,6 +1272,14 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
       go(mf_laplace_kernel<T, 3, false, 3>);
     else if (ty == 4 && batch_env == 2)
       go(mf_laplace_kernel<T, 4, false, 2>);
+    else if (affine && ty == 2)
+      go(mf_laplace_kernel<T, 2, false, 1, true>);
+    else if (affine && ty == 3)
+      go(mf_laplace_kernel<T, 3, false, 1, true>);
+    else if (affine && ty == 4)
+      go(mf_laplace_kernel<T, 4, false, 1, true>);
+    else if (affine)
+      go(mf_laplace_kernel<T, 0, false, 1, true>);
     else if (ty == 2)
       go(mf_laplace_kernel<T, 2, false, 1>);
     else if (ty == 3)

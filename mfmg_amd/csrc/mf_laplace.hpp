@@ -24,6 +24,17 @@ enum class MfMode : int
   next = 3      // out = x + alpha (x - x_prev) - beta dinv (A x - b)
 };
 
+// A numbering the kernel can compute: id(i, j, k) = base + i s0 + j s1 + k s2 on the node grid (any lexicographic
+// numbering; the rotated slab of the tail columns has s0 = row length, s1 = 1), Dirichlet flags on whole faces of the box
+// (bit 0 / 1: i = 0 / Nx - 1, bits 2, 3: j, bits 4, 5: k) and ghost flags on whole layers k < ghost_low, k >= Nz - ghost_high
+// (the slabs of a distributed run).  Verified slot by slot against the records at construction; the id loads -- a
+// request per row whose answer the x requests wait for -- disappear from the kernel.
+struct AffineIds
+{
+  int base, s0, s1, s2;
+  int faces, ghost_low, ghost_high;
+};
+
 template <typename T>
 struct MfArgs; // kernel arguments (mf_laplace.hip)
 
@@ -91,10 +102,15 @@ public:
   {
     return double(_n_dofs) * (2.0 * sizeof(T) + 8 * 4 + (_compact ? 1 : 8) * sizeof(T));
   }
+  // (ids: 4 bytes per DoF from the records; none where the kernel computes them, AffineIds)
   double required_bytes_apply() const
   {
-    return double(_n_dofs) * (2.0 * sizeof(T) + 4 + (_compact ? 1 : 8) * sizeof(T));
+    return double(_n_dofs) * (2.0 * sizeof(T) + (ids_computed() ? 0. : 4.) + (_compact ? 1 : 8) * sizeof(T));
   }
+  // Used by the eight-coefficient kernels only (measured at 257^3 / 512^3 DoFs, Chebyshev(3) apply: 1.35 -> 1.27 ms and
+  // 9.5 -> 9.0 ms; the one-coefficient kernels prefetch their ids a layer ahead and LOSE 3 % to the extra arithmetic).
+  // Both parts of a launch (the mesh and the rotated slab of its tail columns) must have such a numbering.
+  bool ids_computed() const { return !_compact && _affine_ids && (!_tail || _tail->_affine_ids); }
   // bytes of the epilogue operands of a fused mode on top of that: b, then D^-1 (NOT read in the cell-constant layout:
   // the kernel derives it from the cell coefficients), then x_prev
   double epilogue_bytes(int mode) const
@@ -129,5 +145,8 @@ private:
   bool _compact = false;
   bool _dinv_in_record = true; // D^-1 is part of the chunk records (always for eight coefficients per cell)
   size_t _rec_bytes = 0;
+  // a numbering the kernel computes instead of reading it from the records (mf_laplace.hip: AffineIds)
+  AffineIds _affine = {0, 1, 0, 0, 0, 0, 0};
+  bool _affine_ids = false;
 };
 } // namespace mfmg

@@ -87,6 +87,38 @@ def test_mf_vmult_host_arrays_and_renumbered_dofs(ctx):
     assert relerr(host(y, ctx)[perm], ref.vmult(x_lex)) < TOL
 
 
+@pytest.mark.parametrize("n,tile", [((12, 10, 9), None), ((70, 30, 12), (3, 4, 4)), ((20, 13, 9), (2, 3, 2))])
+def test_mf_computed_ids_change_no_bit(ctx, monkeypatch, n, tile):
+    """A lexicographic numbering with Dirichlet faces is computed by the eight-coefficient kernels instead of read from
+    the records (mfmg_hip_mf_laplace_ids_computed); a renumbered mesh and the one-coefficient kernels keep the stored
+    ids.  Every mode of the kernel must give the same bits either way."""
+    prob = M.LaplaceProblem(n, "linear", device="cuda")
+    op = M.MatrixFreeLaplace(ctx, prob)
+    assert op.ids_computed()
+    monkeypatch.setenv("MFMG_MF_AFFINE_IDS", "0")
+    op0 = M.MatrixFreeLaplace(ctx, prob)
+    assert not op0.ids_computed()
+    monkeypatch.delenv("MFMG_MF_AFFINE_IDS")
+    assert not M.MatrixFreeLaplace(ctx, M.LaplaceProblem(n, "constant", device="cuda")).ids_computed()
+    perm = torch.from_numpy(np.random.default_rng(1).permutation(prob.n_dofs))
+    assert not M.MatrixFreeLaplace(ctx, M.LaplaceProblem(n, "linear", device="cpu", dof_numbering=perm)).ids_computed()
+    rng = np.random.default_rng(4)
+    x, b, xp = (dev(rng.standard_normal(prob.n_dofs)) for _ in range(3))
+    outs = []
+    for o in (op, op0):
+        if tile:
+            o.set_tile(*tile)
+        y = [torch.empty_like(x) for _ in range(4)]
+        o.vmult(y[0], x)
+        o.residual(x, b, y[1])
+        o.smoother_step(b, x, None, 0.0, 0.7, y[2])
+        o.smoother_step(b, x, xp, 0.3, 0.7, y[3])
+        ctx.synchronize()
+        outs.append(y)
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+
+
 @pytest.mark.parametrize("n,material,tile", [((12, 10, 9), "discontinuous", None), ((12, 10, 9), "constant", None),
                                              ((70, 30, 12), "constant", (3, 4, 4)), ((70, 30, 12), "linear", (3, 4, 4)),
                                              ((20, 13, 9), "constant", (4, 2, 2)), ((20, 13, 9), "constant", (2, 3, 2)),
