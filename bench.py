@@ -92,7 +92,7 @@ def committed_traffic(cells, degree, compact, tile, prefix="cells"):
     return e.get("traffic_bytes_per_launch") if e else None
 
 
-def operator_bytes_per_dof(word, compact, survey):
+def operator_bytes_per_dof(word, compact, survey, ids_computed=False):
     """Bytes per fine DoF of one operator application y = A x.
     survey=True : SURVEY.md 8(d)'s indexed form -- x + y + 8 index ints + 8 coefficients (112 B in FP64); with one
                   coefficient per cell 8 indices + 1 coefficient.
@@ -100,14 +100,15 @@ def operator_bytes_per_dof(word, compact, survey):
                   its own DoF id, the other seven corners are neighbours' own ids) + the coefficients (8, or 1 for a
                   cell-wise constant material).  Halo re-reads of the tiling are NOT in this figure: they are waste."""
     coef = (1 if compact else 8) * word
-    return 2 * word + (32 if survey else 4) + coef
+    # (ids_computed: the kernel computes the ids of a structured numbering instead of reading them -- not a required byte)
+    return 2 * word + (32 if survey else (0 if ids_computed else 4)) + coef
 
 
-def smoother_bytes_per_dof(n_terms, word, compact, survey, dinv_stored=None):
+def smoother_bytes_per_dof(n_terms, word, compact, survey, dinv_stored=None, ids_computed=False):
     """Chebyshev smoother apply = n_terms fused operator launches: + b + D^-1 each, + x_prev from the second on.  With one
     coefficient per cell the layout holds no D^-1 by default (the kernel derives it from the cell coefficients): then it
     is not a required byte; `dinv_stored` says what the operator at hand does."""
-    b_op = operator_bytes_per_dof(word, compact, survey)
+    b_op = operator_bytes_per_dof(word, compact, survey, ids_computed)
     if dinv_stored is None:
         dinv_stored = not compact
     dinv = word if (survey or dinv_stored) else 0
@@ -209,7 +210,7 @@ def measure_smoother_f32(ctx, torch, M, cells, degree, reps=5, material="linear"
     ev1.synchronize()
     ms = ev0.elapsed_time(ev1) / reps
     # bytes the layout requires in FP32: x 4 + out 4 + one id 4 + 8 (or 1) coefficients, + b + D^-1 (+ x_prev)
-    per_dof = smoother_bytes_per_dof(len(coefs), 4, compact, survey=False)
+    per_dof = smoother_bytes_per_dof(len(coefs), 4, compact, survey=False, ids_computed=op.ids_computed())
     return {"n_dofs": N, "degree": degree, "dtype": "f32", "material": material,
             "coefficient_layout": "one value per cell" if compact else "eight values per cell",
             "ms_per_apply": ms, "required_bytes_per_dof": per_dof,
@@ -290,7 +291,7 @@ def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=20, warmup=3, t
     ts = sorted(ev[r].elapsed_time(ev[r + 1]) for r in range(reps))
     ms = ts[len(ts) // 2]
     survey = smoother_bytes_per_dof(len(coefs), 8, compact, survey=True)
-    required = smoother_bytes_per_dof(len(coefs), 8, compact, survey=False, dinv_stored=dinv_stored)
+    required = smoother_bytes_per_dof(len(coefs), 8, compact, survey=False, dinv_stored=dinv_stored, ids_computed=op.ids_computed())
     traffic = committed_traffic(n_dofs_per_dim, degree, compact, op.get_tile(), prefix="dofs") if dinv_stored == (not compact) else None
     return {"n_dofs": N, "degree": degree, "material": material,
             "coefficient_layout": "one value per cell" if compact else "eight values per cell",
@@ -450,6 +451,7 @@ def main():
     assembled = args.evaluator == "assembled"
     op_monitor = None if assembled else M.MatrixFreeLaplace(ctx, prob)
     compact = (not assembled) and op_monitor.cell_constant_layout()   # same detection as inside the hierarchy
+    ids_computed = (not assembled) and op_monitor.ids_computed()
     r = torch.empty_like(x)
 
     def residual_norm():
@@ -499,6 +501,16 @@ def main():
             h.apply(b, x)
         torch.cuda.synchronize()
         c_launches, c_ms, c_bytes = ctx.profile_query("csr_spmv_kernel")
+        ctx.profile_enable(False)
+    # third pass: the one-pass residual restriction b_c = R (A x - b), where the hierarchy uses it
+    rr_launches = rr_ms = rr_bytes = 0
+    rr_classes = h.residual_restriction_classes() if h.n_levels > 1 else 0
+    if rr_classes > 0:
+        ctx.profile_enable(True, only="residual_restriction")
+        for _ in range(3):
+            h.apply(b, x)
+        torch.cuda.synchronize()
+        rr_launches, rr_ms, rr_bytes = ctx.profile_query("residual_restriction")
         ctx.profile_enable(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -560,7 +572,9 @@ def main():
                 "priced_on": "bytes the data layout requires per launch (x, out, one id, coefficients, b, x_prev, and D^-1 where the "
                              "layout stores it: eight coefficients per cell); "
                              "halo re-reads of the tiling are waste and not counted",
-                "required_bytes_per_dof_operator": (None if assembled else operator_bytes_per_dof(word, compact, False)),
+                "required_bytes_per_dof_operator": (None if assembled else operator_bytes_per_dof(word, compact, False, ids_computed)),
+                "ids": (None if assembled else ("computed by the kernel (structured numbering)" if ids_computed
+                                                else "one 4-byte id per DoF read from the chunk records")),
                 "survey_8d_bytes_per_dof_operator": (None if assembled else operator_bytes_per_dof(word, compact, True)),
                 "survey_8d_GBs": (None if assembled or not launches else      # + the 7 index ints the layout does not read
                                   (k_bytes / launches + 28.0 * n_local) / (k_ms / launches * 1e-3) / 1e9),
@@ -577,6 +591,13 @@ def main():
                                     "share_of_step_time": (c_ms / (ms_per_step * (other_cycles or args.steps))) if c_ms else None,
                                     "timed_in": (f"{other_cycles} extra cycles after the timed region" if other_cycles
                                                  else "the timed region")},
+                "residual_restriction_kernel": (None if not rr_launches else {
+                    "what": "b_c = R (A x - b) in one pass over x and b (the residual of the cycle is never stored): the rows of "
+                            "R A repeat themselves from agglomerate to agglomerate and come from tables",
+                    "agglomerate_classes": rr_classes, "launches": rr_launches, "avg_launch_ms": rr_ms / rr_launches,
+                    "algorithmic_bytes_per_launch": rr_bytes / rr_launches,
+                    "GBs_on_x_b_and_b_c": (rr_bytes / rr_launches) / (rr_ms / rr_launches * 1e-3) / 1e9,
+                    "timed_in": "3 extra cycles after the timed region"}),
             },
         }
         tile = tuple(int(v) for v in args.tile.split(",")) if args.tile else None

@@ -250,6 +250,7 @@ typedef struct mfmg_hip_mf_laplace_f32_s *mfmg_hip_mf_laplace_f32_t;
 int mfmg_hip_mf_laplace_f32_create(mfmg_hip_context_t ctx, const mfmg_hip_mesh_desc *mesh, mfmg_hip_mf_laplace_f32_t *out);
 int mfmg_hip_mf_laplace_f32_destroy(mfmg_hip_mf_laplace_f32_t op);
 int mfmg_hip_mf_laplace_f32_cell_constant_layout(mfmg_hip_mf_laplace_f32_t op, int *in_use);
+int mfmg_hip_mf_laplace_f32_ids_computed(mfmg_hip_mf_laplace_f32_t op, int *computed); /* as mfmg_hip_mf_laplace_ids_computed */
 int mfmg_hip_mf_laplace_f32_vmult(mfmg_hip_mf_laplace_f32_t op, const float *x, float *y);
 int mfmg_hip_mf_laplace_f32_diagonal_inverse(mfmg_hip_mf_laplace_f32_t op, float *dinv);
 int mfmg_hip_mf_laplace_f32_residual(mfmg_hip_mf_laplace_f32_t op, const float *x, const float *b, float *res);

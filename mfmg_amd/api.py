@@ -361,6 +361,11 @@ class MatrixFreeLaplaceF32:
         check(self._lib.mfmg_hip_mf_laplace_f32_cell_constant_layout(self.handle, C.byref(v)))
         return bool(v.value)
 
+    def ids_computed(self) -> bool:
+        v = C.c_int()
+        check(self._lib.mfmg_hip_mf_laplace_f32_ids_computed(self.handle, C.byref(v)))
+        return bool(v.value)
+
     def diagonal_inverse(self) -> torch.Tensor:
         out = torch.empty(self.n_dofs, dtype=torch.float32, device="cuda")
         check(self._lib.mfmg_hip_mf_laplace_f32_diagonal_inverse(self.handle, self._p(out)))

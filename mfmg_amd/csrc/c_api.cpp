@@ -311,6 +311,14 @@ int mfmg_hip_mf_laplace_f32_cell_constant_layout(mfmg_hip_mf_laplace_f32_t op, i
   });
 }
 
+int mfmg_hip_mf_laplace_f32_ids_computed(mfmg_hip_mf_laplace_f32_t op, int *computed)
+{
+  return guarded([&] {
+    require(op && computed, "null argument");
+    *computed = op->op->ids_computed() ? 1 : 0;
+  });
+}
+
 int mfmg_hip_context_set_overlap_exchange(mfmg_hip_context_t ctx, int enable)
 {
   return guarded([&] {

@@ -98,6 +98,7 @@ def load() -> C.CDLL:
         "mfmg_hip_context_set_stored_diagonal": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_mf_laplace_diagonal_in_record": (C.c_int, [vp, P(C.c_int)]),
         "mfmg_hip_mf_laplace_ids_computed": (C.c_int, [vp, P(C.c_int)]),
+        "mfmg_hip_mf_laplace_f32_ids_computed": (C.c_int, [vp, P(C.c_int)]),
         "mfmg_hip_mf_laplace_cell_constant_layout": (C.c_int, [vp, P(C.c_int)]),
         "mfmg_hip_context_halo_layout": (C.c_int, [vp, i32, P(i64), P(i64), P(i64), P(i64)]),
         "mfmg_hip_cell_contraction": (C.c_int, [vp, C.c_int, C.c_int, i64, vp, vp, vp, P(dbl)]),
