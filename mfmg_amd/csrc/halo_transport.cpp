@@ -80,7 +80,7 @@ void rccl_check(int status, const char *what)
 class RcclTransport : public HaloTransport
 {
 public:
-  RcclTransport(int rank, int n_ranks, unsigned char const unique_id[128]) : _rank(rank), _n(n_ranks)
+  RcclTransport(int rank, int n_ranks, unsigned char const unique_id[128]) : _rank(rank)
   {
     ncclUniqueId id;
     std::memcpy(id.internal, unique_id, 128);
@@ -135,7 +135,7 @@ public:
   char const *name() const override { return "rccl"; }
 
 private:
-  int _rank, _n;
+  int _rank;
   ncclComm_t _comm = nullptr;
   DeviceBuffer<double> _scalars;
 };
@@ -145,7 +145,7 @@ class HostTransport : public HaloTransport
 public:
   HostTransport(int rank, int n_ranks, mfmg_hip_host_sendrecv_fn sr, mfmg_hip_host_allreduce_fn ar, mfmg_hip_host_allgather_fn ag,
                 void *user)
-      : _rank(rank), _n(n_ranks), _sr(sr), _ar(ar), _ag(ag), _user(user)
+      : _n(n_ranks), _sr(sr), _ar(ar), _ag(ag), _user(user)
   {
     ASSERT_THROW(sr && ar && ag, "null transport callbacks");
   }
@@ -206,7 +206,7 @@ private:
     MFMG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&_host), (size_t)n * sizeof(double)));
     _host_n = n;
   }
-  int _rank, _n;
+  int _n;
   mfmg_hip_host_sendrecv_fn _sr;
   mfmg_hip_host_allreduce_fn _ar;
   mfmg_hip_host_allgather_fn _ag;
