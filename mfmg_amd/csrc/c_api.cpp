@@ -893,10 +893,16 @@ int mfmg_hip_hierarchy_apply_f32(mfmg_hip_hierarchy_t h, const float *b, float *
       MFMG_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(float) * n, hd.stream));
     for (unsigned int i = 0; i < h->hierarchy->n_smoothing_steps(); ++i)
       smooth();
-    op.residual(x, b, h->f32_res.data());
-    vec::widen(hd, n, h->f32_res.data(), h->f32_res64->get_values());
     auto restrictor = levels[1].get_restrictor();
-    restrictor->apply(*h->f32_res64, *h->f32_bc);
+    auto hip_restrictor = std::dynamic_pointer_cast<HipMatrixOperator const>(restrictor);
+    // b_c = R (A x - b): one pass over the FP32 vectors where the restrictor holds the rows of R A, otherwise the FP32
+    // residual, widened, and the restriction
+    if (!(hip_restrictor && hip_restrictor->restrict_residual_f32(*levels[0].get_operator(), x, b, *h->f32_bc)))
+    {
+      op.residual(x, b, h->f32_res.data());
+      vec::widen(hd, n, h->f32_res.data(), h->f32_res64->get_values());
+      restrictor->apply(*h->f32_res64, *h->f32_bc);
+    }
     h->hierarchy->apply(*h->f32_bc, *h->f32_xc, 1);
     restrictor->apply(*h->f32_xc, *h->f32_corr64, OperatorMode::TRANS);
     vec::subtract_narrowed(hd, n, h->f32_corr64->get_values(), x);

@@ -373,6 +373,15 @@ bool HipMatrixOperator::restrict_residual(Operator<DVector> const &a, DVector co
   return true;
 }
 
+bool HipMatrixOperator::restrict_residual_f32(Operator<DVector> const &a, float const *x, float const *b, DVector &b_coarse) const
+{
+  if (_rr_operator.get() != &a || !_structured || !_structured->has_residual_restriction() || _matrix->handle().comm.enabled())
+    return false;
+  ASSERT_THROW(x != nullptr && b != nullptr && b_coarse.size() == _matrix->m(), "vector sizes do not match the operator");
+  _structured->restrict_residual(x, b, b_coarse.get_values());
+  return true;
+}
+
 std::shared_ptr<Operator<DVector>> HipMatrixOperator::transpose() const
 {
   return std::make_shared<HipMatrixOperator>(get_transposed_matrix());

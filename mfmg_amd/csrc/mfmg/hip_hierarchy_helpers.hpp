@@ -143,6 +143,8 @@ public:
   bool has_residual_restriction() const { return _rr_operator != nullptr; }
   int residual_restriction_classes() const { return _structured ? _structured->residual_restriction_classes() : 0; }
   bool restrict_residual(Operator<DVector> const &a, DVector const &x, DVector const &b, DVector &b_coarse) const override;
+  // the same from the FP32 vectors of the fine level of apply_f32 (one rank; sums and result in FP64)
+  bool restrict_residual_f32(Operator<DVector> const &a, float const *x, float const *b, DVector &b_coarse) const;
 
 private:
   int _domain_space = 0, _range_space = 0, _reverse_range_space = 0;

@@ -40,9 +40,11 @@ struct RrArgs
   int segs;
 };
 
-struct __attribute__((aligned(8))) pair8
+// two consecutive entries of x or b (FP64: 16 bytes at an 8-byte boundary; FP32, the fine level of apply_f32: 8 at a 4-byte one)
+template <typename TI>
+struct __attribute__((aligned(sizeof(TI)))) pair_of
 {
-  double x, y;
+  TI x, y;
 };
 
 // value held by the previous / next lane of the wavefront (DPP wave shift: a VALU move, no LDS crossbar traffic)
@@ -57,9 +59,9 @@ __device__ __forceinline__ double rr_next(double v)
   return __hiloint2double(rr_dpp_next(__double2hiint(v)), rr_dpp_next(__double2loint(v)));
 }
 
-template <int WAVES>
+template <int WAVES, typename TI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void
-residual_restriction_kernel(RrArgs s, double const *__restrict__ x, double const *__restrict__ b, double *__restrict__ y)
+residual_restriction_kernel(RrArgs s, TI const *__restrict__ x, TI const *__restrict__ b, double *__restrict__ y)
 {
   if (blockIdx.x >= s.listed_blocks)
   {
@@ -99,16 +101,24 @@ residual_restriction_kernel(RrArgs s, double const *__restrict__ x, double const
       zo[m] = min(max(2 * ak - 1 + m, 0), N2 - 1) * N1;
       yo[m] = min(max(2 * aj - 1 + m, 0), N1 - 1);
     }
-    double const *xc = x + 2 * aic, *bc = b + 2 * aic;
+    TI const *xc = x + 2 * aic, *bc = b + 2 * aic;
+    using pair_in = pair_of<TI>;
+    using pair8 = pair_of<double>;
     auto load_layer = [&](pair8(&v)[5], int mz) {
 #pragma unroll
       for (int my = 0; my < 5; ++my)
-        v[my] = *reinterpret_cast<pair8 const *>(xc + (zo[mz] + yo[my]) * N0);
+      {
+        const pair_in p = *reinterpret_cast<pair_in const *>(xc + (zo[mz] + yo[my]) * N0);
+        v[my] = pair8{(double)p.x, (double)p.y};
+      }
     };
     auto load_b = [&](pair8(&v)[3], int mz) {
 #pragma unroll
       for (int my = 0; my < 3; ++my)
-        v[my] = *reinterpret_cast<pair8 const *>(bc + (zo[mz + 1] + yo[my + 1]) * N0); // (rows 2 ak + mz, 2 aj + my: never clamped)
+      {
+        const pair_in p = *reinterpret_cast<pair_in const *>(bc + (zo[mz + 1] + yo[my + 1]) * N0); // (rows 2 ak + mz, 2 aj + my: never clamped)
+        v[my] = pair8{(double)p.x, (double)p.y};
+      }
     };
     double s0 = 0., s1 = 0., r0 = 0., r1 = 0.;
     pair8 cur[5], nxt[5], bcur[3];
@@ -177,7 +187,7 @@ residual_restriction_kernel(RrArgs s, double const *__restrict__ x, double const
     const int gx = 2 * ai - o + mm % n, gy = 2 * aj - o + (mm / n) % n, gz = 2 * ak - o + mm / (n * n);
     const bool in = it * 16 + sub < kTab && gx >= 0 && gx < s.N[0] && gy >= 0 && gy < s.N[1] && gz >= 0 && gz < s.N[2];
     const int64_t node = ((int64_t)min(max(gz, 0), s.N[2] - 1) * s.N[1] + min(max(gy, 0), s.N[1] - 1)) * s.N[0] + min(max(gx, 0), s.N[0] - 1);
-    const double v = foot ? x[node] : -b[node];
+    const double v = foot ? (double)x[node] : -(double)b[node];
     const double2 w = t[m];
     s0 += in ? w.x * v : 0.;
     s1 += in ? w.y * v : 0.;
@@ -348,10 +358,12 @@ bool StructuredRestrictorDevice::build_residual_restriction(std::function<void(d
   return true;
 }
 
-void StructuredRestrictorDevice::restrict_residual(double const *x, double const *b, double *y) const
+template <typename TI>
+void StructuredRestrictorDevice::restrict_residual_any(TI const *x, TI const *b, double *y) const
 {
   ASSERT_THROW(has_residual_restriction(), "the residual restriction has not been built");
-  ASSERT_THROW(x != nullptr && b != nullptr && y != nullptr && x != y && b != y, "bad vectors");
+  ASSERT_THROW(x != nullptr && b != nullptr && y != nullptr && (void const *)x != (void const *)y && (void const *)b != (void const *)y,
+               "bad vectors");
   ASSERT_THROW(_n_fine < (int64_t(1) << 31), "the residual restriction indexes with 32 bits");
   RrArgs s;
   s.table = reinterpret_cast<double2 const *>(_rr_table.data());
@@ -371,25 +383,35 @@ void StructuredRestrictorDevice::restrict_residual(double const *x, double const
   s.segs = _rr_segs;
   s.main_last = _rr_main_last;
   s.listed_blocks = (unsigned int)((s.n_listed + 15) / 16);
-  hipEvent_t stop = _handle.profiler.begin("residual_restriction", 16. * double(_n_fine) + 8. * double(_n_coarse), _handle.stream);
+  hipEvent_t stop = _handle.profiler.begin("residual_restriction", 2. * sizeof(TI) * double(_n_fine) + 8. * double(_n_coarse), _handle.stream);
   static const int waves = [] {
     char const *e = std::getenv("MFMG_RR_WAVES");
     return e ? std::atoi(e) : 4; // (3, 4 and 6 wavefronts per SIMD within 5 % of each other; 1, 2 and 8 slower)
   }();
   const dim3 grid(s.main_blocks + s.listed_blocks);
   if (waves == 1)
-    hipLaunchKernelGGL(residual_restriction_kernel<1>, grid, dim3(256), 0, _handle.stream, s, x, b, y);
+    hipLaunchKernelGGL((residual_restriction_kernel<1, TI>), grid, dim3(256), 0, _handle.stream, s, x, b, y);
+  else if (waves == 2)
+    hipLaunchKernelGGL((residual_restriction_kernel<2, TI>), grid, dim3(256), 0, _handle.stream, s, x, b, y);
   else if (waves == 3)
-    hipLaunchKernelGGL(residual_restriction_kernel<3>, grid, dim3(256), 0, _handle.stream, s, x, b, y);
-  else if (waves == 4)
-    hipLaunchKernelGGL(residual_restriction_kernel<4>, grid, dim3(256), 0, _handle.stream, s, x, b, y);
+    hipLaunchKernelGGL((residual_restriction_kernel<3, TI>), grid, dim3(256), 0, _handle.stream, s, x, b, y);
   else if (waves == 6)
-    hipLaunchKernelGGL(residual_restriction_kernel<6>, grid, dim3(256), 0, _handle.stream, s, x, b, y);
+    hipLaunchKernelGGL((residual_restriction_kernel<6, TI>), grid, dim3(256), 0, _handle.stream, s, x, b, y);
   else if (waves == 8)
-    hipLaunchKernelGGL(residual_restriction_kernel<8>, grid, dim3(256), 0, _handle.stream, s, x, b, y);
+    hipLaunchKernelGGL((residual_restriction_kernel<8, TI>), grid, dim3(256), 0, _handle.stream, s, x, b, y);
   else
-    hipLaunchKernelGGL(residual_restriction_kernel<2>, grid, dim3(256), 0, _handle.stream, s, x, b, y);
+    hipLaunchKernelGGL((residual_restriction_kernel<4, TI>), grid, dim3(256), 0, _handle.stream, s, x, b, y);
   KernelProfiler::end(stop, _handle.stream);
   MFMG_HIP_CHECK(hipGetLastError());
+}
+
+void StructuredRestrictorDevice::restrict_residual(double const *x, double const *b, double *y) const
+{
+  restrict_residual_any<double>(x, b, y);
+}
+
+void StructuredRestrictorDevice::restrict_residual(float const *x, float const *b, double *y) const
+{
+  restrict_residual_any<float>(x, b, y);
 }
 } // namespace mfmg

@@ -62,8 +62,12 @@ public:
   void drop_residual_restriction();
   int residual_restriction_classes() const { return _rr_classes; }
   void restrict_residual(double const *x, double const *b, double *y) const;
+  // the same from FP32 vectors (the FP32 fine level of apply_f32): sums and result in FP64
+  void restrict_residual(float const *x, float const *b, double *y) const;
 
 private:
+  template <typename TI>
+  void restrict_residual_any(TI const *x, TI const *b, double *y) const;
   StructuredRestrictorDevice(HipHandle &handle) : _handle(handle) {}
   HipHandle &_handle;
   int _N[3] = {1, 1, 1};   // nodes

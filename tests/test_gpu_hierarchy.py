@@ -75,7 +75,8 @@ def test_matrix_free_chebyshev_vcycle_history(ctx, n, material, degree):
     assert rate_o < 0.5
 
 
-@pytest.mark.parametrize("n,material,degree", [((16, 16, 16), "constant", 3), ((12, 10, 6), "linear", 2), ((66, 8, 6), "constant", 3)])
+@pytest.mark.parametrize("n,material,degree", [((16, 16, 16), "constant", 3), ((12, 10, 6), "linear", 2), ((66, 8, 6), "constant", 3),
+                                               ((132, 10, 8), "constant", 3)])   # (the last two: b_c = R (A x - b) in one pass from FP32 x, b)
 def test_fine_level_in_fp32_against_the_fp64_oracle(ctx, n, material, degree):
     """BASELINE.json configs[4] (FP32): the cycle with the fine level in float (operator, smoother and residual through
     the FP32 instance of the matrix-free kernel, coarse levels in FP64) against the FP64 oracle with the same R and
