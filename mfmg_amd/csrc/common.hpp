@@ -310,7 +310,7 @@ struct HipHandle
   double *host_result = nullptr; // pinned
   KernelProfiler profiler;
   HaloCommunicator comm;
-  // staging of the halo exchanges: [send_low | send_high | recv_low | recv_high], grown on demand
+  // staging of the reverse (adding) exchanges: [recv_low | recv_high], grown on demand
   DeviceBuffer<double> halo_staging;
   int64_t halo_staging_each = 0;
 
@@ -329,35 +329,26 @@ struct HipHandle
       MFMG_HIP_CHECK(hipStreamSynchronize(stream));
       if (comm_stream)
         MFMG_HIP_CHECK(hipStreamSynchronize(comm_stream));
-      halo_staging.resize((size_t)4 * each);
+      halo_staging.resize((size_t)2 * each);
       halo_staging_each = each;
     }
   }
-  // forward exchange on `st`: pack, transport, unpack
+  // forward exchange on `st`.  The `width` owned layers next to a neighbour and the ghost layers they refresh are contiguous
+  // runs of the vector (slabs along z, lexicographic layers): the transport sends from and receives into the vector itself
+  // -- no packing, no staging copies (round 2 moved every layer through a staging buffer: four device copies per exchange).
   void exchange_on(HaloSpace const &s, double *v, hipStream_t pack_stream, hipStream_t st, bool split)
   {
     const int64_t n = (int64_t)s.width * s.layer_elems;
-    staging_reserve(n);
-    double *send_low = halo_staging.data(), *send_high = send_low + halo_staging_each, *recv_low = send_high + halo_staging_each,
-           *recv_high = recv_low + halo_staging_each;
-    const size_t bytes = (size_t)n * sizeof(double);
-    if (s.has_low)
-      MFMG_HIP_CHECK(hipMemcpyAsync(send_low, v + s.owned_begin * s.layer_elems, bytes, hipMemcpyDeviceToDevice, pack_stream));
-    if (s.has_high)
-      MFMG_HIP_CHECK(hipMemcpyAsync(send_high, v + (s.owned_begin + s.owned_count - s.width) * s.layer_elems, bytes,
-                                    hipMemcpyDeviceToDevice, pack_stream));
+    double const *send_low = v + s.owned_begin * s.layer_elems, *send_high = v + (s.owned_begin + s.owned_count - s.width) * s.layer_elems;
+    double *recv_low = v + (s.owned_begin - s.width) * s.layer_elems, *recv_high = v + (s.owned_begin + s.owned_count) * s.layer_elems;
     if (split)
     {
+      // the boundary layers are final on `pack_stream` at this point: the transport stream may read them from here on
       MFMG_HIP_CHECK(hipEventRecord(ev_packed, pack_stream));
       MFMG_HIP_CHECK(hipStreamWaitEvent(st, ev_packed, 0));
     }
     comm.transport->sendrecv(send_low, recv_low, s.has_low ? n : 0, send_high, recv_high, s.has_high ? n : 0, st);
     ++comm.n_exchanges;
-    if (s.has_low)
-      MFMG_HIP_CHECK(hipMemcpyAsync(v + (s.owned_begin - s.width) * s.layer_elems, recv_low, bytes, hipMemcpyDeviceToDevice, st));
-    if (s.has_high)
-      MFMG_HIP_CHECK(hipMemcpyAsync(v + (s.owned_begin + s.owned_count) * s.layer_elems, recv_high, bytes,
-                                    hipMemcpyDeviceToDevice, st));
   }
   // refresh the ghost layers of a distributed vector (no-op on one rank / for local spaces)
   void exchange(int space, double *v)
@@ -400,14 +391,9 @@ struct HipHandle
     HaloSpace &s = space_checked(space);
     const int64_t n = (int64_t)s.width * s.layer_elems;
     staging_reserve(n);
-    double *send_low = halo_staging.data(), *send_high = send_low + halo_staging_each, *recv_low = send_high + halo_staging_each,
-           *recv_high = recv_low + halo_staging_each;
-    const size_t bytes = (size_t)n * sizeof(double);
-    if (s.has_low)
-      MFMG_HIP_CHECK(hipMemcpyAsync(send_low, v + (s.owned_begin - s.width) * s.layer_elems, bytes, hipMemcpyDeviceToDevice, stream));
-    if (s.has_high)
-      MFMG_HIP_CHECK(hipMemcpyAsync(send_high, v + (s.owned_begin + s.owned_count) * s.layer_elems, bytes,
-                                    hipMemcpyDeviceToDevice, stream));
+    // the ghost layers are sent as they lie; what comes back is added to the owned boundary layers, so it is received in staging
+    double const *send_low = v + (s.owned_begin - s.width) * s.layer_elems, *send_high = v + (s.owned_begin + s.owned_count) * s.layer_elems;
+    double *recv_low = halo_staging.data(), *recv_high = recv_low + halo_staging_each;
     comm.transport->sendrecv(send_low, recv_low, s.has_low ? n : 0, send_high, recv_high, s.has_high ? n : 0, stream);
     ++comm.n_exchanges;
     if (s.has_low)
