@@ -739,6 +739,9 @@ def test_restrictor_eigenproblems_on_device(ctx, n, material, evaluator, variant
     ((4, 16, 20), "constant", "HipMatrixFreeMeshEvaluator", None),       # two agglomerates in x: everything in the list
     ((180, 12, 6), "constant", "HipMatrixFreeMeshEvaluator", True),      # 90 agglomerates in x: a full and a partial run
     ((132, 10, 8), "constant", "HipMeshEvaluator", True),                # assembled fine operator
+    ((130, 2, 4), "constant", "HipMatrixFreeMeshEvaluator", None),       # one agglomerate in y (both faces), two in z
+    ((128, 6, 2), "constant", "HipMatrixFreeMeshEvaluator", None),       # one agglomerate layer in z
+    ((70, 66, 4), "discontinuous", "HipMatrixFreeMeshEvaluator", None),  # blocks that repeat in patterns
     ((16, 16, 16), "linear", "HipMatrixFreeMeshEvaluator", False),       # every agglomerate its own block: two steps
     ((12, 10, 6), "discontinuous", "HipMatrixFreeMeshEvaluator", None),  # whatever the classes allow: must agree
 ])
