@@ -15,6 +15,11 @@
 // transcendental-free arithmetic; the lanes of the wavefront only split loops whose iterations are independent.
 #include "amge_device.hpp"
 
+#include <cstdlib>
+#include <string>
+#include <unordered_map>
+#include <utility>
+
 #include <algorithm>
 #include <cmath>
 
@@ -38,6 +43,7 @@ struct AmgeArgs
   double *weights;           // [agglomerates][n_eig][NMAX]
   int32_t *n_vec;            // [agglomerates]
   int64_t n_agg;
+  int64_t const *list; // nullptr: every agglomerate; otherwise the n_agg agglomerates to solve (representatives)
 };
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -64,8 +70,9 @@ __global__ __launch_bounds__(256) void amge_agglomerate_kernel(AmgeArgs a)
   double *startv = dloc + NMAX;             // start vector on all local DoFs
   const int dim = a.dim, nc = a.nc;
 
-  for (int64_t agg = (int64_t)blockIdx.x * wpb + wv; agg < a.n_agg; agg += (int64_t)gridDim.x * wpb)
+  for (int64_t slot = (int64_t)blockIdx.x * wpb + wv; slot < a.n_agg; slot += (int64_t)gridDim.x * wpb)
   {
+    const int64_t agg = a.list ? a.list[slot] : slot;
     int ai[3] = {(int)(agg % a.cnt[0]), (int)((agg / a.cnt[0]) % a.cnt[1]), (int)(agg / ((int64_t)a.cnt[0] * a.cnt[1]))};
     int lo[3] = {0, 0, 0}, ln[3] = {1, 1, 1}, lN[3] = {1, 1, 1};
     for (int d = 0; d < dim; ++d)
@@ -322,6 +329,76 @@ bool amge_device_supported(StructuredMesh const &mesh, RestrictorOptions const &
   return nloc <= 64 && (mesh.dim == 2 || mesh.dim == 3);
 }
 
+namespace
+{
+// What the eigenproblem of an agglomerate depends on: its shape, the constraint flags of its nodes and the coefficients of
+// its cells.  Two independent 64-bit hashes of exactly that; agglomerates with equal keys get ONE solve (the kernel is
+// deterministic: equal input, equal bits) -- for a coefficient that is the same in every cell 27 solves instead of 2.1 M.
+__global__ void amge_key_kernel(AmgeArgs a, uint64_t *keys)
+{
+  for (int64_t agg = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; agg < a.n_agg; agg += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int dim = a.dim, nc = a.nc;
+    int ai[3] = {(int)(agg % a.cnt[0]), (int)((agg / a.cnt[0]) % a.cnt[1]), (int)(agg / ((int64_t)a.cnt[0] * a.cnt[1]))};
+    int lo[3] = {0, 0, 0}, ln[3] = {1, 1, 1}, lN[3] = {1, 1, 1};
+    for (int d = 0; d < dim; ++d)
+    {
+      lo[d] = ai[d] * a.ag[d];
+      ln[d] = min(a.ag[d], a.n[d] - lo[d]);
+      lN[d] = ln[d] + 1;
+    }
+    if (dim == 2)
+    {
+      ln[2] = 1;
+      lN[2] = 1;
+    }
+    uint64_t h1 = 1469598103934665603ull, h2 = 0x9e3779b97f4a7c15ull;
+    auto mix = [&](uint64_t v) {
+      h1 = (h1 ^ v) * 1099511628211ull;
+      h1 ^= h1 >> 29;
+      h2 += v + 0x9e3779b97f4a7c15ull;
+      h2 = (h2 ^ (h2 >> 30)) * 0xbf58476d1ce4e5b9ull;
+      h2 = (h2 ^ (h2 >> 27)) * 0x94d049bb133111ebull;
+      h2 ^= h2 >> 31;
+    };
+    mix((uint64_t)ln[0] | ((uint64_t)ln[1] << 16) | ((uint64_t)ln[2] << 32));
+    for (int k = 0; k < lN[2]; ++k)
+      for (int j = 0; j < lN[1]; ++j)
+        for (int i = 0; i < lN[0]; ++i)
+        {
+          const int64_t node = (lo[0] + i) + (int64_t)a.N[0] * ((lo[1] + j) + (int64_t)a.N[1] * ((dim == 3) ? lo[2] + k : 0));
+          mix(a.constrained[a.node_dof[node]] == 1 ? 1u : 0u);
+        }
+    if (a.use_coefficient)
+      for (int k = 0; k < ((dim == 3) ? ln[2] : 1); ++k)
+        for (int j = 0; j < ln[1]; ++j)
+          for (int i = 0; i < ln[0]; ++i)
+          {
+            const int64_t cell = (lo[0] + i) + (int64_t)a.n[0] * ((lo[1] + j) + (int64_t)a.n[1] * ((dim == 3) ? lo[2] + k : 0));
+            for (int q = 0; q < nc; ++q)
+              mix((uint64_t)__double_as_longlong(a.coefficient[cell * nc + q]));
+          }
+    keys[2 * agg] = h1;
+    keys[2 * agg + 1] = h2;
+  }
+}
+
+// results of the representatives to every member of their class
+__global__ void amge_spread_kernel(int64_t n_agg, int per_agg, int64_t const *rep_of, double *weights, int32_t *n_vec)
+{
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_agg * per_agg; t += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int64_t agg = t / per_agg, r = rep_of[agg];
+    if (r == agg)
+      continue;
+    const int64_t e = t - agg * per_agg;
+    weights[agg * per_agg + e] = weights[r * per_agg + e];
+    if (e == 0)
+      n_vec[agg] = n_vec[r];
+  }
+}
+} // namespace
+
 void amge_device_eigen(HipHandle &handle, StructuredMesh const &mesh, RestrictorOptions const &opts, int const cnt[3],
                        std::vector<double> &weights, std::vector<int32_t> &n_vec, int &nmax)
 {
@@ -364,6 +441,41 @@ void amge_device_eigen(HipHandle &handle, StructuredMesh const &mesh, Restrictor
   a.Kq = d_kq.data();
   a.weights = d_w.data();
   a.n_vec = d_nv.data();
+  a.list = nullptr;
+  // identical agglomerates share one solve (the host path does the same with a table per thread)
+  const int64_t n_all = a.n_agg;
+  DeviceBuffer<int64_t> d_list, d_rep_of;
+  bool shared_solves = false;
+  if (!(std::getenv("MFMG_AMGE_MEMO") && std::string(std::getenv("MFMG_AMGE_MEMO")) == "0") && n_all >= 64)
+  {
+    DeviceBuffer<uint64_t> d_keys((size_t)2 * n_all);
+    hipLaunchKernelGGL(amge_key_kernel, dim3(n_blocks_for(n_all, 256, 1 << 16)), dim3(256), 0, st, a, d_keys.data());
+    MFMG_HIP_CHECK(hipGetLastError());
+    const std::vector<uint64_t> keys = d_keys.download(st);
+    struct KeyHash
+    {
+      size_t operator()(std::pair<uint64_t, uint64_t> const &k) const { return (size_t)(k.first ^ (k.second * 0x9e3779b97f4a7c15ull)); }
+    };
+    std::unordered_map<std::pair<uint64_t, uint64_t>, int64_t, KeyHash> first_of;
+    std::vector<int64_t> rep_of((size_t)n_all), reps;
+    for (int64_t agg = 0; agg < n_all; ++agg)
+    {
+      auto ins = first_of.emplace(std::make_pair(keys[2 * agg], keys[2 * agg + 1]), agg);
+      rep_of[agg] = ins.first->second;
+      if (ins.second)
+        reps.push_back(agg);
+      if ((int64_t)reps.size() * 2 > n_all && agg * 2 < n_all)
+        break; // (a coefficient that differs from cell to cell: nothing to share)
+    }
+    if ((int64_t)reps.size() * 2 <= n_all)
+    {
+      shared_solves = true;
+      d_list.upload(reps.data(), reps.size(), st);
+      d_rep_of.upload(rep_of.data(), rep_of.size(), st);
+      a.list = d_list.data();
+      a.n_agg = (int64_t)reps.size();
+    }
+  }
   const int wpb = nmax == 27 ? 4 : 1;
   const size_t lds = (size_t)wpb * (2 * nmax * nmax + 5 * nmax) * sizeof(double);
   const unsigned int blocks = (unsigned int)std::min<int64_t>((a.n_agg + wpb - 1) / wpb, 256 * 16);
@@ -380,6 +492,12 @@ void amge_device_eigen(HipHandle &handle, StructuredMesh const &mesh, Restrictor
     hipLaunchKernelGGL(amge_agglomerate_kernel<64>, dim3(blocks), dim3(64 * wpb), lds, st, a);
   }
   MFMG_HIP_CHECK(hipGetLastError());
+  if (shared_solves)
+  {
+    hipLaunchKernelGGL(amge_spread_kernel, dim3(n_blocks_for(n_all * a.n_eig * nmax, 256, 1 << 16)), dim3(256), 0, st, n_all,
+                       a.n_eig * nmax, d_rep_of.data(), d_w.data(), d_nv.data());
+    MFMG_HIP_CHECK(hipGetLastError());
+  }
   weights = d_w.download(st);
   n_vec = d_nv.download(st);
 }

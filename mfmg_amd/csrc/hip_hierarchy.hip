@@ -2,6 +2,7 @@
 #include "mfmg/hip_hierarchy_helpers.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cctype>
 #include <cmath>
 
@@ -1269,8 +1270,12 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
   // agglomerate eigenproblems: batched on the device (default) or on the host cores ("restrictor.eigensolver host")
   std::string const where = params->get("restrictor.eigensolver", "device");
   ASSERT_THROW(where == "device" || where == "host", "restrictor.eigensolver must be device or host");
+  const bool verbose = std::getenv("MFMG_HIP_VERBOSE") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_r0 = now();
   HostCsr R = build_restrictor_structured(hip_mesh_evaluator->get_mesh(), global_diag, opts, &_grid_hint.node_of_row,
                                           _grid_hint.dims, where == "device" ? &_handle : nullptr);
+  const double t_r1 = now();
   // component of a coarse row = its position among the eigenvectors of its agglomerate
   _grid_hint.component_of_row.resize(_grid_hint.node_of_row.size());
   _grid_hint.n_components = 1;
@@ -1311,8 +1316,12 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
   if (params->get("restrictor.structured", true))
     structured = StructuredRestrictorDevice::create(_handle, hip_mesh_evaluator->get_mesh(), opts.agglomerate,
                                                     _grid_hint.dims, _grid_hint.node_of_row, R);
+  const double t_r2 = now();
   auto restrictor = std::make_shared<HipMatrixOperator>(upload(_handle, std::move(R)));
   restrictor->set_structured(structured);
+  if (verbose)
+    std::fprintf(stderr, "[mfmg_hip] restrictor: eigenproblems and CSR assembly %.2f s, agglomerate-wise layout %.2f s, upload %.2f s\n",
+                 t_r1 - t_r0, t_r2 - t_r1, now() - t_r2);
   if (comm.enabled())
     restrictor->set_spaces(1, 2);
   _own_restrictor = restrictor;

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <limits>
 #include <numeric>
 #include <type_traits>
@@ -857,21 +858,47 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
     int64_t step = std::max<int64_t>(1, n / 65536);
     while (step % 2 == 0 || step % 3 == 0) // the sample must meet every row position inside a node
       ++step;
-    for (int64_t r = 0; r < n && !too_many; r += step)
-      for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
+    // (every thread collects the offsets of its share of the sample; serial, this loop was the second of the 1.1 s the
+    // analysis of a 38 M-entry level took)
+    const int64_t n_sample = (n + step - 1) / step;
+#pragma omp parallel
+    {
+      std::vector<int32_t> mine;
+      bool mine_too_many = false;
+#pragma omp for schedule(static)
+      for (int64_t q = 0; q < n_sample; ++q)
       {
-        const int32_t o = (int32_t)(col[p] / c - r / c);
-        auto it = std::lower_bound(offs.begin(), offs.end(), o);
-        if (it == offs.end() || *it != o)
+        const int64_t r = q * step;
+        if (mine_too_many)
+          continue;
+        int32_t last = INT32_MIN;
+        for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
         {
-          offs.insert(it, o);
-          if (offs.size() > kMaxBlockDiagonals)
+          const int32_t o = (int32_t)(col[p] / c - r / c);
+          if (o == last)
+            continue;
+          last = o;
+          auto it = std::lower_bound(mine.begin(), mine.end(), o);
+          if (it == mine.end() || *it != o)
           {
-            too_many = true;
-            break;
+            mine.insert(it, o);
+            if (mine.size() > kMaxBlockDiagonals)
+            {
+              mine_too_many = true;
+              break;
+            }
           }
         }
       }
+#pragma omp critical
+      {
+        too_many = too_many || mine_too_many;
+        std::vector<int32_t> merged;
+        std::set_union(offs.begin(), offs.end(), mine.begin(), mine.end(), std::back_inserter(merged));
+        offs.swap(merged);
+      }
+    }
+    too_many = too_many || offs.size() > kMaxBlockDiagonals;
     if (too_many || offs.empty())
       continue;
     const double fill = double(_nnz) / (double(n) * double(offs.size()) * c);
