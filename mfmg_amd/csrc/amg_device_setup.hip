@@ -102,9 +102,9 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
                  "the device setup of the aggregation hierarchy needs node-major rows with a fixed number of components");
 
   // host copy of the current level: owned rows of A (local column ids), near-null vector (local, owned part valid)
+  // (the level's matrix stays on the device: its diagonal and row sums come from a kernel; only the level that is gathered at
+  // the end is downloaded -- the first level alone is 2.7 GB)
   HostCsr A;
-  A.n_rows = A.n_cols = g.n_rows();
-  matrix->download(A.row_ptr, A.col, A.val);
   std::vector<double> B = near_null;
   ASSERT_THROW((int64_t)B.size() == g.n_rows(), "near-null-space vector has the wrong size");
   std::shared_ptr<HipMatrixOperator> a_op = std::const_pointer_cast<HipMatrixOperator>(_matrix_operator);
@@ -151,6 +151,8 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     if (!coarsen_here)
     {
       // ---- gather this level; the rest of the hierarchy is replicated (host setup of one rank)
+      A.n_rows = A.n_cols = g.n_rows();
+      a_op->get_matrix()->download(A.row_ptr, A.col, A.val);
       finish_amg_replicated(a_op, std::move(A), std::move(B), g.space, g.owned_begin, g.owned_count, g.global_begin, g.global_layers,
                             g.dims, C, opts, smoother_params);
       break;
@@ -181,18 +183,16 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     // ---- diagonal, rho = max_i sum_j |a_ij| / |a_ii| over the owned rows of all ranks
     std::vector<double> dinv((size_t)n_f, 0.);
     double rho = 0.;
-#pragma omp parallel for schedule(static) reduction(max : rho)
-    for (int64_t i = row0; i < row0 + n_own; ++i)
     {
-      double d = 0., sum = 0.;
-      for (int p = A.row_ptr[i]; p < A.row_ptr[i + 1]; ++p)
+      DeviceBuffer<double> d_dinv((size_t)n_f), d_ratio((size_t)n_f);
+      a_op->get_matrix()->row_ratios(d_dinv.data(), d_ratio.data());
+      const std::vector<double> all_dinv = d_dinv.download(h.stream), ratio = d_ratio.download(h.stream);
+#pragma omp parallel for schedule(static) reduction(max : rho)
+      for (int64_t i = row0; i < row0 + n_own; ++i)
       {
-        sum += std::abs(A.val[p]);
-        if (A.col[p] == i)
-          d = A.val[p];
+        dinv[i] = all_dinv[i];
+        rho = std::max(rho, ratio[i]);
       }
-      dinv[i] = d != 0. ? 1. / d : 0.;
-      rho = std::max(rho, d != 0. ? sum / std::abs(d) : HUGE_VAL);
     }
     ASSERT_THROW(rho < HUGE_VAL, "zero diagonal in the multilevel coarse solver setup");
     rho = h.allreduce_max(rho);
@@ -393,11 +393,9 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     _amg.push_back(std::move(L));
 
     // ---- next level
-    HostCsr Ac_copy = Ac;
-    auto ac_mat = upload_csr(h, std::move(Ac_copy));
+    auto ac_mat = upload_csr(h, std::move(Ac));
     a_op = std::make_shared<HipMatrixOperator>(ac_mat);
     a_op->set_spaces(c.space, c.space);
-    A = std::move(Ac);
     B = std::move(Bc);
     g = c;
   }

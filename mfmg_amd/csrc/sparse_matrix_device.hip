@@ -225,6 +225,24 @@ __global__ void csr_inv_diag_kernel(T const *val, int32_t const *col, int32_t co
   dinv[row] = (d != T(0)) ? T(1) / d : T(0); // emptied (ghost) rows have no diagonal
 }
 
+// dinv[row] = 1 / a_rr (0 for a row without diagonal), ratio[row] = sum_j |a_rj| / |a_rr| (HUGE_VAL for a zero diagonal): what the setup of the aggregation hierarchy needs from a level -- in the order of the host loop
+template <typename T>
+__global__ void csr_row_ratio_kernel(T const *val, int32_t const *col, int32_t const *row_ptr, int64_t n_rows, T *dinv, T *ratio)
+{
+  const int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (row >= n_rows)
+    return;
+  T d = T(0), sum = T(0);
+  for (int p = row_ptr[row]; p < row_ptr[row + 1]; ++p)
+  {
+    sum += fabs(val[p]);
+    if (col[p] == row)
+      d = val[p];
+  }
+  dinv[row] = (d != T(0)) ? T(1) / d : T(0);
+  ratio[row] = (d != T(0)) ? sum / fabs(d) : T(HUGE_VAL);
+}
+
 // Block-diagonal ("stencil") storage for square matrices whose rows come in nodes of C unknowns on a
 // lexicographically numbered grid -- the coarse operators of the AMGe hierarchy on structured agglomerates:
 // every C x C block sits on one of D block diagonals, node + offs[d].  Values are kept per diagonal and
@@ -1230,25 +1248,49 @@ void SparseMatrixDevice<T>::build_node_classes(std::vector<int32_t> const &row_p
     int64_t step = std::max<int64_t>(1, n_nodes / 65536);
     while (step % 2 == 0 || step % 3 == 0)
       ++step;
-    for (int64_t nd = 0; nd < n_nodes && !too_many; nd += step)
+    const int64_t n_sample = (n_nodes + step - 1) / step;
+#pragma omp parallel
     {
-      const int64_t b = node_base(nd, c);
-      for (int64_t r = nd * c; r < (nd + 1) * c && !too_many; ++r)
-        for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
+      std::vector<int32_t> mine; // (the offsets of a thread's share of the sample, merged below)
+      bool mine_too_many = false;
+#pragma omp for schedule(static)
+      for (int64_t q = 0; q < n_sample; ++q)
+      {
+        const int64_t nd = q * step;
+        if (mine_too_many)
+          continue;
+        const int64_t b = node_base(nd, c);
+        for (int64_t r = nd * c; r < (nd + 1) * c && !mine_too_many; ++r)
         {
-          const int32_t o = (int32_t)(col[p] / c - b);
-          auto it = std::lower_bound(offs.begin(), offs.end(), o);
-          if (it == offs.end() || *it != o)
+          int32_t last = INT32_MIN;
+          for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
           {
-            offs.insert(it, o);
-            if (offs.size() > kMaxBlockDiagonals)
+            const int32_t o = (int32_t)(col[p] / c - b);
+            if (o == last)
+              continue;
+            last = o;
+            auto it = std::lower_bound(mine.begin(), mine.end(), o);
+            if (it == mine.end() || *it != o)
             {
-              too_many = true;
-              break;
+              mine.insert(it, o);
+              if (mine.size() > kMaxBlockDiagonals)
+              {
+                mine_too_many = true;
+                break;
+              }
             }
           }
         }
+      }
+#pragma omp critical
+      {
+        too_many = too_many || mine_too_many;
+        std::vector<int32_t> merged;
+        std::set_union(offs.begin(), offs.end(), mine.begin(), mine.end(), std::back_inserter(merged));
+        offs.swap(merged);
+      }
     }
+    too_many = too_many || offs.size() > kMaxBlockDiagonals;
     if (too_many || offs.empty())
       continue;
     const double fill = double(_nnz) / (double(n_nodes) * double(offs.size()) * c * c);
@@ -1758,6 +1800,15 @@ void SparseMatrixDevice<T>::inverse_diagonal(T *dinv) const
     return;
   hipLaunchKernelGGL(csr_inv_diag_kernel<T>, dim3(n_blocks_for(_n_rows)), dim3(block_size), 0,
                      _handle.stream, _val.data(), _col.data(), _row_ptr.data(), _n_rows, dinv);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void SparseMatrixDevice<T>::row_ratios(T *dinv, T *ratio) const
+{
+  ASSERT_THROW(_n_rows == _n_cols, "row_ratios needs a square matrix");
+  hipLaunchKernelGGL(csr_row_ratio_kernel<T>, dim3(n_blocks_for(_n_rows)), dim3(block_size), 0, _handle.stream, _val.data(), _col.data(),
+                     _row_ptr.data(), _n_rows, dinv, ratio);
   MFMG_HIP_CHECK(hipGetLastError());
 }
 

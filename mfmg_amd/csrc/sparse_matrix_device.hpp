@@ -62,6 +62,8 @@ public:
   }
   // extract_inv_diag (source/cuda/cuda_smoother.cu:86-96)
   void inverse_diagonal(T *dinv) const;
+  // dinv = 1 / diagonal and ratio = (sum of |entries| of the row) / |diagonal| per row (device arrays of m() entries)
+  void row_ratios(T *dinv, T *ratio) const;
 
   // setup-time algebra on the host copy (the reference does the transpose on the
   // host through EpetraExt, cuda_matrix_operator.cu:93-130, and SpGEMM with
