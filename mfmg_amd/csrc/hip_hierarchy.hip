@@ -48,10 +48,10 @@ __global__ void dense_lu_solve_kernel(int n, double const *lu, int32_t const *pe
     x[i] = y[i];
 }
 
-std::shared_ptr<SparseMatrixDevice<double>> upload(HipHandle &handle, HostCsr &&m)
+std::shared_ptr<SparseMatrixDevice<double>> upload(HipHandle &handle, HostCsr &&m, bool analyse = true)
 {
   return std::make_shared<SparseMatrixDevice<double>>(handle, m.n_rows, m.n_cols, std::move(m.row_ptr),
-                                                      std::move(m.col), std::move(m.val));
+                                                      std::move(m.col), std::move(m.val), true, analyse);
 }
 } // namespace
 
@@ -1317,7 +1317,8 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
     structured = StructuredRestrictorDevice::create(_handle, hip_mesh_evaluator->get_mesh(), opts.agglomerate,
                                                     _grid_hint.dims, _grid_hint.node_of_row, R);
   const double t_r2 = now();
-  auto restrictor = std::make_shared<HipMatrixOperator>(upload(_handle, std::move(R)));
+  // (with the agglomerate-wise form in place the CSR copy serves the setup algebra and get_restrictor only: no layouts)
+  auto restrictor = std::make_shared<HipMatrixOperator>(upload(_handle, std::move(R), structured == nullptr));
   restrictor->set_structured(structured);
   if (verbose)
     std::fprintf(stderr, "[mfmg_hip] restrictor: eigenproblems and CSR assembly %.2f s, agglomerate-wise layout %.2f s, upload %.2f s\n",

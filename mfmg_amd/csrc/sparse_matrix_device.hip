@@ -760,7 +760,7 @@ void launch_lpr(CsrArgs<T> const &a, hipStream_t st)
 template <typename T>
 SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int64_t n_cols,
                                           std::vector<int32_t> row_ptr, std::vector<int32_t> col,
-                                          std::vector<T> val, bool keep_host)
+                                          std::vector<T> val, bool keep_host, bool analyse)
     : _handle(handle), _n_rows(n_rows), _n_cols(n_cols)
 {
   ASSERT_THROW((int64_t)row_ptr.size() == n_rows + 1, "row_ptr has the wrong size");
@@ -784,18 +784,18 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
     lpr = 256; // a workgroup per row (csr_spmv_row_block_kernel)
   _lanes_per_row = lpr;
   // ---- block-diagonal storage (see bdia_spmv_kernel); when it applies the LDS lists are not needed
-  if (n_rows == n_cols && n_rows >= 32768 && avg >= 8.)
+  if (analyse && n_rows == n_cols && n_rows >= 32768 && avg >= 8.)
     build_block_diagonals(row_ptr, col, val);
   // ---- row-base storage (see rowbase_spmv_kernel) for matrices the block diagonals do not fit
   // (one thread per row: below ~1000 workgroups the CSR kernels with several lanes per row fill the chip better)
   // ---- node classes (see build_node_classes) for the rectangular operators of a translation-invariant problem
-  if (!_use_bdia && n_rows >= 32768 && avg >= 4.)
+  if (analyse && !_use_bdia && n_rows >= 32768 && avg >= 4.)
     build_node_classes(row_ptr, col, val);
-  if (!_use_bdia && !_use_nodecls && n_rows >= 200000 && avg >= 4. && avg <= 160.)
+  if (analyse && !_use_bdia && !_use_nodecls && n_rows >= 200000 && avg >= 4. && avg <= 160.)
     build_row_base(row_ptr, col, val);
   // ---- block-local column compression for the LDS-cached kernel
   // (a 128-row block per workgroup: below ~256 blocks the plain kernel fills the chip better)
-  if (!_use_bdia && !_use_rowbase && !_use_nodecls && n_rows >= 256 * kRowsPerBlock && avg >= 4.)
+  if (analyse && !_use_bdia && !_use_rowbase && !_use_nodecls && n_rows >= 256 * kRowsPerBlock && avg >= 4.)
   {
     const int64_t nb = (n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
     std::vector<int32_t> blk_ptr(nb + 1, 0);

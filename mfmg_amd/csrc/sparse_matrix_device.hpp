@@ -29,7 +29,9 @@ public:
 
   // convert_matrix (source/cuda/utils.cu:39-168): host CSR -> device
   SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int64_t n_cols, std::vector<int32_t> row_ptr,
-                     std::vector<int32_t> col, std::vector<T> val, bool keep_host = true);
+                     std::vector<int32_t> col, std::vector<T> val, bool keep_host = true, bool analyse = true);
+  // (analyse = false: plain CSR only -- for a matrix kept for the setup algebra and inspection while another object
+  // evaluates it, like the restrictor next to its agglomerate-wise form)
 
   int64_t m() const { return _n_rows; }
   int64_t n() const { return _n_cols; }
