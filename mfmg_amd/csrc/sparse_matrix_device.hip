@@ -932,7 +932,7 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
   const int c = best_c, D = (int)best_offs.size();
   if (double(n) * D * c * sizeof(T) > 6e9) // the planes are built on the host
     return;
-  std::vector<T> dv((size_t)n * D * c, T(0));
+  ZeroedHostArray<T> dv((size_t)n * D * c);
   bool ok = true;
 #pragma omp parallel for schedule(static) reduction(&& : ok)
   for (int64_t r = 0; r < n; ++r)
@@ -1308,7 +1308,7 @@ void SparseMatrixDevice<T>::build_node_classes(std::vector<int32_t> const &row_p
   const size_t tuple = (size_t)c * D * c;
   if (double(n_nodes) * tuple * sizeof(T) > 6e9)
     return;
-  std::vector<T> tv((size_t)n_nodes * tuple, T(0)); // [node][rc][d][cc]
+  ZeroedHostArray<T> tv((size_t)n_nodes * tuple); // [node][rc][d][cc]
   std::vector<int32_t> base(n_nodes, 0);
   bool ok = true;
 #pragma omp parallel for schedule(static) reduction(&& : ok)
@@ -1462,7 +1462,7 @@ void SparseMatrixDevice<T>::build_row_base(std::vector<int32_t> const &row_ptr, 
     return;
   // every row: a base such that all its columns fall on slots (rows at a boundary miss the low slots)
   std::vector<int32_t> base(n, 0);
-  std::vector<T> dv((size_t)n * S, T(0));
+  ZeroedHostArray<T> dv((size_t)n * S);
   bool ok = true;
 #pragma omp parallel for schedule(static) reduction(&& : ok)
   for (int64_t r = 0; r < n; ++r)
