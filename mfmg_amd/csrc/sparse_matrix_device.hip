@@ -768,10 +768,17 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
   ASSERT_THROW((int64_t)col.size() == _nnz && (int64_t)val.size() == _nnz,
                "column index / value arrays do not match row_ptr");
   ASSERT_THROW(n_rows * 64 < (int64_t(1) << 40), "matrix too large");
-  for (int64_t r = 0; r < n_rows; ++r)
-    ASSERT_THROW(row_ptr[r] <= row_ptr[r + 1], "row_ptr must be non-decreasing");
-  for (int64_t p = 0; p < _nnz; ++p)
-    ASSERT_THROW(col[p] >= 0 && col[p] < n_cols, "column index out of range");
+  {
+    bool rows_ok = true, cols_ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : rows_ok)
+    for (int64_t r = 0; r < n_rows; ++r)
+      rows_ok = rows_ok && row_ptr[r] <= row_ptr[r + 1];
+    ASSERT_THROW(rows_ok, "row_ptr must be non-decreasing");
+#pragma omp parallel for schedule(static) reduction(&& : cols_ok)
+    for (int64_t p = 0; p < _nnz; ++p)
+      cols_ok = cols_ok && col[p] >= 0 && col[p] < n_cols;
+    ASSERT_THROW(cols_ok, "column index out of range");
+  }
   const double avg = n_rows > 0 ? double(_nnz) / double(n_rows) : 0.;
   const auto t_begin = std::chrono::steady_clock::now();
   // lanes per row: about 3-6 entries per lane (measured on R, R^T, A_c and the prolongators, profiles/)
