@@ -237,15 +237,19 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     for (int d = 0; d < 3; ++d)
       period_p[d] = std::max(1, std::min(1 + g.reach, gdims_c[d]));
     const int n_col_p = period_p[0] * period_p[1] * period_p[2] * C;
-    std::vector<std::vector<double>> Z((size_t)n_col_p);
+    // (one array for all probes, its pages first touched by all threads, copies queued without a wait in between)
+    std::unique_ptr<ZeroedHostArray<double>> Z(new ZeroedHostArray<double>((size_t)n_col_p * (size_t)n_own));
     for (int col = 0; col < n_col_p; ++col)
     {
       const int comp = col % C, oc = col / C;
       const int phase[3] = {oc % period_p[0], (oc / period_p[0]) % period_p[1], oc / (period_p[0] * period_p[1])};
       vec::select_rows(h, g.dims, C, 2, (int)g.global_begin, period_p, phase, comp, t_dev.get_values(), y_f.get_values());
       a_op->get_matrix()->vmult(z_f.get_values(), y_f.get_values()); // ghosts of y are set locally: no exchange
-      Z[col] = download_range(h, z_f.get_values(), row0, n_own);
+      // (the copy is queued behind the application on the same stream; z_f is overwritten only by the next application)
+      MFMG_HIP_CHECK(hipMemcpyAsync(Z->data() + (size_t)col * n_own, z_f.get_values() + row0, (size_t)n_own * sizeof(double),
+                                    hipMemcpyDeviceToHost, h.stream));
     }
+    MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
     HostCsr P;
     P.n_rows = n_f;
     P.n_cols = n_c;
@@ -271,7 +275,7 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
               const bool own_agg = (I == (x >> 1)) && (J == (y >> 1)) && (K == (int)(zg >> 1));
               for (int comp = 0; comp < C; ++comp)
               {
-                const double ay = Z[(size_t)(oc * C + comp)][(size_t)(i - row0)];
+                const double ay = (*Z)[(size_t)(oc * C + comp) * (size_t)n_own + (size_t)(i - row0)];
                 const double yi = (own_agg && comp == (int)(i % C)) ? t[i] : 0.;
                 const double v = yi - w * dinv[i] * ay;
                 if (v != 0.)
@@ -304,8 +308,7 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
         });
       }
     }
-    Z.clear();
-    Z.shrink_to_fit();
+    Z.reset();
     auto p_mat = upload_csr(h, std::move(P));
     auto pt_mat = p_mat->transpose();
     const double t1 = wall_now();
@@ -316,7 +319,7 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
       period_a[d] = std::max(1, std::min(2 * c.reach + 1, gdims_c[d]));
     const int n_col_a = period_a[0] * period_a[1] * period_a[2] * C;
     const int64_t crow0 = c.owned_row_begin(), cn_own = c.owned_rows();
-    std::vector<std::vector<double>> Y((size_t)n_col_a);
+    std::unique_ptr<ZeroedHostArray<double>> Y(new ZeroedHostArray<double>((size_t)n_col_a * (size_t)cn_own));
     for (int col = 0; col < n_col_a; ++col)
     {
       const int comp = col % C, oc = col / C;
@@ -327,8 +330,10 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
       a_op->get_matrix()->vmult(z_f.get_values(), y_f.get_values());
       pt_mat->vmult(y_c.get_values(), z_f.get_values());
       h.exchange_reverse_add(c.space, y_c.get_values());
-      Y[col] = download_range(h, y_c.get_values(), crow0, cn_own);
+      MFMG_HIP_CHECK(hipMemcpyAsync(Y->data() + (size_t)col * cn_own, y_c.get_values() + crow0, (size_t)cn_own * sizeof(double),
+                                    hipMemcpyDeviceToHost, h.stream));
     }
+    MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
     HostCsr Ac;
     Ac.n_rows = Ac.n_cols = n_c;
     Ac.row_ptr.assign(n_c + 1, 0);
@@ -346,7 +351,7 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
               ASSERT_THROW(Kl >= 0 && Kl < c.dims[2], "internal: coarse-operator column outside the local box");
               for (int comp = 0; comp < C; ++comp)
               {
-                const double v = Y[(size_t)(oc * C + comp)][(size_t)(r - crow0)];
+                const double v = (*Y)[(size_t)(oc * C + comp) * (size_t)cn_own + (size_t)(r - crow0)];
                 if (v != 0.)
                   emit((((int64_t)Kl * c.dims[1] + J) * c.dims[0] + I) * C + comp, v);
               }
@@ -377,8 +382,7 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
         });
       }
     }
-    Y.clear();
-    Y.shrink_to_fit();
+    Y.reset();
     if (verbose)
       std::fprintf(stderr, "[mfmg_hip] amg level %d on the device (%lld local rows, reach %d): P %d probes %.2f s, A_c %d probes %.2f s\n",
                    level, (long long)n_f, g.reach, n_col_p, t1 - t0, n_col_a, wall_now() - t1);
