@@ -146,23 +146,28 @@ void StructuredMesh::build_node_map()
   const int nz_cells = (dim == 3) ? n[2] : 1;
   node_dof.assign((size_t)N[0] * N[1] * N[2], -1);
   int64_t n_bad = 0;
-  for (int k = 0; k < nz_cells; ++k)
-    for (int j = 0; j < n[1]; ++j)
-      for (int i = 0; i < n[0]; ++i)
-      {
-        const int64_t c = cell_index(i, j, k);
-        for (int m = 0; m < ncorn; ++m)
+  // (cell layers of one parity touch disjoint node layers: two parallel sweeps instead of 134 M serial iterations)
+  for (int parity = 0; parity < 2; ++parity)
+  {
+#pragma omp parallel for schedule(static) reduction(+ : n_bad)
+    for (int k = parity; k < nz_cells; k += 2)
+      for (int j = 0; j < n[1]; ++j)
+        for (int i = 0; i < n[0]; ++i)
         {
-          const int64_t nd = node_index(i + (m & 1), j + ((m >> 1) & 1), k + ((m >> 2) & 1));
-          const int32_t g = cell_dofs[c * ncorn + m];
-          if (g < 0 || g >= n_dofs)
-            ++n_bad;
-          else if (node_dof[nd] == -1)
-            node_dof[nd] = g;
-          else if (node_dof[nd] != g)
-            ++n_bad;
+          const int64_t c = cell_index(i, j, k);
+          for (int m = 0; m < ncorn; ++m)
+          {
+            const int64_t nd = node_index(i + (m & 1), j + ((m >> 1) & 1), k + ((m >> 2) & 1));
+            const int32_t g = cell_dofs[c * ncorn + m];
+            if (g < 0 || g >= n_dofs)
+              ++n_bad;
+            else if (node_dof[nd] == -1)
+              node_dof[nd] = g;
+            else if (node_dof[nd] != g)
+              ++n_bad;
+          }
         }
-      }
+  }
   std::vector<uint8_t> seen(n_dofs, 0);
   for (auto g : node_dof)
   {
@@ -351,19 +356,27 @@ std::vector<double> operator_diagonal(StructuredMesh const &mesh, ConstraintSema
   const int nc = mesh.nc();
   std::vector<double> diag(mesh.n_dofs, 0.);
   const int nzc = (mesh.dim == 3) ? mesh.n[2] : 1;
-  // serial scatter over cells in a fixed order (deterministic)
-  for (int k = 0; k < nzc; ++k)
-    for (int j = 0; j < mesh.n[1]; ++j)
-      for (int i = 0; i < mesh.n[0]; ++i)
+  // every node gathers the contributions of its (up to 2^dim) cells in the order a serial scatter over the cells in
+  // (k, j, i) order would add them: the same bits, on all threads
+  const int Nz = (mesh.dim == 3) ? mesh.N[2] : 1;
+#pragma omp parallel for schedule(static)
+  for (int K = 0; K < Nz; ++K)
+    for (int J = 0; J < mesh.N[1]; ++J)
+      for (int I = 0; I < mesh.N[0]; ++I)
       {
-        const int64_t c = mesh.cell_index(i, j, k);
-        for (int m = 0; m < nc; ++m)
-        {
-          double v = 0.;
-          for (int q = 0; q < nc; ++q)
-            v += mesh.coefficient[c * nc + q] * Kq[((size_t)q * nc + m) * nc + m];
-          diag[mesh.cell_dofs[c * nc + m]] += v;
-        }
+        double sum = 0.;
+        for (int k = std::max(K - 1, 0); k <= std::min(K, nzc - 1); ++k)
+          for (int j = std::max(J - 1, 0); j <= std::min(J, mesh.n[1] - 1); ++j)
+            for (int i = std::max(I - 1, 0); i <= std::min(I, mesh.n[0] - 1); ++i)
+            {
+              const int64_t c = mesh.cell_index(i, j, k);
+              const int m = (I - i) + 2 * (J - j) + ((mesh.dim == 3) ? 4 * (K - k) : 0);
+              double v = 0.;
+              for (int q = 0; q < nc; ++q)
+                v += mesh.coefficient[c * nc + q] * Kq[((size_t)q * nc + m) * nc + m];
+              sum += v;
+            }
+        diag[mesh.node_dof[mesh.node_index(I, J, K)]] = sum;
       }
   if (sem == ConstraintSemantics::matrix_free)
     for (int64_t g = 0; g < mesh.n_dofs; ++g)

@@ -157,7 +157,8 @@ RestrictorOptions HipMeshEvaluator::agglomerate_options(ptree const &params) con
 HipMatrixFreeMeshEvaluator::HipMatrixFreeMeshEvaluator(HipHandle &handle, mfmg_hip_mesh_desc const &mesh)
     : HipMeshEvaluator(handle, mesh)
 {
-  _op = std::make_shared<MatrixFreeLaplaceDevice<double>>(handle, _desc, handle.allow_cell_constant);
+  // (from the caller's arrays: when they are on the device already, the host copy of the base class need not travel back)
+  _op = std::make_shared<MatrixFreeLaplaceDevice<double>>(handle, mesh, handle.allow_cell_constant);
   HaloCommunicator &c = handle.comm;
   if (c.enabled())
   {
