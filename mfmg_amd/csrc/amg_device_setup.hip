@@ -250,6 +250,7 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
                                     hipMemcpyDeviceToHost, h.stream));
     }
     MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
+    const double t_probed = wall_now();
     HostCsr P;
     P.n_rows = n_f;
     P.n_cols = n_c;
@@ -309,8 +310,13 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
       }
     }
     Z.reset();
+    const double t_assembled = wall_now();
     auto p_mat = upload_csr(h, std::move(P));
+    const double t_uploaded = wall_now();
     auto pt_mat = p_mat->transpose();
+    if (verbose)
+      std::fprintf(stderr, "[mfmg_hip] amg level %d: P probes %.2f s, assembly %.2f s, upload + layouts %.2f s, transpose %.2f s\n", level,
+                   t_probed - t0, t_assembled - t_probed, t_uploaded - t_assembled, wall_now() - t_uploaded);
     const double t1 = wall_now();
 
     // ---- A_c = P^T A P by probing: coarse nodes (2 reach_c + 1) apart never meet in a row
