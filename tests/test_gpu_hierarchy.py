@@ -734,6 +734,20 @@ def test_restrictor_eigenproblems_on_device(ctx, n, material, evaluator, variant
         assert e < 1e-11 * scale, (r, e)
 
 
+@pytest.mark.parametrize("n,material", [((16, 12, 10), "constant"), ((12, 10, 6), "discontinuous"), ((8, 8, 8), "linear")])
+def test_shared_agglomerate_eigensolves_change_no_bit(ctx, monkeypatch, n, material):
+    """Agglomerates with equal shape, constraint flags and cell coefficients share one eigensolve on the device
+    (amge_device.hip: two 64-bit hashes of exactly that input); the restrictor must come out bit for bit as with a solve
+    per agglomerate."""
+    prob = M.LaplaceProblem(n, material, device="cuda")
+    params = base_params(solver={"type": "pcg", "n_iterations": 2})
+    R1 = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params).restrictor().to_scipy()
+    monkeypatch.setenv("MFMG_AMGE_MEMO", "0")
+    R0 = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params).restrictor().to_scipy()
+    assert np.array_equal(R1.indptr, R0.indptr) and np.array_equal(R1.indices, R0.indices)
+    assert np.array_equal(R1.data, R0.data)
+
+
 @pytest.mark.parametrize("n,material,evaluator,expect", [
     ((8, 8, 8), "constant", "HipMatrixFreeMeshEvaluator", None),         # too small for classes of agglomerates
     ((4, 16, 20), "constant", "HipMatrixFreeMeshEvaluator", None),       # two agglomerates in x: everything in the list
