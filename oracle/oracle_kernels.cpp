@@ -102,6 +102,38 @@ void mf_apply(const Mesh &m, const double *x, double *y)
       y[g] = x[g]; // MatrixFreeOperators::Base::vmult: dst_c = src_c
 }
 
+// compute_diagonal (tests/laplace_matrix_free.hpp:75-98, local_compute_diagonal :158-199): per cell, the operator
+// applied to each unit vector, entry i kept; summed into the global vector; constrained entries set to one
+// (set_constrained_entries_to_one).  Same layer schedule as mf_apply.
+void mf_diagonal(const Mesh &m, double *d)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t g = 0; g < m.n_dofs; ++g)
+    d[g] = 0.;
+  for (int parity = 0; parity < 2; ++parity)
+  {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int k = parity; k < m.n[2]; k += 2)
+      for (int j = 0; j < m.n[1]; ++j)
+        for (int i = 0; i < m.n[0]; ++i)
+        {
+          const int64_t c = i + (int64_t)m.n[0] * (j + (int64_t)m.n[1] * k);
+          const int32_t *cd = m.cell_dofs + c * 8;
+          for (int q = 0; q < 8; ++q)
+          {
+            double u[8] = {0., 0., 0., 0., 0., 0., 0., 0.}, v[8];
+            u[q] = 1.;
+            cell_apply(u, m.coef + c * 8, m.f, v);
+            d[cd[q]] += v[q];
+          }
+        }
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t g = 0; g < m.n_dofs; ++g)
+    if (m.con[g])
+      d[g] = 1.;
+}
+
 void csr_spmv(int64_t n_rows, const int32_t *rp, const int32_t *col, const double *val, const double *x, double *y)
 {
 #pragma omp parallel for schedule(static)
@@ -319,6 +351,13 @@ void oracle_mf_apply(const int *n, const double *h, const int32_t *cell_dofs, co
 {
   Mesh m = make_mesh(n, h, cell_dofs, coef, con);
   mf_apply(m, x, y);
+}
+
+void oracle_mf_diagonal(const int *n, const double *h, const int32_t *cell_dofs, const double *coef,
+                        const uint8_t *con, double *d)
+{
+  Mesh m = make_mesh(n, h, cell_dofs, coef, con);
+  mf_diagonal(m, d);
 }
 
 void oracle_csr_spmv(int64_t n_rows, const int32_t *rp, const int32_t *col, const double *val, const double *x,

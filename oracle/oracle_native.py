@@ -95,6 +95,19 @@ def mf_apply(n, h, cell_dofs, coef, con, x):
     return y
 
 
+def mf_diagonal(n, h, cell_dofs, coef, con):
+    """compute_diagonal of the matrix-free operator (constrained entries one)."""
+    lib = load()
+    n_a = np.asarray(n, dtype=np.int32)
+    h_a = np.asarray(h, dtype=np.float64)
+    cd = np.ascontiguousarray(cell_dofs, dtype=np.int32)
+    co = np.ascontiguousarray(coef, dtype=np.float64)
+    cn = np.ascontiguousarray(con, dtype=np.uint8)
+    d = np.empty(cn.shape[0])
+    lib.oracle_mf_diagonal(_p(n_a), _p(h_a), _p(cd), _p(co), _p(cn), _p(d))
+    return d
+
+
 def csr_spmv(A, x):
     lib = load()
     rp = np.ascontiguousarray(A.indptr, dtype=np.int32)

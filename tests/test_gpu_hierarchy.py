@@ -794,3 +794,41 @@ def test_residual_restriction_in_one_pass(ctx, monkeypatch, n, material, evaluat
         ctx.synchronize()
         hist.append(xx.cpu().numpy())
     assert np.abs(hist[0] - hist[1]).max() <= 1e-12 * np.abs(x0).max()
+
+
+@pytest.mark.parametrize("material", ["constant", "linear"])
+def test_full_size_vcycle_history_against_the_native_oracle(ctx, material):
+    """Parity AT THE SIZE THE BENCH QUOTES (BASELINE.json: 256^3 cells = 257^3 DoFs per GPU, Chebyshev(3), multilevel
+    coarse solve): the harness of /root/reference/tests/test_hierarchy.cc:76-123 (x0 random with the constrained
+    entries zero, b = 0, residual norm after every cycle) run by the GPU product and by oracle/oracle_kernels.cpp
+    (pinned against the numpy oracle in tests/test_oracle_native.py) on the host cores.  The oracle takes the
+    product's own R, A_c and aggregation levels (downloaded), computes the operator, its diagonal, the smoother and
+    every coarse product itself with plain CSR loops: 5-cycle residual history and final iterate to 1e-10 relative."""
+    import oracle_native as ON
+
+    n = (256, 256, 256)
+    prob = M.LaplaceProblem(n, material, device="cuda")
+    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0}, solver={"type": "amg"})
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    deg, lmin, lmax = h.smoother_info()
+    cd = prob.cell_dofs.cpu().numpy()
+    co = prob.coefficient.cpu().numpy()
+    cn = prob.constrained.cpu().numpy()
+    # the operator's diagonal: oracle's own (compute_diagonal), and the product's against it
+    d_o = ON.mf_diagonal(n, prob.h, cd, co, cn)
+    op = M.MatrixFreeLaplace(ctx, prob)
+    d_g = op.diagonal_inverse().cpu().numpy()
+    np.testing.assert_allclose(d_g, 1.0 / d_o, rtol=1e-13)
+    R = h.restrictor().to_scipy()
+    Ac = h.coarse_operator().to_scipy()
+    levels = h.coarse_amg_levels()
+    x0 = np.where(cn.astype(bool), 0.0, np.random.default_rng(5).random(prob.n_dofs))
+    b = np.zeros(prob.n_dofs)
+    cycles = 5
+    x_o, res_o = ON.vcycles(n, prob.h, cd, co, cn, 1.0 / d_o, deg, lmin, lmax, R, Ac, 0, b, x0, cycles,
+                            amg_levels=levels)
+    del R, Ac, levels
+    res_g, x_g = gpu_history(ctx, h, lambda y, x: op.vmult(y, x), b, x0, n_cycles=cycles)
+    np.testing.assert_allclose(res_g, res_o, rtol=HIST_TOL, atol=HIST_ATOL)
+    assert np.abs(x_g - x_o).max() <= 1e-10 * np.abs(x0).max()
+    assert res_o[-1] / res_o[-2] < 0.4

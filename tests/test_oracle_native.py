@@ -33,6 +33,10 @@ def test_native_matrix_free_operator(n, material):
         ref = mf.vmult(x)
         got = ON.mf_apply(n, mesh.h, mesh.cell_dofs(), coef, con, x)
         assert np.abs(got - ref).max() <= TOL * np.abs(ref).max()
+    # compute_diagonal (tests/laplace_matrix_free.hpp:75-98,158-199)
+    d = ON.mf_diagonal(n, mesh.h, mesh.cell_dofs(), coef, con)
+    np.testing.assert_allclose(d, mf.diagonal(), rtol=TOL, atol=0.0)
+    assert np.all(d[con] == 1.0)
 
 
 def test_native_matrix_free_operator_is_thread_count_independent():
