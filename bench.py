@@ -59,6 +59,8 @@ def parse_args():
                     help="fine-level operator: matrix-free (BASELINE configs[1]/[3]) or assembled CSR (configs[2])")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra single-GPU lines (configs[1] 128^3 V-cycle, configs[4] FP32 smoother apply)")
+    ap.add_argument("--allow-missing-extras", action="store_true",
+                    help="report an extra leg that raises as an `error` entry instead of failing the run")
     ap.add_argument("--box", type=str, default="", help="gx,gy,gz: global cells of a distributed run instead of the "
                     "weak-scaling box (rehearsals of the slab shapes of larger runs on fewer ranks)")
     ap.add_argument("--tile", type=str, default="", help="ty,tz[,waves] override of the operator tile (default: timed choice)")
@@ -306,26 +308,27 @@ def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=20, warmup=3, t
 
 
 def cpu_baseline(args, M, h, prob, lmin, lmax, torch):
-    """The oracle's C++/OpenMP restatement ("port") of the same V-cycle on the host cores."""
+    """The oracle's C++/OpenMP restatement ("port") of the same V-cycle on the host cores -- and, since it runs the
+    very workload of the headline, the parity check at that size: the iterates the timed CPU cycles produce are kept
+    and compared with the GPU cycle started from the same vector (`parity_vs_gpu`)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle_native as ON
 
+    ctx = h.ctx
     n = prob.n
     cd = prob.cell_dofs.cpu().numpy()
     co = prob.coefficient.cpu().numpy()
     cn = prob.constrained.cpu().numpy()
     R = h.restrictor().to_scipy()
     Ac = h.coarse_operator().to_scipy()
-    # D^-1 of the matrix-free operator (constrained entries one), from the product's operator
-    op = M.MatrixFreeLaplace(h.ctx, prob)
-    dinv = op.diagonal_inverse().cpu().numpy()
-    del op
+    cores = ON.effective_cpu_count()
+    ON.set_num_threads(cores)
+    # D^-1 of the matrix-free operator (constrained entries one): the oracle's own compute_diagonal
+    dinv = 1.0 / ON.mf_diagonal(n, prob.h, cd, co, cn)
     rng = np.random.default_rng(0)
     x0 = np.where(cn.astype(bool), 0.0, rng.random(prob.n_dofs))
     b = np.zeros(prob.n_dofs)
-    cores = ON.effective_cpu_count()
-    ON.set_num_threads(cores)
     amg = h.coarse_amg_levels() if args.coarse == "amg" else None
     def run(x_in, cycles):
         xx, _ = ON.vcycles(n, prob.h, cd, co, cn, dinv, args.degree, lmin, lmax, R, Ac, args.coarse_iters, b, x_in, cycles,
@@ -335,23 +338,57 @@ def cpu_baseline(args, M, h, prob, lmin, lmax, torch):
     # all host cores, 2 warm-ups, >= 5 timed cycles, median; plus a 1-thread figure (the
     # reference's own tests run one thread per MPI rank)
     x = run(x0, 2)
+    iterates = {2: x}
     times = []
-    for _ in range(args.cpu_cycles):
+    for c in range(args.cpu_cycles):
         t0 = time.perf_counter()
         x = run(x, 1)
         times.append(time.perf_counter() - t0)
+        iterates[3 + c] = x
     dt = sorted(times)[len(times) // 2]
     ON.set_num_threads(1)
     t0 = time.perf_counter()
     run(x, 1)
     dt1 = time.perf_counter() - t0
     ON.set_num_threads(cores)
+    del R, Ac, amg
+    # parity at this size (harness: /root/reference/tests/test_hierarchy.cc:95-123, b = 0): the residual norm
+    # ||A x_k|| / ||A x_0|| of every kept CPU iterate (the oracle's operator) against the GPU cycle's (the product's
+    # operator), and the iterates themselves
+    resn = lambda v: float(np.linalg.norm(ON.mf_apply(n, prob.h, cd, co, cn, v)))
+    r0_cpu = resn(x0)
+    op = M.MatrixFreeLaplace(ctx, prob)
+    xg = torch.from_numpy(x0).cuda()
+    bg = torch.zeros_like(xg)
+    rg = torch.empty_like(xg)
+    op.vmult(rg, xg)
+    r0_gpu = ctx.l2_norm(rg)
+    hist_diff = iter_diff = 0.0
+    hist_cpu, hist_gpu = [], []
+    for k in range(1, max(iterates) + 1):
+        h.apply(bg, xg)
+        if k in iterates:
+            op.vmult(rg, xg)
+            hg, hc = ctx.l2_norm(rg) / r0_gpu, resn(iterates[k]) / r0_cpu
+            hist_cpu.append(hc)
+            hist_gpu.append(hg)
+            hist_diff = max(hist_diff, abs(hg - hc) / hc)
+            xc = torch.from_numpy(iterates[k]).cuda()
+            iter_diff = max(iter_diff, float((xg - xc).abs().max().item()))
+            del xc
+    del op, xg, bg, rg
     return {"value": prob.n_dofs / dt, "unit": "DoF/s", "cores": cores, "kind": "port",
             "sample": f"median of {args.cpu_cycles} V-cycles (after 2 warm-ups) of the same {prob.N[0]}^3-DoF workload, "
                       f"oracle/oracle_kernels.cpp with OpenMP on {cores} host threads",
             "ms_per_step": dt * 1e3,
             "single_thread": {"value": prob.n_dofs / dt1, "unit": "DoF/s", "cores": 1, "ms_per_step": dt1 * 1e3,
-                              "sample": "1 V-cycle of the same workload on one thread"}}
+                              "sample": "1 V-cycle of the same workload on one thread"},
+            "parity_vs_gpu": {"what": "the iterates of the CPU cycles above (same start vector, b = 0) against the GPU "
+                                      "cycle: relative residual history ||A x_k|| / ||A x_0|| and the iterates, cycles "
+                                      f"{min(iterates)}..{max(iterates)}",
+                              "max_rel_history_diff_vs_gpu": hist_diff,
+                              "max_abs_iterate_diff_vs_gpu": iter_diff,
+                              "history_cpu": hist_cpu, "history_gpu": hist_gpu}}
 
 
 def main():
@@ -644,7 +681,9 @@ def main():
                 if not assembled:
                     out["vcycle_256cubed_assembled_config2"] = measure_vcycle_small(
                         ctx, torch, M, args.cells, params, evaluator="HipMeshEvaluator")
-            except Exception as e:  # noqa: BLE001 - report, do not hide the main result
+            except Exception as e:  # noqa: BLE001
+                if not args.allow_missing_extras:
+                    raise
                 out["extras_error"] = str(e)
         # ---- north_star target legs: the fine-level smoother apply at 512^3 DoFs, measured with nothing else resident (the
         #      hierarchies of the other legs are freed first: with ~25 GB of them still allocated the same launches ran 4 %
@@ -660,7 +699,9 @@ def main():
                                      ("linear", "smoother_apply_512cubed_general_coefficient", False)):
                 try:
                     out[key] = measure_smoother(ctx, torch, M, 512, args.degree, tile=tile, material=mat, stored_diagonal=stored)
-                except Exception as e:  # noqa: BLE001 - report, do not hide the main result
+                except Exception as e:  # noqa: BLE001
+                    if not args.allow_missing_extras:
+                        raise
                     out[key] = {"error": str(e)}
             legs = [out[k] for k in ("smoother_apply_512cubed", "smoother_apply_512cubed_stored_diagonal",
                                      "smoother_apply_512cubed_general_coefficient") if "frac_of_8TBs" in out[k]]
