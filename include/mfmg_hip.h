@@ -303,6 +303,10 @@ int mfmg_hip_hierarchy_operator_apply(mfmg_hip_hierarchy_t h, int32_t level, con
 int mfmg_hip_hierarchy_smoother_apply(mfmg_hip_hierarchy_t h, int32_t level, const double *b, double *x);
 /* levels[level].get_restrictor()->apply(in, out, mode): level >= 1 (level.hpp:35-38) */
 int mfmg_hip_hierarchy_restrictor_apply(mfmg_hip_hierarchy_t h, int32_t level, const double *in, double *out, int mode);
+/* out = (A R^T) in for the A R^T the coarse operator of `level` was formed from -- `fast_multiply_transpose()` when the
+ * parameter `fast_ap` is true (include/mfmg/common/hierarchy.hpp:214-221), `a->multiply_transpose(restrictor)` otherwise.
+ * Kept only by a hierarchy built with `keep_ap = true` (tests: the comparison of tests/test_hierarchy.cc:507-642). */
+int mfmg_hip_hierarchy_ap_apply(mfmg_hip_hierarchy_t h, int32_t level, const double *in, double *out);
 /* coarsest Level::get_solver()->apply(b, x) (level.hpp:45-48) */
 int mfmg_hip_hierarchy_coarse_apply(mfmg_hip_hierarchy_t h, const double *b, double *x);
 /* Replace the restrictor (and re-derive the Galerkin coarse operator + coarse solver)

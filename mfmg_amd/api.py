@@ -431,6 +431,11 @@ class Hierarchy:
         ni, no = (nf, nc) if mode == _lib.NO_TRANS else (nc, nf)
         check(self._lib.mfmg_hip_hierarchy_restrictor_apply(self.handle, level, _dev_ptr(vin, ni), _dev_ptr(vout, no), mode))
 
+    def ap_apply(self, level: int, vin, vout):
+        """vout = (A R^T) vin for the A R^T of `level` (hierarchies built with keep_ap = true)."""
+        nf, nc = self.level_size(level - 1), self.level_size(level)
+        check(self._lib.mfmg_hip_hierarchy_ap_apply(self.handle, level, _dev_ptr(vin, nc), _dev_ptr(vout, nf)))
+
     def coarse_apply(self, b, x):
         n = self.level_size(self.n_levels - 1)
         check(self._lib.mfmg_hip_hierarchy_coarse_apply(self.handle, _dev_ptr(b, n), _dev_ptr(x, n)))

@@ -1039,6 +1039,17 @@ int mfmg_hip_hierarchy_restrictor_apply(mfmg_hip_hierarchy_t h, int32_t level, c
   });
 }
 
+int mfmg_hip_hierarchy_ap_apply(mfmg_hip_hierarchy_t h, int32_t level, const double *in, double *out)
+{
+  return guarded([&] {
+    require(h && in && out, "null argument");
+    auto const &aps = h->hierarchy->ap_operators();
+    require(level >= 1 && level <= (int)aps.size(), "no A R^T kept for this level (build the hierarchy with keep_ap = true)");
+    DVector iv(*h->handle, level_size(h, level), const_cast<double *>(in)), ov(*h->handle, level_size(h, level - 1), out);
+    aps[level - 1]->apply(iv, ov);
+  });
+}
+
 int mfmg_hip_hierarchy_residual_restriction_classes(mfmg_hip_hierarchy_t h, int32_t level, int32_t *n_classes)
 {
   return guarded([&] {

@@ -1330,7 +1330,26 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
   if (comm.enabled())
     restrictor->set_spaces(1, 2);
   _own_restrictor = restrictor;
+  _ap_operator.reset();
+  _ap_weak.reset();
+  _fast_ap_prepared = params->get("fast_ap", false);
+  if (_fast_ap_prepared)
+    _ap_operator = get_global_operator(mesh_evaluator)->multiply_transpose(restrictor);
   return restrictor;
+}
+
+template <typename VectorType>
+std::shared_ptr<Operator<VectorType>> HipHierarchyHelpers<VectorType>::fast_multiply_transpose()
+{
+  ASSERT_THROW(_fast_ap_prepared, "fast_multiply_transpose needs a restrictor built with fast_ap = true");
+  // (the assembled A R^T holds 125 entries per coarse row: handed over, not kept alive here; formed again if a later
+  // call finds it gone)
+  auto ap = _ap_operator ? _ap_operator : _ap_weak.lock();
+  if (!ap)
+    ap = _operator->multiply_transpose(_own_restrictor);
+  _ap_weak = ap;
+  _ap_operator.reset();
+  return ap;
 }
 
 template <typename VectorType>

@@ -105,6 +105,10 @@ public:
       timer_enter_subsection(_timer, "Setup: build coarse matrix");
       auto a_coarse = restrictor->multiply(ap);
       timer_leave_subsection(_timer);
+      // Extension ("keep_ap", default false): A R^T of every level stays reachable (ap_operators()), so that a test
+      // can compare it with another way of forming it, as tests/test_hierarchy.cc:507-642 does.
+      if (params->get("keep_ap", false))
+        _ap_operators.push_back(ap);
 
       level_coarse.set_operator(a_coarse);
     }
@@ -198,12 +202,14 @@ public:
   bool is_preconditioner() const { return _is_preconditioner; }
   unsigned int n_smoothing_steps() const { return _n_smoothing_steps; }
   std::shared_ptr<TimerOutput> timer() const { return _timer; }
+  std::vector<std::shared_ptr<Operator<VectorType>>> const &ap_operators() const { return _ap_operators; }
 
 private:
   std::shared_ptr<TimerOutput> _timer;
   std::unique_ptr<HierarchyHelpers<VectorType>> _helpers;
   std::shared_ptr<ptree> _params;
   std::vector<Level<VectorType>> _levels;
+  std::vector<std::shared_ptr<Operator<VectorType>>> _ap_operators; // only with "keep_ap"
   bool _is_preconditioner = true;
   unsigned int _n_smoothing_steps;
 };

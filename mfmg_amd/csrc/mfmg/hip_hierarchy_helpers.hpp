@@ -346,6 +346,14 @@ public:
                                                          std::shared_ptr<MeshEvaluator> mesh_evaluator,
                                                          std::shared_ptr<ptree const> params) override;
 
+  // `fast_ap = true` (the reference's driver forces it, tests/hierarchy_driver.cc:270): A R^T as build_restrictor
+  // prepared it (include/mfmg/common/hierarchy.hpp:214-221, source/dealii/dealii_matrix_free_hierarchy_helpers.cc:326-329).
+  // Matrix-free operator: the symbolic half product whose `R->multiply` forms R A R^T from 27 n_eig applications of
+  // R^T, A and R over colour classes of agglomerates -- the idea of the reference's fast path (agglomerate-local
+  // applications plus the correction of the agglomerate borders, :77-288) carried out with global operator
+  // applications, which need no correction.  Assembled operator: the device product A R^T.
+  std::shared_ptr<Operator<VectorType>> fast_multiply_transpose() override;
+
   std::shared_ptr<Smoother<VectorType>> build_smoother(std::shared_ptr<Operator<VectorType> const> op,
                                                        std::shared_ptr<ptree const> params) override;
 
@@ -366,6 +374,9 @@ private:
   std::shared_ptr<Operator<VectorType>> _operator;
   std::shared_ptr<Operator<VectorType> const> _restrictor_hint;
   std::shared_ptr<Operator<VectorType> const> _own_restrictor; // the one build_restrictor made (grid known)
+  std::shared_ptr<Operator<VectorType>> _ap_operator;            // A R^T, prepared by build_restrictor when fast_ap = true
+  std::weak_ptr<Operator<VectorType>> _ap_weak;                  // ... after it was handed over
+  bool _fast_ap_prepared = false;
   AmgGridHint _grid_hint;
 };
 

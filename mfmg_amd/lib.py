@@ -159,6 +159,7 @@ def load() -> C.CDLL:
         "mfmg_hip_hierarchy_operator_apply": (C.c_int, [vp, i32, vp, vp, C.c_int]),
         "mfmg_hip_hierarchy_smoother_apply": (C.c_int, [vp, i32, vp, vp]),
         "mfmg_hip_hierarchy_restrictor_apply": (C.c_int, [vp, i32, vp, vp, C.c_int]),
+        "mfmg_hip_hierarchy_ap_apply": (C.c_int, [vp, i32, vp, vp]),
         "mfmg_hip_hierarchy_coarse_apply": (C.c_int, [vp, vp, vp]),
         "mfmg_hip_hierarchy_set_restrictor": (C.c_int, [vp, i64, i64, i64, vp, vp, vp]),
         "mfmg_hip_hierarchy_get_restrictor": (C.c_int, [vp, P(vp)]),

@@ -447,8 +447,6 @@ def test_error_conventions(ctx):
         M.Hierarchy(ctx, "HipMeshEvaluator", prob, base_params(solver={"type": "amgx"}))
     with pytest.raises(L.MfmgNotImplementedError):                        # hierarchy.hpp:49-107 string switch
         M.Hierarchy(ctx, "DealIIMeshEvaluator", prob, base_params())
-    with pytest.raises(L.MfmgNotImplementedError):                        # hierarchy_helpers.hpp:45-50
-        M.Hierarchy(ctx, "HipMeshEvaluator", prob, base_params(fast_ap=True))
     with pytest.raises(L.MfmgError, match="must be positive"):            # hierarchy.hpp:173-175
         M.Hierarchy(ctx, "HipMeshEvaluator", prob, base_params(**{"max levels": 0}))
     h = M.Hierarchy(ctx, "HipMeshEvaluator", prob, base_params())
@@ -832,3 +830,59 @@ def test_full_size_vcycle_history_against_the_native_oracle(ctx, material):
     np.testing.assert_allclose(res_g, res_o, rtol=HIST_TOL, atol=HIST_ATOL)
     assert np.abs(x_g - x_o).max() <= 1e-10 * np.abs(x0).max()
     assert res_o[-1] / res_o[-2] < 0.4
+
+
+@pytest.mark.parametrize("evaluator,n,material", [("HipMeshEvaluator", (8, 8), "constant"), ("HipMeshEvaluator", (8, 6, 4), "linear"),
+                                                   ("HipMatrixFreeMeshEvaluator", (8, 6, 4), "linear"),
+                                                   ("HipMatrixFreeMeshEvaluator", (16, 16, 16), "constant")])
+def test_fast_ap(ctx, evaluator, n, material):
+    """`fast_ap = true` -- the parameter set of the reference's driver (/root/reference/tests/hierarchy_driver.cc:270-272:
+    fast_ap, eigensolver.type anasazi, eigensolver.tolerance 1e-3) -- takes `fast_multiply_transpose()` of the helpers
+    (include/mfmg/common/hierarchy.hpp:214-221) instead of `a->multiply_transpose(restrictor)`.  The reference's own check
+    (tests/test_hierarchy.cc:507-642): A R^T of the fast path against the plain one, entry by entry, 1e-9; here also
+    against the oracle's assembled A times R^T, and the hierarchies built either way give the same cycle."""
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, material)
+    con = mesh.constrained_mask()
+    mf = O.MatrixFreeLaplace(mesh, coef) if len(n) == 3 else None
+    matrix_free = evaluator == "HipMatrixFreeMeshEvaluator"
+    prob = M.LaplaceProblem(n, material, device="cuda")
+    smoother = {"type": "Chebyshev", "degree": 2, "smoothing_range": 20.0} if matrix_free else {"type": "Jacobi"}
+    plain = base_params(smoother=smoother, keep_ap=True)
+    fast = base_params(smoother=smoother, keep_ap=True, fast_ap=True)
+    fast["eigensolver"].update({"type": "anasazi", "tolerance": 1e-3})
+    h_plain = M.Hierarchy(ctx, evaluator, prob, plain)
+    h_fast = M.Hierarchy(ctx, evaluator, prob, fast)
+    assert "Setup: fast_ap" in h_fast.timer_report() and "Setup: fast_ap" not in h_plain.timer_report()
+    R = h_plain.restrictor().to_scipy()
+    assert abs(h_fast.restrictor().to_scipy() - R).max() == 0.0
+    nf, nc = h_plain.level_size(0), h_plain.level_size(1)
+    # A R^T column by column (the matrices of the reference's test, read through the operators)
+    A = O.assemble_csr(mesh, coef)
+    ref = (A @ R.T).toarray() if not matrix_free else np.stack([mf.vmult(R.T[:, [j]].toarray().ravel()) for j in range(nc)], axis=1)
+    cols_plain, cols_fast = np.empty((nf, nc)), np.empty((nf, nc))
+    out = torch.empty(nf, dtype=torch.float64, device="cuda")
+    for j in range(nc):
+        e = np.zeros(nc)
+        e[j] = 1.0
+        h_plain.ap_apply(1, dev(e), out)
+        cols_plain[:, j] = out.cpu().numpy()
+        h_fast.ap_apply(1, dev(e), out)
+        cols_fast[:, j] = out.cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(cols_fast - cols_plain).max() <= 1e-12 * scale      # (reference: 1e-9 relative per entry)
+    assert np.abs(cols_fast - ref).max() <= 1e-12 * scale
+    # the coarse operators and the cycles of the two hierarchies
+    Ac_plain, Ac_fast = h_plain.coarse_operator().to_scipy(), h_fast.coarse_operator().to_scipy()
+    assert abs(Ac_fast - Ac_plain).max() <= 1e-12 * abs(Ac_plain).max()
+    x0 = np.where(con, 0.0, np.random.default_rng(4).random(mesh.n_dofs))
+    b = np.zeros(mesh.n_dofs)
+    Ad = M.SparseMatrixDevice(ctx, A)
+    res_p, x_p = gpu_history(ctx, h_plain, lambda y, x: Ad.vmult(y, x), b, x0, n_cycles=8)
+    res_f, x_f = gpu_history(ctx, h_fast, lambda y, x: Ad.vmult(y, x), b, x0, n_cycles=8)
+    np.testing.assert_allclose(res_f, res_p, rtol=1e-12, atol=HIST_ATOL)
+    assert np.abs(x_f - x_p).max() <= 1e-12
+    # a hierarchy without keep_ap holds no A R^T
+    h = M.Hierarchy(ctx, evaluator, prob, base_params(smoother=smoother, fast_ap=True))
+    with pytest.raises(L.MfmgError, match="keep_ap"):
+        h.ap_apply(1, dev(np.zeros(nc)), out)
