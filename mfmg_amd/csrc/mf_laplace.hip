@@ -59,6 +59,7 @@ struct MfArgs
   unsigned int ncols, ntiles_y, ntiles_z; // ntiles_z: z-tiles of THIS launch, the first one is tile z_tile0
   unsigned int ncols_active;              // chunk columns that get workgroups (the last one may go to the tail slab)
   unsigned int z_tile0;
+  int const *ztab; // z-tile t owns the DoF layers [ztab[t], ztab[t+1]) (device array; uniform TZ or graded, see z_tiling)
   T fx, fy, fz;
   T fax, fbx, fay, fby, faz, fbz; // one coefficient per cell: 2 f M00, 2 f M01 per direction (M = [[2/3, 1/3], [1/3, 2/3]])
   T kd;                           // ... and the diagonal entry of the reference cell matrix: diag = kd * sum of the 8 cell coefficients
@@ -368,7 +369,8 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
   const int tzi = a.z_tile0 + w / (a.ncols_active * a.ntiles_y);
   const int ci = tc * kOwn - 1 + lane;              // cell / DoF column of this lane
   const int Yb = tyi * (NW * TY - 1) - 1 + wv * TY; // first cell row of this wavefront
-  const int Z0 = tzi * a.TZ;
+  const int Z0 = a.ztab[tzi];            // (wave-uniform index: scalar loads)
+  const int TZt = a.ztab[tzi + 1] - Z0;  // layers this tile owns
   const bool col_owned = lane >= 1 && lane <= kOwn && ci < a.Nx;
   const int jj0 = (Yb < 0) ? 1 : 0; // cell row -1 does not exist (its sums are the zero initial carries)
   const size_t rec_row = (size_t)a.ncols * a.rec_bytes;
@@ -409,7 +411,7 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
   for (int r = 0; r < (XP ? TYC + 1 : 1); ++r)
     pf[r] = 0;
 
-  for (int kk = 0; kk <= a.TZ; ++kk)
+  for (int kk = 0; kk <= TZt; ++kk)
   {
     const int k = Z0 - 1 + kk;
     if (k >= a.Nz)
@@ -1161,10 +1163,64 @@ void MatrixFreeLaplaceDevice<T>::choose_tile(int &nw, int &ty, int &tz) const
     ty = 2;
 }
 
+// Tiling along z.  A launch of a few rounds of workgroups pays for its last round: when the list of tiles runs out the
+// chip drains for as long as the last tiles take (measured: 257^3 DoFs, three rounds of (4, 3, 8) tiles, 10 % of the launch
+// against the same mesh four times as long in z).  So the tiles that are dispatched LAST are made SHORT: every XCD gets a
+// contiguous run of layers (one eighth of the mesh, as before) cut into the same number of z-tiles whose heights fall
+// off linearly -- 257 layers, tz = 8: 10, 8, 6, 5, 3 instead of 8, 8, 8, 8 -- at the price of one more halo layer per
+// XCD.  Results do not depend on the tiling (bit for bit).  Ranges of z-tiles (the overlapped exchange of a distributed
+// run) keep the uniform tiling: tile t owns the layers [t tz, (t + 1) tz).
+template <typename T>
+int const *MatrixFreeLaplaceDevice<T>::z_tiling(int tz, bool graded, int &n_tiles) const
+{
+  ZTiling &zt = graded ? _zt_graded : _zt_uniform;
+  if (zt.tz != tz)
+  {
+    std::vector<int> tab;
+    const int Nz = _N[2];
+    static const int m_extra = std::getenv("MFMG_MF_GRADE_M") ? std::atoi(std::getenv("MFMG_MF_GRADE_M")) : 1;
+    static const double w_off = std::getenv("MFMG_MF_GRADE_OFF") ? std::atof(std::getenv("MFMG_MF_GRADE_OFF")) : 0.5;
+    const int m = (Nz / 8 + tz / 2) / tz + m_extra; // z-tiles per XCD
+    if (graded && Nz / 8 >= 2 * m)
+    {
+      double total = 0.;
+      for (int k = 0; k < m; ++k)
+        total += m - k + w_off;
+      for (int s = 0; s < 8; ++s)
+      {
+        const int l0 = (int)((int64_t)s * Nz / 8), l1 = (int)((int64_t)(s + 1) * Nz / 8);
+        double cum = 0.;
+        int prev = l0;
+        for (int k = 0; k < m; ++k)
+        {
+          tab.push_back(prev);
+          cum += m - k + w_off;
+          int next = k + 1 == m ? l1 : l0 + (int)std::lround((l1 - l0) * cum / total);
+          next = std::min(std::max(next, prev + 1), l1 - (m - 1 - k)); // every tile owns at least one layer
+          prev = next;
+        }
+      }
+      tab.push_back(Nz);
+    }
+    else
+    {
+      for (int l = 0; l < Nz; l += tz)
+        tab.push_back(l);
+      tab.push_back(Nz);
+    }
+    zt.n_tiles = (int)tab.size() - 1;
+    zt.dev.upload(tab.data(), tab.size(), _handle.stream);
+    MFMG_HIP_CHECK(hipStreamSynchronize(_handle.stream)); // (the host vector goes out of scope)
+    zt.tz = tz;
+  }
+  n_tiles = zt.n_tiles;
+  return zt.dev.data();
+}
+
 template <typename T>
 bool MatrixFreeLaplaceDevice<T>::make_args(MfArgs<T> &a, unsigned int &n_blocks, MfMode mode, T const *x, T const *b,
                                            T const *x_prev, T alpha, T beta, T *out, int nw, int ty, int tz,
-                                           int z_tile_begin, int z_tile_end) const
+                                           int const *ztab, int z_tile_begin, int z_tile_end) const
 {
   a.rec = _rec.data();
   a.x = x;
@@ -1202,10 +1258,7 @@ bool MatrixFreeLaplaceDevice<T>::make_args(MfArgs<T> &a, unsigned int &n_blocks,
   a.ncols_active = _tail ? _ncols - 1 : _ncols;
   // ty cell rows per wavefront, nw ty - 1 owned DoF rows per workgroup
   a.ntiles_y = (_N[1] + nw * ty - 2) / (nw * ty - 1);
-  const int all_z = (_N[2] + tz - 1) / tz;
-  if (z_tile_end < 0)
-    z_tile_end = all_z;
-  ASSERT_THROW(z_tile_begin >= 0 && z_tile_end <= all_z, "z-tile range outside the tiling");
+  a.ztab = ztab;
   n_blocks = 0;
   if (z_tile_begin >= z_tile_end)
     return false;
@@ -1226,11 +1279,19 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
   ASSERT_THROW(ty >= 1 && tz >= 1 && nw * ty >= 2, "operator tile too small");
   MfArgs<T> am, at;
   unsigned int main_blocks = 0, tail_blocks = 0;
-  if (!make_args(am, main_blocks, mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, z_tile_begin, z_tile_end))
+  // the whole mesh: graded z-tiles; a range of z-tiles: the uniform tiling the caller counts in
+  static const bool graded_env = !(std::getenv("MFMG_MF_GRADED_TILES") && std::string(std::getenv("MFMG_MF_GRADED_TILES")) == "0");
+  const bool whole = z_tile_begin == 0 && z_tile_end < 0;
+  int all_z = 0;
+  int const *ztab = z_tiling(tz, whole && graded_env, all_z);
+  if (z_tile_end < 0)
+    z_tile_end = all_z;
+  ASSERT_THROW(z_tile_begin >= 0 && z_tile_end <= all_z, "z-tile range outside the tiling");
+  if (!make_args(am, main_blocks, mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, ztab, z_tile_begin, z_tile_end))
     return;
   at = am;
-  if (_tail) // the columns of the last chunk: same tile shape, same layers, first in the grid
-    _tail->make_args(at, tail_blocks, mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, z_tile_begin, z_tile_end);
+  if (_tail) // the columns of the last chunk: same tile shape, same layers (same table: Nz is the same), first in the grid
+    _tail->make_args(at, tail_blocks, mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, ztab, z_tile_begin, z_tile_end);
   const size_t lds = ((size_t)nw * (3 * ty + 1) + (size_t)2 * nw * 3) * 64 * sizeof(T) + (size_t)nw * (ty + 1) * 64 * sizeof(int);
   ASSERT_THROW(lds <= 160 * 1024, "operator tile too large for the LDS");
   const dim3 grid(main_blocks + tail_blocks);

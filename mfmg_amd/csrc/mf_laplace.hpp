@@ -124,7 +124,15 @@ private:
   void run(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out, int nw, int ty, int tz,
            int z_tile_begin = 0, int z_tile_end = -1) const;
   bool make_args(MfArgs<T> &a, unsigned int &n_blocks, MfMode mode, T const *x, T const *b, T const *x_prev, T alpha,
-                 T beta, T *out, int nw, int ty, int tz, int z_tile_begin, int z_tile_end) const;
+                 T beta, T *out, int nw, int ty, int tz, int const *ztab, int z_tile_begin, int z_tile_end) const;
+  // layers of the z-tiles (device table, built once per tz): graded = shorter tiles at the end of every XCD's run
+  int const *z_tiling(int tz, bool graded, int &n_tiles) const;
+  struct ZTiling
+  {
+    int tz = 0, n_tiles = 0;
+    DeviceBuffer<int> dev;
+  };
+  mutable ZTiling _zt_uniform, _zt_graded;
   void check_vectors(MfMode mode, T const *x, T const *b, T const *x_prev, T const *out) const;
   void choose_tile(int &nw, int &ty, int &tz) const;
 
