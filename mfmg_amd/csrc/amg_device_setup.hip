@@ -11,7 +11,8 @@
 //                                                  (1 + r_l)^3 n_comp applications of A_l;
 //   A_{l+1} = P_l^T A_l P_l                        columns 2 r_{l+1} + 1 apart never meet in a row:
 //                                                  (2 r_{l+1} + 1)^3 n_comp applications of P_l, A_l, P_l^T
-// with r_l the reach of A_l in nodes (r_0 = 1 for the AMGe coarse operator, r_{l+1} = floor((1 + 3 r_l) / 2)).
+// with r_l the reach of A_l in nodes (r_0 = 1 for the AMGe coarse operator, r_{l+1} = floor((1 + 3 r_l) / 2); aggregates of
+// b nodes per direction: r_{l+1} = floor((b - 1 + 3 r_l) / b), so b = 3 keeps a reach of 1).
 // Nothing but vectors crosses between ranks: the probing vectors are defined on global coordinates, A_l reads its
 // ghost layers after a forward halo exchange and P_l^T returns the partial sums of ghost aggregates to their owners
 // by a reverse (adding) exchange -- exactly the exchanges of the cycle itself.  No sparse rows are communicated.
@@ -75,6 +76,11 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
   // 257^3 DoFs; many ranks: below 200000 global rows a level is gathered and the rest replicated)
   const int64_t replicate_rows = this->_params->get("solver.amg.replicate_rows", distributed ? 200000 : 4000);
   const int C = std::max(grid.n_components, 1);
+  // aggregates: cubes of `blk` nodes (solver.amg.aggregate_block), aligned globally.  With 2 the box stencil of the
+  // operators grows from level to level (reach 1, 2, 3, 5: 53, 236, 582, 1520 entries per row); with 3 -- the classic
+  // coarsening of smoothed aggregation -- a reach of 1 stays 1.  General rule: r_{l+1} = floor((blk - 1 + 3 r_l) / blk).
+  const int blk = grid.block[0];
+  ASSERT_THROW(blk >= 2 && grid.block[1] == blk && grid.block[2] == blk, "the device setup needs cubic aggregates");
 
   LevelGeom g;
   for (int d = 0; d < 3; ++d)
@@ -120,9 +126,9 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     // ---- can the next level be built distributed?
     LevelGeom c;
     for (int d = 0; d < 2; ++d)
-      c.dims[d] = (g.dims[d] + 1) / 2;
+      c.dims[d] = (g.dims[d] + blk - 1) / blk;
     c.n_comp = C;
-    c.reach = (1 + 3 * g.reach) / 2;
+    c.reach = (blk - 1 + 3 * g.reach) / blk;
     bool coarsen_here = global_rows > std::max<int64_t>(replicate_rows, opts.coarsest_size) && level + 1 < opts.max_levels;
     if (coarsen_here)
     {
@@ -131,19 +137,19 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
         HaloSpace const &s = comm.spaces[g.space];
         // whole aggregates per rank, aligned globally; the ghost layers of the coarse level must come from the
         // immediate neighbour
-        double ok = (g.owned_count % 2 == 0 && (g.global_begin + g.owned_begin) % 2 == 0 && g.owned_count / 2 >= c.reach) ? 1. : 0.;
+        double ok = (g.owned_count % blk == 0 && (g.global_begin + g.owned_begin) % blk == 0 && g.owned_count / blk >= c.reach) ? 1. : 0.;
         ok = -h.allreduce_max(-ok); // min over the ranks
         coarsen_here = ok > 0.5;
-        c.owned_count = g.owned_count / 2;
+        c.owned_count = g.owned_count / blk;
         c.owned_begin = s.has_low ? c.reach : 0;
         c.dims[2] = (int)(c.owned_begin + c.owned_count + (s.has_high ? c.reach : 0));
-        c.global_begin = (g.global_begin + g.owned_begin) / 2 - c.owned_begin;
-        c.global_layers = g.global_layers / 2;
-        ASSERT_THROW(!coarsen_here || g.global_layers % 2 == 0, "internal: odd number of layers on a distributed level");
+        c.global_begin = (g.global_begin + g.owned_begin) / blk - c.owned_begin;
+        c.global_layers = g.global_layers / blk;
+        ASSERT_THROW(!coarsen_here || g.global_layers % blk == 0, "internal: layers of a distributed level not a multiple of the aggregate size");
       }
       else
       {
-        c.dims[2] = (g.dims[2] + 1) / 2;
+        c.dims[2] = (g.dims[2] + blk - 1) / blk;
         c.owned_begin = 0;
         c.owned_count = c.dims[2];
         c.global_begin = 0;
@@ -205,9 +211,9 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
       comp = (int)(row % C);
       const int64_t nd = row / C;
       const int i = (int)(nd % g.dims[0]), j = (int)((nd / g.dims[0]) % g.dims[1]), k = (int)(nd / ((int64_t)g.dims[0] * g.dims[1]));
-      I = i / 2;
-      J = j / 2;
-      K = (int)((k + g.global_begin) / 2 - c.global_begin); // local coarse layer
+      I = i / blk;
+      J = j / blk;
+      K = (int)((k + g.global_begin) / blk - c.global_begin); // local coarse layer
     };
     std::vector<double> norm2((size_t)n_c, 0.), t((size_t)n_f, 0.), Bc((size_t)n_c, 0.);
     for (int64_t i = row0; i < row0 + n_own; ++i)
@@ -231,11 +237,12 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     h.exchange(g.space, t_dev.get_values());
     t = download_range(h, t_dev.get_values(), 0, n_f);
 
-    // ---- P = (I - w D^-1 A) P_tent by probing: aggregates (1 + reach) apart have disjoint columns
+    // ---- P = (I - w D^-1 A) P_tent by probing: the columns of aggregates floor((blk - 1 + 2 reach) / blk) + 1 apart
+    //      (1 + reach for blk = 2) are disjoint
     const int gdims_c[3] = {c.dims[0], c.dims[1], (int)c.global_layers};
     int period_p[3];
     for (int d = 0; d < 3; ++d)
-      period_p[d] = std::max(1, std::min(1 + g.reach, gdims_c[d]));
+      period_p[d] = std::max(1, std::min((blk - 1 + 2 * g.reach) / blk + 1, gdims_c[d]));
     const int n_col_p = period_p[0] * period_p[1] * period_p[2] * C;
     // (one array for all probes, its pages first touched by all threads, copies queued without a wait in between)
     std::unique_ptr<ZeroedHostArray<double>> Z(new ZeroedHostArray<double>((size_t)n_col_p * (size_t)n_own));
@@ -243,7 +250,7 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     {
       const int comp = col % C, oc = col / C;
       const int phase[3] = {oc % period_p[0], (oc / period_p[0]) % period_p[1], oc / (period_p[0] * period_p[1])};
-      vec::select_rows(h, g.dims, C, 2, (int)g.global_begin, period_p, phase, comp, t_dev.get_values(), y_f.get_values());
+      vec::select_rows(h, g.dims, C, blk, (int)g.global_begin, period_p, phase, comp, t_dev.get_values(), y_f.get_values());
       a_op->get_matrix()->vmult(z_f.get_values(), y_f.get_values()); // ghosts of y are set locally: no exchange
       // (the copy is queued behind the application on the same stream; z_f is overwritten only by the next application)
       MFMG_HIP_CHECK(hipMemcpyAsync(Z->data() + (size_t)col * n_own, z_f.get_values() + row0, (size_t)n_own * sizeof(double),
@@ -261,10 +268,10 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
         const int64_t nd = i / C;
         const int x = (int)(nd % g.dims[0]), y = (int)((nd / g.dims[0]) % g.dims[1]), zl = (int)(nd / ((int64_t)g.dims[0] * g.dims[1]));
         const int64_t zg = zl + g.global_begin;
-        const int lo[3] = {std::max(0, (x - g.reach) >> 1), std::max(0, (y - g.reach) >> 1),
-                           (int)std::max<int64_t>(0, (zg - g.reach) >> 1)};
-        const int hi[3] = {std::min(gdims_c[0] - 1, (x + g.reach) >> 1), std::min(gdims_c[1] - 1, (y + g.reach) >> 1),
-                           (int)std::min<int64_t>(gdims_c[2] - 1, (zg + g.reach) >> 1)};
+        const int lo[3] = {std::max(0, x - g.reach) / blk, std::max(0, y - g.reach) / blk,
+                           (int)(std::max<int64_t>(0, zg - g.reach) / blk)};
+        const int hi[3] = {std::min(gdims_c[0] - 1, (x + g.reach) / blk), std::min(gdims_c[1] - 1, (y + g.reach) / blk),
+                           (int)std::min<int64_t>(gdims_c[2] - 1, (zg + g.reach) / blk)};
         for (int K = lo[2]; K <= hi[2]; ++K)
           for (int J = lo[1]; J <= hi[1]; ++J)
             for (int I = lo[0]; I <= hi[0]; ++I)
@@ -273,7 +280,7 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
               const int64_t Kl = K - c.global_begin;
               ASSERT_THROW(Kl >= 0 && Kl < c.dims[2], "internal: prolongator column outside the local coarse box");
               // own aggregate of the node, for the identity part of S
-              const bool own_agg = (I == (x >> 1)) && (J == (y >> 1)) && (K == (int)(zg >> 1));
+              const bool own_agg = (I == x / blk) && (J == y / blk) && (K == (int)(zg / blk));
               for (int comp = 0; comp < C; ++comp)
               {
                 const double ay = (*Z)[(size_t)(oc * C + comp) * (size_t)n_own + (size_t)(i - row0)];

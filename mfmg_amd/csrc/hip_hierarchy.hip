@@ -1067,7 +1067,7 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
     // setup "device": matrices of the hierarchy read off from operator applications on the device (probing), the
     // levels coupled across the ranks of a distributed run; "host": SpGEMM on the host cores (one rank only)
     // (default: the device wherever its preconditions hold -- one code path for one and for many ranks)
-    bool device_ok = local_grid.valid(n) && opts.smooth_prolongator && local_grid.block[0] == 2 &&
+    bool device_ok = local_grid.valid(n) && opts.smooth_prolongator && local_grid.block[0] >= 2 &&
                      opts.deep_level >= (1 << 30) && std::all_of(b0.begin(), b0.end(), [](double v) { return v != 0.; });
     if (device_ok)
     {
@@ -1085,7 +1085,7 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
     {
       ASSERT_THROW(setup == "device", "distributed runs build the aggregation hierarchy on the device (solver.amg.setup device)");
       ASSERT_THROW(device_ok, "the device setup of the aggregation hierarchy needs the agglomerate grid of the restrictor, a "
-                              "smoothed prolongator, aggregates of 2 x 2 x 2 nodes and a near-null-space vector without zeros");
+                              "smoothed prolongator, cubic aggregates and a near-null-space vector without zeros");
       setup_amg_on_device(matrix, b0, local_grid, opts, smoother_params);
       return;
     }

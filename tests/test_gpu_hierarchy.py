@@ -884,5 +884,5 @@ def test_fast_ap(ctx, evaluator, n, material):
     assert np.abs(x_f - x_p).max() <= 1e-12
     # a hierarchy without keep_ap holds no A R^T
     h = M.Hierarchy(ctx, evaluator, prob, base_params(smoother=smoother, fast_ap=True))
-    with pytest.raises(L.MfmgError, match="keep_ap"):
+    with pytest.raises(L.MfmgInvalidArgument, match="keep_ap"):
         h.ap_apply(1, dev(np.zeros(nc)), out)
