@@ -19,6 +19,7 @@
 // Below `solver.amg.replicate_rows` global rows (or where a slab can no longer be halved) the level is gathered and
 // the rest of the hierarchy is built and applied redundantly on every rank by the host code path of one rank.
 #include "mfmg/hip_hierarchy_helpers.hpp"
+#include "probe_assembly.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -189,18 +190,15 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     const int64_t row0 = g.owned_row_begin(), n_own = g.owned_rows();
 
     // ---- diagonal, rho = max_i sum_j |a_ij| / |a_ii| over the owned rows of all ranks
-    std::vector<double> dinv((size_t)n_f, 0.);
+    DeviceBuffer<double> d_dinv((size_t)n_f);
     double rho = 0.;
     {
-      DeviceBuffer<double> d_dinv((size_t)n_f), d_ratio((size_t)n_f);
+      DeviceBuffer<double> d_ratio((size_t)n_f);
       a_op->get_matrix()->row_ratios(d_dinv.data(), d_ratio.data());
-      const std::vector<double> all_dinv = d_dinv.download(h.stream), ratio = d_ratio.download(h.stream);
+      const std::vector<double> ratio = d_ratio.download(h.stream);
 #pragma omp parallel for schedule(static) reduction(max : rho)
       for (int64_t i = row0; i < row0 + n_own; ++i)
-      {
-        dinv[i] = all_dinv[i];
         rho = std::max(rho, ratio[i]);
-      }
     }
     ASSERT_THROW(rho < HUGE_VAL, "zero diagonal in the multilevel coarse solver setup");
     rho = h.allreduce_max(rho);
@@ -235,7 +233,6 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     DVector t_dev(h, n_f), y_f(h, n_f), z_f(h, n_f), u_c(h, n_c), y_c(h, n_c);
     MFMG_HIP_CHECK(hipMemcpyAsync(t_dev.get_values(), t.data(), (size_t)n_f * sizeof(double), hipMemcpyHostToDevice, h.stream));
     h.exchange(g.space, t_dev.get_values());
-    t = download_range(h, t_dev.get_values(), 0, n_f);
 
     // ---- P = (I - w D^-1 A) P_tent by probing: the columns of aggregates floor((blk - 1 + 2 reach) / blk) + 1 apart
     //      (1 + reach for blk = 2) are disjoint
@@ -244,81 +241,24 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     for (int d = 0; d < 3; ++d)
       period_p[d] = std::max(1, std::min((blk - 1 + 2 * g.reach) / blk + 1, gdims_c[d]));
     const int n_col_p = period_p[0] * period_p[1] * period_p[2] * C;
-    // (one array for all probes, its pages first touched by all threads, copies queued without a wait in between)
-    std::unique_ptr<ZeroedHostArray<double>> Z(new ZeroedHostArray<double>((size_t)n_col_p * (size_t)n_own));
+    // (the probes stay on the device and the rows are assembled there: probe_assembly.hip)
+    DeviceBuffer<double> Z((size_t)n_col_p * (size_t)n_own);
     for (int col = 0; col < n_col_p; ++col)
     {
       const int comp = col % C, oc = col / C;
       const int phase[3] = {oc % period_p[0], (oc / period_p[0]) % period_p[1], oc / (period_p[0] * period_p[1])};
       vec::select_rows(h, g.dims, C, blk, (int)g.global_begin, period_p, phase, comp, t_dev.get_values(), y_f.get_values());
       a_op->get_matrix()->vmult(z_f.get_values(), y_f.get_values()); // ghosts of y are set locally: no exchange
-      // (the copy is queued behind the application on the same stream; z_f is overwritten only by the next application)
-      MFMG_HIP_CHECK(hipMemcpyAsync(Z->data() + (size_t)col * n_own, z_f.get_values() + row0, (size_t)n_own * sizeof(double),
-                                    hipMemcpyDeviceToHost, h.stream));
+      MFMG_HIP_CHECK(hipMemcpyAsync(Z.data() + (size_t)col * n_own, z_f.get_values() + row0, (size_t)n_own * sizeof(double),
+                                    hipMemcpyDeviceToDevice, h.stream));
     }
     MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
     const double t_probed = wall_now();
-    HostCsr P;
-    P.n_rows = n_f;
-    P.n_cols = n_c;
-    P.row_ptr.assign(n_f + 1, 0);
-    {
-      // two passes: count, fill.  Candidates of owned row i: aggregates whose nodes lie within `reach` of its node
-      auto visit = [&](int64_t i, auto &&emit) {
-        const int64_t nd = i / C;
-        const int x = (int)(nd % g.dims[0]), y = (int)((nd / g.dims[0]) % g.dims[1]), zl = (int)(nd / ((int64_t)g.dims[0] * g.dims[1]));
-        const int64_t zg = zl + g.global_begin;
-        const int lo[3] = {std::max(0, x - g.reach) / blk, std::max(0, y - g.reach) / blk,
-                           (int)(std::max<int64_t>(0, zg - g.reach) / blk)};
-        const int hi[3] = {std::min(gdims_c[0] - 1, (x + g.reach) / blk), std::min(gdims_c[1] - 1, (y + g.reach) / blk),
-                           (int)std::min<int64_t>(gdims_c[2] - 1, (zg + g.reach) / blk)};
-        for (int K = lo[2]; K <= hi[2]; ++K)
-          for (int J = lo[1]; J <= hi[1]; ++J)
-            for (int I = lo[0]; I <= hi[0]; ++I)
-            {
-              const int oc = (I % period_p[0]) + period_p[0] * ((J % period_p[1]) + period_p[1] * (K % period_p[2]));
-              const int64_t Kl = K - c.global_begin;
-              ASSERT_THROW(Kl >= 0 && Kl < c.dims[2], "internal: prolongator column outside the local coarse box");
-              // own aggregate of the node, for the identity part of S
-              const bool own_agg = (I == x / blk) && (J == y / blk) && (K == (int)(zg / blk));
-              for (int comp = 0; comp < C; ++comp)
-              {
-                const double ay = (*Z)[(size_t)(oc * C + comp) * (size_t)n_own + (size_t)(i - row0)];
-                const double yi = (own_agg && comp == (int)(i % C)) ? t[i] : 0.;
-                const double v = yi - w * dinv[i] * ay;
-                if (v != 0.)
-                  emit((((int64_t)Kl * c.dims[1] + J) * c.dims[0] + I) * C + comp, v);
-              }
-            }
-      };
-#pragma omp parallel for schedule(static)
-      for (int64_t i = row0; i < row0 + n_own; ++i)
-      {
-        int cnt = 0;
-        visit(i, [&](int64_t, double) { ++cnt; });
-        P.row_ptr[i + 1] = cnt;
-      }
-      for (int64_t i = 0; i < n_f; ++i)
-      {
-        ASSERT_THROW((int64_t)P.row_ptr[i] + P.row_ptr[i + 1] < (int64_t(1) << 31), "prolongator exceeds int32 entries");
-        P.row_ptr[i + 1] += P.row_ptr[i];
-      }
-      P.col.resize(P.row_ptr[n_f]);
-      P.val.resize(P.row_ptr[n_f]);
-#pragma omp parallel for schedule(static)
-      for (int64_t i = row0; i < row0 + n_own; ++i)
-      {
-        int p = P.row_ptr[i];
-        visit(i, [&](int64_t col, double v) {
-          P.col[p] = (int32_t)col;
-          P.val[p] = v;
-          ++p;
-        });
-      }
-    }
-    Z.reset();
+    // candidates of owned row i: aggregates whose nodes lie within `reach` of its node; v = t_i [own aggregate] - w d_i^-1 (A y)_i
+    auto p_mat = prolongator_from_probes(h, g.dims, c.dims, gdims_c, C, blk, g.reach, period_p, g.global_begin, c.global_begin, row0, n_own,
+                                         w, Z.data(), t_dev.get_values(), d_dinv.data());
+    Z.release();
     const double t_assembled = wall_now();
-    auto p_mat = upload_csr(h, std::move(P));
     const double t_uploaded = wall_now();
     auto pt_mat = p_mat->transpose();
     if (verbose)
@@ -332,7 +272,7 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
       period_a[d] = std::max(1, std::min(2 * c.reach + 1, gdims_c[d]));
     const int n_col_a = period_a[0] * period_a[1] * period_a[2] * C;
     const int64_t crow0 = c.owned_row_begin(), cn_own = c.owned_rows();
-    std::unique_ptr<ZeroedHostArray<double>> Y(new ZeroedHostArray<double>((size_t)n_col_a * (size_t)cn_own));
+    DeviceBuffer<double> Y((size_t)n_col_a * (size_t)cn_own);
     for (int col = 0; col < n_col_a; ++col)
     {
       const int comp = col % C, oc = col / C;
@@ -343,59 +283,12 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
       a_op->get_matrix()->vmult(z_f.get_values(), y_f.get_values());
       pt_mat->vmult(y_c.get_values(), z_f.get_values());
       h.exchange_reverse_add(c.space, y_c.get_values());
-      MFMG_HIP_CHECK(hipMemcpyAsync(Y->data() + (size_t)col * cn_own, y_c.get_values() + crow0, (size_t)cn_own * sizeof(double),
-                                    hipMemcpyDeviceToHost, h.stream));
+      MFMG_HIP_CHECK(hipMemcpyAsync(Y.data() + (size_t)col * cn_own, y_c.get_values() + crow0, (size_t)cn_own * sizeof(double),
+                                    hipMemcpyDeviceToDevice, h.stream));
     }
     MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
-    HostCsr Ac;
-    Ac.n_rows = Ac.n_cols = n_c;
-    Ac.row_ptr.assign(n_c + 1, 0);
-    {
-      auto visit = [&](int64_t r, auto &&emit) {
-        const int64_t nd = r / C;
-        const int X = (int)(nd % c.dims[0]), Yc = (int)((nd / c.dims[0]) % c.dims[1]), Zl = (int)(nd / ((int64_t)c.dims[0] * c.dims[1]));
-        const int64_t Zg = Zl + c.global_begin;
-        for (int64_t K = std::max<int64_t>(0, Zg - c.reach); K <= std::min<int64_t>(gdims_c[2] - 1, Zg + c.reach); ++K)
-          for (int J = std::max(0, Yc - c.reach); J <= std::min(gdims_c[1] - 1, Yc + c.reach); ++J)
-            for (int I = std::max(0, X - c.reach); I <= std::min(gdims_c[0] - 1, X + c.reach); ++I)
-            {
-              const int oc = (I % period_a[0]) + period_a[0] * ((J % period_a[1]) + period_a[1] * (int)(K % period_a[2]));
-              const int64_t Kl = K - c.global_begin;
-              ASSERT_THROW(Kl >= 0 && Kl < c.dims[2], "internal: coarse-operator column outside the local box");
-              for (int comp = 0; comp < C; ++comp)
-              {
-                const double v = (*Y)[(size_t)(oc * C + comp) * (size_t)cn_own + (size_t)(r - crow0)];
-                if (v != 0.)
-                  emit((((int64_t)Kl * c.dims[1] + J) * c.dims[0] + I) * C + comp, v);
-              }
-            }
-      };
-#pragma omp parallel for schedule(static)
-      for (int64_t r = crow0; r < crow0 + cn_own; ++r)
-      {
-        int cnt = 0;
-        visit(r, [&](int64_t, double) { ++cnt; });
-        Ac.row_ptr[r + 1] = cnt;
-      }
-      for (int64_t r = 0; r < n_c; ++r)
-      {
-        ASSERT_THROW((int64_t)Ac.row_ptr[r] + Ac.row_ptr[r + 1] < (int64_t(1) << 31), "coarse operator exceeds int32 entries");
-        Ac.row_ptr[r + 1] += Ac.row_ptr[r];
-      }
-      Ac.col.resize(Ac.row_ptr[n_c]);
-      Ac.val.resize(Ac.row_ptr[n_c]);
-#pragma omp parallel for schedule(static)
-      for (int64_t r = crow0; r < crow0 + cn_own; ++r)
-      {
-        int p = Ac.row_ptr[r];
-        visit(r, [&](int64_t col, double v) {
-          Ac.col[p] = (int32_t)col;
-          Ac.val[p] = v;
-          ++p;
-        });
-      }
-    }
-    Y.reset();
+    auto ac_mat = coarse_operator_from_probes(h, c.dims, gdims_c, C, c.reach, period_a, c.global_begin, crow0, cn_own, Y.data());
+    Y.release();
     if (verbose)
       std::fprintf(stderr, "[mfmg_hip] amg level %d on the device (%lld local rows, reach %d): P %d probes %.2f s, A_c %d probes %.2f s\n",
                    level, (long long)n_f, g.reach, n_col_p, t1 - t0, n_col_a, wall_now() - t1);
@@ -412,7 +305,6 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     _amg.push_back(std::move(L));
 
     // ---- next level
-    auto ac_mat = upload_csr(h, std::move(Ac));
     a_op = std::make_shared<HipMatrixOperator>(ac_mat);
     a_op->set_spaces(c.space, c.space);
     B = std::move(Bc);

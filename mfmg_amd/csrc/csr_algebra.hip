@@ -245,16 +245,19 @@ void set_lds_limit(K kernel, size_t bytes)
 
 template <typename T>
 bool csr_transpose_device(HipHandle &h, int64_t n_rows, int64_t n_cols, int64_t nnz, int32_t const *row_ptr, int32_t const *col,
-                          T const *val, std::vector<int32_t> &t_row_ptr, std::vector<int32_t> &t_col, std::vector<T> &t_val)
+                          T const *val, DeviceBuffer<int32_t> &d_tptr, DeviceBuffer<int32_t> &d_tcol, DeviceBuffer<T> &d_tval)
 {
   hipStream_t st = h.stream;
-  t_row_ptr.assign(n_cols + 1, 0);
-  t_col.resize(nnz);
-  t_val.resize(nnz);
+  std::vector<int32_t> t_row_ptr(n_cols + 1, 0);
+  d_tptr.resize((size_t)n_cols + 1);
+  d_tcol.resize((size_t)nnz);
+  d_tval.resize((size_t)nnz);
   if (nnz == 0)
+  {
+    MFMG_HIP_CHECK(hipMemsetAsync(d_tptr.data(), 0, ((size_t)n_cols + 1) * sizeof(int32_t), st));
     return true;
-  DeviceBuffer<int32_t> count((size_t)n_cols + 1), cursor((size_t)n_cols), d_tptr((size_t)n_cols + 1), d_tcol((size_t)nnz);
-  DeviceBuffer<T> d_tval((size_t)nnz);
+  }
+  DeviceBuffer<int32_t> count((size_t)n_cols + 1), cursor((size_t)n_cols);
   MFMG_HIP_CHECK(hipMemsetAsync(count.data(), 0, ((size_t)n_cols + 1) * sizeof(int32_t), st));
   MFMG_HIP_CHECK(hipMemsetAsync(cursor.data(), 0, (size_t)n_cols * sizeof(int32_t), st));
   hipLaunchKernelGGL(count_columns_kernel, dim3(n_blocks_for(nnz, 256, 1 << 16)), dim3(256), 0, st, nnz, col, count.data());
@@ -291,11 +294,27 @@ bool csr_transpose_device(HipHandle &h, int64_t n_rows, int64_t n_cols, int64_t 
     hipLaunchKernelGGL((sort_long_rows_kernel<T>), dim3((unsigned int)long_rows.size()), dim3(256), lds, st, d_rows.data(), d_tptr.data(),
                        d_tcol.data(), d_tval.data());
     MFMG_HIP_CHECK(hipGetLastError());
-    MFMG_HIP_CHECK(hipStreamSynchronize(st));
   }
-  MFMG_HIP_CHECK(hipMemcpyAsync(t_col.data(), d_tcol.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  MFMG_HIP_CHECK(hipMemcpyAsync(t_val.data(), d_tval.data(), (size_t)nnz * sizeof(T), hipMemcpyDeviceToHost, st));
-  MFMG_HIP_CHECK(hipStreamSynchronize(st));
+  MFMG_HIP_CHECK(hipStreamSynchronize(st)); // (t_row_ptr, the scratch buffers and long_rows go out of scope)
+  return true;
+}
+
+template <typename T>
+bool csr_transpose_device(HipHandle &h, int64_t n_rows, int64_t n_cols, int64_t nnz, int32_t const *row_ptr, int32_t const *col,
+                          T const *val, std::vector<int32_t> &t_row_ptr, std::vector<int32_t> &t_col, std::vector<T> &t_val)
+{
+  DeviceBuffer<int32_t> d_tptr, d_tcol;
+  DeviceBuffer<T> d_tval;
+  t_row_ptr.assign(n_cols + 1, 0);
+  t_col.resize(nnz);
+  t_val.resize(nnz);
+  if (nnz == 0)
+    return true;
+  if (!csr_transpose_device<T>(h, n_rows, n_cols, nnz, row_ptr, col, val, d_tptr, d_tcol, d_tval))
+    return false;
+  t_row_ptr = d_tptr.download(h.stream);
+  t_col = d_tcol.download(h.stream);
+  t_val = d_tval.download(h.stream);
   return true;
 }
 
@@ -351,6 +370,10 @@ bool csr_multiply_device(HipHandle &h, int64_t a_rows, int32_t const *a_ptr, int
 
 template bool csr_transpose_device<double>(HipHandle &, int64_t, int64_t, int64_t, int32_t const *, int32_t const *, double const *,
                                            std::vector<int32_t> &, std::vector<int32_t> &, std::vector<double> &);
+template bool csr_transpose_device<double>(HipHandle &, int64_t, int64_t, int64_t, int32_t const *, int32_t const *, double const *,
+                                           DeviceBuffer<int32_t> &, DeviceBuffer<int32_t> &, DeviceBuffer<double> &);
+template bool csr_transpose_device<float>(HipHandle &, int64_t, int64_t, int64_t, int32_t const *, int32_t const *, float const *,
+                                          DeviceBuffer<int32_t> &, DeviceBuffer<int32_t> &, DeviceBuffer<float> &);
 template bool csr_transpose_device<float>(HipHandle &, int64_t, int64_t, int64_t, int32_t const *, int32_t const *, float const *,
                                           std::vector<int32_t> &, std::vector<int32_t> &, std::vector<float> &);
 template bool csr_multiply_device<double>(HipHandle &, int64_t, int32_t const *, int32_t const *, double const *, int32_t const *,

@@ -13,6 +13,11 @@ template <typename T>
 bool csr_transpose_device(HipHandle &h, int64_t n_rows, int64_t n_cols, int64_t nnz, int32_t const *row_ptr, int32_t const *col,
                           T const *val, std::vector<int32_t> &t_row_ptr, std::vector<int32_t> &t_col, std::vector<T> &t_val);
 
+// the same with the result left on the device
+template <typename T>
+bool csr_transpose_device(HipHandle &h, int64_t n_rows, int64_t n_cols, int64_t nnz, int32_t const *row_ptr, int32_t const *col,
+                          T const *val, DeviceBuffer<int32_t> &t_row_ptr, DeviceBuffer<int32_t> &t_col, DeviceBuffer<T> &t_val);
+
 template <typename T>
 bool csr_multiply_device(HipHandle &h, int64_t a_rows, int32_t const *a_ptr, int32_t const *a_col, T const *a_val, int32_t const *b_ptr,
                          int32_t const *b_col, T const *b_val, std::vector<int32_t> &c_ptr, std::vector<int32_t> &c_col,

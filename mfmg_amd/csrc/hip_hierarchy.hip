@@ -1,5 +1,6 @@
 // Implementation of the HIP back-end classes declared in mfmg/hip_hierarchy_helpers.hpp.
 #include "mfmg/hip_hierarchy_helpers.hpp"
+#include "probe_assembly.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -433,13 +434,10 @@ std::shared_ptr<Operator<DVector>> HipMatrixOperator::multiply(std::shared_ptr<O
       const int64_t n_agg = (int64_t)na[0] * na[1] * na[2], nc = n_agg * ne;
       ASSERT_THROW(nc == _matrix->m(), "agglomerate grid does not match the restrictor");
       const int n_colors = k[0] * k[1] * k[2] * ne;
-      std::vector<ZeroedHostArray<double>> Y; // (pages first touched by all threads: 1.8 GB)
-      Y.reserve(n_colors);
-      for (int color = 0; color < n_colors; ++color)
-        Y.emplace_back((size_t)nc);
+      // (the probes stay on the device -- 1.8 GB at 257^3 DoFs -- and the rows are assembled there: probe_assembly.hip)
+      DeviceBuffer<double> Y((size_t)n_colors * (size_t)nc);
       {
         auto u = this->build_range_vector();
-        auto y = this->build_range_vector();
         auto w = half->build_range_vector();
         for (int color = 0; color < n_colors; ++color)
         {
@@ -447,64 +445,11 @@ std::shared_ptr<Operator<DVector>> HipMatrixOperator::multiply(std::shared_ptr<O
           const int o[3] = {oc % k[0], (oc / k[0]) % k[1], oc / (k[0] * k[1])};
           vec::probing_vector(hd, na, ne, k, o, e0, u->get_values(), (int)zoff);
           half->apply(*u, *w);
-          this->apply(*w, *y);
-          MFMG_HIP_CHECK(hipMemcpyAsync(Y[color].data(), y->get_values(), sizeof(double) * nc, hipMemcpyDeviceToHost,
-                                        hd.stream));
+          DVector y(hd, nc, Y.data() + (size_t)color * (size_t)nc);
+          this->apply(*w, y);
         }
-        MFMG_HIP_CHECK(hipStreamSynchronize(hd.stream));
       }
-      HostCsr Ac;
-      Ac.n_rows = Ac.n_cols = nc;
-      Ac.row_ptr.assign(nc + 1, 0);
-      auto neighbours = [&](int64_t a, auto &&visit) {
-        const int ax = (int)(a % na[0]), ay = (int)((a / na[0]) % na[1]), az = (int)(a / ((int64_t)na[0] * na[1]));
-        for (int dz = -1; dz <= 1; ++dz)
-          for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx)
-            {
-              const int bx = ax + dx, by = ay + dy, bz = az + dz;
-              if (bx < 0 || bx >= na[0] || by < 0 || by >= na[1] || bz < 0 || bz >= na[2])
-                continue;
-              visit(bx + (int64_t)na[0] * (by + (int64_t)na[1] * bz),
-                    (bx % k[0]) + k[0] * ((by % k[1]) + k[1] * (int)((bz + zoff) % k[2])));
-            }
-      };
-      auto owned = [&](int64_t a) {
-        const int64_t az = a / ((int64_t)na[0] * na[1]);
-        return az >= z_own0 && az < z_own1;
-      };
-      for (int64_t a = 0; a < n_agg; ++a)
-      {
-        int count = 0;
-        if (owned(a)) // (rows of the neighbours' agglomerates stay empty: a rank applies only its own rows)
-          neighbours(a, [&](int64_t, int) { ++count; });
-        for (int e = 0; e < ne; ++e)
-          Ac.row_ptr[a * ne + e + 1] = count * ne;
-      }
-      for (int64_t r = 0; r < nc; ++r)
-      {
-        ASSERT_THROW((int64_t)Ac.row_ptr[r] + Ac.row_ptr[r + 1] < (int64_t(1) << 31), "coarse operator exceeds int32 entries");
-        Ac.row_ptr[r + 1] += Ac.row_ptr[r];
-      }
-      Ac.col.resize(Ac.row_ptr[nc]);
-      Ac.val.resize(Ac.row_ptr[nc]);
-#pragma omp parallel for schedule(static)
-      for (int64_t a = 0; a < n_agg; ++a)
-        for (int e = 0; e < ne; ++e)
-        {
-          if (!owned(a))
-            continue;
-          const int64_t r = a * ne + e;
-          int p = Ac.row_ptr[r];
-          neighbours(a, [&](int64_t b, int oc) {
-            for (int e2 = 0; e2 < ne; ++e2, ++p)
-            {
-              Ac.col[p] = (int32_t)(b * ne + e2);
-              Ac.val[p] = Y[oc * ne + e2][r];
-            }
-          });
-        }
-      auto coarse = std::make_shared<HipMatrixOperator>(upload(hd, std::move(Ac)));
+      auto coarse = std::make_shared<HipMatrixOperator>(galerkin_from_probes(hd, na, ne, k, zoff, z_own0, z_own1, Y.data()));
       coarse->set_spaces(_range_space, _range_space);
       return coarse;
     }

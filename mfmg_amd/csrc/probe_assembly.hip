@@ -1,0 +1,301 @@
+// CSR matrices of the setup assembled ON THE DEVICE from the results of colour probes.
+//
+// The Galerkin products of the hierarchy are read off from operator applications (hip_hierarchy.hip: R A R^T,
+// amg_device_setup.hip: P = S P_tent and P^T A P): `Y[colour][row]` holds the entry of `row` towards the one column of
+// that colour within reach.  Until round 3 the probes were copied to the host, the rows assembled there (0.8 s for the
+// 223 M entries of the first coarse operator at 257^3 DoFs, 0.5 s for the next level) and uploaded again; here two
+// kernels (count, fill) walk the same candidate boxes in the same order and write the same entries, the row pointer is
+// an exclusive scan of the counts (done on the host: one integer per row).  Arithmetic that the host loop performed
+// (the damped-Jacobi update of the prolongator) is repeated with contraction off: same bits.
+#include "probe_assembly.hpp"
+
+#include <algorithm>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace mfmg
+{
+namespace
+{
+dim3 grid_for(int64_t work) { return dim3(n_blocks_for(work, 256, 1 << 16)); }
+
+// counts[r + 1] (counts[0] = 0) -> row_ptr, in place on the device; returns the number of entries
+int64_t scan_counts(HipHandle &h, DeviceBuffer<int32_t> &row_ptr, int64_t n_rows, char const *what)
+{
+  std::vector<int32_t> rp = row_ptr.download(h.stream);
+  // two-pass scan over blocks of rows
+  const int nt =
+#ifdef _OPENMP
+      omp_get_max_threads();
+#else
+      1;
+#endif
+  std::vector<int64_t> part((size_t)nt + 1, 0);
+#pragma omp parallel num_threads(nt)
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num();
+#else
+    const int t = 0;
+#endif
+    const int64_t b0 = n_rows * t / nt + 1, b1 = n_rows * (t + 1) / nt + 1;
+    int64_t s = 0;
+    for (int64_t r = b0; r < b1; ++r)
+      s += rp[r];
+    part[t + 1] = s;
+#pragma omp barrier
+#pragma omp single
+    for (int q = 0; q < nt; ++q)
+      part[q + 1] += part[q];
+    int64_t run = part[t];
+    for (int64_t r = b0; r < b1; ++r)
+    {
+      run += rp[r];
+      rp[r] = (int32_t)std::min<int64_t>(run, INT32_MAX);
+    }
+  }
+  const int64_t total = part[nt];
+  ASSERT_THROW(total < (int64_t(1) << 31), std::string(what) + " exceeds int32 entries");
+  MFMG_HIP_CHECK(hipMemcpyAsync(row_ptr.data(), rp.data(), rp.size() * sizeof(int32_t), hipMemcpyHostToDevice, h.stream));
+  MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
+  return total;
+}
+
+// ---- R A R^T ----------------------------------------------------------------------------------------------------
+struct GalerkinGeom
+{
+  int na[3], ne, k[3];
+  int64_t zoff, z_own0, z_own1, nc;
+};
+
+template <bool FILL>
+__global__ void galerkin_rows_kernel(GalerkinGeom g, double const *Y, int32_t *row_ptr, int32_t *col, double *val)
+{
+  const int64_t n_agg = (int64_t)g.na[0] * g.na[1] * g.na[2];
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_agg * g.ne; r += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int64_t a = r / g.ne;
+    const int ax = (int)(a % g.na[0]), ay = (int)((a / g.na[0]) % g.na[1]), az = (int)(a / ((int64_t)g.na[0] * g.na[1]));
+    const bool owned = az >= g.z_own0 && az < g.z_own1; // (rows of the neighbours' agglomerates stay empty)
+    int p = FILL ? row_ptr[r] : 0;
+    if (owned)
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx)
+          {
+            const int bx = ax + dx, by = ay + dy, bz = az + dz;
+            if (bx < 0 || bx >= g.na[0] || by < 0 || by >= g.na[1] || bz < 0 || bz >= g.na[2])
+              continue;
+            if (FILL)
+            {
+              const int64_t b = bx + (int64_t)g.na[0] * (by + (int64_t)g.na[1] * bz);
+              const int oc = (bx % g.k[0]) + g.k[0] * ((by % g.k[1]) + g.k[1] * (int)((bz + g.zoff) % g.k[2]));
+              for (int e2 = 0; e2 < g.ne; ++e2, ++p)
+              {
+                col[p] = (int32_t)(b * g.ne + e2);
+                val[p] = Y[(size_t)(oc * g.ne + e2) * (size_t)g.nc + (size_t)r];
+              }
+            }
+            else
+              p += g.ne;
+          }
+    if (!FILL)
+      row_ptr[r + 1] = p;
+  }
+}
+
+// ---- P = (I - w D^-1 A) P_tent -----------------------------------------------------------------------------------
+struct ProlongatorGeom
+{
+  int fdims[3], cdims[3], gdims_c[3], C, blk, reach, period[3];
+  int64_t f_global_begin, c_global_begin, row0, n_own;
+  double w;
+};
+
+template <bool FILL>
+__global__ void prolongator_rows_kernel(ProlongatorGeom g, double const *Z, double const *t, double const *dinv, int32_t *row_ptr,
+                                        int32_t *col, double *val)
+{
+#pragma clang fp contract(off) // multiply, multiply, subtract: the rounding of the host loop this replaces
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < g.n_own; q += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int64_t i = g.row0 + q;
+    const int64_t nd = i / g.C;
+    const int x = (int)(nd % g.fdims[0]), y = (int)((nd / g.fdims[0]) % g.fdims[1]), zl = (int)(nd / ((int64_t)g.fdims[0] * g.fdims[1]));
+    const int64_t zg = zl + g.f_global_begin;
+    const int lo[3] = {max(0, x - g.reach) / g.blk, max(0, y - g.reach) / g.blk, (int)(max((int64_t)0, zg - g.reach) / g.blk)};
+    const int hi[3] = {min(g.gdims_c[0] - 1, (x + g.reach) / g.blk), min(g.gdims_c[1] - 1, (y + g.reach) / g.blk),
+                       (int)min((int64_t)g.gdims_c[2] - 1, (zg + g.reach) / g.blk)};
+    int p = FILL ? row_ptr[i] : 0;
+    for (int K = lo[2]; K <= hi[2]; ++K)
+      for (int J = lo[1]; J <= hi[1]; ++J)
+        for (int I = lo[0]; I <= hi[0]; ++I)
+        {
+          const int oc = (I % g.period[0]) + g.period[0] * ((J % g.period[1]) + g.period[1] * (K % g.period[2]));
+          const int64_t Kl = K - g.c_global_begin;
+          const bool own_agg = (I == x / g.blk) && (J == y / g.blk) && (K == (int)(zg / g.blk));
+          for (int comp = 0; comp < g.C; ++comp)
+          {
+            const double ay = Z[(size_t)(oc * g.C + comp) * (size_t)g.n_own + (size_t)q];
+            const double yi = (own_agg && comp == (int)(i % g.C)) ? t[i] : 0.;
+            const double v = yi - g.w * dinv[i] * ay;
+            if (v != 0.)
+            {
+              if (FILL)
+              {
+                col[p] = (int32_t)((((int64_t)Kl * g.cdims[1] + J) * g.cdims[0] + I) * g.C + comp);
+                val[p] = v;
+              }
+              ++p;
+            }
+          }
+        }
+    if (!FILL)
+      row_ptr[i + 1] = p;
+  }
+}
+
+// ---- A_c = P^T A P -----------------------------------------------------------------------------------------------
+struct CoarseGeom
+{
+  int cdims[3], gdims_c[3], C, reach, period[3];
+  int64_t c_global_begin, crow0, cn_own;
+};
+
+template <bool FILL>
+__global__ void coarse_rows_kernel(CoarseGeom g, double const *Y, int32_t *row_ptr, int32_t *col, double *val)
+{
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < g.cn_own; q += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int64_t r = g.crow0 + q;
+    const int64_t nd = r / g.C;
+    const int X = (int)(nd % g.cdims[0]), Yc = (int)((nd / g.cdims[0]) % g.cdims[1]), Zl = (int)(nd / ((int64_t)g.cdims[0] * g.cdims[1]));
+    const int64_t Zg = Zl + g.c_global_begin;
+    int p = FILL ? row_ptr[r] : 0;
+    for (int64_t K = max((int64_t)0, Zg - g.reach); K <= min((int64_t)g.gdims_c[2] - 1, Zg + g.reach); ++K)
+      for (int J = max(0, Yc - g.reach); J <= min(g.gdims_c[1] - 1, Yc + g.reach); ++J)
+        for (int I = max(0, X - g.reach); I <= min(g.gdims_c[0] - 1, X + g.reach); ++I)
+        {
+          const int oc = (I % g.period[0]) + g.period[0] * ((J % g.period[1]) + g.period[1] * (int)(K % g.period[2]));
+          const int64_t Kl = K - g.c_global_begin;
+          for (int comp = 0; comp < g.C; ++comp)
+          {
+            const double v = Y[(size_t)(oc * g.C + comp) * (size_t)g.cn_own + (size_t)q];
+            if (v != 0.)
+            {
+              if (FILL)
+              {
+                col[p] = (int32_t)((((int64_t)Kl * g.cdims[1] + J) * g.cdims[0] + I) * g.C + comp);
+                val[p] = v;
+              }
+              ++p;
+            }
+          }
+        }
+    if (!FILL)
+      row_ptr[r + 1] = p;
+  }
+}
+
+template <typename Geom, typename CountLaunch, typename FillLaunch>
+std::shared_ptr<SparseMatrixDevice<double>> assemble(HipHandle &h, int64_t n_rows, int64_t n_cols, char const *what, CountLaunch &&count,
+                                                     FillLaunch &&fill)
+{
+  DeviceBuffer<int32_t> row_ptr((size_t)n_rows + 1);
+  MFMG_HIP_CHECK(hipMemsetAsync(row_ptr.data(), 0, ((size_t)n_rows + 1) * sizeof(int32_t), h.stream));
+  count(row_ptr.data());
+  MFMG_HIP_CHECK(hipGetLastError());
+  const int64_t nnz = scan_counts(h, row_ptr, n_rows, what);
+  DeviceBuffer<int32_t> col((size_t)nnz);
+  DeviceBuffer<double> val((size_t)nnz);
+  if (nnz > 0)
+  {
+    fill(row_ptr.data(), col.data(), val.data());
+    MFMG_HIP_CHECK(hipGetLastError());
+  }
+  return std::make_shared<SparseMatrixDevice<double>>(h, n_rows, n_cols, std::move(row_ptr), std::move(col), std::move(val));
+}
+} // namespace
+
+std::shared_ptr<SparseMatrixDevice<double>> galerkin_from_probes(HipHandle &h, int const na[3], int ne, int const k[3], int64_t zoff,
+                                                                 int64_t z_own0, int64_t z_own1, double const *Y)
+{
+  GalerkinGeom g;
+  for (int d = 0; d < 3; ++d)
+  {
+    g.na[d] = na[d];
+    g.k[d] = k[d];
+  }
+  g.ne = ne;
+  g.zoff = zoff;
+  g.z_own0 = z_own0;
+  g.z_own1 = z_own1;
+  g.nc = (int64_t)na[0] * na[1] * na[2] * ne;
+  return assemble<GalerkinGeom>(
+      h, g.nc, g.nc, "coarse operator",
+      [&](int32_t *rp) { hipLaunchKernelGGL(galerkin_rows_kernel<false>, grid_for(g.nc), dim3(256), 0, h.stream, g, Y, rp, nullptr, nullptr); },
+      [&](int32_t *rp, int32_t *col, double *val) {
+        hipLaunchKernelGGL(galerkin_rows_kernel<true>, grid_for(g.nc), dim3(256), 0, h.stream, g, Y, rp, col, val);
+      });
+}
+
+std::shared_ptr<SparseMatrixDevice<double>> prolongator_from_probes(HipHandle &h, int const fdims[3], int const cdims[3],
+                                                                    int const gdims_c[3], int n_comp, int blk, int reach,
+                                                                    int const period[3], int64_t f_global_begin, int64_t c_global_begin,
+                                                                    int64_t row0, int64_t n_own, double w, double const *Z,
+                                                                    double const *t, double const *dinv)
+{
+  ProlongatorGeom g;
+  for (int d = 0; d < 3; ++d)
+  {
+    g.fdims[d] = fdims[d];
+    g.cdims[d] = cdims[d];
+    g.gdims_c[d] = gdims_c[d];
+    g.period[d] = period[d];
+  }
+  g.C = n_comp;
+  g.blk = blk;
+  g.reach = reach;
+  g.f_global_begin = f_global_begin;
+  g.c_global_begin = c_global_begin;
+  g.row0 = row0;
+  g.n_own = n_own;
+  g.w = w;
+  const int64_t n_f = (int64_t)fdims[0] * fdims[1] * fdims[2] * n_comp, n_c = (int64_t)cdims[0] * cdims[1] * cdims[2] * n_comp;
+  return assemble<ProlongatorGeom>(
+      h, n_f, n_c, "prolongator",
+      [&](int32_t *rp) {
+        hipLaunchKernelGGL(prolongator_rows_kernel<false>, grid_for(n_own), dim3(256), 0, h.stream, g, Z, t, dinv, rp, nullptr, nullptr);
+      },
+      [&](int32_t *rp, int32_t *col, double *val) {
+        hipLaunchKernelGGL(prolongator_rows_kernel<true>, grid_for(n_own), dim3(256), 0, h.stream, g, Z, t, dinv, rp, col, val);
+      });
+}
+
+std::shared_ptr<SparseMatrixDevice<double>> coarse_operator_from_probes(HipHandle &h, int const cdims[3], int const gdims_c[3], int n_comp,
+                                                                        int reach, int const period[3], int64_t c_global_begin,
+                                                                        int64_t crow0, int64_t cn_own, double const *Y)
+{
+  CoarseGeom g;
+  for (int d = 0; d < 3; ++d)
+  {
+    g.cdims[d] = cdims[d];
+    g.gdims_c[d] = gdims_c[d];
+    g.period[d] = period[d];
+  }
+  g.C = n_comp;
+  g.reach = reach;
+  g.c_global_begin = c_global_begin;
+  g.crow0 = crow0;
+  g.cn_own = cn_own;
+  const int64_t n_c = (int64_t)cdims[0] * cdims[1] * cdims[2] * n_comp;
+  return assemble<CoarseGeom>(
+      h, n_c, n_c, "coarse operator",
+      [&](int32_t *rp) { hipLaunchKernelGGL(coarse_rows_kernel<false>, grid_for(cn_own), dim3(256), 0, h.stream, g, Y, rp, nullptr, nullptr); },
+      [&](int32_t *rp, int32_t *col, double *val) {
+        hipLaunchKernelGGL(coarse_rows_kernel<true>, grid_for(cn_own), dim3(256), 0, h.stream, g, Y, rp, col, val);
+      });
+}
+} // namespace mfmg

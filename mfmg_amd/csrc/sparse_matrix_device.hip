@@ -1014,12 +1014,144 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
       cols_ok = cols_ok && col[p] >= 0 && col[p] < n_cols;
     ASSERT_THROW(cols_ok, "column index out of range");
   }
-  const double avg = n_rows > 0 ? double(_nnz) / double(n_rows) : 0.;
-  const auto t_begin = std::chrono::steady_clock::now();
-  // (the CSR arrays go to the device first: the layout analysis below runs on them)
+  // (the CSR arrays go to the device first: the layout analysis runs on them)
   _val.upload(val.data(), val.size(), handle.stream);
   _col.upload(col.data(), col.size(), handle.stream);
   _row_ptr.upload(row_ptr.data(), row_ptr.size(), handle.stream);
+  _row_ptr_host = std::move(row_ptr);
+  _col_host = std::move(col);
+  _val_host = std::move(val);
+  choose_layouts(analyse);
+  if (!keep_host)
+  {
+    std::vector<int32_t>().swap(_row_ptr_host);
+    std::vector<int32_t>().swap(_col_host);
+    std::vector<T>().swap(_val_host);
+  }
+}
+
+namespace
+{
+__global__ void csr_validate_kernel(int64_t n_rows, int64_t n_cols, int32_t const *row_ptr, int32_t const *col, int *bad)
+{
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x)
+  {
+    if (row_ptr[r] > row_ptr[r + 1] || row_ptr[r] < 0)
+    {
+      atomicOr(bad, 1);
+      continue;
+    }
+    for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
+      if (col[p] < 0 || col[p] >= n_cols)
+        atomicOr(bad, 2);
+  }
+}
+
+// lengths of a list of rows, and their column indices packed one row after the other
+__global__ void csr_row_lengths_kernel(int32_t const *row_ptr, int64_t const *rows, int64_t n_q, int32_t *len)
+{
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n_q; q += (int64_t)gridDim.x * blockDim.x)
+    len[q] = row_ptr[rows[q] + 1] - row_ptr[rows[q]];
+}
+__global__ void csr_pack_rows_kernel(int32_t const *row_ptr, int32_t const *col, int64_t const *rows, int64_t n_q, int32_t const *out_ptr,
+                                     int32_t *out_col)
+{
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n_q; q += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int p0 = row_ptr[rows[q]], len = row_ptr[rows[q] + 1] - p0;
+    for (int t = 0; t < len; ++t)
+      out_col[out_ptr[q] + t] = col[p0 + t];
+  }
+}
+} // namespace
+
+// From arrays that are on the device already (the setup forms its matrices there): ownership is taken, the host copy
+// is fetched only if something asks for it (download, the host fall-backs of transpose / mmult, the row-base and
+// LDS-cached layouts).
+template <typename T>
+SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int64_t n_cols, DeviceBuffer<int32_t> row_ptr,
+                                          DeviceBuffer<int32_t> col, DeviceBuffer<T> val, bool analyse)
+    : _handle(handle), _n_rows(n_rows), _n_cols(n_cols)
+{
+  ASSERT_THROW((int64_t)row_ptr.size() == n_rows + 1, "row_ptr has the wrong size");
+  ASSERT_THROW(n_rows * 64 < (int64_t(1) << 40), "matrix too large");
+  int32_t last = 0;
+  MFMG_HIP_CHECK(hipMemcpyAsync(&last, row_ptr.data() + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, handle.stream));
+  MFMG_HIP_CHECK(hipStreamSynchronize(handle.stream));
+  _nnz = last;
+  ASSERT_THROW((int64_t)col.size() == _nnz && (int64_t)val.size() == _nnz, "column index / value arrays do not match row_ptr");
+  _row_ptr = std::move(row_ptr);
+  _col = std::move(col);
+  _val = std::move(val);
+  {
+    DeviceBuffer<int> bad(1);
+    MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), handle.stream));
+    hipLaunchKernelGGL(csr_validate_kernel, dim3(n_blocks_for(n_rows, 256, 1 << 16)), dim3(256), 0, handle.stream, n_rows, n_cols,
+                       _row_ptr.data(), _col.data(), bad.data());
+    MFMG_HIP_CHECK(hipGetLastError());
+    const int b = bad.download(handle.stream)[0];
+    ASSERT_THROW((b & 1) == 0, "row_ptr must be non-decreasing");
+    ASSERT_THROW((b & 2) == 0, "column index out of range");
+  }
+  choose_layouts(analyse);
+}
+
+template <typename T>
+void SparseMatrixDevice<T>::ensure_host_copy() const
+{
+  if (!_row_ptr_host.empty() || _n_rows == 0)
+    return;
+  download(_row_ptr_host, _col_host, _val_host);
+}
+
+// column indices of the rows `rows` (ascending), packed: row q occupies [ptr[q], ptr[q+1]) of cols
+template <typename T>
+void SparseMatrixDevice<T>::sample_rows(std::vector<int64_t> const &rows, std::vector<int32_t> &ptr, std::vector<int32_t> &cols) const
+{
+  const int64_t nq = (int64_t)rows.size();
+  ptr.assign(nq + 1, 0);
+  cols.clear();
+  if (nq == 0)
+    return;
+  if (has_host_copy())
+  {
+    for (int64_t q = 0; q < nq; ++q)
+      ptr[q + 1] = ptr[q] + (_row_ptr_host[rows[q] + 1] - _row_ptr_host[rows[q]]);
+    cols.resize(ptr[nq]);
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < nq; ++q)
+      std::copy(_col_host.begin() + _row_ptr_host[rows[q]], _col_host.begin() + _row_ptr_host[rows[q] + 1], cols.begin() + ptr[q]);
+    return;
+  }
+  hipStream_t st = _handle.stream;
+  DeviceBuffer<int64_t> d_rows;
+  d_rows.upload(rows.data(), rows.size(), st);
+  DeviceBuffer<int32_t> d_len((size_t)nq);
+  hipLaunchKernelGGL(csr_row_lengths_kernel, dim3(n_blocks_for(nq, 256, 1 << 16)), dim3(256), 0, st, _row_ptr.data(), d_rows.data(), nq,
+                     d_len.data());
+  MFMG_HIP_CHECK(hipGetLastError());
+  const std::vector<int32_t> len = d_len.download(st);
+  for (int64_t q = 0; q < nq; ++q)
+    ptr[q + 1] = ptr[q] + len[q];
+  cols.resize(ptr[nq]);
+  if (ptr[nq] == 0)
+    return;
+  DeviceBuffer<int32_t> d_ptr, d_cols((size_t)ptr[nq]);
+  d_ptr.upload(ptr.data(), ptr.size(), st);
+  hipLaunchKernelGGL(csr_pack_rows_kernel, dim3(n_blocks_for(nq, 256, 1 << 16)), dim3(256), 0, st, _row_ptr.data(), _col.data(), d_rows.data(),
+                     nq, d_ptr.data(), d_cols.data());
+  MFMG_HIP_CHECK(hipGetLastError());
+  MFMG_HIP_CHECK(hipMemcpyAsync(cols.data(), d_cols.data(), cols.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  MFMG_HIP_CHECK(hipStreamSynchronize(st));
+}
+
+template <typename T>
+void SparseMatrixDevice<T>::choose_layouts(bool analyse)
+{
+  HipHandle &handle = _handle;
+  const int64_t n_rows = _n_rows, n_cols = _n_cols;
+  const double avg = n_rows > 0 ? double(_nnz) / double(n_rows) : 0.;
+  const auto t_begin = std::chrono::steady_clock::now();
   // lanes per row: about 3-6 entries per lane (measured on R, R^T, A_c and the prolongators, profiles/)
   int lpr = 4;
   while (lpr < 64 && lpr * 2 <= avg / 3.3)
@@ -1031,18 +1163,23 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
   _lanes_per_row = lpr;
   // ---- block-diagonal storage (see bdia_spmv_kernel); when it applies the LDS lists are not needed
   if (analyse && n_rows == n_cols && n_rows >= 32768 && avg >= 8.)
-    build_block_diagonals(row_ptr, col, val);
+    build_block_diagonals();
   // ---- row-base storage (see rowbase_spmv_kernel) for matrices the block diagonals do not fit
   // (one thread per row: below ~1000 workgroups the CSR kernels with several lanes per row fill the chip better)
   // ---- node classes (see build_node_classes) for the rectangular operators of a translation-invariant problem
   if (analyse && !_use_bdia && n_rows >= 32768 && avg >= 4.)
-    build_node_classes(row_ptr, col, val);
+    build_node_classes();
   if (analyse && !_use_bdia && !_use_nodecls && n_rows >= 200000 && avg >= 4. && avg <= 160.)
-    build_row_base(row_ptr, col, val);
+  {
+    ensure_host_copy();
+    build_row_base(_row_ptr_host, _col_host, _val_host);
+  }
   // ---- block-local column compression for the LDS-cached kernel
   // (a 128-row block per workgroup: below ~256 blocks the plain kernel fills the chip better)
   if (analyse && !_use_bdia && !_use_rowbase && !_use_nodecls && n_rows >= 256 * kRowsPerBlock && avg >= 4.)
   {
+    ensure_host_copy();
+    std::vector<int32_t> const &row_ptr = _row_ptr_host, &col = _col_host;
     const int64_t nb = (n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
     std::vector<int32_t> blk_ptr(nb + 1, 0);
     std::vector<std::vector<int32_t>> uniq(nb);
@@ -1093,35 +1230,33 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
                  _bdia_sym ? " (symmetric half)" : "", (int)_bdia_regular, _bdia_n_classes,
                  (long long)_bdia_exc_rows.size(), _rb_slots, _nc_classes, _nc_d, _nc_c, (long long)_nc_listed.size(),
                  std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
-  if (keep_host)
-  {
-    _row_ptr_host = std::move(row_ptr);
-    _col_host = std::move(col);
-    _val_host = std::move(val);
-  }
 }
 
 template <typename T>
-void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &row_ptr, std::vector<int32_t> const &col,
-                                                  std::vector<T> const &val)
+void SparseMatrixDevice<T>::build_block_diagonals()
 {
   const int64_t n = _n_rows;
   int best_c = 0;
   std::vector<int32_t> best_offs;
   double best_fill = 0.;
+  // block offsets met on a sample of the rows (their column indices fetched once); the fill pass below checks every entry
+  int64_t step = std::max<int64_t>(1, n / 65536);
+  while (step % 2 == 0 || step % 3 == 0) // the sample must meet every row position inside a node
+    ++step;
+  const int64_t n_sample = (n + step - 1) / step;
+  std::vector<int64_t> sample(n_sample);
+  for (int64_t q = 0; q < n_sample; ++q)
+    sample[q] = q * step;
+  std::vector<int32_t> row_ptr, col; // of the sample: row q = sample[q]
+  sample_rows(sample, row_ptr, col);
   for (int c = 1; c <= 4; ++c)
   {
     if (n % c != 0)
       continue;
-    // block offsets met on a sample of the rows; the fill pass below checks every entry
     std::vector<int32_t> offs;
     bool too_many = false;
-    int64_t step = std::max<int64_t>(1, n / 65536);
-    while (step % 2 == 0 || step % 3 == 0) // the sample must meet every row position inside a node
-      ++step;
     // (every thread collects the offsets of its share of the sample; serial, this loop was the second of the 1.1 s the
     // analysis of a 38 M-entry level took)
-    const int64_t n_sample = (n + step - 1) / step;
 #pragma omp parallel
     {
       std::vector<int32_t> mine;
@@ -1129,11 +1264,11 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
 #pragma omp for schedule(static)
       for (int64_t q = 0; q < n_sample; ++q)
       {
-        const int64_t r = q * step;
+        const int64_t r = sample[q];
         if (mine_too_many)
           continue;
         int32_t last = INT32_MIN;
-        for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
+        for (int p = row_ptr[q]; p < row_ptr[q + 1]; ++p)
         {
           const int32_t o = (int32_t)(col[p] / c - r / c);
           if (o == last)
@@ -1457,20 +1592,12 @@ void SparseMatrixDevice<T>::build_block_diagonals(std::vector<int32_t> const &ro
 // per node instead of 12 B per entry.  Rows of nodes that match no class go through csr_listed_rows_kernel.  The
 // format is used when at least 90 % of the rows are in classes.
 template <typename T>
-void SparseMatrixDevice<T>::build_node_classes(std::vector<int32_t> const &row_ptr, std::vector<int32_t> const &col,
-                                               std::vector<T> const &val)
+void SparseMatrixDevice<T>::build_node_classes()
 {
   const int64_t n = _n_rows, m = _n_cols;
   int best_c = 0;
   std::vector<int32_t> best_offs;
   double best_fill = 0.;
-  auto node_base = [&](int64_t nd, int c) {
-    int64_t b = std::numeric_limits<int64_t>::max();
-    for (int64_t r = nd * c; r < (nd + 1) * c; ++r)
-      for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
-        b = std::min<int64_t>(b, col[p] / c);
-    return b;
-  };
   for (int c = 1; c <= 4; ++c)
   {
     if (n % c != 0 || m % c != 0)
@@ -1482,6 +1609,13 @@ void SparseMatrixDevice<T>::build_node_classes(std::vector<int32_t> const &row_p
     while (step % 2 == 0 || step % 3 == 0)
       ++step;
     const int64_t n_sample = (n_nodes + step - 1) / step;
+    // the rows of the sampled nodes (c rows each), their column indices fetched once
+    std::vector<int64_t> sample((size_t)n_sample * c);
+    for (int64_t q = 0; q < n_sample; ++q)
+      for (int rc = 0; rc < c; ++rc)
+        sample[q * c + rc] = q * step * c + rc;
+    std::vector<int32_t> row_ptr, col; // of the sample
+    sample_rows(sample, row_ptr, col);
 #pragma omp parallel
     {
       std::vector<int32_t> mine; // (the offsets of a thread's share of the sample, merged below)
@@ -1489,11 +1623,12 @@ void SparseMatrixDevice<T>::build_node_classes(std::vector<int32_t> const &row_p
 #pragma omp for schedule(static)
       for (int64_t q = 0; q < n_sample; ++q)
       {
-        const int64_t nd = q * step;
         if (mine_too_many)
           continue;
-        const int64_t b = node_base(nd, c);
-        for (int64_t r = nd * c; r < (nd + 1) * c && !mine_too_many; ++r)
+        int64_t b = std::numeric_limits<int64_t>::max(); // first column node of the row node
+        for (int p = row_ptr[q * c]; p < row_ptr[(q + 1) * c]; ++p)
+          b = std::min<int64_t>(b, col[p] / c);
+        for (int64_t r = q * c; r < (q + 1) * c && !mine_too_many; ++r)
         {
           int32_t last = INT32_MIN;
           for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
@@ -2169,9 +2304,14 @@ std::shared_ptr<SparseMatrixDevice<T>> SparseMatrixDevice<T>::transpose() const
   std::vector<int32_t> rp, cl, trp, tcl;
   std::vector<T> vl, tvl;
   const int64_t nnz = (int64_t)_val.size();
-  if (csr_algebra_on_device() && nnz > 0 &&
-      csr_transpose_device<T>(_handle, _n_rows, _n_cols, nnz, _row_ptr.data(), _col.data(), _val.data(), trp, tcl, tvl))
-    return std::make_shared<SparseMatrixDevice<T>>(_handle, _n_cols, _n_rows, std::move(trp), std::move(tcl), std::move(tvl));
+  if (csr_algebra_on_device() && nnz > 0)
+  {
+    // (the transposed arrays stay on the device: the layout analysis of the new matrix runs there)
+    DeviceBuffer<int32_t> d_ptr, d_col;
+    DeviceBuffer<T> d_val;
+    if (csr_transpose_device<T>(_handle, _n_rows, _n_cols, nnz, _row_ptr.data(), _col.data(), _val.data(), d_ptr, d_col, d_val))
+      return std::make_shared<SparseMatrixDevice<T>>(_handle, _n_cols, _n_rows, std::move(d_ptr), std::move(d_col), std::move(d_val));
+  }
   if (csr_algebra_on_device() && nnz > 0)
     csr_algebra_fell_back("transpose");
   if (has_host_copy())

@@ -33,6 +33,10 @@ public:
   // (analyse = false: plain CSR only -- for a matrix kept for the setup algebra and inspection while another object
   // evaluates it, like the restrictor next to its agglomerate-wise form)
 
+  // from arrays already on the device (ownership taken; the host copy is fetched on demand)
+  SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int64_t n_cols, DeviceBuffer<int32_t> row_ptr, DeviceBuffer<int32_t> col,
+                     DeviceBuffer<T> val, bool analyse = true);
+
   int64_t m() const { return _n_rows; }
   int64_t n() const { return _n_cols; }
   int64_t n_nonzero_elements() const { return _nnz; }
@@ -73,9 +77,21 @@ public:
   std::shared_ptr<SparseMatrixDevice<T>> transpose() const;
   std::shared_ptr<SparseMatrixDevice<T>> mmult(SparseMatrixDevice<T> const &b) const;
 
-  std::vector<int32_t> const &host_row_ptr() const { return _row_ptr_host; }
-  std::vector<int32_t> const &host_col() const { return _col_host; }
-  std::vector<T> const &host_val() const { return _val_host; }
+  std::vector<int32_t> const &host_row_ptr() const
+  {
+    ensure_host_copy();
+    return _row_ptr_host;
+  }
+  std::vector<int32_t> const &host_col() const
+  {
+    ensure_host_copy();
+    return _col_host;
+  }
+  std::vector<T> const &host_val() const
+  {
+    ensure_host_copy();
+    return _val_host;
+  }
   bool has_host_copy() const { return !_row_ptr_host.empty(); }
   void download(std::vector<int32_t> &row_ptr, std::vector<int32_t> &col, std::vector<T> &val) const;
 
@@ -139,8 +155,10 @@ private:
   DeviceBuffer<int32_t> _blk_ptr, _l2g;
   DeviceBuffer<uint16_t> _lcol;
   // block-diagonal storage (chosen at construction for stencil-like square matrices, see the .hip file)
-  void build_block_diagonals(std::vector<int32_t> const &row_ptr, std::vector<int32_t> const &col,
-                             std::vector<T> const &val);
+  void build_block_diagonals();
+  void choose_layouts(bool analyse);
+  void ensure_host_copy() const;
+  void sample_rows(std::vector<int64_t> const &rows, std::vector<int32_t> &ptr, std::vector<int32_t> &cols) const;
   // row-base storage (rectangular stencil-like matrices: the smoothed prolongators), see the .hip file
   void build_row_base(std::vector<int32_t> const &row_ptr, std::vector<int32_t> const &col, std::vector<T> const &val);
   bool _use_rowbase = false;
@@ -149,7 +167,7 @@ private:
   DeviceBuffer<int32_t> _rb_base, _rb_offs;
   // node classes (rectangular stencil-like matrices of a translation-invariant problem: the prolongators and
   // their transposes), see the .hip file
-  void build_node_classes(std::vector<int32_t> const &row_ptr, std::vector<int32_t> const &col, std::vector<T> const &val);
+  void build_node_classes();
   bool _use_nodecls = false;
   int _nc_c = 0, _nc_d = 0, _nc_classes = 0;
   DeviceBuffer<int32_t> _nc_base, _nc_offs, _nc_nodes, _nc_class_of_wave, _nc_listed;
@@ -173,8 +191,8 @@ private:
   DeviceBuffer<T> _val;
   DeviceBuffer<int32_t> _col;
   DeviceBuffer<int32_t> _row_ptr;
-  std::vector<int32_t> _row_ptr_host, _col_host;
-  std::vector<T> _val_host;
+  mutable std::vector<int32_t> _row_ptr_host, _col_host;
+  mutable std::vector<T> _val_host;
 };
 
 // host CSR helpers shared by the setup code
