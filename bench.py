@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--cpu-cycles", type=int, default=5, help="timed V-cycles of the CPU baseline sample")
     ap.add_argument("--no-smoother-512", action="store_true",
                     help="skip the extra fine-level smoother measurement at 512^3 (north_star target config)")
+    ap.add_argument("--no-vcycle-513", action="store_true",
+                    help="skip the one-GPU V-cycle on the global problem of configs[3] (512^3 cells; ~40 s with its setup)")
     ap.add_argument("--amg-block", type=int, default=2, help="nodes per direction of one aggregate of the coarse AMG")
     ap.add_argument("--amg-deep", type=str, default="", help="level,block: bigger geometric aggregates from that AMG level on")
     ap.add_argument("--amg-degree", type=int, default=1, help="Chebyshev degree of the coarse AMG smoothers")
@@ -130,6 +132,10 @@ def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, mater
     x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
     x *= (prob.constrained != 1).to(torch.float64)
     b = torch.zeros(n, dtype=torch.float64, device="cuda")
+    # residual norms around the run (b = 0): the contraction the cycle delivers at this size
+    r = torch.empty_like(x)
+    h.operator_apply(0, x, r)
+    res0 = ctx.l2_norm(r)
     for _ in range(warmup):
         h.apply(b, x)
     torch.cuda.synchronize()
@@ -138,10 +144,15 @@ def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, mater
         h.apply(b, x)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    h.operator_apply(0, x, r)
+    res1 = ctx.l2_norm(r)
+    free_b, total_b = torch.cuda.mem_get_info()
     kind = "matrix-free" if evaluator == "HipMatrixFreeMeshEvaluator" else "assembled CSR fine operator"
     return {"workload": f"{cells}^3 cells = {cells + 1}^3 DoFs, {kind}, material {material}, Chebyshev(3), same "
                         f"hierarchy parameters",
-            "n_dofs": n, "ms_per_step": dt * 1e3, "value": n / dt, "unit": "DoF/s", "setup_seconds": t_setup}
+            "n_dofs": n, "ms_per_step": dt * 1e3, "value": n / dt, "unit": "DoF/s", "setup_seconds": t_setup,
+            "mean_residual_contraction_per_cycle": (res1 / res0) ** (1.0 / (warmup + steps)) if res0 > 0 else 0.0,
+            "device_memory_in_use_GB": (total_b - free_b) / 1e9}
 
 
 def measure_vcycle_f32(ctx, torch, M, h, prob, op_monitor_factory, steps=10, warmup=3):
@@ -685,6 +696,19 @@ def main():
                 if not args.allow_missing_extras:
                     raise
                 out["extras_error"] = str(e)
+        # ---- the GLOBAL problem of BASELINE.json configs[3] (512^3 cells = 513^3 DoFs) on ONE GPU: the strong-scaling anchor
+        #      of the 8-GPU run and the "512^3 V-cycle" figure; fits the 288 GB of one MI355X
+        if world == 1 and not args.no_vcycle_513 and not args.no_extras and not assembled:
+            h = x = b = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                out["vcycle_513cubed_1gpu"] = measure_vcycle_small(ctx, torch, M, 512, params, steps=5, warmup=2)
+            except Exception as e:  # noqa: BLE001
+                if not args.allow_missing_extras:
+                    raise
+                out["vcycle_513cubed_1gpu"] = {"error": str(e)}
         # ---- north_star target legs: the fine-level smoother apply at 512^3 DoFs, measured with nothing else resident (the
         #      hierarchies of the other legs are freed first: with ~25 GB of them still allocated the same launches ran 4 %
         #      slower).  The default cell-constant layout derives D^-1 in the kernel: fewer bytes, faster, and a lower byte

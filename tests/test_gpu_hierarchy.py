@@ -886,3 +886,46 @@ def test_fast_ap(ctx, evaluator, n, material):
     h = M.Hierarchy(ctx, evaluator, prob, base_params(smoother=smoother, fast_ap=True))
     with pytest.raises(L.MfmgInvalidArgument, match="keep_ap"):
         h.ap_apply(1, dev(np.zeros(nc)), out)
+
+
+def test_global_problem_of_config3_on_one_gpu(ctx):
+    """BASELINE.json configs[3]'s GLOBAL problem (512^3 cells = 513^3 DoFs) as one V-cycle hierarchy on ONE GPU -- the
+    strong-scaling anchor of the 8-GPU run (`bench.py: vcycle_513cubed_1gpu`).  The oracle does not reach this size in
+    a test's time (8 x the 257^3 case of test_full_size_vcycle_history_against_the_native_oracle), so: the
+    size-independent properties of the operators on the path and the contraction of the cycle, and the table-driven
+    layouts chosen (the first coarse operator, 33.5 M rows, must not fall back to stored values)."""
+    n = (512, 512, 512)
+    prob = M.LaplaceProblem(n, "constant", device="cuda")
+    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0}, solver={"type": "amg"})
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    nf, nc = h.level_size(0), h.level_size(1)
+    assert nf == 513 ** 3 and nc == 2 * 256 ** 3
+    g = torch.Generator(device="cuda").manual_seed(11)
+    free = (prob.constrained == 0).to(torch.float64)
+    rnd = lambda m: torch.rand(m, dtype=torch.float64, device="cuda", generator=g)
+    x, y = rnd(nf) * free, rnd(nf) * free
+    u, v = rnd(nc), rnd(nc)
+    ax, ay = torch.empty_like(x), torch.empty_like(x)
+    h.operator_apply(0, x, ax)
+    h.operator_apply(0, y, ay)
+    assert abs(ctx.dot(ax, y) - ctx.dot(x, ay)) < 1e-11 * abs(ctx.dot(ax, y))           # A symmetric
+    au, av = torch.empty_like(u), torch.empty_like(u)
+    h.operator_apply(1, u, au)
+    h.operator_apply(1, v, av)
+    assert abs(ctx.dot(au, v) - ctx.dot(u, av)) < 1e-11 * abs(ctx.dot(au, v))           # A_c symmetric
+    t1, t2, t3 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(u)
+    h.restrictor_apply(1, u, t1, L.TRANS)
+    h.operator_apply(0, t1, t2)
+    h.restrictor_apply(1, t2, t3)
+    assert abs(ctx.dot(t3, v) - ctx.dot(au, v)) < 1e-9 * abs(ctx.dot(au, v))             # <R A R^T u, v> = <A_c u, v>
+    del ax, ay, t1, t2, t3, au, av
+    assert h.coarse_operator().get_kernel()[1] == 3 and h.coarse_operator().regular_rows()
+    xx = x
+    b = torch.zeros_like(xx)
+    r = torch.empty_like(xx)
+    norms = []
+    for _ in range(4):
+        h.operator_apply(0, xx, r)
+        norms.append(ctx.l2_norm(r))
+        h.apply(b, xx)
+    assert all(norms[i + 1] < 0.4 * norms[i] for i in range(3)), norms
