@@ -87,6 +87,9 @@ typedef int (*mfmg_hip_host_allgather_fn)(void *user, const double *in, int64_t 
 int mfmg_hip_context_set_communicator(mfmg_hip_context_t ctx, int32_t rank, int32_t n_ranks, int32_t ghost_cells_low,
                                       int32_t ghost_cells_high);
 int mfmg_hip_rccl_unique_id(unsigned char out[128]);
+/* MFMG_HIP_SUCCESS when librccl and the entry points the transport uses can be resolved in this process (dlopen / dlsym
+ * only, no RCCL call is made).  Callers agree on the transport with a collective over this flag before they choose. */
+int mfmg_hip_rccl_available(void);
 int mfmg_hip_context_use_rccl(mfmg_hip_context_t ctx, const unsigned char unique_id[128]);
 int mfmg_hip_context_use_host_transport(mfmg_hip_context_t ctx, mfmg_hip_host_sendrecv_fn sendrecv,
                                         mfmg_hip_host_allreduce_fn allreduce, mfmg_hip_host_allgather_fn allgather, void *user);

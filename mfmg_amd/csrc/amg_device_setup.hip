@@ -200,8 +200,8 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
       for (int64_t i = row0; i < row0 + n_own; ++i)
         rho = std::max(rho, ratio[i]);
     }
+    rho = h.allreduce_max(rho); // (first the collective, then the check: every rank throws or none does)
     ASSERT_THROW(rho < HUGE_VAL, "zero diagonal in the multilevel coarse solver setup");
-    rho = h.allreduce_max(rho);
     const double w = opts.omega / rho;
 
     // ---- tentative prolongator: t = B / |B|_aggregate on the owned nodes, exchanged to the ghosts; B_c = |B|_aggregate

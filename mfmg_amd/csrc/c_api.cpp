@@ -159,6 +159,11 @@ int mfmg_hip_context_set_communicator(mfmg_hip_context_t ctx, int32_t rank, int3
   });
 }
 
+int mfmg_hip_rccl_available(void)
+{
+  return guarded([&] { rccl_available(); });
+}
+
 int mfmg_hip_rccl_unique_id(unsigned char out[128])
 {
   return guarded([&] {

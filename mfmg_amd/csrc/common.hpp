@@ -309,6 +309,10 @@ struct HaloCommunicator
   std::shared_ptr<HaloTransport> transport;
   std::vector<HaloSpace> spaces = std::vector<HaloSpace>(3); // [0] rank-local, [1] fine DoFs, [2] first coarse level, then the aggregation levels
   int64_t n_exchanges = 0; // (diagnostics) point-to-point exchanges issued so far
+  // The spaces from [2] on describe the levels of ONE hierarchy (its operators hold indices into `spaces`): the
+  // hierarchy helpers that configured them own them until they are destroyed; a second hierarchy on the same
+  // communicator is refused while the first is alive (it would re-purpose spaces the first one still exchanges with).
+  void const *spaces_owner = nullptr;
   bool enabled() const { return n_ranks > 1; }
   int add_space(HaloSpace const &s)
   {

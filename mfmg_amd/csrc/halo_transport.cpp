@@ -1,8 +1,10 @@
 #include "halo_transport.hpp"
 
 #include <dlfcn.h>
+#include <link.h>
 
 #include <cstring>
+#include <string>
 
 namespace mfmg
 {
@@ -41,8 +43,23 @@ RcclApi &rccl()
     // the copy already in the process (torch ships its own librccl.so) comes first: two RCCL instances in one
     // process would each bring their own topology state
     const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    // (torch's bundled copy sits under its own directory: the bare soname may not match it, so the loaded objects are
+    // searched for a librccl first and that very file is re-opened)
+    std::string loaded;
+    dl_iterate_phdr(
+        [](struct dl_phdr_info *info, size_t, void *data) {
+          if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl.so") != nullptr)
+          {
+            *static_cast<std::string *>(data) = info->dlpi_name;
+            return 1;
+          }
+          return 0;
+        },
+        &loaded);
+    if (!loaded.empty())
+      a.lib = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD);
     for (const char *n : names)
-      if ((a.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) != nullptr)
+      if (a.lib == nullptr && (a.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) != nullptr)
         break;
     if (!a.lib)
       for (const char *n : names)
@@ -215,6 +232,8 @@ private:
   int64_t _host_n = 0;
 };
 } // namespace
+
+void rccl_available() { (void)rccl(); } // throws when librccl or one of its entry points cannot be resolved
 
 void rccl_unique_id(unsigned char out[128])
 {

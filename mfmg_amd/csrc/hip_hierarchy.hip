@@ -1239,6 +1239,10 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
   HaloCommunicator &comm = _handle.comm;
   if (comm.enabled())
   {
+    ASSERT_THROW(comm.spaces_owner == nullptr || comm.spaces_owner == this,
+                 "this distributed context already carries a hierarchy: its halo spaces are in use -- destroy that "
+                 "hierarchy first (one hierarchy per communicator context at a time)");
+    comm.spaces_owner = this;
     // first coarse level: layers of agglomerates along z, `n_components` unknowns per agglomerate
     ASSERT_THROW(opts.agglomerate[2] == 2, "distributed runs need agglomeration.nz = 2");
     HaloSpace &cs = comm.spaces[2];

@@ -41,7 +41,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
+#include <set>
 #include <type_traits>
+#include <utility>
 
 namespace mfmg
 {
@@ -1298,15 +1301,17 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
   const dim3 block(64 * nw);
   hipStream_t st = _handle.stream;
   auto go = [&](auto kernel) {
-    // (the attribute is per kernel and device: set it whenever the device of the calling thread changes)
-    static int lds_attr_device = -1;
+    // (the attribute is per kernel AND device; every instantiation decays to the same function-pointer type, so the
+    // record of what has been set is keyed on the pointer -- a flag per lambda instantiation would be shared by all variants)
+    static std::mutex attr_mutex;
+    static std::set<std::pair<const void *, int>> attr_set;
     int dev = 0;
     MFMG_HIP_CHECK(hipGetDevice(&dev));
-    if (lds_attr_device != dev)
     {
-      MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024));
-      lds_attr_device = dev;
+      std::lock_guard<std::mutex> lock(attr_mutex);
+      if (attr_set.insert({reinterpret_cast<const void *>(kernel), dev}).second)
+        MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024));
     }
     hipLaunchKernelGGL(kernel, grid, block, lds, st, am, at, tail_blocks);
   };

@@ -339,6 +339,16 @@ class HipHierarchyHelpers : public HierarchyHelpers<VectorType>
 {
 public:
   explicit HipHierarchyHelpers(HipHandle &handle) : _handle(handle) {}
+  ~HipHierarchyHelpers() override
+  {
+    // the halo spaces of this hierarchy's levels go with it (common.hpp: HaloCommunicator::spaces_owner)
+    if (_handle.comm.spaces_owner == this)
+    {
+      _handle.comm.spaces_owner = nullptr;
+      _handle.comm.spaces.resize(3);
+      _handle.comm.spaces[2] = HaloSpace();
+    }
+  }
 
   std::shared_ptr<Operator<VectorType>> get_global_operator(std::shared_ptr<MeshEvaluator> mesh_evaluator) override;
 

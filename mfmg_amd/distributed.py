@@ -107,11 +107,20 @@ class HaloTransport:
         check(self._lib.mfmg_hip_context_set_communicator(ctx.handle, self.rank, self.n_ranks, part.ghost_low,
                                                           part.ghost_high))
         if transport == "rccl":
-            # can this process reach RCCL at all?  (decided identically on every rank: same image, same library)
-            probe = (C.c_ubyte * 128)()
-            if self._lib.mfmg_hip_rccl_unique_id(probe) != 0:
-                print(f"[mfmg_amd] RCCL transport unavailable ({self._lib.mfmg_hip_last_error().decode(errors='replace')}); "
-                      f"falling back to the host transport", flush=True)
+            # can EVERY rank reach RCCL?  The probe resolves the library and its entry points only (no RCCL call, no
+            # bootstrap thread); the decision is a MIN all-reduce over the ranks, so that no rank enters the gloo branch
+            # while the others wait in the broadcast of the unique id
+            ok = 1 if self._lib.mfmg_hip_rccl_available() == 0 else 0
+            why = "" if ok else self._lib.mfmg_hip_last_error().decode(errors="replace")
+            if self.n_ranks > 1 and dist.is_initialized():
+                flag = torch.tensor([ok], dtype=torch.int32)
+                if self.backend == "nccl":
+                    flag = flag.cuda()
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                ok = int(flag.item())
+            if not ok:
+                print(f"[mfmg_amd] RCCL transport unavailable on at least one rank ({why or 'another rank'}); "
+                      f"all ranks fall back to the host transport", flush=True)
                 transport = self.transport = "host"
         if transport == "rccl":
             uid = (C.c_ubyte * 128)()

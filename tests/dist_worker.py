@@ -20,6 +20,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 
 import mfmg_amd as M  # noqa: E402
+from mfmg_amd import lib as L  # noqa: E402
 import mfmg_oracle as O  # noqa: E402
 
 PRM = {"eigensolver": {"number of eigenvectors": 2}, "agglomeration": {"nx": 2, "ny": 2, "nz": 2}}
@@ -334,6 +335,13 @@ def mode_gpu(args):
     h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", part.local_problem(material, "cuda"), params)
     deg, lmin, lmax = h.smoother_info()       # estimated with dot products summed over the ranks
     assert 1.4 < lmax < 2.2, lmax
+    # the halo spaces of the levels belong to this hierarchy: a second one on the same communicator context is refused
+    # while it lives (every rank raises before any collective of the second setup)
+    try:
+        M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", part.local_problem(material, "cuda"), params)
+        raise AssertionError("a second hierarchy on a distributed context must be refused")
+    except L.MfmgError as e:
+        assert "already carries a hierarchy" in str(e)
     # global single-process reference on the same GPU (context without communicator): the SAME parameters -- the
     # distributed hierarchy must be the same preconditioner, eigenvalue estimates included
     gctx = M.Context()
