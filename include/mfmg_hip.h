@@ -33,6 +33,14 @@
 extern "C" {
 #endif
 
+/* ABI version of this header: bumped whenever an entry point changes its signature or disappears; additions leave it.
+ *   1  rounds 1-2 up to the host-callback halo exchange (mfmg_hip_context_set_halo_buffers)
+ *   2  round 2: mfmg_hip_context_set_communicator(ctx, rank, n_ranks, ghost_low, ghost_high) replaces the old signature,
+ *      mfmg_hip_context_set_halo_buffers removed (transports: mfmg_hip_context_use_rccl / _use_host_transport)
+ *   round 3 added mfmg_hip_hierarchy_ap_apply, mfmg_hip_rccl_available, mfmg_hip_abi_version (no change of the version).
+ * mfmg_hip_abi_version() returns the value the loaded library was built with. */
+#define MFMG_HIP_ABI_VERSION 2
+
 #define MFMG_HIP_SUCCESS 0
 #define MFMG_HIP_ERROR_RUNTIME 1
 #define MFMG_HIP_ERROR_NOT_IMPLEMENTED 2
@@ -50,6 +58,7 @@ typedef struct mfmg_hip_hierarchy_s *mfmg_hip_hierarchy_t;   /* Hierarchy<Vector
 
 const char *mfmg_hip_last_error(void);
 const char *mfmg_hip_version(void);
+int mfmg_hip_abi_version(void);
 
 /* ---- context: stream + scratch (CudaHandle, source/cuda/cuda_handle.cu:17-56) ---- */
 /* `hip_stream`: a hipStream_t borrowed from the caller; NULL = the legacy default stream (what the

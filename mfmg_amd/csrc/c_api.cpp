@@ -104,7 +104,8 @@ struct mfmg_hip_hierarchy_s
 extern "C" {
 
 const char *mfmg_hip_last_error(void) { return g_last_error.c_str(); }
-const char *mfmg_hip_version(void) { return "mfmg-hip 0.1.0 (gfx950)"; }
+const char *mfmg_hip_version(void) { return "mfmg-hip 0.3.0 (gfx950)"; }
+int mfmg_hip_abi_version(void) { return MFMG_HIP_ABI_VERSION; }
 
 // ---- context -------------------------------------------------------------------
 int mfmg_hip_context_create(void *hip_stream, mfmg_hip_context_t *ctx)

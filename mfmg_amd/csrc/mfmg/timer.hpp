@@ -3,8 +3,12 @@
 // wall time accumulated per section, summary table on request.
 #pragma once
 
+#include <dlfcn.h>
+
 #include <chrono>
+#include <cstdlib>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -69,8 +73,48 @@ private:
   std::map<std::string, size_t> _order;
 };
 
+// roctx ranges around the same sections (the reference's TimerOutput sections, include/mfmg/common/hierarchy.hpp:164-271),
+// so that a `rocprofv3 --marker-trace` timeline shows "Setup: build restrictor", "Apply: fine levels", ... next to the
+// kernels.  The marker library is resolved at run time: the copy a profiler has already loaded, or -- with
+// MFMG_HIP_ROCTX=1 -- librocprofiler-sdk-roctx / libroctx64 from the ROCm installation; without either the calls are
+// two null-pointer tests.  MFMG_HIP_ROCTX=0 switches the ranges off.
+struct RoctxApi
+{
+  int (*push)(char const *) = nullptr;
+  int (*pop)() = nullptr;
+};
+inline RoctxApi const &roctx_api()
+{
+  static const RoctxApi api = [] {
+    RoctxApi a;
+    char const *env = std::getenv("MFMG_HIP_ROCTX");
+    if (env && env[0] == '0')
+      return a;
+    char const *names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+    void *lib = nullptr;
+    for (char const *n : names)
+      if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) != nullptr)
+        break;
+    if (!lib && env && env[0] == '1')
+      for (char const *n : names)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr)
+          break;
+    if (lib)
+    {
+      a.push = reinterpret_cast<int (*)(char const *)>(dlsym(lib, "roctxRangePushA"));
+      a.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+      if (!a.push || !a.pop)
+        a.push = nullptr, a.pop = nullptr;
+    }
+    return a;
+  }();
+  return api;
+}
+
 inline void timer_enter_subsection(std::shared_ptr<TimerOutput> timer, std::string const &section)
 {
+  if (roctx_api().push)
+    roctx_api().push(section.c_str());
   if (timer)
     timer->enter_subsection(section);
 }
@@ -78,5 +122,7 @@ inline void timer_leave_subsection(std::shared_ptr<TimerOutput> timer)
 {
   if (timer)
     timer->leave_subsection();
+  if (roctx_api().pop)
+    roctx_api().pop();
 }
 } // namespace mfmg

@@ -85,6 +85,7 @@ def load() -> C.CDLL:
         "mfmg_hip_context_set_communicator": (C.c_int, [vp, i32, i32, i32, i32]),
         "mfmg_hip_rccl_unique_id": (C.c_int, [vp]),
         "mfmg_hip_rccl_available": (C.c_int, []),
+        "mfmg_hip_abi_version": (C.c_int, []),
         "mfmg_hip_context_use_rccl": (C.c_int, [vp, vp]),
         "mfmg_hip_context_use_host_transport": (C.c_int, [vp, vp, vp, vp, vp]),
         "mfmg_hip_context_transport_name": (C.c_int, [vp, C.c_char_p, sz]),

@@ -33,6 +33,12 @@ def test_library_exports_every_declared_symbol(mfmg_lib):
     assert set(names) == set(mfmg_lib._declared)
 
 
+def test_abi_version_of_header_and_library_agree(mfmg_lib):
+    text = open(os.path.join(ROOT, "include", "mfmg_hip.h")).read()
+    declared = int(re.search(r"#define\s+MFMG_HIP_ABI_VERSION\s+(\d+)", text).group(1))
+    assert mfmg_lib.mfmg_hip_abi_version() == declared == 2
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a box without a GPU")
 def test_context_fails_loudly_without_gpu(mfmg_lib):
     with pytest.raises(L.MfmgDeviceError, match="no CPU fallback"):
