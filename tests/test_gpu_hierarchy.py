@@ -433,8 +433,10 @@ def test_amg_coarse_solver_parity(ctx, n_cycles, cells):
     res_o, rate, _ = O.vcycle_history(ho, mf.vmult, b, x0, n_cycles=n_hist)
     op = M.MatrixFreeLaplace(ctx, prob)
     res_g, _ = gpu_history(ctx, h, lambda y, x: op.vmult(y, x), b, x0, n_cycles=n_hist)
-    np.testing.assert_allclose(res_g, res_o, rtol=1e-9, atol=HIST_ATOL)
-    assert rate < 0.4          # (sanity band of the contraction; the parity statement is the line above)
+    np.testing.assert_allclose(res_g, res_o, rtol=HIST_TOL, atol=HIST_ATOL)     # 1e-10, BASELINE.json's tolerance
+    # contraction of the cycle with the multilevel coarse solve, measured: 0.217 (32 cells), 0.266 (64), 0.279 (128)
+    # per cycle -- a band of +15 % around the largest, so that a convergence regression of the setup shows
+    assert rate < 0.32
 
 
 def test_error_conventions(ctx):
