@@ -229,7 +229,7 @@ int mfmg_hip_csr_residual(mfmg_hip_csr_t a, const double *x, const double *b, do
  * (:65,100-119), the constrained DoFs (AffineConstraints) and the Cartesian cell size. */
 typedef struct mfmg_hip_mesh_desc
 {
-  int32_t dim;             /* 3 (2 is accepted by the assembled path only) */
+  int32_t dim;             /* 3 or 2 (2-D: the assembled path, and a plain matrix-free kernel for the small meshes of the reference tests) */
   int32_t n_cells[3];      /* cells per direction, lexicographic cell order, x fastest */
   double cell_size[3];     /* h_x, h_y, h_z (J = diag(h)) */
   int64_t n_dofs;          /* (n_cells+1) product */

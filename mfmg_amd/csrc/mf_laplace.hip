@@ -882,6 +882,133 @@ __global__ void mf_fill_dinv_kernel(T const *dinv, int Nx, int ncols, int64_t n_
 }
 } // namespace
 
+// ---- dim = 2 --------------------------------------------------------------------------------------------------
+// The reference exercises its matrix-free path in 2-D too (tests/test_hierarchy.cc:416-443, LaplaceMatrixFree<2>);
+// those meshes are small (3 to 5 global refinements), so the 2-D operator is a plain owner-computes kernel: one
+// thread per node gathers the 4 corners of its (up to) 4 cells, A_e[m][n] = sum_q c(cell, q) K[q][m][n] formed on the
+// fly from the 64 reference constants, with the same fused epilogues and the same constrained-row rule
+// (tests/laplace_matrix_free.hpp:121-156: constrained DoFs read as zero, their rows are identities).
+struct Mf2dTable
+{
+  double K[4][4][4]; // [q][m][n] (amge_structured.cpp: reference_cell_tables)
+};
+
+template <typename T>
+struct Mf2dArgs
+{
+  int32_t const *cell_dofs; // [n_cells][4]
+  T const *coef;            // [n_cells][4]
+  uint8_t const *constrained;
+  int32_t const *node_dof;  // [Nx Ny]
+  int nx, ny;
+  T const *x, *b, *dinv, *xprev;
+  T *out;
+  T alpha, beta;
+  int mode;
+};
+
+__global__ void mf2d_node_dof_kernel(int32_t const *cell_dofs, int nx, int ny, int32_t *node_dof)
+{
+  const int Nx = nx + 1, Ny = ny + 1;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Nx * Ny; t += gridDim.x * blockDim.x)
+  {
+    const int i = t % Nx, j = t / Nx;
+    const int ic = min(i, nx - 1), jc = min(j, ny - 1);
+    node_dof[t] = cell_dofs[(size_t)(ic + nx * jc) * 4 + (i - ic) + 2 * (j - jc)];
+  }
+}
+
+// every corner of every cell must be the DoF its node carries (a logically structured mesh in lexicographic cell order)
+__global__ void mf2d_validate_kernel(int32_t const *cell_dofs, int32_t const *node_dof, int nx, int ny, int64_t n_dofs, int *n_bad)
+{
+  const int Nx = nx + 1;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nx * ny; c += gridDim.x * blockDim.x)
+  {
+    const int i = c % nx, j = c / nx;
+    for (int m = 0; m < 4; ++m)
+    {
+      const int g = cell_dofs[(size_t)c * 4 + m];
+      if (g < 0 || g >= n_dofs || node_dof[(i + (m & 1)) + Nx * (j + (m >> 1))] != g)
+        atomicAdd(n_bad, 1);
+    }
+  }
+}
+
+template <typename T>
+__global__ void mf2d_diagonal_kernel(Mf2dArgs<T> a, Mf2dTable tab, T *diag, T *dinv)
+{
+  const int Nx = a.nx + 1, Ny = a.ny + 1;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Nx * Ny; t += gridDim.x * blockDim.x)
+  {
+    const int i = t % Nx, j = t / Nx;
+    const int g = a.node_dof[t];
+    double d = 0.;
+    for (int m = 0; m < 4; ++m)
+    {
+      const int ci = i - (m & 1), cj = j - (m >> 1); // the cell that has this node as its corner m
+      if (ci < 0 || ci >= a.nx || cj < 0 || cj >= a.ny)
+        continue;
+      const size_t c = (size_t)(ci + a.nx * cj);
+      for (int q = 0; q < 4; ++q)
+        d += (double)a.coef[c * 4 + q] * tab.K[q][m][m];
+    }
+    if (a.constrained[g] & 1)
+      d = 1.;
+    diag[g] = T(d);
+    dinv[g] = T(1. / d);
+  }
+}
+
+template <typename T>
+__global__ void mf2d_apply_kernel(Mf2dArgs<T> a, Mf2dTable tab)
+{
+#pragma clang fp contract(off)
+  const int Nx = a.nx + 1, Ny = a.ny + 1;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Nx * Ny; t += gridDim.x * blockDim.x)
+  {
+    const int i = t % Nx, j = t / Nx;
+    const int g = a.node_dof[t];
+    const uint8_t flag = a.constrained[g];
+    if (flag & 2)
+      continue; // owned by another rank: read, never written
+    const T x0 = a.x[g];
+    T ax = x0; // constrained rows: dst_c = src_c
+    if (!(flag & 1))
+    {
+      T sum = T(0);
+      for (int m = 0; m < 4; ++m)
+      {
+        const int ci = i - (m & 1), cj = j - (m >> 1);
+        if (ci < 0 || ci >= a.nx || cj < 0 || cj >= a.ny)
+          continue;
+        const size_t c = (size_t)(ci + a.nx * cj);
+        for (int n = 0; n < 4; ++n)
+        {
+          const int gn = a.cell_dofs[c * 4 + n];
+          const T u = (a.constrained[gn] & 1) ? T(0) : a.x[gn];
+          T e = T(0);
+          for (int q = 0; q < 4; ++q)
+            e += a.coef[c * 4 + q] * T(tab.K[q][m][n]);
+          sum += e * u;
+        }
+      }
+      ax = sum;
+    }
+    T o;
+    if (a.mode == 0)
+      o = ax;
+    else if (a.mode == 1)
+      o = ax - a.b[g];
+    else
+    {
+      const T r = ax - a.b[g];
+      const T wgt = -(a.beta * a.dinv[g]);
+      o = (a.mode == 2) ? wgt * r + x0 : wgt * r + (a.alpha * (x0 - a.xprev[g]) + x0);
+    }
+    a.out[g] = o;
+  }
+}
+
 namespace
 {
 // Mesh description of the slab of node columns i0 .. Nx-1 seen with x and y exchanged (x' = y, y' = x - i0):
@@ -917,10 +1044,15 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
                                                     bool sub_mesh)
     : _handle(handle)
 {
-  if (mesh.dim != 3)
-    ASSERT_THROW_NOT_IMPLEMENTED("the matrix-free HIP operator is implemented for dim = 3 only");
+  if (mesh.dim != 3 && mesh.dim != 2)
+    ASSERT_THROW_NOT_IMPLEMENTED("the matrix-free HIP operator is implemented for dim = 2 and dim = 3");
   ASSERT_THROW(mesh.cell_dofs && mesh.coefficient && mesh.constrained,
                "mesh description arrays must not be null");
+  if (mesh.dim == 2)
+  {
+    init_2d(mesh);
+    return;
+  }
   int64_t nd = 1, nc = 1;
   for (int d = 0; d < 3; ++d)
   {
@@ -1116,6 +1248,124 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
     if (!_tail->cell_constant_layout())
       _tail.reset(); // (cannot happen: a sub-set of cell-constant cells) both parts must run the same kernel
   }
+}
+
+template <typename T>
+void MatrixFreeLaplaceDevice<T>::init_2d(mfmg_hip_mesh_desc const &mesh)
+{
+  _dim = 2;
+  int64_t nd = 1, nc = 1;
+  for (int d = 0; d < 2; ++d)
+  {
+    ASSERT_THROW(mesh.n_cells[d] >= 1, "n_cells must be positive");
+    _n[d] = mesh.n_cells[d];
+    _N[d] = _n[d] + 1;
+    _h[d] = mesh.cell_size[d];
+    ASSERT_THROW(_h[d] > 0., "cell_size must be positive");
+    nd *= _N[d];
+    nc *= _n[d];
+  }
+  _n[2] = 0;
+  _N[2] = 1;
+  _h[2] = 1.;
+  ASSERT_THROW(nd == mesh.n_dofs, "n_dofs does not match the cell grid (Q1: (n+1)^dim)");
+  ASSERT_THROW(nd < (int64_t(1) << 30), "mesh too large");
+  _n_dofs = nd;
+  hipStream_t st = _handle.stream;
+  _cd2.resize((size_t)nc * 4);
+  _co2.resize((size_t)nc * 4);
+  _cn2.resize((size_t)nd);
+  const hipMemcpyKind kind = mesh.arrays_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  MFMG_HIP_CHECK(hipMemcpyAsync(_cd2.data(), mesh.cell_dofs, (size_t)nc * 4 * sizeof(int32_t), kind, st));
+  MFMG_HIP_CHECK(hipMemcpyAsync(_cn2.data(), mesh.constrained, (size_t)nd, kind, st));
+  {
+    // the coefficient table in the operator's precision
+    std::vector<double> co((size_t)nc * 4);
+    MFMG_HIP_CHECK(hipMemcpyAsync(co.data(), mesh.coefficient, co.size() * sizeof(double),
+                                  mesh.arrays_on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, st));
+    MFMG_HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<T> cot(co.begin(), co.end());
+    _co2.upload(cot.data(), cot.size(), st);
+  }
+  DeviceBuffer<int> bad(1);
+  MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
+  hipLaunchKernelGGL(mf_range_kernel, dim3(n_blocks_for(nc * 4, 256, 1 << 16)), dim3(256), 0, st, _cd2.data(), nc * 4, nd, bad.data());
+  MFMG_HIP_CHECK(hipGetLastError());
+  ASSERT_THROW(bad.download(st)[0] == 0, "cell_dofs is not a logically structured quad mesh in lexicographic cell "
+                                         "order (DoF ids out of range)");
+  _node_dof2.resize((size_t)nd);
+  hipLaunchKernelGGL(mf2d_node_dof_kernel, dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st, _cd2.data(), _n[0], _n[1], _node_dof2.data());
+  MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
+  hipLaunchKernelGGL(mf2d_validate_kernel, dim3(n_blocks_for(nc, 256, 1 << 16)), dim3(256), 0, st, _cd2.data(), _node_dof2.data(), _n[0], _n[1],
+                     nd, bad.data());
+  MFMG_HIP_CHECK(hipGetLastError());
+  const int n_bad = bad.download(st)[0];
+  ASSERT_THROW(n_bad == 0, "cell_dofs is not a logically structured quad mesh in lexicographic cell order (" + std::to_string(n_bad) +
+                               " inconsistent corners)");
+  // K[q][m][n] = sum_d JxW / h_d^2 dphi_m/dxi_d dphi_n/dxi_d at Gauss point q
+  const double gp[2] = {MFMG_GB, MFMG_GA};
+  const double w = _h[0] * _h[1] / 4.;
+  for (int q = 0; q < 4; ++q)
+  {
+    double G[2][4];
+    for (int m = 0; m < 4; ++m)
+      for (int d = 0; d < 2; ++d)
+      {
+        double g = 1.;
+        for (int e = 0; e < 2; ++e)
+        {
+          const int bit = (m >> e) & 1;
+          const double xi = gp[(q >> e) & 1];
+          g *= (e == d) ? (bit ? 1. : -1.) : (bit ? xi : (1. - xi));
+        }
+        G[d][m] = g;
+      }
+    for (int m = 0; m < 4; ++m)
+      for (int n = 0; n < 4; ++n)
+        _k2[(q * 4 + m) * 4 + n] = w / (_h[0] * _h[0]) * G[0][m] * G[0][n] + w / (_h[1] * _h[1]) * G[1][m] * G[1][n];
+  }
+  _diag.resize(nd);
+  _dinv.resize(nd);
+  Mf2dArgs<T> a{};
+  a.cell_dofs = _cd2.data();
+  a.coef = _co2.data();
+  a.constrained = _cn2.data();
+  a.node_dof = _node_dof2.data();
+  a.nx = _n[0];
+  a.ny = _n[1];
+  Mf2dTable tab;
+  for (int t = 0; t < 64; ++t)
+    (&tab.K[0][0][0])[t] = _k2[t];
+  hipLaunchKernelGGL((mf2d_diagonal_kernel<T>), dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st, a, tab, _diag.data(), _dinv.data());
+  MFMG_HIP_CHECK(hipGetLastError());
+  MFMG_HIP_CHECK(hipStreamSynchronize(st));
+  _compact = false;
+  _dinv_in_record = true;
+}
+
+template <typename T>
+void MatrixFreeLaplaceDevice<T>::launch_2d(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out) const
+{
+  Mf2dArgs<T> a{};
+  a.cell_dofs = _cd2.data();
+  a.coef = _co2.data();
+  a.constrained = _cn2.data();
+  a.node_dof = _node_dof2.data();
+  a.nx = _n[0];
+  a.ny = _n[1];
+  a.x = x;
+  a.b = b;
+  a.dinv = _dinv.data();
+  a.xprev = x_prev;
+  a.out = out;
+  a.alpha = alpha;
+  a.beta = beta;
+  a.mode = (int)mode;
+  Mf2dTable tab;
+  for (int t = 0; t < 64; ++t)
+    (&tab.K[0][0][0])[t] = _k2[t];
+  hipLaunchKernelGGL((mf2d_apply_kernel<T>), dim3(n_blocks_for(_n_dofs, 256, 1 << 16)), dim3(256), 0, _handle.stream, a, tab);
+  MFMG_HIP_CHECK(hipGetLastError());
 }
 
 // ---- tile choice ---------------------------------------------------------------------------------
@@ -1389,6 +1639,7 @@ void MatrixFreeLaplaceDevice<T>::launch_z_range(MfMode mode, T const *x, T const
                                                 T *out, int z_tile_begin, int z_tile_end) const
 {
   check_vectors(mode, x, b, x_prev, out);
+  ASSERT_THROW(_dim == 3, "z-tile ranges belong to the 3-D operator");
   if (mode == MfMode::next && (x_prev == nullptr || alpha == T(0)))
     mode = MfMode::first;
   int nw, ty, tz;
@@ -1408,6 +1659,13 @@ void MatrixFreeLaplaceDevice<T>::launch(MfMode mode, T const *x, T const *b, T c
                                         T beta, T *out) const
 {
   check_vectors(mode, x, b, x_prev, out);
+  if (_dim == 2)
+  {
+    if (mode == MfMode::next && (x_prev == nullptr || alpha == T(0)))
+      mode = MfMode::first;
+    launch_2d(mode, x, b, x_prev, alpha, beta, out);
+    return;
+  }
   int nw, ty, tz;
   choose_tile(nw, ty, tz);
   // bytes the layout requires per launch (mf_laplace.hpp), plus the b / D^-1 / x_prev reads of the epilogue

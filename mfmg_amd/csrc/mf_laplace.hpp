@@ -51,6 +51,7 @@ public:
   bool diagonal_in_record() const { return _dinv_in_record; }
 
   int64_t n_dofs() const { return _n_dofs; }
+  int dim() const { return _dim; }
   int dof_grid(int d) const { return _N[d]; }
   int n_cells(int d) const { return _n[d]; }
   double cell_size(int d) const { return _h[d]; }
@@ -134,6 +135,14 @@ private:
   };
   mutable ZTiling _zt_uniform, _zt_graded;
   void check_vectors(MfMode mode, T const *x, T const *b, T const *x_prev, T const *out) const;
+  // dim = 2 (mf_laplace.hip): a plain owner-computes kernel on the caller's arrays
+  void init_2d(mfmg_hip_mesh_desc const &mesh);
+  void launch_2d(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out) const;
+  int _dim = 3;
+  DeviceBuffer<int32_t> _cd2, _node_dof2;
+  DeviceBuffer<T> _co2;
+  DeviceBuffer<uint8_t> _cn2;
+  double _k2[64] = {};
   void choose_tile(int &nw, int &ty, int &tz) const;
 
   HipHandle &_handle;

@@ -931,3 +931,35 @@ def test_global_problem_of_config3_on_one_gpu(ctx):
         norms.append(ctx.l2_norm(r))
         h.apply(b, xx)
     assert all(norms[i + 1] < 0.4 * norms[i] for i in range(3)), norms
+
+
+@pytest.mark.parametrize("n,material,degree", [((8, 8), "constant", 1), ((16, 16), "linear", 3), ((32, 32), "constant", 2)])
+def test_matrix_free_hierarchy_in_two_dimensions(ctx, n, material, degree):
+    """The matrix-free evaluator on a 2-D mesh (the reference: LaplaceMatrixFree<2> behind DealIIMatrixFreeMeshEvaluator<2>,
+    tests/test_hierarchy.cc:276-330 with hierarchy_input.info's laplace.n_refinements; BASELINE.json configs[0] is the 2-D
+    unit square): own restrictor against the oracle's, R A R^T against the column-by-column product, and the 20-cycle
+    residual history to 1e-10."""
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, material)
+    con = mesh.constrained_mask()
+    mf = O.MatrixFreeLaplace(mesh, coef)
+    prob = M.LaplaceProblem(n, material, device="cuda")
+    params = base_params(smoother={"type": "Chebyshev", "degree": degree, "smoothing_range": 20.0})
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    deg, lmin, lmax = h.smoother_info()
+    R = h.restrictor().to_scipy()
+    Ro = O.build_restrictor(mesh, coef, mf.diagonal(), agg=(2, 2), n_eig=2, variant="mf", eig_mode="krylov").csr
+    assert abs(R - Ro).max() < 1e-11
+    Ac = O.galerkin_coarse_matrix(mf.vmult, R)
+    assert abs(h.coarse_operator().to_scipy() - Ac).max() < 1e-11 * abs(Ac).max()
+    p = O.ChebyshevParams(degree=degree, lambda_max=lmax, lambda_min=lmin)
+    dinv = mf.diagonal_inverse()
+    smoother = lambda b, x: O.chebyshev_smoother_apply(mf.vmult, dinv, p, b, x)
+    ho = O.TwoLevelHierarchy(mf.vmult, smoother, R, O.direct_coarse_solver(Ac), 1, False)
+    x0 = O.random_initial_guess(mesh.n_dofs, con)
+    b = np.zeros(mesh.n_dofs)
+    res_o, rate_o, _ = O.vcycle_history(ho, mf.vmult, b, x0)
+    op = M.MatrixFreeLaplace(ctx, prob)
+    res_g, _ = gpu_history(ctx, h, lambda y, x: op.vmult(y, x), b, x0)
+    np.testing.assert_allclose(res_g, res_o, rtol=HIST_TOL, atol=HIST_ATOL)
+    assert rate_o < 0.6

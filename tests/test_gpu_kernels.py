@@ -336,9 +336,44 @@ def test_mf_tail_slab_all_modes_and_renumbering(ctx, nw, ty, tz):
     assert np.array_equal(host(out, ctx), first)
 
 
+@pytest.mark.parametrize("n,material,numbering", [((8, 8), "constant", "lexicographic"), ((12, 7), "linear", "random"),
+                                                   ((33, 5), "discontinuous", "lexicographic"), ((1, 1), "constant", "lexicographic")])
+def test_mf_operator_in_two_dimensions(ctx, n, material, numbering):
+    """The matrix-free operator in 2-D (the reference runs LaplaceMatrixFree<2>, tests/test_hierarchy.cc:276-330,416-443):
+    y = A x with identity rows for the constrained DoFs, the diagonal, and every fused mode against the oracle."""
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, material)
+    ref = O.MatrixFreeLaplace(mesh, coef)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(mesh.n_dofs) if numbering == "random" else np.arange(mesh.n_dofs)
+    prob = M.LaplaceProblem(n, material, device="cuda", dof_numbering=torch.from_numpy(perm))
+    op = M.MatrixFreeLaplace(ctx, prob)
+    x, b, xp = rng.standard_normal(mesh.n_dofs), rng.random(mesh.n_dofs), rng.random(mesh.n_dofs)
+
+    def to_dof(v):
+        o = np.empty_like(v)
+        o[perm] = v
+        return o
+
+    out = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
+    op.vmult(out, dev(to_dof(x)))
+    assert relerr(host(out, ctx)[perm], ref.vmult(x)) < TOL
+    np.testing.assert_allclose(host(op.diagonal(), ctx)[perm], ref.diagonal(), rtol=1e-13)
+    dinv = ref.diagonal_inverse()
+    np.testing.assert_allclose(host(op.diagonal_inverse(), ctx)[perm], dinv, rtol=1e-13)
+    op.residual(dev(to_dof(x)), dev(to_dof(b)), out)
+    assert relerr(host(out, ctx)[perm], ref.vmult(x) - b) < TOL
+    op.smoother_step(dev(to_dof(b)), dev(to_dof(x)), dev(to_dof(xp)), 0.3, 0.45, out)
+    assert relerr(host(out, ctx)[perm], x + 0.3 * (x - xp) - 0.45 * dinv * (ref.vmult(x) - b)) < TOL
+    op.smoother_step(dev(to_dof(b)), dev(to_dof(x)), None, 0.0, 0.45, out)
+    assert relerr(host(out, ctx)[perm], x - 0.45 * dinv * (ref.vmult(x) - b)) < TOL
+
+
 def test_mf_rejects_bad_input(ctx):
-    with pytest.raises(L.MfmgNotImplementedError):
-        M.MatrixFreeLaplace(ctx, M.LaplaceProblem((8, 8), device="cuda"))        # dim = 2
+    p2 = M.LaplaceProblem((4, 4), device="cuda")
+    p2.cell_dofs[5, 2] = p2.cell_dofs[5, 3]
+    with pytest.raises(L.MfmgError, match="not a logically structured"):
+        M.MatrixFreeLaplace(ctx, p2)
     p = M.LaplaceProblem((3, 3, 3), device="cuda")
     p.cell_dofs[5, 2] = p.cell_dofs[5, 3]
     with pytest.raises(L.MfmgError, match="not a logically structured"):
