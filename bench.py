@@ -82,7 +82,7 @@ def smoother_coefficients(degree, lmin, lmax):
     return out
 
 
-def committed_traffic(cells, degree, compact, tile, prefix="cells"):
+def committed_traffic(cells, degree, compact, tile, prefix="cells", want_source=False):
     """HBM bytes per launch of the operator kernel from the PMC passes committed under profiles/ (2 x FETCH_SIZE
     + WRITE_SIZE, MI355X_MICROARCH.md): counters need rocprofv3 around the process, so this is not a live reading.
     The file is keyed on the workload AND the tile; anything else returns None."""
@@ -93,6 +93,8 @@ def committed_traffic(cells, degree, compact, tile, prefix="cells"):
         d = json.load(f)
     key = f"{prefix}{cells}_degree{degree}_{'cell_constant' if compact else 'general'}_tile{'x'.join(str(v) for v in tile)}"
     e = d.get(key)
+    if want_source:
+        return (e.get("traffic_bytes_per_launch"), f"{e.get('source')}; {e.get('date')}") if e else (None, None)
     return e.get("traffic_bytes_per_launch") if e else None
 
 
@@ -623,6 +625,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (None if assembled else committed_traffic(args.cells, args.degree, compact, mf_tile)),
+                "traffic_source": (None if assembled else
+                                   committed_traffic(args.cells, args.degree, compact, mf_tile, want_source=True)[1]),
                 "priced_on": "bytes the data layout requires per launch (x, out, one id, coefficients, b, x_prev, and D^-1 where the "
                              "layout stores it: eight coefficients per cell); "
                              "halo re-reads of the tiling are waste and not counted",
@@ -640,7 +644,7 @@ def main():
             "other_kernels": {
                 "csr_spmv_kernel": {"what": "coarse-level family: A_c and the levels below, R, R^T, prolongators (table-driven "
                                             "layouts read no matrix values, so no byte rate is quoted; HBM bytes per launch "
-                                            "from the PMC passes: profiles/r01_k_cycle_hbm_bytes_per_launch.txt)",
+                                            "from the PMC passes: profiles/r03_d_cycle_hbm_bytes_per_launch.txt)",
                                     "launches": c_launches, "total_ms": c_ms,
                                     "share_of_step_time": (c_ms / (ms_per_step * (other_cycles or args.steps))) if c_ms else None,
                                     "timed_in": (f"{other_cycles} extra cycles after the timed region" if other_cycles
@@ -685,6 +689,11 @@ def main():
                 # cell, every coarse-operator row and restrictor block stored): what a variable coefficient gets
                 gen = measure_vcycle_small(ctx, torch, M, args.cells, params, material="linear")
                 gen["smoother_apply"] = measure_smoother(ctx, torch, M, args.cells + 1, args.degree, material="linear")
+                # the same with the setup's matrices rounded to float ("setup value precision" float: the stored blocks of R,
+                # R A R^T and the aggregation hierarchy take half the bytes; arithmetic FP64; the cycle is the exact cycle of
+                # the rounded matrices -- tests/test_gpu_hierarchy.py::test_setup_value_precision_float)
+                gen["setup_value_precision_float"] = measure_vcycle_small(
+                    ctx, torch, M, args.cells, dict(params, **{"setup value precision": "float"}), material="linear")
                 out["general_coefficient"] = gen
                 out["vcycle_128cubed_config1"] = measure_vcycle_small(ctx, torch, M, 128, params)
                 out["smoother_apply_256cubed_f32_config5"] = measure_smoother_f32(ctx, torch, M, 256, args.degree)

@@ -199,6 +199,10 @@ int mfmg_hip_csr_set_regular_rows(mfmg_hip_csr_t a, int enable);
 /* Of the rows that are not regular: n_classes stencils that groups of nodes share among themselves (the shells
  * next to the boundary; evaluated from per-class tables) and listed_rows rows left to the stored values. */
 int mfmg_hip_csr_stencil_classes(mfmg_hip_csr_t a, int *n_classes, int64_t *listed_rows);
+/* 1 when the values the kernels read (block-diagonal planes; the agglomerate-wise planes of a restrictor) are kept in
+ * float: every one of them is representable in it -- a hierarchy built with "setup value precision" float -- so the
+ * storage is lossless; products and sums stay FP64. */
+int mfmg_hip_csr_float_storage(mfmg_hip_csr_t a, int *in_float);
 /* SparseMatrixDevice::vmult  (…templates.cuh:351-371): y = A x */
 int mfmg_hip_csr_vmult(mfmg_hip_csr_t a, const double *x, double *y);
 /* CudaMatrixOperator::apply (source/cuda/cuda_matrix_operator.cu:80-91); TRANS uses the

@@ -196,6 +196,12 @@ class SparseMatrixDevice:
         check(self._lib.mfmg_hip_csr_stencil_classes(self.handle, C.byref(k), C.byref(r)))
         return k.value, r.value
 
+    def float_storage(self) -> bool:
+        """The values the kernels read are kept in float (all representable in it: lossless)."""
+        v = C.c_int()
+        check(self._lib.mfmg_hip_csr_float_storage(self.handle, C.byref(v)))
+        return bool(v.value)
+
     def set_regular_rows(self, enable: bool):
         check(self._lib.mfmg_hip_csr_set_regular_rows(self.handle, int(bool(enable))))
 

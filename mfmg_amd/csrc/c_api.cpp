@@ -529,6 +529,15 @@ int mfmg_hip_csr_stencil_classes(mfmg_hip_csr_t a, int *n_classes, int64_t *list
     *listed_rows = a->op->get_matrix()->listed_rows();
   });
 }
+int mfmg_hip_csr_float_storage(mfmg_hip_csr_t a, int *in_float)
+{
+  return guarded([&] {
+    require(a && in_float, "null argument");
+    auto op = a->op;
+    // block-diagonal planes of the matrix, or -- for a restrictor with its agglomerate-wise form -- its planes
+    *in_float = (op->get_matrix()->float_storage() || op->structured_float_planes()) ? 1 : 0;
+  });
+}
 int mfmg_hip_csr_set_regular_rows(mfmg_hip_csr_t a, int enable)
 {
   return guarded([&] {

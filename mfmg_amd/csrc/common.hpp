@@ -341,6 +341,10 @@ struct HipHandle
   // R A R^T of a matrix-free A by probing on the device (hip_hierarchy.hip, HipMatrixOperator::multiply) instead of
   // the host triple product
   bool galerkin_on_device = true;
+  // "setup value precision" float (parameter of the hierarchy): the matrices the setup forms -- R, R A R^T, the
+  // prolongators and operators of the aggregation hierarchy -- are rounded to float-representable values when they are
+  // assembled; the layouts then keep them in float (half the bytes per application), arithmetic stays FP64
+  bool setup_values_float = false;
   // scratch for two-stage deterministic reductions
   DeviceBuffer<double> reduce_partials;
   DeviceBuffer<double> reduce_result;

@@ -1224,6 +1224,21 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
   const double t_r0 = now();
   HostCsr R = build_restrictor_structured(hip_mesh_evaluator->get_mesh(), global_diag, opts, &_grid_hint.node_of_row,
                                           _grid_hint.dims, where == "device" ? &_handle : nullptr);
+  // "setup value precision" float | double (default): round the matrices of the setup to float-representable values
+  // (R here; R A R^T and the aggregation hierarchy where they are assembled: probe_assembly.hip).  The hierarchy is then
+  // the exact FP64 cycle of the ROUNDED matrices -- what get_restrictor / get_coarse_operator hand out -- and the stored
+  // blocks of a variable-coefficient problem take half the bytes.  It applies to the device setup by probing.
+  {
+    std::string const prec = to_lower(params->get("setup value precision", "double"));
+    ASSERT_THROW(prec == "double" || prec == "float", "\"setup value precision\" must be double or float");
+    _handle.setup_values_float = prec == "float";
+    if (_handle.setup_values_float)
+    {
+#pragma omp parallel for schedule(static)
+      for (int64_t p = 0; p < (int64_t)R.val.size(); ++p)
+        R.val[p] = (double)(float)R.val[p];
+    }
+  }
   const double t_r1 = now();
   // component of a coarse row = its position among the eigenvectors of its agglomerate
   _grid_hint.component_of_row.resize(_grid_hint.node_of_row.size());

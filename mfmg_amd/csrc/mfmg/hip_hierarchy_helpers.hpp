@@ -137,6 +137,7 @@ public:
   // stays for the setup algebra and for get_restrictor
   void set_structured(std::shared_ptr<StructuredRestrictorDevice> s) { _structured = std::move(s); }
   bool has_structured() const { return _structured != nullptr; }
+  bool structured_float_planes() const { return _structured != nullptr && _structured->float_planes(); }
   // b_c = R (A x - b) in one pass (structured_restrictor.hpp): probes the rows of R A for `a`, checks the result against
   // residual + restriction on a random pair of vectors and keeps it only if the two agree to rounding
   bool prepare_residual_restriction(std::shared_ptr<Operator<DVector> const> a);

@@ -68,6 +68,7 @@ struct GalerkinGeom
 {
   int na[3], ne, k[3];
   int64_t zoff, z_own0, z_own1, nc;
+  int round_to_float; // values rounded to float-representable doubles ("setup value precision" float)
 };
 
 template <bool FILL>
@@ -95,7 +96,21 @@ __global__ void galerkin_rows_kernel(GalerkinGeom g, double const *Y, int32_t *r
               for (int e2 = 0; e2 < g.ne; ++e2, ++p)
               {
                 col[p] = (int32_t)(b * g.ne + e2);
-                val[p] = Y[(size_t)(oc * g.ne + e2) * (size_t)g.nc + (size_t)r];
+                double v = Y[(size_t)(oc * g.ne + e2) * (size_t)g.nc + (size_t)r];
+                if (g.round_to_float)
+                {
+                  // (the product is symmetric to rounding; an entry and its transposed partner must round to the SAME float,
+                  // or the symmetric-half storage is lost: both are replaced by their mean first -- one rank only, where
+                  // every row is computed here)
+                  if (g.z_own0 == 0 && g.z_own1 == g.na[2])
+                  {
+                    const int ocr = (ax % g.k[0]) + g.k[0] * ((ay % g.k[1]) + g.k[1] * (int)((az + g.zoff) % g.k[2]));
+                    const double vt = Y[(size_t)(ocr * g.ne + (int)(r % g.ne)) * (size_t)g.nc + (size_t)(b * g.ne + e2)];
+                    v = 0.5 * (v + vt);
+                  }
+                  v = (double)(float)v;
+                }
+                val[p] = v;
               }
             }
             else
@@ -112,6 +127,7 @@ struct ProlongatorGeom
   int fdims[3], cdims[3], gdims_c[3], C, blk, reach, period[3];
   int64_t f_global_begin, c_global_begin, row0, n_own;
   double w;
+  int round_to_float;
 };
 
 template <bool FILL>
@@ -140,7 +156,8 @@ __global__ void prolongator_rows_kernel(ProlongatorGeom g, double const *Z, doub
           {
             const double ay = Z[(size_t)(oc * g.C + comp) * (size_t)g.n_own + (size_t)q];
             const double yi = (own_agg && comp == (int)(i % g.C)) ? t[i] : 0.;
-            const double v = yi - g.w * dinv[i] * ay;
+            const double v0 = yi - g.w * dinv[i] * ay;
+            const double v = g.round_to_float ? (double)(float)v0 : v0;
             if (v != 0.)
             {
               if (FILL)
@@ -162,6 +179,7 @@ struct CoarseGeom
 {
   int cdims[3], gdims_c[3], C, reach, period[3];
   int64_t c_global_begin, crow0, cn_own;
+  int round_to_float;
 };
 
 template <bool FILL>
@@ -182,7 +200,19 @@ __global__ void coarse_rows_kernel(CoarseGeom g, double const *Y, int32_t *row_p
           const int64_t Kl = K - g.c_global_begin;
           for (int comp = 0; comp < g.C; ++comp)
           {
-            const double v = Y[(size_t)(oc * g.C + comp) * (size_t)g.cn_own + (size_t)q];
+            double v = Y[(size_t)(oc * g.C + comp) * (size_t)g.cn_own + (size_t)q];
+            if (g.round_to_float)
+            {
+              if (g.crow0 == 0 && g.c_global_begin == 0 && g.cn_own == (int64_t)g.cdims[0] * g.cdims[1] * g.cdims[2] * g.C)
+              {
+                // symmetric to rounding: an entry and its transposed partner are replaced by their mean (see above)
+                const int ocr = (X % g.period[0]) + g.period[0] * ((Yc % g.period[1]) + g.period[1] * (int)(Zg % g.period[2]));
+                const int64_t cr = (((int64_t)Kl * g.cdims[1] + J) * g.cdims[0] + I) * g.C + comp;
+                const double vt = Y[(size_t)(ocr * g.C + (int)(r % g.C)) * (size_t)g.cn_own + (size_t)cr];
+                v = 0.5 * (v + vt);
+              }
+              v = (double)(float)v;
+            }
             if (v != 0.)
             {
               if (FILL)
@@ -223,6 +253,7 @@ std::shared_ptr<SparseMatrixDevice<double>> galerkin_from_probes(HipHandle &h, i
                                                                  int64_t z_own0, int64_t z_own1, double const *Y)
 {
   GalerkinGeom g;
+  g.round_to_float = h.setup_values_float ? 1 : 0;
   for (int d = 0; d < 3; ++d)
   {
     g.na[d] = na[d];
@@ -248,6 +279,7 @@ std::shared_ptr<SparseMatrixDevice<double>> prolongator_from_probes(HipHandle &h
                                                                     double const *t, double const *dinv)
 {
   ProlongatorGeom g;
+  g.round_to_float = h.setup_values_float ? 1 : 0;
   for (int d = 0; d < 3; ++d)
   {
     g.fdims[d] = fdims[d];
@@ -279,6 +311,7 @@ std::shared_ptr<SparseMatrixDevice<double>> coarse_operator_from_probes(HipHandl
                                                                         int64_t crow0, int64_t cn_own, double const *Y)
 {
   CoarseGeom g;
+  g.round_to_float = h.setup_values_float ? 1 : 0;
   for (int d = 0; d < 3; ++d)
   {
     g.cdims[d] = cdims[d];

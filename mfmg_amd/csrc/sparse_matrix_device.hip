@@ -250,8 +250,9 @@ __global__ void csr_row_ratio_kernel(T const *val, int32_t const *col, int32_t c
 // block column, val[(d C + cc) n_rows + r], so a wavefront reads 512 contiguous bytes per request and the
 // matrix stream carries no column indices at all (8 B per stored entry instead of 10-12); x is read
 // through L1/L2 (consecutive rows read consecutive entries).  One thread per row, fixed summation order.
-template <typename T, int C>
-__global__ __launch_bounds__(256) void bdia_spmv_kernel(CsrArgs<T> a, T const *val, int32_t const *offs, int D,
+// (V: storage type of the planes -- T, or float where every value is representable in it: half the bytes, sums in T)
+template <typename T, int C, typename V = T>
+__global__ __launch_bounds__(256) void bdia_spmv_kernel(CsrArgs<T> a, V const *val, int32_t const *offs, int D,
                                                         int32_t const *rows, int64_t n_listed)
 {
   // rows != nullptr: only the listed rows (the others are regular, bdia_regular_node_kernel has them)
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void bdia_spmv_kernel(CsrArgs<T> a, T const *v
   const int64_t r = rows != nullptr ? (int64_t)rows[t] : t;
   const int64_t n_nodes = a.n_rows / C;
   const int64_t node = r / C;
-  T const *vp = val + r;
+  V const *vp = val + r;
   const size_t stride = (size_t)a.n_rows;
   T sum = T(0);
 #pragma unroll 4
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void bdia_spmv_kernel(CsrArgs<T> a, T const *v
     {
 #pragma unroll
       for (int cc = 0; cc < C; ++cc)
-        sum += vp[(size_t)(d * C + cc) * stride] * a.x[nb * C + cc];
+        sum += T(vp[(size_t)(d * C + cc) * stride]) * a.x[nb * C + cc];
     }
   }
   const int64_t row = r;
@@ -626,8 +627,8 @@ __global__ __launch_bounds__(256) void csr_listed_rows_kernel(CsrArgs<T> a, int3
 // (256 consecutive rows): four times the wavefronts, each with a quarter of the dependent loads; no branches
 // around the loads (a neighbour outside the matrix is read at a clamped position and its entry replaced by 0), the
 // quarters are added in a fixed order through LDS.
-template <typename T, int C>
-__global__ __launch_bounds__(1024) void bdia_sym_split_kernel(CsrArgs<T> a, T const *val, int32_t const *offs, int D)
+template <typename T, int C, typename V = T>
+__global__ __launch_bounds__(1024) void bdia_sym_split_kernel(CsrArgs<T> a, V const *val, int32_t const *offs, int D)
 {
   __shared__ T part[3][256];
   const int q = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)), lane = threadIdx.x & 255;
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(1024) void bdia_sym_split_kernel(CsrArgs<T> a, T co
   const int64_t node = rr / C;
   const int c = (int)(rr - node * C);
   const size_t stride = (size_t)a.n_rows;
-  T const *vp = val + rr;
+  V const *vp = val + rr;
   const int d0 = (D * q) / 4, d1 = (D * (q + 1)) / 4;
   T sum = T(0);
 #pragma unroll 4
@@ -647,17 +648,17 @@ __global__ __launch_bounds__(1024) void bdia_sym_split_kernel(CsrArgs<T> a, T co
     const int64_t nb = min(node + offs[d], last);
 #pragma unroll
     for (int cc = 0; cc < C; ++cc)
-      sum += vp[(size_t)(d * C + cc) * stride] * a.x[nb * C + cc];
+      sum += T(vp[(size_t)(d * C + cc) * stride]) * a.x[nb * C + cc];
   }
 #pragma unroll 4
   for (int d = max(d0, 1); d < d1; ++d)
   {
     const int64_t nbu = node - offs[d];
     const int64_t nb = max(nbu, (int64_t)0);
-    T const *vq = val + (size_t)(d * C + c) * stride + nb * C;
+    V const *vq = val + (size_t)(d * C + c) * stride + nb * C;
 #pragma unroll
     for (int cc = 0; cc < C; ++cc)
-      sum += (nbu >= 0 ? vq[cc] : T(0)) * a.x[nb * C + cc];
+      sum += (nbu >= 0 ? T(vq[cc]) : T(0)) * a.x[nb * C + cc];
   }
   if (q > 0)
     part[q - 1][lane] = sum;
@@ -666,8 +667,8 @@ __global__ __launch_bounds__(1024) void bdia_sym_split_kernel(CsrArgs<T> a, T co
     store_row(a, r, ((sum + part[0][lane]) + part[1][lane]) + part[2][lane]);
 }
 
-template <typename T, int C>
-__global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, T const *val, int32_t const *offs, int D,
+template <typename T, int C, typename V = T>
+__global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, V const *val, int32_t const *offs, int D,
                                                             BdiaRegular<T> g)
 {
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, T cons
   const int64_t node = r / C;
   const int c = (int)(r - node * C);
   const size_t stride = (size_t)a.n_rows;
-  T const *vp = val + r;
+  V const *vp = val + r;
   T sum = T(0);
 #pragma unroll 4
   for (int d = 0; d < D; ++d) // offs[0] = 0 < offs[1] < ...
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, T cons
     {
 #pragma unroll
       for (int cc = 0; cc < C; ++cc)
-        sum += vp[(size_t)(d * C + cc) * stride] * a.x[nb * C + cc];
+        sum += T(vp[(size_t)(d * C + cc) * stride]) * a.x[nb * C + cc];
     }
   }
 #pragma unroll 4
@@ -698,10 +699,10 @@ __global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, T cons
     const int64_t nb = node - offs[d];
     if (nb >= 0)
     {
-      T const *vq = val + (size_t)(d * C + c) * stride + nb * C;
+      V const *vq = val + (size_t)(d * C + c) * stride + nb * C;
 #pragma unroll
       for (int cc = 0; cc < C; ++cc)
-        sum += vq[cc] * a.x[nb * C + cc];
+        sum += T(vq[cc]) * a.x[nb * C + cc];
     }
   }
   const int64_t row = r;
@@ -965,6 +966,21 @@ __global__ void nodecls_same_kernel(int64_t n_nodes, size_t tuple, T const *tv, 
       eq = tv[(size_t)nd * tuple + k] == tv[(size_t)rp * tuple + k];
     same[nd] = eq ? 1 : 0;
   }
+}
+
+// *flag is raised by a value that a float does not hold exactly
+template <typename T>
+__global__ void not_float_kernel(T const *v, int64_t n, int *flag)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if ((T)(float)v[i] != v[i])
+      atomicOr(flag, 1);
+}
+template <typename T>
+__global__ void narrow_kernel(T const *v, int64_t n, float *out)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (float)v[i];
 }
 
 constexpr size_t kMaxBlockDiagonals = 400; // (343: the third level of the aggregation hierarchy of a Q1 problem)
@@ -1582,6 +1598,23 @@ void SparseMatrixDevice<T>::build_block_diagonals()
   }
   _bdia_c = c;
   _use_bdia = true;
+  // planes whose values are all representable in float (a setup that rounds its matrices: "setup value precision"
+  // float) are kept in float: half the bytes per application, the same products and sums in T
+  if constexpr (sizeof(T) == 8)
+  {
+    const int64_t n_val = (int64_t)_bdia_val.size();
+    MFMG_HIP_CHECK(hipMemsetAsync(d_flag.data(), 0, sizeof(int), st));
+    hipLaunchKernelGGL(not_float_kernel<T>, blocks(n_val), dim3(256), 0, st, _bdia_val.data(), n_val, d_flag.data());
+    MFMG_HIP_CHECK(hipGetLastError());
+    if (n_val > 0 && d_flag.download(st)[0] == 0)
+    {
+      _bdia_val_f32.resize((size_t)n_val);
+      hipLaunchKernelGGL(narrow_kernel<T>, blocks(n_val), dim3(256), 0, st, _bdia_val.data(), n_val, _bdia_val_f32.data());
+      MFMG_HIP_CHECK(hipGetLastError());
+      MFMG_HIP_CHECK(hipStreamSynchronize(st));
+      _bdia_val.release();
+    }
+  }
 }
 
 // Node classes for rectangular stencil-like matrices (the smoothed prolongators of the aggregation hierarchy and
@@ -2042,67 +2075,43 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
       }
     }
     const dim3 rgrid((unsigned int)(((g.exc != nullptr ? g.n_exc : _n_rows) + 255) / 256));
-    if (_bdia_sym && g.exc == nullptr)
-    {
-      const dim3 sgrid((unsigned int)((_n_rows + 255) / 256));
+    // the stored planes: in T, or in float where every value is representable in it (half the bytes, sums in T)
+    auto stored = [&](auto const *planes, auto cc) {
+      using V = std::remove_cv_t<std::remove_pointer_t<decltype(planes)>>;
+      constexpr int C = decltype(cc)::value;
+      if (_bdia_sym && g.exc == nullptr)
+        hipLaunchKernelGGL((bdia_sym_split_kernel<T, C, V>), dim3((unsigned int)((_n_rows + 255) / 256)), dim3(1024), 0, st, a, planes, of,
+                           _bdia_d);
+      else if (_bdia_sym)
+      {
+        if (rgrid.x > 0)
+          hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, C, V>), rgrid, dim3(256), 0, st, a, planes, of, _bdia_d, g);
+      }
+      else if (rgrid.x > 0)
+        hipLaunchKernelGGL((bdia_spmv_kernel<T, C, V>), rgrid, dim3(256), 0, st, a, planes, of, _bdia_d,
+                           g.exc != nullptr ? g.exc_rows : nullptr, g.n_exc);
+    };
+    auto stored_c = [&](auto const *planes) {
       switch (_bdia_c)
       {
       case 1:
-        hipLaunchKernelGGL((bdia_sym_split_kernel<T, 1>), sgrid, dim3(1024), 0, st, a, dv, of, _bdia_d);
+        stored(planes, std::integral_constant<int, 1>());
         break;
       case 2:
-        hipLaunchKernelGGL((bdia_sym_split_kernel<T, 2>), sgrid, dim3(1024), 0, st, a, dv, of, _bdia_d);
+        stored(planes, std::integral_constant<int, 2>());
         break;
       case 3:
-        hipLaunchKernelGGL((bdia_sym_split_kernel<T, 3>), sgrid, dim3(1024), 0, st, a, dv, of, _bdia_d);
+        stored(planes, std::integral_constant<int, 3>());
         break;
       default:
-        hipLaunchKernelGGL((bdia_sym_split_kernel<T, 4>), sgrid, dim3(1024), 0, st, a, dv, of, _bdia_d);
+        stored(planes, std::integral_constant<int, 4>());
         break;
       }
-      KernelProfiler::end(stop, st);
-      MFMG_HIP_CHECK(hipGetLastError());
-      return;
-    }
-    if (_bdia_sym)
-    {
-      if (rgrid.x > 0)
-      switch (_bdia_c)
-      {
-      case 1:
-        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 1>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
-        break;
-      case 2:
-        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 2>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
-        break;
-      case 3:
-        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 3>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
-        break;
-      default:
-        hipLaunchKernelGGL((bdia_sym_spmv_kernel<T, 4>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, g);
-        break;
-      }
-      KernelProfiler::end(stop, st);
-      MFMG_HIP_CHECK(hipGetLastError());
-      return;
-    }
-    int32_t const *rows = g.exc != nullptr ? g.exc_rows : nullptr;
-    if (rgrid.x > 0)
-    switch (_bdia_c)
-    {
-    case 1:
-      hipLaunchKernelGGL((bdia_spmv_kernel<T, 1>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, rows, g.n_exc);
-      break;
-    case 2:
-      hipLaunchKernelGGL((bdia_spmv_kernel<T, 2>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, rows, g.n_exc);
-      break;
-    case 3:
-      hipLaunchKernelGGL((bdia_spmv_kernel<T, 3>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, rows, g.n_exc);
-      break;
-    default:
-      hipLaunchKernelGGL((bdia_spmv_kernel<T, 4>), rgrid, dim3(256), 0, st, a, dv, of, _bdia_d, rows, g.n_exc);
-      break;
-    }
+    };
+    if (_bdia_val_f32.size() > 0)
+      stored_c(_bdia_val_f32.data());
+    else
+      stored_c(dv);
     KernelProfiler::end(stop, st);
     MFMG_HIP_CHECK(hipGetLastError());
     return;

@@ -112,7 +112,7 @@ public:
       _lanes_per_row = lanes_per_row;
     if (use_lds >= 0)
     {
-      _use_bdia = (use_lds == 2 || use_lds == 3) && _bdia_val.size() > 0;
+      _use_bdia = (use_lds == 2 || use_lds == 3) && (_bdia_val.size() > 0 || _bdia_val_f32.size() > 0);
       _use_rowbase = (use_lds == 4) && _rb_val.size() > 0;
       _use_nodecls = (use_lds == 5) && _nc_nodes.size() > 0;
       _use_lds = (use_lds == 1) && _lcol.size() > 0;
@@ -124,6 +124,7 @@ public:
   }
   int block_diagonals() const { return _use_bdia ? _bdia_d : 0; }
   bool symmetric_storage() const { return _use_bdia && _bdia_sym; }
+  bool float_storage() const { return _use_bdia && _bdia_val_f32.size() > 0; }
   bool regular_rows() const
   {
     return _use_regular && ((_use_bdia && _bdia_regular) || _use_nodecls);
@@ -187,6 +188,7 @@ private:
   bool _bdia_all_in_classes = false; // small matrices: the regular nodes are one of the classes (no launch of their own)
   int _bdia_c = 0, _bdia_d = 0;
   DeviceBuffer<T> _bdia_val;
+  DeviceBuffer<float> _bdia_val_f32; // ... or these, when every value is representable in float (see the .hip file)
   DeviceBuffer<int32_t> _bdia_offs;
   DeviceBuffer<T> _val;
   DeviceBuffer<int32_t> _col;

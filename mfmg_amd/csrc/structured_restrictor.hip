@@ -22,6 +22,7 @@ namespace
 struct SrArgs
 {
   double const *planes;
+  float const *planes_f; // the same planes kept in float (every value representable in it); then `planes` is null
   int32_t const *node_dof; // nullptr: identity
   int64_t n_coarse;
   int N[3], na[3], a[3];
@@ -36,6 +37,21 @@ struct SrArgs
   double const *class_table; // [class][patch][n_eig]
 };
 
+// plane entry / pair of plane entries (the two eigenvectors of an agglomerate) from whichever storage the planes have
+__device__ __forceinline__ double sr_plane(SrArgs const &s, size_t idx)
+{
+  return s.planes_f != nullptr ? (double)s.planes_f[idx] : s.planes[idx];
+}
+__device__ __forceinline__ double2 sr_plane_pair(SrArgs const &s, size_t pair_idx)
+{
+  if (s.planes_f != nullptr)
+  {
+    const float2 v = reinterpret_cast<float2 const *>(s.planes_f)[pair_idx];
+    return make_double2((double)v.x, (double)v.y);
+  }
+  return reinterpret_cast<double2 const *>(s.planes)[pair_idx];
+}
+
 __global__ __launch_bounds__(256) void sr_restrict_kernel(SrArgs s, double const *x, double *y)
 {
   const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -44,7 +60,6 @@ __global__ __launch_bounds__(256) void sr_restrict_kernel(SrArgs s, double const
   const int64_t ag = r / s.n_eig;
   const int ai = ag % s.na[0], aj = (ag / s.na[0]) % s.na[1], ak = ag / ((int64_t)s.na[0] * s.na[1]);
   const int64_t base = (int64_t)ai * s.a[0] + (int64_t)s.N[0] * ((int64_t)aj * s.a[1] + (int64_t)s.N[1] * ((int64_t)ak * s.a[2]));
-  double const *p = s.planes + r;
   double sum = 0.;
   int m = 0;
   for (int mz = 0; mz <= s.a[2]; ++mz)
@@ -56,7 +71,7 @@ __global__ __launch_bounds__(256) void sr_restrict_kernel(SrArgs s, double const
       {
         const int64_t node = row + mx;
         const int64_t id = s.node_dof ? (int64_t)s.node_dof[node] : node;
-        sum += p[(size_t)m * s.n_coarse] * x[id];
+        sum += sr_plane(s, (size_t)m * s.n_coarse + r) * x[id];
       }
     }
   y[r] = sum;
@@ -78,7 +93,6 @@ __global__ __launch_bounds__(256) void sr_restrict_pair_kernel(SrArgs s, double 
     return;
   const int ai = ag % s.na[0], aj = (ag / s.na[0]) % s.na[1], ak = ag / ((int64_t)s.na[0] * s.na[1]);
   const int64_t base = (int64_t)ai * a0 + (int64_t)s.N[0] * ((int64_t)aj * a1 + (int64_t)s.N[1] * ((int64_t)ak * a2));
-  double2 const *p = reinterpret_cast<double2 const *>(s.planes) + ag;
   const size_t stride = (size_t)s.n_coarse / 2;
   const bool regular = s.exc != nullptr && s.exc[ag] == 0;
   // a block shared with other agglomerates comes from the class table (cached) instead of the planes (HBM)
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(256) void sr_restrict_pair_kernel(SrArgs s, double 
 #pragma unroll
       for (int m = 0; m < 27; ++m)
       {
-        const double2 pv = p[(size_t)m * stride];
+        const double2 pv = sr_plane_pair(s, (size_t)m * stride + ag);
         sum0 += pv.x * xv[m];
         sum1 += pv.y * xv[m];
       }
@@ -143,7 +157,7 @@ __global__ __launch_bounds__(256) void sr_restrict_pair_kernel(SrArgs s, double 
           else if (cl != 0xffffu)
             pv = ct[m];
           else
-            pv = p[(size_t)m * stride];
+            pv = sr_plane_pair(s, (size_t)m * stride + ag);
           const double xv = x[id];
           sum0 += pv.x * xv;
           sum1 += pv.y * xv;
@@ -189,7 +203,7 @@ __device__ __forceinline__ double sr_node_value(SrArgs const &s, double const *y
           continue;
         const int64_t ag = ax[cx] + (int64_t)s.na[0] * (ay[cy] + (int64_t)s.na[1] * az[cz]);
         const int m = mx[cx] + px * (my[cy] + py * mz[cz]);
-        double const *p = s.planes + (size_t)m * s.n_coarse + ag * s.n_eig;
+        const size_t p0 = (size_t)m * s.n_coarse + ag * s.n_eig;
         double const *yy = y + ag * s.n_eig;
         if (s.n_eig == 2)
         {
@@ -202,14 +216,14 @@ __device__ __forceinline__ double sr_node_value(SrArgs const &s, double const *y
           {
             const unsigned int cl = s.cls != nullptr ? s.cls[ag] : 0xffffu;
             pv = cl != 0xffffu ? reinterpret_cast<double2 const *>(s.class_table)[(size_t)cl * s.patch + m]
-                               : *reinterpret_cast<double2 const *>(p);
+                               : sr_plane_pair(s, p0 / 2);
           }
           sum += pv.x * yv.x;
           sum += pv.y * yv.y;
         }
         else
           for (int e = 0; e < s.n_eig; ++e)
-            sum += p[e] * yy[e];
+            sum += sr_plane(s, p0 + e) * yy[e];
       }
     }
   }
@@ -400,7 +414,23 @@ StructuredRestrictorDevice::create(HipHandle &handle, StructuredMesh const &mesh
   s->_n_fine = mesh.n_dofs;
   s->_nnz = R.row_ptr[R.n_rows];
   s->_identity_numbering = identity;
-  s->_planes.upload(planes.data(), planes.size(), handle.stream);
+  {
+    // planes whose values a float holds exactly ("setup value precision" float rounds R) are kept in float
+    bool all_float = !planes.empty();
+#pragma omp parallel for schedule(static) reduction(&& : all_float)
+    for (int64_t q = 0; q < (int64_t)planes.size(); ++q)
+      all_float = all_float && (double)(float)planes[q] == planes[q];
+    if (all_float && n_eig % 2 == 0)
+    {
+      std::vector<float> pf(planes.size());
+#pragma omp parallel for schedule(static)
+      for (int64_t q = 0; q < (int64_t)planes.size(); ++q)
+        pf[q] = (float)planes[q];
+      s->_planes_f32.upload(pf.data(), pf.size(), handle.stream);
+    }
+    else
+      s->_planes.upload(planes.data(), planes.size(), handle.stream);
+  }
   if (n_eig == 2 && identity && agglomerate[0] == 2 && agglomerate[1] == 2 && agglomerate[2] == 2)
   {
     // class of EVERY agglomerate by the bits of its block (for the residual restriction, residual_restriction.hip);
@@ -625,12 +655,13 @@ double StructuredRestrictorDevice::algorithmic_bytes() const
 
 namespace
 {
-SrArgs make_args(double const *planes, int32_t const *node_dof, int64_t n_coarse, int const N[3], int const na[3],
+SrArgs make_args(double const *planes, float const *planes_f, int32_t const *node_dof, int64_t n_coarse, int const N[3], int const na[3],
                  int const a[3], int n_eig, int patch, uint8_t const *exc, uint8_t const *exc_node, double const *table,
                  uint16_t const *cls, double const *class_table)
 {
   SrArgs s;
   s.planes = planes;
+  s.planes_f = planes_f;
   s.node_dof = node_dof;
   s.n_coarse = n_coarse;
   for (int d = 0; d < 3; ++d)
@@ -653,7 +684,7 @@ SrArgs make_args(double const *planes, int32_t const *node_dof, int64_t n_coarse
 void StructuredRestrictorDevice::restrict_to_coarse(double const *x, double *y) const
 {
   ASSERT_THROW(x != nullptr && y != nullptr && x != y, "bad vectors");
-  SrArgs s = make_args(_planes.data(), _identity_numbering ? nullptr : _node_dof.data(), _n_coarse, _N, _na, _a,
+  SrArgs s = make_args(_planes.data(), _planes_f32.size() ? _planes_f32.data() : nullptr, _identity_numbering ? nullptr : _node_dof.data(), _n_coarse, _N, _na, _a,
                        _n_eig, _patch, _exc.size() ? _exc.data() : nullptr, _exc_node.size() ? _exc_node.data() : nullptr, _table.data(),
                        _cls.size() ? _cls.data() : nullptr, _class_table.data());
   hipEvent_t stop = _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes(), _handle.stream);
@@ -675,7 +706,7 @@ void StructuredRestrictorDevice::restrict_to_coarse(double const *x, double *y) 
 void StructuredRestrictorDevice::prolongate(double const *y, double *out, bool subtract) const
 {
   ASSERT_THROW(y != nullptr && out != nullptr && y != out, "bad vectors");
-  SrArgs s = make_args(_planes.data(), _identity_numbering ? nullptr : _node_dof.data(), _n_coarse, _N, _na, _a,
+  SrArgs s = make_args(_planes.data(), _planes_f32.size() ? _planes_f32.data() : nullptr, _identity_numbering ? nullptr : _node_dof.data(), _n_coarse, _N, _na, _a,
                        _n_eig, _patch, _exc.size() ? _exc.data() : nullptr, _exc_node.size() ? _exc_node.data() : nullptr, _table.data(),
                        _cls.size() ? _cls.data() : nullptr, _class_table.data());
   hipEvent_t stop = _handle.profiler.begin("csr_spmv_kernel", algorithmic_bytes() + (subtract ? 8. * double(_n_fine) : 0.),

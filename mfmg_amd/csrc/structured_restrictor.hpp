@@ -78,6 +78,7 @@ private:
   int64_t _n_coarse = 0, _n_fine = 0, _nnz = 0;
   bool _identity_numbering = false;
   DeviceBuffer<double> _planes;   // [patch][n_coarse]
+  DeviceBuffer<float> _planes_f32; // ... or, when every value is representable in float, these instead
   DeviceBuffer<uint8_t> _exc;     // per agglomerate: 0 = its block equals the reference block `_table`
   DeviceBuffer<uint8_t> _exc_node; // per fine node: 0 = all agglomerates around it are regular
   DeviceBuffer<uint8_t> _blk_exc;  // per agglomerate position (na + 1 per direction): 0 = table-driven block kernel
@@ -92,6 +93,7 @@ private:
 
 public:
   int block_classes() const { return _n_classes; }
+  bool float_planes() const { return _planes_f32.size() > 0; }
 
 private:
   DeviceBuffer<int32_t> _node_dof; // DoF id of lexicographic node (empty when the numbering is lexicographic)

@@ -963,3 +963,52 @@ def test_matrix_free_hierarchy_in_two_dimensions(ctx, n, material, degree):
     res_g, _ = gpu_history(ctx, h, lambda y, x: op.vmult(y, x), b, x0)
     np.testing.assert_allclose(res_g, res_o, rtol=HIST_TOL, atol=HIST_ATOL)
     assert rate_o < 0.6
+
+
+@pytest.mark.parametrize("n,material,solver", [((32, 32, 32), "linear", {"type": "lu_dense"}),
+                                               ((64, 64, 64), "linear", {"type": "amg"}),
+                                               ((64, 64, 64), "discontinuous", {"type": "amg"})])
+def test_setup_value_precision_float(ctx, n, material, solver):
+    """"setup value precision" float: the matrices the setup forms (R, R A R^T, the aggregation hierarchy) are rounded to
+    float-representable values, and the stored blocks of a variable-coefficient problem are then KEPT in float (half the
+    bytes per application) -- arithmetic stays FP64.  The hierarchy is the exact cycle of the rounded matrices: the oracle
+    run on the product's own (downloaded) R, A_c and aggregation levels reproduces the residual history to 1e-10; the
+    rounded R is within float rounding of the FP64 one; the cycle contracts like the FP64 hierarchy."""
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, material)
+    con = mesh.constrained_mask()
+    mf = O.MatrixFreeLaplace(mesh, coef)
+    prob = M.LaplaceProblem(n, material, device="cuda")
+    smoother = {"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0}
+    p64 = base_params(smoother=smoother, solver=solver)
+    p32 = base_params(smoother=smoother, solver=solver, **{"setup value precision": "float"})
+    h64 = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, p64)
+    h32 = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, p32)
+    R64, R32 = h64.restrictor().to_scipy(), h32.restrictor().to_scipy()
+    assert np.array_equal(R32.data, R32.data.astype(np.float32).astype(np.float64))       # float-representable
+    assert abs(R32 - R64).max() <= 2.0 ** -23 * abs(R64).max()                             # ... and R rounded, nothing else
+    Ac32 = h32.coarse_operator().to_scipy()
+    assert np.array_equal(Ac32.data, Ac32.data.astype(np.float32).astype(np.float64))
+    assert abs(Ac32 - Ac32.T).max() == 0.0                                                 # rounded symmetrically
+    G = O.galerkin_coarse_matrix(mf.vmult, R32)
+    assert abs(Ac32 - G).max() <= 2.0 ** -22 * abs(G).max()                                # = fl32(R A R^T) of the rounded R
+    if n[0] >= 64:
+        # the stored layouts hold floats where the FP64 hierarchy holds doubles
+        assert h32.restrictor().float_storage() and not h64.restrictor().float_storage()
+        assert h32.coarse_operator().float_storage() and not h64.coarse_operator().float_storage()
+        assert h32.coarse_operator().get_kernel()[1] == 3                                  # symmetric half, as in FP64
+    deg, lmin, lmax = h32.smoother_info()
+    p = O.ChebyshevParams(deg, lmax, lmin)
+    dinv = mf.diagonal_inverse()
+    sm = lambda b, x: O.chebyshev_smoother_apply(mf.vmult, dinv, p, b, x)
+    coarse = O.amg_coarse_solver(h32.coarse_amg_levels(), 1) if solver["type"] == "amg" else O.direct_coarse_solver(Ac32)
+    ho = O.TwoLevelHierarchy(mf.vmult, sm, R32, coarse, 1, False)
+    x0 = O.random_initial_guess(mesh.n_dofs, con)
+    b = np.zeros(mesh.n_dofs)
+    n_hist = 8
+    res_o, _, x_o = O.vcycle_history(ho, mf.vmult, b, x0, n_cycles=n_hist)
+    op = M.MatrixFreeLaplace(ctx, prob)
+    res_32, x_32 = gpu_history(ctx, h32, lambda y, x: op.vmult(y, x), b, x0, n_cycles=n_hist)
+    np.testing.assert_allclose(res_32, res_o, rtol=HIST_TOL, atol=HIST_ATOL)
+    res_64, _ = gpu_history(ctx, h64, lambda y, x: op.vmult(y, x), b, x0, n_cycles=n_hist)
+    np.testing.assert_allclose(res_32, res_64, rtol=1e-4)        # the same preconditioner up to the rounding of its matrices
