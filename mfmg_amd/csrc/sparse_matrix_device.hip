@@ -1498,6 +1498,12 @@ void SparseMatrixDevice<T>::build_block_diagonals()
         n_classed += classed[nd] ? c : 0;
       if ((n_regular + n_classed) * 2 < n)
         n_classes = 0;
+      // classes pay while their tables stay in the caches: a few hundred large ones (the boundary shells of a
+      // translation-invariant operator: 60 to 240 classes of hundreds to thousands of nodes).  Thousands of small classes
+      // -- values that merely coincide, e.g. a linear coefficient on a dyadic mesh after rounding to float -- run slower
+      // than the stored planes (measured: 249 + 175 us against 249 us per application of the first coarse operator).
+      if (n_classes >= 1024 || n_classed < (int64_t)32 * c * n_classes)
+        n_classes = 0;
       // small levels are bound by the latency of a launch, not by their rows: there the regular nodes join the lists
       // as one more class (their table is the reference stencil; a regular node has its whole stencil inside the
       // matrix, so the clamping of the class kernel never acts) and the launch of their own is dropped
@@ -1790,6 +1796,8 @@ void SparseMatrixDevice<T>::build_node_classes()
   }
   if (n_classes == 0 || n_classed * 10 < n_nodes * 9)
     return;
+  if (n_classes >= 1024 || n_classed < (int64_t)32 * n_classes)
+    return; // thousands of small classes: tables that do not stay in the caches (see build_block_diagonals)
   // (tile, class, node) order, runs padded to whole wavefronts; tiles keep the rows of a wavefront close together
   // (partial cache lines of the output are completed by wavefronts of other classes of the same tile), the whole
   // matrix as one tile where small tiles would mostly hold padding

@@ -12,6 +12,8 @@ params = {"eigensolver": {"number of eigenvectors": 2}, "agglomeration": {"parti
           "smoother": {"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0, "n_smoothing_steps": 1},
           "solver": {"type": "amg", "amg": {"smoother_degree": 1, "smoothing_range": 4.0, "n_cycles": 1, "aggregate_block": 2}},
           "is preconditioner": False, "max levels": 2, "restrictor": {"structured": structured}}
+if os.environ.get("SETUP_FLOAT") == "1":
+    params["setup value precision"] = "float"
 h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
 x = torch.rand(h.level_size(0), dtype=torch.float64, device="cuda"); b = torch.zeros_like(x)
 for _ in range(3): h.apply(b, x)

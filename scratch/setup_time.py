@@ -1,4 +1,4 @@
-# setup time of the hierarchy at 257^3: where the seconds go (timer report), device vs host eigensolver
+# setup time of the hierarchy: where the seconds go (timer report); usage: setup_time.py [material] [eigensolver where] [cells] [float]
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import mfmg_amd as M
@@ -11,6 +11,8 @@ params = {"eigensolver": {"number of eigenvectors": 2}, "agglomeration": {"nx": 
           "smoother": {"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0},
           "solver": {"type": "amg", "amg": {"smoothing_range": 4.0}}, "restrictor": {"eigensolver": where},
           "is preconditioner": False, "max levels": 2}
+if len(sys.argv) > 4 and sys.argv[4] == "float":
+    params["setup value precision"] = "float"
 t = time.perf_counter()
 h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
 ctx.synchronize()
