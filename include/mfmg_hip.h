@@ -339,6 +339,9 @@ int mfmg_hip_hierarchy_residual_restriction_classes(mfmg_hip_hierarchy_t h, int3
 /* restrictor / coarse operator download for inspection: query sizes with *_shape first */
 int mfmg_hip_hierarchy_get_restrictor(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *r_borrowed);
 int mfmg_hip_hierarchy_get_coarse_operator(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *ac_borrowed);
+/* the operator of level 0 when it is an assembled matrix ("HipMeshEvaluator": evaluate_global,
+ * include/mfmg/cuda/cuda_mesh_evaluator.cuh:39-45); borrowed like the two above; an error for a matrix-free hierarchy */
+int mfmg_hip_hierarchy_get_fine_operator(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *a_borrowed);
 /* levels of the multilevel coarse solver (0 when the coarse solver is direct / pcg): operator A_l, prolongator P_l,
  * its transpose as stored for the restriction (which = 0 / 1 / 2; a borrowed handle, valid until the next call) and the
  * Chebyshev bounds of its smoother */

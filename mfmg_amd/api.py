@@ -456,6 +456,12 @@ class Hierarchy:
         check(self._lib.mfmg_hip_hierarchy_get_restrictor(self.handle, C.byref(h)))
         return SparseMatrixDevice(self.ctx, _handle=h, _borrowed=True, _keepalive=self)
 
+    def fine_operator(self) -> SparseMatrixDevice:
+        """The assembled operator of level 0 (HipMeshEvaluator hierarchies)."""
+        h = C.c_void_p()
+        check(self._lib.mfmg_hip_hierarchy_get_fine_operator(self.handle, C.byref(h)))
+        return SparseMatrixDevice(self.ctx, _handle=h, _borrowed=True, _keepalive=self)
+
     def coarse_operator(self) -> SparseMatrixDevice:
         h = C.c_void_p()
         check(self._lib.mfmg_hip_hierarchy_get_coarse_operator(self.handle, C.byref(h)))

@@ -94,7 +94,7 @@ struct mfmg_hip_hierarchy_s
   std::shared_ptr<HipMeshEvaluator> evaluator;
   std::shared_ptr<TimerOutput> timer;
   std::unique_ptr<Hierarchy<DVector>> hierarchy;
-  mfmg_hip_csr_s restrictor_view, coarse_view, amg_view;
+  mfmg_hip_csr_s restrictor_view, coarse_view, amg_view, fine_view;
   // "fine level precision" float: the matrix-free operator and its smoother in FP32 around the FP64 coarse levels
   std::shared_ptr<MatrixFreeLaplaceDevice<float>> fine_f32;
   DeviceBuffer<float> f32_a, f32_b, f32_res;
@@ -1139,6 +1139,18 @@ int mfmg_hip_hierarchy_get_restrictor(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *r_
     h->restrictor_view.op = std::const_pointer_cast<HipMatrixOperator>(r);
     h->restrictor_view.borrowed = true;
     *r_borrowed = &h->restrictor_view;
+  });
+}
+
+int mfmg_hip_hierarchy_get_fine_operator(mfmg_hip_hierarchy_t h, mfmg_hip_csr_t *a_borrowed)
+{
+  return guarded([&] {
+    require(h && a_borrowed, "null argument");
+    auto a = std::dynamic_pointer_cast<HipMatrixOperator const>(h->hierarchy->levels().front().get_operator());
+    require(a != nullptr, "the fine operator is matrix-free");
+    h->fine_view.op = std::const_pointer_cast<HipMatrixOperator>(a);
+    h->fine_view.borrowed = true;
+    *a_borrowed = &h->fine_view;
   });
 }
 

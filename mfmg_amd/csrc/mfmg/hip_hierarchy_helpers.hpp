@@ -189,14 +189,20 @@ private:
   std::shared_ptr<HipMatrixFreeMeshEvaluator> _mesh_evaluator;
 };
 
-// A R^T of the matrix-free operator, kept symbolic: R->multiply(ap) turns it into
-// A_c = R A R^T by a fused triple product on operator rows generated on the fly
-// (the reference builds A R^T with n_coarse operator applies, include/mfmg/dealii/dealii_utils.hpp:32-81).
+// A R^T kept symbolic: R->multiply(ap) turns it into A_c = R A R^T by probing on the device (27 n_eig applications of
+// R^T, A and R over colour classes of agglomerates) -- for the matrix-free operator (the reference builds A R^T with n_coarse
+// operator applies, include/mfmg/dealii/dealii_utils.hpp:32-81) and, since round 3, for an ASSEMBLED A whose restrictor has
+// the agglomerate-wise form (the explicit products A R^T and R (A R^T) of 516 M and 223 M entries took 6 of the 12 s of
+// that setup at 257^3 DoFs).
 class HipGalerkinHalfProduct : public Operator<DVector>
 {
 public:
   HipGalerkinHalfProduct(std::shared_ptr<HipMatrixFreeOperator const> a, std::shared_ptr<HipMatrixOperator const> r)
-      : _a(a), _r(r)
+      : _a(a), _a_op(a), _r(r)
+  {
+  }
+  HipGalerkinHalfProduct(std::shared_ptr<HipMatrixOperator const> a, std::shared_ptr<HipMatrixOperator const> r)
+      : _a_matrix(a), _a_op(a), _r(r)
   {
   }
   void apply(DVector const &x, DVector &y, OperatorMode mode = OperatorMode::NO_TRANS) const override;
@@ -216,15 +222,18 @@ public:
     return nullptr;
   }
   std::shared_ptr<DVector> build_domain_vector() const override { return _r->build_range_vector(); }
-  std::shared_ptr<DVector> build_range_vector() const override { return _a->build_range_vector(); }
+  std::shared_ptr<DVector> build_range_vector() const override { return _a_op->build_range_vector(); }
   size_t grid_complexity() const override { return 0; }
   size_t operator_complexity() const override { return 0; }
 
-  std::shared_ptr<HipMatrixFreeOperator const> get_a() const { return _a; }
+  std::shared_ptr<HipMatrixFreeOperator const> get_a() const { return _a; }               // null for an assembled A
+  std::shared_ptr<HipMatrixOperator const> get_a_matrix() const { return _a_matrix; }     // null for a matrix-free A
   std::shared_ptr<HipMatrixOperator const> get_r() const { return _r; }
 
 private:
   std::shared_ptr<HipMatrixFreeOperator const> _a;
+  std::shared_ptr<HipMatrixOperator const> _a_matrix;
+  std::shared_ptr<HipOperator const> _a_op; // whichever of the two
   std::shared_ptr<HipMatrixOperator const> _r;
 };
 

@@ -229,6 +229,110 @@ __global__ void coarse_rows_kernel(CoarseGeom g, double const *Y, int32_t *row_p
   }
 }
 
+// ---- the assembled fine operator (tests/laplace.hpp:154-204 + AffineConstraints::distribute_local_to_global) -----------------
+// One thread per DoF repeats amge_structured.cpp: operator_row -- the 3^dim stencil of the node from the cell matrices
+// A_e[m][n] = sum_q c(cell, q) K[q][m][n] of the cells around it, in the same order of additions (contraction off: the
+// same bits), Dirichlet rows and columns eliminated -- and writes its entries sorted by column.
+struct FineGeom
+{
+  int dim, nc, n[3], N[3], matrix_free_semantics;
+  int64_t n_dofs;
+};
+
+template <bool FILL>
+__global__ void fine_rows_kernel(FineGeom g, int32_t const *node_dof, int32_t const *dof_node, uint8_t const *constrained,
+                                 double const *coefficient, double const *Kq, int32_t *row_ptr, int32_t *col, double *val)
+{
+#pragma clang fp contract(off)
+  for (int64_t gd = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; gd < g.n_dofs; gd += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int64_t nd = dof_node[gd];
+    const int i = (int)(nd % g.N[0]), j = (int)((nd / g.N[0]) % g.N[1]), k = (int)(nd / ((int64_t)g.N[0] * g.N[1]));
+    const bool con = constrained[gd] == 1;
+    int32_t cols[27];
+    double vals[27];
+    int cnt = 0;
+    if (con && g.matrix_free_semantics)
+    {
+      cols[0] = (int32_t)gd;
+      vals[0] = 1.;
+      cnt = 1;
+    }
+    else
+    {
+      double st[27];
+      const int ns = (g.dim == 3) ? 27 : 9;
+      for (int t = 0; t < ns; ++t)
+        st[t] = 0.;
+      for (int m = 0; m < g.nc; ++m)
+      {
+        const int a = m & 1, b = (m >> 1) & 1, d = (m >> 2) & 1;
+        const int ci = i - a, cj = j - b, ck = (g.dim == 3) ? k - d : 0;
+        if (ci < 0 || cj < 0 || ck < 0 || ci >= g.n[0] || cj >= g.n[1] || (g.dim == 3 && ck >= g.n[2]))
+          continue;
+        const int64_t c = ci + (int64_t)g.n[0] * (cj + (int64_t)g.n[1] * ck);
+        double const *coef = coefficient + c * g.nc;
+        for (int mp = 0; mp < g.nc; ++mp)
+        {
+          if (con && mp != m)
+            continue;
+          double const *kq = Kq + (size_t)m * g.nc + mp;
+          double v = 0.;
+          for (int q = 0; q < g.nc; ++q)
+            v += coef[q] * kq[(size_t)q * g.nc * g.nc];
+          const int da = (mp & 1) - a + 1, db = ((mp >> 1) & 1) - b + 1, dd = (g.dim == 3) ? ((mp >> 2) & 1) - d + 1 : 0;
+          st[da + 3 * db + 9 * dd] += v;
+        }
+      }
+      if (con)
+      {
+        cols[0] = (int32_t)gd;
+        vals[0] = st[(g.dim == 3) ? 13 : 4];
+        cnt = 1;
+      }
+      else
+        for (int t = 0; t < ns; ++t)
+        {
+          const int ni = i + (t % 3) - 1, nj = j + ((t / 3) % 3) - 1, nk = (g.dim == 3) ? k + (t / 9) - 1 : 0;
+          if (ni < 0 || nj < 0 || nk < 0 || ni >= g.N[0] || nj >= g.N[1] || (g.dim == 3 && nk >= g.N[2]))
+            continue;
+          const int32_t gp = node_dof[ni + (int64_t)g.N[0] * (nj + (int64_t)g.N[1] * nk)];
+          if (constrained[gp] == 1)
+            continue;
+          cols[cnt] = gp;
+          vals[cnt] = st[t];
+          ++cnt;
+        }
+    }
+    if (!FILL)
+    {
+      row_ptr[gd + 1] = cnt;
+      continue;
+    }
+    // insertion sort by column (<= 27 entries), then the row
+    for (int t = 1; t < cnt; ++t)
+    {
+      const int32_t cc = cols[t];
+      const double vv = vals[t];
+      int u = t - 1;
+      while (u >= 0 && cols[u] > cc)
+      {
+        cols[u + 1] = cols[u];
+        vals[u + 1] = vals[u];
+        --u;
+      }
+      cols[u + 1] = cc;
+      vals[u + 1] = vv;
+    }
+    const int p0 = row_ptr[gd];
+    for (int t = 0; t < cnt; ++t)
+    {
+      col[p0 + t] = cols[t];
+      val[p0 + t] = vals[t];
+    }
+  }
+}
+
 template <typename Geom, typename CountLaunch, typename FillLaunch>
 std::shared_ptr<SparseMatrixDevice<double>> assemble(HipHandle &h, int64_t n_rows, int64_t n_cols, char const *what, CountLaunch &&count,
                                                      FillLaunch &&fill)
@@ -329,6 +433,42 @@ std::shared_ptr<SparseMatrixDevice<double>> coarse_operator_from_probes(HipHandl
       [&](int32_t *rp) { hipLaunchKernelGGL(coarse_rows_kernel<false>, grid_for(cn_own), dim3(256), 0, h.stream, g, Y, rp, nullptr, nullptr); },
       [&](int32_t *rp, int32_t *col, double *val) {
         hipLaunchKernelGGL(coarse_rows_kernel<true>, grid_for(cn_own), dim3(256), 0, h.stream, g, Y, rp, col, val);
+      });
+}
+std::shared_ptr<SparseMatrixDevice<double>> fine_operator_on_device(HipHandle &h, StructuredMesh const &mesh, bool matrix_free_semantics)
+{
+  FineGeom g;
+  g.dim = mesh.dim;
+  g.nc = mesh.nc();
+  for (int d = 0; d < 3; ++d)
+  {
+    g.n[d] = mesh.n[d];
+    g.N[d] = mesh.N[d];
+  }
+  g.matrix_free_semantics = matrix_free_semantics ? 1 : 0;
+  g.n_dofs = mesh.n_dofs;
+  std::vector<int32_t> dof_node((size_t)mesh.n_dofs);
+#pragma omp parallel for schedule(static)
+  for (int64_t nd = 0; nd < (int64_t)mesh.node_dof.size(); ++nd)
+    dof_node[mesh.node_dof[nd]] = (int32_t)nd;
+  const std::vector<double> Kq = reference_cell_tables(mesh.dim, mesh.h);
+  DeviceBuffer<int32_t> d_node_dof, d_dof_node;
+  DeviceBuffer<uint8_t> d_con;
+  DeviceBuffer<double> d_coef, d_kq;
+  d_node_dof.upload(mesh.node_dof.data(), mesh.node_dof.size(), h.stream);
+  d_dof_node.upload(dof_node.data(), dof_node.size(), h.stream);
+  d_con.upload(mesh.constrained.data(), mesh.constrained.size(), h.stream);
+  d_coef.upload(mesh.coefficient.data(), mesh.coefficient.size(), h.stream);
+  d_kq.upload(Kq.data(), Kq.size(), h.stream);
+  return assemble<FineGeom>(
+      h, mesh.n_dofs, mesh.n_dofs, "assembled matrix",
+      [&](int32_t *rp) {
+        hipLaunchKernelGGL(fine_rows_kernel<false>, grid_for(mesh.n_dofs), dim3(256), 0, h.stream, g, d_node_dof.data(), d_dof_node.data(),
+                           d_con.data(), d_coef.data(), d_kq.data(), rp, nullptr, nullptr);
+      },
+      [&](int32_t *rp, int32_t *col, double *val) {
+        hipLaunchKernelGGL(fine_rows_kernel<true>, grid_for(mesh.n_dofs), dim3(256), 0, h.stream, g, d_node_dof.data(), d_dof_node.data(),
+                           d_con.data(), d_coef.data(), d_kq.data(), rp, col, val);
       });
 }
 } // namespace mfmg

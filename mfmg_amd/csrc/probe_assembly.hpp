@@ -3,6 +3,7 @@
 // functions replace (hip_hierarchy.hip: HipMatrixOperator::multiply; amg_device_setup.hip).
 #pragma once
 
+#include "amge_structured.hpp"
 #include "sparse_matrix_device.hpp"
 
 namespace mfmg
@@ -24,4 +25,7 @@ std::shared_ptr<SparseMatrixDevice<double>> prolongator_from_probes(HipHandle &h
 std::shared_ptr<SparseMatrixDevice<double>> coarse_operator_from_probes(HipHandle &h, int const cdims[3], int const gdims_c[3], int n_comp,
                                                                         int reach, int const period[3], int64_t c_global_begin,
                                                                         int64_t crow0, int64_t cn_own, double const *Y);
+// The assembled fine operator of a structured mesh (amge_structured.cpp: assemble_global_matrix) formed on the device:
+// the same rows, bit for bit, sorted by column.
+std::shared_ptr<SparseMatrixDevice<double>> fine_operator_on_device(HipHandle &h, StructuredMesh const &mesh, bool matrix_free_semantics);
 } // namespace mfmg

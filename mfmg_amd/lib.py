@@ -167,6 +167,7 @@ def load() -> C.CDLL:
         "mfmg_hip_hierarchy_set_restrictor": (C.c_int, [vp, i64, i64, i64, vp, vp, vp]),
         "mfmg_hip_hierarchy_get_restrictor": (C.c_int, [vp, P(vp)]),
         "mfmg_hip_hierarchy_get_coarse_operator": (C.c_int, [vp, P(vp)]),
+        "mfmg_hip_hierarchy_get_fine_operator": (C.c_int, [vp, P(vp)]),
         "mfmg_hip_hierarchy_smoother_info": (C.c_int, [vp, P(i32), P(dbl), P(dbl)]),
         "mfmg_hip_hierarchy_operator_tile": (C.c_int, [vp, P(C.c_int), P(C.c_int), P(C.c_int)]),
         "mfmg_hip_hierarchy_set_operator_tile": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),

@@ -14,7 +14,7 @@ params = {"eigensolver": {"number of eigenvectors": 2}, "agglomeration": {"nx": 
 if len(sys.argv) > 4 and sys.argv[4] == "float":
     params["setup value precision"] = "float"
 t = time.perf_counter()
-h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+h = M.Hierarchy(ctx, os.environ.get("EVALUATOR", "HipMatrixFreeMeshEvaluator"), prob, params)
 ctx.synchronize()
 print(f"material {material} eigensolver {where}: setup {time.perf_counter() - t:.2f} s")
 print(h.timer_report())

@@ -1014,3 +1014,25 @@ def test_setup_value_precision_float(ctx, n, material, solver):
     np.testing.assert_allclose(res_32, res_o, rtol=HIST_TOL, atol=HIST_ATOL)
     res_64, _ = gpu_history(ctx, h64, lambda y, x: op.vmult(y, x), b, x0, n_cycles=n_hist)
     np.testing.assert_allclose(res_32, res_64, rtol=1e-4)        # the same preconditioner up to the rounding of its matrices
+
+
+@pytest.mark.parametrize("n,material,numbering", [((8, 8), "linear", "lexicographic"), ((6, 5, 4), "discontinuous", "random"),
+                                                   ((16, 12, 10), "linear", "lexicographic"), ((3, 3, 3), "constant", "random")])
+def test_fine_operator_assembled_on_the_device(ctx, n, material, numbering):
+    """`HipMeshEvaluator::evaluate_global` (the reference: the user's assembled system matrix, tests/laplace.hpp:154-204,
+    Dirichlet rows and columns eliminated by AffineConstraints::distribute_local_to_global) forms the matrix in a kernel:
+    the same rows as the host assembly bit for bit, and the oracle's matrix to rounding."""
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, material)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(mesh.n_dofs) if numbering == "random" else np.arange(mesh.n_dofs)
+    prob = M.LaplaceProblem(n, material, device="cuda", dof_numbering=torch.from_numpy(perm))
+    h = M.Hierarchy(ctx, "HipMeshEvaluator", prob, base_params(smoother={"type": "Jacobi"}, **{"max levels": 1}))
+    A_dev = h.fine_operator().to_scipy()
+    A_host = M.host_assemble_matrix(M.LaplaceProblem(n, material, device="cpu", dof_numbering=torch.from_numpy(perm)))
+    assert np.array_equal(A_dev.indptr, A_host.indptr) and np.array_equal(A_dev.indices, A_host.indices)
+    assert np.array_equal(A_dev.data, A_host.data)                                       # bit for bit
+    A_o = O.assemble_csr(mesh, coef).tocsr()[:, :]
+    # the oracle numbers nodes lexicographically: value of node i lives at DoF perm[i]
+    P = sp.csr_matrix((np.ones(mesh.n_dofs), (perm, np.arange(mesh.n_dofs))), shape=(mesh.n_dofs,) * 2)
+    assert abs(A_dev - P @ A_o @ P.T).max() <= 1e-14 * abs(A_o).max()
