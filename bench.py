@@ -51,6 +51,9 @@ def parse_args():
                     help="skip the one-GPU V-cycle on the global problem of configs[3] (512^3 cells; ~40 s with its setup)")
     ap.add_argument("--amg-block", type=int, default=2, help="nodes per direction of one aggregate of the coarse AMG")
     ap.add_argument("--amg-deep", type=str, default="", help="level,block: bigger geometric aggregates from that AMG level on")
+    ap.add_argument("--amg-pre-levels", type=int, default=0,
+                    help="levels of the coarse AMG (from its top) that pre-smooth; the ones below run V(0,1) (default 0: post-"
+                         "smoothing only on every level of the aggregation hierarchy; -1: V(1,1) on all of them)")
     ap.add_argument("--amg-degree", type=int, default=1, help="Chebyshev degree of the coarse AMG smoothers")
     ap.add_argument("--amg-replicate-rows", type=int, default=0,
                     help="distributed runs: aggregation levels with at most this many global rows are gathered and solved "
@@ -343,9 +346,10 @@ def cpu_baseline(args, M, h, prob, lmin, lmax, torch):
     x0 = np.where(cn.astype(bool), 0.0, rng.random(prob.n_dofs))
     b = np.zeros(prob.n_dofs)
     amg = h.coarse_amg_levels() if args.coarse == "amg" else None
+    pre_levels = args.amg_pre_levels if args.amg_pre_levels >= 0 else None
     def run(x_in, cycles):
         xx, _ = ON.vcycles(n, prob.h, cd, co, cn, dinv, args.degree, lmin, lmax, R, Ac, args.coarse_iters, b, x_in, cycles,
-                           want_history=False, amg_levels=amg)
+                           want_history=False, amg_levels=amg, amg_pre_smoothing_levels=pre_levels)
         return xx
 
     # all host cores, 2 warm-ups, >= 5 timed cycles, median; plus a 1-thread figure (the
@@ -464,6 +468,7 @@ def main():
                    {"type": "amg", "amg": {"smoother_degree": args.amg_degree, "smoothing_range": 4.0, "n_cycles": 1,
                                            "aggregate_block": args.amg_block,
                                            **({"setup": args.amg_setup} if args.amg_setup else {}),
+                                           **({"pre_smoothing_levels": args.amg_pre_levels} if args.amg_pre_levels >= 0 else {}),
                                            **({"replicate_rows": args.amg_replicate_rows} if args.amg_replicate_rows else {}),
                                            **({"deep_level": int(args.amg_deep.split(",")[0]),
                                                "deep_block": int(args.amg_deep.split(",")[1])} if args.amg_deep else {})}}),
@@ -573,7 +578,9 @@ def main():
     value = n_global / (dt / args.steps)
 
     coarse_desc = (f"{args.coarse_iters} Jacobi-PCG steps" if args.coarse == "pcg" else
-                   "one V-cycle of a smoothed-aggregation hierarchy (Chebyshev(1) = damped-Jacobi smoothers, dense LU at the bottom)")
+                   "one V-cycle of a smoothed-aggregation hierarchy (Chebyshev(1) = damped-Jacobi smoothers, dense LU at the bottom; "
+                   + ("V(1,1) on every level" if args.amg_pre_levels < 0 else
+                      f"V(0,1) -- post-smoothing only -- from level {args.amg_pre_levels} of that hierarchy on") + ")")
     if rank == 0:
         # bytes the layout requires per launch (library accounting: x, out, one id, coefficients + epilogue operands)
         achieved = (k_bytes / launches) / (k_ms / launches * 1e-3) / 1e9 if launches else 0.0
@@ -696,6 +703,12 @@ def main():
                     ctx, torch, M, args.cells, dict(params, **{"setup value precision": "float"}), material="linear")
                 out["general_coefficient"] = gen
                 out["vcycle_128cubed_config1"] = measure_vcycle_small(ctx, torch, M, 128, params)
+                if args.coarse == "amg" and args.amg_pre_levels >= 0:
+                    # the headline workload with the symmetric coarse cycle of rounds 1 and 2 (V(1,1) on every level of the
+                    # aggregation hierarchy: what a CG-preconditioned use needs), for continuity
+                    p11 = json.loads(json.dumps(params))
+                    p11["solver"]["amg"].pop("pre_smoothing_levels", None)
+                    out["vcycle_256cubed_coarse_cycle_v11"] = measure_vcycle_small(ctx, torch, M, args.cells, p11)
                 out["smoother_apply_256cubed_f32_config5"] = measure_smoother_f32(ctx, torch, M, 256, args.degree)
                 out["cell_contraction_256cubed_config5"] = measure_cell_contraction(ctx, torch, 256)
                 if not assembled:

@@ -1008,6 +1008,8 @@ HipSolver::HipSolver(HipHandle &handle, std::shared_ptr<Operator<DVector> const>
     opts.deep_level = this->_params->get("solver.amg.deep_level", 1 << 30);
     opts.deep_block = this->_params->get("solver.amg.deep_block", 2);
     _amg_cycles = this->_params->get("solver.amg.n_cycles", 1);
+    // levels of the aggregation hierarchy (counted from its top) that pre-smooth; the ones below run V(0,1)
+    _amg_pre_smoothing_levels = this->_params->get("solver.amg.pre_smoothing_levels", 1 << 20);
     ASSERT_THROW(opts.coarsest_size <= 16384, "solver.amg.coarsest_size is limited by the dense LU (16384)");
     std::vector<double> b0;
     if (near_null && (int64_t)near_null->size() == n)
@@ -1177,6 +1179,20 @@ void HipSolver::amg_cycle(size_t level, DVector const &b, DVector &x) const
     L.x_work = L.a->build_range_vector();
   }
   // the iterate lives in x_work until the post-smoother writes its result into x
+  if ((int)level >= _amg_pre_smoothing_levels)
+  {
+    // V(0,1) on this level ("solver.amg.pre_smoothing_levels"): from x = 0 the residual is -b, so b itself is restricted and
+    // the correction ADDED (the two signs cancel exactly: the same bits as restricting -b and subtracting) -- no smoother
+    // launch, no operator application before the recursion
+    L.restrictor->apply(b, *L.b_coarse);
+    if ((int)level + 1 == _amg_gather_level)
+      amg_cycle_gathered(level + 1, *L.b_coarse, *L.x_coarse);
+    else
+      amg_cycle(level + 1, *L.b_coarse, *L.x_coarse);
+    L.prolongator->apply(*L.x_coarse, *L.x_work, OperatorMode::NO_TRANS);
+    L.smoother->apply_to(b, *L.x_work, x);
+    return;
+  }
   L.smoother->apply_zero_guess(b, *L.x_work); // zero initial guess by construction
   L.a->residual(*L.x_work, b, *L.res);
   L.restrictor->apply(*L.res, *L.b_coarse);

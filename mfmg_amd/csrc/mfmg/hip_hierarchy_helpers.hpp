@@ -329,6 +329,7 @@ private:
   mutable DeviceBuffer<double> _gather_in;
   std::shared_ptr<DVector> _gather_b, _gather_x;
   int _amg_cycles = 1;
+  int _amg_pre_smoothing_levels = 1 << 20;
   DenseLu _amg_bottom;
 
   HipHandle &_handle;

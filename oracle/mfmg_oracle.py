@@ -745,12 +745,14 @@ def pcg_coarse_solver(Ac: sp.csr_matrix, n_iter: int):
     return solve
 
 
-def amg_coarse_solver(levels, n_cycles: int = 1):
+def amg_coarse_solver(levels, n_cycles: int = 1, pre_smoothing_levels: Optional[int] = None):
     """Build-defined multilevel coarse 'solve' (the role ML / AMGx play upstream,
     source/dealii/dealii_solver.cc:48-66, source/cuda/cuda_solver.cu:204-445): `n_cycles` V-cycles from a
     zero guess over a given aggregation hierarchy.  `levels` = [(A_l, P_l or None, (degree, lmin, lmax)
     or None)], the last level is solved by dense LU.  Every level runs the recursion of
-    Hierarchy::apply (hierarchy.hpp:246-309) with restrictor P_l^T and a Chebyshev smoother."""
+    Hierarchy::apply (hierarchy.hpp:246-309) with restrictor P_l^T and a Chebyshev smoother.
+    `pre_smoothing_levels` (None: all): levels from that index on skip the pre-smoother -- from the zero guess
+    the residual is -b, so b is restricted and the correction added: a V(0,1) cycle."""
     data = []
     for (A, P, cheb) in levels:
         A = A.tocsr()
@@ -765,6 +767,9 @@ def amg_coarse_solver(levels, n_cycles: int = 1):
         if P is None:
             return sla.lu_solve(lu, b)
         dinv, p = sm
+        if pre_smoothing_levels is not None and l >= pre_smoothing_levels:
+            x = P @ cycle(l + 1, P.T @ b)
+            return chebyshev_smoother_apply(lambda z: A @ z, dinv, p, b, x)
         x = np.zeros_like(b)
         x = chebyshev_smoother_apply(lambda z: A @ z, dinv, p, b, x)
         res = A @ x - b

@@ -251,7 +251,9 @@ struct AmgLevelData
   std::vector<int> perm;
 };
 
-void amg_cycle(std::vector<AmgLevelData> &L, size_t l, const double *b, double *x)
+// (pre_levels: levels from that index on skip the pre-smoother: from the zero guess the residual is -b, so b is
+// restricted and the correction added -- a V(0,1) cycle; the product's solver.amg.pre_smoothing_levels)
+void amg_cycle(std::vector<AmgLevelData> &L, size_t l, const double *b, double *x, int pre_levels)
 {
   AmgLevelData &lv = L[l];
   const int64_t n = lv.A.n_rows;
@@ -274,6 +276,15 @@ void amg_cycle(std::vector<AmgLevelData> &L, size_t l, const double *b, double *
     return;
   }
   const int64_t nc = lv.Pt.n_rows;
+  if ((int)l >= pre_levels)
+  {
+    csr_spmv(nc, lv.Pt.rp, lv.Pt.col, lv.Pt.val, b, lv.bc.data());
+    std::fill(lv.xc.begin(), lv.xc.end(), 0.);
+    amg_cycle(L, l + 1, lv.bc.data(), lv.xc.data(), pre_levels);
+    csr_spmv(n, lv.P.rp, lv.P.col, lv.P.val, lv.xc.data(), x);
+    csr_chebyshev_smoother(lv.A, lv.dinv.data(), lv.degree, lv.lmin, lv.lmax, b, x, lv.r, lv.dst, lv.up1, lv.up2);
+    return;
+  }
   csr_chebyshev_smoother(lv.A, lv.dinv.data(), lv.degree, lv.lmin, lv.lmax, b, x, lv.r, lv.dst, lv.up1, lv.up2);
   csr_spmv(n, lv.A.rp, lv.A.col, lv.A.val, x, lv.res.data());
 #pragma omp parallel for schedule(static)
@@ -281,7 +292,7 @@ void amg_cycle(std::vector<AmgLevelData> &L, size_t l, const double *b, double *
     lv.res[i] -= b[i];
   csr_spmv(nc, lv.Pt.rp, lv.Pt.col, lv.Pt.val, lv.res.data(), lv.bc.data());
   std::fill(lv.xc.begin(), lv.xc.end(), 0.);
-  amg_cycle(L, l + 1, lv.bc.data(), lv.xc.data());
+  amg_cycle(L, l + 1, lv.bc.data(), lv.xc.data(), pre_levels);
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i)
   {
@@ -375,7 +386,7 @@ void oracle_vcycles(const int *n, const double *h, const int32_t *cell_dofs, con
                     const int32_t *r_col, const double *r_val, const int32_t *rt_rp, const int32_t *rt_col,
                     const double *rt_val, const int32_t *ac_rp, const int32_t *ac_col, const double *ac_val,
                     int coarse_iters, int n_amg_levels, const OracleAmgLevel *amg_levels, const double *b, double *x,
-                    int n_cycles, double *history)
+                    int n_cycles, double *history, int amg_pre_smoothing_levels)
 {
   Mesh m = make_mesh(n, h, cell_dofs, coef, con);
   const int64_t nf = m.n_dofs, ncs = n_coarse;
@@ -477,7 +488,7 @@ void oracle_vcycles(const int *n, const double *h, const int32_t *cell_dofs, con
     csr_spmv(ncs, r_rp, r_col, r_val, res.data(), bc.data());
     std::fill(xc.begin(), xc.end(), 0.);
     if (n_amg_levels > 0)
-      amg_cycle(amg, 0, bc.data(), xc.data());
+      amg_cycle(amg, 0, bc.data(), xc.data(), amg_pre_smoothing_levels);
     // coarse PCG from zero (coarse_iters = 0 when the multilevel solver is used)
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < ncs; ++i)

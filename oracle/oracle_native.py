@@ -139,9 +139,10 @@ def _csr_struct(M, keep):
 
 
 def vcycles(n, h, cell_dofs, coef, con, dinv, degree, lmin, lmax, R, Ac, coarse_iters, b, x0, n_cycles,
-            want_history=True, amg_levels=None):
+            want_history=True, amg_levels=None, amg_pre_smoothing_levels=None):
     """n_cycles V-cycles (matrix-free fine level, Chebyshev(degree); coarse 'solve' = PCG(coarse_iters), or
-    one V-cycle of the aggregation hierarchy `amg_levels` = [(A_l, P_l or None, (deg, lmin, lmax) or None)]);
+    one V-cycle of the aggregation hierarchy `amg_levels` = [(A_l, P_l or None, (deg, lmin, lmax) or None)], its levels
+    from `amg_pre_smoothing_levels` on without pre-smoother);
     returns (x, history or None)."""
     lib = load()
     n_a = np.asarray(n, dtype=np.int32)
@@ -184,5 +185,6 @@ def vcycles(n, h, cell_dofs, coef, con, dinv, degree, lmin, lmax, R, Ac, coarse_
     lib.oracle_vcycles(_p(n_a), _p(h_a), _p(cd), _p(co), _p(cn), _p(dinv), C.c_int(degree), C.c_double(lmin),
                        C.c_double(lmax), C.c_int64(R.shape[0]), *[_p(a) for a in arrs], C.c_int(coarse_iters),
                        C.c_int(n_amg), lv_arr, _p(b), _p(x), C.c_int(n_cycles),
-                       _p(hist) if want_history else None)
+                       _p(hist) if want_history else None,
+                       C.c_int((1 << 20) if amg_pre_smoothing_levels is None else int(amg_pre_smoothing_levels)))
     return x, hist

@@ -394,8 +394,9 @@ def test_smoother_bounds_cover_the_spectrum_at_row_length_128(ctx):
     assert norms[3] < norms[2] < norms[1] < norms[0]
 
 
-@pytest.mark.parametrize("n_cycles,cells", [(1, 32), (2, 32), (1, 64), (1, 128)])
-def test_amg_coarse_solver_parity(ctx, n_cycles, cells):
+@pytest.mark.parametrize("n_cycles,cells,pre_levels", [(1, 32, None), (2, 32, None), (1, 64, None), (1, 128, None),
+                                                        (1, 32, 0), (2, 32, 1), (1, 64, 0), (1, 128, 0)])
+def test_amg_coarse_solver_parity(ctx, n_cycles, cells, pre_levels):
     """solver.type amg: the V-cycle over the aggregation hierarchy on the GPU against its oracle restatement,
     run on the level matrices downloaded from the product.  64 cells per direction: A_c (65536 rows) in block-diagonal
     storage with regular rows, stencil classes and listed rows, its prolongator in node classes, the restrictor with
@@ -406,8 +407,11 @@ def test_amg_coarse_solver_parity(ctx, n_cycles, cells):
     con = mesh.constrained_mask()
     mf = O.MatrixFreeLaplace(mesh, coef)
     prob = M.LaplaceProblem(n, device="cuda")
+    amg = {"coarsest_size": 600, "n_cycles": n_cycles}
+    if pre_levels is not None:          # V(0,1) from that level of the aggregation hierarchy on (the bench runs 0)
+        amg["pre_smoothing_levels"] = pre_levels
     params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0},
-                         solver={"type": "amg", "amg": {"coarsest_size": 600, "n_cycles": n_cycles}})
+                         solver={"type": "amg", "amg": amg})
     h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
     levels = h.coarse_amg_levels()
     assert [A.shape[0] for A, _, _ in levels] == {32: [8192, 1024, 128], 64: [65536, 8192, 1024, 128], 128: [524288, 65536, 8192, 1024, 128]}[cells]
@@ -417,7 +421,7 @@ def test_amg_coarse_solver_parity(ctx, n_cycles, cells):
     deg, lmin, lmax = h.smoother_info()
     R = h.restrictor().to_scipy()
     # coarse solve alone
-    solve = O.amg_coarse_solver(levels, n_cycles)
+    solve = O.amg_coarse_solver(levels, n_cycles, pre_smoothing_levels=pre_levels)
     bc = np.random.default_rng(1).random(R.shape[0])
     xc = torch.empty(R.shape[0], dtype=torch.float64, device="cuda")
     h.coarse_apply(dev(bc), xc)
@@ -808,7 +812,10 @@ def test_full_size_vcycle_history_against_the_native_oracle(ctx, material):
 
     n = (256, 256, 256)
     prob = M.LaplaceProblem(n, material, device="cuda")
-    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0}, solver={"type": "amg"})
+    # constant: the bench's configuration (the aggregation hierarchy runs V(0,1): post-smoothing only); linear: V(1,1)
+    pre_levels = 0 if material == "constant" else None
+    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0},
+                         solver={"type": "amg", "amg": {} if pre_levels is None else {"pre_smoothing_levels": pre_levels}})
     h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
     deg, lmin, lmax = h.smoother_info()
     cd = prob.cell_dofs.cpu().numpy()
@@ -826,7 +833,7 @@ def test_full_size_vcycle_history_against_the_native_oracle(ctx, material):
     b = np.zeros(prob.n_dofs)
     cycles = 5
     x_o, res_o = ON.vcycles(n, prob.h, cd, co, cn, 1.0 / d_o, deg, lmin, lmax, R, Ac, 0, b, x0, cycles,
-                            amg_levels=levels)
+                            amg_levels=levels, amg_pre_smoothing_levels=pre_levels)
     del R, Ac, levels
     res_g, x_g = gpu_history(ctx, h, lambda y, x: op.vmult(y, x), b, x0, n_cycles=cycles)
     np.testing.assert_allclose(res_g, res_o, rtol=HIST_TOL, atol=HIST_ATOL)

@@ -131,19 +131,20 @@ def test_native_vcycles_pcg_coarse_solve(n, material, degree):
     assert np.abs(x_n - x_o).max() <= TOL * 10 * max(np.abs(x_o).max(), 1.0)
 
 
+@pytest.mark.parametrize("pre_levels", [None, 0, 1])
 @pytest.mark.parametrize("n,material", [((8, 8, 8), "constant"), ((16, 16, 16), "linear")])
-def test_native_vcycles_amg_coarse_solve(n, material):
+def test_native_vcycles_amg_coarse_solve(n, material, pre_levels):
     """The multilevel coarse 'solve' (the role of ML / AMGx, source/dealii/dealii_solver.cc:48-66): the port's
     amg_cycle against mfmg_oracle.amg_coarse_solver on the same level matrices."""
     mesh, coef, mf, con, dinv, R, Ac, p, x0 = _two_level(n, material, 3)
     levels = _aggregation_levels(Ac)
-    solve = O.amg_coarse_solver(levels, 1)
+    solve = O.amg_coarse_solver(levels, 1, pre_smoothing_levels=pre_levels)
     smoother = lambda b, x: O.chebyshev_smoother_apply(mf.vmult, dinv, p, b, x)
     ho = O.TwoLevelHierarchy(mf.vmult, smoother, R, solve, 1, False)
     b = np.zeros(mesh.n_dofs)
     cycles = 6
     res_o, _, x_o = O.vcycle_history(ho, mf.vmult, b, x0, n_cycles=cycles)
     x_n, res_n = ON.vcycles(n, mesh.h, mesh.cell_dofs(), coef, con, dinv, p.degree, p.lambda_min, p.lambda_max, R, Ac,
-                            0, b, x0, cycles, amg_levels=levels)
+                            0, b, x0, cycles, amg_levels=levels, amg_pre_smoothing_levels=pre_levels)
     np.testing.assert_allclose(res_n, res_o, rtol=1e-11, atol=1e-15)
     assert np.abs(x_n - x_o).max() <= 1e-12 * np.abs(x0).max()
