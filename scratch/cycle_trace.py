@@ -10,7 +10,8 @@ ctx = M.Context()
 prob = M.LaplaceProblem((cells,) * 3, material, device="cuda")
 params = {"eigensolver": {"number of eigenvectors": 2}, "agglomeration": {"partitioner": "block", "nx": 2, "ny": 2, "nz": 2},
           "smoother": {"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0, "n_smoothing_steps": 1},
-          "solver": {"type": "amg", "amg": {"smoother_degree": 1, "smoothing_range": 4.0, "n_cycles": 1, "aggregate_block": 2}},
+          "solver": {"type": "amg", "amg": {"smoother_degree": 1, "smoothing_range": 4.0, "n_cycles": 1, "aggregate_block": 2,
+                                            **({} if os.environ.get("AMG_V11") == "1" else {"pre_smoothing_levels": 0})}},
           "is preconditioner": False, "max levels": 2, "restrictor": {"structured": structured}}
 if os.environ.get("SETUP_FLOAT") == "1":
     params["setup value precision"] = "float"
