@@ -217,6 +217,10 @@ int mfmg_hip_csr_transpose(mfmg_hip_csr_t a, mfmg_hip_csr_t *out);
 int mfmg_hip_csr_multiply(mfmg_hip_csr_t a, mfmg_hip_csr_t b, mfmg_hip_csr_t *out);
 /* download (copy_from_dev / convert_to_trilinos_matrix, source/cuda/utils.cu:170-204) */
 int mfmg_hip_csr_download(mfmg_hip_csr_t a, int32_t *row_ptr_host, int32_t *col_host, double *val_host);
+/* CudaSolver(handle, op, params)->apply(b, x) (source/cuda/cuda_solver.cu:204-515, the standalone use of
+ * tests/test_direct_solver_device.cu:23-110): builds the coarse solver `solver.type` names for this matrix -- lu_dense |
+ * cholesky | lu_sparse_host (dense LU factored here), pcg, amg -- applies it once from a zero guess and drops it. */
+int mfmg_hip_csr_solve(mfmg_hip_csr_t a, const char *params_info, const double *b, double *x);
 /* extract_inv_diag (source/cuda/cuda_smoother.cu:86-96): dinv[i] = 1/A_ii on device */
 int mfmg_hip_csr_inverse_diagonal(mfmg_hip_csr_t a, double *dinv);
 /* One fused Jacobi/Chebyshev step on an assembled operator:

@@ -196,6 +196,13 @@ class SparseMatrixDevice:
         check(self._lib.mfmg_hip_csr_stencil_classes(self.handle, C.byref(k), C.byref(r)))
         return k.value, r.value
 
+    def solve(self, params, b, x):
+        """CudaSolver(handle, op, params)->apply(b, x): the coarse solver `solver.type` names, built for this matrix,
+        applied once from a zero guess."""
+        info = params if isinstance(params, str) else params_to_info(params)
+        n = self.shape[0]
+        check(self._lib.mfmg_hip_csr_solve(self.handle, info.encode(), _dev_ptr(b, n), _dev_ptr(x, n)))
+
     def float_storage(self) -> bool:
         """The values the kernels read are kept in float (all representable in it: lossless)."""
         v = C.c_int()

@@ -624,6 +624,20 @@ int mfmg_hip_csr_download(mfmg_hip_csr_t a, int32_t *row_ptr_host, int32_t *col_
   });
 }
 
+int mfmg_hip_csr_solve(mfmg_hip_csr_t a, const char *params_info, const double *b, double *x)
+{
+  return guarded([&] {
+    require(a && b && x, "null argument");
+    auto m = a->op->get_matrix();
+    require(m->m() == m->n(), "the solver needs a square matrix");
+    auto params = std::make_shared<ptree>(ptree::parse_info(params_info ? params_info : ""));
+    HipSolver solver(m->handle(), a->op, params);
+    DVector bv(m->handle(), m->m(), const_cast<double *>(b)), xv(m->handle(), m->m(), x);
+    solver.apply(bv, xv);
+    MFMG_HIP_CHECK(hipStreamSynchronize(m->handle().stream)); // (the solver and its factors go out of scope)
+  });
+}
+
 int mfmg_hip_csr_inverse_diagonal(mfmg_hip_csr_t a, double *dinv)
 {
   return guarded([&] {

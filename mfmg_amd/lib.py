@@ -125,6 +125,7 @@ def load() -> C.CDLL:
         "mfmg_hip_csr_set_regular_rows": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_csr_stencil_classes": (C.c_int, [vp, P(C.c_int), P(i64)]),
         "mfmg_hip_csr_float_storage": (C.c_int, [vp, P(C.c_int)]),
+        "mfmg_hip_csr_solve": (C.c_int, [vp, C.c_char_p, vp, vp]),
         "mfmg_hip_csr_vmult": (C.c_int, [vp, vp, vp]),
         "mfmg_hip_csr_apply": (C.c_int, [vp, vp, vp, C.c_int]),
         "mfmg_hip_csr_transpose": (C.c_int, [vp, P(vp)]),

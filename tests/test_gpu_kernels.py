@@ -739,3 +739,25 @@ def test_cell_contraction_valu_and_mfma(ctx, dtype, tol, variant, n_cells):
     got = v.cpu().numpy().astype(float)
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() < tol * np.abs(ref).max() * 8
+
+
+def test_direct_solvers_on_the_reference_tridiagonal_system(ctx):
+    """/root/reference/tests/test_direct_solver_device.cu:23-110: the 30 x 30 matrix tridiag(-1, 4, -1), a solution drawn
+    from N(10, 2), rhs = A x; CudaSolver with solver.type cholesky / lu_dense / lu_sparse_host must return x to 1e-12 %
+    (here: the three names share the dense LU factored at construction); the iterative types on the same system."""
+    n = 30
+    A = sp.diags([-np.ones(n - 1), 4 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1]).tocsr()
+    sol = 10.0 + 2.0 * np.random.default_rng(0).standard_normal(n)
+    rhs = A @ sol
+    Ad = M.SparseMatrixDevice(ctx, A)
+    x = torch.empty(n, dtype=torch.float64, device="cuda")
+    for solver in ("cholesky", "lu_dense", "lu_sparse_host"):
+        x.fill_(123.0)                                           # the solvers start from zero by themselves
+        Ad.solve({"solver": {"type": solver}}, dev(rhs), x)
+        np.testing.assert_allclose(host(x, ctx), sol, rtol=1e-14)          # (BOOST_CHECK_CLOSE 1e-12 per cent)
+    Ad.solve({"solver": {"type": "pcg", "n_iterations": 30}}, dev(rhs), x)  # CG on 30 unknowns is exact after 30 steps
+    np.testing.assert_allclose(host(x, ctx), sol, rtol=1e-10)
+    with pytest.raises(L.MfmgError, match="Unknown solver name"):           # cuda_solver.cu:71
+        Ad.solve({"solver": {"type": "qr"}}, dev(rhs), x)
+    with pytest.raises(L.MfmgNotImplementedError):                          # no AmgX shim
+        Ad.solve({"solver": {"type": "amgx"}}, dev(rhs), x)
