@@ -507,6 +507,30 @@ def block_agglomerates(mesh: StructuredMesh, agg: Sequence[int]):
     return out, counts
 
 
+def dealii_block_agglomerate_ids(mesh: StructuredMesh, agg: Sequence[int]) -> np.ndarray:
+    """Agglomerate id of every cell as AMGe::build_agglomerates_block leaves it in the cells' user indices
+    (include/mfmg/common/amge.templates.hpp:412-499): cells in deal.II's iteration order (refine_global of a
+    hyper_cube: Morton order, x fastest inside a parent), agglomerates numbered from 1 in the order in which the
+    traversal first meets them.  Requires 2^r cells per direction.  Pinned by the literal arrays of
+    tests/test_agglomerate.cc:69-120,122-230 (one rank)."""
+    dim = mesh.dim
+    n = mesh.n[0]
+    assert all(v == n for v in mesh.n) and (n & (n - 1)) == 0
+    levels = int(math.log2(n))
+    seen = {}
+    out = []
+    for m in range(n ** dim):
+        c = [0] * dim
+        for l in range(levels):
+            for d in range(dim):
+                c[d] |= ((m >> (dim * l + d)) & 1) << l
+        key = tuple(c[d] // agg[d] for d in range(dim))
+        if key not in seen:
+            seen[key] = len(seen) + 1
+        out.append(seen[key])
+    return np.array(out, dtype=np.int64)
+
+
 def agglomerate_local(mesh: StructuredMesh, lo, hi):
     """Local lexicographic DoF numbering of one agglomerate patch: returns
     (global dof ids [nloc], local cell->local-dof [ncell_loc, 2^dim],

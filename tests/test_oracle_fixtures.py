@@ -264,3 +264,18 @@ def test_oracle_reproduces_committed_vectors(name):
     np.testing.assert_array_equal(out["R_indices"], f["R_indices"])
     assert out["lambda_max"] == pytest.approx(float(f["lambda_max"]), rel=1e-12)
     np.testing.assert_allclose(out["history"], f["history"], rtol=1e-9, atol=1e-13)
+
+
+# ---- tests/test_agglomerate.cc:69-230 : block agglomerates 2 x 3 (x 4) on 8 x 8 (x 8) cells, one rank ----
+@pytest.mark.parametrize("dim", [2, 3])
+def test_block_agglomerate_ids_literal_arrays(dim):
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_agglomerate_ids.json")))
+    mesh = O.StructuredMesh((8,) * dim)
+    ids = O.dealii_block_agglomerate_ids(mesh, (2, 3, 4)[:dim])
+    assert ids.tolist() == gold["agglomerate_%dd" % dim]                 # BOOST_TEST(agglomerates == ref_agglomerates)
+    # and they are the boxes the restrictor is built on: same cells per agglomerate as block_agglomerates
+    aggs, counts = O.block_agglomerates(mesh, (2, 3, 4)[:dim])
+    assert len(aggs) == ids.max() == int(np.prod(counts))
+    sizes = sorted(int(np.prod([hi[d] - lo[d] for d in range(dim)])) for lo, hi in aggs)
+    assert sizes == sorted(np.bincount(ids)[1:].tolist())
