@@ -279,3 +279,17 @@ def test_block_agglomerate_ids_literal_arrays(dim):
     assert len(aggs) == ids.max() == int(np.prod(counts))
     sizes = sorted(int(np.prod([hi[d] - lo[d] for d in range(dim)])) for lo, hi in aggs)
     assert sizes == sorted(np.bincount(ids)[1:].tolist())
+
+
+# ---- tests/test_eigenvectors.cc:74-130 : a diagonal agglomerate matrix diag(1 .. n), the first five eigenpairs ----
+@pytest.mark.parametrize("mode", ["lapack", "krylov"])
+def test_eigenvectors_of_a_diagonal_agglomerate_matrix(mode):
+    import scipy.linalg as sla
+    n, n_eig = 81, 5                                   # 8 x 8 cells of Q1: 81 DoFs, n_eigenvectors = 5
+    w, V = sla.eigh(np.diag(np.arange(1.0, n + 1.0)))
+    v0 = np.random.default_rng(0).random(n)            # (a Krylov start vector with a component on every eigenvector)
+    vals, vecs = O._select_eigenvectors(w, V, n_eig, mode, v0)
+    np.testing.assert_allclose(vals, np.arange(1.0, n_eig + 1.0), rtol=1e-12)      # eigenvalues i + 1
+    ref = np.zeros((n, n_eig))
+    ref[np.arange(n_eig), np.arange(n_eig)] = 1.0
+    np.testing.assert_allclose(np.abs(vecs), ref, atol=1e-12)                      # |eigenvector_i| = e_i
