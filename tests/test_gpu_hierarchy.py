@@ -839,6 +839,44 @@ def test_full_size_vcycle_history_against_the_native_oracle(ctx, material):
     np.testing.assert_allclose(res_g, res_o, rtol=HIST_TOL, atol=HIST_ATOL)
     assert np.abs(x_g - x_o).max() <= 1e-10 * np.abs(x0).max()
     assert res_o[-1] / res_o[-2] < 0.4
+    del h
+    torch.cuda.empty_cache()
+    # BASELINE.json configs[2] at its size: the SAME cycle with the ASSEMBLED fine operator (HipMeshEvaluator: CSR matrix of
+    # 27 entries per row formed on the device, Chebyshev(3) through the SpMV kernels, R A R^T by probing).  With b = 0
+    # and x0 = 0 on the Dirichlet DoFs the assembled rows (diagonal kept) and the matrix-free ones (identity) generate the
+    # same iterates, so the matrix-free oracle run above is the reference for it as well -- given the same smoother bounds.
+    pa = dict(params)
+    pa["smoother"] = dict(params["smoother"], lambda_min=lmin, lambda_max=lmax)
+    ha = M.Hierarchy(ctx, "HipMeshEvaluator", prob, pa)
+    # (the oracle takes THIS hierarchy's R, A_c and aggregation levels: the assembled evaluator's AMGe variant differs)
+    x_oa, res_oa = ON.vcycles(n, prob.h, cd, co, cn, 1.0 / d_o, deg, lmin, lmax, ha.restrictor().to_scipy(),
+                              ha.coarse_operator().to_scipy(), 0, b, x0, cycles, amg_levels=ha.coarse_amg_levels(),
+                              amg_pre_smoothing_levels=pre_levels)
+    res_a, x_a = gpu_history(ctx, ha, lambda y, x: op.vmult(y, x), b, x0, n_cycles=cycles)
+    np.testing.assert_allclose(res_a, res_oa, rtol=HIST_TOL, atol=HIST_ATOL)
+    assert np.abs(x_a - x_oa).max() <= 1e-10 * np.abs(x0).max()
+    del ha
+    if material == "constant":
+        # BASELINE.json configs[4] at size: the fine level in FP32 against the FP64 oracle, 1e-4 relative
+        torch.cuda.empty_cache()
+        pf = dict(params)
+        pf["fine level precision"] = "float"
+        hf = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, pf)
+        x0f = x0.astype(np.float32)
+        x_of, res_of = ON.vcycles(n, prob.h, cd, co, cn, 1.0 / d_o, deg, lmin, lmax, hf.restrictor().to_scipy(),
+                                  hf.coarse_operator().to_scipy(), 0, b, x0f.astype(np.float64), 4,
+                                  amg_levels=hf.coarse_amg_levels(), amg_pre_smoothing_levels=pre_levels)
+        xf = torch.from_numpy(x0f).cuda()
+        bf = torch.zeros_like(xf)
+        r = torch.empty(prob.n_dofs, dtype=torch.float64, device="cuda")
+        op.vmult(r, xf.double())
+        r0 = ctx.l2_norm(r)
+        res_f = [1.0]
+        for _ in range(4):
+            hf.apply_f32(bf, xf)
+            op.vmult(r, xf.double())
+            res_f.append(ctx.l2_norm(r) / r0)
+        np.testing.assert_allclose(res_f, res_of, rtol=1e-4, atol=2e-6)
 
 
 @pytest.mark.parametrize("evaluator,n,material", [("HipMeshEvaluator", (8, 8), "constant"), ("HipMeshEvaluator", (8, 6, 4), "linear"),
