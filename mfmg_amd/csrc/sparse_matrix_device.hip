@@ -739,6 +739,14 @@ __global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, V cons
 // of the rectangular operators) walks planes of 1-15 GB several times; on the host cores these passes were a third
 // of the setup of the hierarchy (2.7 s of 8.4 s at 257^3 DoFs).  They run as kernels on the CSR arrays that are on
 // the device anyway; what comes back to the host is small: a flag per row, a hash per exceptional node, the tables.
+// raise a flag once: the atomic is skipped when the flag is visibly up already (a failing analysis would otherwise issue
+// one atomic per entry on the same address)
+__device__ __forceinline__ void raise_flag(int *flag, int bits)
+{
+  if ((*reinterpret_cast<int const volatile *>(flag) & bits) != bits)
+    atomicOr(flag, bits);
+}
+
 __device__ __forceinline__ int find_offset(int32_t const *offs, int D, int32_t o)
 {
   int lo = 0, hi = D;
@@ -764,7 +772,7 @@ __global__ void bdia_fill_kernel(int64_t n, int c, int D, int32_t const *offs, i
       const int d = find_offset(offs, D, (int32_t)(col[p] / c - r / c));
       if (d < 0)
       {
-        atomicOr(bad, 1);
+        raise_flag(bad, 1);
         continue;
       }
       dv[((size_t)d * c + (size_t)(col[p] % c)) * n + r] += val[p];
@@ -898,7 +906,7 @@ __global__ void bdia_symmetry_kernel(int64_t n, int c, int D, int32_t const *off
         const double up = (double)dv[((size_t)d * c + cc) * n + r];
         const double lo = (double)dv[((size_t)(2 * zero - d) * c + rc) * n + (nb * c + cc)];
         if (fabs(up - lo) > tol)
-          atomicOr(asym, 1);
+          raise_flag(asym, 1);
       }
     }
   }
@@ -935,7 +943,7 @@ __global__ void nodecls_fill_kernel(int64_t n_nodes, int c, int D, int32_t const
         const int d = find_offset(offs, D, (int32_t)(col[p] / c - b));
         if (d < 0)
         {
-          atomicOr(bad, 1);
+          raise_flag(bad, 1);
           continue;
         }
         tv[(size_t)nd * tuple + ((size_t)rc * D + d) * c + (size_t)(col[p] % c)] += val[p];
@@ -972,9 +980,17 @@ __global__ void nodecls_same_kernel(int64_t n_nodes, size_t tuple, T const *tv, 
 template <typename T>
 __global__ void not_float_kernel(T const *v, int64_t n, int *flag)
 {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    if ((T)(float)v[i] != v[i])
-      atomicOr(flag, 1);
+  // (one atomic per wavefront at most, none once the flag is up: with FP64 values nearly every entry raises it, and 10^8
+  // atomics on one address took 20 ms)
+  bool bad = false;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n && !bad; i += (int64_t)gridDim.x * blockDim.x)
+  {
+    if (*reinterpret_cast<int const volatile *>(flag) != 0)
+      return;
+    bad = (T)(float)v[i] != v[i];
+  }
+  if (__ballot(bad) != 0 && (threadIdx.x & 63) == __builtin_ctzll(__ballot(bad)))
+    atomicOr(flag, 1);
 }
 template <typename T>
 __global__ void narrow_kernel(T const *v, int64_t n, float *out)
@@ -1054,12 +1070,12 @@ __global__ void csr_validate_kernel(int64_t n_rows, int64_t n_cols, int32_t cons
   {
     if (row_ptr[r] > row_ptr[r + 1] || row_ptr[r] < 0)
     {
-      atomicOr(bad, 1);
+      raise_flag(bad, 1);
       continue;
     }
     for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p)
       if (col[p] < 0 || col[p] >= n_cols)
-        atomicOr(bad, 2);
+        raise_flag(bad, 2);
   }
 }
 
