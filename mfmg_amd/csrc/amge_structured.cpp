@@ -2,6 +2,9 @@
 #include "amge_device.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -566,8 +569,12 @@ HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<doub
   std::vector<int32_t> dev_n_vec;
   int dev_nmax = 0;
   const bool on_device = device != nullptr && amge_device_supported(mesh, opts);
+  const bool verbose_t = std::getenv("MFMG_HIP_VERBOSE") != nullptr;
+  auto now_t = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tt0 = now_t();
   if (on_device)
     amge_device_eigen(*device, mesh, opts, cnt, dev_weights, dev_n_vec, dev_nmax);
+  const double tt1 = now_t();
   // identical agglomerates (same shape, constraints and local matrix) share one eigen-solve;
   // the table is capped so that a spatially varying coefficient cannot blow up host memory
   // (one table per thread: no lock on the hot path; at most threads x classes eigen-solves)
@@ -777,6 +784,7 @@ HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<doub
     }
   }
 
+  const double tt2 = now_t();
   // assemble R (rows: agglomerates in x-fastest order, eigenvectors inside; columns sorted)
   HostCsr R;
   R.n_cols = mesh.n_dofs;
@@ -834,6 +842,9 @@ HostCsr build_restrictor_structured(StructuredMesh const &mesh, std::vector<doub
       }
     }
   }
+  if (verbose_t)
+    std::fprintf(stderr, "[mfmg_hip] restrictor rows: eigenproblems %.2f s, agglomerate DoF lists %.2f s, CSR assembly %.2f s\n", tt1 - tt0,
+                 tt2 - tt1, now_t() - tt2);
   return R;
 }
 

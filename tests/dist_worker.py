@@ -314,6 +314,9 @@ MESHES = {
     # deep: two aggregation levels stay distributed (stencil reach 1 and 2, probing with 16 / 250 and 54 / 686
     # vectors, reverse exchanges two and three layers wide), the third is gathered
     "deep": (24, (16, 16), "linear", {"coarsest_size": 40, "replicate_rows": 40}),
+    # deep01: the same with the V(0,1) coarse cycle of the bench (solver.amg.pre_smoothing_levels 0): b is restricted and the
+    # correction added on every level of the aggregation hierarchy, distributed and gathered ones alike
+    "deep01": (24, (16, 16), "linear", {"coarsest_size": 40, "replicate_rows": 40, "pre_smoothing_levels": 0}),
 }
 
 
@@ -455,7 +458,7 @@ def mode_gpu(args):
     mf = O.MatrixFreeLaplace(mesh, gprob.coefficient.cpu().numpy())
     p = O.ChebyshevParams(deg, glmax, glmin)
     smoother = lambda b, xx: O.chebyshev_smoother_apply(mf.vmult, mf.diagonal_inverse(), p, b, xx)
-    ho = O.TwoLevelHierarchy(mf.vmult, smoother, hg.restrictor().to_scipy(), O.amg_coarse_solver(hg.coarse_amg_levels(), 1), 1, False)
+    ho = O.TwoLevelHierarchy(mf.vmult, smoother, hg.restrictor().to_scipy(), O.amg_coarse_solver(hg.coarse_amg_levels(), 1, pre_smoothing_levels=amg.get("pre_smoothing_levels")), 1, False)
     res_o, rate, _ = O.vcycle_history(ho, mf.vmult, np.zeros(ng), x0g, n_cycles=n_cycles)
     res_o = np.array(res_o)
     np.testing.assert_allclose(hist / hist[0], res_o[:n_cycles + 1] / res_o[0], rtol=1e-9, atol=1e-12)

@@ -64,7 +64,7 @@ def test_distributed_setup_protocol_cpu_gloo(mfmg_lib, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,mesh", [(2, "small"), (3, "small"), (2, "wide"), (2, "deep"), (4, "deep")])
+@pytest.mark.parametrize("world,mesh", [(2, "small"), (3, "small"), (2, "wide"), (2, "deep"), (4, "deep"), (2, "deep01")])
 def test_distributed_library_path_shared_gpu(mfmg_lib, world, mesh):
     assert "gpu distributed checks passed" in _run("gpu", world, mesh=mesh)
 
