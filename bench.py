@@ -2,9 +2,11 @@
 """bench.py -- V-cycle throughput of the MI355X-native mfmg hot path.
 
 One "step" = one `Hierarchy::apply` (V-cycle: Chebyshev(3) pre-smooth, residual, restriction, coarse
-solve = one V-cycle of the smoothed-aggregation hierarchy below the first coarse level, prolongation,
+solve = one V-cycle of the smoothed-aggregation hierarchy below the first coarse level -- V(0,1), i.e. post-smoothing
+only, on its levels by default (`--amg-pre-levels`; the symmetric V(1,1) cycle is measured beside it) --, prolongation,
 Chebyshev(3) post-smooth) on the matrix-free Q1 Laplace of a synthetic 3-D hyper-cube, FP64, inputs
-resident in HBM.  Metric (BASELINE.json): fine-DoFs/sec per V-cycle.  One process per GPU; rank 0
+resident in HBM.  The `cpu_baseline` leg runs the same cycle in the oracle's C++ port and compares its iterates with the
+GPU's (`parity_vs_gpu`).  Metric (BASELINE.json): fine-DoFs/sec per V-cycle.  One process per GPU; rank 0
 prints ONE JSON line.
 
 Byte accounting of the roofline block: `achieved` = bytes the data layout REQUIRES per launch of the
