@@ -46,17 +46,6 @@ struct LevelGeom
   int64_t owned_rows() const { return owned_count * layer_elems(); }
 };
 
-std::vector<double> download_range(HipHandle &h, double const *dev, int64_t begin, int64_t n)
-{
-  std::vector<double> out((size_t)n);
-  if (n > 0)
-  {
-    MFMG_HIP_CHECK(hipMemcpyAsync(out.data(), dev + begin, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h.stream));
-    MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
-  }
-  return out;
-}
-
 std::shared_ptr<SparseMatrixDevice<double>> upload_csr(HipHandle &handle, HostCsr &&m, bool keep_host = true)
 {
   return std::make_shared<SparseMatrixDevice<double>>(handle, m.n_rows, m.n_cols, std::move(m.row_ptr), std::move(m.col),
