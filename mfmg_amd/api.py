@@ -34,6 +34,65 @@ def params_to_info(params: dict, indent: int = 0) -> str:
     return "".join(out)
 
 
+def info_to_params(text: str) -> dict:
+    """boost::property_tree INFO text -> nested dict (the inverse of params_to_info; what
+    boost::property_tree::info_parser::read_info does for tests/hierarchy_driver.cc:255-256): `key value`,
+    `key { children }` with the brace on the same or the next line, "quoted strings", `;` comments.  Values stay
+    strings except true / false, integers and floats."""
+    import shlex
+
+    def convert(v: str):
+        if v == "true":
+            return True
+        if v == "false":
+            return False
+        for cast in (int, float):
+            try:
+                return cast(v)
+            except ValueError:
+                pass
+        return v
+
+    tokens = []
+    for line in text.splitlines():
+        lex = shlex.shlex(line, posix=True)
+        lex.whitespace_split = True
+        lex.commenters = ";"
+        lex.quotes = '"'
+        toks = list(lex)
+        # braces glued to a word do not occur in the files of the reference; split the plain cases anyway
+        for t in toks:
+            tokens.append(("tok", t))
+        tokens.append(("eol", None))
+
+    def parse(pos):
+        node = {}
+        while pos < len(tokens):
+            kind, t = tokens[pos]
+            if kind == "eol":
+                pos += 1
+                continue
+            if t == "}":
+                return node, pos + 1
+            key = t
+            pos += 1
+            value = None
+            if pos < len(tokens) and tokens[pos][0] == "tok" and tokens[pos][1] not in ("{", "}"):
+                value = tokens[pos][1]
+                pos += 1
+            q = pos
+            while q < len(tokens) and tokens[q][0] == "eol":
+                q += 1
+            if q < len(tokens) and tokens[q] == ("tok", "{"):
+                child, pos = parse(q + 1)
+                node[key] = child
+            else:
+                node[key] = convert(value) if value is not None else ""
+        return node, pos
+
+    return parse(0)[0]
+
+
 def _dev_ptr(t: torch.Tensor, n: Optional[int] = None, dtype=torch.float64) -> int:
     if not isinstance(t, torch.Tensor):
         raise TypeError("expected a torch tensor")

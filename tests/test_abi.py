@@ -215,3 +215,18 @@ def test_info_parser_reads_the_reference_data_file():
         else:
             assert got == value
     assert params_get(info, "hidden.coarse.params.coarse: type") == "Amesos-KLU"
+
+
+def test_info_text_to_params_and_back():
+    """The INFO reader of the Python side (examples/hierarchy_driver.py reads the reference's input file with it):
+    the reference's data file, and a round trip through params_to_info."""
+    text = open(os.path.join(ROOT, "tests", "golden", "reference_hierarchy_input.info")).read()
+    p = M.info_to_params(text)
+    assert p["eigensolver"] == {"number of eigenvectors": 2, "tolerance": 1e-14}
+    assert p["smoother"]["type"] == "Gauss-Seidel" and p["is preconditioner"] is False
+    assert p["agglomeration"] == {"partitioner": "block", "nx": 2, "ny": 2, "nz": 2}
+    assert p["laplace"]["n_refinements"] == 5 and p["laplace"]["reordering"] == "None"
+    assert p["hidden"]["coarse"]["params"]["smoother: type"] == "symmetric Gauss-Seidel"
+    assert M.info_to_params(M.params_to_info(p)) == p
+    # the library's own parser reads what params_to_info writes
+    assert params_get(M.params_to_info(p), "hidden.coarse.params.coarse: type") == "Amesos-KLU"

@@ -1081,3 +1081,28 @@ def test_fine_operator_assembled_on_the_device(ctx, n, material, numbering):
     # the oracle numbers nodes lexicographically: value of node i lives at DoF perm[i]
     P = sp.csr_matrix((np.ones(mesh.n_dofs), (perm, np.arange(mesh.n_dofs))), shape=(mesh.n_dofs,) * 2)
     assert abs(A_dev - P @ A_o @ P.T).max() <= 1e-14 * abs(A_o).max()
+
+
+@pytest.mark.parametrize("dim,matrix_free", [(2, 0), (2, 1), (3, 0), (3, 1)])
+@pytest.mark.parametrize("preconditioner", [False, True])
+def test_hierarchy_driver_example(ctx, tmp_path, dim, matrix_free, preconditioner):
+    """examples/hierarchy_driver.py: the reference's driver workflow (tests/hierarchy_driver.cc; its CTest entries run it for
+    -m 0 / 1 and only ask that it completes, tests/CMakeLists.txt:18-42) on the reference's own input file -- 20 cycles with
+    a contracting residual, or CG to the tolerance."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("hierarchy_driver", os.path.join(root, "examples", "hierarchy_driver.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    text = open(os.path.join(root, "tests", "golden", "reference_hierarchy_input.info")).read()
+    p = M.info_to_params(text)
+    p["is preconditioner"] = preconditioner
+    p["laplace"]["n_refinements"] = 4            # (5 in the file: 33^3 DoFs; 4 keeps the eight runs short)
+    f = tmp_path / "input.info"
+    f.write_text(M.params_to_info(p))
+    out = drv.main(["-f", str(f), "-d", str(dim), "-m", str(matrix_free), "-t", "1e-8"])
+    if preconditioner:
+        assert 1 <= out <= 40                    # CG iterations
+    else:
+        assert 0.0 < out < 0.7                   # res[20] / res[19]
