@@ -9,7 +9,7 @@ Same command line (`:216-253`: --filename/-f, --dim/-d, --matrix_free/-m, --tole
 `"is preconditioner" false` -> 20 V-cycles on rhs = 0 from a random start vector and the convergence rate
 res[20] / res[19] (`:74-101`); true -> CG preconditioned by the hierarchy (`:103-116`).  Differences: the mesh is the
 hyper-cube of `laplace.n_refinements` global refinements with Q1 elements only (`laplace.fe_degree` other than 1 is
-refused), and a matrix-based run whose input file asks for an Ifpack relaxation (Gauss-Seidel, the file's default) takes
+refused; where the file names none the reference takes degree 4, `:269`, this script degree 1), and a matrix-based run whose input file asks for an Ifpack relaxation (Gauss-Seidel, the file's default) takes
 Jacobi, the CUDA back-end's smoother, with a note.
 """
 import argparse
