@@ -37,9 +37,11 @@ extern "C" {
  *   1  rounds 1-2 up to the host-callback halo exchange (mfmg_hip_context_set_halo_buffers)
  *   2  round 2: mfmg_hip_context_set_communicator(ctx, rank, n_ranks, ghost_low, ghost_high) replaces the old signature,
  *      mfmg_hip_context_set_halo_buffers removed (transports: mfmg_hip_context_use_rccl / _use_host_transport)
- *   round 3 added mfmg_hip_hierarchy_ap_apply, mfmg_hip_rccl_available, mfmg_hip_abi_version (no change of the version).
+ *      (round 3 added mfmg_hip_hierarchy_ap_apply, mfmg_hip_rccl_available, mfmg_hip_abi_version: no change of the version)
+ *   3  round 3: box decomposition -- mfmg_hip_host_sendrecv_fn receives the two peer ranks (a box has neighbours other than
+ *      rank -+ 1); added mfmg_hip_context_set_communicator_box, mfmg_hip_context_halo_box, mfmg_hip_context_exchange_volume
  * mfmg_hip_abi_version() returns the value the loaded library was built with. */
-#define MFMG_HIP_ABI_VERSION 2
+#define MFMG_HIP_ABI_VERSION 3
 
 #define MFMG_HIP_SUCCESS 0
 #define MFMG_HIP_ERROR_RUNTIME 1
@@ -69,12 +71,19 @@ int mfmg_hip_context_destroy(mfmg_hip_context_t ctx);
 int mfmg_hip_context_synchronize(mfmg_hip_context_t ctx);
 void *mfmg_hip_context_stream(mfmg_hip_context_t ctx);
 
-/* ---- distributed runs: one process per GPU, slab decomposition of the mesh along z ----
+/* ---- distributed runs: one process per GPU, the mesh cut into slabs along z or into boxes (2 x 1 x 1, 2 x 2 x 1, 2 x 2 x 2 ...) ----
  * Replaces deal.II's distributed::Vector ghost exchange inside MatrixFree::cell_loop and the all-gather of
  * the whole vector in front of every SpMV on the CUDA path (source/cuda/utils.cu:363-482,
  * include/mfmg/cuda/sparse_matrix_device.templates.cuh:104-138).  The local mesh of a rank is its owned
- * cell slab plus `ghost_cells_low/high` (0 or 2 = one agglomerate) cell layers of its neighbours; local DoF
- * numbering must be lexicographic; ghost (not owned) DoFs carry the value 2 in mfmg_hip_mesh_desc.constrained.
+ * cell slab (box) plus `ghost_cells_low/high` (0 or 2 = one agglomerate) cell layers of its neighbours (per split axis); local
+ * DoF numbering must be lexicographic; ghost (not owned) DoFs carry the value 2 in mfmg_hip_mesh_desc.constrained.
+ * Boxes (the reference's p4est partition, tests/laplace_matrix_free.hpp:222, with rank-local agglomerates,
+ * include/mfmg/common/amge.templates.hpp:453-478,604-621): mfmg_hip_context_set_communicator_box places the rank at
+ * (cx, cy, cz) = (rank % gx, (rank / gx) % gy, rank / (gx gy)) of a gx x gy x gz grid of equal boxes; interface planes belong
+ * to the upper box (the last box of an axis also owns the top plane).  An exchange runs axis by axis -- x, y, then z, each
+ * with the two face neighbours, the later axes carrying the ghost columns the earlier ones received -- so that edges and
+ * corners need no partners of their own: per fine exchange a rank of a 2 x 2 x 2 grid sends 3 faces of about (N/2)^2 doubles
+ * where a slab of 8 sends 2 planes of N^2.
  * Every level of the V-cycle is coupled across the ranks: before an operator application the library refreshes
  * the ghost layers of its input (owner -> ghost), after a transposed prolongator it returns the partial sums in
  * the ghost layers to their owners (ghost -> owner, added); the levels of the aggregation hierarchy whose global
@@ -86,15 +95,20 @@ void *mfmg_hip_context_stream(mfmg_hip_context_t ctx);
  *                                        rank 0 and must reach every rank through the caller's own channel;
  *   mfmg_hip_context_use_host_transport  the library stages the layers through pinned host memory and calls the
  *                                        callbacks with HOST pointers (tests: gloo, several ranks on one card).
- * `sendrecv` exchanges n_low doubles with rank - 1 and n_high with rank + 1 (a count of 0: no such neighbour);
+ * `sendrecv` exchanges n_low doubles with rank `peer_low` and n_high with rank `peer_high` (a count of 0: no such neighbour;
+ * slabs: rank - 1 and rank + 1);
  * `allreduce` combines `n` doubles over all ranks in place (op 0: sum, 1: max); `allgather` collects `n` doubles of
  * every rank into `out` (n * n_ranks, rank order). */
-typedef int (*mfmg_hip_host_sendrecv_fn)(void *user, const double *send_low, double *recv_low, int64_t n_low,
-                                         const double *send_high, double *recv_high, int64_t n_high);
+typedef int (*mfmg_hip_host_sendrecv_fn)(void *user, int32_t peer_low, int32_t peer_high, const double *send_low, double *recv_low,
+                                         int64_t n_low, const double *send_high, double *recv_high, int64_t n_high);
 typedef int (*mfmg_hip_host_allreduce_fn)(void *user, double *values, int n, int op);
 typedef int (*mfmg_hip_host_allgather_fn)(void *user, const double *in, int64_t n, double *out);
 int mfmg_hip_context_set_communicator(mfmg_hip_context_t ctx, int32_t rank, int32_t n_ranks, int32_t ghost_cells_low,
                                       int32_t ghost_cells_high);
+/* grid[3]: ranks along x, y, z (their product = the number of ranks); ghost_low / ghost_high[3]: ghost cell layers of the local
+ * mesh per axis (2 towards an existing neighbour, else 0).  set_communicator(rank, n, lo, hi) is the grid 1 x 1 x n. */
+int mfmg_hip_context_set_communicator_box(mfmg_hip_context_t ctx, int32_t rank, const int32_t grid[3], const int32_t ghost_low[3],
+                                          const int32_t ghost_high[3]);
 int mfmg_hip_rccl_unique_id(unsigned char out[128]);
 /* MFMG_HIP_SUCCESS when librccl and the entry points the transport uses can be resolved in this process (dlopen / dlsym
  * only, no RCCL call is made).  Callers agree on the transport with a collective over this flag before they choose. */
@@ -109,6 +123,8 @@ int mfmg_hip_context_transport_name(mfmg_hip_context_t ctx, char *buffer, size_t
 int mfmg_hip_context_transport_selftest(mfmg_hip_context_t ctx, int64_t n, double *max_error);
 /* point-to-point exchanges issued through the context so far (diagnostics) */
 int mfmg_hip_context_exchange_count(mfmg_hip_context_t ctx, int64_t *n_exchanges);
+/* ... and the doubles this rank has sent in them */
+int mfmg_hip_context_exchange_volume(mfmg_hip_context_t ctx, int64_t *n_doubles_sent);
 /* one halo exchange of a device vector of `space` (1 fine DoFs, 2 first coarse level, 3.. aggregation levels):
  * reverse = 0 owner -> ghost, 1 ghost -> owner (added).  The cycle does this by itself; exposed for tests. */
 int mfmg_hip_context_exchange(mfmg_hip_context_t ctx, int32_t space, double *vector, int reverse);
@@ -142,6 +158,9 @@ int mfmg_hip_context_set_galerkin_on_device(mfmg_hip_context_t ctx, int enable);
 int mfmg_hip_context_halo_layout(mfmg_hip_context_t ctx, int32_t space, int64_t *layer_elems, int64_t *n_layers,
                                  int64_t *owned_begin, int64_t *owned_count);
 int mfmg_hip_context_halo_space(mfmg_hip_context_t ctx, int32_t space, int64_t out[8]);
+/* the same per axis (x, y, z): out = {entries per node, local nodes[3], first owned[3], owned[3], global index of local node 0 [3],
+ * global nodes[3]}: a vector of the space is the lexicographic array of the local nodes, `entries per node` values each */
+int mfmg_hip_context_halo_box(mfmg_hip_context_t ctx, int32_t space, int64_t out[16]);
 
 /* BASELINE.json configs[4]: the cell-local evaluation of the Q1 Laplace as a batched dense contraction,
  * v[m][cell] = c[cell] * sum_k K_ref[m][k] u[k][cell] (K_ref: reference matrix of a Cartesian cell of size `cell_size`,

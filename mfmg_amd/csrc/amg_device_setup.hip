@@ -1,5 +1,5 @@
 // Setup of the smoothed-aggregation hierarchy below the first coarse level ON THE DEVICE, by probing, for runs
-// where the levels are coupled across the ranks of a slab decomposition (and, on request, for one rank).
+// where the levels are coupled across the ranks of a slab or box decomposition (and, on request, for one rank).
 //
 // The reference delegates the coarse problem to ML / AMGx (source/dealii/dealii_solver.cc:48-66,
 // source/cuda/cuda_solver.cu:204-445) and forms its Galerkin products with host / cuSPARSE SpGEMM
@@ -32,18 +32,14 @@ namespace
 {
 double wall_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// a level: its nodes as a halo space (local box with ghost layers, owned box, global position and size per axis;
+// comps entries per node) + the reach of its operator
 struct LevelGeom
 {
-  int dims[3] = {0, 0, 0}; // local nodes (x, y, z incl. ghost layers)
-  int n_comp = 1;
-  int space = 0;             // halo space of the level's vectors (0: one rank)
-  int64_t owned_begin = 0, owned_count = 0; // owned z layers of the local box
-  int64_t global_begin = 0, global_layers = 0;
-  int reach = 1;             // stencil reach of the level's operator in nodes
-  int64_t layer_elems() const { return (int64_t)dims[0] * dims[1] * n_comp; }
-  int64_t n_rows() const { return layer_elems() * dims[2]; }
-  int64_t owned_row_begin() const { return owned_begin * layer_elems(); }
-  int64_t owned_rows() const { return owned_count * layer_elems(); }
+  HaloSpace s;
+  int space = 0; // index of the halo space of the level's vectors (0: one rank)
+  int reach = 1; // stencil reach of the level's operator in nodes
+  int64_t n_rows() const { return s.n_local(); }
 };
 
 std::shared_ptr<SparseMatrixDevice<double>> upload_csr(HipHandle &handle, HostCsr &&m, bool keep_host = true)
@@ -73,33 +69,28 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
   ASSERT_THROW(blk >= 2 && grid.block[1] == blk && grid.block[2] == blk, "the device setup needs cubic aggregates");
 
   LevelGeom g;
-  for (int d = 0; d < 3; ++d)
-    g.dims[d] = std::max(grid.dims[d], 1);
-  g.n_comp = C;
   g.reach = 1;
   if (distributed)
   {
-    HaloSpace const &s = comm.spaces[op_space];
-    ASSERT_THROW(s.layer_elems == g.layer_elems() && s.n_layers == g.dims[2], "internal: coarse space does not match the agglomerate grid");
+    g.s = comm.spaces[op_space];
+    g.s.check();
+    for (int d = 0; d < 3; ++d)
+      ASSERT_THROW(g.s.dim(d) == std::max(grid.dims[d], 1), "internal: coarse space does not match the agglomerate grid");
+    ASSERT_THROW(g.s.comps == C, "internal: coarse space does not match the agglomerate grid");
     g.space = op_space;
-    g.owned_begin = s.owned_begin;
-    g.owned_count = s.owned_count;
-    g.global_begin = s.global_begin;
-    g.global_layers = s.global_layers;
   }
   else
   {
-    g.owned_begin = 0;
-    g.owned_count = g.dims[2];
-    g.global_begin = 0;
-    g.global_layers = g.dims[2];
+    g.s.set_whole_xy(std::max(grid.dims[0], 1), std::max(grid.dims[1], 1), C);
+    g.s.layer_elems = (int64_t)C * g.s.n_xy[0] * g.s.n_xy[1];
+    g.s.n_layers = g.s.owned_count = g.s.global_layers = std::max(grid.dims[2], 1);
   }
   ASSERT_THROW(matrix->m() == g.n_rows(), "internal: operator rows do not match the agglomerate grid");
   for (int64_t r = 0; r < (int64_t)grid.node_of_row.size(); r += std::max<int64_t>(1, (int64_t)grid.node_of_row.size() / 8191))
     ASSERT_THROW(grid.node_of_row[r] == r / C && (grid.component_of_row.empty() ? 0 : grid.component_of_row[r]) == r % C,
                  "the device setup of the aggregation hierarchy needs node-major rows with a fixed number of components");
 
-  // host copy of the current level: owned rows of A (local column ids), near-null vector (local, owned part valid)
+  // host copy of the current level: near-null vector (local, owned part valid)
   // (the level's matrix stays on the device: its diagonal and row sums come from a kernel; only the level that is gathered at
   // the end is downloaded -- the first level alone is 2.7 GB)
   HostCsr A;
@@ -112,71 +103,83 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
   for (;;)
   {
     const int level = (int)_amg.size();
-    const int64_t global_rows = g.layer_elems() * g.global_layers;
+    const int64_t global_rows = g.s.n_global();
     // ---- can the next level be built distributed?
     LevelGeom c;
-    for (int d = 0; d < 2; ++d)
-      c.dims[d] = (g.dims[d] + blk - 1) / blk;
-    c.n_comp = C;
     c.reach = (blk - 1 + 3 * g.reach) / blk;
     bool coarsen_here = global_rows > std::max<int64_t>(replicate_rows, opts.coarsest_size) && level + 1 < opts.max_levels;
     if (coarsen_here)
     {
+      // per axis: an axis the ranks split needs whole aggregates per rank, aligned globally, and the ghost layers of the
+      // coarse level must come from the immediate neighbour; an axis one rank holds whole rounds up
+      double ok = 1.;
+      int64_t cdim[3], cown0[3], cown_n[3], cg0[3], cgn[3];
+      for (int d = 0; d < 3; ++d)
+      {
+        const bool split = distributed && comm.grid[d] > 1;
+        if (split)
+        {
+          if (!(g.s.own_n(d) % blk == 0 && (g.s.g0(d) + g.s.own0(d)) % blk == 0 && g.s.own_n(d) / blk >= c.reach && g.s.gn(d) % blk == 0))
+            ok = 0.;
+          cown_n[d] = g.s.own_n(d) / blk;
+          cown0[d] = g.s.low(d) ? c.reach : 0;
+          cdim[d] = cown0[d] + cown_n[d] + (g.s.high(d) ? c.reach : 0);
+          cg0[d] = (g.s.g0(d) + g.s.own0(d)) / blk - cown0[d];
+          cgn[d] = g.s.gn(d) / blk;
+        }
+        else
+        {
+          cdim[d] = cown_n[d] = cgn[d] = (g.s.dim(d) + blk - 1) / blk;
+          cown0[d] = cg0[d] = 0;
+        }
+      }
       if (distributed)
       {
-        HaloSpace const &s = comm.spaces[g.space];
-        // whole aggregates per rank, aligned globally; the ghost layers of the coarse level must come from the
-        // immediate neighbour
-        double ok = (g.owned_count % blk == 0 && (g.global_begin + g.owned_begin) % blk == 0 && g.owned_count / blk >= c.reach) ? 1. : 0.;
         ok = -h.allreduce_max(-ok); // min over the ranks
         coarsen_here = ok > 0.5;
-        c.owned_count = g.owned_count / blk;
-        c.owned_begin = s.has_low ? c.reach : 0;
-        c.dims[2] = (int)(c.owned_begin + c.owned_count + (s.has_high ? c.reach : 0));
-        c.global_begin = (g.global_begin + g.owned_begin) / blk - c.owned_begin;
-        c.global_layers = g.global_layers / blk;
-        ASSERT_THROW(!coarsen_here || g.global_layers % blk == 0, "internal: layers of a distributed level not a multiple of the aggregate size");
       }
-      else
+      c.s.comps = C;
+      c.s.width = c.reach;
+      for (int d = 0; d < 2; ++d)
       {
-        c.dims[2] = (g.dims[2] + blk - 1) / blk;
-        c.owned_begin = 0;
-        c.owned_count = c.dims[2];
-        c.global_begin = 0;
-        c.global_layers = c.dims[2];
+        c.s.n_xy[d] = cdim[d];
+        c.s.own0_xy[d] = cown0[d];
+        c.s.own_n_xy[d] = cown_n[d];
+        c.s.g0_xy[d] = cg0[d];
+        c.s.gn_xy[d] = cgn[d];
+        c.s.low_xy[d] = g.s.low(d);
+        c.s.high_xy[d] = g.s.high(d);
       }
+      c.s.layer_elems = (int64_t)C * cdim[0] * cdim[1];
+      c.s.n_layers = cdim[2];
+      c.s.owned_begin = cown0[2];
+      c.s.owned_count = cown_n[2];
+      c.s.global_begin = cg0[2];
+      c.s.global_layers = cgn[2];
+      c.s.has_low = g.s.has_low;
+      c.s.has_high = g.s.has_high;
     }
     if (!coarsen_here)
     {
       // ---- gather this level; the rest of the hierarchy is replicated (host setup of one rank)
       A.n_rows = A.n_cols = g.n_rows();
       a_op->get_matrix()->download(A.row_ptr, A.col, A.val);
-      finish_amg_replicated(a_op, std::move(A), std::move(B), g.space, g.owned_begin, g.owned_count, g.global_begin, g.global_layers,
-                            g.dims, C, opts, smoother_params);
+      finish_amg_replicated(a_op, std::move(A), std::move(B), g.space, g.s, opts, smoother_params);
       break;
     }
     const double t0 = wall_now();
     if (distributed)
     {
-      HaloSpace s;
-      s.layer_elems = c.layer_elems();
-      s.n_layers = c.dims[2];
-      s.owned_begin = c.owned_begin;
-      s.owned_count = c.owned_count;
-      s.global_begin = c.global_begin;
-      s.global_layers = c.global_layers;
-      s.width = c.reach;
-      s.has_low = comm.spaces[g.space].has_low;
-      s.has_high = comm.spaces[g.space].has_high;
-      c.space = comm.add_space(s);
+      c.space = comm.add_space(c.s);
       // the fine level of this pair exchanges as many layers as its operator reaches
-      comm.spaces[g.space].width = std::max(comm.spaces[g.space].width, g.reach);
-      ASSERT_THROW(comm.spaces[g.space].width <= std::min<int64_t>(s.has_low ? comm.spaces[g.space].ghost_low() : 1 << 30,
-                                                                    s.has_high ? comm.spaces[g.space].ghost_high() : 1 << 30),
-                   "internal: not enough ghost layers for the stencil of this level");
+      HaloSpace &fs = comm.spaces[g.space];
+      fs.width = std::max(fs.width, g.reach);
+      g.s.width = fs.width;
+      for (int d = 0; d < 3; ++d)
+        ASSERT_THROW((!fs.low(d) || fs.width <= fs.own0(d)) && (!fs.high(d) || fs.width <= fs.dim(d) - fs.own0(d) - fs.own_n(d)),
+                     "internal: not enough ghost layers for the stencil of this level");
     }
     const int64_t n_f = g.n_rows(), n_c = c.n_rows();
-    const int64_t row0 = g.owned_row_begin(), n_own = g.owned_rows();
 
     // ---- diagonal, rho = max_i sum_j |a_ij| / |a_ii| over the owned rows of all ranks
     DeviceBuffer<double> d_dinv((size_t)n_f);
@@ -186,97 +189,90 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
       a_op->get_matrix()->row_ratios(d_dinv.data(), d_ratio.data());
       const std::vector<double> ratio = d_ratio.download(h.stream);
 #pragma omp parallel for schedule(static) reduction(max : rho)
-      for (int64_t i = row0; i < row0 + n_own; ++i)
-        rho = std::max(rho, ratio[i]);
+      for (int64_t i = 0; i < n_f; ++i)
+        if (g.s.owned(i))
+          rho = std::max(rho, ratio[i]);
     }
     rho = h.allreduce_max(rho); // (first the collective, then the check: every rank throws or none does)
     ASSERT_THROW(rho < HUGE_VAL, "zero diagonal in the multilevel coarse solver setup");
     const double w = opts.omega / rho;
 
     // ---- tentative prolongator: t = B / |B|_aggregate on the owned nodes, exchanged to the ghosts; B_c = |B|_aggregate
-    auto agg_of_row = [&](int64_t row, int &I, int &J, int &K, int &comp) {
-      comp = (int)(row % C);
-      const int64_t nd = row / C;
-      const int i = (int)(nd % g.dims[0]), j = (int)((nd / g.dims[0]) % g.dims[1]), k = (int)(nd / ((int64_t)g.dims[0] * g.dims[1]));
-      I = i / blk;
-      J = j / blk;
-      K = (int)((k + g.global_begin) / blk - c.global_begin); // local coarse layer
+    auto agg_row = [&](int64_t row) {
+      int64_t nd[3];
+      g.s.node_of(row, nd);
+      int64_t a[3];
+      for (int d = 0; d < 3; ++d)
+        a[d] = (nd[d] + g.s.g0(d)) / blk - c.s.g0(d); // local coarse node
+      return ((a[2] * c.s.n_xy[1] + a[1]) * c.s.n_xy[0] + a[0]) * C + row % C;
     };
     std::vector<double> norm2((size_t)n_c, 0.), t((size_t)n_f, 0.), Bc((size_t)n_c, 0.);
-    for (int64_t i = row0; i < row0 + n_own; ++i)
-    {
-      int I, J, K, comp;
-      agg_of_row(i, I, J, K, comp);
-      norm2[(((int64_t)K * c.dims[1] + J) * c.dims[0] + I) * C + comp] += B[i] * B[i];
-    }
-    for (int64_t i = row0; i < row0 + n_own; ++i)
-    {
-      int I, J, K, comp;
-      agg_of_row(i, I, J, K, comp);
-      const double nn = norm2[(((int64_t)K * c.dims[1] + J) * c.dims[0] + I) * C + comp];
-      ASSERT_THROW(nn > 0., "the device setup of the aggregation hierarchy needs a near-null-space vector without zero aggregates");
-      t[i] = B[i] / std::sqrt(nn);
-    }
-    for (int64_t r = c.owned_row_begin(); r < c.owned_row_begin() + c.owned_rows(); ++r)
-      Bc[r] = std::sqrt(norm2[r]);
-    DVector t_dev(h, n_f), y_f(h, n_f), z_f(h, n_f), u_c(h, n_c), y_c(h, n_c);
+    for (int64_t i = 0; i < n_f; ++i)
+      if (g.s.owned(i))
+        norm2[agg_row(i)] += B[i] * B[i];
+    for (int64_t i = 0; i < n_f; ++i)
+      if (g.s.owned(i))
+      {
+        const double nn = norm2[agg_row(i)];
+        ASSERT_THROW(nn > 0., "the device setup of the aggregation hierarchy needs a near-null-space vector without zero aggregates");
+        t[i] = B[i] / std::sqrt(nn);
+      }
+    for (int64_t r = 0; r < n_c; ++r)
+      if (c.s.owned(r))
+        Bc[r] = std::sqrt(norm2[r]);
+    DVector t_dev(h, n_f), y_f(h, n_f), z_f(h, n_f), u_c(h, n_c);
     MFMG_HIP_CHECK(hipMemcpyAsync(t_dev.get_values(), t.data(), (size_t)n_f * sizeof(double), hipMemcpyHostToDevice, h.stream));
     h.exchange(g.space, t_dev.get_values());
 
     // ---- P = (I - w D^-1 A) P_tent by probing: the columns of aggregates floor((blk - 1 + 2 reach) / blk) + 1 apart
     //      (1 + reach for blk = 2) are disjoint
-    const int gdims_c[3] = {c.dims[0], c.dims[1], (int)c.global_layers};
+    const int fdims[3] = {(int)g.s.dim(0), (int)g.s.dim(1), (int)g.s.dim(2)}, cdims[3] = {(int)c.s.dim(0), (int)c.s.dim(1), (int)c.s.dim(2)};
+    const int f_off[3] = {(int)g.s.g0(0), (int)g.s.g0(1), (int)g.s.g0(2)}, c_off[3] = {(int)c.s.g0(0), (int)c.s.g0(1), (int)c.s.g0(2)};
     int period_p[3];
     for (int d = 0; d < 3; ++d)
-      period_p[d] = std::max(1, std::min((blk - 1 + 2 * g.reach) / blk + 1, gdims_c[d]));
+      period_p[d] = (int)std::max<int64_t>(1, std::min<int64_t>((blk - 1 + 2 * g.reach) / blk + 1, c.s.gn(d)));
     const int n_col_p = period_p[0] * period_p[1] * period_p[2] * C;
     // (the probes stay on the device and the rows are assembled there: probe_assembly.hip)
-    DeviceBuffer<double> Z((size_t)n_col_p * (size_t)n_own);
+    DeviceBuffer<double> Z((size_t)n_col_p * (size_t)n_f);
     for (int col = 0; col < n_col_p; ++col)
     {
       const int comp = col % C, oc = col / C;
       const int phase[3] = {oc % period_p[0], (oc / period_p[0]) % period_p[1], oc / (period_p[0] * period_p[1])};
-      vec::select_rows(h, g.dims, C, blk, (int)g.global_begin, period_p, phase, comp, t_dev.get_values(), y_f.get_values());
-      a_op->get_matrix()->vmult(z_f.get_values(), y_f.get_values()); // ghosts of y are set locally: no exchange
-      MFMG_HIP_CHECK(hipMemcpyAsync(Z.data() + (size_t)col * n_own, z_f.get_values() + row0, (size_t)n_own * sizeof(double),
-                                    hipMemcpyDeviceToDevice, h.stream));
+      vec::select_rows(h, fdims, C, blk, f_off, period_p, phase, comp, t_dev.get_values(), y_f.get_values());
+      a_op->get_matrix()->vmult(Z.data() + (size_t)col * n_f, y_f.get_values()); // ghosts of y are set locally: no exchange
     }
     MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
     const double t_probed = wall_now();
     // candidates of owned row i: aggregates whose nodes lie within `reach` of its node; v = t_i [own aggregate] - w d_i^-1 (A y)_i
-    auto p_mat = prolongator_from_probes(h, g.dims, c.dims, gdims_c, C, blk, g.reach, period_p, g.global_begin, c.global_begin, row0, n_own,
-                                         w, Z.data(), t_dev.get_values(), d_dinv.data());
+    auto p_mat = prolongator_from_probes(h, g.s, c.s, blk, g.reach, period_p, w, Z.data(), t_dev.get_values(), d_dinv.data());
     Z.release();
     const double t_assembled = wall_now();
-    const double t_uploaded = wall_now();
     auto pt_mat = p_mat->transpose();
     if (verbose)
-      std::fprintf(stderr, "[mfmg_hip] amg level %d: P probes %.2f s, assembly %.2f s, upload + layouts %.2f s, transpose %.2f s\n", level,
-                   t_probed - t0, t_assembled - t_probed, t_uploaded - t_assembled, wall_now() - t_uploaded);
+      std::fprintf(stderr, "[mfmg_hip] amg level %d: P probes %.2f s, assembly %.2f s, transpose %.2f s\n", level,
+                   t_probed - t0, t_assembled - t_probed, wall_now() - t_assembled);
     const double t1 = wall_now();
 
     // ---- A_c = P^T A P by probing: coarse nodes (2 reach_c + 1) apart never meet in a row
     int period_a[3];
     for (int d = 0; d < 3; ++d)
-      period_a[d] = std::max(1, std::min(2 * c.reach + 1, gdims_c[d]));
+      period_a[d] = (int)std::max<int64_t>(1, std::min<int64_t>(2 * c.reach + 1, c.s.gn(d)));
     const int n_col_a = period_a[0] * period_a[1] * period_a[2] * C;
-    const int64_t crow0 = c.owned_row_begin(), cn_own = c.owned_rows();
-    DeviceBuffer<double> Y((size_t)n_col_a * (size_t)cn_own);
+    DeviceBuffer<double> Y((size_t)n_col_a * (size_t)n_c);
     for (int col = 0; col < n_col_a; ++col)
     {
       const int comp = col % C, oc = col / C;
       const int phase[3] = {oc % period_a[0], (oc / period_a[0]) % period_a[1], oc / (period_a[0] * period_a[1])};
-      vec::select_rows(h, c.dims, C, 1, (int)c.global_begin, period_a, phase, comp, nullptr, u_c.get_values());
+      double *y_c = Y.data() + (size_t)col * n_c;
+      vec::select_rows(h, cdims, C, 1, c_off, period_a, phase, comp, nullptr, u_c.get_values());
       p_mat->vmult(y_f.get_values(), u_c.get_values());
       h.exchange(g.space, y_f.get_values());
       a_op->get_matrix()->vmult(z_f.get_values(), y_f.get_values());
-      pt_mat->vmult(y_c.get_values(), z_f.get_values());
-      h.exchange_reverse_add(c.space, y_c.get_values());
-      MFMG_HIP_CHECK(hipMemcpyAsync(Y.data() + (size_t)col * cn_own, y_c.get_values() + crow0, (size_t)cn_own * sizeof(double),
-                                    hipMemcpyDeviceToDevice, h.stream));
+      pt_mat->vmult(y_c, z_f.get_values());
+      h.exchange_reverse_add(c.space, y_c);
     }
     MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
-    auto ac_mat = coarse_operator_from_probes(h, c.dims, gdims_c, C, c.reach, period_a, c.global_begin, crow0, cn_own, Y.data());
+    auto ac_mat = coarse_operator_from_probes(h, c.s, c.reach, period_a, Y.data());
     Y.release();
     if (verbose)
       std::fprintf(stderr, "[mfmg_hip] amg level %d on the device (%lld local rows, reach %d): P %d probes %.2f s, A_c %d probes %.2f s\n",
@@ -301,15 +297,14 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
   }
 }
 
-// The level `a_op` (owned rows in `A`, local numbering) becomes the first replicated level: its operator and near-null
+// The level `a_op` (owned rows in `A`, local numbering; `geom` its nodes) becomes the first replicated level: its operator and near-null
 // vector are gathered, the remaining hierarchy is built by the host code of one rank, identically on every rank.
 void HipSolver::finish_amg_replicated(std::shared_ptr<HipMatrixOperator> a_op, HostCsr A, std::vector<double> B, int space,
-                                      int64_t owned_begin, int64_t owned_count, int64_t global_begin, int64_t global_layers,
-                                      int const dims[3], int n_comp, AmgOptions const &opts, std::shared_ptr<ptree> smoother_params)
+                                      HaloSpace const &geom, AmgOptions const &opts, std::shared_ptr<ptree> smoother_params)
 {
   HipHandle &h = _handle;
   const bool distributed = h.comm.enabled() && space > 0;
-  const int64_t le = (int64_t)dims[0] * dims[1] * n_comp;
+  const int n_comp = geom.comps;
   HostCsr Ag;
   std::vector<double> Bg;
   if (!distributed)
@@ -319,39 +314,66 @@ void HipSolver::finish_amg_replicated(std::shared_ptr<HipMatrixOperator> a_op, H
   }
   else
   {
-    const int n_ranks = h.comm.n_ranks;
-    const int64_t row0 = owned_begin * le, n_own = owned_count * le, n_glob = global_layers * le;
-    ASSERT_THROW(n_own * n_ranks == n_glob, "internal: the slabs of a gathered level must have equal size");
-    const int64_t shift = global_begin * le; // local column -> global column
-    double nnz_max = (double)(A.row_ptr[row0 + n_own] - A.row_ptr[row0]);
-    nnz_max = h.allreduce_max(nnz_max);
-    const int64_t pad = (int64_t)nnz_max;
-    // [row lengths | near-null | columns (as doubles, exact) | values], padded to the same length on every rank
+    HaloCommunicator const &comm = h.comm;
+    const int n_ranks = comm.n_ranks;
+    const int64_t n_loc = geom.n_local(), n_own = geom.n_owned(), n_glob = geom.n_global();
+    ASSERT_THROW(n_own * n_ranks == n_glob, "internal: the boxes of a gathered level must have equal size");
+    // owned rows in local lexicographic order
+    std::vector<int64_t> own_rows;
+    own_rows.reserve((size_t)n_own);
+    int64_t nnz_own = 0;
+    for (int64_t i = 0; i < n_loc; ++i)
+      if (geom.owned(i))
+      {
+        own_rows.push_back(i);
+        nnz_own += A.row_ptr[i + 1] - A.row_ptr[i];
+      }
+    ASSERT_THROW((int64_t)own_rows.size() == n_own, "internal: owned rows of a gathered level");
+    const int64_t pad = (int64_t)h.allreduce_max((double)nnz_own);
+    // [row lengths | near-null | GLOBAL columns (as doubles, exact) | values], padded to the same length on every rank
     const int64_t each = 2 * n_own + 2 * pad;
     std::vector<double> send((size_t)each, 0.);
-    for (int64_t r = 0; r < n_own; ++r)
     {
-      send[r] = (double)(A.row_ptr[row0 + r + 1] - A.row_ptr[row0 + r]);
-      send[n_own + r] = B[row0 + r];
-    }
-    const int p0 = A.row_ptr[row0];
-    for (int p = p0; p < A.row_ptr[row0 + n_own]; ++p)
-    {
-      send[2 * n_own + (p - p0)] = (double)(A.col[p] + shift);
-      send[2 * n_own + pad + (p - p0)] = A.val[p];
+      int64_t q0 = 0;
+      for (int64_t q = 0; q < n_own; ++q)
+      {
+        const int64_t r = own_rows[q];
+        send[q] = (double)(A.row_ptr[r + 1] - A.row_ptr[r]);
+        send[n_own + q] = B[r];
+        for (int p = A.row_ptr[r]; p < A.row_ptr[r + 1]; ++p, ++q0)
+        {
+          send[2 * n_own + q0] = (double)geom.global_id(A.col[p]);
+          send[2 * n_own + pad + q0] = A.val[p];
+        }
+      }
     }
     DeviceBuffer<double> d_in((size_t)each), d_out((size_t)each * n_ranks);
     MFMG_HIP_CHECK(hipMemcpyAsync(d_in.data(), send.data(), (size_t)each * sizeof(double), hipMemcpyHostToDevice, h.stream));
     h.comm.transport->allgather(d_in.data(), each, d_out.data(), h.stream);
     std::vector<double> all = d_out.download(h.stream);
+    // q-th owned row of rank rk -> its global row (equal boxes: the owned box of rank rk starts at coord * owned nodes)
+    const int64_t on[3] = {geom.own_n(0), geom.own_n(1), geom.own_n(2)};
+    auto global_row = [&](int rk, int64_t q) {
+      const int cr[3] = {rk % comm.grid[0], (rk / comm.grid[0]) % comm.grid[1], rk / (comm.grid[0] * comm.grid[1])};
+      const int64_t nd = q / n_comp;
+      const int64_t o[3] = {nd % on[0], (nd / on[0]) % on[1], nd / (on[0] * on[1])};
+      int64_t gc[3];
+      for (int d = 0; d < 3; ++d)
+        gc[d] = (comm.grid[d] > 1 ? (int64_t)cr[d] * on[d] : 0) + o[d];
+      return ((gc[2] * geom.gn(1) + gc[1]) * geom.gn(0) + gc[0]) * n_comp + q % n_comp;
+    };
     Ag.n_rows = Ag.n_cols = n_glob;
     Ag.row_ptr.assign(n_glob + 1, 0);
     Bg.assign((size_t)n_glob, 0.);
+    std::vector<int32_t> from_ranked((size_t)n_glob, -1);
     for (int rk = 0; rk < n_ranks; ++rk)
-      for (int64_t r = 0; r < n_own; ++r)
+      for (int64_t q = 0; q < n_own; ++q)
       {
-        Ag.row_ptr[rk * n_own + r + 1] = (int32_t)all[(size_t)rk * each + r];
-        Bg[rk * n_own + r] = all[(size_t)rk * each + n_own + r];
+        const int64_t gr = global_row(rk, q);
+        ASSERT_THROW(gr >= 0 && gr < n_glob && from_ranked[gr] < 0, "internal: the boxes of a gathered level do not tile the global level");
+        from_ranked[gr] = (int32_t)(rk * n_own + q);
+        Ag.row_ptr[gr + 1] = (int32_t)all[(size_t)rk * each + q];
+        Bg[gr] = all[(size_t)rk * each + n_own + q];
       }
     for (int64_t r = 0; r < n_glob; ++r)
     {
@@ -362,25 +384,55 @@ void HipSolver::finish_amg_replicated(std::shared_ptr<HipMatrixOperator> a_op, H
     Ag.val.resize(Ag.row_ptr[n_glob]);
     for (int rk = 0; rk < n_ranks; ++rk)
     {
-      const int64_t base = Ag.row_ptr[rk * n_own];
-      const int64_t cnt = Ag.row_ptr[(rk + 1) * n_own] - base;
-      for (int64_t q = 0; q < cnt; ++q)
+      int64_t q0 = 0;
+      for (int64_t q = 0; q < n_own; ++q)
       {
-        Ag.col[base + q] = (int32_t)all[(size_t)rk * each + 2 * n_own + q];
-        Ag.val[base + q] = all[(size_t)rk * each + 2 * n_own + pad + q];
+        const int64_t gr = global_row(rk, q);
+        const int64_t len = Ag.row_ptr[gr + 1] - Ag.row_ptr[gr];
+        for (int64_t e = 0; e < len; ++e, ++q0)
+        {
+          Ag.col[Ag.row_ptr[gr] + e] = (int32_t)all[(size_t)rk * each + 2 * n_own + q0];
+          Ag.val[Ag.row_ptr[gr] + e] = all[(size_t)rk * each + 2 * n_own + pad + q0];
+        }
       }
     }
+    // (the columns of a row arrive in local order; a box leaves them unsorted in the global numbering)
+    if (geom.split_xy())
+#pragma omp parallel for schedule(static)
+      for (int64_t r = 0; r < n_glob; ++r)
+      {
+        const int p0 = Ag.row_ptr[r], p1 = Ag.row_ptr[r + 1];
+        std::vector<std::pair<int32_t, double>> row((size_t)(p1 - p0));
+        for (int p = p0; p < p1; ++p)
+          row[p - p0] = {Ag.col[p], Ag.val[p]};
+        std::sort(row.begin(), row.end());
+        for (int p = p0; p < p1; ++p)
+        {
+          Ag.col[p] = row[p - p0].first;
+          Ag.val[p] = row[p - p0].second;
+        }
+      }
     _amg_gather_level = (int)_amg.size();
     _gather_space = space;
     _gather_in.resize((size_t)n_own);
     _gather_b = std::make_shared<DVector>(h, n_glob);
     _gather_x = std::make_shared<DVector>(h, n_glob);
+    if (geom.split_xy())
+    {
+      std::vector<int32_t> local_ids((size_t)n_loc);
+      for (int64_t i = 0; i < n_loc; ++i)
+        local_ids[i] = (int32_t)geom.global_id(i);
+      _gather_ranked.resize((size_t)n_glob);
+      _gather_from_ranked.upload(from_ranked.data(), from_ranked.size(), h.stream);
+      _gather_local_ids.upload(local_ids.data(), local_ids.size(), h.stream);
+      MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
+    }
   }
   // geometric hint of the (global) level: the same blocks of nodes the distributed levels use
   AmgGridHint hint;
-  hint.dims[0] = dims[0];
-  hint.dims[1] = dims[1];
-  hint.dims[2] = (int)global_layers;
+  hint.dims[0] = (int)geom.gn(0);
+  hint.dims[1] = (int)geom.gn(1);
+  hint.dims[2] = (int)geom.gn(2);
   hint.n_components = n_comp;
   hint.node_of_row.resize((size_t)Ag.n_rows);
   hint.component_of_row.resize((size_t)Ag.n_rows);

@@ -157,6 +157,44 @@ int mfmg_hip_context_set_communicator(mfmg_hip_context_t ctx, int32_t rank, int3
     c.n_ranks = n_ranks;
     c.ghost_cells_low = ghost_cells_low;
     c.ghost_cells_high = ghost_cells_high;
+    c.grid[2] = n_ranks;
+    c.coord[2] = rank;
+    c.ghost_lo[2] = ghost_cells_low;
+    c.ghost_hi[2] = ghost_cells_high;
+  });
+}
+
+int mfmg_hip_context_set_communicator_box(mfmg_hip_context_t ctx, int32_t rank, const int32_t grid[3], const int32_t ghost_low[3],
+                                          const int32_t ghost_high[3])
+{
+  return guarded([&] {
+    require(ctx != nullptr && grid && ghost_low && ghost_high, "null argument");
+    require(grid[0] >= 1 && grid[1] >= 1 && grid[2] >= 1, "the grid of ranks needs at least one rank per axis");
+    const int n_ranks = grid[0] * grid[1] * grid[2];
+    require(rank >= 0 && rank < n_ranks, "rank out of range");
+    const int coord[3] = {rank % grid[0], (rank / grid[0]) % grid[1], rank / (grid[0] * grid[1])};
+    for (int d = 0; d < 3; ++d)
+    {
+      require((ghost_low[d] == 0 || ghost_low[d] == 2) && (ghost_high[d] == 0 || ghost_high[d] == 2),
+              "ghost cell layers must be 0 or 2 (one agglomerate layer)");
+      require((ghost_low[d] == 2) == (coord[d] > 0) && (ghost_high[d] == 2) == (coord[d] + 1 < grid[d]),
+              "ghost layers must be present exactly towards existing neighbours");
+    }
+    HaloCommunicator &c = ctx->handle->comm;
+    auto transport = c.transport;
+    c = HaloCommunicator();
+    c.transport = transport;
+    c.rank = rank;
+    c.n_ranks = n_ranks;
+    for (int d = 0; d < 3; ++d)
+    {
+      c.grid[d] = grid[d];
+      c.coord[d] = coord[d];
+      c.ghost_lo[d] = ghost_low[d];
+      c.ghost_hi[d] = ghost_high[d];
+    }
+    c.ghost_cells_low = ghost_low[2];
+    c.ghost_cells_high = ghost_high[2];
   });
 }
 
@@ -242,6 +280,14 @@ int mfmg_hip_context_exchange_count(mfmg_hip_context_t ctx, int64_t *n_exchanges
   });
 }
 
+int mfmg_hip_context_exchange_volume(mfmg_hip_context_t ctx, int64_t *n_doubles_sent)
+{
+  return guarded([&] {
+    require(ctx != nullptr && n_doubles_sent != nullptr, "null argument");
+    *n_doubles_sent = ctx->handle->comm.n_doubles_sent;
+  });
+}
+
 int mfmg_hip_context_exchange(mfmg_hip_context_t ctx, int32_t space, double *vector, int reverse)
 {
   return guarded([&] {
@@ -259,9 +305,8 @@ int mfmg_hip_context_owned_dot(mfmg_hip_context_t ctx, int32_t space, const doub
     require(ctx != nullptr && x && y && result, "null argument");
     HipHandle &h = *ctx->handle;
     require(space > 0 && space < (int)h.comm.spaces.size() && h.comm.spaces[space].configured(), "unknown vector space");
-    HaloSpace const &s = h.comm.spaces[space];
-    const int64_t off = s.owned_begin * s.layer_elems, n = s.owned_count * s.layer_elems;
-    *result = h.allreduce_sum(vec::dot<double>(h, n, x + off, y + off));
+    DVector vx(h, h.comm.spaces[space].n_local(), const_cast<double *>(x)), vy(h, h.comm.spaces[space].n_local(), const_cast<double *>(y));
+    *result = distributed_dot(h, space, vx, vy);
   });
 }
 
@@ -365,6 +410,24 @@ int mfmg_hip_context_halo_space(mfmg_hip_context_t ctx, int32_t space, int64_t o
     out[5] = s.global_layers;
     out[6] = s.width;
     out[7] = (int64_t)ctx->handle->comm.spaces.size();
+  });
+}
+
+int mfmg_hip_context_halo_box(mfmg_hip_context_t ctx, int32_t space, int64_t out[16])
+{
+  return guarded([&] {
+    require(ctx != nullptr && out != nullptr, "null argument");
+    require(space >= 1 && space < (int)ctx->handle->comm.spaces.size(), "unknown vector space");
+    HaloSpace const &s = ctx->handle->comm.spaces[space];
+    out[0] = s.comps;
+    for (int d = 0; d < 3; ++d)
+    {
+      out[1 + d] = s.dim(d);
+      out[4 + d] = s.own0(d);
+      out[7 + d] = s.own_n(d);
+      out[10 + d] = s.g0(d);
+      out[13 + d] = s.gn(d);
+    }
   });
 }
 

@@ -259,41 +259,99 @@ struct KernelProfiler
   }
 };
 
-// ---- distributed vectors: slab decomposition along the slowest index ----
+// ---- distributed vectors: slabs along the slowest index, or boxes ----
 // The reference gets its ghost exchange from deal.II's distributed::Vector inside
 // MatrixFree::cell_loop / Epetra Import (and all-gathers the whole vector on the CUDA path,
-// source/cuda/utils.cu:363-482).  Here a rank's vector is [ghost layers | owned layers | ghost layers],
-// layers contiguous and the local layers a contiguous run of the global ones.  Every level of the cycle has
-// its own space (fine DoF planes, agglomerate layers, the node layers of the aggregation levels):
+// source/cuda/utils.cu:363-482).  Here a rank's vector is the lexicographic array of its local box of nodes --
+// the nodes it owns plus the ghost layers that belong to its neighbours -- with `comps` entries per node.  Every
+// level of the cycle has its own space (fine DoFs, agglomerates, the nodes of the aggregation levels):
 //   forward exchange     owner -> ghost: the `width` owned layers next to each neighbour refresh that
 //                        neighbour's nearest `width` ghost layers (before an operator reads them);
 //   reverse-add exchange ghost -> owner: the `width` ghost layers are sent back and ADDED to the owner's
 //                        boundary layers (after a transposed prolongator scattered partial sums into them).
+// The ranks form a grid[0] x grid[1] x grid[2] arrangement (rank = cx + grid[0] (cy + grid[1] cz)); 1 x 1 x N are slabs
+// along z, whose layers are contiguous runs of the vector and travel without packing.  A box exchanges axis after
+// axis -- x, then y with the x ghosts just received, then z with both -- so that edges and corners arrive through the
+// six face neighbours (two messages per split axis, no diagonal partners); the reverse exchange runs z, y, x.
 struct HaloSpace
 {
-  int64_t layer_elems = 0;  // entries per layer (a DoF plane, a layer of agglomerates / aggregates)
-  int64_t n_layers = 0;     // layers of the local vector
+  // z (the slowest axis)
+  int64_t layer_elems = 0;  // entries per z layer (a DoF plane, a layer of agglomerates / aggregates)
+  int64_t n_layers = 0;     // z layers of the local vector
   int64_t owned_begin = 0;  // first owned layer
   int64_t owned_count = 0;  // owned layers
   int64_t global_begin = 0; // global index of local layer 0
   int64_t global_layers = 0;
   int width = 1;            // layers moved per side by an exchange (<= the ghost layers present on that side)
   bool has_low = false, has_high = false;
+  // x and y ([0], [1]): whole in a slab run (own = local = global)
+  int comps = 1;                        // entries per node
+  int64_t n_xy[2] = {0, 0};             // local nodes (layer_elems = comps n_xy[0] n_xy[1])
+  int64_t own0_xy[2] = {0, 0}, own_n_xy[2] = {0, 0};
+  int64_t g0_xy[2] = {0, 0}, gn_xy[2] = {0, 0}; // global index of local node 0, global nodes
+  bool low_xy[2] = {false, false}, high_xy[2] = {false, false};
   bool configured() const { return layer_elems > 0; }
   int64_t ghost_low() const { return owned_begin; }
   int64_t ghost_high() const { return n_layers - owned_begin - owned_count; }
+  bool split_xy() const { return low_xy[0] || high_xy[0] || low_xy[1] || high_xy[1]; }
+  // x and y not split: one rank holds every node of a layer
+  void set_whole_xy(int64_t nx, int64_t ny, int n_comps)
+  {
+    comps = n_comps;
+    n_xy[0] = own_n_xy[0] = gn_xy[0] = nx;
+    n_xy[1] = own_n_xy[1] = gn_xy[1] = ny;
+    own0_xy[0] = own0_xy[1] = g0_xy[0] = g0_xy[1] = 0;
+    low_xy[0] = low_xy[1] = high_xy[0] = high_xy[1] = false;
+  }
+  // the three axes alike (d = 2: z)
+  int64_t dim(int d) const { return d == 2 ? n_layers : n_xy[d]; }
+  int64_t own0(int d) const { return d == 2 ? owned_begin : own0_xy[d]; }
+  int64_t own_n(int d) const { return d == 2 ? owned_count : own_n_xy[d]; }
+  int64_t g0(int d) const { return d == 2 ? global_begin : g0_xy[d]; }
+  int64_t gn(int d) const { return d == 2 ? global_layers : gn_xy[d]; }
+  bool low(int d) const { return d == 2 ? has_low : low_xy[d]; }
+  bool high(int d) const { return d == 2 ? has_high : high_xy[d]; }
+  int64_t n_local() const { return layer_elems * n_layers; }
+  int64_t n_owned() const { return comps * own_n_xy[0] * own_n_xy[1] * owned_count; }
+  int64_t n_global() const { return comps * gn_xy[0] * gn_xy[1] * global_layers; }
+  void check() const
+  {
+    if (layer_elems != comps * n_xy[0] * n_xy[1])
+      throw std::runtime_error("internal: halo space without its x / y description");
+  }
+  // entry i of a local vector: its node, whether this rank owns it, its position in the global lexicographic vector
+  void node_of(int64_t i, int64_t c[3]) const
+  {
+    const int64_t nd = i / comps;
+    c[0] = nd % n_xy[0];
+    c[1] = (nd / n_xy[0]) % n_xy[1];
+    c[2] = nd / (n_xy[0] * n_xy[1]);
+  }
+  bool owned(int64_t i) const
+  {
+    int64_t c[3];
+    node_of(i, c);
+    return c[0] >= own0_xy[0] && c[0] < own0_xy[0] + own_n_xy[0] && c[1] >= own0_xy[1] && c[1] < own0_xy[1] + own_n_xy[1] &&
+           c[2] >= owned_begin && c[2] < owned_begin + owned_count;
+  }
+  int64_t global_id(int64_t i) const
+  {
+    int64_t c[3];
+    node_of(i, c);
+    return (((c[2] + global_begin) * gn_xy[1] + (c[1] + g0_xy[1])) * gn_xy[0] + (c[0] + g0_xy[0])) * comps + i % comps;
+  }
 };
 
-// Point-to-point transport between slab neighbours + the few collectives of the setup.  Two implementations:
+// Point-to-point transport between neighbours + the few collectives of the setup.  Two implementations:
 // RCCL send/recv over xGMI on the caller's stream (one process per GPU), and host callbacks (the library stages
 // through pinned host buffers; gloo in the tests, where several ranks share one card).
 struct HaloTransport
 {
   virtual ~HaloTransport() = default;
-  // exchange n_low doubles with rank - 1 and n_high with rank + 1 (device pointers; a count of 0 = no neighbour);
-  // enqueued on `stream` (the host transport synchronises the stream around its callbacks)
-  virtual void sendrecv(double const *send_low, double *recv_low, int64_t n_low, double const *send_high, double *recv_high,
-                        int64_t n_high, hipStream_t stream) = 0;
+  // exchange n_low doubles with rank `peer_low` and n_high with rank `peer_high` (device pointers; a count of 0 = no
+  // neighbour); enqueued on `stream` (the host transport synchronises the stream around its callbacks)
+  virtual void sendrecv(int peer_low, int peer_high, double const *send_low, double *recv_low, int64_t n_low, double const *send_high,
+                        double *recv_high, int64_t n_high, hipStream_t stream) = 0;
   virtual void allreduce(double *host_values, int n, int op /* 0 sum, 1 max */, hipStream_t stream) = 0;
   // every rank contributes n doubles (device), `out` (device) receives n * n_ranks in rank order
   virtual void allgather(double const *in, int64_t n, double *out, hipStream_t stream) = 0;
@@ -305,15 +363,23 @@ struct HaloTransport
 struct HaloCommunicator
 {
   int rank = 0, n_ranks = 1;
-  int ghost_cells_low = 0, ghost_cells_high = 0; // ghost cell layers of the local mesh along z
+  int grid[3] = {1, 1, 1};  // ranks along x, y, z (slabs: 1 x 1 x n_ranks)
+  int coord[3] = {0, 0, 0}; // this rank's position
+  int ghost_lo[3] = {0, 0, 0}, ghost_hi[3] = {0, 0, 0}; // ghost cell layers of the local mesh per axis
+  int ghost_cells_low = 0, ghost_cells_high = 0;        // ... those along z
   std::shared_ptr<HaloTransport> transport;
   std::vector<HaloSpace> spaces = std::vector<HaloSpace>(3); // [0] rank-local, [1] fine DoFs, [2] first coarse level, then the aggregation levels
   int64_t n_exchanges = 0; // (diagnostics) point-to-point exchanges issued so far
+  int64_t n_doubles_sent = 0; // ... and the doubles this rank sent in them
   // The spaces from [2] on describe the levels of ONE hierarchy (its operators hold indices into `spaces`): the
   // hierarchy helpers that configured them own them until they are destroyed; a second hierarchy on the same
   // communicator is refused while the first is alive (it would re-purpose spaces the first one still exchanges with).
   void const *spaces_owner = nullptr;
   bool enabled() const { return n_ranks > 1; }
+  bool split_xy() const { return grid[0] > 1 || grid[1] > 1; }
+  int stride(int d) const { return d == 0 ? 1 : (d == 1 ? grid[0] : grid[0] * grid[1]); }
+  bool has_lower(int d) const { return coord[d] > 0; }
+  bool has_upper(int d) const { return coord[d] + 1 < grid[d]; }
   int add_space(HaloSpace const &s)
   {
     spaces.push_back(s);
@@ -322,6 +388,12 @@ struct HaloCommunicator
 };
 
 void halo_add_layers(double *dst, double const *src, int64_t n, hipStream_t stream); // dst += src (vector_ops.hip)
+// `count` runs of `run` doubles, `stride` apart in `v`, against the contiguous `buf`: mode 0 buf = v (pack), 1 v = buf (unpack),
+// 2 v += buf (vector_ops.hip)
+void halo_strided_runs(double *v, int64_t stride, int64_t run, int64_t count, double *buf, int mode, hipStream_t stream);
+// the owned sub-box (or the whole local box) of a vector of space `s` against the contiguous buf: mode 0 buf = v, 1 v = buf
+void halo_box_copy(double *v, HaloSpace const &s, bool owned_only, double *buf, int mode, hipStream_t stream);
+void gather_indexed(int64_t n, double const *in, int32_t const *index, double *out, hipStream_t stream); // out[i] = in[index[i]]
 
 // ---- HipHandle: stream + reduction scratch; twin of CudaHandle
 //      (include/mfmg/cuda/cuda_handle.cuh:25-48): borrowed by every object built from it ----
@@ -351,9 +423,11 @@ struct HipHandle
   double *host_result = nullptr; // pinned
   KernelProfiler profiler;
   HaloCommunicator comm;
-  // staging of the reverse (adding) exchanges: [recv_low | recv_high], grown on demand
+  // staging of the reverse (adding) exchanges and of the packed x / y faces of a box exchange:
+  // [send_low | send_high | recv_low | recv_high], grown on demand
   DeviceBuffer<double> halo_staging;
   int64_t halo_staging_each = 0;
+  DeviceBuffer<double> dot_scratch; // owned entries of two box vectors, packed for a dot product
 
   HaloSpace &space_checked(int space)
   {
@@ -370,13 +444,44 @@ struct HipHandle
       MFMG_HIP_CHECK(hipStreamSynchronize(stream));
       if (comm_stream)
         MFMG_HIP_CHECK(hipStreamSynchronize(comm_stream));
-      halo_staging.resize((size_t)2 * each);
+      halo_staging.resize((size_t)4 * each);
       halo_staging_each = each;
     }
   }
-  // forward exchange on `st`.  The `width` owned layers next to a neighbour and the ghost layers they refresh are contiguous
-  // runs of the vector (slabs along z, lexicographic layers): the transport sends from and receives into the vector itself
+  // One split axis (d = 0: x, 1: y) of a box exchange on `st`: the `width` layers next to each neighbour along d, over the whole
+  // local extent of the other two axes, are `count` runs of `run` entries `stride` apart -- packed, sent to the two face
+  // neighbours, unpacked into (forward) or added to (reverse) the layers they belong to.
+  void exchange_axis_xy(HaloSpace const &s, double *v, int d, bool reverse, hipStream_t st)
+  {
+    if (!s.low_xy[d] && !s.high_xy[d])
+      return;
+    const int64_t unit = d == 0 ? s.comps : s.comps * s.n_xy[0]; // entries from one layer along d to the next
+    const int64_t run = s.width * unit;
+    const int64_t stride = d == 0 ? s.comps * s.n_xy[0] : s.layer_elems;
+    const int64_t count = d == 0 ? s.n_xy[1] * s.n_layers : s.n_layers;
+    const int64_t n = run * count;
+    staging_reserve(n);
+    double *sl = halo_staging.data(), *sh = sl + halo_staging_each, *rl = sh + halo_staging_each, *rh = rl + halo_staging_each;
+    const int64_t o0 = s.own0_xy[d], o1 = o0 + s.own_n_xy[d];
+    const int64_t src_low = (reverse ? o0 - s.width : o0) * unit, src_high = (reverse ? o1 : o1 - s.width) * unit;
+    const int64_t dst_low = (reverse ? o0 : o0 - s.width) * unit, dst_high = (reverse ? o1 - s.width : o1) * unit;
+    if (s.low_xy[d])
+      halo_strided_runs(v + src_low, stride, run, count, sl, 0, st);
+    if (s.high_xy[d])
+      halo_strided_runs(v + src_high, stride, run, count, sh, 0, st);
+    comm.transport->sendrecv(comm.rank - comm.stride(d), comm.rank + comm.stride(d), sl, rl, s.low_xy[d] ? n : 0, sh, rh,
+                             s.high_xy[d] ? n : 0, st);
+    ++comm.n_exchanges;
+    comm.n_doubles_sent += (s.low_xy[d] ? n : 0) + (s.high_xy[d] ? n : 0);
+    if (s.low_xy[d])
+      halo_strided_runs(v + dst_low, stride, run, count, rl, reverse ? 2 : 1, st);
+    if (s.high_xy[d])
+      halo_strided_runs(v + dst_high, stride, run, count, rh, reverse ? 2 : 1, st);
+  }
+  // forward exchange on `st`.  Along z the `width` owned layers next to a neighbour and the ghost layers they refresh are
+  // contiguous runs of the vector (lexicographic layers): the transport sends from and receives into the vector itself
   // -- no packing, no staging copies (round 2 moved every layer through a staging buffer: four device copies per exchange).
+  // A box exchanges x and y first (packed), so that the z layers carry their ghost columns with them.
   void exchange_on(HaloSpace const &s, double *v, hipStream_t pack_stream, hipStream_t st, bool split)
   {
     const int64_t n = (int64_t)s.width * s.layer_elems;
@@ -388,8 +493,14 @@ struct HipHandle
       MFMG_HIP_CHECK(hipEventRecord(ev_packed, pack_stream));
       MFMG_HIP_CHECK(hipStreamWaitEvent(st, ev_packed, 0));
     }
-    comm.transport->sendrecv(send_low, recv_low, s.has_low ? n : 0, send_high, recv_high, s.has_high ? n : 0, st);
+    exchange_axis_xy(s, v, 0, false, st);
+    exchange_axis_xy(s, v, 1, false, st);
+    if (!s.has_low && !s.has_high)
+      return;
+    comm.transport->sendrecv(comm.rank - comm.stride(2), comm.rank + comm.stride(2), send_low, recv_low, s.has_low ? n : 0, send_high,
+                             recv_high, s.has_high ? n : 0, st);
     ++comm.n_exchanges;
+    comm.n_doubles_sent += (s.has_low ? n : 0) + (s.has_high ? n : 0);
   }
   // refresh the ghost layers of a distributed vector (no-op on one rank / for local spaces)
   void exchange(int space, double *v)
@@ -424,23 +535,31 @@ struct HipHandle
       return;
     MFMG_HIP_CHECK(hipStreamWaitEvent(stream, ev_unpacked, 0));
   }
-  // ghost -> owner: the ghost layers hold partial sums that belong to the neighbours' boundary layers
+  // ghost -> owner: the ghost layers hold partial sums that belong to the neighbours' boundary layers (z first, then y
+  // and x: the sums a z layer received in ITS ghost columns travel on to their owners)
   void exchange_reverse_add(int space, double *v)
   {
     if (!comm.enabled() || space <= 0)
       return;
     HaloSpace &s = space_checked(space);
-    const int64_t n = (int64_t)s.width * s.layer_elems;
-    staging_reserve(n);
-    // the ghost layers are sent as they lie; what comes back is added to the owned boundary layers, so it is received in staging
-    double const *send_low = v + (s.owned_begin - s.width) * s.layer_elems, *send_high = v + (s.owned_begin + s.owned_count) * s.layer_elems;
-    double *recv_low = halo_staging.data(), *recv_high = recv_low + halo_staging_each;
-    comm.transport->sendrecv(send_low, recv_low, s.has_low ? n : 0, send_high, recv_high, s.has_high ? n : 0, stream);
-    ++comm.n_exchanges;
-    if (s.has_low)
-      halo_add_layers(v + s.owned_begin * s.layer_elems, recv_low, n, stream);
-    if (s.has_high)
-      halo_add_layers(v + (s.owned_begin + s.owned_count - s.width) * s.layer_elems, recv_high, n, stream);
+    if (s.has_low || s.has_high)
+    {
+      const int64_t n = (int64_t)s.width * s.layer_elems;
+      staging_reserve(n);
+      // the ghost layers are sent as they lie; what comes back is added to the owned boundary layers, so it is received in staging
+      double const *send_low = v + (s.owned_begin - s.width) * s.layer_elems, *send_high = v + (s.owned_begin + s.owned_count) * s.layer_elems;
+      double *recv_low = halo_staging.data() + 2 * halo_staging_each, *recv_high = recv_low + halo_staging_each;
+      comm.transport->sendrecv(comm.rank - comm.stride(2), comm.rank + comm.stride(2), send_low, recv_low, s.has_low ? n : 0, send_high,
+                               recv_high, s.has_high ? n : 0, stream);
+      ++comm.n_exchanges;
+      comm.n_doubles_sent += (s.has_low ? n : 0) + (s.has_high ? n : 0);
+      if (s.has_low)
+        halo_add_layers(v + s.owned_begin * s.layer_elems, recv_low, n, stream);
+      if (s.has_high)
+        halo_add_layers(v + (s.owned_begin + s.owned_count - s.width) * s.layer_elems, recv_high, n, stream);
+    }
+    exchange_axis_xy(s, v, 1, true, stream);
+    exchange_axis_xy(s, v, 0, true, stream);
   }
   double allreduce_sum(double v)
   {

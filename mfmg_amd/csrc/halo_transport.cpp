@@ -109,8 +109,8 @@ public:
     if (_comm)
       (void)rccl().CommDestroy(_comm);
   }
-  void sendrecv(double const *send_low, double *recv_low, int64_t n_low, double const *send_high, double *recv_high, int64_t n_high,
-                hipStream_t stream) override
+  void sendrecv(int peer_low, int peer_high, double const *send_low, double *recv_low, int64_t n_low, double const *send_high,
+                double *recv_high, int64_t n_high, hipStream_t stream) override
   {
     if (n_low <= 0 && n_high <= 0)
       return;
@@ -118,13 +118,13 @@ public:
     rccl_check(r.GroupStart(), "ncclGroupStart");
     if (n_low > 0)
     {
-      rccl_check(r.Send(send_low, (size_t)n_low, ncclFloat64, _rank - 1, _comm, stream), "ncclSend");
-      rccl_check(r.Recv(recv_low, (size_t)n_low, ncclFloat64, _rank - 1, _comm, stream), "ncclRecv");
+      rccl_check(r.Send(send_low, (size_t)n_low, ncclFloat64, peer_low, _comm, stream), "ncclSend");
+      rccl_check(r.Recv(recv_low, (size_t)n_low, ncclFloat64, peer_low, _comm, stream), "ncclRecv");
     }
     if (n_high > 0)
     {
-      rccl_check(r.Send(send_high, (size_t)n_high, ncclFloat64, _rank + 1, _comm, stream), "ncclSend");
-      rccl_check(r.Recv(recv_high, (size_t)n_high, ncclFloat64, _rank + 1, _comm, stream), "ncclRecv");
+      rccl_check(r.Send(send_high, (size_t)n_high, ncclFloat64, peer_high, _comm, stream), "ncclSend");
+      rccl_check(r.Recv(recv_high, (size_t)n_high, ncclFloat64, peer_high, _comm, stream), "ncclRecv");
     }
     rccl_check(r.GroupEnd(), "ncclGroupEnd");
   }
@@ -171,8 +171,8 @@ public:
     if (_host)
       (void)hipHostFree(_host);
   }
-  void sendrecv(double const *send_low, double *recv_low, int64_t n_low, double const *send_high, double *recv_high, int64_t n_high,
-                hipStream_t stream) override
+  void sendrecv(int peer_low, int peer_high, double const *send_low, double *recv_low, int64_t n_low, double const *send_high,
+                double *recv_high, int64_t n_high, hipStream_t stream) override
   {
     if (n_low <= 0 && n_high <= 0)
       return;
@@ -184,7 +184,7 @@ public:
     if (n_high > 0)
       MFMG_HIP_CHECK(hipMemcpyAsync(h_sh, send_high, n_high * sizeof(double), hipMemcpyDeviceToHost, stream));
     MFMG_HIP_CHECK(hipStreamSynchronize(stream));
-    if (_sr(_user, h_sl, h_rl, n_low, h_sh, h_rh, n_high) != 0)
+    if (_sr(_user, peer_low, peer_high, h_sl, h_rl, n_low, h_sh, h_rh, n_high) != 0)
       throw std::runtime_error("halo exchange transport failed");
     if (n_low > 0)
       MFMG_HIP_CHECK(hipMemcpyAsync(recv_low, h_rl, n_low * sizeof(double), hipMemcpyHostToDevice, stream));

@@ -61,15 +61,26 @@ double distributed_dot(HipHandle &handle, int space, DVector const &x, DVector c
   if (!handle.comm.enabled() || space <= 0)
     return x * y;
   HaloSpace const &s = handle.comm.spaces[space];
-  const int64_t off = s.owned_begin * s.layer_elems, n = s.owned_count * s.layer_elems;
-  const double local = vec::dot<double>(handle, n, x.get_values() + off, y.get_values() + off);
-  return handle.allreduce_sum(local);
+  if (!s.split_xy())
+  {
+    const int64_t off = s.owned_begin * s.layer_elems, n = s.owned_count * s.layer_elems;
+    const double local = vec::dot<double>(handle, n, x.get_values() + off, y.get_values() + off);
+    return handle.allreduce_sum(local);
+  }
+  // boxes: the owned entries are a sub-box of the local array -- packed, then the same dot product (setup and monitoring only)
+  const int64_t n = s.n_owned();
+  if ((int64_t)handle.dot_scratch.size() < 2 * n)
+    handle.dot_scratch.resize((size_t)2 * n);
+  double *a = handle.dot_scratch.data(), *b = a + n;
+  halo_box_copy(const_cast<double *>(x.get_values()), s, true, a, 0, handle.stream);
+  halo_box_copy(const_cast<double *>(y.get_values()), s, true, b, 0, handle.stream);
+  return handle.allreduce_sum(vec::dot<double>(handle, n, a, b));
 }
 
 namespace
 {
-// rows outside [row_begin, row_end) become empty: a rank computes only the rows it owns
-void empty_rows_outside(HostCsr &m, int64_t row_begin, int64_t row_end)
+// rows this rank does not own become empty: a rank computes only the rows it owns
+void empty_rows_outside(HostCsr &m, HaloSpace const &space)
 {
   std::vector<int32_t> rp(m.n_rows + 1, 0), cl;
   std::vector<double> vl;
@@ -77,7 +88,7 @@ void empty_rows_outside(HostCsr &m, int64_t row_begin, int64_t row_end)
   vl.reserve(m.val.size());
   for (int64_t r = 0; r < m.n_rows; ++r)
   {
-    if (r >= row_begin && r < row_end)
+    if (space.owned(r))
       for (int p = m.row_ptr[r]; p < m.row_ptr[r + 1]; ++p)
       {
         cl.push_back(m.col[p]);
@@ -168,24 +179,44 @@ HipMatrixFreeMeshEvaluator::HipMatrixFreeMeshEvaluator(HipHandle &handle, mfmg_h
   HaloCommunicator &c = handle.comm;
   if (c.enabled())
   {
-    // fine DoF space: z-planes of the local (extended) mesh; owned planes [z0, z1) (+ the top plane on the
-    // last rank); the planes below / above belong to the neighbours
+    // fine DoF space: the nodes of the local (extended) mesh; per axis the owned planes [z0, z1) (+ the top plane on the
+    // last rank of the axis); the planes below / above belong to the neighbours
     ASSERT_THROW(_mesh.dim == 3, "distributed runs need a 3-D mesh");
     HaloSpace &s = c.spaces[1];
     s = HaloSpace();
+    s.comps = 1;
     s.layer_elems = (int64_t)_mesh.N[0] * _mesh.N[1];
     s.n_layers = _mesh.N[2];
-    s.has_low = c.ghost_cells_low > 0;
-    s.has_high = c.ghost_cells_high > 0;
-    s.owned_begin = c.ghost_cells_low;
-    s.owned_count = _mesh.N[2] - c.ghost_cells_low - (s.has_high ? c.ghost_cells_high + 1 : 0);
     s.width = 1; // operator applications read one plane of each neighbour
-    // uniform slabs: every rank owns the same number of cell layers, so the global position follows from the rank
-    const int64_t own_cells = _mesh.n[2] - c.ghost_cells_low - c.ghost_cells_high;
-    s.global_begin = (int64_t)c.rank * own_cells - c.ghost_cells_low;
-    s.global_layers = (int64_t)c.n_ranks * own_cells + 1;
-    ASSERT_THROW(s.owned_count >= 2 && s.owned_count % 2 == (s.has_high ? 0 : 1),
-                 "the owned slab must hold a whole number of agglomerate layers");
+    for (int d = 0; d < 3; ++d)
+    {
+      const bool low = c.ghost_lo[d] > 0, high = c.ghost_hi[d] > 0;
+      ASSERT_THROW(low == c.has_lower(d) && high == c.has_upper(d), "ghost cell layers do not match the grid of ranks");
+      const int64_t own0 = c.ghost_lo[d], own_n = _mesh.N[d] - c.ghost_lo[d] - (high ? c.ghost_hi[d] + 1 : 0);
+      // equal boxes: every rank owns the same number of cell layers, so the global position follows from the rank
+      const int64_t own_cells = _mesh.n[d] - c.ghost_lo[d] - c.ghost_hi[d];
+      const int64_t g0 = (int64_t)c.coord[d] * own_cells - c.ghost_lo[d], gn = (int64_t)c.grid[d] * own_cells + 1;
+      ASSERT_THROW(own_n >= 2 && own_n % 2 == (high ? 0 : 1), "the owned box must hold a whole number of agglomerates per axis");
+      if (d == 2)
+      {
+        s.has_low = low;
+        s.has_high = high;
+        s.owned_begin = own0;
+        s.owned_count = own_n;
+        s.global_begin = g0;
+        s.global_layers = gn;
+      }
+      else
+      {
+        s.n_xy[d] = _mesh.N[d];
+        s.low_xy[d] = low;
+        s.high_xy[d] = high;
+        s.own0_xy[d] = own0;
+        s.own_n_xy[d] = own_n;
+        s.g0_xy[d] = g0;
+        s.gn_xy[d] = gn;
+      }
+    }
     // local numbering must be lexicographic so that planes are contiguous
     for (int64_t nd = 0; nd < (int64_t)_mesh.node_dof.size(); nd += std::max<int64_t>(1, (int64_t)_mesh.node_dof.size() / 4099))
       ASSERT_THROW(_mesh.node_dof[nd] == nd, "distributed runs need lexicographic local DoF numbering");
@@ -291,6 +322,9 @@ bool HipMatrixOperator::prepare_residual_restriction(std::shared_ptr<Operator<DV
     return false;
   const bool distributed = hd.comm.enabled();
   if (distributed && !(_domain_space == 1 && _range_space == 2))
+    return false;
+  // (the classes of the one-pass kernel count distances to the faces of a slab: a box keeps residual + restriction in two steps)
+  if (distributed && hd.comm.split_xy())
     return false;
   const int64_t n = _matrix->n(), nc = _matrix->m();
   auto apply_a = [&](double const *v, double *w) {
@@ -425,17 +459,23 @@ std::shared_ptr<Operator<DVector>> HipMatrixOperator::multiply(std::shared_ptr<O
       // 27 n_eig operator applications instead of one per coarse column.
       const int ne = _structured->n_eigenvectors();
       const int na[3] = {_structured->agglomerates(0), _structured->agglomerates(1), _structured->agglomerates(2)};
-      // z: period and phase on the global layer index (local layer + zoff), rows of the owned layers only
-      int64_t zoff = 0, z_own0 = 0, z_own1 = na[2], z_glob = na[2];
+      // period and phase on the GLOBAL agglomerate index (local + offset), rows of the owned agglomerates only
+      int off[3] = {0, 0, 0};
+      int64_t own0[3] = {0, 0, 0}, own1[3] = {na[0], na[1], na[2]}, glob[3] = {na[0], na[1], na[2]};
       if (distributed)
       {
         HaloSpace const &cs = hd.comm.spaces[_range_space];
-        zoff = cs.global_begin;
-        z_own0 = cs.owned_begin;
-        z_own1 = cs.owned_begin + cs.owned_count;
-        z_glob = cs.global_layers;
+        cs.check();
+        for (int d = 0; d < 3; ++d)
+        {
+          ASSERT_THROW(cs.dim(d) == na[d], "internal: coarse space does not match the agglomerate grid");
+          off[d] = (int)cs.g0(d);
+          own0[d] = cs.own0(d);
+          own1[d] = cs.own0(d) + cs.own_n(d);
+          glob[d] = cs.gn(d);
+        }
       }
-      const int k[3] = {std::min(3, na[0]), std::min(3, na[1]), (int)std::min<int64_t>(3, z_glob)};
+      const int k[3] = {(int)std::min<int64_t>(3, glob[0]), (int)std::min<int64_t>(3, glob[1]), (int)std::min<int64_t>(3, glob[2])};
       const int64_t n_agg = (int64_t)na[0] * na[1] * na[2], nc = n_agg * ne;
       ASSERT_THROW(nc == _matrix->m(), "agglomerate grid does not match the restrictor");
       const int n_colors = k[0] * k[1] * k[2] * ne;
@@ -448,13 +488,13 @@ std::shared_ptr<Operator<DVector>> HipMatrixOperator::multiply(std::shared_ptr<O
         {
           const int e0 = color % ne, oc = color / ne;
           const int o[3] = {oc % k[0], (oc / k[0]) % k[1], oc / (k[0] * k[1])};
-          vec::probing_vector(hd, na, ne, k, o, e0, u->get_values(), (int)zoff);
+          vec::probing_vector(hd, na, ne, k, o, e0, u->get_values(), off);
           half->apply(*u, *w);
           DVector y(hd, nc, Y.data() + (size_t)color * (size_t)nc);
           this->apply(*w, y);
         }
       }
-      auto coarse = std::make_shared<HipMatrixOperator>(galerkin_from_probes(hd, na, ne, k, zoff, z_own0, z_own1, Y.data()));
+      auto coarse = std::make_shared<HipMatrixOperator>(galerkin_from_probes(hd, na, ne, k, off, own0, own1, Y.data()));
       coarse->set_spaces(_range_space, _range_space);
       return coarse;
     }
@@ -477,8 +517,7 @@ std::shared_ptr<Operator<DVector>> HipMatrixOperator::multiply(std::shared_ptr<O
     {
       // rows of agglomerates owned by the neighbours are incomplete on the local mesh: a rank applies
       // only its own rows, the others arrive by halo exchange
-      HaloSpace const &cs = hh.comm.spaces[2];
-      empty_rows_outside(Ac, cs.owned_begin * cs.layer_elems, (cs.owned_begin + cs.owned_count) * cs.layer_elems);
+      empty_rows_outside(Ac, hh.comm.spaces[2]);
     }
     auto coarse = std::make_shared<HipMatrixOperator>(upload(hh, std::move(Ac)));
     coarse->set_spaces(_range_space, _range_space);
@@ -576,7 +615,8 @@ void HipMatrixFreeOperator::apply_mode(MfMode mode, double const *x, double cons
     lo_end = (int)std::min<int64_t>(n_tiles, (s.owned_begin - 1 + 1) / tz + 1);
   if (s.has_high)
     hi_begin = (int)std::max<int64_t>(0, (s.owned_begin + s.owned_count + tz - 1) / tz - 1);
-  if (!handle.overlap_exchange || lo_end >= hi_begin)
+  // (a box reads ghost columns in every tile: exchange first)
+  if (!handle.overlap_exchange || lo_end >= hi_begin || s.split_xy())
   {
     handle.exchange(1, const_cast<double *>(x));
     whole();
@@ -753,24 +793,18 @@ void HipSmoother::estimate_eigenvalues(int n_iterations, double residual, double
   auto rhs = _hip_operator->build_range_vector();
   const int64_t n = rhs->size();
   {
-    // (distributed spaces: the pattern follows the GLOBAL id -- the local layers are a contiguous run of the
-    // global ones -- and the mean is the global one, so that every rank count estimates the same eigenvalues)
+    // (distributed spaces: the pattern follows the GLOBAL lexicographic id and the mean is the global one, so that
+    // every rank count -- slabs or boxes -- estimates the same eigenvalues)
     const int sp = _hip_operator->domain_space();
-    int64_t id0 = 0, own_begin = 0, own_end = n;
-    double n_global = double(n);
-    if (h.comm.enabled() && sp > 0)
-    {
-      HaloSpace const &hs = h.comm.spaces[sp];
-      id0 = hs.global_begin * hs.layer_elems;
-      own_begin = hs.owned_begin * hs.layer_elems;
-      own_end = own_begin + hs.owned_count * hs.layer_elems;
-      n_global = double(hs.global_layers * hs.layer_elems);
-    }
+    HaloSpace const *hs = (h.comm.enabled() && sp > 0) ? &h.comm.spaces[sp] : nullptr;
+    if (hs)
+      hs->check();
+    const double n_global = hs ? double(hs->n_global()) : double(n);
     std::vector<double> v(n);
     double mean = 0.;
     for (int64_t i = 0; i < n; ++i)
     {
-      const int64_t gi = i + id0;
+      const int64_t gi = hs ? hs->global_id(i) : i;
       if (_eig_start == "dealii")
         v[i] = double(gi % 11);
       else // splitmix64 finaliser of the DoF id, in [0, 1): white in index space whatever the row length (a
@@ -783,7 +817,7 @@ void HipSmoother::estimate_eigenvalues(int n_iterations, double residual, double
         z ^= z >> 31;
         v[i] = double(z >> 11) / 9007199254740992.0;
       }
-      if (i >= own_begin && i < own_end)
+      if (!hs || hs->owned(i))
         mean += v[i];
     }
     if (h.comm.enabled() && sp > 0)
@@ -1207,16 +1241,26 @@ void HipSolver::amg_cycle(size_t level, DVector const &b, DVector &x) const
 void HipSolver::amg_cycle_gathered(size_t level, DVector const &b_local, DVector &x_local) const
 {
   HaloSpace const &s = _handle.comm.spaces[_gather_space];
-  const int64_t n_own = s.owned_count * s.layer_elems;
-  ASSERT_THROW(b_local.size() == s.n_layers * s.layer_elems && x_local.size() == b_local.size(),
-               "vector sizes do not match the gathered level");
-  MFMG_HIP_CHECK(hipMemcpyAsync(_gather_in.data(), b_local.get_values() + s.owned_begin * s.layer_elems,
-                                (size_t)n_own * sizeof(double), hipMemcpyDeviceToDevice, _handle.stream));
-  _handle.comm.transport->allgather(_gather_in.data(), n_own, _gather_b->get_values(), _handle.stream);
+  const int64_t n_own = s.n_owned();
+  ASSERT_THROW(b_local.size() == s.n_local() && x_local.size() == b_local.size(), "vector sizes do not match the gathered level");
+  if (!s.split_xy())
+  {
+    MFMG_HIP_CHECK(hipMemcpyAsync(_gather_in.data(), b_local.get_values() + s.owned_begin * s.layer_elems,
+                                  (size_t)n_own * sizeof(double), hipMemcpyDeviceToDevice, _handle.stream));
+    _handle.comm.transport->allgather(_gather_in.data(), n_own, _gather_b->get_values(), _handle.stream);
+    amg_cycle(level, *_gather_b, *_gather_x);
+    // the local layers (ghost layers included) are a contiguous run of the global ones
+    MFMG_HIP_CHECK(hipMemcpyAsync(x_local.get_values(), _gather_x->get_values() + s.global_begin * s.layer_elems,
+                                  (size_t)x_local.size() * sizeof(double), hipMemcpyDeviceToDevice, _handle.stream));
+    return;
+  }
+  // boxes: the owned sub-box is packed, the gathered blocks (rank order) are permuted into the global lexicographic order, and
+  // the local box (ghosts included) is read back through its global ids
+  halo_box_copy(const_cast<double *>(b_local.get_values()), s, true, _gather_in.data(), 0, _handle.stream);
+  _handle.comm.transport->allgather(_gather_in.data(), n_own, _gather_ranked.data(), _handle.stream);
+  gather_indexed(_gather_b->size(), _gather_ranked.data(), _gather_from_ranked.data(), _gather_b->get_values(), _handle.stream);
   amg_cycle(level, *_gather_b, *_gather_x);
-  // the local layers (ghost layers included) are a contiguous run of the global ones
-  MFMG_HIP_CHECK(hipMemcpyAsync(x_local.get_values(), _gather_x->get_values() + s.global_begin * s.layer_elems,
-                                (size_t)x_local.size() * sizeof(double), hipMemcpyDeviceToDevice, _handle.stream));
+  gather_indexed(x_local.size(), _gather_x->get_values(), _gather_local_ids.data(), x_local.get_values(), _handle.stream);
 }
 
 // ---- HipHierarchyHelpers ---------------------------------------------------------
@@ -1294,22 +1338,43 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
                  "this distributed context already carries a hierarchy: its halo spaces are in use -- destroy that "
                  "hierarchy first (one hierarchy per communicator context at a time)");
     comm.spaces_owner = this;
-    // first coarse level: layers of agglomerates along z, `n_components` unknowns per agglomerate
-    ASSERT_THROW(opts.agglomerate[2] == 2, "distributed runs need agglomeration.nz = 2");
+    // first coarse level: the agglomerates of the local mesh, `n_components` unknowns each
     HaloSpace &cs = comm.spaces[2];
     cs = HaloSpace();
     const int64_t per_layer = (int64_t)_grid_hint.dims[0] * _grid_hint.dims[1] * _grid_hint.n_components;
     ASSERT_THROW(R.n_rows == per_layer * _grid_hint.dims[2],
                  "distributed runs need the same number of eigenvectors on every agglomerate");
+    cs.comps = _grid_hint.n_components;
     cs.layer_elems = per_layer;
     cs.n_layers = _grid_hint.dims[2];
-    cs.has_low = comm.ghost_cells_low > 0;
-    cs.has_high = comm.ghost_cells_high > 0;
-    cs.owned_begin = comm.ghost_cells_low / 2;
-    cs.owned_count = cs.n_layers - comm.ghost_cells_low / 2 - comm.ghost_cells_high / 2;
     cs.width = 1;
-    cs.global_begin = (int64_t)comm.rank * cs.owned_count - cs.owned_begin;
-    cs.global_layers = (int64_t)comm.n_ranks * cs.owned_count;
+    for (int d = 0; d < 3; ++d)
+    {
+      const bool low = comm.ghost_lo[d] > 0, high = comm.ghost_hi[d] > 0;
+      ASSERT_THROW((!low && !high) || opts.agglomerate[d] == 2, "distributed runs need agglomerates of 2 cells along a split axis");
+      const int64_t own0 = low ? 1 : 0; // (2 ghost cell layers = one agglomerate)
+      const int64_t own_n = _grid_hint.dims[d] - own0 - (high ? 1 : 0);
+      const int64_t g0 = (int64_t)comm.coord[d] * own_n - own0, gn = (int64_t)comm.grid[d] * own_n;
+      if (d == 2)
+      {
+        cs.has_low = low;
+        cs.has_high = high;
+        cs.owned_begin = own0;
+        cs.owned_count = own_n;
+        cs.global_begin = g0;
+        cs.global_layers = gn;
+      }
+      else
+      {
+        cs.n_xy[d] = _grid_hint.dims[d];
+        cs.low_xy[d] = low;
+        cs.high_xy[d] = high;
+        cs.own0_xy[d] = own0;
+        cs.own_n_xy[d] = own_n;
+        cs.g0_xy[d] = g0;
+        cs.gn_xy[d] = gn;
+      }
+    }
     comm.spaces.resize(3); // the spaces of the aggregation levels belong to the coarse solver built next
     // rows of the neighbours' agglomerates stay: the lower neighbour's top face is my first owned plane
     // (prolongation), and the Galerkin product of my boundary rows couples to both ghost layers

@@ -306,9 +306,9 @@ private:
   // aggregation hierarchy by probing on the device, coupled across the ranks (amg_device_setup.hip)
   void setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> matrix, std::vector<double> const &near_null,
                            AmgGridHint const &grid, AmgOptions const &opts, std::shared_ptr<ptree> smoother_params);
+  // (`geom`: the level as a halo space -- local box, owned box, global box; on one rank all three coincide)
   void finish_amg_replicated(std::shared_ptr<HipMatrixOperator> a_op, HostCsr A, std::vector<double> B, int space,
-                             int64_t owned_begin, int64_t owned_count, int64_t global_begin, int64_t global_layers,
-                             int const dims[3], int n_comp, AmgOptions const &opts, std::shared_ptr<ptree> smoother_params);
+                             HaloSpace const &geom, AmgOptions const &opts, std::shared_ptr<ptree> smoother_params);
   // Dense LU with partial pivoting, factored ONCE at setup (the reference re-factorises in every apply,
   // source/cuda/dealii_operator_device_helpers.cu:169-228).  Up to kTriangularInverseLimit rows the factors are
   // stored inverted as two dense triangular matrices and the solve is two SpMV launches over the whole chip
@@ -328,6 +328,9 @@ private:
   int _gather_space = 0;
   mutable DeviceBuffer<double> _gather_in;
   std::shared_ptr<DVector> _gather_b, _gather_x;
+  // boxes: the gathered blocks arrive in rank order; [global entry] -> position among them, [local entry] -> global entry
+  mutable DeviceBuffer<double> _gather_ranked;
+  DeviceBuffer<int32_t> _gather_from_ranked, _gather_local_ids;
   int _amg_cycles = 1;
   int _amg_pre_smoothing_levels = 1 << 20;
   DenseLu _amg_bottom;

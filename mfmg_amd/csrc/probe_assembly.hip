@@ -67,7 +67,9 @@ int64_t scan_counts(HipHandle &h, DeviceBuffer<int32_t> &row_ptr, int64_t n_rows
 struct GalerkinGeom
 {
   int na[3], ne, k[3];
-  int64_t zoff, z_own0, z_own1, nc;
+  int off[3], own0[3], own1[3]; // global index of local agglomerate 0; owned agglomerates [own0, own1) per axis
+  int all_owned;
+  int64_t nc;
   int round_to_float; // values rounded to float-representable doubles ("setup value precision" float)
 };
 
@@ -79,7 +81,8 @@ __global__ void galerkin_rows_kernel(GalerkinGeom g, double const *Y, int32_t *r
   {
     const int64_t a = r / g.ne;
     const int ax = (int)(a % g.na[0]), ay = (int)((a / g.na[0]) % g.na[1]), az = (int)(a / ((int64_t)g.na[0] * g.na[1]));
-    const bool owned = az >= g.z_own0 && az < g.z_own1; // (rows of the neighbours' agglomerates stay empty)
+    // (rows of the neighbours' agglomerates stay empty)
+    const bool owned = ax >= g.own0[0] && ax < g.own1[0] && ay >= g.own0[1] && ay < g.own1[1] && az >= g.own0[2] && az < g.own1[2];
     int p = FILL ? row_ptr[r] : 0;
     if (owned)
       for (int dz = -1; dz <= 1; ++dz)
@@ -92,7 +95,7 @@ __global__ void galerkin_rows_kernel(GalerkinGeom g, double const *Y, int32_t *r
             if (FILL)
             {
               const int64_t b = bx + (int64_t)g.na[0] * (by + (int64_t)g.na[1] * bz);
-              const int oc = (bx % g.k[0]) + g.k[0] * ((by % g.k[1]) + g.k[1] * (int)((bz + g.zoff) % g.k[2]));
+              const int oc = ((bx + g.off[0]) % g.k[0]) + g.k[0] * (((by + g.off[1]) % g.k[1]) + g.k[1] * ((bz + g.off[2]) % g.k[2]));
               for (int e2 = 0; e2 < g.ne; ++e2, ++p)
               {
                 col[p] = (int32_t)(b * g.ne + e2);
@@ -102,9 +105,9 @@ __global__ void galerkin_rows_kernel(GalerkinGeom g, double const *Y, int32_t *r
                   // (the product is symmetric to rounding; an entry and its transposed partner must round to the SAME float,
                   // or the symmetric-half storage is lost: both are replaced by their mean first -- one rank only, where
                   // every row is computed here)
-                  if (g.z_own0 == 0 && g.z_own1 == g.na[2])
+                  if (g.all_owned)
                   {
-                    const int ocr = (ax % g.k[0]) + g.k[0] * ((ay % g.k[1]) + g.k[1] * (int)((az + g.zoff) % g.k[2]));
+                    const int ocr = ((ax + g.off[0]) % g.k[0]) + g.k[0] * (((ay + g.off[1]) % g.k[1]) + g.k[1] * ((az + g.off[2]) % g.k[2]));
                     const double vt = Y[(size_t)(ocr * g.ne + (int)(r % g.ne)) * (size_t)g.nc + (size_t)(b * g.ne + e2)];
                     v = 0.5 * (v + vt);
                   }
@@ -125,7 +128,9 @@ __global__ void galerkin_rows_kernel(GalerkinGeom g, double const *Y, int32_t *r
 struct ProlongatorGeom
 {
   int fdims[3], cdims[3], gdims_c[3], C, blk, reach, period[3];
-  int64_t f_global_begin, c_global_begin, row0, n_own;
+  int f_g0[3], c_g0[3];   // global index of the local fine node / coarse node 0 per axis
+  int own0[3], own1[3];   // owned fine nodes [own0, own1) per axis: the other rows stay empty
+  int64_t n_f;            // local fine rows = the stride of the probes
   double w;
   int round_to_float;
 };
@@ -135,40 +140,43 @@ __global__ void prolongator_rows_kernel(ProlongatorGeom g, double const *Z, doub
                                         int32_t *col, double *val)
 {
 #pragma clang fp contract(off) // multiply, multiply, subtract: the rounding of the host loop this replaces
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < g.n_own; q += (int64_t)gridDim.x * blockDim.x)
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < g.n_f; i += (int64_t)gridDim.x * blockDim.x)
   {
-    const int64_t i = g.row0 + q;
     const int64_t nd = i / g.C;
-    const int x = (int)(nd % g.fdims[0]), y = (int)((nd / g.fdims[0]) % g.fdims[1]), zl = (int)(nd / ((int64_t)g.fdims[0] * g.fdims[1]));
-    const int64_t zg = zl + g.f_global_begin;
-    const int lo[3] = {max(0, x - g.reach) / g.blk, max(0, y - g.reach) / g.blk, (int)(max((int64_t)0, zg - g.reach) / g.blk)};
-    const int hi[3] = {min(g.gdims_c[0] - 1, (x + g.reach) / g.blk), min(g.gdims_c[1] - 1, (y + g.reach) / g.blk),
-                       (int)min((int64_t)g.gdims_c[2] - 1, (zg + g.reach) / g.blk)};
+    const int xl = (int)(nd % g.fdims[0]), yl = (int)((nd / g.fdims[0]) % g.fdims[1]), zl = (int)(nd / ((int64_t)g.fdims[0] * g.fdims[1]));
+    const bool owned = xl >= g.own0[0] && xl < g.own1[0] && yl >= g.own0[1] && yl < g.own1[1] && zl >= g.own0[2] && zl < g.own1[2];
     int p = FILL ? row_ptr[i] : 0;
-    for (int K = lo[2]; K <= hi[2]; ++K)
-      for (int J = lo[1]; J <= hi[1]; ++J)
-        for (int I = lo[0]; I <= hi[0]; ++I)
-        {
-          const int oc = (I % g.period[0]) + g.period[0] * ((J % g.period[1]) + g.period[1] * (K % g.period[2]));
-          const int64_t Kl = K - g.c_global_begin;
-          const bool own_agg = (I == x / g.blk) && (J == y / g.blk) && (K == (int)(zg / g.blk));
-          for (int comp = 0; comp < g.C; ++comp)
+    if (owned)
+    {
+      const int x = xl + g.f_g0[0], y = yl + g.f_g0[1], zg = zl + g.f_g0[2]; // global node
+      const int lo[3] = {max(0, x - g.reach) / g.blk, max(0, y - g.reach) / g.blk, max(0, zg - g.reach) / g.blk};
+      const int hi[3] = {min(g.gdims_c[0] - 1, (x + g.reach) / g.blk), min(g.gdims_c[1] - 1, (y + g.reach) / g.blk),
+                         min(g.gdims_c[2] - 1, (zg + g.reach) / g.blk)};
+      for (int K = lo[2]; K <= hi[2]; ++K)
+        for (int J = lo[1]; J <= hi[1]; ++J)
+          for (int I = lo[0]; I <= hi[0]; ++I)
           {
-            const double ay = Z[(size_t)(oc * g.C + comp) * (size_t)g.n_own + (size_t)q];
-            const double yi = (own_agg && comp == (int)(i % g.C)) ? t[i] : 0.;
-            const double v0 = yi - g.w * dinv[i] * ay;
-            const double v = g.round_to_float ? (double)(float)v0 : v0;
-            if (v != 0.)
+            const int oc = (I % g.period[0]) + g.period[0] * ((J % g.period[1]) + g.period[1] * (K % g.period[2]));
+            const int Il = I - g.c_g0[0], Jl = J - g.c_g0[1], Kl = K - g.c_g0[2];
+            const bool own_agg = (I == x / g.blk) && (J == y / g.blk) && (K == zg / g.blk);
+            for (int comp = 0; comp < g.C; ++comp)
             {
-              if (FILL)
+              const double ay = Z[(size_t)(oc * g.C + comp) * (size_t)g.n_f + (size_t)i];
+              const double yi = (own_agg && comp == (int)(i % g.C)) ? t[i] : 0.;
+              const double v0 = yi - g.w * dinv[i] * ay;
+              const double v = g.round_to_float ? (double)(float)v0 : v0;
+              if (v != 0.)
               {
-                col[p] = (int32_t)((((int64_t)Kl * g.cdims[1] + J) * g.cdims[0] + I) * g.C + comp);
-                val[p] = v;
+                if (FILL)
+                {
+                  col[p] = (int32_t)((((int64_t)Kl * g.cdims[1] + Jl) * g.cdims[0] + Il) * g.C + comp);
+                  val[p] = v;
+                }
+                ++p;
               }
-              ++p;
             }
           }
-        }
+    }
     if (!FILL)
       row_ptr[i + 1] = p;
   }
@@ -178,52 +186,57 @@ __global__ void prolongator_rows_kernel(ProlongatorGeom g, double const *Z, doub
 struct CoarseGeom
 {
   int cdims[3], gdims_c[3], C, reach, period[3];
-  int64_t c_global_begin, crow0, cn_own;
+  int c_g0[3], own0[3], own1[3]; // global index of local node 0; owned nodes [own0, own1) per axis
+  int all_owned;
+  int64_t n_c;                   // local rows = the stride of the probes
   int round_to_float;
 };
 
 template <bool FILL>
 __global__ void coarse_rows_kernel(CoarseGeom g, double const *Y, int32_t *row_ptr, int32_t *col, double *val)
 {
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < g.cn_own; q += (int64_t)gridDim.x * blockDim.x)
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < g.n_c; r += (int64_t)gridDim.x * blockDim.x)
   {
-    const int64_t r = g.crow0 + q;
     const int64_t nd = r / g.C;
-    const int X = (int)(nd % g.cdims[0]), Yc = (int)((nd / g.cdims[0]) % g.cdims[1]), Zl = (int)(nd / ((int64_t)g.cdims[0] * g.cdims[1]));
-    const int64_t Zg = Zl + g.c_global_begin;
+    const int Xl = (int)(nd % g.cdims[0]), Yl = (int)((nd / g.cdims[0]) % g.cdims[1]), Zl = (int)(nd / ((int64_t)g.cdims[0] * g.cdims[1]));
+    const bool owned = Xl >= g.own0[0] && Xl < g.own1[0] && Yl >= g.own0[1] && Yl < g.own1[1] && Zl >= g.own0[2] && Zl < g.own1[2];
     int p = FILL ? row_ptr[r] : 0;
-    for (int64_t K = max((int64_t)0, Zg - g.reach); K <= min((int64_t)g.gdims_c[2] - 1, Zg + g.reach); ++K)
-      for (int J = max(0, Yc - g.reach); J <= min(g.gdims_c[1] - 1, Yc + g.reach); ++J)
-        for (int I = max(0, X - g.reach); I <= min(g.gdims_c[0] - 1, X + g.reach); ++I)
-        {
-          const int oc = (I % g.period[0]) + g.period[0] * ((J % g.period[1]) + g.period[1] * (int)(K % g.period[2]));
-          const int64_t Kl = K - g.c_global_begin;
-          for (int comp = 0; comp < g.C; ++comp)
+    if (owned)
+    {
+      const int X = Xl + g.c_g0[0], Yc = Yl + g.c_g0[1], Zg = Zl + g.c_g0[2];
+      for (int K = max(0, Zg - g.reach); K <= min(g.gdims_c[2] - 1, Zg + g.reach); ++K)
+        for (int J = max(0, Yc - g.reach); J <= min(g.gdims_c[1] - 1, Yc + g.reach); ++J)
+          for (int I = max(0, X - g.reach); I <= min(g.gdims_c[0] - 1, X + g.reach); ++I)
           {
-            double v = Y[(size_t)(oc * g.C + comp) * (size_t)g.cn_own + (size_t)q];
-            if (g.round_to_float)
+            const int oc = (I % g.period[0]) + g.period[0] * ((J % g.period[1]) + g.period[1] * (K % g.period[2]));
+            const int Il = I - g.c_g0[0], Jl = J - g.c_g0[1], Kl = K - g.c_g0[2];
+            for (int comp = 0; comp < g.C; ++comp)
             {
-              if (g.crow0 == 0 && g.c_global_begin == 0 && g.cn_own == (int64_t)g.cdims[0] * g.cdims[1] * g.cdims[2] * g.C)
+              double v = Y[(size_t)(oc * g.C + comp) * (size_t)g.n_c + (size_t)r];
+              if (g.round_to_float)
               {
-                // symmetric to rounding: an entry and its transposed partner are replaced by their mean (see above)
-                const int ocr = (X % g.period[0]) + g.period[0] * ((Yc % g.period[1]) + g.period[1] * (int)(Zg % g.period[2]));
-                const int64_t cr = (((int64_t)Kl * g.cdims[1] + J) * g.cdims[0] + I) * g.C + comp;
-                const double vt = Y[(size_t)(ocr * g.C + (int)(r % g.C)) * (size_t)g.cn_own + (size_t)cr];
-                v = 0.5 * (v + vt);
+                if (g.all_owned)
+                {
+                  // symmetric to rounding: an entry and its transposed partner are replaced by their mean (see above)
+                  const int ocr = (X % g.period[0]) + g.period[0] * ((Yc % g.period[1]) + g.period[1] * (Zg % g.period[2]));
+                  const int64_t cr = (((int64_t)Kl * g.cdims[1] + Jl) * g.cdims[0] + Il) * g.C + comp;
+                  const double vt = Y[(size_t)(ocr * g.C + (int)(r % g.C)) * (size_t)g.n_c + (size_t)cr];
+                  v = 0.5 * (v + vt);
+                }
+                v = (double)(float)v;
               }
-              v = (double)(float)v;
-            }
-            if (v != 0.)
-            {
-              if (FILL)
+              if (v != 0.)
               {
-                col[p] = (int32_t)((((int64_t)Kl * g.cdims[1] + J) * g.cdims[0] + I) * g.C + comp);
-                val[p] = v;
+                if (FILL)
+                {
+                  col[p] = (int32_t)((((int64_t)Kl * g.cdims[1] + Jl) * g.cdims[0] + Il) * g.C + comp);
+                  val[p] = v;
+                }
+                ++p;
               }
-              ++p;
             }
           }
-        }
+    }
     if (!FILL)
       row_ptr[r + 1] = p;
   }
@@ -353,20 +366,23 @@ std::shared_ptr<SparseMatrixDevice<double>> assemble(HipHandle &h, int64_t n_row
 }
 } // namespace
 
-std::shared_ptr<SparseMatrixDevice<double>> galerkin_from_probes(HipHandle &h, int const na[3], int ne, int const k[3], int64_t zoff,
-                                                                 int64_t z_own0, int64_t z_own1, double const *Y)
+std::shared_ptr<SparseMatrixDevice<double>> galerkin_from_probes(HipHandle &h, int const na[3], int ne, int const k[3], int const off[3],
+                                                                 int64_t const own0[3], int64_t const own1[3], double const *Y)
 {
   GalerkinGeom g;
   g.round_to_float = h.setup_values_float ? 1 : 0;
+  g.all_owned = 1;
   for (int d = 0; d < 3; ++d)
   {
     g.na[d] = na[d];
     g.k[d] = k[d];
+    g.off[d] = off[d];
+    g.own0[d] = (int)own0[d];
+    g.own1[d] = (int)own1[d];
+    if (own0[d] != 0 || own1[d] != na[d])
+      g.all_owned = 0;
   }
   g.ne = ne;
-  g.zoff = zoff;
-  g.z_own0 = z_own0;
-  g.z_own1 = z_own1;
   g.nc = (int64_t)na[0] * na[1] * na[2] * ne;
   return assemble<GalerkinGeom>(
       h, g.nc, g.nc, "coarse operator",
@@ -376,63 +392,65 @@ std::shared_ptr<SparseMatrixDevice<double>> galerkin_from_probes(HipHandle &h, i
       });
 }
 
-std::shared_ptr<SparseMatrixDevice<double>> prolongator_from_probes(HipHandle &h, int const fdims[3], int const cdims[3],
-                                                                    int const gdims_c[3], int n_comp, int blk, int reach,
-                                                                    int const period[3], int64_t f_global_begin, int64_t c_global_begin,
-                                                                    int64_t row0, int64_t n_own, double w, double const *Z,
+std::shared_ptr<SparseMatrixDevice<double>> prolongator_from_probes(HipHandle &h, HaloSpace const &fine, HaloSpace const &coarse, int blk,
+                                                                    int reach, int const period[3], double w, double const *Z,
                                                                     double const *t, double const *dinv)
 {
   ProlongatorGeom g;
   g.round_to_float = h.setup_values_float ? 1 : 0;
   for (int d = 0; d < 3; ++d)
   {
-    g.fdims[d] = fdims[d];
-    g.cdims[d] = cdims[d];
-    g.gdims_c[d] = gdims_c[d];
+    g.fdims[d] = (int)fine.dim(d);
+    g.cdims[d] = (int)coarse.dim(d);
+    g.gdims_c[d] = (int)coarse.gn(d);
     g.period[d] = period[d];
+    g.f_g0[d] = (int)fine.g0(d);
+    g.c_g0[d] = (int)coarse.g0(d);
+    g.own0[d] = (int)fine.own0(d);
+    g.own1[d] = (int)(fine.own0(d) + fine.own_n(d));
   }
-  g.C = n_comp;
+  g.C = fine.comps;
   g.blk = blk;
   g.reach = reach;
-  g.f_global_begin = f_global_begin;
-  g.c_global_begin = c_global_begin;
-  g.row0 = row0;
-  g.n_own = n_own;
   g.w = w;
-  const int64_t n_f = (int64_t)fdims[0] * fdims[1] * fdims[2] * n_comp, n_c = (int64_t)cdims[0] * cdims[1] * cdims[2] * n_comp;
+  const int64_t n_f = fine.n_local(), n_c = coarse.n_local();
+  g.n_f = n_f;
   return assemble<ProlongatorGeom>(
       h, n_f, n_c, "prolongator",
       [&](int32_t *rp) {
-        hipLaunchKernelGGL(prolongator_rows_kernel<false>, grid_for(n_own), dim3(256), 0, h.stream, g, Z, t, dinv, rp, nullptr, nullptr);
+        hipLaunchKernelGGL(prolongator_rows_kernel<false>, grid_for(n_f), dim3(256), 0, h.stream, g, Z, t, dinv, rp, nullptr, nullptr);
       },
       [&](int32_t *rp, int32_t *col, double *val) {
-        hipLaunchKernelGGL(prolongator_rows_kernel<true>, grid_for(n_own), dim3(256), 0, h.stream, g, Z, t, dinv, rp, col, val);
+        hipLaunchKernelGGL(prolongator_rows_kernel<true>, grid_for(n_f), dim3(256), 0, h.stream, g, Z, t, dinv, rp, col, val);
       });
 }
 
-std::shared_ptr<SparseMatrixDevice<double>> coarse_operator_from_probes(HipHandle &h, int const cdims[3], int const gdims_c[3], int n_comp,
-                                                                        int reach, int const period[3], int64_t c_global_begin,
-                                                                        int64_t crow0, int64_t cn_own, double const *Y)
+std::shared_ptr<SparseMatrixDevice<double>> coarse_operator_from_probes(HipHandle &h, HaloSpace const &coarse, int reach, int const period[3],
+                                                                        double const *Y)
 {
   CoarseGeom g;
   g.round_to_float = h.setup_values_float ? 1 : 0;
+  g.all_owned = 1;
   for (int d = 0; d < 3; ++d)
   {
-    g.cdims[d] = cdims[d];
-    g.gdims_c[d] = gdims_c[d];
+    g.cdims[d] = (int)coarse.dim(d);
+    g.gdims_c[d] = (int)coarse.gn(d);
     g.period[d] = period[d];
+    g.c_g0[d] = (int)coarse.g0(d);
+    g.own0[d] = (int)coarse.own0(d);
+    g.own1[d] = (int)(coarse.own0(d) + coarse.own_n(d));
+    if (coarse.g0(d) != 0 || coarse.own0(d) != 0 || coarse.own_n(d) != coarse.dim(d))
+      g.all_owned = 0;
   }
-  g.C = n_comp;
+  g.C = coarse.comps;
   g.reach = reach;
-  g.c_global_begin = c_global_begin;
-  g.crow0 = crow0;
-  g.cn_own = cn_own;
-  const int64_t n_c = (int64_t)cdims[0] * cdims[1] * cdims[2] * n_comp;
+  const int64_t n_c = coarse.n_local();
+  g.n_c = n_c;
   return assemble<CoarseGeom>(
       h, n_c, n_c, "coarse operator",
-      [&](int32_t *rp) { hipLaunchKernelGGL(coarse_rows_kernel<false>, grid_for(cn_own), dim3(256), 0, h.stream, g, Y, rp, nullptr, nullptr); },
+      [&](int32_t *rp) { hipLaunchKernelGGL(coarse_rows_kernel<false>, grid_for(n_c), dim3(256), 0, h.stream, g, Y, rp, nullptr, nullptr); },
       [&](int32_t *rp, int32_t *col, double *val) {
-        hipLaunchKernelGGL(coarse_rows_kernel<true>, grid_for(cn_own), dim3(256), 0, h.stream, g, Y, rp, col, val);
+        hipLaunchKernelGGL(coarse_rows_kernel<true>, grid_for(n_c), dim3(256), 0, h.stream, g, Y, rp, col, val);
       });
 }
 std::shared_ptr<SparseMatrixDevice<double>> fine_operator_on_device(HipHandle &h, StructuredMesh const &mesh, bool matrix_free_semantics)

@@ -49,7 +49,7 @@ __global__ void scaled_pointwise_kernel(int64_t n, T s, T const *d, T const *v, 
 }
 
 __global__ void probing_vector_kernel(int nx, int ny, int nz, int n_eig, int kx, int ky, int kz, int ox, int oy, int oz,
-                                      int e0, double *u, int z_offset)
+                                      int e0, double *u, int x_offset, int y_offset, int z_offset)
 {
   const int64_t n = (int64_t)nx * ny * nz * n_eig;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -57,14 +57,14 @@ __global__ void probing_vector_kernel(int nx, int ny, int nz, int n_eig, int kx,
     const int e = (int)(i % n_eig);
     const int64_t ag = i / n_eig;
     const int ax = (int)(ag % nx), ay = (int)((ag / nx) % ny), az = (int)(ag / ((int64_t)nx * ny));
-    u[i] = (e == e0 && ax % kx == ox && ay % ky == oy && (az + z_offset) % kz == oz) ? 1. : 0.;
+    u[i] = (e == e0 && (ax + x_offset) % kx == ox && (ay + y_offset) % ky == oy && (az + z_offset) % kz == oz) ? 1. : 0.;
   }
 }
 
 // out[r] = in[r] (or 1 when `in` is null) where row r = node * n_comp + comp lives on a node whose block
-// coordinates (node coordinates / block, the z coordinate taken globally: z_local + z_offset) are congruent to
+// coordinates (GLOBAL node coordinates / block: local + offset) are congruent to
 // `phase` modulo `period` and comp == comp0; 0 elsewhere.  Probing vectors of the aggregation-hierarchy setup.
-__global__ void select_rows_kernel(int nx, int ny, int nz, int n_comp, int block, int z_offset, int px, int py, int pz,
+__global__ void select_rows_kernel(int nx, int ny, int nz, int n_comp, int block, int x_offset, int y_offset, int z_offset, int px, int py, int pz,
                                    int ox, int oy, int oz, int comp0, double const *in, double *out)
 {
   const int64_t n = (int64_t)nx * ny * nz * n_comp;
@@ -73,7 +73,7 @@ __global__ void select_rows_kernel(int nx, int ny, int nz, int n_comp, int block
     const int c = (int)(r % n_comp);
     const int64_t nd = r / n_comp;
     const int i = (int)(nd % nx), j = (int)((nd / nx) % ny), k = (int)(nd / ((int64_t)nx * ny));
-    const bool hit = c == comp0 && (i / block) % px == ox && (j / block) % py == oy && ((k + z_offset) / block) % pz == oz;
+    const bool hit = c == comp0 && ((i + x_offset) / block) % px == ox && ((j + y_offset) / block) % py == oy && ((k + z_offset) / block) % pz == oz;
     out[r] = hit ? (in ? in[r] : 1.) : 0.;
   }
 }
@@ -82,6 +82,47 @@ __global__ void add_layers_kernel(int64_t n, double const *src, double *dst)
 {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     dst[i] += src[i];
+}
+
+// `count` runs of `run` entries, `stride` apart in v, against the contiguous buf (mode 0: buf = v, 1: v = buf, 2: v += buf)
+__global__ void strided_runs_kernel(double *v, int64_t stride, int64_t run, int64_t count, double *buf, int mode)
+{
+  const int64_t n = run * count;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int64_t c = i / run, r = i - c * run;
+    double *p = v + c * stride + r;
+    if (mode == 0)
+      buf[i] = *p;
+    else if (mode == 1)
+      *p = buf[i];
+    else
+      *p += buf[i];
+  }
+}
+
+// the sub-box [b0, b0 + bn) of the lexicographic array of nodes `dims` (comps entries per node) against the contiguous buf
+// (mode 0: buf = v, 1: v = buf)
+__global__ void box_copy_kernel(double *v, int comps, int64_t nx, int64_t ny, int64_t bx0, int64_t by0, int64_t bz0, int64_t bnx,
+                                int64_t bny, int64_t bnz, double *buf, int mode)
+{
+  const int64_t n = bnx * bny * bnz * comps, rx = bnx * comps;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+  {
+    const int64_t x = i % rx, j = (i / rx) % bny, k = i / (rx * bny);
+    double *p = v + ((k + bz0) * ny + (j + by0)) * nx * comps + bx0 * comps + x;
+    if (mode == 0)
+      buf[i] = *p;
+    else
+      *p = buf[i];
+  }
+}
+
+// out[i] = in[index[i]]
+__global__ void gather_indexed_kernel(int64_t n, double const *in, int32_t const *index, double *out)
+{
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = in[index[i]];
 }
 
 __global__ void widen_kernel(int64_t n, float const *in, double *out)
@@ -218,24 +259,24 @@ void scaled_pointwise(HipHandle &h, int64_t n, T s, T const *d, T const *v, T *o
   MFMG_HIP_CHECK(hipGetLastError());
 }
 
-void probing_vector(HipHandle &h, int const na[3], int n_eig, int const k[3], int const o[3], int e0, double *u, int z_offset)
+void probing_vector(HipHandle &h, int const na[3], int n_eig, int const k[3], int const o[3], int e0, double *u, int const offset[3])
 {
   const int64_t n = (int64_t)na[0] * na[1] * na[2] * n_eig;
   if (n <= 0)
     return;
   hipLaunchKernelGGL(probing_vector_kernel, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, na[0], na[1], na[2],
-                     n_eig, k[0], k[1], k[2], o[0], o[1], o[2], e0, u, z_offset);
+                     n_eig, k[0], k[1], k[2], o[0], o[1], o[2], e0, u, offset[0], offset[1], offset[2]);
   MFMG_HIP_CHECK(hipGetLastError());
 }
 
-void select_rows(HipHandle &h, int const dims[3], int n_comp, int block, int z_offset, int const period[3], int const phase[3],
+void select_rows(HipHandle &h, int const dims[3], int n_comp, int block, int const offset[3], int const period[3], int const phase[3],
                  int comp, double const *in, double *out)
 {
   const int64_t n = (int64_t)dims[0] * dims[1] * dims[2] * n_comp;
   if (n <= 0)
     return;
   hipLaunchKernelGGL(select_rows_kernel, dim3(stream_blocks(n)), dim3(block_size), 0, h.stream, dims[0], dims[1], dims[2], n_comp,
-                     block, z_offset, period[0], period[1], period[2], phase[0], phase[1], phase[2], comp, in, out);
+                     block, offset[0], offset[1], offset[2], period[0], period[1], period[2], phase[0], phase[1], phase[2], comp, in, out);
   MFMG_HIP_CHECK(hipGetLastError());
 }
 
@@ -316,6 +357,37 @@ void cg_direction(HipHandle &h, int64_t n, T const *z, T *p, double const *scal,
 MFMG_INSTANTIATE_VEC(double)
 MFMG_INSTANTIATE_VEC(float)
 } // namespace vec
+
+void halo_strided_runs(double *v, int64_t stride, int64_t run, int64_t count, double *buf, int mode, hipStream_t stream)
+{
+  const int64_t n = run * count;
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(vec::strided_runs_kernel, dim3(n_blocks_for(n, block_size, 4096)), dim3(block_size), 0, stream, v, stride, run, count,
+                     buf, mode);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+void halo_box_copy(double *v, HaloSpace const &s, bool owned_only, double *buf, int mode, hipStream_t stream)
+{
+  s.check();
+  const int64_t b0[3] = {owned_only ? s.own0(0) : 0, owned_only ? s.own0(1) : 0, owned_only ? s.own0(2) : 0};
+  const int64_t bn[3] = {owned_only ? s.own_n(0) : s.dim(0), owned_only ? s.own_n(1) : s.dim(1), owned_only ? s.own_n(2) : s.dim(2)};
+  const int64_t n = bn[0] * bn[1] * bn[2] * s.comps;
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(vec::box_copy_kernel, dim3(n_blocks_for(n, block_size, 4096)), dim3(block_size), 0, stream, v, s.comps, s.n_xy[0],
+                     s.n_xy[1], b0[0], b0[1], b0[2], bn[0], bn[1], bn[2], buf, mode);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
+void gather_indexed(int64_t n, double const *in, int32_t const *index, double *out, hipStream_t stream)
+{
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(vec::gather_indexed_kernel, dim3(n_blocks_for(n, block_size, 4096)), dim3(block_size), 0, stream, n, in, index, out);
+  MFMG_HIP_CHECK(hipGetLastError());
+}
 
 void halo_add_layers(double *dst, double const *src, int64_t n, hipStream_t stream)
 {

@@ -25,13 +25,13 @@ void scaled_pointwise(HipHandle &h, int64_t n, T s, T const *d, T const *v, T *o
 
 // probing vector of the Galerkin product on device: u[(a, e)] = 1 where e == e0 and the agglomerate a (x fastest on a
 // grid na) has a_d mod k_d == o_d in every direction, else 0
-// (z_offset: global index of the local agglomerate layer 0 in a distributed run)
-void probing_vector(HipHandle &h, int const na[3], int n_eig, int const k[3], int const o[3], int e0, double *u, int z_offset = 0);
+// (offset: global index of the local agglomerate 0 per axis in a distributed run)
+void probing_vector(HipHandle &h, int const na[3], int n_eig, int const k[3], int const o[3], int e0, double *u, int const offset[3]);
 
 // out[r] = in[r] (1 when in is null) on the rows r = node * n_comp + comp of the nodes whose block coordinates
-// (node / block; z taken globally: z_local + z_offset) are congruent to `phase` modulo `period`, with comp == `comp`;
+// ((local + offset) / block: global coordinates) are congruent to `phase` modulo `period`, with comp == `comp`;
 // 0 elsewhere (probing vectors of the aggregation-hierarchy setup)
-void select_rows(HipHandle &h, int const dims[3], int n_comp, int block, int z_offset, int const period[3], int const phase[3],
+void select_rows(HipHandle &h, int const dims[3], int n_comp, int block, int const offset[3], int const period[3], int const phase[3],
                  int comp, double const *in, double *out);
 
 // fine level in FP32 around an FP64 coarse hierarchy: out = (double) in, and x -= (float) correction

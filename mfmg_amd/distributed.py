@@ -1,4 +1,4 @@
-"""One process per GPU: slab decomposition of the mesh along z and the halo transport.
+"""One process per GPU: decomposition of the mesh into slabs along z or into boxes, and the halo transport.
 
 The reference partitions the mesh with p4est and exchanges ghost DoFs inside deal.II
 (tests/laplace_matrix_free.hpp:222, MatrixFree::cell_loop); its CUDA path all-gathers the whole
@@ -21,60 +21,135 @@ from .laplace import LaplaceProblem
 from .lib import check
 
 
-class SlabPartition:
-    """Owned cell layers [z0, z1) of rank `rank` out of `n_ranks` for a global mesh of `cells`."""
+class BoxPartition:
+    """Owned cell box of rank `rank` in a grid (gx, gy, gz) of equal boxes over a global mesh of `cells`
+    (rank = cx + gx (cy + gy cz); SURVEY.md 8e: 2 x 1 x 1, 2 x 2 x 1, 2 x 2 x 2).  The local mesh is the box plus one
+    agglomerate (2 cell layers) of each face neighbour, numbered lexicographically; interface planes belong to the upper
+    box, the last box of an axis also owns the top plane.  (1, 1, n) are the slabs along z."""
 
-    def __init__(self, cells: Sequence[int], rank: int, n_ranks: int, length: Sequence[float] | float = 1.0):
+    def __init__(self, cells: Sequence[int], rank: int, grid: Sequence[int], length: Sequence[float] | float = 1.0):
         self.cells = tuple(int(c) for c in cells)
-        assert len(self.cells) == 3
-        self.rank, self.n_ranks = int(rank), int(n_ranks)
-        cz = self.cells[2]
-        if cz % (2 * n_ranks) != 0:
-            raise ValueError("the cell layers must split into whole agglomerate layers per rank")
-        per = cz // n_ranks
-        self.z0, self.z1 = rank * per, (rank + 1) * per
-        self.ghost_low = 2 if rank > 0 else 0
-        self.ghost_high = 2 if rank + 1 < n_ranks else 0
-        self.local_cells = (self.cells[0], self.cells[1], per + self.ghost_low + self.ghost_high)
-        self.z_offset = self.z0 - self.ghost_low          # global index of local cell layer 0
+        self.grid = tuple(int(g) for g in grid)
+        assert len(self.cells) == 3 and len(self.grid) == 3
+        self.n_ranks = self.grid[0] * self.grid[1] * self.grid[2]
+        self.rank = int(rank)
+        assert 0 <= self.rank < self.n_ranks
+        self.coord = (self.rank % self.grid[0], (self.rank // self.grid[0]) % self.grid[1], self.rank // (self.grid[0] * self.grid[1]))
+        for d in range(3):
+            if self.grid[d] > 1 and self.cells[d] % (2 * self.grid[d]) != 0:
+                raise ValueError("the cell layers must split into whole agglomerate layers per rank")
+        self.per = tuple(self.cells[d] // self.grid[d] for d in range(3))
+        self.c0 = tuple(self.coord[d] * self.per[d] for d in range(3))
+        self.ghost_lo = tuple(2 if self.coord[d] > 0 else 0 for d in range(3))
+        self.ghost_hi = tuple(2 if self.coord[d] + 1 < self.grid[d] else 0 for d in range(3))
+        self.local_cells = tuple(self.per[d] + self.ghost_lo[d] + self.ghost_hi[d] for d in range(3))
+        self.offset = tuple(self.c0[d] - self.ghost_lo[d] for d in range(3))     # global index of local cell / node 0
         ln = (length,) * 3 if isinstance(length, (int, float)) else tuple(length)
         self.h = tuple(ln[d] / self.cells[d] for d in range(3))
-        self.plane = (self.cells[0] + 1) * (self.cells[1] + 1)
-        self.n_local_planes = self.local_cells[2] + 1
-        # owned node planes: [z0, z1), plus the top plane on the last rank
-        self.owned_plane_begin = self.ghost_low
-        self.owned_plane_count = per + (1 if rank + 1 == n_ranks else 0)
-        self.n_global_dofs = self.plane * (cz + 1)
+        self.local_nodes = tuple(c + 1 for c in self.local_cells)
+        self.global_nodes = tuple(c + 1 for c in self.cells)
+        self.own0 = self.ghost_lo
+        self.own_n = tuple(self.per[d] + (1 if self.coord[d] + 1 == self.grid[d] else 0) for d in range(3))
+        self.n_global_dofs = self.global_nodes[0] * self.global_nodes[1] * self.global_nodes[2]
+        self.n_local_dofs = self.local_nodes[0] * self.local_nodes[1] * self.local_nodes[2]
+        # the names of the slab code (z axis)
+        self.z0, self.z1 = self.c0[2], self.c0[2] + self.per[2]
+        self.ghost_low, self.ghost_high = self.ghost_lo[2], self.ghost_hi[2]
+        self.z_offset = self.offset[2]
+        self.plane = self.local_nodes[0] * self.local_nodes[1]
+        self.n_local_planes = self.local_nodes[2]
+        self.owned_plane_begin, self.owned_plane_count = self.own0[2], self.own_n[2]
+
+    @property
+    def split_xy(self) -> bool:
+        return self.grid[0] > 1 or self.grid[1] > 1
+
+    def exchange_doubles(self, width: int = 1) -> int:
+        """Doubles this rank sends in one exchange of a fine-level vector: per split axis `width` layers towards each neighbour,
+        over the whole local extent of the other two axes."""
+        ln = self.local_nodes
+        return sum(width * (self.n_local_dofs // ln[d]) * ((self.coord[d] > 0) + (self.coord[d] + 1 < self.grid[d])) for d in range(3))
 
     def local_problem(self, material: str = "constant", device="cpu") -> LaplaceProblem:
-        """Mesh arrays of the local (extended) slab: global Dirichlet nodes carry 1, ghost nodes 2."""
+        """Mesh arrays of the local (extended) box: global Dirichlet nodes carry 1, ghost nodes 2."""
         prob = LaplaceProblem(self.local_cells, material, device=device, dirichlet=False, cell_size=self.h,
-                              cell_offset=(0, 0, self.z_offset))
-        Nx, Ny = self.cells[0] + 1, self.cells[1] + 1
-        k = torch.arange(self.n_local_planes, device=prob.device).view(-1, 1, 1) + self.z_offset
-        j = torch.arange(Ny, device=prob.device).view(1, -1, 1)
-        i = torch.arange(Nx, device=prob.device).view(1, 1, -1)
-        boundary = (i == 0) | (i == Nx - 1) | (j == 0) | (j == Ny - 1) | (k == 0) | (k == self.cells[2])
-        lk = torch.arange(self.n_local_planes, device=prob.device).view(-1, 1, 1)
-        ghost = (lk < self.owned_plane_begin) | (lk >= self.owned_plane_begin + self.owned_plane_count)
-        flags = torch.where(boundary, 1, torch.where(ghost.expand_as(boundary), 2, 0)).to(torch.uint8)
+                              cell_offset=self.offset)
+        dv = prob.device
+        idx = [torch.arange(self.local_nodes[d], device=dv) for d in range(3)]
+        shape = [(1, 1, -1), (1, -1, 1), (-1, 1, 1)]
+        boundary = None
+        ghost = None
+        for d in range(3):
+            g = (idx[d] + self.offset[d]).view(shape[d])
+            bd = (g == 0) | (g == self.cells[d])
+            gh = ((idx[d] < self.own0[d]) | (idx[d] >= self.own0[d] + self.own_n[d])).view(shape[d])
+            boundary = bd if boundary is None else (boundary | bd)
+            ghost = gh if ghost is None else (ghost | gh)
+        full = (self.local_nodes[2], self.local_nodes[1], self.local_nodes[0])
+        boundary, ghost = boundary.expand(full), ghost.expand(full)
+        flags = torch.where(boundary, 1, torch.where(ghost, 2, 0)).to(torch.uint8)
         prob.constrained = flags.reshape(-1).contiguous()
         return prob
 
+    # -- index maps between the local (extended) vector, its owned part and the global lexicographic vector --------
+    def _ids(self, lo, n, dims, shift):
+        k = torch.arange(lo[2], lo[2] + n[2]).view(-1, 1, 1) + shift[2]
+        j = torch.arange(lo[1], lo[1] + n[1]).view(1, -1, 1) + shift[1]
+        i = torch.arange(lo[0], lo[0] + n[0]).view(1, 1, -1) + shift[0]
+        return ((k * dims[1] + j) * dims[0] + i).reshape(-1)
+
+    def owned_local_index(self) -> torch.Tensor:
+        """Positions of the owned DoFs in the local vector (lexicographic order of the owned box)."""
+        return self._ids(self.own0, self.own_n, self.local_nodes, (0, 0, 0))
+
+    def owned_global_index(self) -> torch.Tensor:
+        """... and where they live in the global lexicographic vector."""
+        return self._ids(self.own0, self.own_n, self.global_nodes, self.offset)
+
+    def local_global_index(self) -> torch.Tensor:
+        """Global position of every entry of the local vector (ghosts included)."""
+        return self._ids((0, 0, 0), self.local_nodes, self.global_nodes, self.offset)
+
     def owned_slice(self) -> slice:
+        assert not self.split_xy, "the owned DoFs of a box are not one run: owned_local_index()"
         return slice(self.owned_plane_begin * self.plane, (self.owned_plane_begin + self.owned_plane_count) * self.plane)
 
     def global_slice(self) -> slice:
-        """Where the owned entries live in the global lexicographic vector."""
+        """Where the owned entries live in the global lexicographic vector (slabs)."""
+        assert not self.split_xy, "the owned DoFs of a box are not one run: owned_global_index()"
         return slice(self.z0 * self.plane, (self.z0 + self.owned_plane_count) * self.plane)
 
     def local_from_global(self, xg: torch.Tensor) -> torch.Tensor:
         """Local (extended) vector cut out of a global lexicographic vector (ghosts filled as well)."""
-        lo = self.z_offset * self.plane
-        return xg[lo: lo + self.n_local_planes * self.plane].clone()
+        if not self.split_xy:
+            lo = self.z_offset * self.plane
+            return xg[lo: lo + self.n_local_planes * self.plane].clone()
+        return xg[self.local_global_index().to(xg.device)].clone()
 
 
-_SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64,
+class SlabPartition(BoxPartition):
+    """Owned cell layers [z0, z1) of rank `rank` out of `n_ranks` for a global mesh of `cells`: the grid 1 x 1 x n_ranks."""
+
+    def __init__(self, cells: Sequence[int], rank: int, n_ranks: int, length: Sequence[float] | float = 1.0):
+        super().__init__(cells, rank, (1, 1, int(n_ranks)), length)
+
+
+def box_grid(n_ranks: int) -> tuple:
+    """The grid of SURVEY.md 8e for a rank count: 2 x 1 x 1, 2 x 2 x 1, 2 x 2 x 2; otherwise as cubic as the factors allow
+    (x fastest), slabs for a prime count."""
+    grid = [1, 1, 1]
+    n, d = int(n_ranks), 0
+    f = 2
+    while n > 1:
+        while n % f:
+            f += 1
+        grid[d % 3] *= f
+        n //= f
+        d += 1
+    return tuple(grid)
+
+
+_SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64,
                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
 _ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
 _ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double))
@@ -95,7 +170,7 @@ class HaloTransport:
     into torch.distributed on a gloo group (tests: several ranks on one card).  Default: "rccl" when the default
     process group is nccl, else "host"."""
 
-    def __init__(self, ctx, part: SlabPartition, n_eigenvectors: int = 2, group=None, transport: str | None = None):
+    def __init__(self, ctx, part: BoxPartition, n_eigenvectors: int = 2, group=None, transport: str | None = None):
         self._lib = _lib.load()
         self.ctx, self.part, self.group = ctx, part, group
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
@@ -104,8 +179,13 @@ class HaloTransport:
             transport = "rccl" if self.backend == "nccl" else "host"
         assert transport in ("rccl", "host")
         self.transport = transport
-        check(self._lib.mfmg_hip_context_set_communicator(ctx.handle, self.rank, self.n_ranks, part.ghost_low,
-                                                          part.ghost_high))
+        if part.split_xy:
+            i3 = C.c_int32 * 3
+            check(self._lib.mfmg_hip_context_set_communicator_box(ctx.handle, self.rank, i3(*part.grid), i3(*part.ghost_lo),
+                                                                  i3(*part.ghost_hi)))
+        else:
+            check(self._lib.mfmg_hip_context_set_communicator(ctx.handle, self.rank, self.n_ranks, part.ghost_low,
+                                                              part.ghost_high))
         if transport == "rccl":
             # can EVERY rank reach RCCL?  The probe resolves the library and its entry points only (no RCCL call, no
             # bootstrap thread); the decision is a MIN all-reduce over the ranks, so that no rank enters the gloo branch
@@ -146,15 +226,15 @@ class HaloTransport:
         ctx._transport = self  # keep the callbacks alive as long as the context
 
     # -- callbacks of the host transport (invoked from inside the library, on the calling Python thread) --------
-    def _sendrecv(self, user, send_low, recv_low, n_low, send_high, recv_high, n_high):
+    def _sendrecv(self, user, peer_low, peer_high, send_low, recv_low, n_low, send_high, recv_high, n_high):
         try:
             ops = []
             if n_low > 0:
-                ops += [dist.P2POp(dist.isend, _host_tensor(send_low, n_low), self.rank - 1, self._host_group),
-                        dist.P2POp(dist.irecv, _host_tensor(recv_low, n_low), self.rank - 1, self._host_group)]
+                ops += [dist.P2POp(dist.isend, _host_tensor(send_low, n_low), peer_low, self._host_group),
+                        dist.P2POp(dist.irecv, _host_tensor(recv_low, n_low), peer_low, self._host_group)]
             if n_high > 0:
-                ops += [dist.P2POp(dist.isend, _host_tensor(send_high, n_high), self.rank + 1, self._host_group),
-                        dist.P2POp(dist.irecv, _host_tensor(recv_high, n_high), self.rank + 1, self._host_group)]
+                ops += [dist.P2POp(dist.isend, _host_tensor(send_high, n_high), peer_high, self._host_group),
+                        dist.P2POp(dist.irecv, _host_tensor(recv_high, n_high), peer_high, self._host_group)]
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
@@ -192,6 +272,33 @@ class HaloTransport:
         check(self._lib.mfmg_hip_context_halo_space(self.ctx.handle, space, out))
         keys = ("layer_elems", "n_layers", "owned_begin", "owned_count", "global_begin", "global_layers", "width", "n_spaces")
         return dict(zip(keys, [int(v) for v in out]))
+
+    def box(self, space: int) -> dict:
+        """The space per axis (x, y, z): local nodes, owned range, global position and size; `comps` entries per node."""
+        out = (C.c_int64 * 16)()
+        check(self._lib.mfmg_hip_context_halo_box(self.ctx.handle, space, out))
+        v = [int(x) for x in out]
+        return {"comps": v[0], "dims": tuple(v[1:4]), "own0": tuple(v[4:7]), "own_n": tuple(v[7:10]), "g0": tuple(v[10:13]),
+                "gn": tuple(v[13:16])}
+
+    def space_index(self, space: int):
+        """(owned local positions, their global positions, global position of every local entry) of a vector of `space`."""
+        b = self.box(space)
+        c = b["comps"]
+
+        def ids(lo, n, dims, shift):
+            k = torch.arange(lo[2], lo[2] + n[2]).view(-1, 1, 1, 1) + shift[2]
+            j = torch.arange(lo[1], lo[1] + n[1]).view(1, -1, 1, 1) + shift[1]
+            i = torch.arange(lo[0], lo[0] + n[0]).view(1, 1, -1, 1) + shift[0]
+            return ((((k * dims[1] + j) * dims[0] + i) * c) + torch.arange(c).view(1, 1, 1, -1)).reshape(-1)
+        return (ids(b["own0"], b["own_n"], b["dims"], (0, 0, 0)), ids(b["own0"], b["own_n"], b["gn"], b["g0"]),
+                ids((0, 0, 0), b["dims"], b["gn"], b["g0"]))
+
+    def exchange_volume(self) -> int:
+        """Doubles this rank has sent in halo exchanges so far."""
+        n = C.c_int64()
+        check(self._lib.mfmg_hip_context_exchange_volume(self.ctx.handle, C.byref(n)))
+        return n.value
 
     def exchange(self, space: int, v: torch.Tensor, reverse: bool = False):
         """One halo exchange of a vector of `space` (the cycle does this by itself; for tests)."""

@@ -125,6 +125,137 @@ def mode_cpu(args):
         print("cpu distributed checks passed", flush=True)
 
 
+def parse_grid(text, world):
+    if not text:
+        return (1, 1, world)
+    g = tuple(int(v) for v in text.split("x"))
+    assert len(g) == 3 and g[0] * g[1] * g[2] == world, (text, world)
+    return g
+
+
+def exchange_box_np(v, part, dims, own0, own_n, comps=1, width=1, reverse=False):
+    """The box exchange of common.hpp (HipHandle::exchange_on / exchange_reverse_add) restated in numpy + gloo: axis after axis
+    -- x, y, z forward; z, y, x for the reverse (adding) direction -- each with the two face neighbours only, the message
+    spanning the whole local extent of the other two axes (so that edges and corners travel with the later axes)."""
+    V = v.reshape(dims[2], dims[1], dims[0] * comps)
+    stride = (1, part.grid[0], part.grid[0] * part.grid[1])
+
+    def sl(d, a, b):
+        u = comps if d == 0 else 1
+        idx = [slice(None)] * 3
+        idx[2 - d] = slice(a * u, b * u)
+        return tuple(idx)
+    for d in ((2, 1, 0) if reverse else (0, 1, 2)):
+        o0, o1, w = own0[d], own0[d] + own_n[d], width
+        ops, recv = [], {}
+        for side, has in (("low", part.coord[d] > 0), ("high", part.coord[d] + 1 < part.grid[d])):
+            if not has:
+                continue
+            peer = part.rank - stride[d] if side == "low" else part.rank + stride[d]
+            if not reverse:
+                src = V[sl(d, o0, o0 + w)] if side == "low" else V[sl(d, o1 - w, o1)]
+            else:
+                src = V[sl(d, o0 - w, o0)] if side == "low" else V[sl(d, o1, o1 + w)]
+            t = torch.from_numpy(np.ascontiguousarray(src).reshape(-1).copy())
+            r = torch.empty_like(t)
+            ops += [dist.P2POp(dist.isend, t, peer), dist.P2POp(dist.irecv, r, peer)]
+            recv[side] = (r, src.shape)
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
+        for side, (r, shape) in recv.items():
+            blk = r.numpy().reshape(shape)
+            if not reverse:
+                V[sl(d, o0 - w, o0) if side == "low" else sl(d, o1, o1 + w)] = blk
+            else:
+                V[sl(d, o0, o0 + w) if side == "low" else sl(d, o1 - w, o1)] += blk
+
+
+def mode_cpu_box(args):
+    """The box partition on CPU ranks: local problems of M.BoxPartition, the product's HOST setup on the local (extended) box,
+    the oracle's numpy kernels and the numpy restatement of the axis-by-axis exchange; owned parts must reproduce the global
+    operators."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    grid = parse_grid(args.grid, world)
+    cells = tuple(8 * g if g > 1 else 6 for g in grid)
+    material = "linear"
+    part = M.BoxPartition(cells, rank, grid, length=tuple(c / 8.0 for c in cells))
+    mesh = O.StructuredMesh(cells)
+    mesh.h = part.h
+    gprob = M.LaplaceProblem(cells, material, cell_size=part.h)
+    coef_g = gprob.coefficient.numpy()
+    mf_g = O.MatrixFreeLaplace(mesh, coef_g)
+    Rg = M.host_build_restrictor(gprob, PRM, matrix_free=True)
+    Acg = M.host_galerkin(gprob, Rg, "matrix_free")
+    rng = np.random.default_rng(0)
+    xg = rng.random(mesh.n_dofs)
+    lprob = part.local_problem(material)
+    lmesh = O.StructuredMesh(part.local_cells)
+    lmesh.h = part.h
+    flags = lprob.constrained.numpy()
+    own_l, own_g, loc_g = part.owned_local_index().numpy(), part.owned_global_index().numpy(), part.local_global_index().numpy()
+    # every DoF has exactly one owner; ghost flags exactly off the owned box (global Dirichlet nodes keep 1)
+    cover = torch.zeros(mesh.n_dofs, dtype=torch.float64); cover[torch.from_numpy(own_g)] = 1.0
+    assert (_all_reduce_cpu(cover).numpy() == 1.0).all()
+    ghost = np.ones(part.n_local_dofs, bool); ghost[own_l] = False
+    assert ((flags == 2) <= ghost).all() and (flags[ghost] != 0).all() and (flags[own_l] != 2).all()
+    mf_l = O.MatrixFreeLaplace(lmesh, lprob.coefficient.numpy(), constrained=(flags == 1))
+    # coefficient table of the box == the cells of the global table
+    lc, gc = part.local_cells, cells
+    k, j, i = np.meshgrid(*(np.arange(lc[d]) + part.offset[d] for d in (2, 1, 0)), indexing="ij")
+    np.testing.assert_array_equal(lprob.coefficient.numpy(), coef_g.reshape(-1, coef_g.shape[-1])[((k * gc[1] + j) * gc[0] + i).reshape(-1)])
+    # garbage in the ghosts, then the exchange must restore them -- edges and corners included
+    xl = xg[loc_g].copy()
+    xl_g = xl.copy(); xl_g[ghost] = -7.0
+    exchange_box_np(xl_g, part, part.local_nodes, part.own0, part.own_n)
+    # (one layer per side travels: the nodes within one layer of the owned box along EVERY axis are valid afterwards)
+    ln = part.local_nodes
+    near = np.ones(ln[::-1], bool)
+    for d in range(3):
+        idx = np.arange(ln[d])
+        ok = (idx >= part.own0[d] - (part.coord[d] > 0)) & (idx < part.own0[d] + part.own_n[d] + (part.coord[d] + 1 < grid[d]))
+        near &= ok.reshape([-1 if a == 2 - d else 1 for a in range(3)])
+    near = near.reshape(-1)
+    assert near.sum() > len(own_l)
+    np.testing.assert_array_equal(xl_g[near], xl[near])
+    def gather(v_local, idx_l, idx_g, n):
+        out = torch.zeros(n, dtype=torch.float64)
+        out[torch.from_numpy(idx_g)] = torch.from_numpy(np.ascontiguousarray(v_local[idx_l]))
+        return _all_reduce_cpu(out).numpy()
+    np.testing.assert_allclose(gather(mf_l.vmult(xl_g), own_l, own_g, mesh.n_dofs), mf_g.vmult(xg), rtol=1e-13, atol=1e-14)
+    # ---- restrictor / coarse operator of the local box against the global ones
+    Rl = M.host_build_restrictor(lprob, PRM, matrix_free=True)
+    na_l = tuple(c // 2 for c in part.local_cells); na_g = tuple(c // 2 for c in cells)
+    c_own0 = tuple(g // 2 for g in part.ghost_lo); c_own_n = tuple(p // 2 for p in part.per)
+    c_g0 = tuple(part.c0[d] // 2 - c_own0[d] for d in range(3))
+    def cids(lo, n, dims, shift):
+        kk = np.arange(lo[2], lo[2] + n[2]).reshape(-1, 1, 1, 1) + shift[2]
+        jj = np.arange(lo[1], lo[1] + n[1]).reshape(1, -1, 1, 1) + shift[1]
+        ii = np.arange(lo[0], lo[0] + n[0]).reshape(1, 1, -1, 1) + shift[0]
+        return ((((kk * dims[1] + jj) * dims[0] + ii) * 2) + np.arange(2).reshape(1, 1, 1, -1)).reshape(-1)
+    c_own_l, c_own_g = cids(c_own0, c_own_n, na_l, (0, 0, 0)), cids(c_own0, c_own_n, na_g, c_g0)
+    c_loc_g = cids((0, 0, 0), na_l, na_g, c_g0)
+    assert Rl.shape[0] == len(c_loc_g)
+    ncg = Rg.shape[0]
+    np.testing.assert_allclose(gather(Rl @ xl, c_own_l, c_own_g, ncg), Rg @ xg, rtol=1e-12, atol=1e-14)
+    xc_g = rng.random(ncg)
+    xc_l = xc_g[c_loc_g].copy()
+    np.testing.assert_allclose(gather(Rl.T @ xc_l, own_l, own_g, mesh.n_dofs), Rg.T @ xc_g, rtol=1e-12, atol=1e-14)
+    Acl = M.host_galerkin(lprob, Rl, "matrix_free")
+    np.testing.assert_allclose(gather(Acl @ xc_l, c_own_l, c_own_g, ncg), Acg @ xc_g, rtol=1e-11, atol=1e-14)
+    # reverse (adding) exchange on the coarse space: an owned entry ends up with the number of ranks that hold a copy of it
+    ones = np.ones(len(c_loc_g))
+    exchange_box_np(ones, part, na_l, c_own0, c_own_n, comps=2, reverse=True)
+    nd = c_own_l // 2
+    pos = (nd % na_l[0], (nd // na_l[0]) % na_l[1], nd // (na_l[0] * na_l[1]))
+    expect = np.ones(len(c_own_l))
+    for d in range(3):
+        expect = expect * (1 + ((pos[d] == c_own0[d]) & (part.coord[d] > 0)) + ((pos[d] == c_own0[d] + c_own_n[d] - 1) & (part.coord[d] + 1 < grid[d])))
+    np.testing.assert_array_equal(ones[c_own_l], expect)
+    if rank == 0:
+        print("cpu box checks passed", flush=True)
+
+
 def mode_protocol(args):
     """CPU restatement of the distributed setup protocol of amg_device_setup.hip: on a z-slab partition of a node grid
     with two unknowns per node, P = (I - w D^-1 A) P_tent and A_c = P^T A P are READ OFF from operator applications on
@@ -305,7 +436,7 @@ def mode_protocol(args):
 
 
 MESHES = {
-    # name: (cells per rank along z, (cx, cy), material, amg parameters)
+    # name: (cells per rank along z, (cx, cy) = cells per rank along x and y (slabs: the global counts), material, amg parameters)
     # small: A_c (768 rows at 2 ranks) is gathered right away: replicated hierarchy behind one all-gather
     "small": (8, (16, 12), "linear", {"coarsest_size": 300}),
     # wide: 67 node columns and 65 node rows with a constant material: the operator runs its one-coefficient-per-cell
@@ -317,6 +448,11 @@ MESHES = {
     # deep01: the same with the V(0,1) coarse cycle of the bench (solver.amg.pre_smoothing_levels 0): b is restricted and the
     # correction added on every level of the aggregation hierarchy, distributed and gathered ones alike
     "deep01": (24, (16, 16), "linear", {"coarsest_size": 40, "replicate_rows": 40, "pre_smoothing_levels": 0}),
+    # boxes (--grid 2x1x1, 2x2x1, 2x1x2, 1x2x2): 24 cells per rank along every axis keep two aggregation levels distributed along
+    # the split axes (12 agglomerates -> 6 -> 3 nodes per rank; reach 1, 2, 3), the third is gathered through the permutation
+    # of the rank-ordered blocks
+    "cube": (24, (24, 24), "linear", {"coarsest_size": 40, "replicate_rows": 40, "pre_smoothing_levels": 0}),
+    "cube11": (24, (24, 24), "constant", {"coarsest_size": 40, "replicate_rows": 40}),
 }
 
 
@@ -325,9 +461,12 @@ def mode_gpu(args):
     # gloo: all ranks share cuda:0 (host transport); nccl: one GPU per rank, the native RCCL transport
     native = dist.get_backend() == "nccl"
     torch.cuda.set_device(rank if native else 0)
+    grid = parse_grid(args.grid, world)
     per, (cx, cy), material, amg = MESHES[args.mesh]
-    cells = (cx, cy, per * world)
-    part = M.SlabPartition(cells, rank, world, length=tuple(c / float(cells[0]) for c in cells))   # cubic cells
+    # (cx, cy): cells per rank along x and y, `per` along z
+    cells = (cx * grid[0], cy * grid[1], per * grid[2])
+    part = M.BoxPartition(cells, rank, grid, length=tuple(c / float(cells[0]) for c in cells))   # cubic cells
+    box = part.split_xy
     params = dict(PRM)
     params.update({"smoother": {"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0},
                    "solver": {"type": "amg", "amg": dict(amg)}, "is preconditioner": False})
@@ -352,26 +491,39 @@ def mode_gpu(args):
     hg = M.Hierarchy(gctx, "HipMatrixFreeMeshEvaluator", gprob, params)
     _, glmin, glmax = hg.smoother_info()
     assert abs(glmax - lmax) < 1e-9 * lmax and abs(glmin - lmin) < 1e-9 * lmax, (lmin, lmax, glmin, glmax)
-    ng, nl = gprob.n_dofs, part.plane * part.n_local_planes
+    ng, nl = gprob.n_dofs, part.n_local_dofs
+    own_l, own_g, loc_g = part.owned_local_index().numpy(), part.owned_global_index().numpy(), part.local_global_index().numpy()
+    f1 = tr.space_index(1)                     # the library's own description of the fine space must say the same
+    assert np.array_equal(f1[0].numpy(), own_l) and np.array_equal(f1[1].numpy(), own_g) and np.array_equal(f1[2].numpy(), loc_g)
+    ghost_l = np.ones(nl, bool); ghost_l[own_l] = False
     rng = np.random.default_rng(0)
     xg, bg = rng.random(ng), rng.random(ng)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     def local(vg, poison=True):
-        v = part.local_from_global(torch.from_numpy(vg)).numpy()
+        v = vg[loc_g].copy()
         if poison:   # ghosts must come from the exchange, not from the test
-            lo, cnt = part.owned_plane_begin, part.owned_plane_count
-            v[:lo * part.plane] = 1e30
-            v[(lo + cnt) * part.plane:] = 1e30
+            v[ghost_l] = 1e30
         return v
+    def gather(v_local, idx_l, idx_g, n):
+        out = torch.zeros(n, dtype=torch.float64)
+        out[torch.from_numpy(idx_g)] = torch.from_numpy(np.ascontiguousarray(v_local[idx_l]))
+        return _all_reduce_cpu(out).numpy()
     def check(local_out, global_out, what, tol=1e-12):
-        got = gather_owned(local_out.cpu().numpy(), part, ng, part.owned_slice(), part.global_slice())
+        got = gather(local_out.cpu().numpy(), own_l, own_g, ng)
         ref = global_out.cpu().numpy()
         err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300)
         assert err < tol, f"{what}: {err}"
     # fine operator
     yl = torch.zeros(nl, dtype=torch.float64, device="cuda"); yg = torch.empty(ng, dtype=torch.float64, device="cuda")
+    v0 = tr.exchange_volume()
     h.operator_apply(0, dev(local(xg)), yl); hg.operator_apply(0, dev(xg), yg)
+    sent = tr.exchange_volume() - v0
     check(yl, yg, "fine operator")
+    # what one fine exchange moves: per split axis the two (or one) faces of the local box, the later axes with the ghost
+    # columns of the earlier ones -- a box sends faces of about (N / 2)^2 where a slab sends planes of N^2
+    ln = part.local_nodes
+    expect = sum((ln[0] * ln[1] * ln[2] // ln[d]) * ((part.coord[d] > 0) + (part.coord[d] + 1 < grid[d])) for d in range(3))
+    assert sent == expect, (sent, expect)
     # smoother (3 fused steps, 3 exchanges)
     xl = dev(local(xg)); xs = dev(xg)
     h.smoother_apply(0, dev(local(bg, False)), xl); hg.smoother_apply(0, dev(bg), xs)
@@ -382,52 +534,56 @@ def mode_gpu(args):
     h.operator_apply(0, dev(local(xg)), yl2)
     xl2 = dev(local(xg))
     h.smoother_apply(0, dev(local(bg, False)), xl2)
-    sl = part.owned_slice()
+    sl = torch.from_numpy(own_l).cuda()
     assert torch.equal(yl2[sl], yl[sl]) and torch.equal(xl2[sl], xl[sl]), "overlapped exchange changed the result"
     ctx.set_overlap_exchange(True)
     # restriction / prolongation / coarse operator
-    lay, nlay, cb, cc = tr.layout(2)
-    sp = tr.space(2)
-    assert sp["global_begin"] == part.z0 // 2 - cb and sp["global_layers"] == cells[2] // 2
-    ncl, ncg = lay * nlay, hg.level_size(1)
+    c_own_l, c_own_g, c_loc_g = (t.numpy() for t in tr.space_index(2))
+    cb = tr.box(2)
+    assert cb["comps"] == 2 and cb["gn"] == tuple(c // 2 for c in cells)
+    for d in range(3):
+        assert cb["own_n"][d] == part.per[d] // 2 and cb["g0"][d] + cb["own0"][d] == part.c0[d] // 2
+    if not box:
+        lay, nlay, cb0, cc0 = tr.layout(2)
+        sp = tr.space(2)
+        assert sp["global_begin"] == part.z0 // 2 - cb0 and sp["global_layers"] == cells[2] // 2
+    ncl, ncg = len(c_loc_g), hg.level_size(1)
     assert h.level_size(1) == ncl
-    c_glob0 = (part.z0 // 2 - cb) * lay
-    def gather_c(v):
-        out = torch.zeros(ncg, dtype=torch.float64)
-        out[c_glob0 + cb * lay: c_glob0 + (cb + cc) * lay] = v.cpu()[cb * lay:(cb + cc) * lay]
-        return _all_reduce_cpu(out).numpy()
+    c_ghost = np.ones(ncl, bool); c_ghost[c_own_l] = False
+    gather_c = lambda v: gather(v.cpu().numpy(), c_own_l, c_own_g, ncg)
     rl = torch.zeros(ncl, dtype=torch.float64, device="cuda"); rg = torch.empty(ncg, dtype=torch.float64, device="cuda")
     h.restrictor_apply(1, dev(local(xg)), rl); hg.restrictor_apply(1, dev(xg), rg)
     np.testing.assert_allclose(gather_c(rl), rg.cpu().numpy(), rtol=1e-12, atol=1e-13)
     # residual + restriction as the cycle computes them (one pass over x and b where the rows of R A repeat themselves:
     # x is then needed two ghost layers deep, b one -- both poisoned here, so they must come from the exchanges)
-    if args.mesh == "wide":
+    if args.mesh == "wide" and not box:
         assert h.residual_restriction_classes() > 0 and hg.residual_restriction_classes() > 0
     r1 = torch.zeros(ncl, dtype=torch.float64, device="cuda"); r1g = torch.empty(ncg, dtype=torch.float64, device="cuda")
     h.restrict_residual(dev(local(xg)), dev(local(bg)), r1); hg.restrict_residual(dev(xg), dev(bg), r1g)
     np.testing.assert_allclose(gather_c(r1), r1g.cpu().numpy(), rtol=1e-11, atol=1e-12 * np.abs(r1g.cpu().numpy()).max())
     xcg = rng.random(ncg)
-    xcl = xcg[c_glob0: c_glob0 + ncl].copy()
-    xcl[:cb * lay] = 1e30
-    xcl[(cb + cc) * lay:] = 1e30
+    xcl = xcg[c_loc_g].copy()
+    xcl[c_ghost] = 1e30
     pl = torch.zeros(nl, dtype=torch.float64, device="cuda"); pg = torch.empty(ng, dtype=torch.float64, device="cuda")
     h.restrictor_apply(1, dev(xcl), pl, 1); hg.restrictor_apply(1, dev(xcg), pg, 1)
     check(pl, pg, "prolongation")
     al = torch.zeros(ncl, dtype=torch.float64, device="cuda"); ag = torch.empty(ncg, dtype=torch.float64, device="cuda")
     h.operator_apply(1, dev(xcl), al); hg.operator_apply(1, dev(xcg), ag)
     np.testing.assert_allclose(gather_c(al), ag.cpu().numpy(), rtol=1e-11, atol=1e-13)
-    # reverse (adding) exchange: every ghost entry returns to its owner exactly once
+    # reverse (adding) exchange: every ghost entry returns to its owner exactly once -- an owned entry ends up with the number
+    # of ranks that hold a copy of it (its boundary layers along every axis with a neighbour)
     ones = torch.ones(ncl, dtype=torch.float64, device="cuda")
     tr.exchange(2, ones, reverse=True)
-    expect = np.ones(ncl)
-    if rank > 0:
-        expect[cb * lay:(cb + 1) * lay] += 1.0
-    if rank + 1 < world:
-        expect[(cb + cc - 1) * lay:(cb + cc) * lay] += 1.0
-    np.testing.assert_array_equal(ones.cpu().numpy()[cb * lay:(cb + cc) * lay], expect[cb * lay:(cb + cc) * lay])
+    nd = c_own_l // cb["comps"]
+    pos = (nd % cb["dims"][0], (nd // cb["dims"][0]) % cb["dims"][1], nd // (cb["dims"][0] * cb["dims"][1]))
+    expect = np.ones(len(c_own_l))
+    for d in range(3):
+        copies = 1 + ((pos[d] == cb["own0"][d]) & (part.coord[d] > 0)) + ((pos[d] == cb["own0"][d] + cb["own_n"][d] - 1) & (part.coord[d] + 1 < grid[d]))
+        expect = expect * copies
+    np.testing.assert_array_equal(ones.cpu().numpy()[c_own_l], expect)
     # the coarse solve: the aggregation hierarchy coupled across the ranks against the single-process one
     bcg = rng.random(ncg)
-    bcl = bcg[c_glob0: c_glob0 + ncl].copy()
+    bcl = bcg[c_loc_g].copy()
     scl = torch.zeros(ncl, dtype=torch.float64, device="cuda"); scg = torch.empty(ncg, dtype=torch.float64, device="cuda")
     h.coarse_apply(dev(bcl), scl); hg.coarse_apply(dev(bcg), scg)
     np.testing.assert_allclose(gather_c(scl), scg.cpu().numpy(), rtol=1e-9, atol=1e-11 * np.abs(scg.cpu().numpy()).max())
@@ -464,8 +620,8 @@ def mode_gpu(args):
     np.testing.assert_allclose(hist / hist[0], res_o[:n_cycles + 1] / res_o[0], rtol=1e-9, atol=1e-12)
     assert rate < 0.6
     if rank == 0:
-        print("gpu distributed checks passed; transport", tr.name(), "exchanges", tr.n_exchanges(), "spaces", tr.space(1)["n_spaces"],
-              "residuals", ["%.3e" % v for v in hist[:6]], flush=True)
+        print("gpu distributed checks passed; grid", "x".join(map(str, grid)), "transport", tr.name(), "exchanges", tr.n_exchanges(),
+              "spaces", tr.space(1)["n_spaces"], "residuals", ["%.3e" % v for v in hist[:6]], flush=True)
 
 
 if __name__ == "__main__":
@@ -473,6 +629,7 @@ if __name__ == "__main__":
     ap.add_argument("--mode", default="cpu")
     ap.add_argument("--mesh", default="small")
     ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--grid", default="", help="ranks along x, y, z as 2x2x1 (default: slabs, 1x1xworld)")
     a = ap.parse_args()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if a.backend == "nccl":
@@ -482,6 +639,6 @@ if __name__ == "__main__":
     else:
         dist.init_process_group("gloo")
     try:
-        {"cpu": mode_cpu, "gpu": mode_gpu, "protocol": mode_protocol}[a.mode](a)
+        {"cpu": mode_cpu, "cpu_box": mode_cpu_box, "gpu": mode_gpu, "protocol": mode_protocol}[a.mode](a)
     finally:
         dist.destroy_process_group()

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(mfmg_lib):
 def test_abi_version_of_header_and_library_agree(mfmg_lib):
     text = open(os.path.join(ROOT, "include", "mfmg_hip.h")).read()
     declared = int(re.search(r"#define\s+MFMG_HIP_ABI_VERSION\s+(\d+)", text).group(1))
-    assert mfmg_lib.mfmg_hip_abi_version() == declared == 2
+    assert mfmg_lib.mfmg_hip_abi_version() == declared == 3
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a box without a GPU")

@@ -20,10 +20,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(mode, world, timeout=600, mesh="small", backend="gloo"):
+def _run(mode, world, timeout=600, mesh="small", backend="gloo", grid=""):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--mesh", mesh, "--backend", backend]
+           os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--mesh", mesh, "--backend", backend, "--grid", grid]
     env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
@@ -50,6 +50,40 @@ def test_slab_partition_geometry(mfmg_lib):
         M.SlabPartition((8, 8, 10), 0, 2)
 
 
+def test_box_partition_geometry(mfmg_lib):
+    """2 x 2 x 2 boxes: one owner per DoF, ghost layers exactly towards the neighbours, and the volume of a fine exchange at
+    the shape of BASELINE configs[3] (8 ranks, 256^3 cells each) against slabs of the same mesh."""
+    cells = (8, 12, 16)
+    grid = (2, 2, 2)
+    covered = np.zeros(9 * 13 * 17, dtype=int)
+    for r in range(8):
+        p = M.BoxPartition(cells, r, grid)
+        assert p.coord == (r % 2, (r // 2) % 2, r // 4)
+        covered[p.owned_global_index().numpy()] += 1
+        for d in range(3):
+            assert p.ghost_lo[d] == (2 if p.coord[d] > 0 else 0) and p.ghost_hi[d] == (2 if p.coord[d] == 0 else 0)
+            assert p.local_cells[d] == cells[d] // 2 + 2
+        flags = p.local_problem("constant").constrained.numpy()
+        own = np.zeros(p.n_local_dofs, bool); own[p.owned_local_index().numpy()] = True
+        assert (flags[own] != 2).all() and (flags[~own] != 0).all()
+        assert np.array_equal(p.local_global_index().numpy()[p.owned_local_index().numpy()], p.owned_global_index().numpy())
+    assert (covered == 1).all()
+    assert M.box_grid(2) == (2, 1, 1) and M.box_grid(4) == (2, 2, 1) and M.box_grid(8) == (2, 2, 2) and M.box_grid(3) == (3, 1, 1)
+    with pytest.raises(ValueError):
+        M.BoxPartition((10, 8, 8), 0, (2, 1, 1))
+    # doubles one rank sends per fine exchange, 512^3 cells on 8 ranks: three faces of 259^2 against two planes of 513^2
+    box = M.BoxPartition((512,) * 3, 0, grid)
+    slab = M.SlabPartition((512,) * 3, 3, 8)
+    assert box.exchange_doubles() == 3 * 259 * 259 and slab.exchange_doubles() == 2 * 513 * 513
+    assert slab.exchange_doubles() / box.exchange_doubles() > 2.6
+
+
+@pytest.mark.parametrize("world,grid", [(2, "2x1x1"), (4, "2x2x1"), (4, "1x2x2"), (8, "2x2x2")])
+def test_box_construction_cpu_gloo(mfmg_lib, world, grid):
+    """Box partition: host setup on the local boxes + the axis-by-axis exchange restated in numpy over gloo."""
+    assert "cpu box checks passed" in _run("cpu_box", world, grid=grid)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_construction_cpu_gloo(mfmg_lib, world):
     assert "cpu distributed checks passed" in _run("cpu", world)
@@ -67,6 +101,16 @@ def test_distributed_setup_protocol_cpu_gloo(mfmg_lib, world):
 @pytest.mark.parametrize("world,mesh", [(2, "small"), (3, "small"), (2, "wide"), (2, "deep"), (4, "deep"), (2, "deep01")])
 def test_distributed_library_path_shared_gpu(mfmg_lib, world, mesh):
     assert "gpu distributed checks passed" in _run("gpu", world, mesh=mesh)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,grid,mesh", [(2, "2x1x1", "small"), (4, "2x2x1", "small"), (4, "2x2x1", "cube"), (4, "2x1x2", "cube11"),
+                                             (4, "1x2x2", "cube")])
+def test_box_decomposition_library_path_shared_gpu(mfmg_lib, world, grid, mesh):
+    """Boxes instead of slabs: every pair of split axes, with the aggregation levels distributed along them --
+    each operator against the single-process hierarchy, 20-cycle history == single process == oracle to 1e-10, and the
+    doubles a fine exchange moves."""
+    assert "gpu distributed checks passed; grid " + grid in _run("gpu", world, mesh=mesh, grid=grid, timeout=900)
 
 
 @pytest.mark.gpu
