@@ -70,6 +70,10 @@ def parse_args():
                     help="report an extra leg that raises as an `error` entry instead of failing the run")
     ap.add_argument("--box", type=str, default="", help="gx,gy,gz: global cells of a distributed run instead of the "
                     "weak-scaling box (rehearsals of the slab shapes of larger runs on fewer ranks)")
+    ap.add_argument("--partition", default="box", choices=["box", "slab"],
+                    help="N > 1: equal boxes on the grid the weak-scaling mesh grows by (1x1x2, 1x2x2, 2x2x2; SURVEY.md 8e) or slabs "
+                         "along z")
+    ap.add_argument("--grid", type=str, default="", help="px,py,pz: ranks along x, y, z of a box run (default: follows the mesh)")
     ap.add_argument("--tile", type=str, default="", help="ty,tz[,waves] override of the operator tile (default: timed choice)")
     return ap.parse_args()
 
@@ -451,7 +455,17 @@ def main():
     if world > 1:
         if world & (world - 1):
             raise SystemExit("--gpus must be a power of two")
-        part = M.SlabPartition((gx, gy, gz), rank, world, length=(gx / args.cells, gy / args.cells, gz / args.cells))
+        # boxes: the ranks sit where the weak-scaling mesh grew (z, then y, then x), one box of cells^3 each
+        rank_grid = (1, 1, world)
+        if args.grid:
+            rank_grid = tuple(int(v) for v in args.grid.split(","))
+        elif args.partition == "box":
+            rank_grid = [1, 1, 1]
+            for i in range(int(round(math.log2(world)))):
+                rank_grid[2 - i % 3] *= 2
+            rank_grid = tuple(rank_grid)
+        assert rank_grid[0] * rank_grid[1] * rank_grid[2] == world, "--grid must multiply to --gpus"
+        part = M.BoxPartition((gx, gy, gz), rank, rank_grid, length=(gx / args.cells, gy / args.cells, gz / args.cells))
         if backend != "nccl":
             os.environ.setdefault("MFMG_BENCH_TRANSPORT", "host")
         transport = M.HaloTransport(ctx, part, 2, transport=os.environ.get("MFMG_BENCH_TRANSPORT") or None)
@@ -490,7 +504,7 @@ def main():
     degree, lmin, lmax = h.smoother_info()
     n_local, n_coarse = h.level_size(0), h.level_size(1)
     # DoFs this rank owns (the local vector also holds the ghost planes of the neighbours)
-    n_fine = n_local if part is None else part.plane * part.owned_plane_count
+    n_fine = n_local if part is None else part.own_n[0] * part.own_n[1] * part.own_n[2]
     n_global = n_fine if part is None else part.n_global_dofs
 
     # the same global start vector whatever the number of ranks (a rank cuts its slab out of it)
@@ -614,7 +628,8 @@ def main():
                 "coarse_amg_levels_rows_nnzA_nnzP": (h.coarse_amg_shapes() if args.coarse == "amg" else None),
                 "smoother": {"type": "Chebyshev", "degree": degree, "lambda_min": lmin, "lambda_max": lmax},
                 "parallelism": "1 GPU" if world == 1 else
-                               f"{world} GPUs, z-slab domain decomposition of a {gx}x{gy}x{gz}-cell box, halo exchange "
+                               f"{world} GPUs, {'x'.join(map(str, part.grid))} ranks (x, y, z) on a {gx}x{gy}x{gz}-cell box "
+                               f"({'boxes' if part.split_xy else 'slabs along z'}), halo exchange "
                                f"per operator application on every level of the cycle (transport: {transport.name()}, "
                                f"{n_exchanges_per_cycle:.1f} point-to-point exchanges per cycle), aggregation levels coupled "
                                f"across the ranks, the levels from {h.coarse_amg_gather_rows()} global rows down gathered and solved "

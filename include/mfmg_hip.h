@@ -38,8 +38,9 @@ extern "C" {
  *   2  round 2: mfmg_hip_context_set_communicator(ctx, rank, n_ranks, ghost_low, ghost_high) replaces the old signature,
  *      mfmg_hip_context_set_halo_buffers removed (transports: mfmg_hip_context_use_rccl / _use_host_transport)
  *      (round 3 added mfmg_hip_hierarchy_ap_apply, mfmg_hip_rccl_available, mfmg_hip_abi_version: no change of the version)
- *   3  round 3: box decomposition -- mfmg_hip_host_sendrecv_fn receives the two peer ranks (a box has neighbours other than
- *      rank -+ 1); added mfmg_hip_context_set_communicator_box, mfmg_hip_context_halo_box, mfmg_hip_context_exchange_volume
+ *   3  round 3: box decomposition -- mfmg_hip_host_exchange_fn (any number of partner ranks per call) replaces
+ *      mfmg_hip_host_sendrecv_fn (rank -+ 1); added mfmg_hip_context_set_communicator_box, mfmg_hip_context_halo_box,
+ *      mfmg_hip_context_exchange_volume
  * mfmg_hip_abi_version() returns the value the loaded library was built with. */
 #define MFMG_HIP_ABI_VERSION 3
 
@@ -80,10 +81,10 @@ void *mfmg_hip_context_stream(mfmg_hip_context_t ctx);
  * Boxes (the reference's p4est partition, tests/laplace_matrix_free.hpp:222, with rank-local agglomerates,
  * include/mfmg/common/amge.templates.hpp:453-478,604-621): mfmg_hip_context_set_communicator_box places the rank at
  * (cx, cy, cz) = (rank % gx, (rank / gx) % gy, rank / (gx gy)) of a gx x gy x gz grid of equal boxes; interface planes belong
- * to the upper box (the last box of an axis also owns the top plane).  An exchange runs axis by axis -- x, y, then z, each
- * with the two face neighbours, the later axes carrying the ghost columns the earlier ones received -- so that edges and
- * corners need no partners of their own: per fine exchange a rank of a 2 x 2 x 2 grid sends 3 faces of about (N/2)^2 doubles
- * where a slab of 8 sends 2 planes of N^2.
+ * to the upper box (the last box of an axis also owns the top plane).  One exchange = one packing kernel, ONE grouped
+ * send/recv with all neighbours (faces, edges, corners: 7 on a 2 x 2 x 2 grid, at most 26) and one unpacking kernel: per fine
+ * exchange a rank of a 2 x 2 x 2 grid sends 3 faces of (N/2)^2 doubles (+ 3 edges + 1 corner) where a slab of 8 sends 2 planes
+ * of N^2.
  * Every level of the V-cycle is coupled across the ranks: before an operator application the library refreshes
  * the ghost layers of its input (owner -> ghost), after a transposed prolongator it returns the partial sums in
  * the ghost layers to their owners (ghost -> owner, added); the levels of the aggregation hierarchy whose global
@@ -95,12 +96,12 @@ void *mfmg_hip_context_stream(mfmg_hip_context_t ctx);
  *                                        rank 0 and must reach every rank through the caller's own channel;
  *   mfmg_hip_context_use_host_transport  the library stages the layers through pinned host memory and calls the
  *                                        callbacks with HOST pointers (tests: gloo, several ranks on one card).
- * `sendrecv` exchanges n_low doubles with rank `peer_low` and n_high with rank `peer_high` (a count of 0: no such neighbour;
- * slabs: rank - 1 and rank + 1);
+ * `exchange` sends count[i] doubles from send[i] to rank peers[i] and receives as many from it into recv[i], for i < n, all
+ * at once (slabs: rank - 1 and / or rank + 1);
  * `allreduce` combines `n` doubles over all ranks in place (op 0: sum, 1: max); `allgather` collects `n` doubles of
  * every rank into `out` (n * n_ranks, rank order). */
-typedef int (*mfmg_hip_host_sendrecv_fn)(void *user, int32_t peer_low, int32_t peer_high, const double *send_low, double *recv_low,
-                                         int64_t n_low, const double *send_high, double *recv_high, int64_t n_high);
+typedef int (*mfmg_hip_host_exchange_fn)(void *user, int32_t n, const int32_t *peers, const double *const *send, double *const *recv,
+                                         const int64_t *count);
 typedef int (*mfmg_hip_host_allreduce_fn)(void *user, double *values, int n, int op);
 typedef int (*mfmg_hip_host_allgather_fn)(void *user, const double *in, int64_t n, double *out);
 int mfmg_hip_context_set_communicator(mfmg_hip_context_t ctx, int32_t rank, int32_t n_ranks, int32_t ghost_cells_low,
@@ -114,7 +115,7 @@ int mfmg_hip_rccl_unique_id(unsigned char out[128]);
  * only, no RCCL call is made).  Callers agree on the transport with a collective over this flag before they choose. */
 int mfmg_hip_rccl_available(void);
 int mfmg_hip_context_use_rccl(mfmg_hip_context_t ctx, const unsigned char unique_id[128]);
-int mfmg_hip_context_use_host_transport(mfmg_hip_context_t ctx, mfmg_hip_host_sendrecv_fn sendrecv,
+int mfmg_hip_context_use_host_transport(mfmg_hip_context_t ctx, mfmg_hip_host_exchange_fn exchange,
                                         mfmg_hip_host_allreduce_fn allreduce, mfmg_hip_host_allgather_fn allgather, void *user);
 /* "rccl", "host" or "" (none) */
 int mfmg_hip_context_transport_name(mfmg_hip_context_t ctx, char *buffer, size_t buffer_size);

@@ -220,14 +220,14 @@ int mfmg_hip_context_use_rccl(mfmg_hip_context_t ctx, const unsigned char unique
   });
 }
 
-int mfmg_hip_context_use_host_transport(mfmg_hip_context_t ctx, mfmg_hip_host_sendrecv_fn sendrecv,
+int mfmg_hip_context_use_host_transport(mfmg_hip_context_t ctx, mfmg_hip_host_exchange_fn exchange,
                                         mfmg_hip_host_allreduce_fn allreduce, mfmg_hip_host_allgather_fn allgather, void *user)
 {
   return guarded([&] {
     require(ctx != nullptr, "null context");
-    require(sendrecv && allreduce && allgather, "null transport callbacks");
+    require(exchange && allreduce && allgather, "null transport callbacks");
     HaloCommunicator &c = ctx->handle->comm;
-    c.transport = make_host_transport(c.rank, c.n_ranks, sendrecv, allreduce, allgather, user);
+    c.transport = make_host_transport(c.rank, c.n_ranks, exchange, allreduce, allgather, user);
   });
 }
 

@@ -270,9 +270,10 @@ struct KernelProfiler
 //   reverse-add exchange ghost -> owner: the `width` ghost layers are sent back and ADDED to the owner's
 //                        boundary layers (after a transposed prolongator scattered partial sums into them).
 // The ranks form a grid[0] x grid[1] x grid[2] arrangement (rank = cx + grid[0] (cy + grid[1] cz)); 1 x 1 x N are slabs
-// along z, whose layers are contiguous runs of the vector and travel without packing.  A box exchanges axis after
-// axis -- x, then y with the x ghosts just received, then z with both -- so that edges and corners arrive through the
-// six face neighbours (two messages per split axis, no diagonal partners); the reverse exchange runs z, y, x.
+// along z, whose layers are contiguous runs of the vector and travel without packing.  A box exchanges with ALL its
+// neighbours at once -- up to 26 in general, 7 on a 2 x 2 x 2 grid: 3 faces, 3 edges, 1 corner -- one packing kernel, one
+// grouped send/recv, one unpacking kernel: towards the neighbour at offset o in {-1, 0, 1}^3 travel the `width` owned
+// layers next to it along the axes with o_d != 0, over the OWNED range of the axes with o_d = 0.
 struct HaloSpace
 {
   // z (the slowest axis)
@@ -342,6 +343,15 @@ struct HaloSpace
   }
 };
 
+// the sub-boxes of a local array that one box exchange packs (or unpacks): region r = nodes [b, b + n) per axis, its entries
+// at off[r] .. off[r + 1] of the packed buffer
+struct HaloRegions
+{
+  int count = 0;
+  int b[26][3], n[26][3];
+  int64_t off[27];
+};
+
 // Point-to-point transport between neighbours + the few collectives of the setup.  Two implementations:
 // RCCL send/recv over xGMI on the caller's stream (one process per GPU), and host callbacks (the library stages
 // through pinned host buffers; gloo in the tests, where several ranks share one card).
@@ -352,6 +362,9 @@ struct HaloTransport
   // neighbour); enqueued on `stream` (the host transport synchronises the stream around its callbacks)
   virtual void sendrecv(int peer_low, int peer_high, double const *send_low, double *recv_low, int64_t n_low, double const *send_high,
                         double *recv_high, int64_t n_high, hipStream_t stream) = 0;
+  // the same with any number of partners in one group: message i = count[i] doubles to and from rank peers[i]
+  virtual void exchange_many(int n, int const *peers, double const *const *send, double *const *recv, int64_t const *count,
+                             hipStream_t stream) = 0;
   virtual void allreduce(double *host_values, int n, int op /* 0 sum, 1 max */, hipStream_t stream) = 0;
   // every rank contributes n doubles (device), `out` (device) receives n * n_ranks in rank order
   virtual void allgather(double const *in, int64_t n, double *out, hipStream_t stream) = 0;
@@ -388,9 +401,10 @@ struct HaloCommunicator
 };
 
 void halo_add_layers(double *dst, double const *src, int64_t n, hipStream_t stream); // dst += src (vector_ops.hip)
-// `count` runs of `run` doubles, `stride` apart in `v`, against the contiguous `buf`: mode 0 buf = v (pack), 1 v = buf (unpack),
-// 2 v += buf (vector_ops.hip)
-void halo_strided_runs(double *v, int64_t stride, int64_t run, int64_t count, double *buf, int mode, hipStream_t stream);
+struct HaloRegions;
+struct HaloSpace;
+// the regions of a vector of space `s` against the packed buffer: mode 0 buf = v (pack), 1 v = buf (unpack), 2 v += buf (vector_ops.hip)
+void halo_regions_copy(double *v, HaloSpace const &s, HaloRegions const &regions, double *buf, int mode, hipStream_t stream);
 // the owned sub-box (or the whole local box) of a vector of space `s` against the contiguous buf: mode 0 buf = v, 1 v = buf
 void halo_box_copy(double *v, HaloSpace const &s, bool owned_only, double *buf, int mode, hipStream_t stream);
 void gather_indexed(int64_t n, double const *in, int32_t const *index, double *out, hipStream_t stream); // out[i] = in[index[i]]
@@ -423,8 +437,8 @@ struct HipHandle
   double *host_result = nullptr; // pinned
   KernelProfiler profiler;
   HaloCommunicator comm;
-  // staging of the reverse (adding) exchanges and of the packed x / y faces of a box exchange:
-  // [send_low | send_high | recv_low | recv_high], grown on demand
+  // staging of the reverse (adding) exchanges and of the packed regions of a box exchange:
+  // [send_low | send_high | recv_low | recv_high] resp. [send (2 segments) | recv (2 segments)], grown on demand
   DeviceBuffer<double> halo_staging;
   int64_t halo_staging_each = 0;
   DeviceBuffer<double> dot_scratch; // owned entries of two box vectors, packed for a dot product
@@ -448,40 +462,67 @@ struct HipHandle
       halo_staging_each = each;
     }
   }
-  // One split axis (d = 0: x, 1: y) of a box exchange on `st`: the `width` layers next to each neighbour along d, over the whole
-  // local extent of the other two axes, are `count` runs of `run` entries `stride` apart -- packed, sent to the two face
-  // neighbours, unpacked into (forward) or added to (reverse) the layers they belong to.
-  void exchange_axis_xy(HaloSpace const &s, double *v, int d, bool reverse, hipStream_t st)
+  // A box exchange on `st` (forward: owner -> ghost; reverse: ghost -> owner, added): every existing neighbour at an offset
+  // o in {-1, 0, 1}^3 gets one message.  Along an axis with o_d = -1 / +1 the message spans the `width` owned layers next to that
+  // neighbour (forward: sent; reverse: added to) resp. the `width` ghost layers beyond them (forward: received; reverse: sent);
+  // along an axis with o_d = 0 it spans the owned range.
+  void exchange_box(HaloSpace const &s, double *v, bool reverse, hipStream_t st)
   {
-    if (!s.low_xy[d] && !s.high_xy[d])
+    HaloRegions own, ghost;
+    int peers[26];
+    int64_t counts[26];
+    int64_t total = 0;
+    for (int oz = -1; oz <= 1; ++oz)
+      for (int oy = -1; oy <= 1; ++oy)
+        for (int ox = -1; ox <= 1; ++ox)
+        {
+          const int o[3] = {ox, oy, oz};
+          if (ox == 0 && oy == 0 && oz == 0)
+            continue;
+          bool exists = true;
+          for (int d = 0; d < 3; ++d)
+            if ((o[d] < 0 && !s.low(d)) || (o[d] > 0 && !s.high(d)))
+              exists = false;
+          if (!exists)
+            continue;
+          const int r = own.count;
+          int64_t n = s.comps;
+          for (int d = 0; d < 3; ++d)
+          {
+            const int o0 = (int)s.own0(d), o1 = (int)(s.own0(d) + s.own_n(d)), w = s.width;
+            own.b[r][d] = o[d] < 0 ? o0 : (o[d] > 0 ? o1 - w : o0);
+            ghost.b[r][d] = o[d] < 0 ? o0 - w : (o[d] > 0 ? o1 : o0);
+            own.n[r][d] = ghost.n[r][d] = o[d] == 0 ? o1 - o0 : w;
+            n *= own.n[r][d];
+          }
+          own.off[r] = ghost.off[r] = total;
+          peers[r] = comm.rank + ox * comm.stride(0) + oy * comm.stride(1) + oz * comm.stride(2);
+          counts[r] = n;
+          total += n;
+          own.count = ghost.count = r + 1;
+        }
+    if (own.count == 0)
       return;
-    const int64_t unit = d == 0 ? s.comps : s.comps * s.n_xy[0]; // entries from one layer along d to the next
-    const int64_t run = s.width * unit;
-    const int64_t stride = d == 0 ? s.comps * s.n_xy[0] : s.layer_elems;
-    const int64_t count = d == 0 ? s.n_xy[1] * s.n_layers : s.n_layers;
-    const int64_t n = run * count;
-    staging_reserve(n);
-    double *sl = halo_staging.data(), *sh = sl + halo_staging_each, *rl = sh + halo_staging_each, *rh = rl + halo_staging_each;
-    const int64_t o0 = s.own0_xy[d], o1 = o0 + s.own_n_xy[d];
-    const int64_t src_low = (reverse ? o0 - s.width : o0) * unit, src_high = (reverse ? o1 : o1 - s.width) * unit;
-    const int64_t dst_low = (reverse ? o0 : o0 - s.width) * unit, dst_high = (reverse ? o1 - s.width : o1) * unit;
-    if (s.low_xy[d])
-      halo_strided_runs(v + src_low, stride, run, count, sl, 0, st);
-    if (s.high_xy[d])
-      halo_strided_runs(v + src_high, stride, run, count, sh, 0, st);
-    comm.transport->sendrecv(comm.rank - comm.stride(d), comm.rank + comm.stride(d), sl, rl, s.low_xy[d] ? n : 0, sh, rh,
-                             s.high_xy[d] ? n : 0, st);
+    own.off[own.count] = ghost.off[own.count] = total;
+    staging_reserve((total + 1) / 2 + 1);
+    double *send = halo_staging.data(), *recv = send + 2 * halo_staging_each;
+    double const *send_ptr[26];
+    double *recv_ptr[26];
+    for (int r = 0; r < own.count; ++r)
+    {
+      send_ptr[r] = send + own.off[r];
+      recv_ptr[r] = recv + own.off[r];
+    }
+    halo_regions_copy(v, s, reverse ? ghost : own, send, 0, st);
+    comm.transport->exchange_many(own.count, peers, send_ptr, recv_ptr, counts, st);
     ++comm.n_exchanges;
-    comm.n_doubles_sent += (s.low_xy[d] ? n : 0) + (s.high_xy[d] ? n : 0);
-    if (s.low_xy[d])
-      halo_strided_runs(v + dst_low, stride, run, count, rl, reverse ? 2 : 1, st);
-    if (s.high_xy[d])
-      halo_strided_runs(v + dst_high, stride, run, count, rh, reverse ? 2 : 1, st);
+    comm.n_doubles_sent += total;
+    halo_regions_copy(v, s, reverse ? own : ghost, recv, reverse ? 2 : 1, st);
   }
   // forward exchange on `st`.  Along z the `width` owned layers next to a neighbour and the ghost layers they refresh are
   // contiguous runs of the vector (lexicographic layers): the transport sends from and receives into the vector itself
   // -- no packing, no staging copies (round 2 moved every layer through a staging buffer: four device copies per exchange).
-  // A box exchanges x and y first (packed), so that the z layers carry their ghost columns with them.
+  // A box packs the regions of all its neighbours (exchange_box).
   void exchange_on(HaloSpace const &s, double *v, hipStream_t pack_stream, hipStream_t st, bool split)
   {
     const int64_t n = (int64_t)s.width * s.layer_elems;
@@ -493,8 +534,11 @@ struct HipHandle
       MFMG_HIP_CHECK(hipEventRecord(ev_packed, pack_stream));
       MFMG_HIP_CHECK(hipStreamWaitEvent(st, ev_packed, 0));
     }
-    exchange_axis_xy(s, v, 0, false, st);
-    exchange_axis_xy(s, v, 1, false, st);
+    if (s.split_xy())
+    {
+      exchange_box(s, v, false, st);
+      return;
+    }
     if (!s.has_low && !s.has_high)
       return;
     comm.transport->sendrecv(comm.rank - comm.stride(2), comm.rank + comm.stride(2), send_low, recv_low, s.has_low ? n : 0, send_high,
@@ -535,13 +579,17 @@ struct HipHandle
       return;
     MFMG_HIP_CHECK(hipStreamWaitEvent(stream, ev_unpacked, 0));
   }
-  // ghost -> owner: the ghost layers hold partial sums that belong to the neighbours' boundary layers (z first, then y
-  // and x: the sums a z layer received in ITS ghost columns travel on to their owners)
+  // ghost -> owner: the ghost layers hold partial sums that belong to the neighbours' boundary layers
   void exchange_reverse_add(int space, double *v)
   {
     if (!comm.enabled() || space <= 0)
       return;
     HaloSpace &s = space_checked(space);
+    if (s.split_xy())
+    {
+      exchange_box(s, v, true, stream);
+      return;
+    }
     if (s.has_low || s.has_high)
     {
       const int64_t n = (int64_t)s.width * s.layer_elems;
@@ -558,8 +606,6 @@ struct HipHandle
       if (s.has_high)
         halo_add_layers(v + (s.owned_begin + s.owned_count - s.width) * s.layer_elems, recv_high, n, stream);
     }
-    exchange_axis_xy(s, v, 1, true, stream);
-    exchange_axis_xy(s, v, 0, true, stream);
   }
   double allreduce_sum(double v)
   {

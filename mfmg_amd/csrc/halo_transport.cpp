@@ -128,6 +128,21 @@ public:
     }
     rccl_check(r.GroupEnd(), "ncclGroupEnd");
   }
+  void exchange_many(int n, int const *peers, double const *const *send, double *const *recv, int64_t const *count,
+                     hipStream_t stream) override
+  {
+    if (n <= 0)
+      return;
+    RcclApi &r = rccl();
+    rccl_check(r.GroupStart(), "ncclGroupStart");
+    for (int i = 0; i < n; ++i)
+      if (count[i] > 0)
+      {
+        rccl_check(r.Send(send[i], (size_t)count[i], ncclFloat64, peers[i], _comm, stream), "ncclSend");
+        rccl_check(r.Recv(recv[i], (size_t)count[i], ncclFloat64, peers[i], _comm, stream), "ncclRecv");
+      }
+    rccl_check(r.GroupEnd(), "ncclGroupEnd");
+  }
   void allreduce(double *host_values, int n, int op, hipStream_t stream) override
   {
     ASSERT_THROW(n >= 1 && n <= 16, "all-reduce of at most 16 scalars");
@@ -160,7 +175,7 @@ private:
 class HostTransport : public HaloTransport
 {
 public:
-  HostTransport(int rank, int n_ranks, mfmg_hip_host_sendrecv_fn sr, mfmg_hip_host_allreduce_fn ar, mfmg_hip_host_allgather_fn ag,
+  HostTransport(int rank, int n_ranks, mfmg_hip_host_exchange_fn sr, mfmg_hip_host_allreduce_fn ar, mfmg_hip_host_allgather_fn ag,
                 void *user)
       : _n(n_ranks), _sr(sr), _ar(ar), _ag(ag), _user(user)
   {
@@ -174,22 +189,53 @@ public:
   void sendrecv(int peer_low, int peer_high, double const *send_low, double *recv_low, int64_t n_low, double const *send_high,
                 double *recv_high, int64_t n_high, hipStream_t stream) override
   {
-    if (n_low <= 0 && n_high <= 0)
+    int peers[2], n = 0;
+    double const *send[2];
+    double *recv[2];
+    int64_t count[2];
+    if (n_low > 0)
+    {
+      peers[n] = peer_low;
+      send[n] = send_low;
+      recv[n] = recv_low;
+      count[n++] = n_low;
+    }
+    if (n_high > 0)
+    {
+      peers[n] = peer_high;
+      send[n] = send_high;
+      recv[n] = recv_high;
+      count[n++] = n_high;
+    }
+    exchange_many(n, peers, send, recv, count, stream);
+  }
+  void exchange_many(int n, int const *peers, double const *const *send, double *const *recv, int64_t const *count,
+                     hipStream_t stream) override
+  {
+    if (n <= 0)
       return;
-    const int64_t each = std::max(n_low, n_high);
-    reserve(4 * each);
-    double *h_sl = _host, *h_sh = _host + each, *h_rl = _host + 2 * each, *h_rh = _host + 3 * each;
-    if (n_low > 0)
-      MFMG_HIP_CHECK(hipMemcpyAsync(h_sl, send_low, n_low * sizeof(double), hipMemcpyDeviceToHost, stream));
-    if (n_high > 0)
-      MFMG_HIP_CHECK(hipMemcpyAsync(h_sh, send_high, n_high * sizeof(double), hipMemcpyDeviceToHost, stream));
+    ASSERT_THROW(n <= 26, "at most 26 neighbours");
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i)
+      total += count[i];
+    reserve(2 * total);
+    const double *h_send[26];
+    double *h_recv[26];
+    int32_t h_peers[26];
+    int64_t off = 0;
+    for (int i = 0; i < n; ++i)
+    {
+      h_send[i] = _host + off;
+      h_recv[i] = _host + total + off;
+      h_peers[i] = peers[i];
+      MFMG_HIP_CHECK(hipMemcpyAsync(_host + off, send[i], (size_t)count[i] * sizeof(double), hipMemcpyDeviceToHost, stream));
+      off += count[i];
+    }
     MFMG_HIP_CHECK(hipStreamSynchronize(stream));
-    if (_sr(_user, peer_low, peer_high, h_sl, h_rl, n_low, h_sh, h_rh, n_high) != 0)
+    if (_sr(_user, n, h_peers, h_send, h_recv, count) != 0)
       throw std::runtime_error("halo exchange transport failed");
-    if (n_low > 0)
-      MFMG_HIP_CHECK(hipMemcpyAsync(recv_low, h_rl, n_low * sizeof(double), hipMemcpyHostToDevice, stream));
-    if (n_high > 0)
-      MFMG_HIP_CHECK(hipMemcpyAsync(recv_high, h_rh, n_high * sizeof(double), hipMemcpyHostToDevice, stream));
+    for (int i = 0; i < n; ++i)
+      MFMG_HIP_CHECK(hipMemcpyAsync(recv[i], h_recv[i], (size_t)count[i] * sizeof(double), hipMemcpyHostToDevice, stream));
     MFMG_HIP_CHECK(hipStreamSynchronize(stream)); // the pinned buffers are reused by the next call
   }
   void allreduce(double *host_values, int n, int op, hipStream_t) override
@@ -224,7 +270,7 @@ private:
     _host_n = n;
   }
   int _n;
-  mfmg_hip_host_sendrecv_fn _sr;
+  mfmg_hip_host_exchange_fn _sr;
   mfmg_hip_host_allreduce_fn _ar;
   mfmg_hip_host_allgather_fn _ag;
   void *_user;
@@ -247,7 +293,7 @@ std::shared_ptr<HaloTransport> make_rccl_transport(int rank, int n_ranks, unsign
   return std::make_shared<RcclTransport>(rank, n_ranks, unique_id);
 }
 
-std::shared_ptr<HaloTransport> make_host_transport(int rank, int n_ranks, mfmg_hip_host_sendrecv_fn sendrecv,
+std::shared_ptr<HaloTransport> make_host_transport(int rank, int n_ranks, mfmg_hip_host_exchange_fn sendrecv,
                                                    mfmg_hip_host_allreduce_fn allreduce, mfmg_hip_host_allgather_fn allgather,
                                                    void *user)
 {

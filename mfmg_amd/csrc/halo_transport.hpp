@@ -19,7 +19,7 @@ void rccl_unique_id(unsigned char out[128]);
 // resolves librccl and the entry points used (dlopen / dlsym only: no RCCL call); throws if that fails
 void rccl_available();
 std::shared_ptr<HaloTransport> make_rccl_transport(int rank, int n_ranks, unsigned char const unique_id[128]);
-std::shared_ptr<HaloTransport> make_host_transport(int rank, int n_ranks, mfmg_hip_host_sendrecv_fn sendrecv,
+std::shared_ptr<HaloTransport> make_host_transport(int rank, int n_ranks, mfmg_hip_host_exchange_fn sendrecv,
                                                    mfmg_hip_host_allreduce_fn allreduce, mfmg_hip_host_allgather_fn allgather,
                                                    void *user);
 } // namespace mfmg

@@ -84,20 +84,44 @@ __global__ void add_layers_kernel(int64_t n, double const *src, double *dst)
     dst[i] += src[i];
 }
 
-// `count` runs of `run` entries, `stride` apart in v, against the contiguous buf (mode 0: buf = v, 1: v = buf, 2: v += buf)
-__global__ void strided_runs_kernel(double *v, int64_t stride, int64_t run, int64_t count, double *buf, int mode)
+// the regions of a box exchange (sub-boxes of the lexicographic array of nodes nx x ny x ., comps entries per node) against
+// the packed buffer: mode 0 buf = v, 1 v = buf, 2 v += buf
+__global__ void regions_copy_kernel(double *v, int comps, int64_t nx, int64_t ny, HaloRegions t, double *buf, int mode)
 {
-  const int64_t n = run * count;
+  const int64_t n = t.off[t.count];
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
   {
-    const int64_t c = i / run, r = i - c * run;
-    double *p = v + c * stride + r;
+    int r = 0;
+    while (r + 1 < t.count && i >= t.off[r + 1])
+      ++r;
+    const int64_t q = i - t.off[r], rx = (int64_t)t.n[r][0] * comps;
+    const int64_t x = q % rx, j = (q / rx) % t.n[r][1], k = q / (rx * t.n[r][1]);
+    double *p = v + ((k + t.b[r][2]) * ny + (j + t.b[r][1])) * nx * comps + (int64_t)t.b[r][0] * comps + x;
     if (mode == 0)
       buf[i] = *p;
     else if (mode == 1)
       *p = buf[i];
     else
-      *p += buf[i];
+    {
+      // the regions that receive sums overlap (an owned corner node belongs to three faces, three edges and the corner): the
+      // thread of the FIRST region that holds the node adds the contributions of all of them, in the order of the regions
+      const int c[3] = {(int)(x / comps) + t.b[r][0], (int)j + t.b[r][1], (int)k + t.b[r][2]};
+      const int e = (int)(x % comps);
+      auto inside = [&](int q2) {
+        return c[0] >= t.b[q2][0] && c[0] < t.b[q2][0] + t.n[q2][0] && c[1] >= t.b[q2][1] && c[1] < t.b[q2][1] + t.n[q2][1] &&
+               c[2] >= t.b[q2][2] && c[2] < t.b[q2][2] + t.n[q2][2];
+      };
+      bool first = true;
+      for (int q2 = 0; q2 < r && first; ++q2)
+        first = !inside(q2);
+      if (!first)
+        continue;
+      double sum = *p;
+      for (int q2 = r; q2 < t.count; ++q2)
+        if (inside(q2))
+          sum += buf[t.off[q2] + (((int64_t)(c[2] - t.b[q2][2]) * t.n[q2][1] + (c[1] - t.b[q2][1])) * t.n[q2][0] + (c[0] - t.b[q2][0])) * comps + e];
+      *p = sum;
+    }
   }
 }
 
@@ -358,13 +382,14 @@ MFMG_INSTANTIATE_VEC(double)
 MFMG_INSTANTIATE_VEC(float)
 } // namespace vec
 
-void halo_strided_runs(double *v, int64_t stride, int64_t run, int64_t count, double *buf, int mode, hipStream_t stream)
+void halo_regions_copy(double *v, HaloSpace const &s, HaloRegions const &regions, double *buf, int mode, hipStream_t stream)
 {
-  const int64_t n = run * count;
+  s.check();
+  const int64_t n = regions.count > 0 ? regions.off[regions.count] : 0;
   if (n <= 0)
     return;
-  hipLaunchKernelGGL(vec::strided_runs_kernel, dim3(n_blocks_for(n, block_size, 4096)), dim3(block_size), 0, stream, v, stride, run, count,
-                     buf, mode);
+  hipLaunchKernelGGL(vec::regions_copy_kernel, dim3(n_blocks_for(n, block_size, 4096)), dim3(block_size), 0, stream, v, s.comps, s.n_xy[0],
+                     s.n_xy[1], regions, buf, mode);
   MFMG_HIP_CHECK(hipGetLastError());
 }
 

@@ -65,10 +65,23 @@ class BoxPartition:
         return self.grid[0] > 1 or self.grid[1] > 1
 
     def exchange_doubles(self, width: int = 1) -> int:
-        """Doubles this rank sends in one exchange of a fine-level vector: per split axis `width` layers towards each neighbour,
-        over the whole local extent of the other two axes."""
-        ln = self.local_nodes
-        return sum(width * (self.n_local_dofs // ln[d]) * ((self.coord[d] > 0) + (self.coord[d] + 1 < self.grid[d])) for d in range(3))
+        """Doubles this rank sends in one exchange of a fine-level vector: to every neighbour (faces, edges, corners) `width`
+        layers along the axes in which it is offset, the owned range along the others.  Slabs send whole local planes."""
+        if not self.split_xy:
+            return width * self.plane * ((self.coord[2] > 0) + (self.coord[2] + 1 < self.grid[2]))
+        total = 0
+        for oz in (-1, 0, 1):
+            for oy in (-1, 0, 1):
+                for ox in (-1, 0, 1):
+                    o = (ox, oy, oz)
+                    if o == (0, 0, 0) or any((o[d] < 0 and self.coord[d] == 0) or (o[d] > 0 and self.coord[d] + 1 == self.grid[d])
+                                             for d in range(3)):
+                        continue
+                    n = 1
+                    for d in range(3):
+                        n *= width if o[d] else self.own_n[d]
+                    total += n
+        return total
 
     def local_problem(self, material: str = "constant", device="cpu") -> LaplaceProblem:
         """Mesh arrays of the local (extended) box: global Dirichlet nodes carry 1, ghost nodes 2."""
@@ -149,8 +162,8 @@ def box_grid(n_ranks: int) -> tuple:
     return tuple(grid)
 
 
-_SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64,
-                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
+_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_double)),
+                           C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int64))
 _ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
 _ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double))
 
@@ -217,7 +230,7 @@ class HaloTransport:
         else:
             # CPU tensors travel over gloo (a second group when the default one is nccl)
             self._host_group = group if self.backend == "gloo" else dist.new_group(backend="gloo")
-            self._sendrecv_cb = _SENDRECV_FN(self._sendrecv)
+            self._sendrecv_cb = _EXCHANGE_FN(self._exchange)
             self._allreduce_cb = _ALLREDUCE_FN(self._allreduce)
             self._allgather_cb = _ALLGATHER_FN(self._allgather)
             check(self._lib.mfmg_hip_context_use_host_transport(
@@ -226,15 +239,13 @@ class HaloTransport:
         ctx._transport = self  # keep the callbacks alive as long as the context
 
     # -- callbacks of the host transport (invoked from inside the library, on the calling Python thread) --------
-    def _sendrecv(self, user, peer_low, peer_high, send_low, recv_low, n_low, send_high, recv_high, n_high):
+    def _exchange(self, user, n, peers, send, recv, count):
         try:
             ops = []
-            if n_low > 0:
-                ops += [dist.P2POp(dist.isend, _host_tensor(send_low, n_low), peer_low, self._host_group),
-                        dist.P2POp(dist.irecv, _host_tensor(recv_low, n_low), peer_low, self._host_group)]
-            if n_high > 0:
-                ops += [dist.P2POp(dist.isend, _host_tensor(send_high, n_high), peer_high, self._host_group),
-                        dist.P2POp(dist.irecv, _host_tensor(recv_high, n_high), peer_high, self._host_group)]
+            for i in range(n):
+                if count[i] > 0:
+                    ops += [dist.P2POp(dist.isend, _host_tensor(send[i], count[i]), int(peers[i]), self._host_group),
+                            dist.P2POp(dist.irecv, _host_tensor(recv[i], count[i]), int(peers[i]), self._host_group)]
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()

@@ -134,41 +134,40 @@ def parse_grid(text, world):
 
 
 def exchange_box_np(v, part, dims, own0, own_n, comps=1, width=1, reverse=False):
-    """The box exchange of common.hpp (HipHandle::exchange_on / exchange_reverse_add) restated in numpy + gloo: axis after axis
-    -- x, y, z forward; z, y, x for the reverse (adding) direction -- each with the two face neighbours only, the message
-    spanning the whole local extent of the other two axes (so that edges and corners travel with the later axes)."""
-    V = v.reshape(dims[2], dims[1], dims[0] * comps)
+    """The box exchange of common.hpp (HipHandle::exchange_box) restated in numpy + gloo: one message to and from every
+    existing neighbour at an offset o in {-1, 0, 1}^3 (faces, edges, corners), all at once.  Along an axis with o_d != 0 the
+    message spans `width` layers -- the owned ones next to that neighbour on the owner's side, the ghost ones beyond them on
+    the other -- along an axis with o_d = 0 the owned range."""
+    V = v.reshape(dims[2], dims[1], dims[0], comps)
     stride = (1, part.grid[0], part.grid[0] * part.grid[1])
-
-    def sl(d, a, b):
-        u = comps if d == 0 else 1
-        idx = [slice(None)] * 3
-        idx[2 - d] = slice(a * u, b * u)
-        return tuple(idx)
-    for d in ((2, 1, 0) if reverse else (0, 1, 2)):
-        o0, o1, w = own0[d], own0[d] + own_n[d], width
-        ops, recv = [], {}
-        for side, has in (("low", part.coord[d] > 0), ("high", part.coord[d] + 1 < part.grid[d])):
-            if not has:
-                continue
-            peer = part.rank - stride[d] if side == "low" else part.rank + stride[d]
-            if not reverse:
-                src = V[sl(d, o0, o0 + w)] if side == "low" else V[sl(d, o1 - w, o1)]
-            else:
-                src = V[sl(d, o0 - w, o0)] if side == "low" else V[sl(d, o1, o1 + w)]
-            t = torch.from_numpy(np.ascontiguousarray(src).reshape(-1).copy())
-            r = torch.empty_like(t)
-            ops += [dist.P2POp(dist.isend, t, peer), dist.P2POp(dist.irecv, r, peer)]
-            recv[side] = (r, src.shape)
-        if ops:
-            for q in dist.batch_isend_irecv(ops):
-                q.wait()
-        for side, (r, shape) in recv.items():
-            blk = r.numpy().reshape(shape)
-            if not reverse:
-                V[sl(d, o0 - w, o0) if side == "low" else sl(d, o1, o1 + w)] = blk
-            else:
-                V[sl(d, o0, o0 + w) if side == "low" else sl(d, o1 - w, o1)] += blk
+    ops, recv = [], []
+    for oz in (-1, 0, 1):
+        for oy in (-1, 0, 1):
+            for ox in (-1, 0, 1):
+                o = (ox, oy, oz)
+                if o == (0, 0, 0) or any((o[d] < 0 and part.coord[d] == 0) or (o[d] > 0 and part.coord[d] + 1 == part.grid[d])
+                                         for d in range(3)):
+                    continue
+                own, ghost = [], []
+                for d in range(3):
+                    o0, o1, w = own0[d], own0[d] + own_n[d], width
+                    own.append(slice(o0, o0 + w) if o[d] < 0 else (slice(o1 - w, o1) if o[d] > 0 else slice(o0, o1)))
+                    ghost.append(slice(o0 - w, o0) if o[d] < 0 else (slice(o1, o1 + w) if o[d] > 0 else slice(o0, o1)))
+                own, ghost = tuple(own[::-1]), tuple(ghost[::-1])
+                peer = part.rank + sum(o[d] * stride[d] for d in range(3))
+                src = V[ghost] if reverse else V[own]
+                t = torch.from_numpy(np.ascontiguousarray(src).reshape(-1).copy())
+                r = torch.empty_like(t)
+                ops += [dist.P2POp(dist.isend, t, peer), dist.P2POp(dist.irecv, r, peer)]
+                recv.append((r, own if reverse else ghost, src.shape))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+    for r, where, shape in recv:
+        if reverse:
+            V[where] += r.numpy().reshape(shape)
+        else:
+            V[where] = r.numpy().reshape(shape)
 
 
 def mode_cpu_box(args):
@@ -519,11 +518,9 @@ def mode_gpu(args):
     h.operator_apply(0, dev(local(xg)), yl); hg.operator_apply(0, dev(xg), yg)
     sent = tr.exchange_volume() - v0
     check(yl, yg, "fine operator")
-    # what one fine exchange moves: per split axis the two (or one) faces of the local box, the later axes with the ghost
-    # columns of the earlier ones -- a box sends faces of about (N / 2)^2 where a slab sends planes of N^2
-    ln = part.local_nodes
-    expect = sum((ln[0] * ln[1] * ln[2] // ln[d]) * ((part.coord[d] > 0) + (part.coord[d] + 1 < grid[d])) for d in range(3))
-    assert sent == expect, (sent, expect)
+    # what one fine exchange moves: the faces, edges and corners of the owned box towards the neighbours that exist -- a box
+    # sends faces of (N / 2)^2 where a slab sends planes of N^2
+    assert sent == part.exchange_doubles(), (sent, part.exchange_doubles())
     # smoother (3 fused steps, 3 exchanges)
     xl = dev(local(xg)); xs = dev(xg)
     h.smoother_apply(0, dev(local(bg, False)), xl); hg.smoother_apply(0, dev(bg), xs)

@@ -26,7 +26,10 @@ def _run(mode, world, timeout=600, mesh="small", backend="gloo", grid=""):
            os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--mesh", mesh, "--backend", backend, "--grid", grid]
     env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    if res.returncode != 0:
+        # the first traceback of a rank (the tail of stderr is the launcher's summary)
+        at = res.stderr.find("Traceback")
+        raise AssertionError(res.stdout[-1500:] + (res.stderr[at:at + 3000] if at >= 0 else res.stderr[-3000:]))
     return res.stdout
 
 
@@ -71,16 +74,17 @@ def test_box_partition_geometry(mfmg_lib):
     assert M.box_grid(2) == (2, 1, 1) and M.box_grid(4) == (2, 2, 1) and M.box_grid(8) == (2, 2, 2) and M.box_grid(3) == (3, 1, 1)
     with pytest.raises(ValueError):
         M.BoxPartition((10, 8, 8), 0, (2, 1, 1))
-    # doubles one rank sends per fine exchange, 512^3 cells on 8 ranks: three faces of 259^2 against two planes of 513^2
+    # doubles one rank sends per fine exchange, 512^3 cells on 8 ranks: three faces of 256^2 (+ three edges and a corner)
+    # against two planes of 513^2
     box = M.BoxPartition((512,) * 3, 0, grid)
     slab = M.SlabPartition((512,) * 3, 3, 8)
-    assert box.exchange_doubles() == 3 * 259 * 259 and slab.exchange_doubles() == 2 * 513 * 513
+    assert box.exchange_doubles() == 3 * 256 * 256 + 3 * 256 + 1 and slab.exchange_doubles() == 2 * 513 * 513
     assert slab.exchange_doubles() / box.exchange_doubles() > 2.6
 
 
 @pytest.mark.parametrize("world,grid", [(2, "2x1x1"), (4, "2x2x1"), (4, "1x2x2"), (8, "2x2x2")])
 def test_box_construction_cpu_gloo(mfmg_lib, world, grid):
-    """Box partition: host setup on the local boxes + the axis-by-axis exchange restated in numpy over gloo."""
+    """Box partition: host setup on the local boxes + the all-neighbours exchange restated in numpy over gloo."""
     assert "cpu box checks passed" in _run("cpu_box", world, grid=grid)
 
 
