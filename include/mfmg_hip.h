@@ -124,8 +124,9 @@ int mfmg_hip_context_transport_name(mfmg_hip_context_t ctx, char *buffer, size_t
 int mfmg_hip_context_transport_selftest(mfmg_hip_context_t ctx, int64_t n, double *max_error);
 /* point-to-point exchanges issued through the context so far (diagnostics) */
 int mfmg_hip_context_exchange_count(mfmg_hip_context_t ctx, int64_t *n_exchanges);
-/* ... and the doubles this rank has sent in them */
-int mfmg_hip_context_exchange_volume(mfmg_hip_context_t ctx, int64_t *n_doubles_sent);
+/* ... the doubles this rank has sent in them, and (n_overlapped, may be NULL) how many of the exchanges ran on the second
+ * stream beside the operator tiles that read no ghost plane */
+int mfmg_hip_context_exchange_volume(mfmg_hip_context_t ctx, int64_t *n_doubles_sent, int64_t *n_overlapped);
 /* one halo exchange of a device vector of `space` (1 fine DoFs, 2 first coarse level, 3.. aggregation levels):
  * reverse = 0 owner -> ghost, 1 ghost -> owner (added).  The cycle does this by itself; exposed for tests. */
 int mfmg_hip_context_exchange(mfmg_hip_context_t ctx, int32_t space, double *vector, int reverse);

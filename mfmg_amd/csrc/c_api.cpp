@@ -280,11 +280,13 @@ int mfmg_hip_context_exchange_count(mfmg_hip_context_t ctx, int64_t *n_exchanges
   });
 }
 
-int mfmg_hip_context_exchange_volume(mfmg_hip_context_t ctx, int64_t *n_doubles_sent)
+int mfmg_hip_context_exchange_volume(mfmg_hip_context_t ctx, int64_t *n_doubles_sent, int64_t *n_overlapped)
 {
   return guarded([&] {
     require(ctx != nullptr && n_doubles_sent != nullptr, "null argument");
     *n_doubles_sent = ctx->handle->comm.n_doubles_sent;
+    if (n_overlapped)
+      *n_overlapped = ctx->handle->comm.n_overlapped;
   });
 }
 

@@ -384,6 +384,7 @@ struct HaloCommunicator
   std::vector<HaloSpace> spaces = std::vector<HaloSpace>(3); // [0] rank-local, [1] fine DoFs, [2] first coarse level, then the aggregation levels
   int64_t n_exchanges = 0; // (diagnostics) point-to-point exchanges issued so far
   int64_t n_doubles_sent = 0; // ... and the doubles this rank sent in them
+  int64_t n_overlapped = 0;   // ... and how many of them ran on the second stream beside operator tiles
   // The spaces from [2] on describe the levels of ONE hierarchy (its operators hold indices into `spaces`): the
   // hierarchy helpers that configured them own them until they are destroyed; a second hierarchy on the same
   // communicator is refused while the first is alive (it would re-purpose spaces the first one still exchanges with).
@@ -571,6 +572,7 @@ struct HipHandle
       MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_unpacked, hipEventDisableTiming));
     }
     exchange_on(s, v, stream, comm_stream, true);
+    ++comm.n_overlapped;
     MFMG_HIP_CHECK(hipEventRecord(ev_unpacked, comm_stream));
   }
   void exchange_end(int space)

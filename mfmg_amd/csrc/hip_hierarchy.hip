@@ -323,9 +323,6 @@ bool HipMatrixOperator::prepare_residual_restriction(std::shared_ptr<Operator<DV
   const bool distributed = hd.comm.enabled();
   if (distributed && !(_domain_space == 1 && _range_space == 2))
     return false;
-  // (the classes of the one-pass kernel count distances to the faces of a slab: a box keeps residual + restriction in two steps)
-  if (distributed && hd.comm.split_xy())
-    return false;
   const int64_t n = _matrix->n(), nc = _matrix->m();
   auto apply_a = [&](double const *v, double *w) {
     DVector vv(hd, n, const_cast<double *>(v)), ww(hd, n, w);
@@ -341,6 +338,15 @@ bool HipMatrixOperator::prepare_residual_restriction(std::shared_ptr<Operator<DV
     slab.has_high = f.has_high;
     slab.owned_begin = (int)c.owned_begin;
     slab.owned_end = (int)(c.owned_begin + c.owned_count);
+    for (int d = 0; d < 2; ++d)
+    {
+      slab.valid_begin_xy[d] = (int)f.own0_xy[d];
+      slab.valid_end_xy[d] = (int)(f.own0_xy[d] + f.own_n_xy[d]);
+      slab.has_low_xy[d] = f.low_xy[d];
+      slab.has_high_xy[d] = f.high_xy[d];
+      slab.owned_begin_xy[d] = (int)c.own0_xy[d];
+      slab.owned_end_xy[d] = (int)(c.own0_xy[d] + c.own_n_xy[d]);
+    }
   }
   double ok = _structured->build_residual_restriction(apply_a, slab) ? 1. : 0.;
   if (distributed)
@@ -349,8 +355,9 @@ bool HipMatrixOperator::prepare_residual_restriction(std::shared_ptr<Operator<DV
     ok = -hd.allreduce_max(-ok);
     // the 5 node layers around the top agglomerates of the slab reach one layer further than an operator application
     HaloSpace const &f = hd.comm.spaces[1];
-    if (ok > 0. && ((f.has_low && f.ghost_low() < 2) || (f.has_high && f.ghost_high() < 2)))
-      ok = 0.;
+    for (int d = 0; d < 3; ++d)
+      if (ok > 0. && ((f.low(d) && f.own0(d) < 2) || (f.high(d) && f.dim(d) - f.own0(d) - f.own_n(d) < 2)))
+        ok = 0.;
   }
   if (ok == 0.)
   {
@@ -586,7 +593,8 @@ HipMatrixFreeOperator::HipMatrixFreeOperator(std::shared_ptr<HipMatrixFreeMeshEv
 }
 
 // One operator application of a distributed run: the tiles that do not read a ghost plane run while the
-// boundary planes travel on the second stream; the (at most four) z-tiles next to the ghost planes follow.
+// boundary planes travel on the second stream; the tiles next to the ghost planes follow (slabs: at most four z-tiles;
+// boxes: a shell of tiles along all three axes).
 void HipMatrixFreeOperator::apply_mode(MfMode mode, double const *x, double const *b, double const *x_prev,
                                        double alpha, double beta, double *out) const
 {
@@ -606,6 +614,51 @@ void HipMatrixFreeOperator::apply_mode(MfMode mode, double const *x, double cons
     return;
   }
   HaloSpace const &s = handle.comm.spaces[1];
+  if (s.split_xy())
+  {
+    // boxes: tiles along all three axes.  Tile t of an axis owns the planes [t R, (t + 1) R) and reads one more on either side;
+    // the planes the exchange writes are own0 - 1 (towards a lower neighbour) and own0 + own_n (towards an upper one):
+    // plane g is read by the tiles ceil(g / R) - 1 ... floor((g + 1) / R).  The tiles that read none of them form a box
+    // [lo, hi) of tiles and run while the faces, edges and corners travel; the shell around them -- at most six slabs of
+    // tiles and the columns of the tail -- follows.
+    int nt[3], rows[3], lo[3], hi[3];
+    op->tiling(nt, rows);
+    bool interior = handle.overlap_exchange;
+    for (int d = 0; d < 3; ++d)
+    {
+      lo[d] = 0;
+      hi[d] = nt[d];
+      if (s.low(d))
+        lo[d] = (int)std::min<int64_t>(nt[d], s.own0(d) / rows[d] + 1);
+      if (s.high(d))
+        hi[d] = (int)std::max<int64_t>(0, std::min<int64_t>(nt[d], (s.own0(d) + s.own_n(d) + rows[d] - 1) / rows[d] - 1));
+      if (lo[d] >= hi[d])
+        interior = false;
+    }
+    if (!interior)
+    {
+      handle.exchange(1, const_cast<double *>(x));
+      whole();
+      return;
+    }
+    const int zero[3] = {0, 0, 0};
+    handle.exchange_begin(1, const_cast<double *>(x));
+    op->launch_tiles(mode, x, b, x_prev, alpha, beta, out, lo, hi, true, false);
+    handle.exchange_end(1);
+    // z slabs over all columns and rows (+ the tail columns over all z-tiles), y slabs between them, x slabs between those
+    for (int side = 0; side < 2; ++side)
+    {
+      int b0[3] = {0, 0, side == 0 ? 0 : hi[2]}, b1[3] = {nt[0], nt[1], side == 0 ? lo[2] : nt[2]};
+      op->launch_tiles(mode, x, b, x_prev, alpha, beta, out, b0, b1, true, false);
+      int c0[3] = {0, side == 0 ? 0 : hi[1], lo[2]}, c1[3] = {nt[0], side == 0 ? lo[1] : nt[1], hi[2]};
+      op->launch_tiles(mode, x, b, x_prev, alpha, beta, out, c0, c1, true, false);
+      int d0[3] = {side == 0 ? 0 : hi[0], lo[1], lo[2]}, d1[3] = {side == 0 ? lo[0] : nt[0], hi[1], hi[2]};
+      op->launch_tiles(mode, x, b, x_prev, alpha, beta, out, d0, d1, true, false);
+    }
+    if (op->has_tail())
+      op->launch_tiles(mode, x, b, x_prev, alpha, beta, out, zero, nt, false, true);
+    return;
+  }
   const int n_tiles = op->n_z_tiles(), tz = op->tile_layers();
   // tile t reads the DoF planes [t tz - 1, (t + 1) tz]; the received ghost planes are owned_begin - 1 (low)
   // and owned_begin + owned_count (high)
@@ -615,8 +668,7 @@ void HipMatrixFreeOperator::apply_mode(MfMode mode, double const *x, double cons
     lo_end = (int)std::min<int64_t>(n_tiles, (s.owned_begin - 1 + 1) / tz + 1);
   if (s.has_high)
     hi_begin = (int)std::max<int64_t>(0, (s.owned_begin + s.owned_count + tz - 1) / tz - 1);
-  // (a box reads ghost columns in every tile: exchange first)
-  if (!handle.overlap_exchange || lo_end >= hi_begin || s.split_xy())
+  if (!handle.overlap_exchange || lo_end >= hi_begin)
   {
     handle.exchange(1, const_cast<double *>(x));
     whole();

@@ -59,9 +59,10 @@ struct MfArgs
   T *out;
   int Nx, Ny, Nz;
   int TY, TZ;
-  unsigned int ncols, ntiles_y, ntiles_z; // ntiles_z: z-tiles of THIS launch, the first one is tile z_tile0
-  unsigned int ncols_active;              // chunk columns that get workgroups (the last one may go to the tail slab)
-  unsigned int z_tile0;
+  unsigned int ncols, ntiles_y, ntiles_z; // ntiles_y, ntiles_z: y- and z-tiles of THIS launch, the first ones are ty0 and z_tile0
+  unsigned int ncols_active;              // chunk columns that get workgroups in this launch, the first one is col0 (the last
+                                          // column of the mesh may go to the tail slab)
+  unsigned int z_tile0, ty0, col0;
   int const *ztab; // z-tile t owns the DoF layers [ztab[t], ztab[t+1]) (device array; uniform TZ or graded, see z_tiling)
   T fx, fy, fz;
   T fax, fbx, fay, fby, faz, fbz; // one coefficient per cell: 2 f M00, 2 f M01 per direction (M = [[2/3, 1/3], [1/3, 2/3]])
@@ -367,8 +368,8 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
     if (w >= n_tiles)
       return; // the whole workgroup leaves: no barrier is left waiting
   }
-  const int tc = w % a.ncols_active;
-  const int tyi = (w / a.ncols_active) % a.ntiles_y;
+  const int tc = a.col0 + w % a.ncols_active;
+  const int tyi = a.ty0 + (w / a.ncols_active) % a.ntiles_y;
   const int tzi = a.z_tile0 + w / (a.ncols_active * a.ntiles_y);
   const int ci = tc * kOwn - 1 + lane;              // cell / DoF column of this lane
   const int Yb = tyi * (NW * TY - 1) - 1 + wv * TY; // first cell row of this wavefront
@@ -1473,7 +1474,7 @@ int const *MatrixFreeLaplaceDevice<T>::z_tiling(int tz, bool graded, int &n_tile
 template <typename T>
 bool MatrixFreeLaplaceDevice<T>::make_args(MfArgs<T> &a, unsigned int &n_blocks, MfMode mode, T const *x, T const *b,
                                            T const *x_prev, T alpha, T beta, T *out, int nw, int ty, int tz,
-                                           int const *ztab, int z_tile_begin, int z_tile_end) const
+                                           int const *ztab, int z_tile_begin, int z_tile_end, int const *xy_range) const
 {
   a.rec = _rec.data();
   a.x = x;
@@ -1511,8 +1512,21 @@ bool MatrixFreeLaplaceDevice<T>::make_args(MfArgs<T> &a, unsigned int &n_blocks,
   a.ncols_active = _tail ? _ncols - 1 : _ncols;
   // ty cell rows per wavefront, nw ty - 1 owned DoF rows per workgroup
   a.ntiles_y = (_N[1] + nw * ty - 2) / (nw * ty - 1);
+  a.col0 = a.ty0 = 0;
   a.ztab = ztab;
   n_blocks = 0;
+  if (xy_range)
+  {
+    // a sub-range of the column and y-tiles: {col begin, col end, y-tile begin, y-tile end}
+    ASSERT_THROW(xy_range[0] >= 0 && xy_range[1] <= (int)a.ncols_active && xy_range[2] >= 0 && xy_range[3] <= (int)a.ntiles_y,
+                 "tile range outside the tiling");
+    if (xy_range[0] >= xy_range[1] || xy_range[2] >= xy_range[3])
+      return false;
+    a.col0 = (unsigned int)xy_range[0];
+    a.ncols_active = (unsigned int)(xy_range[1] - xy_range[0]);
+    a.ty0 = (unsigned int)xy_range[2];
+    a.ntiles_y = (unsigned int)(xy_range[3] - xy_range[2]);
+  }
   if (z_tile_begin >= z_tile_end)
     return false;
   a.z_tile0 = (unsigned int)z_tile_begin;
@@ -1526,7 +1540,8 @@ bool MatrixFreeLaplaceDevice<T>::make_args(MfArgs<T> &a, unsigned int &n_blocks,
 
 template <typename T>
 void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out,
-                                     int nw, int ty, int tz, int z_tile_begin, int z_tile_end) const
+                                     int nw, int ty, int tz, int z_tile_begin, int z_tile_end, int const *xy_range, bool with_main,
+                                     bool with_tail) const
 {
   ASSERT_THROW(nw >= 1 && nw <= 8, "1..8 wavefronts per workgroup");
   ASSERT_THROW(ty >= 1 && tz >= 1 && nw * ty >= 2, "operator tile too small");
@@ -1540,11 +1555,16 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
   if (z_tile_end < 0)
     z_tile_end = all_z;
   ASSERT_THROW(z_tile_begin >= 0 && z_tile_end <= all_z, "z-tile range outside the tiling");
-  if (!make_args(am, main_blocks, mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, ztab, z_tile_begin, z_tile_end))
+  const bool have_main = make_args(am, main_blocks, mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, ztab, z_tile_begin, z_tile_end, xy_range);
+  if (!have_main && !_tail)
     return;
+  if (!with_main)
+    main_blocks = 0;
   at = am;
-  if (_tail) // the columns of the last chunk: same tile shape, same layers (same table: Nz is the same), first in the grid
-    _tail->make_args(at, tail_blocks, mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, ztab, z_tile_begin, z_tile_end);
+  if (_tail && with_tail) // the columns of the last chunk: same tile shape, same layers (same table: Nz is the same), first in the grid
+    _tail->make_args(at, tail_blocks, mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, ztab, z_tile_begin, z_tile_end, nullptr);
+  if (main_blocks + tail_blocks == 0)
+    return;
   const size_t lds = ((size_t)nw * (3 * ty + 1) + (size_t)2 * nw * 3) * 64 * sizeof(T) + (size_t)nw * (ty + 1) * 64 * sizeof(int);
   ASSERT_THROW(lds <= 160 * 1024, "operator tile too large for the LDS");
   const dim3 grid(main_blocks + tail_blocks);
@@ -1651,6 +1671,51 @@ void MatrixFreeLaplaceDevice<T>::launch_z_range(MfMode mode, T const *x, T const
   hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel", share * (required_bytes_apply() + epilogue_bytes((int)mode)),
                                            _handle.stream);
   run(mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, z_tile_begin, z_tile_end);
+  KernelProfiler::end(stop, _handle.stream);
+}
+
+template <typename T>
+void MatrixFreeLaplaceDevice<T>::tiling(int n_tiles[3], int rows[3]) const
+{
+  int nw, ty, tz;
+  choose_tile(nw, ty, tz);
+  n_tiles[0] = _tail ? _ncols - 1 : _ncols;
+  rows[0] = kOwn;
+  rows[1] = nw * ty - 1;
+  n_tiles[1] = (_N[1] + rows[1] - 1) / rows[1];
+  rows[2] = tz;
+  n_tiles[2] = (_N[2] + tz - 1) / tz;
+}
+
+template <typename T>
+void MatrixFreeLaplaceDevice<T>::launch_tiles(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out,
+                                              int const begin[3], int const end[3], bool main_part, bool tail_part) const
+{
+  check_vectors(mode, x, b, x_prev, out);
+  ASSERT_THROW(_dim == 3, "tile ranges belong to the 3-D operator");
+  if (mode == MfMode::next && (x_prev == nullptr || alpha == T(0)))
+    mode = MfMode::first;
+  int nw, ty, tz;
+  choose_tile(nw, ty, tz);
+  int nt[3], rows[3];
+  tiling(nt, rows);
+  if (begin[2] >= end[2])
+    return;
+  const bool m = main_part && begin[0] < end[0] && begin[1] < end[1], t = tail_part && _tail != nullptr;
+  if (!m && !t)
+    return;
+  // share of the DoFs this launch updates (for the profiler's bytes)
+  const double zshare = double(end[2] - begin[2]) / double(nt[2]);
+  const double tail_cols = _tail ? double(_N[0] - (_ncols - 1) * kOwn) : 0.;
+  double share = 0.;
+  if (m)
+    share += zshare * (double(end[0] - begin[0]) * kOwn / double(_N[0])) * (double(end[1] - begin[1]) / double(nt[1]));
+  if (t)
+    share += zshare * tail_cols / double(_N[0]);
+  hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel", std::min(1., share) * (required_bytes_apply() + epilogue_bytes((int)mode)),
+                                           _handle.stream);
+  const int xy[4] = {begin[0], end[0], begin[1], end[1]};
+  run(mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, begin[2], end[2], xy, m, t);
   KernelProfiler::end(stop, _handle.stream);
 }
 

@@ -78,6 +78,15 @@ public:
   int tile_layers() const;
   void launch_z_range(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out, int z_tile_begin,
                       int z_tile_end) const;
+  // ... and to a box of tiles along all three axes (a box decomposition overlaps its exchange with the tiles that read
+  // no ghost plane along any axis): n_tiles / rows per axis -- column tiles of `rows[0]` DoF columns, y-tiles of rows[1] DoF
+  // rows, z-tiles of rows[2] layers; tile t of an axis owns [t rows, (t + 1) rows) and reads one plane below and above.
+  // The columns of a nearly empty last chunk are not part of the column tiles: they are the `tail_part` (all y, the
+  // z-tiles of the range), `main_part` the tiles [begin, end).
+  void tiling(int n_tiles[3], int rows[3]) const;
+  bool has_tail() const { return _tail != nullptr; }
+  void launch_tiles(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out, int const begin[3],
+                    int const end[3], bool main_part, bool tail_part) const;
 
   T const *diagonal() const { return _diag.data(); }
   T const *diagonal_inverse() const { return _dinv.data(); }
@@ -123,9 +132,11 @@ public:
 private:
   void launch(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out) const;
   void run(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out, int nw, int ty, int tz,
-           int z_tile_begin = 0, int z_tile_end = -1) const;
+           int z_tile_begin = 0, int z_tile_end = -1, int const *xy_range = nullptr, bool with_main = true,
+           bool with_tail = true) const;
   bool make_args(MfArgs<T> &a, unsigned int &n_blocks, MfMode mode, T const *x, T const *b, T const *x_prev, T alpha,
-                 T beta, T *out, int nw, int ty, int tz, int const *ztab, int z_tile_begin, int z_tile_end) const;
+                 T beta, T *out, int nw, int ty, int tz, int const *ztab, int z_tile_begin, int z_tile_end,
+                 int const *xy_range) const;
   // layers of the z-tiles (device table, built once per tz): graded = shorter tiles at the end of every XCD's run
   int const *z_tiling(int tz, bool graded, int &n_tiles) const;
   struct ZTiling

@@ -249,13 +249,19 @@ bool StructuredRestrictorDevice::build_residual_restriction(std::function<void(d
   // class of an agglomerate for R A: the block of R it repeats and, per direction, which faces of the box its 5 nodes reach
   auto position = [&](int a, int d) { return (a == 0 ? 1 : 0) + (a == _na[d] - 1 ? 2 : 0); };
   // a representative must see its whole 5 x 5 x 5 neighbourhood computed by this rank
-  auto can_represent = [&](int ak) {
-    for (int mz = 0; mz < 5; ++mz)
+  auto can_represent = [&](int ai, int aj, int ak) {
+    const int a[3] = {ai, aj, ak};
+    for (int d = 0; d < 3; ++d)
     {
-      const int gz = 2 * ak - 1 + mz;
-      const bool outside_box = (gz < 0 && !slab.has_low) || (gz >= _N[2] && !slab.has_high);
-      if (!outside_box && !(gz >= slab.valid_begin && gz < std::min(slab.valid_end, _N[2])))
-        return false;
+      const bool low = d == 2 ? slab.has_low : slab.has_low_xy[d], high = d == 2 ? slab.has_high : slab.has_high_xy[d];
+      const int v0 = d == 2 ? slab.valid_begin : slab.valid_begin_xy[d], v1 = d == 2 ? slab.valid_end : slab.valid_end_xy[d];
+      for (int m = 0; m < 5; ++m)
+      {
+        const int g = 2 * a[d] - 1 + m;
+        const bool outside_box = (g < 0 && !low) || (g >= _N[d] && !high);
+        if (!outside_box && !(g >= v0 && g < std::min(v1, _N[d])))
+          return false;
+      }
     }
     return true;
   };
@@ -277,9 +283,10 @@ bool StructuredRestrictorDevice::build_residual_restriction(std::function<void(d
       needed.push_back(0);
     }
     cls[ag] = (uint16_t)it->second;
-    if (representative[it->second] < 0 && can_represent(ak))
+    if (representative[it->second] < 0 && can_represent(ai, aj, ak))
       representative[it->second] = ag;
-    if (ak >= slab.owned_begin && ak < slab.owned_end)
+    if (ak >= slab.owned_begin && ak < slab.owned_end && ai >= slab.owned_begin_xy[0] && ai < slab.owned_end_xy[0] &&
+        aj >= slab.owned_begin_xy[1] && aj < slab.owned_end_xy[1])
       needed[it->second] = 1;
   }
   for (size_t c = 0; c < representative.size(); ++c)

@@ -44,14 +44,18 @@ public:
   // verifies the result against the two-step path before use (HipMatrixOperator::prepare_residual_restriction).
   // Returns false -- nothing built -- when the blocks of R fall into more than 4096 classes (no two alike), for
   // agglomerates other than 2 x 2 x 2 cells with two eigenvectors, or for a renumbered mesh.
-  // Distributed runs (slabs along z): rows of A are computed locally only on the node layers [valid_begin, valid_end), and
-  // a layer outside the local mesh is outside the BOX only where no neighbour exists; a class with an agglomerate in the
-  // layers [owned_begin, owned_end) of agglomerates needs a representative whose 5 layers qualify.
+  // Distributed runs (slabs along z, or boxes: the _xy members, [0] = x, [1] = y): rows of A are computed locally only on the
+  // node layers [valid_begin, valid_end), and a layer outside the local mesh is outside the BOX only where no neighbour exists;
+  // a class with an agglomerate in the layers [owned_begin, owned_end) of agglomerates needs a representative whose 5 layers
+  // qualify (along every axis).
   struct SlabInfo
   {
     int valid_begin = 0, valid_end = 1 << 30; // node layers whose rows apply_a computes
     bool has_low = false, has_high = false;   // neighbours below / above
     int owned_begin = 0, owned_end = 1 << 30; // agglomerate layers this rank owns
+    int valid_begin_xy[2] = {0, 0}, valid_end_xy[2] = {1 << 30, 1 << 30};
+    bool has_low_xy[2] = {false, false}, has_high_xy[2] = {false, false};
+    int owned_begin_xy[2] = {0, 0}, owned_end_xy[2] = {1 << 30, 1 << 30};
   };
   bool build_residual_restriction(std::function<void(double const *, double *)> const &apply_a, SlabInfo const &slab);
   bool build_residual_restriction(std::function<void(double const *, double *)> const &apply_a)

@@ -308,8 +308,14 @@ class HaloTransport:
     def exchange_volume(self) -> int:
         """Doubles this rank has sent in halo exchanges so far."""
         n = C.c_int64()
-        check(self._lib.mfmg_hip_context_exchange_volume(self.ctx.handle, C.byref(n)))
+        check(self._lib.mfmg_hip_context_exchange_volume(self.ctx.handle, C.byref(n), None))
         return n.value
+
+    def n_overlapped(self) -> int:
+        """Exchanges so far that ran on the second stream beside the operator tiles that read no ghost plane."""
+        n, m = C.c_int64(), C.c_int64()
+        check(self._lib.mfmg_hip_context_exchange_volume(self.ctx.handle, C.byref(n), C.byref(m)))
+        return m.value
 
     def exchange(self, space: int, v: torch.Tensor, reverse: bool = False):
         """One halo exchange of a vector of `space` (the cycle does this by itself; for tests)."""

@@ -84,7 +84,7 @@ def load() -> C.CDLL:
         "mfmg_hip_context_stream": (vp, [vp]),
         "mfmg_hip_context_set_communicator": (C.c_int, [vp, i32, i32, i32, i32]),
         "mfmg_hip_context_set_communicator_box": (C.c_int, [vp, i32, P(i32), P(i32), P(i32)]),
-        "mfmg_hip_context_exchange_volume": (C.c_int, [vp, P(i64)]),
+        "mfmg_hip_context_exchange_volume": (C.c_int, [vp, P(i64), P(i64)]),
         "mfmg_hip_context_halo_box": (C.c_int, [vp, i32, vp]),
         "mfmg_hip_rccl_unique_id": (C.c_int, [vp]),
         "mfmg_hip_rccl_available": (C.c_int, []),

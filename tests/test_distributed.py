@@ -109,7 +109,7 @@ def test_distributed_library_path_shared_gpu(mfmg_lib, world, mesh):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,grid,mesh", [(2, "2x1x1", "small"), (4, "2x2x1", "small"), (4, "2x2x1", "cube"), (4, "2x1x2", "cube11"),
-                                             (4, "1x2x2", "cube")])
+                                             (4, "1x2x2", "cube"), (4, "2x2x1", "boxwide"), (4, "2x1x2", "boxwide")])
 def test_box_decomposition_library_path_shared_gpu(mfmg_lib, world, grid, mesh):
     """Boxes instead of slabs: every pair of split axes, with the aggregation levels distributed along them --
     each operator against the single-process hierarchy, 20-cycle history == single process == oracle to 1e-10, and the
