@@ -551,6 +551,8 @@ def main():
     dominant = "csr_spmv_kernel" if assembled else "mf_laplace_kernel"
     ctx.profile_enable(True, only=dominant)
     n_ex0 = transport.n_exchanges() if transport is not None else 0
+    n_vol0 = transport.exchange_volume() if transport is not None else 0
+    n_ov0 = transport.n_overlapped() if transport is not None else 0
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -560,6 +562,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     n_exchanges_per_cycle = ((transport.n_exchanges() - n_ex0) / max(args.steps, 1)) if transport is not None else 0.0
+    mb_sent_per_cycle = ((transport.exchange_volume() - n_vol0) * 8e-6 / max(args.steps, 1)) if transport is not None else 0.0
+    n_overlapped_per_cycle = ((transport.n_overlapped() - n_ov0) / max(args.steps, 1)) if transport is not None else 0.0
     res_end = residual_norm()
     contraction = (res_end / res_start) ** (1.0 / max(args.warmup + args.steps, 1)) if res_start > 0 else 0.0
     del op_monitor, r
@@ -631,7 +635,9 @@ def main():
                                f"{world} GPUs, {'x'.join(map(str, part.grid))} ranks (x, y, z) on a {gx}x{gy}x{gz}-cell box "
                                f"({'boxes' if part.split_xy else 'slabs along z'}), halo exchange "
                                f"per operator application on every level of the cycle (transport: {transport.name()}, "
-                               f"{n_exchanges_per_cycle:.1f} point-to-point exchanges per cycle), aggregation levels coupled "
+                               f"{n_exchanges_per_cycle:.1f} exchanges per cycle and rank, each ONE grouped send/recv with all "
+                               f"neighbours, {n_overlapped_per_cycle:.1f} of them beside operator tiles on a second stream, "
+                               f"{mb_sent_per_cycle:.2f} MB sent per cycle by rank 0), aggregation levels coupled "
                                f"across the ranks, the levels from {h.coarse_amg_gather_rows()} global rows down gathered and solved "
                                f"redundantly: the same preconditioner as on one GPU",
                 "global_dofs": n_global,

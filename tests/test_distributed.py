@@ -137,12 +137,12 @@ def test_rccl_transport_on_one_gpu(mfmg_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,mesh", [(2, "deep"), (4, "deep")])
-def test_distributed_rccl_one_gpu_per_rank(mfmg_lib, world, mesh):
+@pytest.mark.parametrize("world,mesh,grid", [(2, "deep", ""), (4, "deep", ""), (4, "cube", "2x2x1"), (8, "cube", "2x2x2")])
+def test_distributed_rccl_one_gpu_per_rank(mfmg_lib, world, mesh, grid):
     """The same checks with one GPU per rank and the native transport (ncclSend / ncclRecv over xGMI on the library's
     stream, ncclAllReduce / ncclAllGather for the setup): needs `world` GPUs in the box, skipped otherwise (the pool's
     test boxes have one; a multi-GPU node runs it).  The worker never counts devices after HIP is initialised: the
     count is taken here, in the parent, without touching the GPU."""
     if torch.cuda.device_count() < world:
         pytest.skip(f"needs {world} GPUs, this box has {torch.cuda.device_count()}")
-    assert "gpu distributed checks passed" in _run("gpu", world, mesh=mesh, backend="nccl")
+    assert "gpu distributed checks passed" in _run("gpu", world, mesh=mesh, backend="nccl", grid=grid)
