@@ -183,11 +183,19 @@ class HaloTransport:
     into torch.distributed on a gloo group (tests: several ranks on one card).  Default: "rccl" when the default
     process group is nccl, else "host"."""
 
-    def __init__(self, ctx, part: BoxPartition, n_eigenvectors: int = 2, group=None, transport: str | None = None):
+    def __init__(self, ctx, part: BoxPartition, n_eigenvectors: int = 2, group=None, transport: str | None = None,
+                 callbacks=None):
+        """callbacks = (exchange, allreduce, allgather): a host transport of the caller's own instead of torch.distributed --
+        exchange(peers, send, recv) with lists of numpy views (send[i] goes to rank peers[i], recv[i] is filled from it, all
+        at once), allreduce(values, op) in place on a numpy view (op 0 sum, 1 max), allgather(src, out) -- e.g. mailboxes
+        between threads of one process that each drive a rank (tests/test_box_threads.py)."""
         self._lib = _lib.load()
         self.ctx, self.part, self.group = ctx, part, group
-        self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self._user_callbacks = callbacks
+        self.backend = "custom" if callbacks else (dist.get_backend(group) if dist.is_initialized() else "none")
         self.rank, self.n_ranks = part.rank, part.n_ranks
+        if callbacks:
+            transport = "host"
         if transport is None:
             transport = "rccl" if self.backend == "nccl" else "host"
         assert transport in ("rccl", "host")
@@ -229,7 +237,7 @@ class HaloTransport:
             self._host_group = None
         else:
             # CPU tensors travel over gloo (a second group when the default one is nccl)
-            self._host_group = group if self.backend == "gloo" else dist.new_group(backend="gloo")
+            self._host_group = None if callbacks else (group if self.backend == "gloo" else dist.new_group(backend="gloo"))
             self._sendrecv_cb = _EXCHANGE_FN(self._exchange)
             self._allreduce_cb = _ALLREDUCE_FN(self._allreduce)
             self._allgather_cb = _ALLGATHER_FN(self._allgather)
@@ -241,6 +249,12 @@ class HaloTransport:
     # -- callbacks of the host transport (invoked from inside the library, on the calling Python thread) --------
     def _exchange(self, user, n, peers, send, recv, count):
         try:
+            if self._user_callbacks:
+                import numpy as np
+                view = lambda p, m: np.ctypeslib.as_array(p, shape=(int(m),))
+                self._user_callbacks[0]([int(peers[i]) for i in range(n)], [view(send[i], count[i]) for i in range(n)],
+                                        [view(recv[i], count[i]) for i in range(n)])
+                return 0
             ops = []
             for i in range(n):
                 if count[i] > 0:
@@ -256,6 +270,10 @@ class HaloTransport:
 
     def _allreduce(self, user, values, n, op):
         try:
+            if self._user_callbacks:
+                import numpy as np
+                self._user_callbacks[1](np.ctypeslib.as_array(values, shape=(int(n),)), int(op))
+                return 0
             t = _host_tensor(values, n)
             dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM, group=self._host_group)
             return 0
@@ -265,6 +283,10 @@ class HaloTransport:
 
     def _allgather(self, user, src, n, out):
         try:
+            if self._user_callbacks:
+                import numpy as np
+                self._user_callbacks[2](np.ctypeslib.as_array(src, shape=(int(n),)), np.ctypeslib.as_array(out, shape=(int(n) * self.n_ranks,)))
+                return 0
             o = _host_tensor(out, n * self.n_ranks)
             dist.all_gather_into_tensor(o, _host_tensor(src, n).clone(), group=self._host_group)
             return 0
