@@ -44,6 +44,7 @@ struct CsrArgs
   T *out;
   T alpha, beta;
   int mode;
+  int pairs; // every vector the mode touches is 16-byte aligned: the two rows of a node are one access per operand (store_node)
 };
 
 // the fused epilogues of a row (the modes of CsrMode)
@@ -76,6 +77,112 @@ __device__ __forceinline__ void store_row(CsrArgs<T> const &a, int64_t row, T su
     break;
   }
   a.out[row] = o;
+}
+
+// The epilogue of the C rows of one NODE (the node kernels below).  Row by row (store_row) the operands of the second row
+// could only be requested after the store of the first -- nothing tells the compiler that out does not alias x, b or D^-1 --,
+// one more dependent round trip in kernels that are bound by their latency.  Here every operand of the node is requested
+// before the first store, and for C = 2 in FP64 the rows 2 n, 2 n + 1 are ONE 16-byte access per operand (a.pairs: the
+// vectors are 16-byte aligned, checked at launch).  Same operations in the same order as store_row: same bits.
+template <typename T, int C>
+__device__ __forceinline__ void store_node(CsrArgs<T> const &a, int64_t node, T const (&sum)[C])
+{
+  const int64_t row0 = node * C;
+  T xr[C], br[C], dr[C], pr[C], orr[C];
+  const int mode = a.mode;
+  const bool need_x = mode == 2 || mode == 3, need_b = mode >= 1 && mode <= 3, need_d = need_x, need_p = mode == 3,
+             need_o = mode >= 4;
+  if constexpr (C == 2 && sizeof(T) == 8)
+  {
+    if (a.pairs)
+    {
+      auto ld2 = [&](T const *v, T(&t)[C]) {
+        const double2 q = *reinterpret_cast<double2 const *>(v + row0);
+        t[0] = q.x;
+        t[1] = q.y;
+      };
+      if (need_x)
+        ld2(a.x, xr);
+      if (need_b)
+        ld2(a.b, br);
+      if (need_d)
+        ld2(a.dinv, dr);
+      if (need_p)
+        ld2(a.xprev, pr);
+      if (need_o)
+        ld2(a.out, orr);
+      T o[C];
+#pragma unroll
+      for (int rc = 0; rc < C; ++rc)
+      {
+        switch (mode)
+        {
+        case 0:
+          o[rc] = sum[rc];
+          break;
+        case 1:
+          o[rc] = sum[rc] - br[rc];
+          break;
+        case 2:
+          o[rc] = xr[rc] - a.beta * dr[rc] * (sum[rc] - br[rc]);
+          break;
+        case 3:
+          o[rc] = xr[rc] + a.alpha * (xr[rc] - pr[rc]) - a.beta * dr[rc] * (sum[rc] - br[rc]);
+          break;
+        case 4:
+          o[rc] = orr[rc] - sum[rc];
+          break;
+        default:
+          o[rc] = orr[rc] + sum[rc];
+          break;
+        }
+      }
+      *reinterpret_cast<double2 *>(a.out + row0) = make_double2(o[0], o[1]);
+      return;
+    }
+  }
+#pragma unroll
+  for (int rc = 0; rc < C; ++rc)
+  {
+    const int64_t row = row0 + rc;
+    if (need_x)
+      xr[rc] = a.x[row];
+    if (need_b)
+      br[rc] = a.b[row];
+    if (need_d)
+      dr[rc] = a.dinv[row];
+    if (need_p)
+      pr[rc] = a.xprev[row];
+    if (need_o)
+      orr[rc] = a.out[row];
+  }
+#pragma unroll
+  for (int rc = 0; rc < C; ++rc)
+  {
+    T o;
+    switch (mode)
+    {
+    case 0:
+      o = sum[rc];
+      break;
+    case 1:
+      o = sum[rc] - br[rc];
+      break;
+    case 2:
+      o = xr[rc] - a.beta * dr[rc] * (sum[rc] - br[rc]);
+      break;
+    case 3:
+      o = xr[rc] + a.alpha * (xr[rc] - pr[rc]) - a.beta * dr[rc] * (sum[rc] - br[rc]);
+      break;
+    case 4:
+      o = orr[rc] - sum[rc];
+      break;
+    default:
+      o = orr[rc] + sum[rc];
+      break;
+    }
+    a.out[row0 + rc] = o;
+  }
 }
 
 template <typename T, int LPR>
@@ -349,6 +456,17 @@ struct BdiaRegular
   int64_t n_col_nodes = 0;
 };
 
+// Stencil tables and offset lists are read-only for the whole launch and addressed wave-uniformly: through the CONSTANT
+// address space their loads are scalar loads whatever the compiler can prove about the stores of the kernel (with the plain
+// pointer a change of the epilogue turned the 27 table loads of a node into per-lane 16-byte vector loads: 41 -> 60 us).
+template <typename V>
+using const_as = __attribute__((address_space(4))) const V;
+template <typename V>
+__device__ __forceinline__ const_as<V> *as_constant(V const *p)
+{
+  return reinterpret_cast<const_as<V> *>(reinterpret_cast<uintptr_t>(p));
+}
+
 // One thread per NODE whose C rows are all regular: the x values of a neighbour node are fetched once for the C
 // rows (one 16-byte request for C = 2), the stencil constants are wave-uniform (scalar loads).
 template <typename T, int C>
@@ -361,10 +479,12 @@ __global__ __launch_bounds__(256) void bdia_regular_node_kernel(CsrArgs<T> a, Bd
 #pragma unroll
   for (int rc = 0; rc < C; ++rc)
     sum[rc] = T(0);
+  const_as<T> *table = as_constant(g.table);
+  const_as<int32_t> *offs = as_constant(g.offs);
 #pragma unroll 8
   for (int d = 0; d < g.Df; ++d)
   {
-    const int64_t nb = node + g.offs[d];
+    const int64_t nb = node + offs[d];
     T xv[C];
     if constexpr (C == 2 && sizeof(T) == 8)
     {
@@ -382,39 +502,9 @@ __global__ __launch_bounds__(256) void bdia_regular_node_kernel(CsrArgs<T> a, Bd
     for (int rc = 0; rc < C; ++rc)
 #pragma unroll
       for (int cc = 0; cc < C; ++cc)
-        sum[rc] += g.table[((size_t)rc * g.Df + d) * C + cc] * xv[cc];
+        sum[rc] += table[((size_t)rc * g.Df + d) * C + cc] * xv[cc];
   }
-#pragma unroll
-  for (int rc = 0; rc < C; ++rc)
-  {
-    const int64_t row = node * C + rc;
-    T o;
-    switch (a.mode)
-    {
-    case 0:
-      o = sum[rc];
-      break;
-    case 1:
-      o = sum[rc] - a.b[row];
-      break;
-    case 2:
-      o = a.x[row] - a.beta * a.dinv[row] * (sum[rc] - a.b[row]);
-      break;
-    case 3:
-    {
-      const T xr = a.x[row];
-      o = xr + a.alpha * (xr - a.xprev[row]) - a.beta * a.dinv[row] * (sum[rc] - a.b[row]);
-      break;
-    }
-    case 4:
-      o = a.out[row] - sum[rc];
-      break;
-    default:
-      o = a.out[row] + sum[rc];
-      break;
-    }
-    a.out[row] = o;
-  }
+  store_node<T, C>(a, node, sum);
 }
 
 // One wavefront over the CSR entries of one listed row (rows that are neither regular nor in a class): a thread per
@@ -462,7 +552,8 @@ __global__ __launch_bounds__(256) void bdia_class_node_kernel(CsrArgs<T> a, Bdia
     return;
   const int64_t last = g.n_col_nodes - 1;
   const int64_t first = g.base != nullptr ? (int64_t)g.base[node] : node;
-  T const *tab = class_table + (size_t)cls * (size_t)(C * g.Df * C);
+  const_as<T> *tab = as_constant(class_table + (size_t)cls * (size_t)(C * g.Df * C));
+  const_as<int32_t> *offs = as_constant(g.offs);
   T sum[C];
 #pragma unroll
   for (int rc = 0; rc < C; ++rc)
@@ -471,7 +562,7 @@ __global__ __launch_bounds__(256) void bdia_class_node_kernel(CsrArgs<T> a, Bdia
   for (int d = 0; d < g.Df; ++d)
   {
     // (node indices are int32 in every layout: the clamp is two 32-bit instructions instead of 64-bit selects)
-    const int64_t nb = max(0, min((int)first + g.offs[d], (int)last));
+    const int64_t nb = max(0, min((int)first + offs[d], (int)last));
     T xv[C];
     if constexpr (C == 2 && sizeof(T) == 8)
     {
@@ -491,37 +582,7 @@ __global__ __launch_bounds__(256) void bdia_class_node_kernel(CsrArgs<T> a, Bdia
       for (int cc = 0; cc < C; ++cc)
         sum[rc] += tab[((size_t)rc * g.Df + d) * C + cc] * xv[cc];
   }
-#pragma unroll
-  for (int rc = 0; rc < C; ++rc)
-  {
-    const int64_t row = node * C + rc;
-    T o;
-    switch (a.mode)
-    {
-    case 0:
-      o = sum[rc];
-      break;
-    case 1:
-      o = sum[rc] - a.b[row];
-      break;
-    case 2:
-      o = a.x[row] - a.beta * a.dinv[row] * (sum[rc] - a.b[row]);
-      break;
-    case 3:
-    {
-      const T xr = a.x[row];
-      o = xr + a.alpha * (xr - a.xprev[row]) - a.beta * a.dinv[row] * (sum[rc] - a.b[row]);
-      break;
-    }
-    case 4:
-      o = a.out[row] - sum[rc];
-      break;
-    default:
-      o = a.out[row] + sum[rc];
-      break;
-    }
-    a.out[row] = o;
-  }
+  store_node<T, C>(a, node, sum);
 }
 
 // The same two node kernels for wide stencils (the second level of the aggregation hierarchy couples 125 nodes):
@@ -550,12 +611,13 @@ __global__ __launch_bounds__(1024) void bdia_node_split_kernel(CsrArgs<T> a, Bdi
   const int q = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / NB)), lane = threadIdx.x % NB;
   const int64_t slot = (int64_t)blockIdx.x * NB + lane;
   int64_t node = -1;
-  T const *tab = g.table;
+  const_as<T> *tab = as_constant(g.table);
+  const_as<int32_t> *offs = as_constant(g.offs);
   if constexpr (CLASSES)
   {
     // (n_slots is a multiple of 64: one class per wavefront, its table pointer stays in scalar registers)
     const int64_t ws = slot < n_slots ? slot : n_slots - 1;
-    tab = class_table + (size_t)__builtin_amdgcn_readfirstlane(class_of_wave[ws >> 6]) * (size_t)(C * g.Df * C);
+    tab = as_constant(class_table + (size_t)__builtin_amdgcn_readfirstlane(class_of_wave[ws >> 6]) * (size_t)(C * g.Df * C));
     node = slot < n_slots ? (int64_t)nodes[ws] : -1;
   }
   else if (slot * C < a.n_rows && g.exc[slot * C] == 0)
@@ -572,9 +634,9 @@ __global__ __launch_bounds__(1024) void bdia_node_split_kernel(CsrArgs<T> a, Bdi
 #pragma unroll 8
     for (int d = d0; d < d1; ++d)
     {
-      int64_t nb = first + g.offs[d];
+      int64_t nb = first + offs[d];
       if constexpr (CLASSES)
-        nb = max(0, min((int)first + g.offs[d], (int)last)); // (int32 node indices: a 32-bit clamp)
+        nb = max(0, min((int)first + offs[d], (int)last)); // (int32 node indices: a 32-bit clamp)
       T xv[C];
       if constexpr (C == 2 && sizeof(T) == 8)
       {
@@ -604,15 +666,16 @@ __global__ __launch_bounds__(1024) void bdia_node_split_kernel(CsrArgs<T> a, Bdi
   __syncthreads();
   if (q == 0 && node >= 0)
   {
+    T total[C];
 #pragma unroll
     for (int rc = 0; rc < C; ++rc)
     {
-      T total = sum[rc];
+      total[rc] = sum[rc];
 #pragma unroll
       for (int k = 0; k < P - 1; ++k)
-        total += part[k][rc][lane];
-      store_row(a, node * C + rc, total);
+        total[rc] += part[k][rc][lane];
     }
+    store_node<T, C>(a, node, total);
   }
 }
 
@@ -1962,6 +2025,10 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
   a.alpha = alpha;
   a.beta = beta;
   a.mode = static_cast<int>(mode);
+  {
+    auto aligned = [](void const *p) { return p == nullptr || reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    a.pairs = (aligned(x) && aligned(b) && aligned(dinv) && aligned(x_prev) && aligned(out)) ? 1 : 0;
+  }
   hipStream_t st = _handle.stream;
   const double extra = (mode == CsrMode::apply) ? 0. : (mode == CsrMode::first) ? 3. : (mode == CsrMode::next) ? 4. : 1.;
   hipEvent_t stop =

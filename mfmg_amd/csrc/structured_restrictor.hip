@@ -293,12 +293,31 @@ __global__ __launch_bounds__(256) void sr_prolong_block222_kernel(SrArgs s, doub
                          : make_double2(0., 0.);
   }
   const bool pair = 2 * vi + 1 < s.N[0];
+  // the four rows this thread finishes: all four reads of `out` are requested up front, together with the y pairs above
+  // (row by row each read waited behind the store of the row before: out may alias out, four dependent round trips)
+  bool live[4];
+  double *orow[4];
+  sr_pair ov[4];
+#pragma unroll
+  for (int dyz = 0; dyz < 4; ++dyz)
+  {
+    const int j = 2 * vj + (dyz & 1), k = 2 * vk + (dyz >> 1);
+    live[dyz] = j < s.N[1] && k < s.N[2];
+    orow[dyz] = out + 2 * vi + (int64_t)s.N[0] * (min(j, s.N[1] - 1) + (int64_t)s.N[1] * min(k, s.N[2] - 1));
+    ov[dyz] = sr_pair{0., 0.};
+    if (live[dyz] && subtract)
+    {
+      if (pair)
+        ov[dyz] = *reinterpret_cast<sr_pair const *>(orow[dyz]);
+      else
+        ov[dyz].x = orow[dyz][0];
+    }
+  }
 #pragma unroll
   for (int dyz = 0; dyz < 4; ++dyz)
   {
     const int dy = dyz & 1, dz = dyz >> 1;
-    const int j = 2 * vj + dy, k = 2 * vk + dz;
-    if (j >= s.N[1] || k >= s.N[2])
+    if (!live[dyz])
       continue;
     double sums[2];
 #pragma unroll
@@ -323,16 +342,13 @@ __global__ __launch_bounds__(256) void sr_prolong_block222_kernel(SrArgs s, doub
           }
       sums[dx] = sum;
     }
-    double *o = out + 2 * vi + (int64_t)s.N[0] * (j + (int64_t)s.N[1] * k);
+    sr_pair v = ov[dyz];
+    v.x = subtract ? v.x - sums[0] : sums[0];
+    v.y = subtract ? v.y - sums[1] : sums[1];
     if (pair)
-    {
-      sr_pair v = subtract ? *reinterpret_cast<sr_pair const *>(o) : sr_pair{0., 0.};
-      v.x = subtract ? v.x - sums[0] : sums[0];
-      v.y = subtract ? v.y - sums[1] : sums[1];
-      *reinterpret_cast<sr_pair *>(o) = v;
-    }
+      *reinterpret_cast<sr_pair *>(orow[dyz]) = v;
     else
-      o[0] = subtract ? o[0] - sums[0] : sums[0];
+      orow[dyz][0] = v.x;
   }
 }
 } // namespace
