@@ -674,7 +674,7 @@ def main():
             "other_kernels": {
                 "csr_spmv_kernel": {"what": "coarse-level family: A_c and the levels below, R, R^T, prolongators (table-driven "
                                             "layouts read no matrix values, so no byte rate is quoted; HBM bytes per launch "
-                                            "from the PMC passes: profiles/r03_d_cycle_hbm_bytes_per_launch.txt)",
+                                            "from the PMC passes: profiles/r03_g_cycle_hbm_bytes_per_launch.txt)",
                                     "launches": c_launches, "total_ms": c_ms,
                                     "share_of_step_time": (c_ms / (ms_per_step * (other_cycles or args.steps))) if c_ms else None,
                                     "timed_in": (f"{other_cycles} extra cycles after the timed region" if other_cycles
