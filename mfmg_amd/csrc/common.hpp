@@ -581,6 +581,30 @@ struct HipHandle
       return;
     MFMG_HIP_CHECK(hipStreamWaitEvent(stream, ev_unpacked, 0));
   }
+  // Work enqueued on the exchange stream behind the unpacking (the shell tiles of the fine operator: they run beside the
+  // interior tiles on `stream` instead of after them); join_exchange_stream makes `stream` wait for it.
+  hipStream_t exchange_stream()
+  {
+    if (comm_stream == nullptr)
+    {
+      MFMG_HIP_CHECK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+      MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming));
+      MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_unpacked, hipEventDisableTiming));
+    }
+    return comm_stream;
+  }
+  void join_exchange_stream()
+  {
+    MFMG_HIP_CHECK(hipEventRecord(ev_unpacked, exchange_stream()));
+    MFMG_HIP_CHECK(hipStreamWaitEvent(stream, ev_unpacked, 0));
+  }
+  // (one rank, measurement only: the exchange stream waits for what `stream` has enqueued so far)
+  void fork_exchange_stream()
+  {
+    hipStream_t cs = exchange_stream();
+    MFMG_HIP_CHECK(hipEventRecord(ev_packed, stream));
+    MFMG_HIP_CHECK(hipStreamWaitEvent(cs, ev_packed, 0));
+  }
   // ghost -> owner: the ghost layers hold partial sums that belong to the neighbours' boundary layers
   void exchange_reverse_add(int space, double *v)
   {

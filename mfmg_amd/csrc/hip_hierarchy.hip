@@ -608,44 +608,34 @@ void HipMatrixFreeOperator::apply_mode(MfMode mode, double const *x, double cons
     else
       op->smoother_step(b, x, x_prev, alpha, beta, out);
   };
-  if (!handle.comm.enabled())
-  {
-    whole();
-    return;
-  }
-  HaloSpace const &s = handle.comm.spaces[1];
-  if (s.split_xy())
-  {
-    // boxes: tiles along all three axes.  Tile t of an axis owns the planes [t R, (t + 1) R) and reads one more on either side;
-    // the planes the exchange writes are own0 - 1 (towards a lower neighbour) and own0 + own_n (towards an upper one):
-    // plane g is read by the tiles ceil(g / R) - 1 ... floor((g + 1) / R).  The tiles that read none of them form a box
-    // [lo, hi) of tiles and run while the faces, edges and corners travel; the shell around them -- at most six slabs of
-    // tiles and the columns of the tail -- follows.
-    int nt[3], rows[3], lo[3], hi[3];
-    op->tiling(nt, rows);
-    bool interior = handle.overlap_exchange;
-    for (int d = 0; d < 3; ++d)
+  // The shell around the interior tiles is ONE launch over a compact list of its tiles (launch_outside: z slabs, y slabs, x
+  // slabs and the tail columns; consecutive workgroups, consecutive tiles, so that the XCDs share it evenly), enqueued on the
+  // EXCHANGE stream behind the unpacking: it runs beside the interior tiles and its workgroups fill the slots the interior
+  // launch leaves while it drains.  Measured on one GPU with the launches of the corner rank of a 2 x 2 x 2 grid and no exchange
+  // (MFMG_MF_EMULATE_SPLIT=1, 257^3 DoFs, us per operator application, start to start): one launch for the whole mesh 192;
+  // interior, then the shell slab by slab (five launches, each a fraction of a round of workgroups and as long as one workgroup
+  // lives: rounds 1-3) 290; interior, then the shell as one launch ("MFMG_MF_SHELL=after") 236; beside each other 218.
+  // Same tiles, same bits (owner computes).  "MFMG_MF_SHELL=slabs" keeps the old launches for that comparison.
+  static const std::string shell_env = std::getenv("MFMG_MF_SHELL") ? std::getenv("MFMG_MF_SHELL") : "";
+  static const bool shell_slabs = shell_env == "slabs", shell_after = shell_env == "after";
+  // concurrent: the shell launch goes to the exchange stream, behind the unpacking, and runs BESIDE the interior tiles (its
+  // workgroups fill the slots the interior launch leaves free while it drains); `stream` joins afterwards.  The two launches
+  // write disjoint DoFs and read x, b and x_prev only (a term that overwrites its own x_prev reads and writes it DoF by DoF).
+  auto shell = [&](int const lo[3], int const hi[3], int const nt[3]) {
+    if (!shell_slabs && !shell_after)
     {
-      lo[d] = 0;
-      hi[d] = nt[d];
-      if (s.low(d))
-        lo[d] = (int)std::min<int64_t>(nt[d], s.own0(d) / rows[d] + 1);
-      if (s.high(d))
-        hi[d] = (int)std::max<int64_t>(0, std::min<int64_t>(nt[d], (s.own0(d) + s.own_n(d) + rows[d] - 1) / rows[d] - 1));
-      if (lo[d] >= hi[d])
-        interior = false;
+      op->launch_outside(mode, x, b, x_prev, alpha, beta, out, lo, hi, handle.exchange_stream());
+      handle.join_exchange_stream();
+      return;
     }
-    if (!interior)
+    handle.exchange_end(1);
+    if (shell_after)
     {
-      handle.exchange(1, const_cast<double *>(x));
-      whole();
+      op->launch_outside(mode, x, b, x_prev, alpha, beta, out, lo, hi);
       return;
     }
     const int zero[3] = {0, 0, 0};
-    handle.exchange_begin(1, const_cast<double *>(x));
-    op->launch_tiles(mode, x, b, x_prev, alpha, beta, out, lo, hi, true, false);
-    handle.exchange_end(1);
-    // z slabs over all columns and rows (+ the tail columns over all z-tiles), y slabs between them, x slabs between those
+    // z slabs over all columns and rows, y slabs between them, x slabs between those, then the tail columns over all z-tiles
     for (int side = 0; side < 2; ++side)
     {
       int b0[3] = {0, 0, side == 0 ? 0 : hi[2]}, b1[3] = {nt[0], nt[1], side == 0 ? lo[2] : nt[2]};
@@ -657,28 +647,56 @@ void HipMatrixFreeOperator::apply_mode(MfMode mode, double const *x, double cons
     }
     if (op->has_tail())
       op->launch_tiles(mode, x, b, x_prev, alpha, beta, out, zero, nt, false, true);
+  };
+  if (!handle.comm.enabled())
+  {
+    // (measurement only: the launches of the corner rank of a 2 x 2 x 2 grid -- one neighbour on the high side of every
+    // axis -- without the exchange)
+    static const bool emulate = std::getenv("MFMG_MF_EMULATE_SPLIT") && std::string(std::getenv("MFMG_MF_EMULATE_SPLIT")) == "1";
+    if (emulate && op->dim() == 3)
+    {
+      int nt[3], rows[3];
+      op->tiling(nt, rows);
+      if (nt[0] >= 2 && nt[1] >= 2 && nt[2] >= 2)
+      {
+        const int lo[3] = {0, 0, 0}, hi[3] = {nt[0] - 1, nt[1] - 1, nt[2] - 1};
+        handle.fork_exchange_stream(); // (what an exchange_begin does to the two streams, without the exchange)
+        op->launch_tiles(mode, x, b, x_prev, alpha, beta, out, lo, hi, true, false);
+        shell(lo, hi, nt);
+        return;
+      }
+    }
+    whole();
     return;
   }
-  const int n_tiles = op->n_z_tiles(), tz = op->tile_layers();
-  // tile t reads the DoF planes [t tz - 1, (t + 1) tz]; the received ghost planes are owned_begin - 1 (low)
-  // and owned_begin + owned_count (high)
-  // => plane g is read by the tiles ceil(g / tz) - 1 ... floor((g + 1) / tz)
-  int lo_end = 0, hi_begin = n_tiles;
-  if (s.has_low)
-    lo_end = (int)std::min<int64_t>(n_tiles, (s.owned_begin - 1 + 1) / tz + 1);
-  if (s.has_high)
-    hi_begin = (int)std::max<int64_t>(0, (s.owned_begin + s.owned_count + tz - 1) / tz - 1);
-  if (!handle.overlap_exchange || lo_end >= hi_begin)
+  HaloSpace const &s = handle.comm.spaces[1];
+  // Tile t of an axis owns the planes [t R, (t + 1) R) and reads one more on either side; the planes the exchange writes are
+  // own0 - 1 (towards a lower neighbour) and own0 + own_n (towards an upper one): plane g is read by the tiles
+  // ceil(g / R) - 1 ... floor((g + 1) / R).  The tiles that read none of them form a box [lo, hi) of tiles and run while the
+  // faces, edges and corners travel (slabs: the two planes along z); the shell around them and the columns of the tail follow.
+  int nt[3], rows[3], lo[3], hi[3];
+  op->tiling(nt, rows);
+  bool interior = handle.overlap_exchange;
+  for (int d = 0; d < 3; ++d)
+  {
+    lo[d] = 0;
+    hi[d] = nt[d];
+    if (s.low(d))
+      lo[d] = (int)std::min<int64_t>(nt[d], s.own0(d) / rows[d] + 1);
+    if (s.high(d))
+      hi[d] = (int)std::max<int64_t>(0, std::min<int64_t>(nt[d], (s.own0(d) + s.own_n(d) + rows[d] - 1) / rows[d] - 1));
+    if (lo[d] >= hi[d])
+      interior = false;
+  }
+  if (!interior)
   {
     handle.exchange(1, const_cast<double *>(x));
     whole();
     return;
   }
   handle.exchange_begin(1, const_cast<double *>(x));
-  op->launch_z_range(mode, x, b, x_prev, alpha, beta, out, lo_end, hi_begin);
-  handle.exchange_end(1);
-  op->launch_z_range(mode, x, b, x_prev, alpha, beta, out, 0, lo_end);
-  op->launch_z_range(mode, x, b, x_prev, alpha, beta, out, hi_begin, n_tiles);
+  op->launch_tiles(mode, x, b, x_prev, alpha, beta, out, lo, hi, true, false);
+  shell(lo, hi, nt);
 }
 
 void HipMatrixFreeOperator::apply_local(DVector const &x, DVector &y) const

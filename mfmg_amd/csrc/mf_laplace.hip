@@ -75,6 +75,17 @@ struct MfArgs
   AffineIds aff;
 };
 
+// n_boxes > 0: the tiles of the main part of a launch are those of up to six boxes of (column, y, z) tiles, one after the other
+// (box q: the tiles bx_end[q - 1] .. bx_end[q] - 1 of the list) -- the shell around the interior tiles of a distributed run as
+// ONE launch (launch_outside).  Consecutive workgroups take consecutive tiles of the list: the shell is spread evenly over the
+// XCDs (leaving the interior out of the full list instead gave two of the eight XCDs the whole x slab: 170 us for 30 % of the
+// tiles).  An argument of its own, not part of MfArgs: the two argument blocks of a launch are selected field by field.
+struct MfBoxes
+{
+  unsigned int n_boxes = 0;
+  unsigned int bx_end[6] = {}, bx_c0[6] = {}, bx_nc[6] = {}, bx_y0[6] = {}, bx_ny[6] = {}, bx_z0[6] = {};
+};
+
 namespace
 {
 constexpr unsigned int kFlag = 0x80000000u;  // bit 31: Dirichlet-constrained DoF (read as zero, row = identity)
@@ -336,7 +347,7 @@ __device__ __forceinline__ T mf_epilogue(MfArgs<T> const &a, int id0, T x0, T yv
 // moves, constant LDS offsets, the whole pass is one request batch for TYC <= 4); TYC = 0: rows from the
 // arguments, one request batch per row.
 template <typename T, int TYC, bool CC, int BATCH, bool AFF>
-__device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int bid)
+__device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int bid, MfBoxes const &bx, bool boxes)
 {
 #pragma clang fp contract(off)
   constexpr int B = TYC > 0 ? BATCH : 1; // cell rows per request batch (divides TYC)
@@ -359,18 +370,40 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
 
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8,
   // observed, speed only); give every XCD a contiguous run of the tile list.
-  const unsigned int n_tiles = a.ncols_active * a.ntiles_y * a.ntiles_z;
+  const unsigned int n_tiles = boxes ? bx.bx_end[5] : a.ncols_active * a.ntiles_y * a.ntiles_z;
   unsigned int w = bid;
   if (n_tiles >= 64)
   {
     const unsigned int per_xcd = (n_tiles + 7) / 8;
-    w = (bid % 8) * per_xcd + bid / 8;
+    if (!boxes)
+      w = (bid % 8) * per_xcd + bid / 8;
     if (w >= n_tiles)
       return; // the whole workgroup leaves: no barrier is left waiting
   }
-  const int tc = a.col0 + w % a.ncols_active;
-  const int tyi = a.ty0 + (w / a.ncols_active) % a.ntiles_y;
-  const int tzi = a.z_tile0 + w / (a.ncols_active * a.ntiles_y);
+  // (the box of a tile list: wave-uniform selects over constant indices -- no dynamic indexing of the argument block)
+  unsigned int c0 = a.col0, nc = a.ncols_active, y0 = a.ty0, ny = a.ntiles_y, z0 = a.z_tile0;
+  if (boxes)
+  {
+    unsigned int first = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+    {
+      const unsigned int lo = q > 0 ? bx.bx_end[q - 1] : 0u;
+      if (w >= lo && w < bx.bx_end[q])
+      {
+        first = lo;
+        c0 = bx.bx_c0[q];
+        nc = bx.bx_nc[q];
+        y0 = bx.bx_y0[q];
+        ny = bx.bx_ny[q];
+        z0 = bx.bx_z0[q];
+      }
+    }
+    w -= first;
+  }
+  const int tc = c0 + w % nc;
+  const int tyi = y0 + (w / nc) % ny;
+  const int tzi = z0 + w / (nc * ny);
   const int ci = tc * kOwn - 1 + lane;              // cell / DoF column of this lane
   const int Yb = tyi * (NW * TY - 1) - 1 + wv * TY; // first cell row of this wavefront
   const int Z0 = a.ztab[tzi];            // (wave-uniform index: scalar loads)
@@ -673,10 +706,11 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
 // cell-constant variant, fewer for eight coefficients per cell (16 VGPRs of coefficients per row in FP64).
 // AFF: the ids are computed from the position (AffineIds) instead of read from the records.
 template <typename T, int TYC, bool CC, int BATCH, bool AFF = false>
-__global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> am, MfArgs<T> at, unsigned int n_tail_blocks)
+__global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> am, MfArgs<T> at, unsigned int n_tail_blocks, MfBoxes boxes)
 {
   const bool tail = blockIdx.x < n_tail_blocks;
-  mf_laplace_body<T, TYC, CC, BATCH, AFF>(tail ? at : am, tail ? blockIdx.x : blockIdx.x - n_tail_blocks);
+  mf_laplace_body<T, TYC, CC, BATCH, AFF>(tail ? at : am, tail ? blockIdx.x : blockIdx.x - n_tail_blocks, boxes,
+                                          !tail && boxes.n_boxes > 0);
 }
 
 // ---- setup kernels -----------------------------------------------------------
@@ -1541,15 +1575,16 @@ bool MatrixFreeLaplaceDevice<T>::make_args(MfArgs<T> &a, unsigned int &n_blocks,
 template <typename T>
 void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out,
                                      int nw, int ty, int tz, int z_tile_begin, int z_tile_end, int const *xy_range, bool with_main,
-                                     bool with_tail) const
+                                     bool with_tail, int const *exclude, hipStream_t on_stream) const
 {
   ASSERT_THROW(nw >= 1 && nw <= 8, "1..8 wavefronts per workgroup");
   ASSERT_THROW(ty >= 1 && tz >= 1 && nw * ty >= 2, "operator tile too small");
   MfArgs<T> am, at;
+  MfBoxes boxes;
   unsigned int main_blocks = 0, tail_blocks = 0;
   // the whole mesh: graded z-tiles; a range of z-tiles: the uniform tiling the caller counts in
   static const bool graded_env = !(std::getenv("MFMG_MF_GRADED_TILES") && std::string(std::getenv("MFMG_MF_GRADED_TILES")) == "0");
-  const bool whole = z_tile_begin == 0 && z_tile_end < 0;
+  const bool whole = z_tile_begin == 0 && z_tile_end < 0 && exclude == nullptr;
   int all_z = 0;
   int const *ztab = z_tiling(tz, whole && graded_env, all_z);
   if (z_tile_end < 0)
@@ -1561,6 +1596,37 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
   if (!with_main)
     main_blocks = 0;
   at = am;
+  if (exclude)
+  {
+    // the tiles of the uniform tiling outside the box {lo[3], hi[3]}: z slabs over all columns and rows, y slabs between them,
+    // x slabs between those (the tail columns are not column tiles: they are the `at` part of the launch as always)
+    const int nt[3] = {(int)am.ncols_active, (int)am.ntiles_y, (int)am.ntiles_z};
+    int lo[3], hi[3];
+    for (int d = 0; d < 3; ++d)
+    {
+      lo[d] = std::min(std::max(exclude[d], 0), nt[d]);
+      hi[d] = std::min(std::max(exclude[3 + d], lo[d]), nt[d]);
+    }
+    const int box[6][6] = {{0, nt[0], 0, nt[1], 0, lo[2]},         {0, nt[0], 0, nt[1], hi[2], nt[2]},
+                           {0, nt[0], 0, lo[1], lo[2], hi[2]},     {0, nt[0], hi[1], nt[1], lo[2], hi[2]},
+                           {0, lo[0], lo[1], hi[1], lo[2], hi[2]}, {hi[0], nt[0], lo[1], hi[1], lo[2], hi[2]}};
+    unsigned int end = 0;
+    for (int q = 0; q < 6; ++q)
+    {
+      const int ncq = box[q][1] - box[q][0], nyq = box[q][3] - box[q][2], nzq = box[q][5] - box[q][4];
+      const bool empty = ncq <= 0 || nyq <= 0 || nzq <= 0;
+      if (!empty)
+        end += (unsigned int)ncq * nyq * nzq;
+      boxes.bx_end[q] = end;
+      boxes.bx_c0[q] = (unsigned int)box[q][0];
+      boxes.bx_nc[q] = empty ? 1u : (unsigned int)ncq;
+      boxes.bx_y0[q] = (unsigned int)box[q][2];
+      boxes.bx_ny[q] = empty ? 1u : (unsigned int)nyq;
+      boxes.bx_z0[q] = (unsigned int)box[q][4];
+    }
+    boxes.n_boxes = 6;
+    main_blocks = with_main ? (end >= 64 ? ((end + 7) / 8) * 8 : end) : 0;
+  }
   if (_tail && with_tail) // the columns of the last chunk: same tile shape, same layers (same table: Nz is the same), first in the grid
     _tail->make_args(at, tail_blocks, mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, ztab, z_tile_begin, z_tile_end, nullptr);
   if (main_blocks + tail_blocks == 0)
@@ -1569,7 +1635,7 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
   ASSERT_THROW(lds <= 160 * 1024, "operator tile too large for the LDS");
   const dim3 grid(main_blocks + tail_blocks);
   const dim3 block(64 * nw);
-  hipStream_t st = _handle.stream;
+  hipStream_t st = on_stream ? on_stream : _handle.stream;
   auto go = [&](auto kernel) {
     // (the attribute is per kernel AND device; every instantiation decays to the same function-pointer type, so the
     // record of what has been set is keyed on the pointer -- a flag per lambda instantiation would be shared by all variants)
@@ -1583,7 +1649,7 @@ void MatrixFreeLaplaceDevice<T>::run(MfMode mode, T const *x, T const *b, T cons
         MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024));
     }
-    hipLaunchKernelGGL(kernel, grid, block, lds, st, am, at, tail_blocks);
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, am, at, tail_blocks, boxes);
   };
   // both parts of the launch must read their ids the same way
   const bool affine = ids_computed();
@@ -1717,6 +1783,35 @@ void MatrixFreeLaplaceDevice<T>::launch_tiles(MfMode mode, T const *x, T const *
   const int xy[4] = {begin[0], end[0], begin[1], end[1]};
   run(mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, begin[2], end[2], xy, m, t);
   KernelProfiler::end(stop, _handle.stream);
+}
+
+// Everything launch_tiles(begin, end, main) leaves: the tiles of the uniform tiling OUTSIDE the box [begin, end) and the tail
+// columns, as ONE launch (the workgroups of the excluded tiles leave at once).  Launched slab by slab -- up to six launches
+// and the tail, each a fraction of a round of workgroups and as long as one workgroup lives -- the shell of a box rank cost
+// more than the interior it surrounds.
+template <typename T>
+void MatrixFreeLaplaceDevice<T>::launch_outside(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out,
+                                                int const begin[3], int const end[3], hipStream_t on_stream) const
+{
+  check_vectors(mode, x, b, x_prev, out);
+  ASSERT_THROW(_dim == 3, "tile ranges belong to the 3-D operator");
+  if (mode == MfMode::next && (x_prev == nullptr || alpha == T(0)))
+    mode = MfMode::first;
+  int nw, ty, tz;
+  choose_tile(nw, ty, tz);
+  int nt[3], rows[3];
+  tiling(nt, rows);
+  double inside = 1.;
+  for (int d = 0; d < 3; ++d)
+  {
+    ASSERT_THROW(begin[d] >= 0 && begin[d] <= end[d] && end[d] <= nt[d], "tile range outside the tiling");
+    inside *= double(end[d] - begin[d]) * (d == 0 ? double(rows[0]) / double(_N[0]) : 1. / double(nt[d]));
+  }
+  hipStream_t st = on_stream ? on_stream : _handle.stream;
+  hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel", std::max(0., 1. - inside) * (required_bytes_apply() + epilogue_bytes((int)mode)), st);
+  const int ex[6] = {begin[0], begin[1], begin[2], end[0], end[1], end[2]};
+  run(mode, x, b, x_prev, alpha, beta, out, nw, ty, tz, 0, -1, nullptr, true, true, ex, st);
+  KernelProfiler::end(stop, st);
 }
 
 template <typename T>

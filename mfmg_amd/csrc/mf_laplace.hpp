@@ -87,6 +87,11 @@ public:
   bool has_tail() const { return _tail != nullptr; }
   void launch_tiles(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out, int const begin[3],
                     int const end[3], bool main_part, bool tail_part) const;
+  // ... and everything such a box leaves (the tiles outside [begin, end) and the tail columns) as ONE launch
+  // (on_stream: another stream than the context's -- the shell of a distributed run is launched on the exchange stream, behind
+  // the unpacking of the ghost planes, and runs BESIDE the interior tiles)
+  void launch_outside(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out, int const begin[3],
+                      int const end[3], hipStream_t on_stream = nullptr) const;
 
   T const *diagonal() const { return _diag.data(); }
   T const *diagonal_inverse() const { return _dinv.data(); }
@@ -133,7 +138,7 @@ private:
   void launch(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out) const;
   void run(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out, int nw, int ty, int tz,
            int z_tile_begin = 0, int z_tile_end = -1, int const *xy_range = nullptr, bool with_main = true,
-           bool with_tail = true) const;
+           bool with_tail = true, int const *exclude = nullptr, hipStream_t on_stream = nullptr) const;
   bool make_args(MfArgs<T> &a, unsigned int &n_blocks, MfMode mode, T const *x, T const *b, T const *x_prev, T alpha,
                  T beta, T *out, int nw, int ty, int tz, int const *ztab, int z_tile_begin, int z_tile_end,
                  int const *xy_range) const;
