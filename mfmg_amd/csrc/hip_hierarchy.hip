@@ -616,8 +616,9 @@ void HipMatrixFreeOperator::apply_mode(MfMode mode, double const *x, double cons
   // interior, then the shell slab by slab (five launches, each a fraction of a round of workgroups and as long as one workgroup
   // lives: rounds 1-3) 290; interior, then the shell as one launch ("MFMG_MF_SHELL=after") 236; beside each other 218.
   // Same tiles, same bits (owner computes).  "MFMG_MF_SHELL=slabs" keeps the old launches for that comparison.
-  static const std::string shell_env = std::getenv("MFMG_MF_SHELL") ? std::getenv("MFMG_MF_SHELL") : "";
-  static const bool shell_slabs = shell_env == "slabs", shell_after = shell_env == "after";
+  // (read at every application: a test switches between the variants inside one process)
+  const std::string shell_env = std::getenv("MFMG_MF_SHELL") ? std::getenv("MFMG_MF_SHELL") : "";
+  const bool shell_slabs = shell_env == "slabs", shell_after = shell_env == "after";
   // concurrent: the shell launch goes to the exchange stream, behind the unpacking, and runs BESIDE the interior tiles (its
   // workgroups fill the slots the interior launch leaves free while it drains); `stream` joins afterwards.  The two launches
   // write disjoint DoFs and read x, b and x_prev only (a term that overwrites its own x_prev reads and writes it DoF by DoF).
@@ -652,7 +653,7 @@ void HipMatrixFreeOperator::apply_mode(MfMode mode, double const *x, double cons
   {
     // (measurement only: the launches of the corner rank of a 2 x 2 x 2 grid -- one neighbour on the high side of every
     // axis -- without the exchange)
-    static const bool emulate = std::getenv("MFMG_MF_EMULATE_SPLIT") && std::string(std::getenv("MFMG_MF_EMULATE_SPLIT")) == "1";
+    const bool emulate = std::getenv("MFMG_MF_EMULATE_SPLIT") && std::string(std::getenv("MFMG_MF_EMULATE_SPLIT")) == "1";
     if (emulate && op->dim() == 3)
     {
       int nt[3], rows[3];

@@ -1106,3 +1106,36 @@ def test_hierarchy_driver_example(ctx, tmp_path, dim, matrix_free, preconditione
         assert 1 <= out <= 40                    # CG iterations
     else:
         assert 0.0 < out < 0.7                   # res[20] / res[19]
+
+
+@pytest.mark.parametrize("n,material", [((140, 40, 30), "constant"), ((70, 30, 20), "linear"), ((130, 70, 12), "constant")])   # (the last: tail columns)
+def test_interior_and_shell_launches_change_no_bit(ctx, monkeypatch, n, material):
+    """A rank of a box decomposition applies its fine operator as two launches -- the tiles that read no ghost plane, and the
+    shell around them (one launch over a compact tile list, on the exchange stream beside the interior tiles).  The same
+    launches can be produced on ONE rank (MFMG_MF_EMULATE_SPLIT: the corner rank of a 2 x 2 x 2 grid, no exchange; the
+    measurement of DESIGN.md section 7 uses it): every variant -- concurrent, one after the other, the slab-by-slab launches
+    of the first box version -- must reproduce the single launch bit for bit, cycle after cycle."""
+    prob = M.LaplaceProblem(n, material, device="cuda")
+    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0}, solver={"type": "pcg", "n_iterations": 4})
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    h.set_operator_tile(2, 2, 4)          # several column, y- and z-tiles on these small meshes
+    rng = np.random.default_rng(12)
+    x0 = dev(rng.random(prob.n_dofs) * (prob.constrained.cpu().numpy() != 1))
+    b = dev(rng.random(prob.n_dofs) * (prob.constrained.cpu().numpy() != 1))
+
+    def run():
+        x = x0.clone()
+        for _ in range(3):
+            h.apply(b, x)
+        r = torch.empty_like(x)
+        h.operator_apply(0, x, r)
+        ctx.synchronize()
+        return x.clone(), r.clone()
+
+    ref = run()
+    monkeypatch.setenv("MFMG_MF_EMULATE_SPLIT", "1")
+    for variant in ("", "after", "slabs"):
+        if variant:
+            monkeypatch.setenv("MFMG_MF_SHELL", variant)
+        out = run()
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), variant or "concurrent"
