@@ -418,7 +418,7 @@ struct HipHandle
   bool owns_stream = false;
   // second stream of the overlapped halo exchange (created at first use) and its two events
   hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_packed = nullptr, ev_unpacked = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_unpacked = nullptr, ev_async = nullptr;
   bool overlap_exchange = true;
   // matrix-free operators built from this handle may keep one coefficient per cell when a cell's eight are equal
   bool allow_cell_constant = true;
@@ -598,6 +598,26 @@ struct HipHandle
     MFMG_HIP_CHECK(hipEventRecord(ev_unpacked, exchange_stream()));
     MFMG_HIP_CHECK(hipStreamWaitEvent(stream, ev_unpacked, 0));
   }
+  // A whole exchange on the exchange stream, behind what `stream` has enqueued so far; `stream` goes on and waits for it with
+  // exchange_async_wait() where it needs the ghost entries (the right-hand side of a cycle: prefetch_rhs).  In between `stream`
+  // must not read the ghost entries of `v` nor write its boundary layers.
+  void exchange_async(int space, double *v)
+  {
+    if (!comm.enabled() || space <= 0)
+      return;
+    HaloSpace &s = space_checked(space);
+    hipStream_t cs = exchange_stream();
+    if (ev_async == nullptr)
+      MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_async, hipEventDisableTiming));
+    exchange_on(s, v, stream, cs, true);
+    ++comm.n_overlapped;
+    MFMG_HIP_CHECK(hipEventRecord(ev_async, cs));
+  }
+  void exchange_async_wait()
+  {
+    if (ev_async != nullptr)
+      MFMG_HIP_CHECK(hipStreamWaitEvent(stream, ev_async, 0));
+  }
   // (one rank, measurement only: the exchange stream waits for what `stream` has enqueued so far)
   void fork_exchange_stream()
   {
@@ -674,6 +694,8 @@ struct HipHandle
       (void)hipStreamSynchronize(comm_stream);
       (void)hipEventDestroy(ev_packed);
       (void)hipEventDestroy(ev_unpacked);
+      if (ev_async)
+        (void)hipEventDestroy(ev_async);
       (void)hipStreamDestroy(comm_stream);
     }
     if (host_result)

@@ -417,9 +417,27 @@ bool HipMatrixOperator::restrict_residual(Operator<DVector> const &a, DVector co
   // distributed runs: two exchanges as in the two-step form (there: x for the residual, the residual for R) -- here x two
   // layers deep and b one layer deep
   hd.exchange(_rr_space, const_cast<double *>(x.get_values()));
-  hd.exchange(_domain_space, const_cast<double *>(b.get_values()));
+  if (_prefetched_rhs == b.get_values())
+    hd.exchange_async_wait(); // (the ghost entries of b left at the start of the cycle: prefetch_rhs)
+  else
+    hd.exchange(_domain_space, const_cast<double *>(b.get_values()));
+  _prefetched_rhs = nullptr;
   _structured->restrict_residual(x.get_values(), b.get_values(), b_coarse.get_values());
   return true;
+}
+
+// The ghost entries of the right-hand side are read by one kernel of the cycle, the restriction of the residual (the smoother
+// reads b at the DoFs a rank owns).  They are refreshed on the exchange stream at the start of the cycle, beside the
+// pre-smoother, instead of by a blocking exchange in front of that kernel.
+void HipMatrixOperator::prefetch_rhs(DVector const &b) const
+{
+  _prefetched_rhs = nullptr;
+  HipHandle &hd = _matrix->handle();
+  if (!hd.comm.enabled() || !hd.overlap_exchange || _domain_space <= 0 || !_rr_operator || !_structured ||
+      !_structured->has_residual_restriction() || b.size() != _matrix->n())
+    return;
+  hd.exchange_async(_domain_space, const_cast<double *>(b.get_values()));
+  _prefetched_rhs = b.get_values();
 }
 
 bool HipMatrixOperator::restrict_residual_f32(Operator<DVector> const &a, float const *x, float const *b, DVector &b_coarse) const

@@ -150,6 +150,10 @@ public:
       auto &level_coarse = _levels[level_index + 1];
       auto restrictor = level_coarse.get_restrictor();
 
+      // (distributed runs: the ghost entries of b, which only the restriction of the residual reads, travel beside the
+      // pre-smoother instead of in front of the restriction)
+      restrictor->prefetch_rhs(b);
+
       // pre-smoother
       auto smoother = level_fine.get_smoother();
       for (unsigned int i = 0; i < _n_smoothing_steps; ++i)

@@ -144,6 +144,7 @@ public:
   bool has_residual_restriction() const { return _rr_operator != nullptr; }
   int residual_restriction_classes() const { return _structured ? _structured->residual_restriction_classes() : 0; }
   bool restrict_residual(Operator<DVector> const &a, DVector const &x, DVector const &b, DVector &b_coarse) const override;
+  void prefetch_rhs(DVector const &b) const override;
   // the same from the FP32 vectors of the fine level of apply_f32 (one rank; sums and result in FP64)
   bool restrict_residual_f32(Operator<DVector> const &a, float const *x, float const *b, DVector &b_coarse) const;
 
@@ -154,6 +155,7 @@ private:
   std::shared_ptr<StructuredRestrictorDevice> _structured;
   std::shared_ptr<Operator<DVector> const> _rr_operator; // the fine operator the rows of R A were probed for
   int _rr_space = 0; // distributed runs: the fine space with two ghost layers refreshed per side (the 5 layers of R A)
+  mutable double const *_prefetched_rhs = nullptr; // the b whose ghost entries are travelling on the exchange stream
   mutable DeviceBuffer<double> _dinv;
 };
 
