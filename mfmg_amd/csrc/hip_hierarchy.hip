@@ -671,14 +671,17 @@ void HipMatrixFreeOperator::apply_mode(MfMode mode, double const *x, double cons
   {
     // (measurement only: the launches of the corner rank of a 2 x 2 x 2 grid -- one neighbour on the high side of every
     // axis -- without the exchange)
-    const bool emulate = std::getenv("MFMG_MF_EMULATE_SPLIT") && std::string(std::getenv("MFMG_MF_EMULATE_SPLIT")) == "1";
+    // ("1" / "xyz": 2 x 2 x 2; "yz": 1 x 2 x 2; "z": 1 x 1 x 2 -- the grids of the weak-scaling run at 8, 4 and 2 ranks)
+    const std::string emu = std::getenv("MFMG_MF_EMULATE_SPLIT") ? std::getenv("MFMG_MF_EMULATE_SPLIT") : "";
+    const bool emulate = emu == "1" || emu == "xyz" || emu == "yz" || emu == "z";
     if (emulate && op->dim() == 3)
     {
       int nt[3], rows[3];
       op->tiling(nt, rows);
       if (nt[0] >= 2 && nt[1] >= 2 && nt[2] >= 2)
       {
-        const int lo[3] = {0, 0, 0}, hi[3] = {nt[0] - 1, nt[1] - 1, nt[2] - 1};
+        const int lo[3] = {0, 0, 0};
+        const int hi[3] = {nt[0] - ((emu == "1" || emu == "xyz") ? 1 : 0), nt[1] - (emu == "z" ? 0 : 1), nt[2] - 1};
         handle.fork_exchange_stream(); // (what an exchange_begin does to the two streams, without the exchange)
         op->launch_tiles(mode, x, b, x_prev, alpha, beta, out, lo, hi, true, false);
         shell(lo, hi, nt);
