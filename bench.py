@@ -710,6 +710,28 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, M, h, prob, lmin, lmax, torch)
         if world == 1 and not args.no_extras:
             try:
+                if not assembled:
+                    # what the PARTITION of a distributed run costs a rank by itself, measured here on one GPU: the fine operator
+                    # applied with the launches of a rank that has a neighbour along z (the grid at 2 ranks), y and z (4), x, y and
+                    # z (8) -- interior tiles, the shell around them beside them on the exchange stream -- and no exchange
+                    # (MFMG_MF_EMULATE_SPLIT, read by the library at every application; same bits as the single launch)
+                    emu = {"what": "the headline cycle with the fine operator applied as a rank of 1x1x2 / 1x2x2 / 2x2x2 would (interior "
+                                   "tiles + one shell launch beside them, no exchange, nothing on the wire): ms per cycle on this GPU",
+                           "unsplit": ms_per_step}
+                    try:
+                        for grid_name in ("z", "yz", "xyz"):
+                            os.environ["MFMG_MF_EMULATE_SPLIT"] = grid_name
+                            for _ in range(3):
+                                h.apply(b, x)
+                            torch.cuda.synchronize()
+                            t_e = time.perf_counter()
+                            for _ in range(10):
+                                h.apply(b, x)
+                            torch.cuda.synchronize()
+                            emu[{"z": "1x1x2", "yz": "1x2x2", "xyz": "2x2x2"}[grid_name]] = (time.perf_counter() - t_e) / 10 * 1e3
+                    finally:
+                        os.environ.pop("MFMG_MF_EMULATE_SPLIT", None)
+                    out["distributed_launch_structure_on_one_gpu"] = emu
                 if with_f32:
                     out["vcycle_fp32_fine_level_config5"] = measure_vcycle_f32(ctx, torch, M, h, prob,
                                                                               lambda: M.MatrixFreeLaplace(ctx, prob))
