@@ -117,7 +117,13 @@ int mfmg_hip_rccl_available(void);
 int mfmg_hip_context_use_rccl(mfmg_hip_context_t ctx, const unsigned char unique_id[128]);
 int mfmg_hip_context_use_host_transport(mfmg_hip_context_t ctx, mfmg_hip_host_exchange_fn exchange,
                                         mfmg_hip_host_allreduce_fn allreduce, mfmg_hip_host_allgather_fn allgather, void *user);
-/* "rccl", "host" or "" (none) */
+/* MEASUREMENT of one rank's share of a distributed cycle on one GPU, for a hierarchy that was set up with a real transport:
+ * from this call on every message this rank sends is copied back on the device as the message it would have received, an
+ * all-gather repeats its block, an all-reduce is the identity -- all kernels, packings, stream joins and replicated levels of
+ * the partition with a wire that costs nothing (scratch/rank_cycle_on_one_gpu.py).  What the rank iterates on afterwards is
+ * not a solution of anything. */
+int mfmg_hip_context_use_reflecting_transport(mfmg_hip_context_t ctx);
+/* "rccl", "host", "reflecting" or "" (none) */
 int mfmg_hip_context_transport_name(mfmg_hip_context_t ctx, char *buffer, size_t buffer_size);
 /* exercises the registered transport: `n` doubles sent to this rank itself and back, an all-gather and sum / max
  * all-reduces over all ranks; returns the largest deviation from the known answers (0 when everything arrived) */

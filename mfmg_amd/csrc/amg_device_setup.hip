@@ -60,7 +60,11 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
   const bool verbose = std::getenv("MFMG_HIP_VERBOSE") != nullptr;
   // (one rank: the small levels too are read off from operator applications -- 0.7 s less than their host products at
   // 257^3 DoFs; many ranks: below 200000 global rows a level is gathered and the rest replicated)
-  const int64_t replicate_rows = this->_params->get("solver.amg.replicate_rows", distributed ? 200000 : 4000);
+  // (distributed default: 20 000 global rows.  With 200 000 -- the default until the end of round 3 -- a rank of the 2 x 2 x 2 run
+  // of 512^3 cells replicated the level of 65 536 global rows, whose stencils have grown to 2000 entries per row at that depth:
+  // 1.6 GB per application; measured with a wire that costs nothing (scratch/rank_cycle_on_one_gpu.py): 2.67 -> 2.40 ms per
+  // cycle and rank, for three more exchanges)
+  const int64_t replicate_rows = this->_params->get("solver.amg.replicate_rows", distributed ? 20000 : 4000);
   const int C = std::max(grid.n_components, 1);
   // aggregates: cubes of `blk` nodes (solver.amg.aggregate_block), aligned globally.  With 2 the box stencil of the
   // operators grows from level to level (reach 1, 2, 3, 5: 53, 236, 582, 1520 entries per row); with 3 -- the classic

@@ -231,6 +231,16 @@ int mfmg_hip_context_use_host_transport(mfmg_hip_context_t ctx, mfmg_hip_host_ex
   });
 }
 
+int mfmg_hip_context_use_reflecting_transport(mfmg_hip_context_t ctx)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    HaloCommunicator &c = ctx->handle->comm;
+    require(c.enabled(), "no communicator was set");
+    c.transport = make_reflecting_transport(c.n_ranks);
+  });
+}
+
 int mfmg_hip_context_transport_name(mfmg_hip_context_t ctx, char *buffer, size_t buffer_size)
 {
   return guarded([&] {

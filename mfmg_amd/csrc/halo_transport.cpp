@@ -277,7 +277,60 @@ private:
   double *_host = nullptr;
   int64_t _host_n = 0;
 };
+// One rank of a grid on its own, for MEASUREMENT of an existing hierarchy: every message this rank sends comes straight back as
+// the message it would have received (a device copy on the stream of the exchange), an all-gather repeats this rank's block, an
+// all-reduce is the identity.  Registered AFTER the hierarchy was set up with a real transport (the setup needs the real
+// neighbours), the rank then runs every kernel, packing, unpacking, stream join and replicated level of its share of a
+// distributed cycle with a wire that costs nothing -- what the partition costs by itself (scratch/rank_cycle_on_one_gpu.py).
+// The numbers it iterates on are not a solution of anything.
+class ReflectingTransport : public HaloTransport
+{
+public:
+  explicit ReflectingTransport(int n_ranks) : _n(n_ranks) {}
+  void sendrecv(int, int, double const *send_low, double *recv_low, int64_t n_low, double const *send_high, double *recv_high,
+                int64_t n_high, hipStream_t stream) override
+  {
+    if (n_low > 0)
+      MFMG_HIP_CHECK(hipMemcpyAsync(recv_low, send_low, (size_t)n_low * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    if (n_high > 0)
+      MFMG_HIP_CHECK(hipMemcpyAsync(recv_high, send_high, (size_t)n_high * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  }
+  void exchange_many(int n, int const *, double const *const *send, double *const *recv, int64_t const *count,
+                     hipStream_t stream) override
+  {
+    // (the segments of a box exchange are consecutive in the staging buffers: one copy when they are)
+    int64_t total = 0;
+    bool contiguous = n > 0;
+    for (int i = 0; i < n; ++i)
+    {
+      contiguous = contiguous && send[i] == send[0] + total && recv[i] == recv[0] + total;
+      total += count[i];
+    }
+    if (contiguous && total > 0)
+      MFMG_HIP_CHECK(hipMemcpyAsync(recv[0], send[0], (size_t)total * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    else
+      for (int i = 0; i < n; ++i)
+        if (count[i] > 0)
+          MFMG_HIP_CHECK(hipMemcpyAsync(recv[i], send[i], (size_t)count[i] * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  }
+  void allreduce(double *, int, int, hipStream_t) override {}
+  void allgather(double const *in, int64_t n, double *out, hipStream_t stream) override
+  {
+    for (int r = 0; r < _n; ++r)
+      MFMG_HIP_CHECK(hipMemcpyAsync(out + (size_t)r * n, in, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  }
+  void loopback(double const *send, double *recv, int64_t n, hipStream_t stream) override
+  {
+    MFMG_HIP_CHECK(hipMemcpyAsync(recv, send, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  }
+  char const *name() const override { return "reflecting"; }
+
+private:
+  int _n;
+};
 } // namespace
+
+std::shared_ptr<HaloTransport> make_reflecting_transport(int n_ranks) { return std::make_shared<ReflectingTransport>(n_ranks); }
 
 void rccl_available() { (void)rccl(); } // throws when librccl or one of its entry points cannot be resolved
 

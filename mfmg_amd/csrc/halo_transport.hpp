@@ -8,6 +8,7 @@
 //     else /opt/rocm/lib/librccl.so.1), so the library itself does not link against it.
 //   * HostTransport: the library stages the layers through pinned host buffers and calls the registered callbacks
 //     (gloo through torch.distributed in the tests, where several ranks share one card).
+//   * ReflectingTransport: measurement of one rank's share of a distributed cycle on one GPU (no wire).
 #pragma once
 
 #include "common.hpp"
@@ -22,4 +23,6 @@ std::shared_ptr<HaloTransport> make_rccl_transport(int rank, int n_ranks, unsign
 std::shared_ptr<HaloTransport> make_host_transport(int rank, int n_ranks, mfmg_hip_host_exchange_fn sendrecv,
                                                    mfmg_hip_host_allreduce_fn allreduce, mfmg_hip_host_allgather_fn allgather,
                                                    void *user);
+// measurement: one rank of a grid on its own, every message reflected on the device (halo_transport.cpp)
+std::shared_ptr<HaloTransport> make_reflecting_transport(int n_ranks);
 } // namespace mfmg

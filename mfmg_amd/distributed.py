@@ -343,6 +343,11 @@ class HaloTransport:
         """One halo exchange of a vector of `space` (the cycle does this by itself; for tests)."""
         check(self._lib.mfmg_hip_context_exchange(self.ctx.handle, space, v.data_ptr(), 1 if reverse else 0))
 
+    def reflect(self):
+        """MEASUREMENT: from here on the messages of this rank are mirrored on the device (no partner is involved any more):
+        its share of a distributed cycle with a wire that costs nothing.  For a hierarchy that was set up with the real transport."""
+        check(self._lib.mfmg_hip_context_use_reflecting_transport(self.ctx.handle))
+
     def n_exchanges(self) -> int:
         n = C.c_int64()
         check(self._lib.mfmg_hip_context_exchange_count(self.ctx.handle, C.byref(n)))

@@ -91,6 +91,7 @@ def load() -> C.CDLL:
         "mfmg_hip_abi_version": (C.c_int, []),
         "mfmg_hip_context_use_rccl": (C.c_int, [vp, vp]),
         "mfmg_hip_context_use_host_transport": (C.c_int, [vp, vp, vp, vp, vp]),
+        "mfmg_hip_context_use_reflecting_transport": (C.c_int, [vp]),
         "mfmg_hip_context_transport_name": (C.c_int, [vp, C.c_char_p, sz]),
         "mfmg_hip_context_exchange_count": (C.c_int, [vp, P(i64)]),
         "mfmg_hip_context_transport_selftest": (C.c_int, [vp, i64, P(dbl)]),

@@ -1,0 +1,100 @@
+"""What the PARTITION costs a rank of a box run, measured on one GPU.
+
+Eight (or gx gy gz) ranks are set up as threads of this process, each with its own context and hierarchy, messages handed over
+through in-memory mailboxes behind the host transport (the harness of tests/test_box_threads.py): the setup needs the real
+neighbours.  Then ONE rank switches to the reflecting transport (include/mfmg_hip.h: every message it sends is copied back on
+the device as the message it would have received) and runs its V-cycles alone: every kernel, packing and unpacking kernel,
+stream fork and join, the all-gather of the gathered level and its replicated work -- with a wire that costs nothing.  The
+other ranks idle meanwhile.  The same cycle on one rank of the same mesh size is timed beside it.
+
+usage: rank_cycle_on_one_gpu.py [cells_per_rank] [gx,gy,gz] [rank]        (default 128 2,2,2 0)
+       env TRACE=1: only the timed rank's cycles run after the marker (for rocprofv3 --kernel-trace)"""
+import os, sys, threading, time, json
+import numpy as np
+import torch
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import mfmg_amd as M
+from test_box_threads import Mailboxes
+
+per = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+grid = tuple(int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "2,2,2").split(","))
+timed_rank = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+n_ranks = grid[0] * grid[1] * grid[2]
+cells = tuple(per * g for g in grid)
+length = tuple(float(g) for g in grid)
+params = {"eigensolver": {"number of eigenvectors": 2}, "agglomeration": {"partitioner": "block", "nx": 2, "ny": 2, "nz": 2},
+          "smoother": {"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0, "n_smoothing_steps": 1},
+          "solver": {"type": "amg", "amg": {"smoother_degree": 1, "smoothing_range": 4.0, "n_cycles": 1, "aggregate_block": 2,
+                                            "pre_smoothing_levels": 0}},
+          "is preconditioner": False, "max levels": 2}
+material = os.environ.get("MATERIAL", "constant")
+if os.environ.get("AMG_REPLICATE_ROWS"):      # levels with fewer global rows are gathered and solved redundantly (default 200000)
+    params["solver"]["amg"]["replicate_rows"] = int(os.environ["AMG_REPLICATE_ROWS"])
+
+def cycles(ctx, h, n, steps=10, warmup=3):
+    x = torch.rand(n, dtype=torch.float64, device="cuda"); b = torch.zeros_like(x)
+    for _ in range(warmup):
+        h.apply(b, x)
+    ctx.synchronize(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        h.apply(b, x)
+    ctx.synchronize(); torch.cuda.synchronize()
+    return (time.perf_counter() - t) / steps * 1e3
+
+# ---- one rank of the same size, no partition
+ctx1 = M.Context()
+p1 = M.LaplaceProblem((per,) * 3, material, device="cuda")
+h1 = M.Hierarchy(ctx1, "HipMatrixFreeMeshEvaluator", p1, params)
+ms_single = cycles(ctx1, h1, h1.level_size(0))
+del h1, p1
+torch.cuda.empty_cache()
+
+mb = Mailboxes(n_ranks)
+errors = [None] * n_ranks
+result = {}
+ready = threading.Barrier(n_ranks, timeout=3600)
+
+def worker(rank):
+    try:
+        torch.cuda.set_device(0)
+        part = M.BoxPartition(cells, rank, grid, length=length)
+        ctx = M.Context()
+        tr = M.HaloTransport(ctx, part, callbacks=mb.callbacks(rank))
+        t0 = time.perf_counter()
+        h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", part.local_problem(material, "cuda"), params)
+        ctx.synchronize()
+        setup_s = time.perf_counter() - t0
+        ready.wait()
+        if rank == timed_rank:
+            tr.reflect()
+            e0, v0, o0 = tr.n_exchanges(), tr.exchange_volume(), tr.n_overlapped()
+            ms = cycles(ctx, h, h.level_size(0))
+            n_cyc = 13
+            result.update({"rank": rank, "grid": list(grid), "cells_per_rank": per, "local_cells": list(part.local_cells),
+                           "ms_per_cycle_rank_alone_reflecting": ms, "ms_per_cycle_one_rank_same_size": ms_single,
+                           "ratio": ms / ms_single, "exchanges_per_cycle": (tr.n_exchanges() - e0) / n_cyc,
+                           "overlapped_per_cycle": (tr.n_overlapped() - o0) / n_cyc,
+                           "mb_sent_per_cycle": (tr.exchange_volume() - v0) * 8e-6 / n_cyc, "setup_seconds_in_threads": setup_s,
+                           "gathered_from_rows": h.coarse_amg_gather_rows(), "levels": h.coarse_amg_shapes()})
+        ready.wait()
+        del h
+    except BaseException as e:  # noqa: BLE001
+        errors[rank] = e
+        mb.barrier.abort(); ready.abort()
+        for p in range(n_ranks):
+            mb.q[(rank, p)].put(np.zeros(0))
+
+threads = [threading.Thread(target=worker, args=(r,)) for r in range(n_ranks)]
+for t in threads:
+    t.start()
+for t in threads:
+    t.join()
+first = next((e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)), None) or \
+    next((e for e in errors if e is not None), None)
+if first is not None:
+    raise first
+print(json.dumps(result))
