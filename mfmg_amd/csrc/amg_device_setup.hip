@@ -291,6 +291,72 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     L.restrictor->set_spaces(0, 0);        // P^T has entries in owned fine rows only ...
     L.restrictor->set_reverse_range_space(c.space); // ... and returns the sums of ghost aggregates to their owners
     L.smoother = std::make_shared<HipSmoother>(L.a, smoother_params);
+    // ---- P~ = (I - beta D^-1 A) P for a level that runs V(0,1) with a damped-Jacobi post-smoother: the correction of such a
+    //      level is x = P x_c followed by x' = x - beta D^-1 (A x - b) = P~ x_c + beta D^-1 b.  Probing with the columns of P
+    //      themselves: the columns of coarse nodes floor((blk - 1 + 2 R) / blk) + 1 apart are disjoint, R = 2 reach the reach of
+    //      P~ in fine nodes.  ("solver.amg.smoothed_prolongation false" keeps the two steps; a hierarchy whose matrices are
+    //      rounded to float keeps them too: the rounded P~ would not be the product of the rounded matrices.)
+    static const bool smoothed_env = !(std::getenv("MFMG_AMG_SMOOTHED_PROLONGATION") && std::string(std::getenv("MFMG_AMG_SMOOTHED_PROLONGATION")) == "0");
+    // Where it pays (measured at 257^3 DoFs, one GPU, us per cycle, two steps -> one): levels whose operators are evaluated from
+    // stencil tables (4.2 M rows: 33 + 67 -> 76; 524 k: 16 + 38 -> 52) and small levels, which are bound by their launches
+    // (8192 rows: 10 + 40 -> 22); in between (65 536 rows) P~ has 488 stored entries per row where A comes from tables and P has
+    // 105: 18 + 25 -> 70, so one rank keeps the two steps there.  A distributed run takes it wherever it fits: every level
+    // saves a blocking exchange.
+    // (one rank, measured end to end: 1.677-1.702 ms per cycle with it, 1.696-1.700 without, and 0.5-0.8 s more setup: off by
+    // default there, "solver.amg.smoothed_prolongation true" switches it on for the levels named above)
+    const bool one_rank_on = this->_params->get_optional<bool>("solver.amg.smoothed_prolongation").value_or(false);
+    const bool pays = distributed || (one_rank_on && (n_f >= 262144 || n_f <= 16384));
+    if (smoothed_env && pays && level >= _amg_pre_smoothing_levels && L.smoother->coefficients().size() == 1 && !h.setup_values_float &&
+        this->_params->get("solver.amg.smoothed_prolongation", true))
+    {
+      const double t2 = wall_now();
+      const double beta = L.smoother->coefficients()[0].second;
+      const int R = 2 * g.reach;
+      // the coarse nodes a row of P~ couples to -- up to R fine nodes beyond the owned box -- must lie inside the local coarse
+      // box and inside the layers its exchange refreshes; decided collectively (a rank that skipped it would wait alone)
+      double misfit = 0.;
+      for (int d = 0; d < 3; ++d)
+      {
+        const int64_t f0 = g.s.g0(d) + g.s.own0(d), f1 = g.s.g0(d) + g.s.own0(d) + g.s.own_n(d) - 1; // owned fine nodes, global
+        const int64_t lo = std::max<int64_t>(0, f0 - R) / blk, hi = std::min<int64_t>(c.s.gn(d) - 1, (f1 + R) / blk);
+        const int64_t c_lo = c.s.g0(d), c_hi = c.s.g0(d) + c.s.dim(d) - 1;
+        const int64_t own_lo = c.s.g0(d) + c.s.own0(d), own_hi = own_lo + c.s.own_n(d) - 1;
+        if (lo < c_lo || hi > c_hi || own_lo - lo > (distributed ? c.s.width : own_lo) || hi - own_hi > (distributed ? c.s.width : hi))
+          misfit = 1.;
+      }
+      if (distributed)
+        misfit = h.allreduce_max(misfit);
+      if (misfit == 0.)
+      {
+      int period_t[3];
+      for (int d = 0; d < 3; ++d)
+        period_t[d] = (int)std::max<int64_t>(1, std::min<int64_t>((blk - 1 + 2 * R) / blk + 1, c.s.gn(d)));
+      const int n_col_t = period_t[0] * period_t[1] * period_t[2] * C;
+      DeviceBuffer<double> Yp((size_t)n_col_t * (size_t)n_f), Zt((size_t)n_col_t * (size_t)n_f);
+      for (int col = 0; col < n_col_t; ++col)
+      {
+        const int comp = col % C, oc = col / C;
+        const int phase[3] = {oc % period_t[0], (oc / period_t[0]) % period_t[1], oc / (period_t[0] * period_t[1])};
+        double *yp = Yp.data() + (size_t)col * n_f;
+        vec::select_rows(h, cdims, C, 1, c_off, period_t, phase, comp, nullptr, u_c.get_values()); // (ghost aggregates set locally)
+        p_mat->vmult(yp, u_c.get_values());
+        h.exchange(g.space, yp);
+        a_op->get_matrix()->vmult(Zt.data() + (size_t)col * n_f, yp);
+      }
+      MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
+      auto pt_smoothed = prolongator_from_probes(h, g.s, c.s, blk, R, period_t, beta, Zt.data(), nullptr, L.a->get_diagonal_inverse(), Yp.data());
+      Yp.release();
+      Zt.release();
+      L.smoothed_prolongator = std::make_shared<HipMatrixOperator>(pt_smoothed);
+      L.smoothed_prolongator->set_spaces(c.space, 0);
+      L.smoothed_beta = beta;
+      if (verbose)
+        std::fprintf(stderr, "[mfmg_hip] amg level %d: smoothed prolongator of the cycle, %d probes, %lld entries, %.2f s\n", level, n_col_t,
+                     (long long)pt_smoothed->n_nonzero_elements(), wall_now() - t2);
+      }
+      else if (verbose)
+        std::fprintf(stderr, "[mfmg_hip] amg level %d: the smoothed prolongator does not fit the ghost layers of the coarse level, two steps kept\n", level);
+    }
     _amg.push_back(std::move(L));
 
     // ---- next level

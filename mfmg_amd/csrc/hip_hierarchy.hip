@@ -295,6 +295,14 @@ void HipMatrixOperator::apply(DVector const &x, DVector &y, OperatorMode mode) c
   }
 }
 
+void HipMatrixOperator::apply_plus_scaled(DVector const &x, double const *dinv, DVector const &b, double beta, DVector &y) const
+{
+  ASSERT_THROW(x.size() == _matrix->n() && y.size() == _matrix->m() && b.size() == _matrix->m() && dinv != nullptr,
+               "vector sizes do not match the operator");
+  _matrix->handle().exchange(_domain_space, const_cast<double *>(x.get_values()));
+  _matrix->vmult_plus_scaled(y.get_values(), x.get_values(), dinv, b.get_values(), beta);
+}
+
 void HipMatrixOperator::residual(DVector const &x, DVector const &b, DVector &res) const
 {
   _matrix->handle().exchange(_domain_space, const_cast<double *>(x.get_values()));
@@ -1315,6 +1323,12 @@ void HipSolver::amg_cycle(size_t level, DVector const &b, DVector &x) const
       amg_cycle_gathered(level + 1, *L.b_coarse, *L.x_coarse);
     else
       amg_cycle(level + 1, *L.b_coarse, *L.x_coarse);
+    if (L.smoothed_prolongator)
+    {
+      // prolongation and post-smoothing in one operator (AmgLevel::smoothed_prolongator)
+      L.smoothed_prolongator->apply_plus_scaled(*L.x_coarse, L.a->get_diagonal_inverse(), b, L.smoothed_beta, x);
+      return;
+    }
     L.prolongator->apply(*L.x_coarse, *L.x_work, OperatorMode::NO_TRANS);
     L.smoother->apply_to(b, *L.x_work, x);
     return;

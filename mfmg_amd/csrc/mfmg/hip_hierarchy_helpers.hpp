@@ -145,6 +145,8 @@ public:
   int residual_restriction_classes() const { return _structured ? _structured->residual_restriction_classes() : 0; }
   bool restrict_residual(Operator<DVector> const &a, DVector const &x, DVector const &b, DVector &b_coarse) const override;
   void prefetch_rhs(DVector const &b) const override;
+  // y = A x + beta D^-1 b (x in the domain space: its ghost entries are refreshed first)
+  void apply_plus_scaled(DVector const &x, double const *dinv, DVector const &b, double beta, DVector &y) const;
   // the same from the FP32 vectors of the fine level of apply_f32 (one rank; sums and result in FP64)
   bool restrict_residual_f32(Operator<DVector> const &a, float const *x, float const *b, DVector &b_coarse) const;
 
@@ -294,6 +296,11 @@ public:
     std::shared_ptr<HipMatrixOperator> restrictor; // P^T as a matrix; its (lazy) transpose is P
     std::shared_ptr<HipMatrixOperator> prolongator;
     std::shared_ptr<HipSmoother> smoother;
+    // V(0,1) levels with a damped-Jacobi post-smoother: x = P x_c, then x' = x - beta D^-1 (A x - b), is ONE operator applied
+    // to x_c, x' = P~ x_c + beta D^-1 b with P~ = (I - beta D^-1 A) P formed at setup (amg_device_setup.hip): one launch and
+    // -- in a distributed run -- one exchange instead of two of each, and A is not applied in the cycle at all
+    std::shared_ptr<HipMatrixOperator> smoothed_prolongator;
+    double smoothed_beta = 0.;
     mutable std::shared_ptr<DVector> res, b_coarse, x_coarse, x_work;
   };
   std::vector<AmgLevel> const &amg_levels() const { return _amg; }

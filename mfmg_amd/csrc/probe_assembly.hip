@@ -135,9 +135,11 @@ struct ProlongatorGeom
   int round_to_float;
 };
 
+// (Yp != nullptr: the smoothed prolongator of the cycle, P~ = (I - w D^-1 A) P: the probes are columns of P -- Yp = P e, Z = A P e
+// -- instead of columns of the tentative prolongator, whose only entry in row i is t_i)
 template <bool FILL>
 __global__ void prolongator_rows_kernel(ProlongatorGeom g, double const *Z, double const *t, double const *dinv, int32_t *row_ptr,
-                                        int32_t *col, double *val)
+                                        int32_t *col, double *val, double const *Yp = nullptr)
 {
 #pragma clang fp contract(off) // multiply, multiply, subtract: the rounding of the host loop this replaces
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < g.n_f; i += (int64_t)gridDim.x * blockDim.x)
@@ -162,7 +164,8 @@ __global__ void prolongator_rows_kernel(ProlongatorGeom g, double const *Z, doub
             for (int comp = 0; comp < g.C; ++comp)
             {
               const double ay = Z[(size_t)(oc * g.C + comp) * (size_t)g.n_f + (size_t)i];
-              const double yi = (own_agg && comp == (int)(i % g.C)) ? t[i] : 0.;
+              const double yi = Yp != nullptr ? Yp[(size_t)(oc * g.C + comp) * (size_t)g.n_f + (size_t)i]
+                                              : ((own_agg && comp == (int)(i % g.C)) ? t[i] : 0.);
               const double v0 = yi - g.w * dinv[i] * ay;
               const double v = g.round_to_float ? (double)(float)v0 : v0;
               if (v != 0.)
@@ -394,7 +397,7 @@ std::shared_ptr<SparseMatrixDevice<double>> galerkin_from_probes(HipHandle &h, i
 
 std::shared_ptr<SparseMatrixDevice<double>> prolongator_from_probes(HipHandle &h, HaloSpace const &fine, HaloSpace const &coarse, int blk,
                                                                     int reach, int const period[3], double w, double const *Z,
-                                                                    double const *t, double const *dinv)
+                                                                    double const *t, double const *dinv, double const *Yp)
 {
   ProlongatorGeom g;
   g.round_to_float = h.setup_values_float ? 1 : 0;
@@ -418,10 +421,10 @@ std::shared_ptr<SparseMatrixDevice<double>> prolongator_from_probes(HipHandle &h
   return assemble<ProlongatorGeom>(
       h, n_f, n_c, "prolongator",
       [&](int32_t *rp) {
-        hipLaunchKernelGGL(prolongator_rows_kernel<false>, grid_for(n_f), dim3(256), 0, h.stream, g, Z, t, dinv, rp, nullptr, nullptr);
+        hipLaunchKernelGGL(prolongator_rows_kernel<false>, grid_for(n_f), dim3(256), 0, h.stream, g, Z, t, dinv, rp, nullptr, nullptr, Yp);
       },
       [&](int32_t *rp, int32_t *col, double *val) {
-        hipLaunchKernelGGL(prolongator_rows_kernel<true>, grid_for(n_f), dim3(256), 0, h.stream, g, Z, t, dinv, rp, col, val);
+        hipLaunchKernelGGL(prolongator_rows_kernel<true>, grid_for(n_f), dim3(256), 0, h.stream, g, Z, t, dinv, rp, col, val, Yp);
       });
 }
 

@@ -19,7 +19,9 @@ std::shared_ptr<SparseMatrixDevice<double>> galerkin_from_probes(HipHandle &h, i
 // halo spaces (local box, owned box, global position and size per axis; one rank: all three coincide).
 std::shared_ptr<SparseMatrixDevice<double>> prolongator_from_probes(HipHandle &h, HaloSpace const &fine, HaloSpace const &coarse, int blk,
                                                                     int reach, int const period[3], double w, double const *Z,
-                                                                    double const *t, double const *dinv);
+                                                                    double const *t, double const *dinv, double const *Yp = nullptr);
+// (Yp != nullptr: the smoothed prolongator of the cycle, P~ = (I - w D^-1 A) P, from probes with the columns of P themselves:
+// Yp[colour][row] = (P e_colour)(row), Z = A Yp; `reach` = the reach of P~ in fine nodes, twice that of A)
 
 // A_c = P^T A P: Y[colour][local coarse row] = (P^T A P u_colour)(row); rows of the owned nodes only, zeros are dropped.
 std::shared_ptr<SparseMatrixDevice<double>> coarse_operator_from_probes(HipHandle &h, HaloSpace const &coarse, int reach, int const period[3],

@@ -72,6 +72,9 @@ __device__ __forceinline__ void store_row(CsrArgs<T> const &a, int64_t row, T su
   case 4:
     o = a.out[row] - sum;
     break;
+  case 6:
+    o = sum + a.beta * a.dinv[row] * a.b[row];
+    break;
   default:
     o = a.out[row] + sum;
     break;
@@ -90,8 +93,8 @@ __device__ __forceinline__ void store_node(CsrArgs<T> const &a, int64_t node, T 
   const int64_t row0 = node * C;
   T xr[C], br[C], dr[C], pr[C], orr[C];
   const int mode = a.mode;
-  const bool need_x = mode == 2 || mode == 3, need_b = mode >= 1 && mode <= 3, need_d = need_x, need_p = mode == 3,
-             need_o = mode >= 4;
+  const bool need_x = mode == 2 || mode == 3, need_b = (mode >= 1 && mode <= 3) || mode == 6, need_d = need_x || mode == 6,
+             need_p = mode == 3, need_o = mode == 4 || mode == 5;
   if constexpr (C == 2 && sizeof(T) == 8)
   {
     if (a.pairs)
@@ -131,6 +134,9 @@ __device__ __forceinline__ void store_node(CsrArgs<T> const &a, int64_t node, T 
           break;
         case 4:
           o[rc] = orr[rc] - sum[rc];
+          break;
+        case 6:
+          o[rc] = sum[rc] + a.beta * dr[rc] * br[rc];
           break;
         default:
           o[rc] = orr[rc] + sum[rc];
@@ -176,6 +182,9 @@ __device__ __forceinline__ void store_node(CsrArgs<T> const &a, int64_t node, T 
       break;
     case 4:
       o = orr[rc] - sum[rc];
+      break;
+    case 6:
+      o = sum[rc] + a.beta * dr[rc] * br[rc];
       break;
     default:
       o = orr[rc] + sum[rc];
@@ -223,6 +232,9 @@ __global__ void csr_spmv_kernel(CsrArgs<T> a)
     }
     case 4:
       o = a.out[row] - sum;
+      break;
+    case 6:
+      o = sum + a.beta * a.dinv[row] * a.b[row];
       break;
     default:
       o = a.out[row] + sum;
@@ -309,6 +321,9 @@ __global__ void csr_spmv_lds_kernel(CsrArgs<T> a, int32_t const *blk_ptr, int32_
       }
       case 4:
         o = a.out[row] - sum;
+        break;
+      case 6:
+        o = sum + a.beta * a.dinv[row] * a.b[row];
         break;
       default:
         o = a.out[row] + sum;
@@ -404,6 +419,9 @@ __global__ __launch_bounds__(256) void bdia_spmv_kernel(CsrArgs<T> a, V const *v
   }
   case 4:
     o = a.out[row] - sum;
+    break;
+  case 6:
+    o = sum + a.beta * a.dinv[row] * a.b[row];
     break;
   default:
     o = a.out[row] + sum;
@@ -789,6 +807,9 @@ __global__ __launch_bounds__(256) void bdia_sym_spmv_kernel(CsrArgs<T> a, V cons
   }
   case 4:
     o = a.out[row] - sum;
+    break;
+  case 6:
+    o = sum + a.beta * a.dinv[row] * a.b[row];
     break;
   default:
     o = a.out[row] + sum;

@@ -18,7 +18,8 @@ enum class CsrMode : int
   first = 2,    // out = x - beta dinv (A x - b)
   next = 3,     // out = x + alpha (x - x_prev) - beta dinv (A x - b)
   subtract = 4, // out -= A x            (x.add(-1, R^T x_c), hierarchy.hpp:297-302)
-  add = 5       // out += A x
+  add = 5,      // out += A x
+  plus_scaled = 6 // out = A x + beta dinv b   (prolongation and damped-Jacobi post-smoothing of a correction in one step)
 };
 
 template <typename T>
@@ -65,6 +66,11 @@ public:
   void vmult_add(T *inout, T const *src) const
   {
     launch(CsrMode::add, src, nullptr, nullptr, nullptr, T(0), T(0), inout);
+  }
+  // dst = A src + beta dinv b (dinv, b: vectors of m() entries)
+  void vmult_plus_scaled(T *dst, T const *src, T const *dinv, T const *b, T beta) const
+  {
+    launch(CsrMode::plus_scaled, src, b, dinv, nullptr, T(0), beta, dst);
   }
   // extract_inv_diag (source/cuda/cuda_smoother.cu:86-96)
   void inverse_diagonal(T *dinv) const;

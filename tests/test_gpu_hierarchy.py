@@ -1139,3 +1139,32 @@ def test_interior_and_shell_launches_change_no_bit(ctx, monkeypatch, n, material
             monkeypatch.setenv("MFMG_MF_SHELL", variant)
         out = run()
         assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), variant or "concurrent"
+
+
+@pytest.mark.parametrize("cells", [32, 64])
+def test_smoothed_prolongation_equals_two_steps(ctx, cells):
+    """V(0,1) levels of the aggregation hierarchy with a damped-Jacobi post-smoother: prolongation and post-smoothing as ONE
+    operator, x' = P~ x_c + beta D^-1 b with P~ = (I - beta D^-1 A) P formed at setup by probing (a distributed run saves a
+    blocking exchange per level with it; one rank takes it on request).  The same cycle as the two steps, to rounding."""
+    prob = M.LaplaceProblem((cells,) * 3, "constant", device="cuda")
+    amg = {"smoother_degree": 1, "smoothing_range": 4.0, "n_cycles": 1, "pre_smoothing_levels": 0, "coarsest_size": 300}
+    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0}, solver={"type": "amg", "amg": dict(amg)})
+    h2 = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    params["solver"]["amg"]["smoothed_prolongation"] = True
+    h1 = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    rng = np.random.default_rng(5)
+    free = prob.constrained.cpu().numpy() != 1
+    x0, b = rng.random(prob.n_dofs) * free, rng.random(prob.n_dofs) * free
+    hist = []
+    for h in (h2, h1):
+        res, x = gpu_history(ctx, h, lambda y, xx: h.operator_apply(0, xx, y), b, x0, n_cycles=8)
+        hist.append((res, x))
+    np.testing.assert_allclose(hist[1][0], hist[0][0], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(hist[1][1], hist[0][1], rtol=0, atol=1e-11 * np.abs(hist[0][1]).max())
+    # ... and it is a different sequence of launches: the coarse solve of the one-step hierarchy applies no level operator
+    xc = torch.rand(h1.level_size(1), dtype=torch.float64, device="cuda")
+    y1, y2 = torch.empty_like(xc), torch.empty_like(xc)
+    h1.coarse_apply(xc, y1)
+    h2.coarse_apply(xc, y2)
+    ctx.synchronize()
+    assert relerr(y1.cpu().numpy(), y2.cpu().numpy()) < 1e-12
