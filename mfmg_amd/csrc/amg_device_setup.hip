@@ -302,10 +302,10 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     // (8192 rows: 10 + 40 -> 22); in between (65 536 rows) P~ has 488 stored entries per row where A comes from tables and P has
     // 105: 18 + 25 -> 70, so one rank keeps the two steps there.  A distributed run takes it wherever it fits: every level
     // saves a blocking exchange.
-    // (one rank, measured end to end: 1.677-1.702 ms per cycle with it, 1.696-1.700 without, and 0.5-0.8 s more setup: off by
-    // default there, "solver.amg.smoothed_prolongation true" switches it on for the levels named above)
+    // (one rank, measured end to end with all of them: 1.677-1.702 ms per cycle, 1.696-1.700 without, and 0.5-0.8 s more setup:
+    // there only the small levels take it by default -- 0.04 s of setup --, "solver.amg.smoothed_prolongation true" adds the large ones)
     const bool one_rank_on = this->_params->get_optional<bool>("solver.amg.smoothed_prolongation").value_or(false);
-    const bool pays = distributed || (one_rank_on && (n_f >= 262144 || n_f <= 16384));
+    const bool pays = distributed || n_f <= 16384 || (one_rank_on && n_f >= 262144);
     if (smoothed_env && pays && level >= _amg_pre_smoothing_levels && L.smoother->coefficients().size() == 1 && !h.setup_values_float &&
         this->_params->get("solver.amg.smoothed_prolongation", true))
     {
@@ -529,6 +529,61 @@ void HipSolver::finish_amg_replicated(std::shared_ptr<HipMatrixOperator> a_op, H
       L.prolongator = std::make_shared<HipMatrixOperator>(upload_csr(h, std::move(host_levels[l].P)));
       L.restrictor = std::dynamic_pointer_cast<HipMatrixOperator>(L.prolongator->transpose());
       L.smoother = std::make_shared<HipSmoother>(L.a, smoother_params);
+      // prolongation and post-smoothing as one operator (AmgLevel::smoothed_prolongator) on the small levels built here: P~ =
+      // (I - beta D^-1 A) P column by column -- n_c applications of P and A on the device -- and kept as CSR without its zeros.
+      // The stencils of these levels span most of the level (8192 rows of 3900 entries below a 512^3-cell mesh): P~ is hardly
+      // larger than P and the level operator, the largest matrix of the replicated part, leaves the cycle (95 + 19 -> ~25 us).
+      const int64_t nf = L.a->get_matrix()->m(), nc = L.prolongator->get_matrix()->n();
+      static const bool smoothed_env = !(std::getenv("MFMG_AMG_SMOOTHED_PROLONGATION") && std::string(std::getenv("MFMG_AMG_SMOOTHED_PROLONGATION")) == "0");
+      if (smoothed_env && (int)(first + l) >= _amg_pre_smoothing_levels && L.smoother->coefficients().size() == 1 && !h.setup_values_float &&
+          this->_params->get("solver.amg.smoothed_prolongation", true) && nf <= 16384 && nf * nc <= (int64_t(1) << 25))
+      {
+        const double beta = L.smoother->coefficients()[0].second;
+        DVector e(h, nc), y(h, nf), z(h, nf);
+        DeviceBuffer<double> dense((size_t)nf * (size_t)nc); // column j at dense[j nf ...]
+        double const *dinv = L.a->get_diagonal_inverse();
+        e = 0.;
+        const std::vector<double> unit = {1., 0.}; // (alive until the download below has synchronised the stream)
+        double const &one = unit[0], &zero = unit[1];
+        for (int64_t j = 0; j < nc; ++j)
+        {
+          MFMG_HIP_CHECK(hipMemcpyAsync(e.get_values() + j, &one, sizeof(double), hipMemcpyHostToDevice, h.stream));
+          L.prolongator->get_matrix()->vmult(y.get_values(), e.get_values());
+          L.a->get_matrix()->vmult(z.get_values(), y.get_values());
+          // column = y - beta D^-1 z  (the fused first-term epilogue of the vector kernels: out = x - beta dinv (A x - b) with A x = z, b = 0)
+          vec::scaled_pointwise<double>(h, nf, -beta, dinv, z.get_values(), z.get_values());
+          vec::sadd<double>(h, nf, 1., 1., y.get_values(), z.get_values()); // z = z + y
+          MFMG_HIP_CHECK(hipMemcpyAsync(dense.data() + (size_t)j * nf, z.get_values(), (size_t)nf * sizeof(double), hipMemcpyDeviceToDevice, h.stream));
+          MFMG_HIP_CHECK(hipMemcpyAsync(e.get_values() + j, &zero, sizeof(double), hipMemcpyHostToDevice, h.stream));
+        }
+        const std::vector<double> cols = dense.download(h.stream);
+        HostCsr pt;
+        pt.n_rows = nf;
+        pt.n_cols = nc;
+        pt.row_ptr.assign((size_t)nf + 1, 0);
+        for (int64_t i = 0; i < nf; ++i)
+        {
+          int32_t cnt = 0;
+          for (int64_t j = 0; j < nc; ++j)
+            cnt += cols[(size_t)j * nf + i] != 0. ? 1 : 0;
+          pt.row_ptr[i + 1] = pt.row_ptr[i] + cnt;
+        }
+        pt.col.resize((size_t)pt.row_ptr[nf]);
+        pt.val.resize((size_t)pt.row_ptr[nf]);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < nf; ++i)
+        {
+          int32_t p = pt.row_ptr[i];
+          for (int64_t j = 0; j < nc; ++j)
+            if (cols[(size_t)j * nf + i] != 0.)
+            {
+              pt.col[p] = (int32_t)j;
+              pt.val[p++] = cols[(size_t)j * nf + i];
+            }
+        }
+        L.smoothed_prolongator = std::make_shared<HipMatrixOperator>(upload_csr(h, std::move(pt), false));
+        L.smoothed_beta = beta;
+      }
     }
   }
   auto last = _amg.back().a->get_matrix();
