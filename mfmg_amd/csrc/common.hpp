@@ -567,7 +567,13 @@ struct HipHandle
     HaloSpace &s = space_checked(space);
     if (comm_stream == nullptr)
     {
-      MFMG_HIP_CHECK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+      {
+        // (highest priority: the packing, the transport and the shell tiles enqueued here must not queue behind the workgroups the
+        // interior launch still has to dispatch on the compute stream)
+        int pr_low = 0, pr_high = 0;
+        MFMG_HIP_CHECK(hipDeviceGetStreamPriorityRange(&pr_low, &pr_high));
+        MFMG_HIP_CHECK(hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, pr_high));
+      }
       MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming));
       MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_unpacked, hipEventDisableTiming));
     }
@@ -587,7 +593,13 @@ struct HipHandle
   {
     if (comm_stream == nullptr)
     {
-      MFMG_HIP_CHECK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+      {
+        // (highest priority: the packing, the transport and the shell tiles enqueued here must not queue behind the workgroups the
+        // interior launch still has to dispatch on the compute stream)
+        int pr_low = 0, pr_high = 0;
+        MFMG_HIP_CHECK(hipDeviceGetStreamPriorityRange(&pr_low, &pr_high));
+        MFMG_HIP_CHECK(hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, pr_high));
+      }
       MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming));
       MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_unpacked, hipEventDisableTiming));
     }
