@@ -303,9 +303,12 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     // 105: 18 + 25 -> 70, so one rank keeps the two steps there.  A distributed run takes it wherever it fits: every level
     // saves a blocking exchange.
     // (one rank, measured end to end with all of them: 1.677-1.702 ms per cycle, 1.696-1.700 without, and 0.5-0.8 s more setup:
-    // there only the small levels take it by default -- 0.04 s of setup --, "solver.amg.smoothed_prolongation true" adds the large ones)
+    // there the small levels take it by default -- 0.04 s of setup --, "solver.amg.smoothed_prolongation true" adds all large ones)
     const bool one_rank_on = this->_params->get_optional<bool>("solver.amg.smoothed_prolongation").value_or(false);
-    const bool pays = distributed || n_f <= 16384 || (one_rank_on && n_f >= 262144);
+    // (... and the largest level, >= 2 M rows: 33 + 67 -> 76 us per cycle for 0.2 s of setup; measured end to end with the small
+    // level: 1.681-1.703 -> 1.652-1.653 ms per cycle on the same box.  MFMG_AMG_SMOOTHED_LARGE=rows moves that threshold.)
+    static const int64_t large_rows = std::getenv("MFMG_AMG_SMOOTHED_LARGE") ? std::atoll(std::getenv("MFMG_AMG_SMOOTHED_LARGE")) : 2000000;
+    const bool pays = distributed || n_f <= 16384 || n_f >= large_rows || (one_rank_on && n_f >= 262144);
     if (smoothed_env && pays && level >= _amg_pre_smoothing_levels && L.smoother->coefficients().size() == 1 && !h.setup_values_float &&
         this->_params->get("solver.amg.smoothed_prolongation", true))
     {
