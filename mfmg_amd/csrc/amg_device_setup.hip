@@ -308,7 +308,12 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     // (... and the largest level, >= 2 M rows: 33 + 67 -> 76 us per cycle for 0.2 s of setup; measured end to end with the small
     // level: 1.681-1.703 -> 1.652-1.653 ms per cycle on the same box.  MFMG_AMG_SMOOTHED_LARGE=rows moves that threshold.)
     static const int64_t large_rows = std::getenv("MFMG_AMG_SMOOTHED_LARGE") ? std::atoll(std::getenv("MFMG_AMG_SMOOTHED_LARGE")) : 2000000;
-    const bool pays = distributed || n_f <= 16384 || n_f >= large_rows || (one_rank_on && n_f >= 262144);
+    // (only the first level of the hierarchy, whose operator reaches one node, and up to 8 M rows: on the global problem of
+    // BASELINE configs[3] on one GPU -- 33.5 M rows on that level -- the cycle went from 11.8 to 13.4 ms and the setup from 27 to 33 s)
+    // ... and only where the level operator repeats its stencils (a variable coefficient stores P~ entry by entry: 1 % of the cycle
+    // for 1.5 s of setup)
+    const bool large = level == 0 && g.reach == 1 && n_f >= large_rows && n_f <= (int64_t(1) << 23) && a_op->get_matrix()->stencil_classes() > 0;
+    const bool pays = distributed || n_f <= 16384 || large || (one_rank_on && n_f >= 262144);
     if (smoothed_env && pays && level >= _amg_pre_smoothing_levels && L.smoother->coefficients().size() == 1 && !h.setup_values_float &&
         this->_params->get("solver.amg.smoothed_prolongation", true))
     {
