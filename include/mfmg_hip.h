@@ -41,6 +41,7 @@ extern "C" {
  *   3  round 3: box decomposition -- mfmg_hip_host_exchange_fn (any number of partner ranks per call) replaces
  *      mfmg_hip_host_sendrecv_fn (rank -+ 1); added mfmg_hip_context_set_communicator_box, mfmg_hip_context_halo_box,
  *      mfmg_hip_context_exchange_volume
+ *      (later in round 3 added mfmg_hip_context_use_reflecting_transport: no change of the version)
  * mfmg_hip_abi_version() returns the value the loaded library was built with. */
 #define MFMG_HIP_ABI_VERSION 3
 
