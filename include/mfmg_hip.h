@@ -151,6 +151,11 @@ int mfmg_hip_context_set_cell_constant_layout(mfmg_hip_context_t ctx, int enable
  * less to read, 768 instead of 1280 B per chunk).  enable != 0: operators created afterwards keep D^-1 in the records. */
 int mfmg_hip_context_set_stored_diagonal(mfmg_hip_context_t ctx, int enable);
 int mfmg_hip_mf_laplace_diagonal_in_record(mfmg_hip_mf_laplace_t op, int *in_record);
+/* Polynomial terms of the Chebyshev smoother that ONE sweep of a matrix-free operator may run (1, 2 or 3; default 3: the whole
+ * Chebyshev(3) apply of DealIIMatrixFreeSmoother::apply, source/dealii/dealii_matrix_free_smoother.cc:63-76, reads x, b and the
+ * coefficients once).  Operators created afterwards cut their rows into chunks with that many halo columns on either side
+ * (1 = the layout of the one-term kernels, which a distributed run always takes). */
+int mfmg_hip_context_set_mf_fused_terms(mfmg_hip_context_t ctx, int n_terms);
 /* 1 when the operator kernel COMPUTES the DoF ids instead of reading them from its records: a numbering that is affine
  * on the node grid (any lexicographic one), Dirichlet DoFs on whole faces of the box, ghost DoFs on whole z-layers,
  * checked slot by slot at construction; used by the eight-coefficient kernels (where it pays).  MFMG_MF_AFFINE_IDS=0
@@ -291,6 +296,17 @@ int mfmg_hip_mf_laplace_residual(mfmg_hip_mf_laplace_t op, const double *x, cons
  * source/dealii/dealii_matrix_free_smoother.cc:63-76, one polynomial term per call) */
 int mfmg_hip_mf_laplace_smoother_step(mfmg_hip_mf_laplace_t op, const double *b, const double *x,
                                       const double *x_prev, double alpha, double beta, double *out);
+/* n_terms (2 or 3) smoother terms in one sweep: x_1 = x - beta[0] dinv (A x - b), x_s = x_{s-1} + alpha[s-1] (x_{s-1} - x_{s-2})
+ * - beta[s-1] dinv (A x_{s-1} - b); out = x_{n_terms}, out_prev (may be NULL) = x_{n_terms - 1}.  Bit for bit what n_terms calls
+ * of mfmg_hip_mf_laplace_smoother_step return.  alpha[0] must be 0; x, out and out_prev must be different vectors.
+ * MFMG_HIP_ERROR_NOT_IMPLEMENTED when the operator cannot run it (mfmg_hip_mf_laplace_sweep_available: cell-constant layout,
+ * a numbering the kernel can compute, at least n_terms halo columns, one rank). */
+int mfmg_hip_mf_laplace_sweep_available(mfmg_hip_mf_laplace_t op, int n_terms, int *available);
+int mfmg_hip_mf_laplace_smoother_sweep(mfmg_hip_mf_laplace_t op, int n_terms, const double *alpha, const double *beta,
+                                       const double *b, const double *x, double *out, double *out_prev);
+/* tile of the sweep: n_waves wavefronts of tile_y cell rows (2, 3 or 4), tile_z owned layers; 0, 0, 0 = chosen from the mesh */
+int mfmg_hip_mf_laplace_set_sweep_tile(mfmg_hip_mf_laplace_t op, int n_waves, int tile_y, int tile_z);
+int mfmg_hip_mf_laplace_get_sweep_tile(mfmg_hip_mf_laplace_t op, int n_terms, int *n_waves, int *tile_y, int *tile_z);
 /* FP32 instance of the same operator (BASELINE.json configs[4]; the coefficient table is converted once,
  * vectors are device `float`).  The cell kernel stays on the vector ALU: at ~11 flop/B it sits below the
  * FP32-MFMA ridge, so a batched-GEMM reformulation would not lift the HBM bound. */
@@ -304,6 +320,9 @@ int mfmg_hip_mf_laplace_f32_diagonal_inverse(mfmg_hip_mf_laplace_f32_t op, float
 int mfmg_hip_mf_laplace_f32_residual(mfmg_hip_mf_laplace_f32_t op, const float *x, const float *b, float *res);
 int mfmg_hip_mf_laplace_f32_smoother_step(mfmg_hip_mf_laplace_f32_t op, const float *b, const float *x,
                                           const float *x_prev, float alpha, float beta, float *out);
+int mfmg_hip_mf_laplace_f32_sweep_available(mfmg_hip_mf_laplace_f32_t op, int n_terms, int *available);
+int mfmg_hip_mf_laplace_f32_smoother_sweep(mfmg_hip_mf_laplace_f32_t op, int n_terms, const float *alpha, const float *beta,
+                                           const float *b, const float *x, float *out, float *out_prev);
 /* tuning knob: owned DoF rows / planes per workgroup tile (0 = heuristic) */
 int mfmg_hip_mf_laplace_set_tile(mfmg_hip_mf_laplace_t op, int tile_y, int tile_z);
 /* wavefronts per workgroup (1..8) stacked in y that hand their boundary sums on through LDS (0 = heuristic) */

@@ -141,6 +141,10 @@ class Context:
         """Cell-constant operators created afterwards keep D^-1 in their chunk records (default: derived in the kernel)."""
         check(self._lib.mfmg_hip_context_set_stored_diagonal(self.handle, int(bool(enable))))
 
+    def set_mf_fused_terms(self, n_terms: int):
+        """Matrix-free operators created afterwards can run up to n_terms (1..3) smoother terms per sweep (default 3)."""
+        check(self._lib.mfmg_hip_context_set_mf_fused_terms(self.handle, int(n_terms)))
+
     def set_galerkin_on_device(self, enable: bool):
         """Hierarchies created afterwards form R A R^T of a matrix-free A by probing on the device (default) or on the host."""
         check(self._lib.mfmg_hip_context_set_galerkin_on_device(self.handle, int(bool(enable))))
@@ -354,6 +358,27 @@ class MatrixFreeLaplace:
                                                           _dev_ptr(x_prev, n) if x_prev is not None else None,
                                                           alpha, beta, _dev_ptr(out, n)))
 
+    def sweep_available(self, n_terms: int) -> bool:
+        v = C.c_int()
+        check(self._lib.mfmg_hip_mf_laplace_sweep_available(self.handle, int(n_terms), C.byref(v)))
+        return bool(v.value)
+
+    def smoother_sweep(self, alpha, beta, b, x, out, out_prev=None):
+        """len(alpha) smoother terms in one sweep; out = the last iterate, out_prev (optional) the one before."""
+        n, k = self.n_dofs, len(alpha)
+        a = (C.c_double * k)(*[float(v) for v in alpha])
+        be = (C.c_double * k)(*[float(v) for v in beta])
+        check(self._lib.mfmg_hip_mf_laplace_smoother_sweep(self.handle, k, a, be, _dev_ptr(b, n), _dev_ptr(x, n), _dev_ptr(out, n),
+                                                           _dev_ptr(out_prev, n) if out_prev is not None else None))
+
+    def set_sweep_tile(self, waves: int, ty: int, tz: int):
+        check(self._lib.mfmg_hip_mf_laplace_set_sweep_tile(self.handle, waves, ty, tz))
+
+    def get_sweep_tile(self, n_terms: int):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.mfmg_hip_mf_laplace_get_sweep_tile(self.handle, int(n_terms), C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def diagonal_inverse(self) -> torch.Tensor:
         out = torch.empty(self.n_dofs, dtype=torch.float64, device="cuda")
         check(self._lib.mfmg_hip_mf_laplace_diagonal_inverse(self.handle, _dev_ptr(out)))
@@ -427,6 +452,18 @@ class MatrixFreeLaplaceF32:
         check(self._lib.mfmg_hip_mf_laplace_f32_smoother_step(self.handle, self._p(b), self._p(x),
                                                               self._p(x_prev) if x_prev is not None else None,
                                                               alpha, beta, self._p(out)))
+
+    def sweep_available(self, n_terms: int) -> bool:
+        v = C.c_int()
+        check(self._lib.mfmg_hip_mf_laplace_f32_sweep_available(self.handle, int(n_terms), C.byref(v)))
+        return bool(v.value)
+
+    def smoother_sweep(self, alpha, beta, b, x, out, out_prev=None):
+        k = len(alpha)
+        a = (C.c_float * k)(*[float(v) for v in alpha])
+        be = (C.c_float * k)(*[float(v) for v in beta])
+        check(self._lib.mfmg_hip_mf_laplace_f32_smoother_sweep(self.handle, k, a, be, self._p(b), self._p(x), self._p(out),
+                                                               self._p(out_prev) if out_prev is not None else None))
 
     def cell_constant_layout(self) -> bool:
         v = C.c_int()

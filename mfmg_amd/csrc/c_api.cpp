@@ -336,6 +336,14 @@ int mfmg_hip_context_set_stored_diagonal(mfmg_hip_context_t ctx, int enable)
     ctx->handle->stored_diagonal = enable != 0;
   });
 }
+int mfmg_hip_context_set_mf_fused_terms(mfmg_hip_context_t ctx, int n_terms)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    require(n_terms >= 1 && n_terms <= 3, "1, 2 or 3 terms per sweep");
+    ctx->handle->mf_fused_terms = n_terms;
+  });
+}
 int mfmg_hip_mf_laplace_diagonal_in_record(mfmg_hip_mf_laplace_t op, int *in_record)
 {
   return guarded([&] {
@@ -813,6 +821,39 @@ int mfmg_hip_mf_laplace_smoother_step(mfmg_hip_mf_laplace_t op, const double *b,
   });
 }
 
+int mfmg_hip_mf_laplace_sweep_available(mfmg_hip_mf_laplace_t op, int n_terms, int *available)
+{
+  return guarded([&] {
+    require(op && available, "null argument");
+    *available = op->op->fused_sweep_available(n_terms) ? 1 : 0;
+  });
+}
+int mfmg_hip_mf_laplace_smoother_sweep(mfmg_hip_mf_laplace_t op, int n_terms, const double *alpha, const double *beta,
+                                       const double *b, const double *x, double *out, double *out_prev)
+{
+  return guarded([&] {
+    require(op && alpha && beta && b && x && out, "null argument");
+    if (!op->op->fused_sweep_available(n_terms))
+      ASSERT_THROW_NOT_IMPLEMENTED("the multi-term smoother sweep is not available for this operator");
+    op->op->smoother_sweep(n_terms, alpha, beta, b, x, out, out_prev);
+  });
+}
+int mfmg_hip_mf_laplace_set_sweep_tile(mfmg_hip_mf_laplace_t op, int n_waves, int tile_y, int tile_z)
+{
+  return guarded([&] {
+    require(op != nullptr, "null operator");
+    require(n_waves >= 0 && n_waves <= 8 && tile_y >= 0 && tile_y <= 4 && tile_z >= 0 && tile_z <= 4096, "sweep tile out of range");
+    op->op->set_fused_tile(n_waves, tile_y, tile_z);
+  });
+}
+int mfmg_hip_mf_laplace_get_sweep_tile(mfmg_hip_mf_laplace_t op, int n_terms, int *n_waves, int *tile_y, int *tile_z)
+{
+  return guarded([&] {
+    require(op && n_waves && tile_y && tile_z, "null argument");
+    op->op->get_fused_tile(n_terms, *n_waves, *tile_y, *tile_z);
+  });
+}
+
 // ---- FP32 instance ----------------------------------------------------------------------
 int mfmg_hip_mf_laplace_f32_create(mfmg_hip_context_t ctx, const mfmg_hip_mesh_desc *mesh, mfmg_hip_mf_laplace_f32_t *out)
 {
@@ -854,6 +895,24 @@ int mfmg_hip_mf_laplace_f32_smoother_step(mfmg_hip_mf_laplace_f32_t op, const fl
   return guarded([&] {
     require(op && b && x && out, "null argument");
     op->op->smoother_step(b, x, x_prev, alpha, beta, out);
+  });
+}
+
+int mfmg_hip_mf_laplace_f32_sweep_available(mfmg_hip_mf_laplace_f32_t op, int n_terms, int *available)
+{
+  return guarded([&] {
+    require(op && available, "null argument");
+    *available = op->op->fused_sweep_available(n_terms) ? 1 : 0;
+  });
+}
+int mfmg_hip_mf_laplace_f32_smoother_sweep(mfmg_hip_mf_laplace_f32_t op, int n_terms, const float *alpha, const float *beta,
+                                           const float *b, const float *x, float *out, float *out_prev)
+{
+  return guarded([&] {
+    require(op && alpha && beta && b && x && out, "null argument");
+    if (!op->op->fused_sweep_available(n_terms))
+      ASSERT_THROW_NOT_IMPLEMENTED("the multi-term smoother sweep is not available for this operator");
+    op->op->smoother_sweep(n_terms, alpha, beta, b, x, out, out_prev);
   });
 }
 

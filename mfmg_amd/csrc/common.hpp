@@ -425,6 +425,9 @@ struct HipHandle
   // ... and then keep D^-1 in the chunk records (8 more bytes per DoF and smoother launch) instead of deriving it
   // in the kernel from the cell coefficients
   bool stored_diagonal = false;
+  // polynomial terms of the Chebyshev smoother that one sweep of the matrix-free operator may run (mf_cheb_fused.hip); the chunk
+  // records of operators built from this handle carry that many halo lanes (1 = one term per launch, the layout of rounds 1-3)
+  int mf_fused_terms = 3;
   // R A R^T of a matrix-free A by probing on the device (hip_hierarchy.hip, HipMatrixOperator::multiply) instead of
   // the host triple product
   bool galerkin_on_device = true;
@@ -440,8 +443,11 @@ struct HipHandle
   HaloCommunicator comm;
   // staging of the reverse (adding) exchanges and of the packed regions of a box exchange:
   // [send_low | send_high | recv_low | recv_high] resp. [send (2 segments) | recv (2 segments)], grown on demand
-  DeviceBuffer<double> halo_staging;
-  int64_t halo_staging_each = 0;
+  // One buffer per STREAM: an exchange on the exchange stream (the overlapped fine exchange, prefetch_rhs) and one on the compute
+  // stream (a rank without interior tiles, the x exchange of the residual restriction) may be in flight together, and a shared
+  // buffer let their packed regions overwrite each other.  Exchanges of one stream are ordered by the stream.
+  DeviceBuffer<double> halo_staging, halo_staging_comm;
+  int64_t halo_staging_each = 0, halo_staging_comm_each = 0;
   DeviceBuffer<double> dot_scratch; // owned entries of two box vectors, packed for a dot product
 
   HaloSpace &space_checked(int space)
@@ -452,16 +458,22 @@ struct HipHandle
       throw std::runtime_error("no halo transport was registered with the context");
     return comm.spaces[space];
   }
-  void staging_reserve(int64_t each)
+  // staging of the exchanges enqueued on `st` (grown on demand; both streams are drained before a buffer is replaced)
+  double *staging_reserve(int64_t each, hipStream_t st, int64_t &each_now)
   {
-    if (each > halo_staging_each)
+    const bool on_comm = comm_stream != nullptr && st == comm_stream;
+    DeviceBuffer<double> &buf = on_comm ? halo_staging_comm : halo_staging;
+    int64_t &have = on_comm ? halo_staging_comm_each : halo_staging_each;
+    if (each > have)
     {
       MFMG_HIP_CHECK(hipStreamSynchronize(stream));
       if (comm_stream)
         MFMG_HIP_CHECK(hipStreamSynchronize(comm_stream));
-      halo_staging.resize((size_t)4 * each);
-      halo_staging_each = each;
+      buf.resize((size_t)4 * each);
+      have = each;
     }
+    each_now = have;
+    return buf.data();
   }
   // A box exchange on `st` (forward: owner -> ghost; reverse: ghost -> owner, added): every existing neighbour at an offset
   // o in {-1, 0, 1}^3 gets one message.  Along an axis with o_d = -1 / +1 the message spans the `width` owned layers next to that
@@ -505,8 +517,8 @@ struct HipHandle
     if (own.count == 0)
       return;
     own.off[own.count] = ghost.off[own.count] = total;
-    staging_reserve((total + 1) / 2 + 1);
-    double *send = halo_staging.data(), *recv = send + 2 * halo_staging_each;
+    int64_t each = 0;
+    double *send = staging_reserve((total + 1) / 2 + 1, st, each), *recv = send + 2 * each;
     double const *send_ptr[26];
     double *recv_ptr[26];
     for (int r = 0; r < own.count; ++r)
@@ -651,10 +663,11 @@ struct HipHandle
     if (s.has_low || s.has_high)
     {
       const int64_t n = (int64_t)s.width * s.layer_elems;
-      staging_reserve(n);
+      int64_t each = 0;
+      double *staging = staging_reserve(n, stream, each);
       // the ghost layers are sent as they lie; what comes back is added to the owned boundary layers, so it is received in staging
       double const *send_low = v + (s.owned_begin - s.width) * s.layer_elems, *send_high = v + (s.owned_begin + s.owned_count) * s.layer_elems;
-      double *recv_low = halo_staging.data() + 2 * halo_staging_each, *recv_high = recv_low + halo_staging_each;
+      double *recv_low = staging + 2 * each, *recv_high = recv_low + each;
       comm.transport->sendrecv(comm.rank - comm.stride(2), comm.rank + comm.stride(2), send_low, recv_low, s.has_low ? n : 0, send_high,
                                recv_high, s.has_high ? n : 0, stream);
       ++comm.n_exchanges;

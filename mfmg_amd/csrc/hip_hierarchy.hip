@@ -798,6 +798,21 @@ void HipMatrixFreeOperator::smoother_step(DVector const &b, DVector const &x, DV
              x_prev ? x_prev->get_values() : nullptr, alpha, beta, out.get_values());
 }
 
+bool HipMatrixFreeOperator::sweep_available(int n_terms) const
+{
+  return _mesh_evaluator->get_device_operator()->fused_sweep_available(n_terms);
+}
+
+bool HipMatrixFreeOperator::smoother_sweep(int n_terms, double const *alpha, double const *beta, DVector const &b, DVector const &x,
+                                           DVector &out, DVector *out_prev) const
+{
+  auto op = _mesh_evaluator->get_device_operator();
+  if (!op->fused_sweep_available(n_terms))
+    return false;
+  op->smoother_sweep(n_terms, alpha, beta, b.get_values(), x.get_values(), out.get_values(), out_prev ? out_prev->get_values() : nullptr);
+  return true;
+}
+
 double const *HipMatrixFreeOperator::get_diagonal_inverse() const
 {
   return _mesh_evaluator->matrix_free_get_diagonal_inverse();
@@ -824,6 +839,9 @@ HipSmoother::HipSmoother(std::shared_ptr<Operator<DVector> const> op, std::share
   // the matrix-free path (source/dealii/dealii_matrix_free_smoother.cc:24)
   std::string prec_type = this->_params->get("smoother.type", matrix_free ? "Chebyshev" : "Jacobi");
   _type = to_lower(prec_type);
+  // polynomial terms per sweep over the mesh (matrix-free operator, mf_cheb_fused.hip); 1 = one launch per term
+  _fused_terms = this->_params->get("smoother.fused_terms", 3);
+  ASSERT_THROW(_fused_terms >= 1 && _fused_terms <= 3, "smoother.fused_terms must be 1, 2 or 3");
   if (_type == "jacobi")
   {
     _lambda_min = _lambda_max = 1.;
@@ -974,22 +992,76 @@ void HipSmoother::estimate_eigenvalues(int n_iterations, double residual, double
   max_est = w.back();
 }
 
+// terms [k0, d) of the polynomial, one fused kernel per term: `cur` = x_{k0}, `prev` = x_{k0 - 1} (null for k0 = 0); the last
+// term lands in x_out, the others alternate between the scratch vectors (a term may overwrite its own x_{k-1}, never its x_k)
+void HipSmoother::run_terms(int k0, DVector const &b, DVector const *cur, DVector const *prev, DVector &x_out) const
+{
+  const int d = (int)_coefficients.size();
+  for (int k = k0; k < d; ++k)
+  {
+    DVector *target = &x_out;
+    if (k + 1 < d)
+    {
+      // any scratch vector that is not x_k (x_{k-1} may be overwritten in place)
+      if (!_scratch_a)
+        _scratch_a = this->_operator->build_domain_vector();
+      target = _scratch_a.get();
+      if (target == cur)
+      {
+        if (!_scratch_b)
+          _scratch_b = this->_operator->build_domain_vector();
+        target = _scratch_b.get();
+      }
+    }
+    ASSERT_THROW(target != cur, "internal: a smoother term cannot overwrite the iterate it reads");
+    _hip_operator->smoother_step(b, *cur, prev, _coefficients[k].first, _coefficients[k].second, *target);
+    prev = cur;
+    cur = target;
+  }
+}
+
+// the first K terms in one sweep where the operator offers it: x_K -> out, x_{K-1} -> out_prev
+bool HipSmoother::run_sweep(int K, DVector const &b, DVector const &x_in, DVector &out, DVector *out_prev) const
+{
+  if (K < 2 || K > _fused_terms || !_hip_operator->sweep_available(K))
+    return false;
+  double alpha[3], beta[3];
+  for (int k = 0; k < K; ++k)
+  {
+    alpha[k] = _coefficients[k].first;
+    beta[k] = _coefficients[k].second;
+  }
+  if (alpha[0] != 0.)
+    return false;
+  return _hip_operator->smoother_sweep(K, alpha, beta, b, x_in, out, out_prev);
+}
+
 void HipSmoother::apply(DVector const &b, DVector &x) const
 {
-  // x <- x - B^{-1}(A x - b) with B^{-1} the Jacobi / Chebyshev polynomial, one fused kernel
-  // per polynomial term.  Targets alternate between two scratch vectors so that the last
-  // term lands in x (a term may overwrite its own x_{k-1}, never its x_k).
+  // x <- x - B^{-1}(A x - b) with B^{-1} the Jacobi / Chebyshev polynomial.  In place, so the last term must be a launch of
+  // its own that lands in x: the terms before it run as one sweep into the scratch vectors where the operator can (d >= 3),
+  // else one fused kernel per polynomial term.
   const int d = (int)_coefficients.size();
   if (!_scratch_a)
     _scratch_a = this->_operator->build_domain_vector();
-  if (d >= 3 && !_scratch_b)
-    _scratch_b = this->_operator->build_domain_vector();
   if (d == 1)
   {
     _hip_operator->smoother_step(b, x, nullptr, 0., _coefficients[0].second, *_scratch_a);
     x = *_scratch_a;
     return;
   }
+  if (d >= 3 && !_scratch_b)
+    _scratch_b = this->_operator->build_domain_vector();
+  if (d >= 3)
+  {
+    const int K = std::min(d - 1, _fused_terms);
+    if (K >= 2 && run_sweep(K, b, x, *_scratch_a, _scratch_b.get()))
+    {
+      run_terms(K, b, _scratch_a.get(), _scratch_b.get(), x);
+      return;
+    }
+  }
+  // term by term: x -> a -> b -> ... -> x
   std::vector<DVector *> target(d);
   target[d - 1] = &x;
   for (int k = d - 2, flip = 0; k >= 0; --k, flip ^= 1)
@@ -1019,16 +1091,37 @@ void HipSmoother::apply_zero_guess(DVector const &b, DVector &x) const
                                 _hip_operator->get_diagonal_inverse(), b.get_values(), x.get_values());
 }
 
+bool HipSmoother::prefers_out_of_place() const
+{
+  const int d = (int)_coefficients.size();
+  return d >= 2 && _fused_terms >= 2 && _hip_operator->sweep_available(std::min(d, _fused_terms));
+}
+
 void HipSmoother::apply_to(DVector const &b, DVector const &x_in, DVector &x_out) const
 {
   ASSERT_THROW(x_in.get_values() != x_out.get_values(), "apply_to needs two vectors");
-  if (_coefficients.size() == 1)
+  const int d = (int)_coefficients.size();
+  if (d == 1)
   {
     _hip_operator->smoother_step(b, x_in, nullptr, 0., _coefficients[0].second, x_out);
     return;
   }
-  x_out = x_in;
-  apply(b, x_out);
+  const int K = std::min(d, _fused_terms);
+  if (K == d && run_sweep(K, b, x_in, x_out, nullptr))
+    return;
+  if (K < d && K >= 2)
+  {
+    if (!_scratch_a)
+      _scratch_a = this->_operator->build_domain_vector();
+    if (!_scratch_b)
+      _scratch_b = this->_operator->build_domain_vector();
+    if (run_sweep(K, b, x_in, *_scratch_a, _scratch_b.get()))
+    {
+      run_terms(K, b, _scratch_a.get(), _scratch_b.get(), x_out);
+      return;
+    }
+  }
+  run_terms(0, b, &x_in, nullptr, x_out);
 }
 
 // ---- HipSolver -----------------------------------------------------------------

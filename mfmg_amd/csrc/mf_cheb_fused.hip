@@ -1,0 +1,714 @@
+// Several terms of the Chebyshev / Jacobi smoother of the matrix-free Q1 Laplace operator in ONE sweep over the mesh
+// (temporal blocking).
+//
+// What it computes, bit for bit, is what K launches of mf_laplace_kernel in its smoother modes compute
+// (source/dealii/dealii_matrix_free_smoother.cc:63-76 with the operator of tests/laplace_matrix_free.hpp:129-156):
+//   x_1 = x_0 - beta_1 D^-1 (A x_0 - b),      x_s = x_{s-1} + alpha_s (x_{s-1} - x_{s-2}) - beta_s D^-1 (A x_{s-1} - b),  s = 2 .. K
+// with x_0, b, the coefficients and the ids read ONCE and only x_K (and x_{K-1} when a further term follows) written.
+//
+// Decomposition.  A workgroup of NW wavefronts owns (64 - 2 halo) columns x (NW TY - 2K + 1) rows x TZ layers and marches
+// over the layers of its tile.  Term ("stage") s runs one cell layer behind term s - 1: in super-pass p stage 1 works on
+// the cell layer c, stage 2 on c - 1, stage 3 on c - 2; a stage completes the DoF layer with the number of its cell layer
+// (the cells below were the previous super-pass, their sums wait in registers).  A DoF of stage s is right only where its
+// whole stencil of stage s - 1 was, so the valid region shrinks by one node per stage on every side of the tile: K halo
+// lanes, rows and layers on either side are recomputed by the neighbouring tiles (owner computes, no atomics; results do
+// not depend on the tiling, bit for bit, and equal those of the one-term kernel: same cell kernel, same order of the
+// corner sums, explicit fma, contraction off).
+//
+// Where the state lives.  Everything a stage reads from the stage before is private to a LANE: its own node column
+// (the neighbour column comes by DPP from the next lane), so the planes x_{s-1} of the two node layers a stage reads sit
+// in an LDS ring of two slots per stage that only the lane itself writes and reads -- no barrier protects them.
+// b, D^-1, the cell coefficient and the momentum term of a DoF ride in registers from the super-pass that loads /
+// forms them to the later stages (shifted once per super-pass).  The only exchange between wavefronts is the one the
+// one-term kernel has: the sums of a wavefront's first and last cell row go to the neighbours below and above (one
+// barrier per stage pass), and BOTH complete the node row they share, with the same operands in the same order, so
+// that each keeps the rows of its own cells to itself.
+//
+// Memory pipeline.  Only stage 1 reads global memory: the x_0 plane two node layers ahead, b and the coefficients
+// one layer ahead are requested at the top of a super-pass and land in the ring / the registers at its end -- a whole
+// super-pass of arithmetic hides the round trip, so two wavefronts per SIMD suffice (the per-lane state costs ~200
+// VGPRs).  Dirichlet DoFs (identity rows: their recurrence involves no other DoF) are finished by stage 1 on the spot and
+// read as zero by every stage.
+//
+// Preconditions (checked on the host; anything else takes the term-by-term kernels): cell-constant layout, ids the
+// kernel can compute (AffineIds: lexicographic numbering, Dirichlet DoFs on whole faces), records with >= K halo lanes,
+// one rank.
+#include "mf_device.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <set>
+#include <string>
+#include <utility>
+
+namespace mfmg
+{
+template <typename T>
+struct MfFusedArgs
+{
+  unsigned char const *rec;
+  T const *x;  // x_0
+  T const *b;
+  T *out;      // x_K
+  T *out_prev; // x_{K-1} (nullptr: not wanted)
+  int Nx, Ny, Nz;
+  unsigned int ncols, ntiles_y, ntiles_z;
+  int own, halo;
+  int TZ; // DoF layers a z-tile owns
+  unsigned int rec_bytes;
+  int dinv_in_record;
+  T fax, fbx, fay, fby, faz, fbz, kd;
+  T alpha[3], beta[3];
+  AffineIds aff;
+  unsigned int vec_bytes, rec_total_bytes; // extents of the vectors / of the record array (descriptors; at most 2^32 - 1)
+};
+
+namespace
+{
+template <int V>
+struct IntTag
+{
+  static constexpr int value = V;
+};
+
+// ring s holds x_s: three slots where a later stage still reads the own value of the layer two below (the momentum term of
+// stage s + 2), two for the last one
+__host__ __device__ constexpr int ring_depth(int s, int K) { return s <= K - 2 ? 3 : 2; }
+__host__ __device__ constexpr int ring_planes(int K) { return K == 1 ? 2 : (K == 2 ? 5 : 8); }
+__host__ __device__ constexpr int ring_base(int s, int K) { return s == 0 ? 0 : (s == 1 ? ring_depth(0, K) : ring_depth(0, K) + ring_depth(1, K)); }
+
+// Global memory through buffer descriptors: a request is "descriptor (4 SGPRs, built once per array from the kernel
+// arguments) + uniform 32-bit byte offset (an SGPR: row and layer) + per-lane 32-bit byte offset (one VGPR, loop invariant)".
+// No 64-bit per-lane addresses: the loop optimiser otherwise keeps a 64-bit pointer per request stream in VGPRs.
+template <typename T>
+struct BufIO;
+template <>
+struct BufIO<double>
+{
+  typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ double ld(__amdgpu_buffer_rsrc_t r, unsigned int voff, unsigned int soff)
+  {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+  }
+  static __device__ __forceinline__ void st(double v, __amdgpu_buffer_rsrc_t r, unsigned int voff, unsigned int soff)
+  {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, 0);
+  }
+};
+template <>
+struct BufIO<float>
+{
+  static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned int voff, unsigned int soff)
+  {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  }
+  static __device__ __forceinline__ void st(float v, __amdgpu_buffer_rsrc_t r, unsigned int voff, unsigned int soff)
+  {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0);
+  }
+};
+
+// DBG (timing experiments only, wrong results): 1 = no barrier, 2 = no division, 3 = no global stores
+template <typename T, int K, int TY, bool DREC, int DBG = 0>
+__device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
+{
+#pragma clang fp contract(off)
+  constexpr int R = TY + 1; // node rows of a wavefront
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int NW = blockDim.x >> 6;
+  // LDS: per wavefront the rings x_0 .. x_{K-1} ([planes][R rows][64 lanes]); then the exports [2][NW][4][64]
+  T *ring = reinterpret_cast<T *>(smem_raw) + (size_t)wv * (ring_planes(K) * R * 64) + lane;
+  T *xport = reinterpret_cast<T *>(smem_raw) + (size_t)NW * (ring_planes(K) * R * 64) + lane;
+
+  // XCD-aware tile order (as mf_laplace_body): every XCD takes a contiguous run of the tile list
+  const unsigned int n_tiles = a.ncols * a.ntiles_y * a.ntiles_z;
+  unsigned int w = blockIdx.x;
+  if (n_tiles >= 64)
+  {
+    const unsigned int per_xcd = (n_tiles + 7) / 8;
+    w = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (w >= n_tiles)
+      return; // the whole workgroup leaves
+  }
+  const int tc = w % a.ncols;
+  const int tyi = (w / a.ncols) % a.ntiles_y;
+  const int tzi = w / (a.ncols * a.ntiles_y);
+
+  const int ci = tc * a.own - a.halo + lane; // node / cell column of this lane
+  const bool lane_in = ci >= 0 && ci < a.Nx;
+  const bool lane_face = ((a.aff.faces & 1) && ci == 0) || ((a.aff.faces & 2) && ci == a.Nx - 1);
+  const bool lane_free = lane_in && !lane_face;
+  const bool col_owned = lane >= a.halo && lane < a.halo + a.own && ci < a.Nx;
+  const int RY = NW * TY - 2 * K + 1;    // DoF rows a tile owns
+  const int Yw = tyi * RY - K + wv * TY; // first node row of this wavefront: node rows Yw .. Yw + TY, cell rows Yw .. Yw + TY - 1
+  const int own_y0 = tyi * RY, own_y1 = min(own_y0 + RY, a.Ny);
+  const int Z0 = tzi * a.TZ, Z1 = min(Z0 + a.TZ, a.Nz);
+  // per-lane part of an address: a 32-bit byte offset from a uniform base (lanes outside the mesh load at a clamped column;
+  // what they load is never used)
+  const unsigned int off_lane = (unsigned int)(a.aff.base + min(max(ci, 0), a.Nx - 1) * a.aff.s0) * (unsigned int)sizeof(T);
+  const unsigned int rec_lane = (unsigned int)lane * (unsigned int)sizeof(T);
+
+  // Arguments that only the epilogues and the requests need (alpha, beta, kd, the vector bases) are re-read from the kernel
+  // argument segment where they are used (scalar loads through a pointer the compiler cannot see through): held in scalar
+  // registers for the whole pass they pushed ~90 other scalars into VGPR lanes (a v_readlane / v_writelane per use).
+  typedef const __attribute__((address_space(4))) char *karg_ptr_t;
+  auto karg_T = [&](size_t off) -> T {
+    karg_ptr_t p = (karg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(p + off);
+  };
+  auto karg_ptr = [&](size_t off) -> void * {
+    karg_ptr_t p = (karg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *reinterpret_cast<void *const __attribute__((address_space(4))) *>(p + off);
+  };
+  auto k_alpha = [&](int s) { return karg_T(offsetof(MfFusedArgs<T>, alpha) + (size_t)s * sizeof(T)); };
+  auto k_beta = [&](int s) { return karg_T(offsetof(MfFusedArgs<T>, beta) + (size_t)s * sizeof(T)); };
+
+  CellFactors<T> fac;
+  fac.fx = fac.fy = fac.fz = T(0);
+  fac.fax = a.fax;
+  fac.fbx = a.fbx;
+  fac.fay = a.fay;
+  fac.fby = a.fby;
+  fac.faz = a.faz;
+  fac.fbz = a.fbz;
+
+  // wave-uniform description of the node rows, one bit per row
+  unsigned int rows_free = 0, rows_own = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+  {
+    const int j = Yw + r;
+    const bool real = j >= 0 && j < a.Ny;
+    if (real && !(((a.aff.faces & 4) && j == 0) || ((a.aff.faces & 8) && j == a.Ny - 1)))
+      rows_free |= 1u << r;
+    if (r < TY && j >= own_y0 && j < own_y1) // (the node row two wavefronts share is stored by the upper one)
+      rows_own |= 1u << r;
+  }
+  // descriptors and uniform byte offsets: node row r / node layer n of a vector (clamped into the mesh), cell row q / layer n
+  // of this chunk column's records
+  auto rs_vec = [&](size_t off) { return __builtin_amdgcn_make_buffer_rsrc(karg_ptr(off), 0, a.vec_bytes, 0x00020000); };
+  auto rs_rec_f = [&]() { return __builtin_amdgcn_make_buffer_rsrc(karg_ptr(offsetof(MfFusedArgs<T>, rec)), 0, a.rec_total_bytes, 0x00020000); };
+  const bool want_prev = a.out_prev != nullptr;
+  const unsigned int row_stride = (unsigned int)a.aff.s1 * (unsigned int)sizeof(T), layer_stride = (unsigned int)a.aff.s2 * (unsigned int)sizeof(T);
+  const unsigned int rec_row = a.ncols * a.rec_bytes;
+  const unsigned int rec_layer = (unsigned int)a.Ny * rec_row;
+  const unsigned int rec_col = (unsigned int)tc * a.rec_bytes;
+  auto layer_free = [&](int n) { return n >= 0 && n < a.Nz && !(((a.aff.faces & 16) && n == 0) || ((a.aff.faces & 32) && n == a.Nz - 1)); };
+  auto layer_own = [&](int n) { return n >= Z0 && n < Z1 && n >= a.aff.ghost_low && n < a.Nz - a.aff.ghost_high; };
+  auto vec_off = [&](int r, int n) -> unsigned int {
+    return (unsigned int)min(max(Yw + r, 0), a.Ny - 1) * row_stride + (unsigned int)min(max(n, 0), a.Nz - 1) * layer_stride;
+  };
+  auto rec_off = [&](int q, int n) -> unsigned int {
+    return rec_col + (unsigned int)min(max(n, 0), a.Nz - 1) * rec_layer + (unsigned int)min(max(Yw + q, 0), a.Ny - 1) * rec_row;
+  };
+  auto ld_coef = [&](__amdgpu_buffer_rsrc_t rs_rec, int q, int n) -> T { return BufIO<T>::ld(rs_rec, rec_lane, rec_off(q, n) + (unsigned int)Rec<T, true>::kCoefOff); };
+  auto ld_dinv = [&](__amdgpu_buffer_rsrc_t rs_rec, int r, int n) -> T { return BufIO<T>::ld(rs_rec, rec_lane, rec_off(r, n) + (unsigned int)Rec<T, true>::kDinvOff); };
+  // slot of a node layer in a ring of depth 2 / 3 (layers are >= -1 here)
+  auto slot2 = [](int n) { return n & 1; };
+  auto slot3 = [](int n) { return (int)((unsigned int)(n + 3) % 3u); };
+  auto ring_at = [&](int s, int n, int r) -> T * {
+    const int sl = ring_depth(s, K) == 3 ? slot3(n) : slot2(n);
+    return ring + ((ring_base(s, K) + sl) * R + r) * 64;
+  };
+
+  // ---- per-lane state carried from super-pass to super-pass (stage s + 1 uses entry s)
+  T bq[K][R];  // b of the DoF (row r, layer of the stage)
+  T dq[K][R];  // D^-1 likewise (entry 0 written by stage 1 / loaded from the records)
+  T cq[K][TY]; // coefficient of the cell (row q, cell layer of the stage)
+  T pt[K][R];  // z-carry of the partial sums
+  T pcs[R];    // z-carry of the coefficient sums (D^-1 on the fly)
+  T clo = T(0), chi = T(0); // coefficients of the cell rows below / above the wavefront's own, stage-1 layer (D^-1 of the shared rows)
+#pragma unroll
+  for (int s = 0; s < K; ++s)
+  {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      bq[s][r] = dq[s][r] = pt[s][r] = T(0);
+#pragma unroll
+    for (int q = 0; q < TY; ++q)
+      cq[s][q] = T(0);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    pcs[r] = T(0);
+
+  // stage s works on the cell layers start(s) .. end(s)
+  auto stage_start = [&](int s) { return max(Z0 - K + (s - 1), 0); };
+  auto stage_end = [&](int s) { return min(Z1 - 1 + (K - s), a.Nz - 1); };
+  const int cb = stage_start(1);
+
+  // ---- prologue: the two x_0 layers, b (D^-1) and the coefficients of the first super-pass
+  {
+    const __amdgpu_buffer_rsrc_t rs_x = rs_vec(offsetof(MfFusedArgs<T>, x)), rs_b = rs_vec(offsetof(MfFusedArgs<T>, b)), rs_rec = rs_rec_f();
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+    {
+      *ring_at(0, cb, r) = BufIO<T>::ld(rs_x, off_lane, vec_off(r, cb));
+      *ring_at(0, cb + 1, r) = BufIO<T>::ld(rs_x, off_lane, vec_off(r, cb + 1));
+      bq[0][r] = BufIO<T>::ld(rs_b, off_lane, vec_off(r, cb));
+      if constexpr (DREC)
+        dq[0][r] = ld_dinv(rs_rec, r, cb);
+    }
+#pragma unroll
+    for (int q = 0; q < TY; ++q)
+    {
+      const T cv = ld_coef(rs_rec, q, cb);
+      cq[0][q] = (Yw + q >= 0) ? cv : T(0);
+    }
+    if constexpr (!DREC)
+    {
+      const T l = ld_coef(rs_rec, -1, cb);
+      const T h = ld_coef(rs_rec, TY, cb);
+      clo = (Yw - 1 >= 0) ? l : T(0);
+      chi = (Yw + TY >= 0) ? h : T(0);
+    }
+  }
+
+  unsigned int ex = 0; // stage passes so far (parity of the export buffers)
+
+  // ---- one stage pass: stage S (1-based) on the cell layer c
+  auto stage_pass = [&](auto tag, int c) {
+    constexpr int S = decltype(tag)::value;
+    const bool lo_free = layer_free(c), hi_free = layer_free(c + 1);
+    const bool l_own = layer_own(c);
+    T xl[R], xu[R], xown[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+    {
+      const T l = *ring_at(S - 1, c, r), u = *ring_at(S - 1, c + 1, r);
+      xown[r] = l;
+      if constexpr (S == 1)
+      {
+        // x_0 sits in the ring as it was read; Dirichlet and out-of-mesh values enter the cells as zero
+        const bool rf = (rows_free >> r) & 1u;
+        xl[r] = (lane_free && rf && lo_free) ? l : T(0);
+        xu[r] = (lane_free && rf && hi_free) ? u : T(0);
+      }
+      else
+      {
+        xl[r] = l;
+        xu[r] = u;
+      }
+    }
+    T xln[R], xun[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+    {
+      xln[r] = from_next_lane(xl[r]);
+      xun[r] = from_next_lane(xu[r]);
+    }
+    T s00[TY], s10[TY], s01[TY], s11[TY], sx[TY];
+#pragma unroll
+    for (int q = 0; q < TY; ++q)
+    {
+      T u[8], v[8];
+      u[0] = xl[q];
+      u[1] = xln[q];
+      u[2] = xl[q + 1];
+      u[3] = xln[q + 1];
+      u[4] = xu[q];
+      u[5] = xun[q];
+      u[6] = xu[q + 1];
+      u[7] = xun[q + 1];
+      const T cv = cq[S - 1][q];
+      cell_apply_cc<T>(u, cv, fac, v);
+      // x combine: DoF column ci gets the a=0 corners of its own cell and the a=1 corners of the cell of the lane to the left
+      s00[q] = v[0] + from_prev_lane(v[1]);
+      s10[q] = v[2] + from_prev_lane(v[3]);
+      s01[q] = v[4] + from_prev_lane(v[5]);
+      s11[q] = v[6] + from_prev_lane(v[7]);
+      sx[q] = T(0);
+      if constexpr (S == 1 && !DREC)
+        sx[q] = cv + from_prev_lane(cv);
+    }
+    // the sums of the last cell row go up, those of the first go down (double-buffered by the parity of the pass)
+    {
+      T *xp = xport + (size_t)((ex & 1) * NW + wv) * 4 * 64;
+      xp[0] = s10[TY - 1];
+      xp[64] = s11[TY - 1];
+      xp[128] = s00[0];
+      xp[192] = s01[0];
+    }
+    // one DoF (row r, layer c) of this stage is complete: yv = (A x_{S-1}) there
+    auto finish = [&](auto rtag, T yv, T tcs) {
+      constexpr int r = decltype(rtag)::value;
+      const bool fr = lane_free && ((rows_free >> r) & 1u) && lo_free;
+      const bool st = col_owned && ((rows_own >> r) & 1u) && l_own;
+      if constexpr (S == 1)
+      {
+        T d;
+        if constexpr (!DREC)
+        {
+          // the eight cells of the DoF: two rows of this layer + the same of the layer below (carried)
+          const T sum8 = tcs + pcs[r];
+          pcs[r] = tcs;
+          d = DBG == 2 ? karg_T(offsetof(MfFusedArgs<T>, kd)) * sum8 : T(1) / (karg_T(offsetof(MfFusedArgs<T>, kd)) * sum8);
+          dq[0][r] = d;
+        }
+        else
+          d = dq[0][r];
+        const T x0 = xown[r], lb = bq[0][r];
+        const T x1 = fmadd<T>(-(k_beta(0) * d), yv - lb, x0);
+        if constexpr (K == 1)
+        {
+          if (st && fr)
+            BufIO<T>::st(x1, rs_vec(offsetof(MfFusedArgs<T>, out)), off_lane, vec_off(r, c));
+        }
+        else
+        {
+          *ring_at(1, c, r) = fr ? x1 : T(0);
+          if constexpr (K == 2)
+            if (st && fr && want_prev)
+              BufIO<T>::st(x1, rs_vec(offsetof(MfFusedArgs<T>, out_prev)), off_lane, vec_off(r, c));
+        }
+        // Dirichlet DoFs: identity rows with D^-1 = 1 (the stored diagonal says so too) -- the whole recurrence here
+        if (st && !fr)
+        {
+          const T dc = DREC ? d : T(1);
+          T xa = x0, xb = fmadd<T>(-(k_beta(0) * dc), x0 - lb, x0); // x_{s-1}, x_s
+#pragma unroll
+          for (int s = 1; s < K; ++s)
+          {
+            const T xn = fmadd<T>(-(k_beta(s) * dc), xb - lb, fmadd<T>(k_alpha(s), xb - xa, xb));
+            xa = xb;
+            xb = xn;
+          }
+          BufIO<T>::st(xb, rs_vec(offsetof(MfFusedArgs<T>, out)), off_lane, vec_off(r, c));
+          if (K > 1 && want_prev)
+            BufIO<T>::st(xa, rs_vec(offsetof(MfFusedArgs<T>, out_prev)), off_lane, vec_off(r, c));
+        }
+      }
+      else
+      {
+        // x_{S-1} and x_{S-2} of the DoF (zero where it is not free: the result is dropped there)
+        const T xo = xown[r];
+        const T xoo = *ring_at(S - 2, c, r);
+        const T xoo_m = (S == 2) ? ((lane_free && ((rows_free >> r) & 1u) && lo_free) ? xoo : T(0)) : xoo; // (x_0 sits in its ring unmasked)
+        const T xs = fmadd<T>(-(k_beta(S - 1) * dq[S - 1][r]), yv - bq[S - 1][r], fmadd<T>(k_alpha(S - 1), xo - xoo_m, xo));
+        if constexpr (S < K)
+        {
+          *ring_at(S, c, r) = fr ? xs : T(0);
+          if constexpr (S == K - 1)
+            if (st && fr && want_prev)
+              BufIO<T>::st(xs, rs_vec(offsetof(MfFusedArgs<T>, out_prev)), off_lane, vec_off(r, c));
+        }
+        else
+        {
+          if (st && fr)
+            BufIO<T>::st(xs, rs_vec(offsetof(MfFusedArgs<T>, out)), off_lane, vec_off(r, c));
+        }
+      }
+    };
+    // the rows between the wavefront's own cells
+    auto inner = [&](auto rtag) {
+      constexpr int r = decltype(rtag)::value;
+      const T t0 = s00[r] + s10[r - 1];
+      const T t1 = s01[r] + s11[r - 1];
+      const T yv = t0 + pt[S - 1][r];
+      pt[S - 1][r] = t1;
+      finish(rtag, yv, sx[r] + sx[r - 1]);
+    };
+    if constexpr (TY >= 2)
+      inner(IntTag<1>{});
+    if constexpr (TY >= 3)
+      inner(IntTag<2>{});
+    if constexpr (TY >= 4)
+      inner(IntTag<3>{});
+    // (LDS only: the requests of the next super-pass stay in flight across the barrier -- __syncthreads() would drain them.
+    // Tried instead: a word per wavefront that its two neighbours poll, no workgroup-wide rendezvous -- 7 % slower.)
+    if constexpr (DBG != 1)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // the rows shared with the neighbours: both wavefronts complete them, with the same operands in the same order
+    {
+      T lo0 = T(0), lo1 = T(0), hi0 = T(0), hi1 = T(0);
+      if (wv > 0)
+      {
+        T const *ip = xport + (size_t)((ex & 1) * NW + wv - 1) * 4 * 64;
+        lo0 = ip[0];
+        lo1 = ip[64];
+      }
+      if (wv + 1 < NW)
+      {
+        T const *ip = xport + (size_t)((ex & 1) * NW + wv + 1) * 4 * 64;
+        hi0 = ip[128];
+        hi1 = ip[192];
+      }
+      {
+        const T t0 = s00[0] + lo0;
+        const T t1 = s01[0] + lo1;
+        const T yv = t0 + pt[S - 1][0];
+        pt[S - 1][0] = t1;
+        T tcs = T(0);
+        if constexpr (S == 1 && !DREC)
+          tcs = sx[0] + (clo + from_prev_lane(clo));
+        finish(IntTag<0>{}, yv, tcs);
+      }
+      {
+        const T t0 = hi0 + s10[TY - 1];
+        const T t1 = hi1 + s11[TY - 1];
+        const T yv = t0 + pt[S - 1][TY];
+        pt[S - 1][TY] = t1;
+        T tcs = T(0);
+        if constexpr (S == 1 && !DREC)
+          tcs = (chi + from_prev_lane(chi)) + sx[TY - 1];
+        finish(IntTag<TY>{}, yv, tcs);
+      }
+    }
+    ++ex;
+  };
+
+  // ---- the march
+  const int c_last = stage_end(K) + (K - 1);
+  for (int c1 = cb; c1 <= c_last; ++c1)
+  {
+    // requests for the next super-pass: x_0 two node layers ahead, b (D^-1) and the coefficients one
+    T pfx[R], pfb[R], pfd[R], pfc[TY], pflo = T(0), pfhi = T(0);
+    const __amdgpu_buffer_rsrc_t rs_x = rs_vec(offsetof(MfFusedArgs<T>, x)), rs_b = rs_vec(offsetof(MfFusedArgs<T>, b)), rs_rec = rs_rec_f();
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+    {
+      pfx[r] = BufIO<T>::ld(rs_x, off_lane, vec_off(r, c1 + 2));
+      pfb[r] = BufIO<T>::ld(rs_b, off_lane, vec_off(r, c1 + 1));
+      pfd[r] = T(0);
+      if constexpr (DREC)
+        pfd[r] = ld_dinv(rs_rec, r, c1 + 1);
+    }
+#pragma unroll
+    for (int q = 0; q < TY; ++q)
+      pfc[q] = ld_coef(rs_rec, q, c1 + 1);
+    if constexpr (!DREC)
+    {
+      pflo = ld_coef(rs_rec, -1, c1 + 1);
+      pfhi = ld_coef(rs_rec, TY, c1 + 1);
+    }
+
+    if (c1 <= stage_end(1))
+      stage_pass(IntTag<1>{}, c1);
+    if constexpr (K >= 2)
+      if (c1 - 1 >= stage_start(2) && c1 - 1 <= stage_end(2))
+        stage_pass(IntTag<2>{}, c1 - 1);
+    if constexpr (K >= 3)
+      if (c1 - 2 >= stage_start(3) && c1 - 2 <= stage_end(3))
+        stage_pass(IntTag<3>{}, c1 - 2);
+
+    // shift the carried state by one stage, land the requests
+#pragma unroll
+    for (int s = K - 1; s >= 1; --s)
+    {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+      {
+        bq[s][r] = bq[s - 1][r];
+        dq[s][r] = dq[s - 1][r];
+      }
+#pragma unroll
+      for (int q = 0; q < TY; ++q)
+        cq[s][q] = cq[s - 1][q];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+    {
+      bq[0][r] = pfb[r];
+      if constexpr (DREC)
+        dq[0][r] = pfd[r];
+      *ring_at(0, c1 + 2, r) = pfx[r];
+    }
+#pragma unroll
+    for (int q = 0; q < TY; ++q)
+      cq[0][q] = (Yw + q >= 0) ? pfc[q] : T(0);
+    if constexpr (!DREC)
+    {
+      clo = (Yw - 1 >= 0) ? pflo : T(0);
+      chi = (Yw + TY >= 0) ? pfhi : T(0);
+    }
+  }
+}
+
+template <typename T, int K, int TY, bool DREC, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void mf_cheb_fused_kernel(MfFusedArgs<T> a)
+{
+  mf_cheb_fused_body<T, K, TY, DREC, DBG>(a);
+}
+} // namespace
+
+// ---- host side --------------------------------------------------------------------------------------------------
+template <typename T>
+bool MatrixFreeLaplaceDevice<T>::fused_sweep_available(int n_terms) const
+{
+  return _dim == 3 && _compact && _affine_ids && !_tail && n_terms >= 2 && n_terms <= 3 && _halo >= n_terms && !_handle.comm.enabled() &&
+         _affine.ghost_low == 0 && _affine.ghost_high == 0 && (uint64_t)_rec.size() <= 0xffffffffull;
+}
+
+// tile of the sweep: NW wavefronts of TY cell rows, TZ owned layers.  One workgroup of eight wavefronts per CU (two per
+// SIMD: the per-lane state takes ~200 VGPRs) or two of four; the height is chosen so that the workgroups fill whole
+// rounds of the chip -- a workgroup lives for K TZ + K^2 stage passes, a part-filled round costs a full one.
+template <typename T>
+void MatrixFreeLaplaceDevice<T>::choose_fused_tile(int n_terms, int &nw, int &ty, int &tz) const
+{
+  nw = 8;
+  ty = 3;
+  tz = 0;
+  static const std::string env = std::getenv("MFMG_MF_FUSED_TILE") ? std::getenv("MFMG_MF_FUSED_TILE") : "";
+  if (_fused_tile[0] > 0)
+  {
+    nw = _fused_tile[0];
+    ty = _fused_tile[1];
+    tz = _fused_tile[2];
+  }
+  else if (!env.empty())
+  {
+    int v[3] = {0, 0, 0};
+    if (std::sscanf(env.c_str(), "%d,%d,%d", &v[0], &v[1], &v[2]) == 3)
+    {
+      nw = v[0];
+      ty = v[1];
+      tz = v[2];
+    }
+  }
+  ASSERT_THROW(nw >= 1 && nw <= 8 && (ty == 2 || ty == 3 || ty == 4), "tile of the multi-term sweep: 1..8 wavefronts of 2, 3 or 4 rows");
+  const int ry = nw * ty - 2 * n_terms + 1;
+  ASSERT_THROW(ry >= 1, "tile of the multi-term sweep too small for its halo rows");
+  if (tz > 0)
+    return;
+  static const int n_cus = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      v = 256;
+    return v > 0 ? v : 256;
+  }();
+  const int64_t slots = (int64_t)n_cus * (8 / nw);
+  const int64_t tiles_xy = (int64_t)_ncols * ((_N[1] + ry - 1) / ry);
+  double best = 0.;
+  for (int nz = 1; nz <= _N[2]; ++nz)
+  {
+    const int t = (_N[2] + nz - 1) / nz;
+    if ((_N[2] + t - 1) / t != nz)
+      continue;
+    const int64_t rounds = (tiles_xy * nz + slots - 1) / slots;
+    const double cost = double(rounds) * (double(n_terms) * t + double(n_terms) * n_terms);
+    if (tz == 0 || cost < best)
+    {
+      best = cost;
+      tz = t;
+    }
+  }
+}
+
+template <typename T>
+void MatrixFreeLaplaceDevice<T>::smoother_sweep(int n_terms, T const *alpha, T const *beta, T const *b, T const *x, T *out, T *out_prev) const
+{
+  ASSERT_THROW(fused_sweep_available(n_terms), "the multi-term smoother sweep is not available for this operator");
+  ASSERT_THROW(x != nullptr && b != nullptr && out != nullptr, "null vector");
+  ASSERT_THROW(x != out && x != out_prev && out != out_prev, "the multi-term sweep cannot run in place");
+  ASSERT_THROW(alpha[0] == T(0), "the first term of a sweep takes no momentum");
+  int nw, ty, tz;
+  choose_fused_tile(n_terms, nw, ty, tz);
+  MfFusedArgs<T> a{};
+  a.rec = _rec.data();
+  a.x = x;
+  a.b = b;
+  a.out = out;
+  a.out_prev = out_prev;
+  a.Nx = _N[0];
+  a.Ny = _N[1];
+  a.Nz = _N[2];
+  a.ncols = (unsigned int)_ncols;
+  const int ry = nw * ty - 2 * n_terms + 1;
+  a.ntiles_y = (unsigned int)((_N[1] + ry - 1) / ry);
+  a.ntiles_z = (unsigned int)((_N[2] + tz - 1) / tz);
+  a.own = _own;
+  a.halo = _halo;
+  a.TZ = tz;
+  a.rec_bytes = (unsigned int)_rec_bytes;
+  a.dinv_in_record = _dinv_in_record ? 1 : 0;
+  {
+    const double vol = _h[0] * _h[1] * _h[2];
+    const double m00 = MFMG_GA * MFMG_GA + MFMG_GB * MFMG_GB, m01 = 2. * MFMG_GA * MFMG_GB;
+    const double f[3] = {vol / 8. / (_h[0] * _h[0]), vol / 8. / (_h[1] * _h[1]), vol / 8. / (_h[2] * _h[2])};
+    a.fax = T(2. * f[0] * m00);
+    a.fbx = T(2. * f[0] * m01);
+    a.fay = T(2. * f[1] * m00);
+    a.fby = T(2. * f[1] * m01);
+    a.faz = T(2. * f[2] * m00);
+    a.fbz = T(2. * f[2] * m01);
+    a.kd = T(2. * m00 * m00 * (f[0] + f[1] + f[2]));
+  }
+  for (int s = 0; s < 3; ++s)
+  {
+    a.alpha[s] = s < n_terms ? alpha[s] : T(0);
+    a.beta[s] = s < n_terms ? beta[s] : T(0);
+  }
+  a.aff = _affine;
+  a.vec_bytes = (unsigned int)std::min<uint64_t>((uint64_t)_n_dofs * sizeof(T), 0xffffffffull);
+  ASSERT_THROW((uint64_t)_rec.size() <= 0xffffffffull, "chunk records beyond 4 GiB: the multi-term sweep addresses them with 32-bit offsets");
+  a.rec_total_bytes = (unsigned int)_rec.size();
+  const uint64_t n_tiles = (uint64_t)a.ncols * a.ntiles_y * a.ntiles_z;
+  ASSERT_THROW(n_tiles < (1ull << 30), "tile of the multi-term sweep too small for this mesh (grid size limit)");
+  const unsigned int n_blocks = (unsigned int)(n_tiles >= 64 ? ((n_tiles + 7) / 8) * 8 : n_tiles);
+  const size_t lds = ((size_t)nw * ring_planes(n_terms) * (ty + 1) + (size_t)2 * nw * 4) * 64 * sizeof(T);
+  ASSERT_THROW(lds <= 160 * 1024, "tile of the multi-term sweep too large for the LDS");
+  hipStream_t st = _handle.stream;
+  // bytes the layout requires: x_0, b, the coefficient (one per cell), x_K (+ x_{K-1}); ids are computed
+  const double bytes = double(_n_dofs) * sizeof(T) * (4. + (out_prev ? 1. : 0.));
+  hipEvent_t stop = _handle.profiler.begin("mf_cheb_fused_kernel", bytes, st);
+  auto go = [&](auto kernel) {
+    static std::mutex attr_mutex;
+    static std::set<std::pair<const void *, int>> attr_set;
+    int dev = 0;
+    MFMG_HIP_CHECK(hipGetDevice(&dev));
+    {
+      std::lock_guard<std::mutex> lock(attr_mutex);
+      if (attr_set.insert({reinterpret_cast<const void *>(kernel), dev}).second)
+        MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(64 * nw), lds, st, a);
+  };
+  auto pick = [&](auto kt, auto dt) {
+    constexpr int KK = decltype(kt)::value;
+    constexpr bool DR = decltype(dt)::value != 0;
+    if (ty == 2)
+      go(mf_cheb_fused_kernel<T, KK, 2, DR>);
+    else if (ty == 3)
+      go(mf_cheb_fused_kernel<T, KK, 3, DR>);
+    else
+      go(mf_cheb_fused_kernel<T, KK, 4, DR>);
+  };
+  static const int dbg = std::getenv("MFMG_MF_FUSED_DBG") ? std::atoi(std::getenv("MFMG_MF_FUSED_DBG")) : 0;
+  if (dbg > 0 && n_terms == 3 && ty == 3 && !_dinv_in_record && std::is_same<T, double>::value)
+  {
+    if (dbg == 1)
+      go(mf_cheb_fused_kernel<T, 3, 3, false, 1>);
+    else
+      go(mf_cheb_fused_kernel<T, 3, 3, false, 2>);
+  }
+  else if (n_terms == 2)
+  {
+    if (_dinv_in_record)
+      pick(IntTag<2>{}, IntTag<1>{});
+    else
+      pick(IntTag<2>{}, IntTag<0>{});
+  }
+  else
+  {
+    if (_dinv_in_record)
+      pick(IntTag<3>{}, IntTag<1>{});
+    else
+      pick(IntTag<3>{}, IntTag<0>{});
+  }
+  MFMG_HIP_CHECK(hipGetLastError());
+  KernelProfiler::end(stop, st);
+}
+
+template bool MatrixFreeLaplaceDevice<double>::fused_sweep_available(int) const;
+template bool MatrixFreeLaplaceDevice<float>::fused_sweep_available(int) const;
+template void MatrixFreeLaplaceDevice<double>::choose_fused_tile(int, int &, int &, int &) const;
+template void MatrixFreeLaplaceDevice<float>::choose_fused_tile(int, int &, int &, int &) const;
+template void MatrixFreeLaplaceDevice<double>::smoother_sweep(int, double const *, double const *, double const *, double const *, double *,
+                                                               double *) const;
+template void MatrixFreeLaplaceDevice<float>::smoother_sweep(int, float const *, float const *, float const *, float const *, float *, float *) const;
+} // namespace mfmg

@@ -46,288 +46,12 @@
 #include <type_traits>
 #include <utility>
 
+#include "mf_device.hpp"
+
 namespace mfmg
 {
-template <typename T>
-struct MfArgs
-{
-  unsigned char const *rec;
-  T const *x;
-  T const *b;
-  T const *dinv; // by DoF id (the rows handed over between wavefronts)
-  T const *xprev;
-  T *out;
-  int Nx, Ny, Nz;
-  int TY, TZ;
-  unsigned int ncols, ntiles_y, ntiles_z; // ntiles_y, ntiles_z: y- and z-tiles of THIS launch, the first ones are ty0 and z_tile0
-  unsigned int ncols_active;              // chunk columns that get workgroups in this launch, the first one is col0 (the last
-                                          // column of the mesh may go to the tail slab)
-  unsigned int z_tile0, ty0, col0;
-  int const *ztab; // z-tile t owns the DoF layers [ztab[t], ztab[t+1]) (device array; uniform TZ or graded, see z_tiling)
-  T fx, fy, fz;
-  T fax, fbx, fay, fby, faz, fbz; // one coefficient per cell: 2 f M00, 2 f M01 per direction (M = [[2/3, 1/3], [1/3, 2/3]])
-  T kd;                           // ... and the diagonal entry of the reference cell matrix: diag = kd * sum of the 8 cell coefficients
-  T alpha, beta;
-  int mode;
-  unsigned int rec_bytes;  // bytes of one chunk record
-  int dinv_in_record;      // D^-1 is part of the record (always for eight coefficients per cell)
-  // structured numbering (AffineIds below): the kernel computes the ids instead of reading them from the records
-  AffineIds aff;
-};
-
-// n_boxes > 0: the tiles of the main part of a launch are those of up to six boxes of (column, y, z) tiles, one after the other
-// (box q: the tiles bx_end[q - 1] .. bx_end[q] - 1 of the list) -- the shell around the interior tiles of a distributed run as
-// ONE launch (launch_outside).  Consecutive workgroups take consecutive tiles of the list: the shell is spread evenly over the
-// XCDs (leaving the interior out of the full list instead gave two of the eight XCDs the whole x slab: 170 us for 30 % of the
-// tiles).  An argument of its own, not part of MfArgs: the two argument blocks of a launch are selected field by field.
-struct MfBoxes
-{
-  unsigned int n_boxes = 0;
-  unsigned int bx_end[6] = {}, bx_c0[6] = {}, bx_nc[6] = {}, bx_y0[6] = {}, bx_ny[6] = {}, bx_z0[6] = {};
-};
-
 namespace
 {
-constexpr unsigned int kFlag = 0x80000000u;  // bit 31: Dirichlet-constrained DoF (read as zero, row = identity)
-constexpr unsigned int kGhost = 0x40000000u; // bit 30: DoF owned by another rank (read normally, never written)
-constexpr unsigned int kIdMask = ~(kFlag | kGhost);
-constexpr int kOwn = 62; // DoF columns a chunk owns (lanes 1 .. 62; lanes 0 and 63 repeat the neighbours' columns)
-
-// geometry of one chunk record.  CC ("cell constant"): the eight quadrature coefficients of every cell are
-// equal (a constant or cell-wise constant material: the reference's default `material_property constant`), and
-// ONE value per cell is stored instead of eight -- 76 -> 20 bytes per cell in FP64.
-template <typename T, bool CC>
-struct Rec
-{
-  static constexpr int W = 16 / sizeof(T);                           // values per 16-byte vector
-  static constexpr int NP = 8 / W;                                    // coefficient vectors per slot
-  static constexpr size_t kCoefOff = 256;                             // after the own ids
-  static constexpr size_t kCoefBytes = CC ? 64 * sizeof(T) : (size_t)NP * 1024;
-  static constexpr size_t kDinvOff = kCoefOff + kCoefBytes;           // after the coefficients (general layout only)
-  // FP64: 4864 B general, 768 B cell-constant (1280 with D^-1).  By default the cell-constant record has no D^-1: with
-  // one coefficient per cell the diagonal of a DoF is kd * (sum of the coefficients of the eight cells around it), and the
-  // kernel forms that sum on the fly with the same lane / row / layer combines that assemble A x (8 bytes per DoF and
-  // launch less to read); mfmg_hip_context_set_stored_diagonal keeps the stored form
-  static constexpr size_t bytes(bool with_dinv) { return with_dinv ? kDinvOff + 64 * sizeof(T) : kDinvOff; }
-};
-
-
-// Gauss points of QGauss<1>(2) on [0,1]: interpolation weights S[p][i]
-#define MFMG_GA 0.78867513459481288225 // 1 - g0
-#define MFMG_GB 0.21132486540518711775 // g0
-
-// v = h-scaled G^T diag(c) G u for one Cartesian Q1 cell, sum-factorised.
-// corner m = a + 2b + 4d ; quadrature point q = qa + 2qb + 4qc
-// (FEEvaluation::evaluate / submit_gradient / integrate of
-//  tests/laplace_matrix_free.hpp:145-155).
-// Every multiply-add is written as an explicit fma and implicit contraction is off, so that a
-// cell evaluates to the same bits in whichever (peeled / unrolled) copy of the loop body it is
-// computed: a halo cell of one tile is an interior cell of its neighbour.
-template <typename T>
-__device__ __forceinline__ T fmadd(T a, T b, T c)
-{
-  return __builtin_fma(a, b, c);
-}
-template <>
-__device__ __forceinline__ float fmadd<float>(float a, float b, float c)
-{
-  return __builtin_fmaf(a, b, c);
-}
-
-// value held by the previous / next lane of the wavefront (DPP wave shift: a VALU move, no LDS
-// crossbar traffic); lanes without a source keep their own value
-__device__ __forceinline__ int dpp_from_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int dpp_from_next(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
-__device__ __forceinline__ double from_prev_lane(double v)
-{
-  return __hiloint2double(dpp_from_prev(__double2hiint(v)), dpp_from_prev(__double2loint(v)));
-}
-__device__ __forceinline__ float from_prev_lane(float v)
-{
-  return __int_as_float(dpp_from_prev(__float_as_int(v)));
-}
-__device__ __forceinline__ double from_next_lane(double v)
-{
-  return __hiloint2double(dpp_from_next(__double2hiint(v)), dpp_from_next(__double2loint(v)));
-}
-__device__ __forceinline__ float from_next_lane(float v)
-{
-  return __int_as_float(dpp_from_next(__float_as_int(v)));
-}
-
-// out[p][.] = S[p][0] in0 + S[p][1] in1 with S = [[A, B], [B, A]] and A + B = 1 (true for the Gauss
-// interpolation weights and for the 1-D mass matrix S^T S):  out0 = in1 + A (in0 - in1),  out1 = in0 - A (in0 - in1)
-// -- three instructions instead of four.
-#define MFMG_INTERP(o0, o1, i0, i1, A)                                                                       \
-  T o0, o1;                                                                                                  \
-  {                                                                                                          \
-    const T dlt = (i0) - (i1);                                                                               \
-    o0 = fmadd<T>(A, dlt, i1);                                                                               \
-    o1 = fmadd<T>(-(A), dlt, i0);                                                                            \
-  }
-// the same with both outputs scaled by a factor folded into the constants: fa = f A, fb = f B
-#define MFMG_INTERP_SCALED(o0, o1, i0, i1, fa, fb)                                                           \
-  const T o0 = fmadd<T>(fa, i0, (fb) * (i1));                                                                \
-  const T o1 = fmadd<T>(fb, i0, (fa) * (i1));
-
-template <typename T>
-__device__ __forceinline__ void direction_apply(T d00, T d10, T d01, T d11, T c00, T c10, T c01, T c11, T f,
-                                                T &X00, T &X10, T &X01, T &X11)
-{
-#pragma clang fp contract(off)
-  const T A = T(MFMG_GA);
-  // interpolate the one-sided differences d[p][r] to the 2x2 Gauss points of the two other directions
-  MFMG_INTERP(t00, t10, d00, d10, A) // t[qp][r=0]
-  MFMG_INTERP(t01, t11, d01, d11, A) // t[qp][r=1]
-  MFMG_INTERP(g00, g01, t00, t01, A) // g[qp=0][qr]
-  MFMG_INTERP(g10, g11, t10, t11, A) // g[qp=1][qr]
-  // flux, already summed over the two Gauss points of the differentiated direction; the direction factor rides along
-  const T s00 = g00 * (f * c00), s10 = g10 * (f * c10), s01 = g01 * (f * c01), s11 = g11 * (f * c11);
-  // transposed interpolation back to the corners
-  MFMG_INTERP(w00, w01, s00, s01, A) // w[qp=0][r]
-  MFMG_INTERP(w10, w11, s10, s11, A) // w[qp=1][r]
-  MFMG_INTERP(x00, x10, w00, w10, A) // x[p][r=0]
-  MFMG_INTERP(x01, x11, w01, w11, A) // x[p][r=1]
-  X00 = x00;
-  X10 = x10;
-  X01 = x01;
-  X11 = x11;
-}
-
-// The same with one coefficient per cell: the flux is a uniform scaling, so interpolation to the Gauss points
-// and back collapses into the 1-D mass matrix M = S^T S = [[A^2 + B^2, 2AB], [2AB, A^2 + B^2]] (= [[2/3, 1/3],
-// [1/3, 2/3]], the two-point rule is exact here) applied once per transverse direction.  The direction factor
-// (and the 2 of the two Gauss points of the differentiated direction) is folded into the constants of the second
-// pass (fa = 2 f 2/3, fb = 2 f 1/3, computed on the host); the coefficient multiplies the eight corner sums at the end.
-template <typename T>
-__device__ __forceinline__ void direction_apply_cc(T d00, T d10, T d01, T d11, T fa, T fb, T &X00, T &X10, T &X01, T &X11)
-{
-#pragma clang fp contract(off)
-  const T A = T(MFMG_GA * MFMG_GA + MFMG_GB * MFMG_GB);
-  MFMG_INTERP(t00, t10, d00, d10, A)            // mass matrix over p, r = 0
-  MFMG_INTERP(t01, t11, d01, d11, A)            // r = 1
-  MFMG_INTERP_SCALED(x00, x01, t00, t01, fa, fb) // mass matrix over r, p = 0
-  MFMG_INTERP_SCALED(x10, x11, t10, t11, fa, fb) // p = 1
-  X00 = x00;
-  X10 = x10;
-  X01 = x01;
-  X11 = x11;
-}
-
-template <typename T>
-struct CellFactors
-{
-  T fx, fy, fz;             // h-scaling of the three directions (eight coefficients per cell)
-  T fax, fbx, fay, fby, faz, fbz; // 2 f M00, 2 f M01 per direction (one coefficient per cell)
-};
-
-template <typename T>
-__device__ __forceinline__ void cell_apply_cc(T const u[8], T cv, CellFactors<T> const &f, T v[8])
-{
-#pragma clang fp contract(off)
-  T X00, X10, X01, X11, Y00, Y10, Y01, Y11, Z00, Z10, Z01, Z11;
-  direction_apply_cc<T>(u[1] - u[0], u[3] - u[2], u[5] - u[4], u[7] - u[6], f.fax, f.fbx, X00, X10, X01, X11);
-  direction_apply_cc<T>(u[2] - u[0], u[3] - u[1], u[6] - u[4], u[7] - u[5], f.fay, f.fby, Y00, Y10, Y01, Y11);
-  direction_apply_cc<T>(u[4] - u[0], u[5] - u[1], u[6] - u[2], u[7] - u[3], f.faz, f.fbz, Z00, Z10, Z01, Z11);
-  // corner m = a + 2b + 4d: x pairs (a): X[b][d]; y pairs (b): Y[a][d]; z pairs (d): Z[a][b]
-  v[0] = cv * ((-X00 - Y00) - Z00);
-  v[1] = cv * ((X00 - Y10) - Z10);
-  v[2] = cv * ((Y00 - X10) - Z01);
-  v[3] = cv * ((X10 + Y10) - Z11);
-  v[4] = cv * ((Z00 - X01) - Y01);
-  v[5] = cv * ((X01 - Y11) + Z10);
-  v[6] = cv * ((Y01 - X11) + Z01);
-  v[7] = cv * ((X11 + Y11) + Z11);
-}
-
-template <typename T>
-__device__ __forceinline__ void cell_apply(T const u[8], T const c[8], CellFactors<T> const &f, T v[8])
-{
-#pragma clang fp contract(off)
-  T X00, X10, X01, X11, Y00, Y10, Y01, Y11, Z00, Z10, Z01, Z11;
-  // x: differences along a, (p, r) = (b, d); coefficient pairs summed over qa
-  direction_apply<T>(u[1] - u[0], u[3] - u[2], u[5] - u[4], u[7] - u[6], c[0] + c[1], c[2] + c[3], c[4] + c[5],
-                     c[6] + c[7], f.fx, X00, X10, X01, X11);
-  // y: differences along b, (p, r) = (a, d); summed over qb
-  direction_apply<T>(u[2] - u[0], u[3] - u[1], u[6] - u[4], u[7] - u[5], c[0] + c[2], c[1] + c[3], c[4] + c[6],
-                     c[5] + c[7], f.fy, Y00, Y10, Y01, Y11);
-  // z: differences along d, (p, r) = (a, b); summed over qc
-  direction_apply<T>(u[4] - u[0], u[5] - u[1], u[6] - u[2], u[7] - u[3], c[0] + c[4], c[1] + c[5], c[2] + c[6],
-                     c[3] + c[7], f.fz, Z00, Z10, Z01, Z11);
-  v[0] = (-X00 - Y00) - Z00;
-  v[1] = (X00 - Y10) - Z10;
-  v[2] = (Y00 - X10) - Z01;
-  v[3] = (X10 + Y10) - Z11;
-  v[4] = (Z00 - X01) - Y01;
-  v[5] = (X01 - Y11) + Z10;
-  v[6] = (Y01 - X11) + Z01;
-  v[7] = (X11 + Y11) + Z11;
-}
-
-// 32-bit byte offsets from a uniform base: the global_load takes the base from SGPRs and one VGPR per
-// lane instead of a 64-bit VGPR pair per request (vectors are limited to 2^32 bytes, checked on the host)
-template <typename T>
-__device__ __forceinline__ T ld_off(T const *base, unsigned int byte_off)
-{
-  return *reinterpret_cast<T const *>(reinterpret_cast<char const *>(base) + byte_off);
-}
-template <typename T>
-__device__ __forceinline__ void st_off(T *base, unsigned int byte_off, T v)
-{
-  *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
-}
-template <typename T>
-__device__ __forceinline__ unsigned int id_off(int id)
-{
-  return ((unsigned int)id & kIdMask) * (unsigned int)sizeof(T);
-}
-// constrained DoFs read as zero (bit 31 of the id)
-template <typename T>
-__device__ __forceinline__ T masked(T x, int id)
-{
-  return (id < 0) ? T(0) : x;
-}
-
-template <typename T, bool CC>
-__device__ __forceinline__ void load_coef(unsigned char const *rec, int lane, T c[8])
-{
-  if constexpr (CC)
-  {
-    const T v = reinterpret_cast<T const *>(rec + Rec<T, true>::kCoefOff)[lane];
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      c[q] = v;
-  }
-  else
-  {
-    constexpr int W = Rec<T, false>::W;
-    using vec_t = typename std::conditional<sizeof(T) == 8, double2, float4>::type;
-#pragma unroll
-    for (int p = 0; p < Rec<T, false>::NP; ++p)
-    {
-      const vec_t v = reinterpret_cast<vec_t const *>(rec + Rec<T, false>::kCoefOff + p * 1024)[lane];
-      T const *e = reinterpret_cast<T const *>(&v);
-#pragma unroll
-      for (int w = 0; w < W; ++w)
-        c[p * W + w] = e[w];
-    }
-  }
-}
-
-// fused epilogue of one DoF: yv = (A x)_g for an unconstrained row, x0 = x_g
-template <typename T>
-__device__ __forceinline__ T mf_epilogue(MfArgs<T> const &a, int id0, T x0, T yv, T lb, T ld, T lxp)
-{
-#pragma clang fp contract(off)
-  const T ax = (id0 < 0) ? x0 : yv; // constrained rows: dst_c = src_c
-  if (a.mode == 0)
-    return ax;
-  if (a.mode == 1)
-    return ax - lb;
-  const T wgt = -(a.beta * ld);
-  const T r = ax - lb;
-  return (a.mode == 2) ? fmadd<T>(wgt, r, x0) : fmadd<T>(wgt, r, fmadd<T>(a.alpha, x0 - lxp, x0));
-}
 
 // The tile body.  There is no per-lane control flow around the cell arithmetic: every lane of every row computes a
 // cell.  What makes that legal is the data, not branches:
@@ -404,11 +128,11 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
   const int tc = c0 + w % nc;
   const int tyi = y0 + (w / nc) % ny;
   const int tzi = z0 + w / (nc * ny);
-  const int ci = tc * kOwn - 1 + lane;              // cell / DoF column of this lane
+  const int ci = tc * a.own - a.halo + lane;        // cell / DoF column of this lane
   const int Yb = tyi * (NW * TY - 1) - 1 + wv * TY; // first cell row of this wavefront
   const int Z0 = a.ztab[tzi];            // (wave-uniform index: scalar loads)
   const int TZt = a.ztab[tzi + 1] - Z0;  // layers this tile owns
-  const bool col_owned = lane >= 1 && lane <= kOwn && ci < a.Nx;
+  const bool col_owned = lane >= a.halo && lane < a.halo + a.own && ci < a.Nx;
   const int jj0 = (Yb < 0) ? 1 : 0; // cell row -1 does not exist (its sums are the zero initial carries)
   const size_t rec_row = (size_t)a.ncols * a.rec_bytes;
   const size_t rec_layer = (size_t)a.Ny * rec_row;
@@ -716,14 +440,14 @@ __global__ __launch_bounds__(512) void mf_laplace_kernel(MfArgs<T> am, MfArgs<T>
 // ---- setup kernels -----------------------------------------------------------
 // *mismatch is raised when a slot of the records does not carry the id AffineIds gives it
 __global__ void mf_affine_check_kernel(unsigned char const *rec, size_t rec_bytes, int64_t n_slots, int Nx, int Ny, int Nz, int ncols,
-                                       AffineIds f, int *mismatch)
+                                       int own, int halo, AffineIds f, int *mismatch)
 {
   for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n_slots; s += (int64_t)gridDim.x * blockDim.x)
   {
     const int lane = s & 63;
     const int64_t chunk = s >> 6;
     const int c = chunk % ncols, j = (chunk / ncols) % Ny, k = chunk / ((int64_t)ncols * Ny);
-    const int i = c * kOwn - 1 + lane;
+    const int i = c * own - halo + lane;
     if (i < 0 || i >= Nx)
       continue;
     const bool face = ((f.faces & 1) && i == 0) || ((f.faces & 2) && i == Nx - 1) || ((f.faces & 4) && j == 0) ||
@@ -737,7 +461,7 @@ __global__ void mf_affine_check_kernel(unsigned char const *rec, size_t rec_byte
 
 template <typename T, bool CC>
 __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coefficient,
-                                 uint8_t const *constrained, int Nx, int Ny, int Nz, int ncols,
+                                 uint8_t const *constrained, int Nx, int Ny, int Nz, int ncols, int own, int halo,
                                  unsigned char *rec, size_t rec_bytes, int with_dinv)
 {
   const int64_t n_slots = (int64_t)ncols * Nz * Ny * 64;
@@ -752,7 +476,7 @@ __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coeffic
     const int c = chunk % ncols;
     const int j = (chunk / ncols) % Ny;
     const int k = chunk / ((int64_t)ncols * Ny);
-    const int i = c * kOwn - 1 + lane;
+    const int i = c * own - halo + lane;
     int id[8];
     T cf[8];
     if (i < 0 || i >= Nx)
@@ -797,10 +521,10 @@ __global__ void mf_repack_kernel(int32_t const *cell_dofs, double const *coeffic
 }
 
 // chunk and lane of cell / DoF (i,j,k) (the copy owned by its column)
-__device__ __forceinline__ size_t chunk_of(int i, int j, int k, int Ny, int ncols, int &lane)
+__device__ __forceinline__ size_t chunk_of(int i, int j, int k, int Ny, int ncols, int own, int halo, int &lane)
 {
-  const int c = i / kOwn; // chunk c owns the columns kOwn c .. kOwn c + kOwn - 1 in its lanes 1 .. kOwn
-  lane = i + 1 - kOwn * c;
+  const int c = min(i / own, ncols - 1); // chunk c owns the columns own c .. own c + own - 1 in its lanes halo .. halo + own - 1
+  lane = i + halo - own * c;
   return ((size_t)k * Ny + j) * ncols + c;
 }
 
@@ -814,7 +538,7 @@ __global__ void mf_range_kernel(int32_t const *cell_dofs, int64_t n, int64_t n_d
 // Every corner (a,b,d) of real cell (i,j,k) as read from cell_dofs must be corner 0 of slot
 // (i+a,j+b,k+d): the logical-structure precondition of the tiled kernel.  Also checks the id range.
 __global__ void mf_validate_kernel(int32_t const *cell_dofs, unsigned char const *rec, size_t rec_bytes, int Nx, int Ny, int Nz, int ncols,
-                                   int64_t n_dofs, int *n_bad)
+                                   int own, int halo, int64_t n_dofs, int *n_bad)
 {
   const int nx = Nx - 1, ny = Ny - 1, nz = Nz - 1;
   const int64_t n = (int64_t)nx * ny * nz;
@@ -833,7 +557,7 @@ __global__ void mf_validate_kernel(int32_t const *cell_dofs, unsigned char const
         continue;
       }
       int lane;
-      const size_t r = chunk_of(i + (m & 1), j + ((m >> 1) & 1), k + (m >> 2), Ny, ncols, lane);
+      const size_t r = chunk_of(i + (m & 1), j + ((m >> 1) & 1), k + (m >> 2), Ny, ncols, own, halo, lane);
       if ((int)((unsigned int)reinterpret_cast<int const *>(rec + r * rec_bytes)[lane] & kIdMask) != g)
         bad = true;
     }
@@ -850,7 +574,7 @@ struct DiagTable
 // compute_diagonal (tests/laplace_matrix_free.hpp:75-98,158-199): per-cell
 // unit-vector applies summed per DoF; constrained entries set to one.
 template <typename T, bool CC>
-__global__ void mf_diagonal_kernel(unsigned char const *rec, size_t rec_bytes, int Nx, int Ny, int Nz, int ncols,
+__global__ void mf_diagonal_kernel(unsigned char const *rec, size_t rec_bytes, int Nx, int Ny, int Nz, int ncols, int own, int halo,
                                    DiagTable tab, T *diag, T *dinv)
 {
   const int64_t n = (int64_t)Nx * Ny * Nz;
@@ -861,7 +585,7 @@ __global__ void mf_diagonal_kernel(unsigned char const *rec, size_t rec_bytes, i
     const int j = (t / Nx) % Ny;
     const int k = t / ((int64_t)Nx * Ny);
     int lane;
-    const size_t r = chunk_of(i, j, k, Ny, ncols, lane);
+    const size_t r = chunk_of(i, j, k, Ny, ncols, own, halo, lane);
     const int id0 = reinterpret_cast<int const *>(rec + r * rec_bytes)[lane];
     double sum = 0.;
     for (int m = 0; m < 8; ++m)
@@ -871,7 +595,7 @@ __global__ void mf_diagonal_kernel(unsigned char const *rec, size_t rec_bytes, i
         continue;
       T c[8];
       int cl;
-      const size_t cr = chunk_of(ci, cj, ck, Ny, ncols, cl);
+      const size_t cr = chunk_of(ci, cj, ck, Ny, ncols, own, halo, cl);
       load_coef<T, CC>(rec + cr * rec_bytes, cl, c);
       for (int q = 0; q < 8; ++q)
         sum += (double)c[q] * tab.K[q][m];
@@ -899,7 +623,7 @@ __global__ void mf_cell_constant_kernel(double const *coefficient, int64_t n_cel
 
 // copy of D^-1 in slot order inside the records (every slot of a real DoF, the duplicated halo slots too)
 template <typename T, bool CC>
-__global__ void mf_fill_dinv_kernel(T const *dinv, int Nx, int ncols, int64_t n_slots,
+__global__ void mf_fill_dinv_kernel(T const *dinv, int Nx, int ncols, int own, int halo, int64_t n_slots,
                                     unsigned char *rec, size_t rec_bytes)
 {
   for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n_slots;
@@ -907,7 +631,7 @@ __global__ void mf_fill_dinv_kernel(T const *dinv, int Nx, int ncols, int64_t n_
   {
     const int lane = s & 63;
     const int64_t chunk = s >> 6;
-    const int i = (int)(chunk % ncols) * kOwn - 1 + lane;
+    const int i = (int)(chunk % ncols) * own - halo + lane;
     if (i < 0 || i >= Nx)
       continue;
     unsigned char *r = rec + (size_t)chunk * rec_bytes;
@@ -1128,9 +852,6 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
     co = co_tmp.data();
     cn = cn_tmp.data();
   }
-  _ncols = (_N[0] + kOwn - 1) / kOwn;
-  const size_t n_slots = (size_t)_ncols * _N[2] * _N[1] * 64;
-  _n_slots = n_slots;
   _diag.resize(nd);
   _dinv.resize(nd);
 
@@ -1142,6 +863,23 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
                      bad.data());
   MFMG_HIP_CHECK(hipGetLastError());
   _compact = allow_compact && bad.download(st)[0] == 0;
+  // Chunk geometry.  One halo lane on either side (62 owned columns, the tail columns of a 2^k + 1 wide row as a rotated slab)
+  // serves the kernels that run one polynomial term per launch; the multi-term sweep (mf_cheb_fused.hip) needs as many halo lanes
+  // as it runs terms, and then every chunk owns the same number of columns (no tail slab: 257 columns = 5 chunks of 52).
+  // Distributed runs, the slab operator and eight coefficients per cell keep the one-lane geometry (their smoother runs term by term).
+  _halo = (sub_mesh || handle.comm.enabled() || !_compact) ? 1 : std::min(std::max(handle.mf_fused_terms, 1), 3);
+  if (_halo == 1)
+  {
+    _own = 62;
+    _ncols = (_N[0] + _own - 1) / _own;
+  }
+  else
+  {
+    _ncols = (_N[0] + (64 - 2 * _halo) - 1) / (64 - 2 * _halo);
+    _own = (_N[0] + _ncols - 1) / _ncols;
+  }
+  const size_t n_slots = (size_t)_ncols * _N[2] * _N[1] * 64;
+  _n_slots = n_slots;
   _dinv_in_record = !_compact || handle.stored_diagonal;
   _rec_bytes = _compact ? Rec<T, true>::bytes(_dinv_in_record) : Rec<T, false>::bytes(true);
   _rec.resize((n_slots / 64) * _rec_bytes);
@@ -1153,15 +891,15 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
                                          "order (DoF ids out of range)");
   if (_compact)
     hipLaunchKernelGGL((mf_repack_kernel<T, true>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, cd,
-                       co, cn, _N[0], _N[1], _N[2], _ncols, _rec.data(), _rec_bytes, _dinv_in_record ? 1 : 0);
+                       co, cn, _N[0], _N[1], _N[2], _ncols, _own, _halo, _rec.data(), _rec_bytes, _dinv_in_record ? 1 : 0);
   else
     hipLaunchKernelGGL((mf_repack_kernel<T, false>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, cd,
-                       co, cn, _N[0], _N[1], _N[2], _ncols, _rec.data(), _rec_bytes, _dinv_in_record ? 1 : 0);
+                       co, cn, _N[0], _N[1], _N[2], _ncols, _own, _halo, _rec.data(), _rec_bytes, _dinv_in_record ? 1 : 0);
   MFMG_HIP_CHECK(hipGetLastError());
 
   MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
   hipLaunchKernelGGL(mf_validate_kernel, dim3(n_blocks_for(nc, 256, 1 << 16)), dim3(256), 0, st, cd,
-                     _rec.data(), _rec_bytes, _N[0], _N[1], _N[2], _ncols, _n_dofs,
+                     _rec.data(), _rec_bytes, _N[0], _N[1], _N[2], _ncols, _own, _halo, _n_dofs,
                      bad.data());
   MFMG_HIP_CHECK(hipGetLastError());
   int n_bad = bad.download(st)[0];
@@ -1174,10 +912,10 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
     if (!(env && std::string(env) == "0") && _N[0] >= 3 && _N[1] >= 3 && _N[2] >= 3)
     {
       auto slot_id = [&](int i, int j, int k) {
-        const int c = i / kOwn;
+        const int c = std::min(i / _own, _ncols - 1);
         const int64_t chunk = c + (int64_t)_ncols * (j + (int64_t)_N[1] * k);
         int v = 0;
-        MFMG_HIP_CHECK(hipMemcpyAsync(&v, _rec.data() + (size_t)chunk * _rec_bytes + (size_t)(i + 1 - kOwn * c) * sizeof(int), sizeof(int),
+        MFMG_HIP_CHECK(hipMemcpyAsync(&v, _rec.data() + (size_t)chunk * _rec_bytes + (size_t)(i + _halo - _own * c) * sizeof(int), sizeof(int),
                                       hipMemcpyDeviceToHost, st));
         MFMG_HIP_CHECK(hipStreamSynchronize(st));
         return (unsigned int)v;
@@ -1199,7 +937,7 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
         ++f.ghost_high;
       MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
       hipLaunchKernelGGL(mf_affine_check_kernel, dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, _rec.data(), _rec_bytes,
-                         (int64_t)n_slots, _N[0], _N[1], _N[2], _ncols, f, bad.data());
+                         (int64_t)n_slots, _N[0], _N[1], _N[2], _ncols, _own, _halo, f, bad.data());
       MFMG_HIP_CHECK(hipGetLastError());
       _affine_ids = bad.download(st)[0] == 0;
       _affine = f;
@@ -1234,17 +972,17 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   if (_compact)
   {
     hipLaunchKernelGGL((mf_diagonal_kernel<T, true>), dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
-                       _rec.data(), _rec_bytes, _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
+                       _rec.data(), _rec_bytes, _N[0], _N[1], _N[2], _ncols, _own, _halo, tab, _diag.data(), _dinv.data());
     if (_dinv_in_record)
       hipLaunchKernelGGL((mf_fill_dinv_kernel<T, true>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st,
-                         _dinv.data(), _N[0], _ncols, (int64_t)n_slots, _rec.data(), _rec_bytes);
+                         _dinv.data(), _N[0], _ncols, _own, _halo, (int64_t)n_slots, _rec.data(), _rec_bytes);
   }
   else
   {
     hipLaunchKernelGGL((mf_diagonal_kernel<T, false>), dim3(n_blocks_for(nd, 256, 1 << 16)), dim3(256), 0, st,
-                       _rec.data(), _rec_bytes, _N[0], _N[1], _N[2], _ncols, tab, _diag.data(), _dinv.data());
+                       _rec.data(), _rec_bytes, _N[0], _N[1], _N[2], _ncols, _own, _halo, tab, _diag.data(), _dinv.data());
     hipLaunchKernelGGL((mf_fill_dinv_kernel<T, false>), dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st,
-                       _dinv.data(), _N[0], _ncols, (int64_t)n_slots, _rec.data(), _rec_bytes);
+                       _dinv.data(), _N[0], _ncols, _own, _halo, (int64_t)n_slots, _rec.data(), _rec_bytes);
   }
   MFMG_HIP_CHECK(hipGetLastError());
   MFMG_HIP_CHECK(hipStreamSynchronize(st));
@@ -1255,10 +993,10 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   // instruction issue (the cell-constant variant).  Those columns (plus the last column of the previous chunk as
   // a halo that is read, not written) form a thin slab whose LONG direction is y: the same kernel runs on it
   // with x and y exchanged, lanes along y, inside the same launch, and the main part skips the last chunk.
-  const int tail_cols = _N[0] - kOwn * (_ncols - 1); // DoF columns owned by the last chunk
-  if (!sub_mesh && _compact && _ncols >= 2 && tail_cols <= 24 && _N[1] >= 64)
+  const int tail_cols = _N[0] - _own * (_ncols - 1); // DoF columns owned by the last chunk
+  if (!sub_mesh && _halo == 1 && _compact && _ncols >= 2 && tail_cols <= 24 && _N[1] >= 64)
   {
-    const int i0 = kOwn * (_ncols - 1) - 1; // halo column of the last chunk = last column of the chunk before
+    const int i0 = _own * (_ncols - 1) - 1; // halo column of the last chunk = last column of the chunk before
     const int sc = _n[0] - i0;            // cell columns of the slab
     const int64_t s_cells = (int64_t)_n[1] * sc * _n[2];
     DeviceBuffer<int32_t> s_cd((size_t)s_cells * 8);
@@ -1540,6 +1278,8 @@ bool MatrixFreeLaplaceDevice<T>::make_args(MfArgs<T> &a, unsigned int &n_blocks,
   a.beta = beta;
   a.mode = static_cast<int>(mode);
   a.rec_bytes = (unsigned int)_rec_bytes;
+  a.own = _own;
+  a.halo = _halo;
   a.dinv_in_record = _dinv_in_record ? 1 : 0;
   a.aff = _affine;
   a.ncols = _ncols;
@@ -1746,7 +1486,7 @@ void MatrixFreeLaplaceDevice<T>::tiling(int n_tiles[3], int rows[3]) const
   int nw, ty, tz;
   choose_tile(nw, ty, tz);
   n_tiles[0] = _tail ? _ncols - 1 : _ncols;
-  rows[0] = kOwn;
+  rows[0] = _own;
   rows[1] = nw * ty - 1;
   n_tiles[1] = (_N[1] + rows[1] - 1) / rows[1];
   rows[2] = tz;
@@ -1772,10 +1512,10 @@ void MatrixFreeLaplaceDevice<T>::launch_tiles(MfMode mode, T const *x, T const *
     return;
   // share of the DoFs this launch updates (for the profiler's bytes)
   const double zshare = double(end[2] - begin[2]) / double(nt[2]);
-  const double tail_cols = _tail ? double(_N[0] - (_ncols - 1) * kOwn) : 0.;
+  const double tail_cols = _tail ? double(_N[0] - (_ncols - 1) * _own) : 0.;
   double share = 0.;
   if (m)
-    share += zshare * (double(end[0] - begin[0]) * kOwn / double(_N[0])) * (double(end[1] - begin[1]) / double(nt[1]));
+    share += zshare * (double(end[0] - begin[0]) * _own / double(_N[0])) * (double(end[1] - begin[1]) / double(nt[1]));
   if (t)
     share += zshare * tail_cols / double(_N[0]);
   hipEvent_t stop = _handle.profiler.begin("mf_laplace_kernel", std::min(1., share) * (required_bytes_apply() + epilogue_bytes((int)mode)),

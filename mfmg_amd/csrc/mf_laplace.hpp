@@ -93,6 +93,23 @@ public:
   void launch_outside(MfMode mode, T const *x, T const *b, T const *x_prev, T alpha, T beta, T *out, int const begin[3],
                       int const end[3], hipStream_t on_stream = nullptr) const;
 
+  // Several smoother terms in ONE sweep (mf_cheb_fused.hip): x_1 = x - beta[0] dinv (A x - b), then
+  // x_s = x_{s-1} + alpha[s-1] (x_{s-1} - x_{s-2}) - beta[s-1] dinv (A x_{s-1} - b) up to s = n_terms (2 or 3); out = x_{n_terms},
+  // out_prev (may be null) = x_{n_terms - 1}.  The same bits as n_terms calls of smoother_step.  alpha[0] must be zero; out,
+  // out_prev and x must be three different vectors.  Available for the cell-constant layout with a numbering the kernel can
+  // compute on one rank (fused_sweep_available); callers fall back to smoother_step otherwise.
+  bool fused_sweep_available(int n_terms) const;
+  void smoother_sweep(int n_terms, T const *alpha, T const *beta, T const *b, T const *x, T *out, T *out_prev) const;
+  // tile of the sweep: nw wavefronts of ty cell rows, tz owned layers (0, 0, 0: chosen from the mesh)
+  void set_fused_tile(int nw, int ty, int tz)
+  {
+    _fused_tile[0] = nw;
+    _fused_tile[1] = ty;
+    _fused_tile[2] = tz;
+  }
+  void get_fused_tile(int n_terms, int &nw, int &ty, int &tz) const { choose_fused_tile(n_terms, nw, ty, tz); }
+  int halo_lanes() const { return _halo; }
+
   T const *diagonal() const { return _diag.data(); }
   T const *diagonal_inverse() const { return _dinv.data(); }
 
@@ -160,6 +177,8 @@ private:
   DeviceBuffer<uint8_t> _cn2;
   double _k2[64] = {};
   void choose_tile(int &nw, int &ty, int &tz) const;
+  void choose_fused_tile(int n_terms, int &nw, int &ty, int &tz) const;
+  int _fused_tile[3] = {0, 0, 0};
 
   HipHandle &_handle;
   int _N[3]; // DoF grid
@@ -169,6 +188,7 @@ private:
   // internal layout (mf_laplace.hip): rows cut into aligned chunks of 64 cell slots (62 owned DoFs + the
   // halo cell); one record per chunk with the b=1 face ids, the coefficients and D^-1, plus the b=0 face ids
   int _ncols = 0;
+  int _own = 62, _halo = 1; // chunk c holds the node columns _own c - _halo + lane and owns its lanes [_halo, _halo + _own)
   size_t _n_slots = 0;
   // columns of a nearly empty last chunk, as a slab operator with x and y exchanged (mf_laplace.hip)
   std::unique_ptr<MatrixFreeLaplaceDevice<T>> _tail;

@@ -154,18 +154,33 @@ public:
       // pre-smoother instead of in front of the restriction)
       restrictor->prefetch_rhs(b);
 
-      // pre-smoother
+      // pre-smoother.  A smoother that works out of place (the multi-term sweep: it cannot write the vector it reads) alternates
+      // between x and a workspace vector; pre- and post-smoothing together switch an even number of times.
       auto smoother = level_fine.get_smoother();
-      for (unsigned int i = 0; i < _n_smoothing_steps; ++i)
-        smoother->apply(b, x);
+      VectorType *cur = &x, *other = nullptr;
+      auto smooth = [&] {
+        for (unsigned int i = 0; i < _n_smoothing_steps; ++i)
+        {
+          if (smoother->prefers_out_of_place())
+          {
+            if (other == nullptr)
+              other = level_fine.workspace_vector(3).get();
+            smoother->apply_to(b, *cur, *other);
+            std::swap(cur, other);
+          }
+          else
+            smoother->apply(b, *cur);
+        }
+      };
+      smooth();
 
       // negative residual -r = A x - b and its restriction: one pass where the restrictor holds the rows of R A,
       // otherwise one fused kernel for the residual and the restriction after it
       auto b_coarse = level_coarse.workspace_vector(1);
-      if (!restrictor->restrict_residual(*a, x, b, *b_coarse))
+      if (!restrictor->restrict_residual(*a, *cur, b, *b_coarse))
       {
         auto res = level_fine.workspace_vector(0);
-        a->residual(x, b, *res);
+        a->residual(*cur, b, *res);
         restrictor->apply(*res, *b_coarse);
       }
 
@@ -174,11 +189,12 @@ public:
       apply(*b_coarse, *x_coarse, level_index + 1);
 
       // x -= R^T x_c (prolongation fused with the update)
-      restrictor->apply_subtract(*x_coarse, x, OperatorMode::TRANS);
+      restrictor->apply_subtract(*x_coarse, *cur, OperatorMode::TRANS);
 
       // post-smoother
-      for (unsigned int i = 0; i < _n_smoothing_steps; ++i)
-        smoother->apply(b, x);
+      smooth();
+      if (cur != &x)
+        x = *cur;
       timer_leave_subsection(_timer);
     }
   }

@@ -85,6 +85,14 @@ public:
   // out = x + alpha (x - x_prev) - beta D^{-1} (A x - b); x_prev may be null when alpha == 0
   virtual void smoother_step(DVector const &b, DVector const &x, DVector const *x_prev, double alpha, double beta,
                              DVector &out) const = 0;
+  // the first n_terms (2 or 3) polynomial terms in ONE sweep: out = x_{n_terms}, out_prev (may be null) = x_{n_terms - 1};
+  // alpha[0] = 0.  False (nothing done) where the operator has no such kernel: the smoother then goes term by term.
+  virtual bool smoother_sweep(int /*n_terms*/, double const * /*alpha*/, double const * /*beta*/, DVector const & /*b*/, DVector const & /*x*/,
+                              DVector & /*out*/, DVector * /*out_prev*/) const
+  {
+    return false;
+  }
+  virtual bool sweep_available(int /*n_terms*/) const { return false; }
   virtual double const *get_diagonal_inverse() const = 0; // device pointer
   virtual HipHandle &get_hip_handle() const = 0;
   // distributed vector space of the domain / range (0: rank-local, 1: fine DoFs, 2: first coarse level)
@@ -180,6 +188,9 @@ public:
 
   void smoother_step(DVector const &b, DVector const &x, DVector const *x_prev, double alpha, double beta,
                      DVector &out) const override;
+  bool smoother_sweep(int n_terms, double const *alpha, double const *beta, DVector const &b, DVector const &x, DVector &out,
+                      DVector *out_prev) const override;
+  bool sweep_available(int n_terms) const override;
   double const *get_diagonal_inverse() const override;
   HipHandle &get_hip_handle() const override { return _mesh_evaluator->get_hip_handle(); }
   std::shared_ptr<HipMatrixFreeMeshEvaluator> get_mesh_evaluator() const { return _mesh_evaluator; }
@@ -252,8 +263,11 @@ public:
   void apply(DVector const &b, DVector &x) const override;
   // same update when x is known to be zero on entry (content of x ignored); saves one operator application
   void apply_zero_guess(DVector const &b, DVector &x) const;
-  // same update from x_in into a different vector x_out (one polynomial term: no copy back from the scratch vector)
-  void apply_to(DVector const &b, DVector const &x_in, DVector &x_out) const;
+  // same update from x_in into a different vector x_out: the whole polynomial in one sweep where the operator offers it
+  // (smoother.fused_terms, default 3), no copy back from a scratch vector
+  void apply_to(DVector const &b, DVector const &x_in, DVector &x_out) const override;
+  bool prefers_out_of_place() const override;
+  int fused_terms() const { return _fused_terms; }
 
   int degree() const { return (int)_coefficients.size(); }
   // (alpha_k, beta_k) of the polynomial terms: x_{k+1} = x_k + alpha_k (x_k - x_{k-1}) - beta_k D^-1 (A x_k - b)
@@ -264,12 +278,15 @@ public:
 
 private:
   void estimate_eigenvalues(int n_iterations, double residual, double &min_est, double &max_est) const;
+  void run_terms(int k0, DVector const &b, DVector const *cur, DVector const *prev, DVector &x_out) const;
+  bool run_sweep(int K, DVector const &b, DVector const &x_in, DVector &out, DVector *out_prev) const;
 
   std::shared_ptr<HipOperator const> _hip_operator;
   std::string _type;
   std::string _eig_start = "hashed";
   double _lambda_min = 1., _lambda_max = 1.;
   std::vector<std::pair<double, double>> _coefficients; // (alpha_k, beta_k)
+  int _fused_terms = 3; // polynomial terms per sweep (1: one launch per term)
   mutable std::shared_ptr<DVector> _scratch_a, _scratch_b;
 };
 

@@ -21,6 +21,16 @@ public:
 
   virtual void apply(vector_type const &b, vector_type &x) const = 0;
 
+  // Extension: the same update from x_in into a DIFFERENT vector x_out.  A smoother that runs its whole polynomial in one sweep
+  // over the mesh cannot write into the vector it reads; Hierarchy::apply alternates between x and a workspace vector when
+  // prefers_out_of_place() says so (an even number of applications per cycle: the result lands in x without a copy).
+  virtual void apply_to(vector_type const &b, vector_type const &x_in, vector_type &x_out) const
+  {
+    x_out = x_in;
+    apply(b, x_out);
+  }
+  virtual bool prefers_out_of_place() const { return false; }
+
 protected:
   std::shared_ptr<operator_type const> _operator;
   std::shared_ptr<ptree const> _params;

@@ -64,6 +64,16 @@ def build_library(verbose: bool = False) -> str:
 _lib = None
 
 
+def _declared_abi_version():
+    import re
+    header = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mfmg_hip.h")
+    try:
+        m = re.search(r"#define\s+MFMG_HIP_ABI_VERSION\s+(\d+)", open(header).read())
+    except OSError:
+        return None
+    return int(m.group(1)) if m else None
+
+
 def load() -> C.CDLL:
     global _lib
     if _lib is not None:
@@ -73,6 +83,17 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(the mfmg HIP path has no Python/CPU fallback)")
     lib = C.CDLL(LIB_PATH)
+    # a library built from another revision of include/mfmg_hip.h would be called with the wrong callback layouts
+    declared = _declared_abi_version()
+    try:
+        lib.mfmg_hip_abi_version.restype = C.c_int
+        built = int(lib.mfmg_hip_abi_version())
+    except AttributeError:
+        built = None
+    if declared is not None and built != declared:
+        raise ImportError(
+            f"{LIB_PATH} was built with ABI version {built}, include/mfmg_hip.h declares {declared}: rebuild it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'`")
     vp, i32, i64, dbl, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_size_t
     P = C.POINTER
     sig = {
@@ -103,6 +124,13 @@ def load() -> C.CDLL:
         "mfmg_hip_context_set_galerkin_on_device": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_context_set_stored_diagonal": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_mf_laplace_diagonal_in_record": (C.c_int, [vp, P(C.c_int)]),
+        "mfmg_hip_context_set_mf_fused_terms": (C.c_int, [vp, C.c_int]),
+        "mfmg_hip_mf_laplace_sweep_available": (C.c_int, [vp, C.c_int, P(C.c_int)]),
+        "mfmg_hip_mf_laplace_smoother_sweep": (C.c_int, [vp, C.c_int, P(dbl), P(dbl), vp, vp, vp, vp]),
+        "mfmg_hip_mf_laplace_set_sweep_tile": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+        "mfmg_hip_mf_laplace_get_sweep_tile": (C.c_int, [vp, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int)]),
+        "mfmg_hip_mf_laplace_f32_sweep_available": (C.c_int, [vp, C.c_int, P(C.c_int)]),
+        "mfmg_hip_mf_laplace_f32_smoother_sweep": (C.c_int, [vp, C.c_int, P(C.c_float), P(C.c_float), vp, vp, vp, vp]),
         "mfmg_hip_mf_laplace_ids_computed": (C.c_int, [vp, P(C.c_int)]),
         "mfmg_hip_mf_laplace_f32_ids_computed": (C.c_int, [vp, P(C.c_int)]),
         "mfmg_hip_mf_laplace_cell_constant_layout": (C.c_int, [vp, P(C.c_int)]),
