@@ -9,11 +9,13 @@ resident in HBM.  The `cpu_baseline` leg runs the same cycle in the oracle's C++
 GPU's (`parity_vs_gpu`).  Metric (BASELINE.json): fine-DoFs/sec per V-cycle.  One process per GPU; rank 0
 prints ONE JSON line.
 
-Byte accounting of the roofline block: `achieved` = bytes the data layout REQUIRES per launch of the
-operator kernel (x, out, one id, the coefficients, the epilogue operands; halo re-reads excluded) / the
-average launch time from HIP events on the launch stream; `traffic` = HBM bytes per launch from the
-rocprofv3 PMC passes committed under profiles/ for exactly this workload and tile (null otherwise);
-the SURVEY.md 8(d) figure (8 index ints + 8 coefficients per DoF) is printed beside it, named as such.
+Byte accounting of the roofline block: `achieved` = ALGORITHMIC bytes of the smoother terms one launch of the
+dominant kernel performs -- per term what the data layout requires of a launch of that term (x, out, one id, the
+coefficients, the epilogue operands; halo re-reads excluded); the multi-term sweep performs three terms per launch and is
+priced on the three, with the bytes the fused form itself must move printed beside it -- / the average launch time from HIP
+events on the launch stream; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
+for exactly this workload and tile (null otherwise); SURVEY.md 8(d)'s own figures (112 B/DoF per operator application, 144
+per fused smoother term, 432 per Chebyshev(3) apply) are printed under `survey_8d_*`.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -119,6 +121,13 @@ def operator_bytes_per_dof(word, compact, survey, ids_computed=False):
     return 2 * word + (32 if survey else (0 if ids_computed else 4)) + coef
 
 
+def survey_8d_bytes_per_dof(n_terms, word=8):
+    """SURVEY.md 8(d), whatever the layout: operator application 112 B/DoF in FP64 (x + y + 8 index ints + 8 coefficients; 72
+    in FP32), + 32 (b, D^-1, x_prev, x+) per fused smoother term = 144, Chebyshev(3) apply = 3 terms = 432."""
+    op = 2 * word + 8 * 4 + 8 * word
+    return {"operator": op, "smoother_term": op + 4 * word, "smoother_apply": n_terms * (op + 4 * word)}
+
+
 def smoother_bytes_per_dof(n_terms, word, compact, survey, dinv_stored=None, ids_computed=False):
     """Chebyshev smoother apply = n_terms fused operator launches: + b + D^-1 each, + x_prev from the second on.  With one
     coefficient per cell the layout holds no D^-1 by default (the kernel derives it from the cell coefficients): then it
@@ -128,6 +137,14 @@ def smoother_bytes_per_dof(n_terms, word, compact, survey, dinv_stored=None, ids
         dinv_stored = not compact
     dinv = word if (survey or dinv_stored) else 0
     return (b_op + word + dinv) + (n_terms - 1) * (b_op + 2 * word + dinv)
+
+
+def ms_per_decade(ms_per_cycle, contraction):
+    """Time to reduce the residual by a factor of ten at the measured contraction per cycle: the figure that prices a change
+    of the CYCLE (V(0,1) against V(1,1) on the aggregation levels: ADVICE r03) -- cheaper cycles that contract less do not win."""
+    if not (0.0 < contraction < 1.0):
+        return None
+    return ms_per_cycle / (-math.log10(contraction))
 
 
 def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, material="constant",
@@ -163,6 +180,7 @@ def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, mater
                         f"hierarchy parameters",
             "n_dofs": n, "ms_per_step": dt * 1e3, "value": n / dt, "unit": "DoF/s", "setup_seconds": t_setup,
             "mean_residual_contraction_per_cycle": (res1 / res0) ** (1.0 / (warmup + steps)) if res0 > 0 else 0.0,
+            "ms_per_residual_decade": ms_per_decade(dt * 1e3, (res1 / res0) ** (1.0 / (warmup + steps)) if res0 > 0 else 0.0),
             "device_memory_in_use_GB": (total_b - free_b) / 1e9}
 
 
@@ -294,8 +312,8 @@ def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=20, warmup=3, t
     s1, s2 = torch.empty_like(x), torch.empty_like(x)
     coefs = smoother_coefficients(degree, 0.09, 1.8)
 
-    def apply():
-        # x_{k+1} targets alternate so that the last term lands in x (HipSmoother::apply)
+    def apply_terms():
+        # x_{k+1} targets alternate so that the last term lands in x (HipSmoother::apply, one launch per term)
         bufs = [s1, s2]
         cur, prev = x, None
         for k, (al, be) in enumerate(coefs):
@@ -303,30 +321,50 @@ def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=20, warmup=3, t
             op.smoother_step(b, cur, prev, al, be, tgt)
             prev, cur = cur, tgt
 
-    for _ in range(warmup):
-        apply()
-    ctx.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-    ev[0].record()
-    for r in range(reps):
-        apply()
-        ev[r + 1].record()
-    ev[-1].synchronize()
-    ts = sorted(ev[r].elapsed_time(ev[r + 1]) for r in range(reps))
+    state = {"cur": x, "other": s1}
+
+    def apply_sweep():
+        # the whole polynomial in one sweep, out of place (HipSmoother::apply_to: the hierarchy alternates two vectors)
+        op.smoother_sweep([c[0] for c in coefs], [c[1] for c in coefs], b, state["cur"], state["other"])
+        state["cur"], state["other"] = state["other"], state["cur"]
+
+    def timed(apply):
+        for _ in range(warmup):
+            apply()
+        ctx.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        ev[0].record()
+        for r in range(reps):
+            apply()
+            ev[r + 1].record()
+        ev[-1].synchronize()
+        return sorted(ev[r].elapsed_time(ev[r + 1]) for r in range(reps))
+
+    sweep = 2 <= len(coefs) <= 3 and op.sweep_available(len(coefs))
+    ts_terms = timed(apply_terms)
+    ts = timed(apply_sweep) if sweep else ts_terms
     ms = ts[len(ts) // 2]
-    survey = smoother_bytes_per_dof(len(coefs), 8, compact, survey=True)
+    survey = survey_8d_bytes_per_dof(len(coefs))["smoother_apply"]
     required = smoother_bytes_per_dof(len(coefs), 8, compact, survey=False, dinv_stored=dinv_stored, ids_computed=op.ids_computed())
-    traffic = committed_traffic(n_dofs_per_dim, degree, compact, op.get_tile(), prefix="dofs") if dinv_stored == (not compact) else None
+    fused_form = 8 * (4 + (1 if dinv_stored else 0)) if sweep else None     # x_0, b, one coefficient per cell (D^-1), x_K
+    traffic = committed_traffic(n_dofs_per_dim, degree, compact, op.get_tile(), prefix="dofs") if (dinv_stored == (not compact) and not sweep) else None
     return {"n_dofs": N, "degree": degree, "material": material,
             "coefficient_layout": "one value per cell" if compact else "eight values per cell",
             "diagonal": "D^-1 stored in the chunk records" if dinv_stored else "D^-1 derived in the kernel from the cell coefficients (not read)",
-            "tile_waves_ty_tz": list(op.get_tile()),
+            "kernel": (f"mf_cheb_fused_kernel: the {len(coefs)} terms in one sweep" if sweep else f"mf_laplace_kernel: {len(coefs)} launches, one per term"),
+            "tile_waves_ty_tz": list(op.get_sweep_tile(len(coefs)) if sweep else op.get_tile()),
             "hbm_traffic_bytes_per_launch_pmc": traffic,
             "hbm_traffic_GBs": (traffic * len(coefs) / (ms * 1e-3) / 1e9) if traffic else None,
             "ms_per_apply": ms, "ms_min": ts[0], "ms_max": ts[-1], "reps": reps, "warmup": warmup,
-            "required_bytes_per_dof": required, "required_GBs": N * required / (ms * 1e-3) / 1e9,
+            "ms_per_apply_term_by_term": ts_terms[len(ts_terms) // 2],
+            "required_bytes_per_dof": required,
+            "required_bytes_are": "the sum over the polynomial terms of what the layout requires of a launch of that term (x, out, one "
+                                  "id, coefficients, b, x_prev, D^-1 where stored) -- the figure of rounds 1-3, whichever kernel runs",
+            "required_GBs": N * required / (ms * 1e-3) / 1e9,
             "frac_of_8TBs": N * required / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "survey_8d_bytes_per_dof": survey, "survey_8d_GBs": N * survey / (ms * 1e-3) / 1e9}
+            "fused_form_bytes_per_dof": fused_form,
+            "fused_form_GBs": (N * fused_form / (ms * 1e-3) / 1e9) if fused_form else None,
+            "survey_8d_bytes_per_dof_smoother_apply": survey, "survey_8d_GBs": N * survey / (ms * 1e-3) / 1e9}
 
 
 def cpu_baseline(args, M, h, prob, lmin, lmax, torch):
@@ -548,7 +586,7 @@ def main():
         h.apply(b, x)
     # HIP events around the launches of the dominant kernel only: an event pair costs ~5 us on the stream, and the
     # cycle has ~45 launches; the other kernel family is timed in a separate pass after the timed region
-    dominant = "csr_spmv_kernel" if assembled else "mf_laplace_kernel"
+    dominant = "csr_spmv_kernel" if assembled else "mf_laplace_kernel,mf_cheb_fused_kernel"
     ctx.profile_enable(True, only=dominant)
     n_ex0 = transport.n_exchanges() if transport is not None else 0
     n_vol0 = transport.exchange_volume() if transport is not None else 0
@@ -568,6 +606,11 @@ def main():
     contraction = (res_end / res_start) ** (1.0 / max(args.warmup + args.steps, 1)) if res_start > 0 else 0.0
     del op_monitor, r
     launches, k_ms, k_bytes = ctx.profile_query("mf_laplace_kernel")
+    f_launches, f_ms, f_bytes = ctx.profile_query("mf_cheb_fused_kernel")
+    fused_dominant = f_ms > k_ms
+    one_term = {"launches": launches, "total_ms": k_ms, "algorithmic_bytes": k_bytes}
+    if fused_dominant:
+        launches, k_ms, k_bytes = f_launches, f_ms, f_bytes
     c_launches, c_ms, c_bytes = ctx.profile_query("csr_spmv_kernel")
     ctx.profile_enable(False)
     other_cycles = 0
@@ -646,9 +689,17 @@ def main():
                                         + (", the FP32 instance of the fine operator" if with_f32 else "") + ")",
                 "problem_seconds": t_problem,
                 "mean_residual_contraction_per_cycle": contraction,
+                "ms_per_residual_decade": ms_per_decade(ms_per_step, contraction),
+                "coarse_cycle": ("V(1,1) on every level of the aggregation hierarchy (the library default, symmetric: what a CG-"
+                                 "preconditioned use needs)" if args.amg_pre_levels < 0 or args.coarse != "amg" else
+                                 f"V(0,1) from level {args.amg_pre_levels} of the aggregation hierarchy on (post-smoothing only: not a "
+                                 "symmetric preconditioner; the symmetric V(1,1) cycle is measured beside it: "
+                                 "vcycle_256cubed_coarse_cycle_v11, with ms_per_residual_decade for both)"),
+                "rccl_ranks": (transport.comm_ranks() if transport is not None else None),
             },
             "roofline": {
-                "kernel": "mf_laplace_kernel (fused matrix-free operator + smoother/residual epilogue)",
+                "kernel": (f"mf_cheb_fused_kernel (the {degree} terms of the Chebyshev smoother over the matrix-free operator in ONE sweep)"
+                           if fused_dominant else "mf_laplace_kernel (fused matrix-free operator + smoother/residual epilogue)"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -657,15 +708,21 @@ def main():
                 "traffic": (None if assembled else committed_traffic(args.cells, args.degree, compact, mf_tile)),
                 "traffic_source": (None if assembled else
                                    committed_traffic(args.cells, args.degree, compact, mf_tile, want_source=True)[1]),
-                "priced_on": "bytes the data layout requires per launch (x, out, one id, coefficients, b, x_prev, and D^-1 where the "
-                             "layout stores it: eight coefficients per cell); "
-                             "halo re-reads of the tiling are waste and not counted",
+                "priced_on": "algorithmic bytes of the smoother terms a launch performs: per term what the data layout requires of a "
+                             "launch of that term (x, out, one id, coefficients, b, x_prev, and D^-1 where the layout stores it: eight "
+                             "coefficients per cell); halo re-reads of the tiling are waste and not counted"
+                             + ("; the sweep performs all terms per launch, the bytes its fused form must move are `fused_form_*`" if fused_dominant else ""),
+                "terms_per_launch": (degree if fused_dominant else 1),
+                "fused_form_bytes_per_launch": (32.0 * n_local if fused_dominant else None),
+                "fused_form_GBs": ((32.0 * n_local) / (k_ms / launches * 1e-3) / 1e9 if fused_dominant and launches else None),
+                "one_term_kernel_in_timed_region": (one_term if fused_dominant else None),
                 "required_bytes_per_dof_operator": (None if assembled else operator_bytes_per_dof(word, compact, False, ids_computed)),
                 "ids": (None if assembled else ("computed by the kernel (structured numbering)" if ids_computed
                                                 else "one 4-byte id per DoF read from the chunk records")),
-                "survey_8d_bytes_per_dof_operator": (None if assembled else operator_bytes_per_dof(word, compact, True)),
-                "survey_8d_GBs": (None if assembled or not launches else      # + the 7 index ints the layout does not read
-                                  (k_bytes / launches + 28.0 * n_local) / (k_ms / launches * 1e-3) / 1e9),
+                "survey_8d_bytes_per_dof": (None if assembled else survey_8d_bytes_per_dof(degree)),
+                "survey_8d_GBs": (None if assembled or not launches else      # SURVEY.md 8(d)'s own figure for what one launch does
+                                  survey_8d_bytes_per_dof(degree)["smoother_apply" if fused_dominant else "smoother_term"] * n_local
+                                  / (k_ms / launches * 1e-3) / 1e9),
                 "launches_in_timed_region": launches, "tile_waves_ty_tz": list(mf_tile),
                 "avg_launch_ms": k_ms / launches if launches else None,
                 "required_bytes_per_launch": k_bytes / launches if launches else None,
@@ -714,23 +771,32 @@ def main():
                     # what the PARTITION of a distributed run costs a rank by itself, measured here on one GPU: the fine operator
                     # applied with the launches of a rank that has a neighbour along z (the grid at 2 ranks), y and z (4), x, y and
                     # z (8) -- interior tiles, the shell around them beside them on the exchange stream -- and no exchange
-                    # (MFMG_MF_EMULATE_SPLIT, read by the library at every application; same bits as the single launch)
-                    emu = {"what": "the headline cycle with the fine operator applied as a rank of 1x1x2 / 1x2x2 / 2x2x2 would (interior "
-                                   "tiles + one shell launch beside them, no exchange, nothing on the wire): ms per cycle on this GPU",
-                           "unsplit": ms_per_step}
+                    # (Context.set_mf_emulate_split; same bits as the single launch).  The smoother of a distributed run goes term by
+                    # term, so this leg builds its hierarchy with `smoother.fused_terms 1` and the one-halo-lane records.
+                    emu = {"what": "the headline cycle, smoother term by term (the cycle of a distributed rank), with the fine operator applied "
+                                   "as a rank of 1x1x2 / 1x2x2 / 2x2x2 would (interior tiles + one shell launch beside them, no exchange, "
+                                   "nothing on the wire): ms per cycle on this GPU"}
+                    p1 = json.loads(json.dumps(params))
+                    p1["smoother"]["fused_terms"] = 1
+                    ctx.set_mf_fused_terms(1)
                     try:
-                        for grid_name in ("z", "yz", "xyz"):
-                            os.environ["MFMG_MF_EMULATE_SPLIT"] = grid_name
+                        h1 = M.Hierarchy(ctx, evaluator, prob, p1)
+                    finally:
+                        ctx.set_mf_fused_terms(3)
+                    try:
+                        for grid_name in (None, "z", "yz", "xyz"):
+                            ctx.set_mf_emulate_split(grid_name)
                             for _ in range(3):
-                                h.apply(b, x)
+                                h1.apply(b, x)
                             torch.cuda.synchronize()
                             t_e = time.perf_counter()
                             for _ in range(10):
-                                h.apply(b, x)
+                                h1.apply(b, x)
                             torch.cuda.synchronize()
-                            emu[{"z": "1x1x2", "yz": "1x2x2", "xyz": "2x2x2"}[grid_name]] = (time.perf_counter() - t_e) / 10 * 1e3
+                            emu[{None: "unsplit", "z": "1x1x2", "yz": "1x2x2", "xyz": "2x2x2"}[grid_name]] = (time.perf_counter() - t_e) / 10 * 1e3
                     finally:
-                        os.environ.pop("MFMG_MF_EMULATE_SPLIT", None)
+                        ctx.set_mf_emulate_split(None)
+                    del h1
                     out["distributed_launch_structure_on_one_gpu"] = emu
                 if with_f32:
                     out["vcycle_fp32_fine_level_config5"] = measure_vcycle_f32(ctx, torch, M, h, prob,

@@ -126,6 +126,8 @@ int mfmg_hip_context_use_host_transport(mfmg_hip_context_t ctx, mfmg_hip_host_ex
 int mfmg_hip_context_use_reflecting_transport(mfmg_hip_context_t ctx);
 /* "rccl", "host", "reflecting" or "" (none) */
 int mfmg_hip_context_transport_name(mfmg_hip_context_t ctx, char *buffer, size_t buffer_size);
+/* ranks the registered transport's own communicator reports (RCCL: ncclCommCount; 1 without a transport) */
+int mfmg_hip_context_transport_ranks(mfmg_hip_context_t ctx, int *n_ranks);
 /* exercises the registered transport: `n` doubles sent to this rank itself and back, an all-gather and sum / max
  * all-reduces over all ranks; returns the largest deviation from the known answers (0 when everything arrived) */
 int mfmg_hip_context_transport_selftest(mfmg_hip_context_t ctx, int64_t n, double *max_error);
@@ -156,6 +158,12 @@ int mfmg_hip_mf_laplace_diagonal_in_record(mfmg_hip_mf_laplace_t op, int *in_rec
  * coefficients once).  Operators created afterwards cut their rows into chunks with that many halo columns on either side
  * (1 = the layout of the one-term kernels, which a distributed run always takes). */
 int mfmg_hip_context_set_mf_fused_terms(mfmg_hip_context_t ctx, int n_terms);
+/* Measurement switches of the distributed fine operator (the environment variables MFMG_MF_SHELL / MFMG_MF_EMULATE_SPLIT give the
+ * initial values when the context is created; nothing reads the environment per application).  shell mode: 0 = the shell of
+ * tiles around the interior as one launch on the exchange stream beside the interior tiles (default), 1 = after them, 2 = slab
+ * by slab.  emulate split (one rank): the launches a rank of 1x1x2 (1), 1x2x2 (2), 2x2x2 (3) would make, without an exchange. */
+int mfmg_hip_context_set_mf_shell(mfmg_hip_context_t ctx, int mode);
+int mfmg_hip_context_set_mf_emulate_split(mfmg_hip_context_t ctx, int axes);
 /* 1 when the operator kernel COMPUTES the DoF ids instead of reading them from its records: a numbering that is affine
  * on the node grid (any lexicographic one), Dirichlet DoFs on whole faces of the box, ghost DoFs on whole z-layers,
  * checked slot by slot at construction; used by the eight-coefficient kernels (where it pays).  MFMG_MF_AFFINE_IDS=0

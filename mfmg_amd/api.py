@@ -145,6 +145,14 @@ class Context:
         """Matrix-free operators created afterwards can run up to n_terms (1..3) smoother terms per sweep (default 3)."""
         check(self._lib.mfmg_hip_context_set_mf_fused_terms(self.handle, int(n_terms)))
 
+    def set_mf_shell(self, mode):
+        """Distributed fine operator: the shell of tiles 'beside' (default) / 'after' the interior tiles, or as 'slabs'."""
+        check(self._lib.mfmg_hip_context_set_mf_shell(self.handle, {"beside": 0, "": 0, "after": 1, "slabs": 2}[mode]))
+
+    def set_mf_emulate_split(self, axes):
+        """One rank, measurement only: the launches of a rank with neighbours along 'z', 'yz' or 'xyz' ('' / None: off)."""
+        check(self._lib.mfmg_hip_context_set_mf_emulate_split(self.handle, {None: 0, "": 0, "z": 1, "yz": 2, "xyz": 3, "1": 3}[axes]))
+
     def set_galerkin_on_device(self, enable: bool):
         """Hierarchies created afterwards form R A R^T of a matrix-free A by probing on the device (default) or on the host."""
         check(self._lib.mfmg_hip_context_set_galerkin_on_device(self.handle, int(bool(enable))))

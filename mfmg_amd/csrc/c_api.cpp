@@ -217,6 +217,12 @@ int mfmg_hip_context_use_rccl(mfmg_hip_context_t ctx, const unsigned char unique
     require(ctx != nullptr && unique_id != nullptr, "null argument");
     HaloCommunicator &c = ctx->handle->comm;
     c.transport = make_rccl_transport(c.rank, c.n_ranks, unique_id);
+    // the exchange stream gets its communicator HERE, where every rank is (ncclCommSplit is collective; created lazily it
+    // would be created wherever a rank first overlaps an exchange)
+    if (ctx->handle->comm_stream != nullptr)
+      c.transport->bind_exchange_stream(ctx->handle->comm_stream);
+    else
+      (void)ctx->handle->exchange_stream();
   });
 }
 
@@ -247,6 +253,14 @@ int mfmg_hip_context_transport_name(mfmg_hip_context_t ctx, char *buffer, size_t
     require(ctx != nullptr && buffer != nullptr && buffer_size > 0, "null argument");
     std::string name = ctx->handle->comm.transport ? ctx->handle->comm.transport->name() : "";
     std::snprintf(buffer, buffer_size, "%s", name.c_str());
+  });
+}
+
+int mfmg_hip_context_transport_ranks(mfmg_hip_context_t ctx, int *n_ranks)
+{
+  return guarded([&] {
+    require(ctx != nullptr && n_ranks != nullptr, "null argument");
+    *n_ranks = ctx->handle->comm.transport ? ctx->handle->comm.transport->comm_ranks() : 1;
   });
 }
 
@@ -342,6 +356,22 @@ int mfmg_hip_context_set_mf_fused_terms(mfmg_hip_context_t ctx, int n_terms)
     require(ctx != nullptr, "null context");
     require(n_terms >= 1 && n_terms <= 3, "1, 2 or 3 terms per sweep");
     ctx->handle->mf_fused_terms = n_terms;
+  });
+}
+int mfmg_hip_context_set_mf_shell(mfmg_hip_context_t ctx, int mode)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    require(mode >= 0 && mode <= 2, "shell mode: 0 beside the interior tiles, 1 after them, 2 slab by slab");
+    ctx->handle->mf_shell_mode = mode;
+  });
+}
+int mfmg_hip_context_set_mf_emulate_split(mfmg_hip_context_t ctx, int axes)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    require(axes >= 0 && axes <= 3, "emulated split: 0 off, 1 = z, 2 = yz, 3 = xyz");
+    ctx->handle->mf_emulate_split = axes;
   });
 }
 int mfmg_hip_mf_laplace_diagonal_in_record(mfmg_hip_mf_laplace_t op, int *in_record)

@@ -195,7 +195,7 @@ struct KernelProfiler
     double algorithmic_bytes = 0.;
   };
   bool enabled = false;
-  std::string only; // when not empty: time launches of this kernel name only (two event records cost ~5 us)
+  std::string only; // when not empty: time launches of these kernel names only ("a" or "a,b": two event records cost ~5 us)
   std::map<std::string, Entry> entries;
 
   ~KernelProfiler()
@@ -218,7 +218,7 @@ struct KernelProfiler
   // returns the stop event to record after the launch (nullptr when disabled)
   hipEvent_t begin(char const *name, double bytes, hipStream_t stream)
   {
-    if (!enabled || (!only.empty() && only != name))
+    if (!enabled || (!only.empty() && only != name && ("," + only + ",").find(std::string(",") + name + ",") == std::string::npos))
       return nullptr;
     Entry &e = entries[name];
     if (e.used == e.events.size())
@@ -371,6 +371,12 @@ struct HaloTransport
   // send n doubles to this rank itself and receive them (exercises the point-to-point path on a single GPU)
   virtual void loopback(double const *send, double *recv, int64_t n, hipStream_t stream) = 0;
   virtual char const *name() const = 0;
+  // ranks the transport's own communicator reports (RCCL: ncclCommCount), for the record of a multi-GPU run
+  virtual int comm_ranks() const = 0;
+  // the stream the overlapped exchanges run on: a transport may give it a communicator of its own, so that exchanges on the
+  // compute stream and on the exchange stream do not queue behind each other inside ONE communicator (RCCL orders the
+  // operations of a communicator)
+  virtual void bind_exchange_stream(hipStream_t) {}
 };
 
 struct HaloCommunicator
@@ -428,6 +434,11 @@ struct HipHandle
   // polynomial terms of the Chebyshev smoother that one sweep of the matrix-free operator may run (mf_cheb_fused.hip); the chunk
   // records of operators built from this handle carry that many halo lanes (1 = one term per launch, the layout of rounds 1-3)
   int mf_fused_terms = 3;
+  // measurement switches of the distributed fine operator (hip_hierarchy.hip: HipMatrixFreeOperator::apply_mode), read from the
+  // environment ONCE when the handle is built (MFMG_MF_SHELL = slabs | after, MFMG_MF_EMULATE_SPLIT = z | yz | xyz | 1) and
+  // set at run time through mfmg_hip_context_set_mf_shell / _set_mf_emulate_split -- not read per application
+  int mf_shell_mode = 0;    // 0: the shell beside the interior tiles on the exchange stream; 1: after them; 2: slab by slab
+  int mf_emulate_split = 0; // one rank only: 0 off, 1 = z, 2 = yz, 3 = xyz: the launches of a rank of 1x1x2 / 1x2x2 / 2x2x2, no exchange
   // R A R^T of a matrix-free A by probing on the device (hip_hierarchy.hip, HipMatrixOperator::multiply) instead of
   // the host triple product
   bool galerkin_on_device = true;
@@ -577,18 +588,7 @@ struct HipHandle
     if (!comm.enabled() || space <= 0)
       return;
     HaloSpace &s = space_checked(space);
-    if (comm_stream == nullptr)
-    {
-      {
-        // (highest priority: the packing, the transport and the shell tiles enqueued here must not queue behind the workgroups the
-        // interior launch still has to dispatch on the compute stream)
-        int pr_low = 0, pr_high = 0;
-        MFMG_HIP_CHECK(hipDeviceGetStreamPriorityRange(&pr_low, &pr_high));
-        MFMG_HIP_CHECK(hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, pr_high));
-      }
-      MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming));
-      MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_unpacked, hipEventDisableTiming));
-    }
+    (void)exchange_stream();
     exchange_on(s, v, stream, comm_stream, true);
     ++comm.n_overlapped;
     MFMG_HIP_CHECK(hipEventRecord(ev_unpacked, comm_stream));
@@ -614,6 +614,8 @@ struct HipHandle
       }
       MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming));
       MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_unpacked, hipEventDisableTiming));
+      if (comm.transport)
+        comm.transport->bind_exchange_stream(comm_stream);
     }
     return comm_stream;
   }
@@ -708,6 +710,13 @@ struct HipHandle
     }
     else
       stream = s;
+    if (char const *e = std::getenv("MFMG_MF_SHELL"))
+      mf_shell_mode = std::string(e) == "after" ? 1 : (std::string(e) == "slabs" ? 2 : 0);
+    if (char const *e = std::getenv("MFMG_MF_EMULATE_SPLIT"))
+    {
+      const std::string v(e);
+      mf_emulate_split = v == "z" ? 1 : (v == "yz" ? 2 : ((v == "xyz" || v == "1") ? 3 : 0));
+    }
     reduce_partials.resize(4096);
     reduce_result.resize(16);
     MFMG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&host_result), 16 * sizeof(double)));

@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 #include <link.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -26,6 +27,8 @@ struct RcclApi
   int (*GetUniqueId)(ncclUniqueId *) = nullptr;
   int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*CommCount)(ncclComm_t, int *) = nullptr;
+  int (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *) = nullptr; // (optional: NCCL >= 2.18)
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -76,6 +79,8 @@ RcclApi &rccl()
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(sym("ncclCommCount"));
+    a.CommSplit = reinterpret_cast<decltype(a.CommSplit)>(dlsym(a.lib, "ncclCommSplit"));
     a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
     a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
     a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
@@ -106,8 +111,28 @@ public:
   }
   ~RcclTransport() override
   {
+    if (_comm_x)
+      (void)rccl().CommDestroy(_comm_x);
     if (_comm)
       (void)rccl().CommDestroy(_comm);
+  }
+  // A second communicator over the same ranks for the exchange stream (ncclCommSplit with one colour: collective, every rank
+  // binds its exchange stream at the same point of the setup).  RCCL serialises the operations of ONE communicator, so the
+  // overlapped fine exchange on the exchange stream and a coarse exchange on the compute stream would otherwise wait for each
+  // other through the communicator's internal events (multi-GPU (i)).  MFMG_RCCL_ONE_COMM=1 keeps one.
+  void bind_exchange_stream(hipStream_t s) override
+  {
+    _exchange_stream = s;
+    char const *one = std::getenv("MFMG_RCCL_ONE_COMM");
+    if (_comm_x == nullptr && rccl().CommSplit != nullptr && !(one && std::string(one) == "1"))
+      rccl_check(rccl().CommSplit(_comm, 0, _rank, &_comm_x, nullptr), "ncclCommSplit");
+  }
+  ncclComm_t comm_for(hipStream_t s) const { return (_comm_x != nullptr && s == _exchange_stream) ? _comm_x : _comm; }
+  int comm_ranks() const override
+  {
+    int n = 0;
+    rccl_check(rccl().CommCount(_comm, &n), "ncclCommCount");
+    return n;
   }
   void sendrecv(int peer_low, int peer_high, double const *send_low, double *recv_low, int64_t n_low, double const *send_high,
                 double *recv_high, int64_t n_high, hipStream_t stream) override
@@ -115,16 +140,17 @@ public:
     if (n_low <= 0 && n_high <= 0)
       return;
     RcclApi &r = rccl();
+    ncclComm_t comm = comm_for(stream);
     rccl_check(r.GroupStart(), "ncclGroupStart");
     if (n_low > 0)
     {
-      rccl_check(r.Send(send_low, (size_t)n_low, ncclFloat64, peer_low, _comm, stream), "ncclSend");
-      rccl_check(r.Recv(recv_low, (size_t)n_low, ncclFloat64, peer_low, _comm, stream), "ncclRecv");
+      rccl_check(r.Send(send_low, (size_t)n_low, ncclFloat64, peer_low, comm, stream), "ncclSend");
+      rccl_check(r.Recv(recv_low, (size_t)n_low, ncclFloat64, peer_low, comm, stream), "ncclRecv");
     }
     if (n_high > 0)
     {
-      rccl_check(r.Send(send_high, (size_t)n_high, ncclFloat64, peer_high, _comm, stream), "ncclSend");
-      rccl_check(r.Recv(recv_high, (size_t)n_high, ncclFloat64, peer_high, _comm, stream), "ncclRecv");
+      rccl_check(r.Send(send_high, (size_t)n_high, ncclFloat64, peer_high, comm, stream), "ncclSend");
+      rccl_check(r.Recv(recv_high, (size_t)n_high, ncclFloat64, peer_high, comm, stream), "ncclRecv");
     }
     rccl_check(r.GroupEnd(), "ncclGroupEnd");
   }
@@ -134,12 +160,13 @@ public:
     if (n <= 0)
       return;
     RcclApi &r = rccl();
+    ncclComm_t comm = comm_for(stream);
     rccl_check(r.GroupStart(), "ncclGroupStart");
     for (int i = 0; i < n; ++i)
       if (count[i] > 0)
       {
-        rccl_check(r.Send(send[i], (size_t)count[i], ncclFloat64, peers[i], _comm, stream), "ncclSend");
-        rccl_check(r.Recv(recv[i], (size_t)count[i], ncclFloat64, peers[i], _comm, stream), "ncclRecv");
+        rccl_check(r.Send(send[i], (size_t)count[i], ncclFloat64, peers[i], comm, stream), "ncclSend");
+        rccl_check(r.Recv(recv[i], (size_t)count[i], ncclFloat64, peers[i], comm, stream), "ncclRecv");
       }
     rccl_check(r.GroupEnd(), "ncclGroupEnd");
   }
@@ -168,7 +195,8 @@ public:
 
 private:
   int _rank;
-  ncclComm_t _comm = nullptr;
+  ncclComm_t _comm = nullptr, _comm_x = nullptr;
+  hipStream_t _exchange_stream = nullptr;
   DeviceBuffer<double> _scalars;
 };
 
@@ -258,6 +286,7 @@ public:
     MFMG_HIP_CHECK(hipMemcpyAsync(recv, send, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
   }
   char const *name() const override { return "host"; }
+  int comm_ranks() const override { return _n; }
 
 private:
   void reserve(int64_t n)
@@ -324,6 +353,7 @@ public:
     MFMG_HIP_CHECK(hipMemcpyAsync(recv, send, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
   }
   char const *name() const override { return "reflecting"; }
+  int comm_ranks() const override { return _n; }
 
 private:
   int _n;

@@ -642,9 +642,8 @@ void HipMatrixFreeOperator::apply_mode(MfMode mode, double const *x, double cons
   // interior, then the shell slab by slab (five launches, each a fraction of a round of workgroups and as long as one workgroup
   // lives: rounds 1-3) 290; interior, then the shell as one launch ("MFMG_MF_SHELL=after") 236; beside each other 218.
   // Same tiles, same bits (owner computes).  "MFMG_MF_SHELL=slabs" keeps the old launches for that comparison.
-  // (read at every application: a test switches between the variants inside one process)
-  const std::string shell_env = std::getenv("MFMG_MF_SHELL") ? std::getenv("MFMG_MF_SHELL") : "";
-  const bool shell_slabs = shell_env == "slabs", shell_after = shell_env == "after";
+  // (HipHandle::mf_shell_mode: a test switches between the variants inside one process through the context)
+  const bool shell_slabs = handle.mf_shell_mode == 2, shell_after = handle.mf_shell_mode == 1;
   // concurrent: the shell launch goes to the exchange stream, behind the unpacking, and runs BESIDE the interior tiles (its
   // workgroups fill the slots the interior launch leaves free while it drains); `stream` joins afterwards.  The two launches
   // write disjoint DoFs and read x, b and x_prev only (a term that overwrites its own x_prev reads and writes it DoF by DoF).
@@ -680,16 +679,15 @@ void HipMatrixFreeOperator::apply_mode(MfMode mode, double const *x, double cons
     // (measurement only: the launches of the corner rank of a 2 x 2 x 2 grid -- one neighbour on the high side of every
     // axis -- without the exchange)
     // ("1" / "xyz": 2 x 2 x 2; "yz": 1 x 2 x 2; "z": 1 x 1 x 2 -- the grids of the weak-scaling run at 8, 4 and 2 ranks)
-    const std::string emu = std::getenv("MFMG_MF_EMULATE_SPLIT") ? std::getenv("MFMG_MF_EMULATE_SPLIT") : "";
-    const bool emulate = emu == "1" || emu == "xyz" || emu == "yz" || emu == "z";
-    if (emulate && op->dim() == 3)
+    const int emu = handle.mf_emulate_split; // 1 = z, 2 = yz, 3 = xyz
+    if (emu > 0 && op->dim() == 3)
     {
       int nt[3], rows[3];
       op->tiling(nt, rows);
       if (nt[0] >= 2 && nt[1] >= 2 && nt[2] >= 2)
       {
         const int lo[3] = {0, 0, 0};
-        const int hi[3] = {nt[0] - ((emu == "1" || emu == "xyz") ? 1 : 0), nt[1] - (emu == "z" ? 0 : 1), nt[2] - 1};
+        const int hi[3] = {nt[0] - (emu == 3 ? 1 : 0), nt[1] - (emu == 1 ? 0 : 1), nt[2] - 1};
         handle.fork_exchange_stream(); // (what an exchange_begin does to the two streams, without the exchange)
         op->launch_tiles(mode, x, b, x_prev, alpha, beta, out, lo, hi, true, false);
         shell(lo, hi, nt);

@@ -540,7 +540,7 @@ __global__ __launch_bounds__(512, 2) void mf_cheb_fused_kernel(MfFusedArgs<T> a)
 template <typename T>
 bool MatrixFreeLaplaceDevice<T>::fused_sweep_available(int n_terms) const
 {
-  return _dim == 3 && _compact && _affine_ids && !_tail && n_terms >= 2 && n_terms <= 3 && _halo >= n_terms && !_handle.comm.enabled() &&
+  return _dim == 3 && _compact && _affine_ids && !_tail && n_terms >= 1 && n_terms <= 3 && _halo >= n_terms && !_handle.comm.enabled() &&
          _affine.ghost_low == 0 && _affine.ghost_high == 0 && (uint64_t)_rec.size() <= 0xffffffffull;
 }
 
@@ -653,8 +653,12 @@ void MatrixFreeLaplaceDevice<T>::smoother_sweep(int n_terms, T const *alpha, T c
   const size_t lds = ((size_t)nw * ring_planes(n_terms) * (ty + 1) + (size_t)2 * nw * 4) * 64 * sizeof(T);
   ASSERT_THROW(lds <= 160 * 1024, "tile of the multi-term sweep too large for the LDS");
   hipStream_t st = _handle.stream;
-  // bytes the layout requires: x_0, b, the coefficient (one per cell), x_K (+ x_{K-1}); ids are computed
-  const double bytes = double(_n_dofs) * sizeof(T) * (4. + (out_prev ? 1. : 0.));
+  // Algorithmic bytes of the launch: what its n_terms smoother terms require as launches of their own (x, out, one id, the
+  // coefficient, b, x_prev: mf_laplace.hpp) -- the figure the one-term kernel is priced on, so that the two compare.  What the
+  // sweep itself must move is fused_sweep_bytes(): x_0, b, the coefficient, x_K (+ x_{K-1}), the ids computed.
+  double bytes = 0.;
+  for (int k = 0; k < n_terms; ++k)
+    bytes += required_bytes_apply() + epilogue_bytes(k == 0 ? 2 : 3);
   hipEvent_t stop = _handle.profiler.begin("mf_cheb_fused_kernel", bytes, st);
   auto go = [&](auto kernel) {
     static std::mutex attr_mutex;
@@ -685,6 +689,13 @@ void MatrixFreeLaplaceDevice<T>::smoother_sweep(int n_terms, T const *alpha, T c
       go(mf_cheb_fused_kernel<T, 3, 3, false, 1>);
     else
       go(mf_cheb_fused_kernel<T, 3, 3, false, 2>);
+  }
+  else if (n_terms == 1)
+  {
+    if (_dinv_in_record)
+      pick(IntTag<1>{}, IntTag<1>{});
+    else
+      pick(IntTag<1>{}, IntTag<0>{});
   }
   else if (n_terms == 2)
   {

@@ -109,6 +109,8 @@ public:
   }
   void get_fused_tile(int n_terms, int &nw, int &ty, int &tz) const { choose_fused_tile(n_terms, nw, ty, tz); }
   int halo_lanes() const { return _halo; }
+  // bytes one sweep of n_terms must move at least: x_0, b, one coefficient per cell (D^-1 where the records hold it), x_K
+  double fused_sweep_bytes(bool with_prev) const { return double(_n_dofs) * sizeof(T) * (4. + (_dinv_in_record ? 1. : 0.) + (with_prev ? 1. : 0.)); }
 
   T const *diagonal() const { return _diag.data(); }
   T const *diagonal_inverse() const { return _dinv.data(); }

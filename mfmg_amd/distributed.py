@@ -148,15 +148,16 @@ class SlabPartition(BoxPartition):
 
 
 def box_grid(n_ranks: int) -> tuple:
-    """The grid of SURVEY.md 8e for a rank count: 2 x 1 x 1, 2 x 2 x 1, 2 x 2 x 2; otherwise as cubic as the factors allow
-    (x fastest), slabs for a prime count."""
+    """The grid (ranks along x, y, z) of SURVEY.md 8e for a rank count, split along z FIRST -- 1 x 1 x 2, 1 x 2 x 2, 2 x 2 x 2: the
+    grid the weak-scaling mesh of bench.py grows by (z, then y, then x; the boundary layers of a z-split are contiguous runs of the
+    vector and travel without packing); otherwise as cubic as the factors allow, slabs along z for a prime count."""
     grid = [1, 1, 1]
     n, d = int(n_ranks), 0
     f = 2
     while n > 1:
         while n % f:
             f += 1
-        grid[d % 3] *= f
+        grid[2 - d % 3] *= f
         n //= f
         d += 1
     return tuple(grid)
@@ -358,6 +359,12 @@ class HaloTransport:
         e = C.c_double()
         check(self._lib.mfmg_hip_context_transport_selftest(self.ctx.handle, n, C.byref(e)))
         return e.value
+
+    def comm_ranks(self) -> int:
+        """Ranks the transport's own communicator reports (RCCL: ncclCommCount)."""
+        n = C.c_int()
+        check(self._lib.mfmg_hip_context_transport_ranks(self.ctx.handle, C.byref(n)))
+        return n.value
 
     def name(self) -> str:
         buf = C.create_string_buffer(32)

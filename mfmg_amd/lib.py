@@ -114,6 +114,7 @@ def load() -> C.CDLL:
         "mfmg_hip_context_use_host_transport": (C.c_int, [vp, vp, vp, vp, vp]),
         "mfmg_hip_context_use_reflecting_transport": (C.c_int, [vp]),
         "mfmg_hip_context_transport_name": (C.c_int, [vp, C.c_char_p, sz]),
+        "mfmg_hip_context_transport_ranks": (C.c_int, [vp, P(C.c_int)]),
         "mfmg_hip_context_exchange_count": (C.c_int, [vp, P(i64)]),
         "mfmg_hip_context_transport_selftest": (C.c_int, [vp, i64, P(dbl)]),
         "mfmg_hip_context_exchange": (C.c_int, [vp, i32, vp, C.c_int]),
@@ -125,6 +126,8 @@ def load() -> C.CDLL:
         "mfmg_hip_context_set_stored_diagonal": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_mf_laplace_diagonal_in_record": (C.c_int, [vp, P(C.c_int)]),
         "mfmg_hip_context_set_mf_fused_terms": (C.c_int, [vp, C.c_int]),
+        "mfmg_hip_context_set_mf_shell": (C.c_int, [vp, C.c_int]),
+        "mfmg_hip_context_set_mf_emulate_split": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_mf_laplace_sweep_available": (C.c_int, [vp, C.c_int, P(C.c_int)]),
         "mfmg_hip_mf_laplace_smoother_sweep": (C.c_int, [vp, C.c_int, P(dbl), P(dbl), vp, vp, vp, vp]),
         "mfmg_hip_mf_laplace_set_sweep_tile": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),

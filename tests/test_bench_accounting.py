@@ -29,6 +29,14 @@ def test_smoother_bytes_per_dof():
     assert bench.smoother_bytes_per_dof(1, 8, True, False) == 36      # Jacobi
 
 
+def test_survey_figures_are_the_surveys():
+    # 112 B/DoF per operator application, + 32 per fused smoother term, 432 per Chebyshev(3) apply -- printed
+    # under `survey_8d_*` whatever the layout of the operator at hand reads
+    assert bench.survey_8d_bytes_per_dof(3) == {"operator": 112, "smoother_term": 144, "smoother_apply": 432}
+    assert bench.survey_8d_bytes_per_dof(1)["smoother_apply"] == 144
+    assert bench.survey_8d_bytes_per_dof(3, word=4)["operator"] == 72
+
+
 def test_chebyshev_coefficients_first_term():
     c = bench.smoother_coefficients(3, 0.09, 1.8)
     assert len(c) == 3 and c[0][0] == 0.0 and abs(c[0][1] - 1.0 / 0.945) < 1e-15

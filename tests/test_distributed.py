@@ -71,7 +71,7 @@ def test_box_partition_geometry(mfmg_lib):
         assert (flags[own] != 2).all() and (flags[~own] != 0).all()
         assert np.array_equal(p.local_global_index().numpy()[p.owned_local_index().numpy()], p.owned_global_index().numpy())
     assert (covered == 1).all()
-    assert M.box_grid(2) == (2, 1, 1) and M.box_grid(4) == (2, 2, 1) and M.box_grid(8) == (2, 2, 2) and M.box_grid(3) == (3, 1, 1)
+    assert M.box_grid(2) == (1, 1, 2) and M.box_grid(4) == (1, 2, 2) and M.box_grid(8) == (2, 2, 2) and M.box_grid(3) == (1, 1, 3)
     with pytest.raises(ValueError):
         M.BoxPartition((10, 8, 8), 0, (2, 1, 1))
     # doubles one rank sends per fine exchange, 512^3 cells on 8 ranks: three faces of 256^2 (+ three edges and a corner)

@@ -800,7 +800,7 @@ def test_residual_restriction_in_one_pass(ctx, monkeypatch, n, material, evaluat
     assert np.abs(hist[0] - hist[1]).max() <= 1e-12 * np.abs(x0).max()
 
 
-@pytest.mark.parametrize("material", ["constant", "linear"])
+@pytest.mark.parametrize("material", ["constant", "linear", "discontinuous", "linear_x"])
 def test_full_size_vcycle_history_against_the_native_oracle(ctx, material):
     """Parity AT THE SIZE THE BENCH QUOTES (BASELINE.json: 256^3 cells = 257^3 DoFs per GPU, Chebyshev(3), multilevel
     coarse solve): the harness of /root/reference/tests/test_hierarchy.cc:76-123 (x0 random with the constrained
@@ -838,9 +838,13 @@ def test_full_size_vcycle_history_against_the_native_oracle(ctx, material):
     res_g, x_g = gpu_history(ctx, h, lambda y, x: op.vmult(y, x), b, x0, n_cycles=cycles)
     np.testing.assert_allclose(res_g, res_o, rtol=HIST_TOL, atol=HIST_ATOL)
     assert np.abs(x_g - x_o).max() <= 1e-10 * np.abs(x0).max()
-    assert res_o[-1] / res_o[-2] < 0.4
+    assert res_o[-1] / res_o[-2] < (0.4 if material != "discontinuous" else 0.7)
     del h
     torch.cuda.empty_cache()
+    if material in ("discontinuous", "linear_x"):
+        # (the other two of the reference's four materials, /root/reference/tests/test_hierarchy_helpers.hpp:75-188 as exercised at
+        # tests/test_hierarchy.cc:644-695: the matrix-free cycle at full size; the assembled and FP32 legs run on the first two)
+        return
     # BASELINE.json configs[2] at its size: the SAME cycle with the ASSEMBLED fine operator (HipMeshEvaluator: CSR matrix of
     # 27 entries per row formed on the device, Chebyshev(3) through the SpMV kernels, R A R^T by probing).  With b = 0
     # and x0 = 0 on the Dirichlet DoFs the assembled rows (diagonal kept) and the matrix-free ones (identity) generate the
@@ -877,6 +881,66 @@ def test_full_size_vcycle_history_against_the_native_oracle(ctx, material):
             op.vmult(r, xf.double())
             res_f.append(ctx.l2_norm(r) / r0)
         np.testing.assert_allclose(res_f, res_of, rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("material,stored_diagonal", [("constant", False), ("constant", True), ("linear", False)])
+def test_smoother_apply_at_512cubed_against_the_native_oracle(ctx, material, stored_diagonal):
+    """Oracle parity WHERE north_star QUOTES ITS TARGET: the fine-level Chebyshev(3) smoother apply at 512^3 DoFs, the three
+    layouts of the bench (one coefficient per cell with D^-1 derived in the kernel / kept in the records; eight coefficients per
+    cell), as the product runs it (one sweep over the mesh where the operator offers it, else a launch per term), against
+    oracle_native's operator and diagonal composed into the reference's smoother wrapper
+    (/root/reference/source/dealii/dealii_matrix_free_smoother.cc:63-76: r = A x - b, tmp = B^-1 r, x -= tmp, B^-1 the Chebyshev
+    polynomial; the three-term form on x is that order to rounding, tests/test_oracle_fixtures.py) -- three operator applications
+    on the host cores, 1e-12 of the iterate's max-norm."""
+    import psutil
+    import oracle_native as ON
+    if psutil.virtual_memory().available < 60e9:
+        pytest.skip("needs ~50 GB of host memory for the 511^3-cell mesh arrays and the vectors of the oracle")
+    from bench import smoother_coefficients
+    n = (511, 511, 511)
+    prob = M.LaplaceProblem(n, material, device="cuda")
+    ctx.set_stored_diagonal(stored_diagonal)
+    try:
+        op = M.MatrixFreeLaplace(ctx, prob)
+    finally:
+        ctx.set_stored_diagonal(False)
+    assert op.cell_constant_layout() == (material == "constant")
+    assert op.diagonal_in_record() == (stored_diagonal or material != "constant")
+    N = prob.n_dofs
+    coefs = smoother_coefficients(3, 0.09, 1.8)
+    rng = np.random.default_rng(3)
+    x0 = rng.random(N)          # nonzero on the Dirichlet DoFs too: identity rows
+    b = rng.random(N)
+    xg, bg = dev(x0), dev(b)
+    out = torch.empty_like(xg)
+    if op.sweep_available(3):
+        op.smoother_sweep([c[0] for c in coefs], [c[1] for c in coefs], bg, xg, out)
+    else:
+        s1, s2 = torch.empty_like(xg), torch.empty_like(xg)
+        op.smoother_step(bg, xg, None, coefs[0][0], coefs[0][1], s1)
+        op.smoother_step(bg, s1, xg, coefs[1][0], coefs[1][1], s2)
+        op.smoother_step(bg, s2, s1, coefs[2][0], coefs[2][1], out)
+        del s1, s2
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    del xg, bg, out, op
+    torch.cuda.empty_cache()
+    cd = prob.cell_dofs.cpu().numpy()
+    co = prob.coefficient.cpu().numpy()
+    cn = prob.constrained.cpu().numpy()
+    del prob
+    torch.cuda.empty_cache()
+    dinv = 1.0 / ON.mf_diagonal(n, (1.0 / 511,) * 3, cd, co, cn)
+    cur, prev = x0, None
+    for al, be in coefs:
+        r = ON.mf_apply(n, (1.0 / 511,) * 3, cd, co, cn, cur)
+        r -= b
+        r *= dinv
+        nxt = cur - be * r
+        if prev is not None:
+            nxt += al * (cur - prev)
+        prev, cur = cur, nxt
+    assert np.abs(got - cur).max() <= 1e-12 * np.abs(cur).max()
 
 
 @pytest.mark.parametrize("evaluator,n,material", [("HipMeshEvaluator", (8, 8), "constant"), ("HipMeshEvaluator", (8, 6, 4), "linear"),
@@ -1112,12 +1176,18 @@ def test_hierarchy_driver_example(ctx, tmp_path, dim, matrix_free, preconditione
 def test_interior_and_shell_launches_change_no_bit(ctx, monkeypatch, n, material):
     """A rank of a box decomposition applies its fine operator as two launches -- the tiles that read no ghost plane, and the
     shell around them (one launch over a compact tile list, on the exchange stream beside the interior tiles).  The same
-    launches can be produced on ONE rank (MFMG_MF_EMULATE_SPLIT: the corner rank of a 2 x 2 x 2 grid, no exchange; the
+    launches can be produced on ONE rank (Context.set_mf_emulate_split: the corner rank of a 2 x 2 x 2 grid, no exchange; the
     measurement of DESIGN.md section 7 uses it): every variant -- concurrent, one after the other, the slab-by-slab launches
     of the first box version -- must reproduce the single launch bit for bit, cycle after cycle."""
     prob = M.LaplaceProblem(n, material, device="cuda")
-    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0}, solver={"type": "pcg", "n_iterations": 4})
-    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    # (one smoother term per launch and chunk records with one halo lane: the layout and launches of a distributed rank)
+    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0, "fused_terms": 1},
+                         solver={"type": "pcg", "n_iterations": 4})
+    ctx.set_mf_fused_terms(1)
+    try:
+        h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+    finally:
+        ctx.set_mf_fused_terms(3)
     h.set_operator_tile(2, 2, 4)          # several column, y- and z-tiles on these small meshes
     rng = np.random.default_rng(12)
     x0 = dev(rng.random(prob.n_dofs) * (prob.constrained.cpu().numpy() != 1))
@@ -1133,12 +1203,15 @@ def test_interior_and_shell_launches_change_no_bit(ctx, monkeypatch, n, material
         return x.clone(), r.clone()
 
     ref = run()
-    monkeypatch.setenv("MFMG_MF_EMULATE_SPLIT", "1")
-    for variant in ("", "after", "slabs"):
-        if variant:
-            monkeypatch.setenv("MFMG_MF_SHELL", variant)
-        out = run()
-        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), variant or "concurrent"
+    try:
+        ctx.set_mf_emulate_split("xyz")
+        for variant in ("beside", "after", "slabs"):
+            ctx.set_mf_shell(variant)
+            out = run()
+            assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), variant
+    finally:
+        ctx.set_mf_emulate_split(None)
+        ctx.set_mf_shell("beside")
 
 
 @pytest.mark.parametrize("cells", [32, 64])

@@ -297,10 +297,20 @@ def test_mf_cell_constant_layout(ctx, material, expect):
     assert relerr(outs[0], outs[1]) < 1e-13
 
 
+@pytest.mark.parametrize("halo_lanes", [1, 3])
 @pytest.mark.parametrize("nw,ty,tz", [(0, 0, 0), (1, 2, 1), (4, 3, 8), (2, 5, 2), (4, 4, 3)])
-def test_mf_tail_slab_all_modes_and_renumbering(ctx, nw, ty, tz):
-    """The rotated slab of the tail columns (cell-wise constant coefficient, 67 node columns = 63 + 4): every fused
-    mode, a random DoF numbering, Dirichlet and interior nodes, tile independence."""
+def test_mf_tail_slab_all_modes_and_renumbering(ctx, nw, ty, tz, halo_lanes):
+    """The rotated slab of the tail columns (cell-wise constant coefficient, 67 node columns = 63 + 4; chunk records with one
+    halo lane -- with three, the layout of the multi-term sweep, the columns are spread evenly and there is no slab): every
+    fused mode, a random DoF numbering, Dirichlet and interior nodes, tile independence."""
+    ctx.set_mf_fused_terms(halo_lanes)
+    try:
+        _tail_slab_case(ctx, nw, ty, tz)
+    finally:
+        ctx.set_mf_fused_terms(3)
+
+
+def _tail_slab_case(ctx, nw, ty, tz):
     n = (66, 67, 4)
     mesh = O.StructuredMesh(n)
     rng = np.random.default_rng(31)
@@ -334,6 +344,112 @@ def test_mf_tail_slab_all_modes_and_renumbering(ctx, nw, ty, tz):
     op.set_tile(3, 2, 2)
     op.smoother_step(dev(to_dof(b)), dev(to_dof(x)), None, 0.0, 0.45, out)
     assert np.array_equal(host(out, ctx), first)
+
+
+# ---- several smoother terms in one sweep (mf_cheb_fused.hip) -----------------------------------------------------------
+def _cellwise_problem(n, seed=7):
+    prob = M.LaplaceProblem(n, "constant", device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    prob.coefficient = (0.5 + torch.rand(prob.n_cells_total, 1, dtype=torch.float64, device="cuda", generator=g)).expand(-1, 8).contiguous()
+    return prob
+
+
+SWEEP_COEFS = [(0.0, 0.61), (0.23, 0.87), (0.31, 0.79)]     # (alpha, beta) of three Chebyshev-like terms
+
+
+@pytest.mark.parametrize("n,material", [((6, 5, 7), "constant"), ((20, 17, 9), "cellwise"), ((70, 30, 20), "constant"),
+                                        ((130, 40, 33), "cellwise")])
+@pytest.mark.parametrize("n_terms", [2, 3])
+@pytest.mark.parametrize("tile", [None, (4, 3, 8), (8, 3, 5), (2, 4, 7), (8, 2, 64), (1, 4, 3)])
+def test_smoother_sweep_equals_term_by_term_bit_for_bit(ctx, n, material, n_terms, tile):
+    """2 or 3 smoother terms in one sweep over the mesh == the same terms as one launch each, bit for bit, for every
+    tiling of the sweep (owner computes; same cell kernel and summation order; source/dealii/dealii_matrix_free_smoother.cc:63-76)."""
+    if tile is not None and tile[0] * tile[1] - 2 * n_terms + 1 < 1:
+        pytest.skip("tile smaller than its halo rows")
+    prob = _cellwise_problem(n) if material == "cellwise" else M.LaplaceProblem(n, material, device="cuda")
+    op = M.MatrixFreeLaplace(ctx, prob)
+    assert op.sweep_available(n_terms)
+    N = prob.n_dofs
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    x = torch.rand(N, dtype=torch.float64, device="cuda", generator=g)          # nonzero on the Dirichlet DoFs too
+    b = torch.rand(N, dtype=torch.float64, device="cuda", generator=g)
+    al = [c[0] for c in SWEEP_COEFS][:n_terms]
+    be = [c[1] for c in SWEEP_COEFS][:n_terms]
+    its = [x]
+    for k in range(n_terms):
+        o = torch.full_like(x, float("nan"))
+        op.smoother_step(b, its[-1], its[-2] if k > 0 else None, al[k], be[k], o)
+        its.append(o)
+    if tile is not None:
+        op.set_sweep_tile(*tile)
+    out = torch.full_like(x, float("nan"))
+    outp = torch.full_like(x, float("nan"))
+    op.smoother_sweep(al, be, b, x, out, outp)
+    ctx.synchronize()
+    assert torch.equal(out, its[-1])
+    assert torch.equal(outp, its[-2])
+    out2 = torch.full_like(x, float("nan"))
+    op.smoother_sweep(al, be, b, x, out2, None)           # without the second output
+    ctx.synchronize()
+    assert torch.equal(out2, its[-1])
+
+
+def test_smoother_sweep_against_the_oracle_and_other_layouts(ctx):
+    """The three-term sweep against the oracle's operator (1e-12), with D^-1 kept in the records, in FP32, and refused where
+    the operator cannot run it (eight coefficients per cell, a random numbering, one halo lane)."""
+    n = (40, 33, 21)
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "constant")
+    ref = O.MatrixFreeLaplace(mesh, coef)
+    rng = np.random.default_rng(5)
+    x, b = rng.random(mesh.n_dofs), rng.random(mesh.n_dofs)
+    dinv = ref.diagonal_inverse()
+    al = [c[0] for c in SWEEP_COEFS]
+    be = [c[1] for c in SWEEP_COEFS]
+    want, prev = x, None
+    for k in range(3):
+        nxt = want + (al[k] * (want - prev) if prev is not None else 0.0) - be[k] * dinv * (ref.vmult(want) - b)
+        prev, want = want, nxt
+    prob = M.LaplaceProblem(n, "constant", device="cuda")
+    op = M.MatrixFreeLaplace(ctx, prob)
+    out = torch.empty(mesh.n_dofs, dtype=torch.float64, device="cuda")
+    op.smoother_sweep(al, be, dev(b), dev(x), out)
+    assert relerr(host(out, ctx), want) < TOL
+    ctx.set_stored_diagonal(True)
+    try:
+        op_stored = M.MatrixFreeLaplace(ctx, prob)
+    finally:
+        ctx.set_stored_diagonal(False)
+    assert op_stored.diagonal_in_record()
+    out_s = torch.empty_like(out)
+    op_stored.smoother_sweep(al, be, dev(b), dev(x), out_s)
+    assert relerr(host(out_s, ctx), want) < TOL
+    op32 = M.MatrixFreeLaplaceF32(ctx, prob)
+    assert op32.sweep_available(3)
+    o32 = torch.empty(mesh.n_dofs, dtype=torch.float32, device="cuda")
+    x32, b32 = dev(x).float(), dev(b).float()
+    op32.smoother_sweep(al, be, b32, x32, o32)
+    t32 = [x32]
+    for k in range(3):
+        o = torch.empty_like(x32)
+        op32.smoother_step(b32, t32[-1], t32[-2] if k > 0 else None, al[k], be[k], o)
+        t32.append(o)
+    ctx.synchronize()
+    assert torch.equal(o32, t32[-1])
+    # refused: eight coefficients per cell, a numbering the kernel cannot compute, records with one halo lane
+    assert not M.MatrixFreeLaplace(ctx, M.LaplaceProblem(n, "linear", device="cuda")).sweep_available(3)
+    perm = torch.from_numpy(rng.permutation(mesh.n_dofs))
+    assert not M.MatrixFreeLaplace(ctx, M.LaplaceProblem(n, "constant", device="cuda", dof_numbering=perm)).sweep_available(2)
+    ctx.set_mf_fused_terms(1)
+    try:
+        op1 = M.MatrixFreeLaplace(ctx, prob)
+    finally:
+        ctx.set_mf_fused_terms(3)
+    assert not op1.sweep_available(2)
+    with pytest.raises(L.MfmgNotImplementedError):
+        op1.smoother_sweep(al, be, dev(b), dev(x), out)
 
 
 @pytest.mark.parametrize("n,material,numbering", [((8, 8), "constant", "lexicographic"), ((12, 7), "linear", "random"),
