@@ -460,6 +460,29 @@ struct HipHandle
   DeviceBuffer<double> halo_staging, halo_staging_comm;
   int64_t halo_staging_each = 0, halo_staging_comm_each = 0;
   DeviceBuffer<double> dot_scratch; // owned entries of two box vectors, packed for a dot product
+  // The right-hand side of the cycle in flight (Hierarchy::apply -> Operator::prefetch_rhs): the vector whose ghost entries are
+  // travelling on the exchange stream / are known to be fresh until the cycle ends (release_rhs).  The multi-term smoother sweep
+  // and the one-pass residual restriction both read b at ghost DoFs; outside a cycle both exchange it themselves.
+  double const *rhs_in_flight = nullptr, *rhs_fresh = nullptr, *rhs_of_cycle = nullptr;
+  bool rhs_ghosts_wanted = false; // the fine smoother of this context reads b at ghost DoFs (distributed multi-term sweep)
+  // make the ghost entries of the fine-level vector b current on `stream`
+  void need_rhs_ghosts(double const *b)
+  {
+    if (!comm.enabled())
+      return;
+    if (rhs_in_flight == b)
+    {
+      exchange_async_wait();
+      rhs_fresh = b;
+      rhs_in_flight = nullptr;
+    }
+    else if (rhs_fresh != b)
+    {
+      exchange(1, const_cast<double *>(b));
+      if (rhs_of_cycle == b) // (fresh only while the cycle that announced this vector is running)
+        rhs_fresh = b;
+    }
+  }
 
   HaloSpace &space_checked(int space)
   {

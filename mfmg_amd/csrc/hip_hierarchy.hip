@@ -425,10 +425,8 @@ bool HipMatrixOperator::restrict_residual(Operator<DVector> const &a, DVector co
   // distributed runs: two exchanges as in the two-step form (there: x for the residual, the residual for R) -- here x two
   // layers deep and b one layer deep
   hd.exchange(_rr_space, const_cast<double *>(x.get_values()));
-  if (_prefetched_rhs == b.get_values())
-    hd.exchange_async_wait(); // (the ghost entries of b left at the start of the cycle: prefetch_rhs)
-  else
-    hd.exchange(_domain_space, const_cast<double *>(b.get_values()));
+  // (the ghost entries of b left at the start of the cycle, prefetch_rhs; the pre-smoother may have waited for them already)
+  hd.need_rhs_ghosts(b.get_values());
   _prefetched_rhs = nullptr;
   _structured->restrict_residual(x.get_values(), b.get_values(), b_coarse.get_values());
   return true;
@@ -441,11 +439,24 @@ void HipMatrixOperator::prefetch_rhs(DVector const &b) const
 {
   _prefetched_rhs = nullptr;
   HipHandle &hd = _matrix->handle();
-  if (!hd.comm.enabled() || !hd.overlap_exchange || _domain_space <= 0 || !_rr_operator || !_structured ||
-      !_structured->has_residual_restriction() || b.size() != _matrix->n())
+  hd.rhs_in_flight = hd.rhs_fresh = nullptr;
+  hd.rhs_of_cycle = b.get_values();
+  const bool restriction_reads_it = _rr_operator && _structured && _structured->has_residual_restriction();
+  if (!hd.comm.enabled() || !hd.overlap_exchange || _domain_space <= 0 || b.size() != _matrix->n() ||
+      !(restriction_reads_it || hd.rhs_ghosts_wanted))
     return;
   hd.exchange_async(_domain_space, const_cast<double *>(b.get_values()));
-  _prefetched_rhs = b.get_values();
+  hd.rhs_in_flight = b.get_values();
+  if (restriction_reads_it)
+    _prefetched_rhs = b.get_values();
+}
+
+void HipMatrixOperator::release_rhs() const
+{
+  HipHandle &hd = _matrix->handle();
+  if (hd.rhs_in_flight != nullptr)
+    hd.exchange_async_wait(); // (nobody read the ghost entries: the exchange must still be over before the caller touches b)
+  hd.rhs_in_flight = hd.rhs_fresh = hd.rhs_of_cycle = nullptr;
 }
 
 bool HipMatrixOperator::restrict_residual_f32(Operator<DVector> const &a, float const *x, float const *b, DVector &b_coarse) const
@@ -807,6 +818,19 @@ bool HipMatrixFreeOperator::smoother_sweep(int n_terms, double const *alpha, dou
   auto op = _mesh_evaluator->get_device_operator();
   if (!op->fused_sweep_available(n_terms))
     return false;
+  HipHandle &handle = get_hip_handle();
+  if (handle.comm.enabled())
+  {
+    // Distributed: term s of the sweep is right where the whole stencil of term s - 1 was, so the rank computes the ghost DoFs
+    // next to its box redundantly: x travels n_terms ghost planes deep (ONE exchange for the n_terms terms instead of one each),
+    // b n_terms - 1 planes deep -- as much as the local mesh holds (one agglomerate = two cell layers per neighbour: two terms).
+    handle.rhs_ghosts_wanted = true;
+    HaloSpace deep = handle.comm.spaces[1];
+    deep.width = n_terms;
+    handle.exchange_on(deep, const_cast<double *>(x.get_values()), handle.stream, handle.stream, false);
+    ASSERT_THROW(n_terms <= 2, "internal: the right-hand side is exchanged one plane deep");
+    handle.need_rhs_ghosts(b.get_values());
+  }
   op->smoother_sweep(n_terms, alpha, beta, b.get_values(), x.get_values(), out.get_values(), out_prev ? out_prev->get_values() : nullptr);
   return true;
 }

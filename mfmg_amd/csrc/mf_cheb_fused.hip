@@ -141,7 +141,7 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
   const bool lane_in = ci >= 0 && ci < a.Nx;
   const bool lane_face = ((a.aff.faces & 1) && ci == 0) || ((a.aff.faces & 2) && ci == a.Nx - 1);
   const bool lane_free = lane_in && !lane_face;
-  const bool col_owned = lane >= a.halo && lane < a.halo + a.own && ci < a.Nx;
+  const bool col_owned = lane >= a.halo && lane < a.halo + a.own && ci < a.Nx - a.aff.ghost_hi[0] && ci >= a.aff.ghost_lo[0]; // (ghost DoFs: computed, never written)
   const int RY = NW * TY - 2 * K + 1;    // DoF rows a tile owns
   const int Yw = tyi * RY - K + wv * TY; // first node row of this wavefront: node rows Yw .. Yw + TY, cell rows Yw .. Yw + TY - 1
   const int own_y0 = tyi * RY, own_y1 = min(own_y0 + RY, a.Ny);
@@ -186,7 +186,7 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
     const bool real = j >= 0 && j < a.Ny;
     if (real && !(((a.aff.faces & 4) && j == 0) || ((a.aff.faces & 8) && j == a.Ny - 1)))
       rows_free |= 1u << r;
-    if (r < TY && j >= own_y0 && j < own_y1) // (the node row two wavefronts share is stored by the upper one)
+    if (r < TY && j >= own_y0 && j < own_y1 && j >= a.aff.ghost_lo[1] && j < a.Ny - a.aff.ghost_hi[1]) // (the node row two wavefronts share is stored by the upper one)
       rows_own |= 1u << r;
   }
   // descriptors and uniform byte offsets: node row r / node layer n of a vector (clamped into the mesh), cell row q / layer n
@@ -199,7 +199,7 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
   const unsigned int rec_layer = (unsigned int)a.Ny * rec_row;
   const unsigned int rec_col = (unsigned int)tc * a.rec_bytes;
   auto layer_free = [&](int n) { return n >= 0 && n < a.Nz && !(((a.aff.faces & 16) && n == 0) || ((a.aff.faces & 32) && n == a.Nz - 1)); };
-  auto layer_own = [&](int n) { return n >= Z0 && n < Z1 && n >= a.aff.ghost_low && n < a.Nz - a.aff.ghost_high; };
+  auto layer_own = [&](int n) { return n >= Z0 && n < Z1 && n >= a.aff.ghost_lo[2] && n < a.Nz - a.aff.ghost_hi[2]; };
   auto vec_off = [&](int r, int n) -> unsigned int {
     return (unsigned int)min(max(Yw + r, 0), a.Ny - 1) * row_stride + (unsigned int)min(max(n, 0), a.Nz - 1) * layer_stride;
   };
@@ -540,8 +540,13 @@ __global__ __launch_bounds__(512, 2) void mf_cheb_fused_kernel(MfFusedArgs<T> a)
 template <typename T>
 bool MatrixFreeLaplaceDevice<T>::fused_sweep_available(int n_terms) const
 {
-  return _dim == 3 && _compact && _affine_ids && !_tail && n_terms >= 1 && n_terms <= 3 && _halo >= n_terms && !_handle.comm.enabled() &&
-         _affine.ghost_low == 0 && _affine.ghost_high == 0 && (uint64_t)_rec.size() <= 0xffffffffull;
+  if (!(_dim == 3 && _compact && _affine_ids && !_tail && n_terms >= 1 && n_terms <= 3 && _halo >= n_terms && (uint64_t)_rec.size() <= 0xffffffffull))
+    return false;
+  // a side with ghost planes (a neighbouring rank) must hold n_terms of them: the sweep computes them redundantly
+  for (int d = 0; d < 3; ++d)
+    if ((_affine.ghost_lo[d] > 0 && _affine.ghost_lo[d] < n_terms) || (_affine.ghost_hi[d] > 0 && _affine.ghost_hi[d] < n_terms))
+      return false;
+  return true;
 }
 
 // tile of the sweep: NW wavefronts of TY cell rows, TZ owned layers.  One workgroup of eight wavefronts per CU (two per

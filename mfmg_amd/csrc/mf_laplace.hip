@@ -152,6 +152,7 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
   const int id_lane = a.aff.base + ci * a.aff.s0; // (AFF) the part of the id that belongs to the lane
   const bool lane_in = ci >= 0 && ci < a.Nx;
   const bool lane_face = ((a.aff.faces & 1) && ci == 0) || ((a.aff.faces & 2) && ci == a.Nx - 1);
+  const bool lane_ghost = ci < a.aff.ghost_lo[0] || ci >= a.Nx - a.aff.ghost_hi[0];
   auto own_id = [&](int kz, int jrow) {
     const int jr = min(max(jrow, 0), a.Ny - 1);
     if constexpr (AFF)
@@ -160,8 +161,8 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
       const int id_row = jr * a.aff.s1 + kz * a.aff.s2;
       const bool row_face = ((a.aff.faces & 4) && jr == 0) || ((a.aff.faces & 8) && jr == a.Ny - 1) ||
                             ((a.aff.faces & 16) && kz == 0) || ((a.aff.faces & 32) && kz == a.Nz - 1);
-      const int ghost = (kz < a.aff.ghost_low || kz >= a.Nz - a.aff.ghost_high) ? (int)kGhost : 0;
-      const int id = (id_lane + id_row) | ((lane_face || row_face) ? (int)kFlag : 0) | ghost;
+      const bool row_ghost = kz < a.aff.ghost_lo[2] || kz >= a.Nz - a.aff.ghost_hi[2] || jr < a.aff.ghost_lo[1] || jr >= a.Ny - a.aff.ghost_hi[1];
+      const int id = (id_lane + id_row) | ((lane_face || row_face) ? (int)kFlag : 0) | ((lane_ghost || row_ghost) ? (int)kGhost : 0);
       return lane_in ? id : 0; // (lanes outside the mesh carry id 0 in the records too)
     }
     else
@@ -452,7 +453,8 @@ __global__ void mf_affine_check_kernel(unsigned char const *rec, size_t rec_byte
       continue;
     const bool face = ((f.faces & 1) && i == 0) || ((f.faces & 2) && i == Nx - 1) || ((f.faces & 4) && j == 0) ||
                       ((f.faces & 8) && j == Ny - 1) || ((f.faces & 16) && k == 0) || ((f.faces & 32) && k == Nz - 1);
-    const bool ghost = k < f.ghost_low || k >= Nz - f.ghost_high;
+    const bool ghost = i < f.ghost_lo[0] || i >= Nx - f.ghost_hi[0] || j < f.ghost_lo[1] || j >= Ny - f.ghost_hi[1] || k < f.ghost_lo[2] ||
+                       k >= Nz - f.ghost_hi[2];
     const int want = (f.base + i * f.s0 + j * f.s1 + k * f.s2) | (face ? (int)kFlag : 0) | (ghost ? (int)kGhost : 0);
     if (reinterpret_cast<int const *>(rec + (size_t)chunk * rec_bytes)[lane] != want)
       atomicOr(mismatch, 1);
@@ -866,8 +868,9 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   // Chunk geometry.  One halo lane on either side (62 owned columns, the tail columns of a 2^k + 1 wide row as a rotated slab)
   // serves the kernels that run one polynomial term per launch; the multi-term sweep (mf_cheb_fused.hip) needs as many halo lanes
   // as it runs terms, and then every chunk owns the same number of columns (no tail slab: 257 columns = 5 chunks of 52).
-  // Distributed runs, the slab operator and eight coefficients per cell keep the one-lane geometry (their smoother runs term by term).
-  _halo = (sub_mesh || handle.comm.enabled() || !_compact) ? 1 : std::min(std::max(handle.mf_fused_terms, 1), 3);
+  // The slab operator and eight coefficients per cell keep the one-lane geometry (their smoother runs term by term).
+  // (a distributed rank holds two ghost planes per neighbour: at most two terms per sweep)
+  _halo = (sub_mesh || !_compact) ? 1 : std::min(std::max(handle.mf_fused_terms, 1), handle.comm.enabled() ? 2 : 3);
   if (_halo == 1)
   {
     _own = 62;
@@ -930,11 +933,16 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
       f.faces = ((slot_id(0, mj, mk) & kFlag) ? 1 : 0) | ((slot_id(_N[0] - 1, mj, mk) & kFlag) ? 2 : 0) |
                 ((slot_id(mi, 0, mk) & kFlag) ? 4 : 0) | ((slot_id(mi, _N[1] - 1, mk) & kFlag) ? 8 : 0) |
                 ((slot_id(mi, mj, 0) & kFlag) ? 16 : 0) | ((slot_id(mi, mj, _N[2] - 1) & kFlag) ? 32 : 0);
-      f.ghost_low = f.ghost_high = 0;
-      while (f.ghost_low < std::min(_N[2], 4) && (slot_id(mi, mj, f.ghost_low) & kGhost))
-        ++f.ghost_low;
-      while (f.ghost_high < std::min(_N[2], 4) && (slot_id(mi, mj, _N[2] - 1 - f.ghost_high) & kGhost))
-        ++f.ghost_high;
+      // ghost planes per axis, read along the three centre lines
+      for (int d = 0; d < 3; ++d)
+      {
+        auto at = [&](int t) { return d == 0 ? slot_id(t, mj, mk) : (d == 1 ? slot_id(mi, t, mk) : slot_id(mi, mj, t)); };
+        f.ghost_lo[d] = f.ghost_hi[d] = 0;
+        while (f.ghost_lo[d] < std::min(_N[d] / 2, 4) && (at(f.ghost_lo[d]) & kGhost))
+          ++f.ghost_lo[d];
+        while (f.ghost_hi[d] < std::min(_N[d] / 2, 4) && (at(_N[d] - 1 - f.ghost_hi[d]) & kGhost))
+          ++f.ghost_hi[d];
+      }
       MFMG_HIP_CHECK(hipMemsetAsync(bad.data(), 0, sizeof(int), st));
       hipLaunchKernelGGL(mf_affine_check_kernel, dim3(n_blocks_for(n_slots, 256, 1 << 16)), dim3(256), 0, st, _rec.data(), _rec_bytes,
                          (int64_t)n_slots, _N[0], _N[1], _N[2], _ncols, _own, _halo, f, bad.data());

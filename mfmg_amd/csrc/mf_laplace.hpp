@@ -26,13 +26,14 @@ enum class MfMode : int
 
 // A numbering the kernel can compute: id(i, j, k) = base + i s0 + j s1 + k s2 on the node grid (any lexicographic
 // numbering; the rotated slab of the tail columns has s0 = row length, s1 = 1), Dirichlet flags on whole faces of the box
-// (bit 0 / 1: i = 0 / Nx - 1, bits 2, 3: j, bits 4, 5: k) and ghost flags on whole layers k < ghost_low, k >= Nz - ghost_high
-// (the slabs of a distributed run).  Verified slot by slot against the records at construction; the id loads -- a
+// (bit 0 / 1: i = 0 / Nx - 1, bits 2, 3: j, bits 4, 5: k) and ghost flags on whole planes along every axis: the ghost_lo[d] first
+// and the ghost_hi[d] last node planes of axis d (the slabs and boxes of a distributed run).  Verified slot by slot against the records at construction; the id loads -- a
 // request per row whose answer the x requests wait for -- disappear from the kernel.
 struct AffineIds
 {
   int base, s0, s1, s2;
-  int faces, ghost_low, ghost_high;
+  int faces;
+  int ghost_lo[3], ghost_hi[3];
 };
 
 template <typename T>
@@ -201,7 +202,7 @@ private:
   bool _dinv_in_record = true; // D^-1 is part of the chunk records (always for eight coefficients per cell)
   size_t _rec_bytes = 0;
   // a numbering the kernel computes instead of reading it from the records (mf_laplace.hip: AffineIds)
-  AffineIds _affine = {0, 1, 0, 0, 0, 0, 0};
+  AffineIds _affine = {0, 1, 0, 0, 0, {0, 0, 0}, {0, 0, 0}};
   bool _affine_ids = false;
 };
 } // namespace mfmg

@@ -195,6 +195,7 @@ public:
       smooth();
       if (cur != &x)
         x = *cur;
+      restrictor->release_rhs();
       timer_leave_subsection(_timer);
     }
   }

@@ -153,6 +153,7 @@ public:
   int residual_restriction_classes() const { return _structured ? _structured->residual_restriction_classes() : 0; }
   bool restrict_residual(Operator<DVector> const &a, DVector const &x, DVector const &b, DVector &b_coarse) const override;
   void prefetch_rhs(DVector const &b) const override;
+  void release_rhs() const override;
   // y = A x + beta D^-1 b (x in the domain space: its ghost entries are refreshed first)
   void apply_plus_scaled(DVector const &x, double const *dinv, DVector const &b, double beta, DVector &y) const;
   // the same from the FP32 vectors of the fine level of apply_f32 (one rank; sums and result in FP64)

@@ -56,6 +56,8 @@ public:
   // Called on a RESTRICTOR at the start of a cycle, with the right-hand side the cycle will restrict later: a distributed run
   // may refresh the ghost entries of b meanwhile (restrict_residual finds them in place).  Default: nothing.
   virtual void prefetch_rhs(vector_type const & /*b*/) const {}
+  // ... and the end of that cycle: nothing of it may still be in flight, nothing is known about b any more
+  virtual void release_rhs() const {}
   // y -= op(A) x : `restrictor->apply(*x_coarse, *x_correction, TRANS); x.add(-1., *x_correction);`
   // of hierarchy.hpp:297-302
   virtual void apply_subtract(vector_type const &x, vector_type &y, OperatorMode mode) const
