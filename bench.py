@@ -356,14 +356,17 @@ def measure_smoother(ctx, torch, M, n_dofs_per_dim, degree, reps=20, warmup=3, t
     survey = survey_8d_bytes_per_dof(len(coefs))["smoother_apply"]
     required = smoother_bytes_per_dof(len(coefs), 8, compact, survey=False, dinv_stored=dinv_stored, ids_computed=op.ids_computed())
     fused_form = 8 * (4 + (1 if dinv_stored else 0)) if sweep else None     # x_0, b, one coefficient per cell (D^-1), x_K
-    traffic = committed_traffic(n_dofs_per_dim, degree, compact, op.get_tile(), prefix="dofs") if (dinv_stored == (not compact) and not sweep) else None
+    traffic = None
+    if dinv_stored == (not compact):
+        traffic = (committed_traffic(n_dofs_per_dim, degree, compact, op.get_sweep_tile(len(coefs)), prefix="sweep_dofs") if sweep else
+                   committed_traffic(n_dofs_per_dim, degree, compact, op.get_tile(), prefix="dofs"))
     return {"n_dofs": N, "degree": degree, "material": material,
             "coefficient_layout": "one value per cell" if compact else "eight values per cell",
             "diagonal": "D^-1 stored in the chunk records" if dinv_stored else "D^-1 derived in the kernel from the cell coefficients (not read)",
             "kernel": (f"mf_cheb_fused_kernel: the {len(coefs)} terms in one sweep" if sweep else f"mf_laplace_kernel: {len(coefs)} launches, one per term"),
             "tile_waves_ty_tz": list(op.get_sweep_tile(len(coefs)) if sweep else op.get_tile()),
             "hbm_traffic_bytes_per_launch_pmc": traffic,
-            "hbm_traffic_GBs": (traffic * len(coefs) / (ms * 1e-3) / 1e9) if traffic else None,
+            "hbm_traffic_GBs": (traffic * (1 if sweep else len(coefs)) / (ms * 1e-3) / 1e9) if traffic else None,
             "ms_per_apply": ms, "ms_min": ts[0], "ms_max": ts[-1], "reps": reps, "warmup": warmup,
             "ms_per_apply_term_by_term": ts_terms[len(ts_terms) // 2],
             "required_bytes_per_dof": required,
@@ -591,6 +594,8 @@ def main():
         _t = [int(v) for v in args.tile.split(',')]
         h.set_operator_tile(_t[2] if len(_t) > 2 else 0, _t[0], _t[1])
     mf_tile = (0, 0, 0) if assembled else h.operator_tile()
+    sweep_terms = (0, 0) if assembled else h.smoother_sweep_terms()
+    sweep_tile = h.sweep_tile(sweep_terms[1]) if sweep_terms[1] else None
     for _ in range(args.warmup):
         h.apply(b, x)
     # HIP events around the launches of the dominant kernel only: an event pair costs ~5 us on the stream, and the
@@ -731,9 +736,12 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (None if assembled else committed_traffic(args.cells, args.degree, compact, mf_tile)),
+                "traffic": (None if assembled else
+                            committed_traffic(args.cells, args.degree, compact, sweep_tile, prefix="sweep_cells") if fused_dominant else
+                            committed_traffic(args.cells, args.degree, compact, mf_tile)),
                 "traffic_source": (None if assembled else
-                                   committed_traffic(args.cells, args.degree, compact, mf_tile, want_source=True)[1]),
+                                   committed_traffic(args.cells, args.degree, compact, sweep_tile, prefix="sweep_cells", want_source=True)[1]
+                                   if fused_dominant else committed_traffic(args.cells, args.degree, compact, mf_tile, want_source=True)[1]),
                 "priced_on": "algorithmic bytes of the smoother terms a launch performs: per term what the data layout requires of a "
                              "launch of that term (x, out, one id, coefficients, b, x_prev, and D^-1 where the layout stores it: eight "
                              "coefficients per cell); halo re-reads of the tiling are waste and not counted"
@@ -749,7 +757,7 @@ def main():
                 "survey_8d_GBs": (None if assembled or not launches else      # SURVEY.md 8(d)'s own figure for what one launch does
                                   survey_8d_bytes_per_dof(degree)["smoother_apply" if fused_dominant else "smoother_term"] * n_local
                                   / (k_ms / launches * 1e-3) / 1e9),
-                "launches_in_timed_region": launches, "tile_waves_ty_tz": list(mf_tile),
+                "launches_in_timed_region": launches, "tile_waves_ty_tz": list(sweep_tile if fused_dominant else mf_tile),
                 "avg_launch_ms": k_ms / launches if launches else None,
                 "required_bytes_per_launch": k_bytes / launches if launches else None,
                 "share_of_step_time": k_ms / (ms_per_step * args.steps) if launches else None,

@@ -124,6 +124,13 @@ int mfmg_hip_context_use_host_transport(mfmg_hip_context_t ctx, mfmg_hip_host_ex
  * the partition with a wire that costs nothing (scratch/rank_cycle_on_one_gpu.py).  What the rank iterates on afterwards is
  * not a solution of anything. */
 int mfmg_hip_context_use_reflecting_transport(mfmg_hip_context_t ctx);
+/* ... the same with a price on the wire: every grouped send/recv and every collective holds its stream for
+ * `microseconds_per_group` (a one-thread kernel) before the reflected data arrive -- the latency of a real group, e.g. what
+ * mfmg_hip_context_transport_loopback_time measured for the RCCL transport */
+int mfmg_hip_context_use_reflecting_transport_delay(mfmg_hip_context_t ctx, double microseconds_per_group);
+/* stream time of one loop-back group (send to self + receive from self, n doubles) of the registered transport: `reps` groups
+ * back to back between two events */
+int mfmg_hip_context_transport_loopback_time(mfmg_hip_context_t ctx, int64_t n, int reps, double *microseconds);
 /* "rccl", "host", "reflecting" or "" (none) */
 int mfmg_hip_context_transport_name(mfmg_hip_context_t ctx, char *buffer, size_t buffer_size);
 /* ranks the registered transport's own communicator reports (RCCL: ncclCommCount; 1 without a transport) */
@@ -413,6 +420,13 @@ int mfmg_hip_hierarchy_coarse_amg_smoother(mfmg_hip_hierarchy_t h, int32_t level
                                            double *lambda_max);
 /* smoother polynomial actually used (degree, lambda_min, lambda_max) */
 int mfmg_hip_hierarchy_smoother_info(mfmg_hip_hierarchy_t h, int32_t *degree, double *lambda_min, double *lambda_max);
+/* polynomial terms the fine-level smoother runs as ONE sweep over the mesh (mf_cheb_fused.hip): by Smoother::apply (in place: the last
+ * term stays a launch of its own) and by the out-of-place form Hierarchy::apply uses where the whole polynomial fits a sweep;
+ * 0 = one launch per term (eight coefficients per cell, a numbering the kernel cannot compute, smoother.fused_terms 1) */
+int mfmg_hip_hierarchy_smoother_sweep_terms(mfmg_hip_hierarchy_t h, int *terms_in_place, int *terms_out_of_place);
+/* tile of that sweep for n_terms terms: n_waves wavefronts of tile_y cell rows, tile_z owned layers (0, 0, 0 sets the heuristic) */
+int mfmg_hip_hierarchy_sweep_tile(mfmg_hip_hierarchy_t h, int n_terms, int *n_waves, int *tile_y, int *tile_z);
+int mfmg_hip_hierarchy_set_sweep_tile(mfmg_hip_hierarchy_t h, int n_waves, int tile_y, int tile_z);
 /* tile of the matrix-free fine-level operator (n_waves, rows per wavefront, layers), see mfmg_hip_mf_laplace_get_tile */
 int mfmg_hip_hierarchy_operator_tile(mfmg_hip_hierarchy_t h, int *n_waves, int *tile_y, int *tile_z);
 int mfmg_hip_hierarchy_set_operator_tile(mfmg_hip_hierarchy_t h, int n_waves, int tile_y, int tile_z); /* 0 = automatic */

@@ -657,6 +657,12 @@ class Hierarchy:
             out.append((rows, an, pn))
         return out
 
+    def smoother_sweep_terms(self):
+        """(terms per sweep of the in-place smoother apply, of the out-of-place one); 0 = one launch per term."""
+        a, b = C.c_int(), C.c_int()
+        check(self._lib.mfmg_hip_hierarchy_smoother_sweep_terms(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def smoother_info(self):
         d, lo, hi = C.c_int32(), C.c_double(), C.c_double()
         check(self._lib.mfmg_hip_hierarchy_smoother_info(self.handle, C.byref(d), C.byref(lo), C.byref(hi)))
@@ -678,6 +684,14 @@ class Hierarchy:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         check(self._lib.mfmg_hip_hierarchy_operator_tile(self.handle, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def sweep_tile(self, n_terms: int):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.mfmg_hip_hierarchy_sweep_tile(self.handle, int(n_terms), C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def set_sweep_tile(self, waves: int, ty: int, tz: int):
+        check(self._lib.mfmg_hip_hierarchy_set_sweep_tile(self.handle, waves, ty, tz))
 
     def set_operator_tile(self, waves: int, ty: int, tz: int):
         check(self._lib.mfmg_hip_hierarchy_set_operator_tile(self.handle, waves, ty, tz))

@@ -247,6 +247,45 @@ int mfmg_hip_context_use_reflecting_transport(mfmg_hip_context_t ctx)
   });
 }
 
+int mfmg_hip_context_use_reflecting_transport_delay(mfmg_hip_context_t ctx, double microseconds_per_group)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    require(microseconds_per_group >= 0. && microseconds_per_group <= 1e4, "delay out of range");
+    HaloCommunicator &c = ctx->handle->comm;
+    require(c.enabled(), "no communicator was set");
+    c.transport = make_reflecting_transport(c.n_ranks, microseconds_per_group);
+  });
+}
+
+// `reps` loop-back groups (send to self + receive from self) of n doubles back to back on the context's stream, bracketed by
+// one event pair: microseconds of stream time per group -- what a grouped send/recv costs before any byte crosses a wire
+int mfmg_hip_context_transport_loopback_time(mfmg_hip_context_t ctx, int64_t n, int reps, double *microseconds)
+{
+  return guarded([&] {
+    require(ctx != nullptr && microseconds != nullptr && n > 0 && reps > 0, "bad argument");
+    HipHandle &h = *ctx->handle;
+    require(h.comm.transport != nullptr, "no transport registered");
+    DeviceBuffer<double> a((size_t)n), b((size_t)n);
+    MFMG_HIP_CHECK(hipMemsetAsync(a.data(), 0, (size_t)n * sizeof(double), h.stream));
+    for (int i = 0; i < 3; ++i)
+      h.comm.transport->loopback(a.data(), b.data(), n, h.stream);
+    hipEvent_t e0, e1;
+    MFMG_HIP_CHECK(hipEventCreate(&e0));
+    MFMG_HIP_CHECK(hipEventCreate(&e1));
+    MFMG_HIP_CHECK(hipEventRecord(e0, h.stream));
+    for (int i = 0; i < reps; ++i)
+      h.comm.transport->loopback(a.data(), b.data(), n, h.stream);
+    MFMG_HIP_CHECK(hipEventRecord(e1, h.stream));
+    MFMG_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MFMG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *microseconds = 1e3 * ms / reps;
+  });
+}
+
 int mfmg_hip_context_transport_name(mfmg_hip_context_t ctx, char *buffer, size_t buffer_size)
 {
   return guarded([&] {
@@ -1418,6 +1457,16 @@ int mfmg_hip_hierarchy_smoother_info(mfmg_hip_hierarchy_t h, int32_t *degree, do
   });
 }
 
+int mfmg_hip_hierarchy_smoother_sweep_terms(mfmg_hip_hierarchy_t h, int *terms_in_place, int *terms_out_of_place)
+{
+  return guarded([&] {
+    require(h != nullptr && terms_in_place != nullptr && terms_out_of_place != nullptr, "null argument");
+    auto s = std::dynamic_pointer_cast<HipSmoother const>(h->hierarchy->levels()[0].get_smoother());
+    require(s != nullptr, "level 0 has no HIP smoother");
+    s->sweep_terms(*terms_in_place, *terms_out_of_place);
+  });
+}
+
 int mfmg_hip_hierarchy_operator_tile(mfmg_hip_hierarchy_t h, int *n_waves, int *tile_y, int *tile_z)
 {
   return guarded([&] {
@@ -1425,6 +1474,27 @@ int mfmg_hip_hierarchy_operator_tile(mfmg_hip_hierarchy_t h, int *n_waves, int *
     auto op = std::dynamic_pointer_cast<HipMatrixFreeOperator const>(h->hierarchy->levels()[0].get_operator());
     require(op != nullptr, "the fine-level operator is not matrix-free");
     op->get_mesh_evaluator()->get_device_operator()->get_tile(*n_waves, *tile_y, *tile_z);
+  });
+}
+
+int mfmg_hip_hierarchy_sweep_tile(mfmg_hip_hierarchy_t h, int n_terms, int *n_waves, int *tile_y, int *tile_z)
+{
+  return guarded([&] {
+    require(h && n_waves && tile_y && tile_z, "null argument");
+    auto op = std::dynamic_pointer_cast<HipMatrixFreeOperator const>(h->hierarchy->levels()[0].get_operator());
+    require(op != nullptr, "the fine-level operator is not matrix-free");
+    op->get_mesh_evaluator()->get_device_operator()->get_fused_tile(n_terms, *n_waves, *tile_y, *tile_z);
+  });
+}
+
+int mfmg_hip_hierarchy_set_sweep_tile(mfmg_hip_hierarchy_t h, int n_waves, int tile_y, int tile_z)
+{
+  return guarded([&] {
+    require(h != nullptr, "null argument");
+    require(n_waves >= 0 && n_waves <= 8 && tile_y >= 0 && tile_y <= 4 && tile_z >= 0, "bad tile");
+    auto op = std::dynamic_pointer_cast<HipMatrixFreeOperator const>(h->hierarchy->levels()[0].get_operator());
+    require(op != nullptr, "the fine-level operator is not matrix-free");
+    op->get_mesh_evaluator()->get_device_operator()->set_fused_tile(n_waves, tile_y, tile_z);
   });
 }
 

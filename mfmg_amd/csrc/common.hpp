@@ -408,6 +408,7 @@ struct HaloCommunicator
 };
 
 void halo_add_layers(double *dst, double const *src, int64_t n, hipStream_t stream); // dst += src (vector_ops.hip)
+void stream_delay(double microseconds, hipStream_t stream); // a one-thread kernel that holds the stream that long (vector_ops.hip)
 struct HaloRegions;
 struct HaloSpace;
 // the regions of a vector of space `s` against the packed buffer: mode 0 buf = v (pack), 1 v = buf (unpack), 2 v += buf (vector_ops.hip)

@@ -315,10 +315,15 @@ private:
 class ReflectingTransport : public HaloTransport
 {
 public:
-  explicit ReflectingTransport(int n_ranks) : _n(n_ranks) {}
+  // delay_us: what one grouped send/recv (resp. one collective) holds its stream for before the reflected data are there -- the
+  // latency of the wire the harness otherwise leaves out (a free wire cannot show what 20-40 us per group do to a
+  // cycle of 17 exchanges).  A one-thread kernel on the stream of the exchange, in FRONT of the copy.
+  explicit ReflectingTransport(int n_ranks, double delay_us) : _n(n_ranks), _delay_us(delay_us) {}
   void sendrecv(int, int, double const *send_low, double *recv_low, int64_t n_low, double const *send_high, double *recv_high,
                 int64_t n_high, hipStream_t stream) override
   {
+    if (n_low > 0 || n_high > 0)
+      stream_delay(_delay_us, stream);
     if (n_low > 0)
       MFMG_HIP_CHECK(hipMemcpyAsync(recv_low, send_low, (size_t)n_low * sizeof(double), hipMemcpyDeviceToDevice, stream));
     if (n_high > 0)
@@ -335,6 +340,8 @@ public:
       contiguous = contiguous && send[i] == send[0] + total && recv[i] == recv[0] + total;
       total += count[i];
     }
+    if (total > 0)
+      stream_delay(_delay_us, stream);
     if (contiguous && total > 0)
       MFMG_HIP_CHECK(hipMemcpyAsync(recv[0], send[0], (size_t)total * sizeof(double), hipMemcpyDeviceToDevice, stream));
     else
@@ -345,6 +352,7 @@ public:
   void allreduce(double *, int, int, hipStream_t) override {}
   void allgather(double const *in, int64_t n, double *out, hipStream_t stream) override
   {
+    stream_delay(_delay_us, stream);
     for (int r = 0; r < _n; ++r)
       MFMG_HIP_CHECK(hipMemcpyAsync(out + (size_t)r * n, in, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
   }
@@ -357,10 +365,14 @@ public:
 
 private:
   int _n;
+  double _delay_us;
 };
 } // namespace
 
-std::shared_ptr<HaloTransport> make_reflecting_transport(int n_ranks) { return std::make_shared<ReflectingTransport>(n_ranks); }
+std::shared_ptr<HaloTransport> make_reflecting_transport(int n_ranks, double delay_us)
+{
+  return std::make_shared<ReflectingTransport>(n_ranks, delay_us);
+}
 
 void rccl_available() { (void)rccl(); } // throws when librccl or one of its entry points cannot be resolved
 

@@ -24,5 +24,5 @@ std::shared_ptr<HaloTransport> make_host_transport(int rank, int n_ranks, mfmg_h
                                                    mfmg_hip_host_allreduce_fn allreduce, mfmg_hip_host_allgather_fn allgather,
                                                    void *user);
 // measurement: one rank of a grid on its own, every message reflected on the device (halo_transport.cpp)
-std::shared_ptr<HaloTransport> make_reflecting_transport(int n_ranks);
+std::shared_ptr<HaloTransport> make_reflecting_transport(int n_ranks, double delay_us = 0.);
 } // namespace mfmg

@@ -1113,6 +1113,21 @@ void HipSmoother::apply_zero_guess(DVector const &b, DVector &x) const
                                 _hip_operator->get_diagonal_inverse(), b.get_values(), x.get_values());
 }
 
+void HipSmoother::sweep_terms(int &in_place, int &out_of_place) const
+{
+  const int d = (int)_coefficients.size();
+  in_place = out_of_place = 0;
+  if (d >= 3)
+  {
+    const int K = std::min(d - 1, _fused_terms);
+    if (K >= 2 && _hip_operator->sweep_available(K))
+      in_place = K;
+  }
+  const int K = std::min(d, _fused_terms);
+  if (K >= 2 && _hip_operator->sweep_available(K))
+    out_of_place = K;
+}
+
 bool HipSmoother::prefers_out_of_place() const
 {
   const int d = (int)_coefficients.size();

@@ -207,6 +207,15 @@ template <typename T>
 __device__ __forceinline__ void cell_apply(T const u[8], T const c[8], CellFactors<T> const &f, T v[8])
 {
 #pragma clang fp contract(off)
+#ifdef MFMG_MF_ABLATE_CELL
+  // MEASUREMENT BUILD ONLY (scratch/r04_fp32_ablation.sh): the whole cell arithmetic replaced by one multiply per corner, every
+  // load, lane shift, carry and store kept -- what the ~800 flops per cell cost a launch (BASELINE configs[4])
+  (void)f;
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+    v[m] = c[m] * u[m];
+  return;
+#endif
   T X00, X10, X01, X11, Y00, Y10, Y01, Y11, Z00, Z10, Z01, Z11;
   // x: differences along a, (p, r) = (b, d); coefficient pairs summed over qa
   direction_apply<T>(u[1] - u[0], u[3] - u[2], u[5] - u[4], u[7] - u[6], c[0] + c[1], c[2] + c[3], c[4] + c[5],

@@ -162,7 +162,9 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
       const bool row_face = ((a.aff.faces & 4) && jr == 0) || ((a.aff.faces & 8) && jr == a.Ny - 1) ||
                             ((a.aff.faces & 16) && kz == 0) || ((a.aff.faces & 32) && kz == a.Nz - 1);
       const bool row_ghost = kz < a.aff.ghost_lo[2] || kz >= a.Nz - a.aff.ghost_hi[2] || jr < a.aff.ghost_lo[1] || jr >= a.Ny - a.aff.ghost_hi[1];
-      const int id = (id_lane + id_row) | ((lane_face || row_face) ? (int)kFlag : 0) | ((lane_ghost || row_ghost) ? (int)kGhost : 0);
+      // (a node on a Dirichlet face carries the Dirichlet flag only, also in a ghost plane: mfmg_amd/distributed.py, local_problem)
+      const bool face = lane_face || row_face;
+      const int id = (id_lane + id_row) | (face ? (int)kFlag : 0) | (((lane_ghost || row_ghost) && !face) ? (int)kGhost : 0);
       return lane_in ? id : 0; // (lanes outside the mesh carry id 0 in the records too)
     }
     else
@@ -455,7 +457,7 @@ __global__ void mf_affine_check_kernel(unsigned char const *rec, size_t rec_byte
                       ((f.faces & 8) && j == Ny - 1) || ((f.faces & 16) && k == 0) || ((f.faces & 32) && k == Nz - 1);
     const bool ghost = i < f.ghost_lo[0] || i >= Nx - f.ghost_hi[0] || j < f.ghost_lo[1] || j >= Ny - f.ghost_hi[1] || k < f.ghost_lo[2] ||
                        k >= Nz - f.ghost_hi[2];
-    const int want = (f.base + i * f.s0 + j * f.s1 + k * f.s2) | (face ? (int)kFlag : 0) | (ghost ? (int)kGhost : 0);
+    const int want = (f.base + i * f.s0 + j * f.s1 + k * f.s2) | (face ? (int)kFlag : 0) | ((ghost && !face) ? (int)kGhost : 0);
     if (reinterpret_cast<int const *>(rec + (size_t)chunk * rec_bytes)[lane] != want)
       atomicOr(mismatch, 1);
   }

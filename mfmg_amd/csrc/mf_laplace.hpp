@@ -27,7 +27,8 @@ enum class MfMode : int
 // A numbering the kernel can compute: id(i, j, k) = base + i s0 + j s1 + k s2 on the node grid (any lexicographic
 // numbering; the rotated slab of the tail columns has s0 = row length, s1 = 1), Dirichlet flags on whole faces of the box
 // (bit 0 / 1: i = 0 / Nx - 1, bits 2, 3: j, bits 4, 5: k) and ghost flags on whole planes along every axis: the ghost_lo[d] first
-// and the ghost_hi[d] last node planes of axis d (the slabs and boxes of a distributed run).  Verified slot by slot against the records at construction; the id loads -- a
+// and the ghost_hi[d] last node planes of axis d (the slabs and boxes of a distributed run; a node on a Dirichlet face carries
+// the Dirichlet flag only, in a ghost plane too).  Verified slot by slot against the records at construction; the id loads -- a
 // request per row whose answer the x requests wait for -- disappear from the kernel.
 struct AffineIds
 {

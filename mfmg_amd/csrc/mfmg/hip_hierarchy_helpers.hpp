@@ -269,6 +269,9 @@ public:
   void apply_to(DVector const &b, DVector const &x_in, DVector &x_out) const override;
   bool prefers_out_of_place() const override;
   int fused_terms() const { return _fused_terms; }
+  // polynomial terms the fine smoother runs as ONE sweep: by apply() (in place: the last term is a launch of its own) and by
+  // apply_to() (0: one launch per term)
+  void sweep_terms(int &in_place, int &out_of_place) const;
 
   int degree() const { return (int)_coefficients.size(); }
   // (alpha_k, beta_k) of the polynomial terms: x_{k+1} = x_k + alpha_k (x_k - x_{k-1}) - beta_k D^-1 (A x_k - b)

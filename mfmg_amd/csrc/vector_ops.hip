@@ -414,6 +414,25 @@ void gather_indexed(int64_t n, double const *in, int32_t const *index, double *o
   MFMG_HIP_CHECK(hipGetLastError());
 }
 
+namespace vec
+{
+// keeps the stream busy for `ticks` of the 100 MHz wall clock (s_memrealtime): the price of a wire in the one-GPU harness
+__global__ void stream_delay_kernel(long long ticks)
+{
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks)
+    __builtin_amdgcn_s_sleep(8);
+}
+} // namespace vec
+
+void stream_delay(double microseconds, hipStream_t stream)
+{
+  if (!(microseconds > 0.))
+    return;
+  hipLaunchKernelGGL(vec::stream_delay_kernel, dim3(1), dim3(1), 0, stream, (long long)(microseconds * 100.));
+  MFMG_HIP_CHECK(hipGetLastError());
+}
+
 void halo_add_layers(double *dst, double const *src, int64_t n, hipStream_t stream)
 {
   if (n <= 0)

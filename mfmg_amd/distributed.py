@@ -344,10 +344,20 @@ class HaloTransport:
         """One halo exchange of a vector of `space` (the cycle does this by itself; for tests)."""
         check(self._lib.mfmg_hip_context_exchange(self.ctx.handle, space, v.data_ptr(), 1 if reverse else 0))
 
-    def reflect(self):
+    def reflect(self, delay_us: float = 0.0):
         """MEASUREMENT: from here on the messages of this rank are mirrored on the device (no partner is involved any more):
-        its share of a distributed cycle with a wire that costs nothing.  For a hierarchy that was set up with the real transport."""
-        check(self._lib.mfmg_hip_context_use_reflecting_transport(self.ctx.handle))
+        its share of a distributed cycle with a wire that costs nothing -- or `delay_us` of stream time per grouped send/recv and
+        collective (the latency of a real group).  For a hierarchy that was set up with the real transport."""
+        if delay_us > 0.0:
+            check(self._lib.mfmg_hip_context_use_reflecting_transport_delay(self.ctx.handle, float(delay_us)))
+        else:
+            check(self._lib.mfmg_hip_context_use_reflecting_transport(self.ctx.handle))
+
+    def loopback_time(self, n: int = 32768, reps: int = 50) -> float:
+        """Stream time (us) of one loop-back group of the registered transport: send to self + receive from self, n doubles."""
+        us = C.c_double()
+        check(self._lib.mfmg_hip_context_transport_loopback_time(self.ctx.handle, int(n), int(reps), C.byref(us)))
+        return us.value
 
     def n_exchanges(self) -> int:
         n = C.c_int64()

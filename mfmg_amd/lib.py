@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfmg_hip.so")
+# (MFMG_HIP_LIBRARY: another build of the same library, e.g. a measurement build of scratch/r04_fp32_ablation.sh; never a fallback)
+LIB_PATH = os.environ.get("MFMG_HIP_LIBRARY") or os.path.join(_HERE, "libmfmg_hip.so")
 
 SUCCESS = 0
 ERROR_RUNTIME = 1
@@ -113,6 +114,8 @@ def load() -> C.CDLL:
         "mfmg_hip_context_use_rccl": (C.c_int, [vp, vp]),
         "mfmg_hip_context_use_host_transport": (C.c_int, [vp, vp, vp, vp, vp]),
         "mfmg_hip_context_use_reflecting_transport": (C.c_int, [vp]),
+        "mfmg_hip_context_use_reflecting_transport_delay": (C.c_int, [vp, dbl]),
+        "mfmg_hip_context_transport_loopback_time": (C.c_int, [vp, i64, C.c_int, P(dbl)]),
         "mfmg_hip_context_transport_name": (C.c_int, [vp, C.c_char_p, sz]),
         "mfmg_hip_context_transport_ranks": (C.c_int, [vp, P(C.c_int)]),
         "mfmg_hip_context_exchange_count": (C.c_int, [vp, P(i64)]),
@@ -205,6 +208,9 @@ def load() -> C.CDLL:
         "mfmg_hip_hierarchy_get_coarse_operator": (C.c_int, [vp, P(vp)]),
         "mfmg_hip_hierarchy_get_fine_operator": (C.c_int, [vp, P(vp)]),
         "mfmg_hip_hierarchy_smoother_info": (C.c_int, [vp, P(i32), P(dbl), P(dbl)]),
+        "mfmg_hip_hierarchy_smoother_sweep_terms": (C.c_int, [vp, P(C.c_int), P(C.c_int)]),
+        "mfmg_hip_hierarchy_sweep_tile": (C.c_int, [vp, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int)]),
+        "mfmg_hip_hierarchy_set_sweep_tile": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "mfmg_hip_hierarchy_operator_tile": (C.c_int, [vp, P(C.c_int), P(C.c_int), P(C.c_int)]),
         "mfmg_hip_hierarchy_set_operator_tile": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "mfmg_hip_hierarchy_timer_report": (C.c_int, [vp, C.c_char_p, sz]),

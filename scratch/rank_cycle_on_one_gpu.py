@@ -45,6 +45,18 @@ def cycles(ctx, h, n, steps=10, warmup=3):
     ctx.synchronize(); torch.cuda.synchronize()
     return (time.perf_counter() - t) / steps * 1e3
 
+# ---- what one grouped RCCL send/recv costs its stream before a byte crosses a wire: loop-back on this GPU
+loopback_us = None
+try:
+    _ctx = M.Context()
+    _tr = M.HaloTransport(_ctx, M.SlabPartition((8, 8, 8), 0, 1), transport="rccl")
+    loopback_us = {"32768 doubles": _tr.loopback_time(32768, 50), "2048 doubles": _tr.loopback_time(2048, 50)}
+    del _tr, _ctx
+except Exception as e:  # noqa: BLE001
+    loopback_us = {"error": str(e)[:200]}
+delays = [float(v) for v in os.environ.get("DELAY_US", "").split(",") if v] or \
+    ([round(loopback_us["2048 doubles"], 1)] if "2048 doubles" in loopback_us else [25.0])
+
 # ---- one rank of the same size, no partition
 ctx1 = M.Context()
 p1 = M.LaplaceProblem((per,) * 3, material, device="cuda")
@@ -79,7 +91,14 @@ def worker(rank):
                            "ratio": ms / ms_single, "exchanges_per_cycle": (tr.n_exchanges() - e0) / n_cyc,
                            "overlapped_per_cycle": (tr.n_overlapped() - o0) / n_cyc,
                            "mb_sent_per_cycle": (tr.exchange_volume() - v0) * 8e-6 / n_cyc, "setup_seconds_in_threads": setup_s,
-                           "gathered_from_rows": h.coarse_amg_gather_rows(), "levels": h.coarse_amg_shapes()})
+                           "gathered_from_rows": h.coarse_amg_gather_rows(), "levels": h.coarse_amg_shapes(),
+                           "smoother_sweep_terms": list(h.smoother_sweep_terms()), "rccl_loopback_us_per_group": loopback_us})
+            # ... and with a price on the wire: every grouped send/recv and collective holds its stream that long
+            with_delay = {}
+            for d_us in delays:
+                tr.reflect(d_us)
+                with_delay[f"{d_us:g} us per group"] = cycles(ctx, h, h.level_size(0))
+            result["ms_per_cycle_rank_alone_with_wire_latency"] = with_delay
         ready.wait()
         del h
     except BaseException as e:  # noqa: BLE001

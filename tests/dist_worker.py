@@ -479,6 +479,9 @@ def mode_gpu(args):
     h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", part.local_problem(material, "cuda"), params)
     deg, lmin, lmax = h.smoother_info()       # estimated with dot products summed over the ranks
     assert 1.4 < lmax < 2.2, lmax
+    # one coefficient per cell: the first two Chebyshev terms run as ONE sweep (x exchanged two ghost planes deep once, the
+    # ghost DoFs computed redundantly), the third as a launch of its own; eight coefficients per cell: a launch per term
+    assert h.smoother_sweep_terms() == ((2, 0) if material == "constant" else (0, 0)), h.smoother_sweep_terms()
     # the halo spaces of the levels belong to this hierarchy: a second one on the same communicator context is refused
     # while it lives (every rank raises before any collective of the second setup)
     try:

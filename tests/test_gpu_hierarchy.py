@@ -1214,6 +1214,42 @@ def test_interior_and_shell_launches_change_no_bit(ctx, monkeypatch, n, material
         ctx.set_mf_shell("beside")
 
 
+@pytest.mark.parametrize("n,degree,steps", [((40, 36, 30), 3, 1), ((70, 20, 24), 2, 1), ((33, 32, 31), 5, 1), ((36, 36, 36), 3, 2), ((24, 24, 24), 4, 3)])
+def test_cycle_with_the_multi_term_sweep_is_the_term_by_term_cycle(ctx, n, degree, steps):
+    """The fine-level Chebyshev smoother as ONE sweep over the mesh (the hierarchy alternates between x and a workspace vector,
+    degree <= 3; beyond that three terms per sweep and a launch per further term) against `smoother.fused_terms 1`, a launch per
+    term on chunk records with one halo lane: the same V-cycle bit for bit -- iterates and residual history, any number of
+    smoothing steps (an odd number of out-of-place applications ends in the workspace vector and is copied back)."""
+    prob = M.LaplaceProblem(n, "constant", device="cuda")
+    sm = {"type": "Chebyshev", "degree": degree, "smoothing_range": 20.0, "n_smoothing_steps": steps, "lambda_max": 1.9, "lambda_min": 0.095}
+    amg = {"coarsest_size": 300, "pre_smoothing_levels": 0}
+    h_sweep = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, base_params(smoother=dict(sm), solver={"type": "amg", "amg": dict(amg)}))
+    assert h_sweep.smoother_sweep_terms() == (min(degree - 1, 3) if degree >= 3 else 0, min(degree, 3))
+    ctx.set_mf_fused_terms(1)
+    try:
+        h_terms = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob,
+                              base_params(smoother=dict(sm, fused_terms=1), solver={"type": "amg", "amg": dict(amg)}))
+    finally:
+        ctx.set_mf_fused_terms(3)
+    assert h_terms.smoother_sweep_terms() == (0, 0)
+    rng = np.random.default_rng(8)
+    free = prob.constrained.cpu().numpy() != 1
+    x0 = rng.random(prob.n_dofs) * free
+    b = rng.random(prob.n_dofs) * free
+    runs = []
+    for h in (h_sweep, h_terms):
+        x, bb = dev(x0), dev(b)
+        for _ in range(4):
+            h.apply(bb, x)
+        # the smoother on its own, in place (two terms per sweep + a launch) and through the C ABI's smoother_apply
+        y = dev(x0)
+        h.smoother_apply(0, bb, y)
+        ctx.synchronize()
+        runs.append((x.clone(), y.clone()))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
+
+
 @pytest.mark.parametrize("cells", [32, 64])
 def test_smoothed_prolongation_equals_two_steps(ctx, cells):
     """V(0,1) levels of the aggregation hierarchy with a damped-Jacobi post-smoother: prolongation and post-smoothing as ONE
