@@ -190,7 +190,8 @@ def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, mater
             "mean_residual_contraction_per_cycle": (res1 / res0) ** (1.0 / (warmup + steps)) if res0 > 0 else 0.0,
             "residual_contraction_per_cycle_first_8": contraction8,
             "ms_per_residual_decade": ms_per_decade(dt * 1e3, contraction8),
-            "device_memory_in_use_GB": (total_b - free_b) / 1e9}
+            "device_memory_in_use_GB": (total_b - free_b) / 1e9,
+            "device_memory_inventory_GB": {line[14:].strip(): float(line[:10]) for line in M.memory_inventory().splitlines() if line.strip()}}
 
 
 def measure_vcycle_f32(ctx, torch, M, h, prob, op_monitor_factory, steps=10, warmup=3):

@@ -63,6 +63,10 @@ typedef struct mfmg_hip_hierarchy_s *mfmg_hip_hierarchy_t;   /* Hierarchy<Vector
 const char *mfmg_hip_last_error(void);
 const char *mfmg_hip_version(void);
 int mfmg_hip_abi_version(void);
+/* What the device memory of the library is spent on right now: one line per (setup section of the reference's TimerOutput |
+ * kind of structure) with at least 1 MB live -- "Setup: build restrictor | CSR arrays (val, col, row_ptr)", ... -- and the total,
+ * as text (GB).  Process-wide (all contexts). */
+int mfmg_hip_memory_inventory(char *buffer, size_t buffer_size);
 
 /* ---- context: stream + scratch (CudaHandle, source/cuda/cuda_handle.cu:17-56) ---- */
 /* `hip_stream`: a hipStream_t borrowed from the caller; NULL = the legacy default stream (what the
@@ -319,6 +323,11 @@ int mfmg_hip_mf_laplace_smoother_step(mfmg_hip_mf_laplace_t op, const double *b,
 int mfmg_hip_mf_laplace_sweep_available(mfmg_hip_mf_laplace_t op, int n_terms, int *available);
 int mfmg_hip_mf_laplace_smoother_sweep(mfmg_hip_mf_laplace_t op, int n_terms, const double *alpha, const double *beta,
                                        const double *b, const double *x, double *out, double *out_prev);
+/* The sweep's cell arithmetic.  Default (0): the cell matrix in mode space -- per direction a Q1 cell acts on the sum and the
+ * difference of its two nodes alone, the 8 x 8 cell matrix is diagonal on the eight modes and the butterflies are shared between
+ * neighbouring cells: ~30 % fewer FP64 operations, the same operator with its own rounding (1e-15 per cell).  on != 0: the
+ * arithmetic of the one-term kernel, bit for bit (tests compare the two kernels that way). */
+int mfmg_hip_mf_laplace_set_sweep_reference(mfmg_hip_mf_laplace_t op, int on);
 /* tile of the sweep: n_waves wavefronts of tile_y cell rows (2, 3 or 4), tile_z owned layers; 0, 0, 0 = chosen from the mesh */
 int mfmg_hip_mf_laplace_set_sweep_tile(mfmg_hip_mf_laplace_t op, int n_waves, int tile_y, int tile_z);
 int mfmg_hip_mf_laplace_get_sweep_tile(mfmg_hip_mf_laplace_t op, int n_terms, int *n_waves, int *tile_y, int *tile_z);
@@ -336,6 +345,7 @@ int mfmg_hip_mf_laplace_f32_residual(mfmg_hip_mf_laplace_f32_t op, const float *
 int mfmg_hip_mf_laplace_f32_smoother_step(mfmg_hip_mf_laplace_f32_t op, const float *b, const float *x,
                                           const float *x_prev, float alpha, float beta, float *out);
 int mfmg_hip_mf_laplace_f32_sweep_available(mfmg_hip_mf_laplace_f32_t op, int n_terms, int *available);
+int mfmg_hip_mf_laplace_f32_set_sweep_reference(mfmg_hip_mf_laplace_f32_t op, int on);
 int mfmg_hip_mf_laplace_f32_smoother_sweep(mfmg_hip_mf_laplace_f32_t op, int n_terms, const float *alpha, const float *beta,
                                            const float *b, const float *x, float *out, float *out_prev);
 /* tuning knob: owned DoF rows / planes per workgroup tile (0 = heuristic) */

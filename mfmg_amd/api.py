@@ -105,6 +105,14 @@ def _dev_ptr(t: torch.Tensor, n: Optional[int] = None, dtype=torch.float64) -> i
     return t.data_ptr()
 
 
+def memory_inventory() -> str:
+    """Live bytes of the library's device buffers per (setup section | kind of structure), as text."""
+    lib = _lib.load()
+    buf = C.create_string_buffer(1 << 16)
+    check(lib.mfmg_hip_memory_inventory(buf, len(buf)))
+    return buf.value.decode()
+
+
 class Context:
     """CudaHandle twin: a HIP stream + scratch (source/cuda/cuda_handle.cu:17-56)."""
 
@@ -382,6 +390,10 @@ class MatrixFreeLaplace:
     def set_sweep_tile(self, waves: int, ty: int, tz: int):
         check(self._lib.mfmg_hip_mf_laplace_set_sweep_tile(self.handle, waves, ty, tz))
 
+    def set_sweep_reference(self, on: bool):
+        """The sweep's cell kernel: mode space (default) or the arithmetic of the one-term kernel, bit for bit."""
+        check(self._lib.mfmg_hip_mf_laplace_set_sweep_reference(self.handle, int(bool(on))))
+
     def get_sweep_tile(self, n_terms: int):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         check(self._lib.mfmg_hip_mf_laplace_get_sweep_tile(self.handle, int(n_terms), C.byref(a), C.byref(b), C.byref(c)))
@@ -472,6 +484,9 @@ class MatrixFreeLaplaceF32:
         be = (C.c_float * k)(*[float(v) for v in beta])
         check(self._lib.mfmg_hip_mf_laplace_f32_smoother_sweep(self.handle, k, a, be, self._p(b), self._p(x), self._p(out),
                                                                self._p(out_prev) if out_prev is not None else None))
+
+    def set_sweep_reference(self, on: bool):
+        check(self._lib.mfmg_hip_mf_laplace_f32_set_sweep_reference(self.handle, int(bool(on))))
 
     def cell_constant_layout(self) -> bool:
         v = C.c_int()

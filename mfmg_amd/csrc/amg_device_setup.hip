@@ -108,6 +108,7 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
   {
     const int level = (int)_amg.size();
     const int64_t global_rows = g.s.n_global();
+    MemoryPhase phase("Setup: build coarse solver, aggregation level " + std::to_string(level) + " (" + std::to_string(global_rows) + " rows)");
     // ---- can the next level be built distributed?
     LevelGeom c;
     c.reach = (blk - 1 + 3 * g.reach) / blk;

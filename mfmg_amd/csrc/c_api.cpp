@@ -107,6 +107,15 @@ const char *mfmg_hip_last_error(void) { return g_last_error.c_str(); }
 const char *mfmg_hip_version(void) { return "mfmg-hip 0.3.0 (gfx950)"; }
 int mfmg_hip_abi_version(void) { return MFMG_HIP_ABI_VERSION; }
 
+int mfmg_hip_memory_inventory(char *buffer, size_t buffer_size)
+{
+  return guarded([&] {
+    require(buffer != nullptr && buffer_size > 0, "null argument");
+    const std::string text = DeviceMemoryLedger::get().report();
+    std::snprintf(buffer, buffer_size, "%s", text.c_str());
+  });
+}
+
 // ---- context -------------------------------------------------------------------
 int mfmg_hip_context_create(void *hip_stream, mfmg_hip_context_t *ctx)
 {
@@ -905,6 +914,20 @@ int mfmg_hip_mf_laplace_smoother_sweep(mfmg_hip_mf_laplace_t op, int n_terms, co
     if (!op->op->fused_sweep_available(n_terms))
       ASSERT_THROW_NOT_IMPLEMENTED("the multi-term smoother sweep is not available for this operator");
     op->op->smoother_sweep(n_terms, alpha, beta, b, x, out, out_prev);
+  });
+}
+int mfmg_hip_mf_laplace_set_sweep_reference(mfmg_hip_mf_laplace_t op, int on)
+{
+  return guarded([&] {
+    require(op != nullptr, "null operator");
+    op->op->set_fused_reference(on != 0);
+  });
+}
+int mfmg_hip_mf_laplace_f32_set_sweep_reference(mfmg_hip_mf_laplace_f32_t op, int on)
+{
+  return guarded([&] {
+    require(op != nullptr, "null operator");
+    op->op->set_fused_reference(on != 0);
   });
 }
 int mfmg_hip_mf_laplace_set_sweep_tile(mfmg_hip_mf_laplace_t op, int n_waves, int tile_y, int tile_z)

@@ -3,11 +3,13 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -111,6 +113,81 @@ private:
   size_t _n;
 };
 
+// ---- what the device memory is spent on: live bytes of the DeviceBuffers per (setup phase | kind of structure) ----
+// The phase is the section of the reference's TimerOutput that is open when a buffer is allocated (mfmg/timer.hpp:
+// "Setup: build restrictor", ...; the levels of the aggregation hierarchy add their own), the kind is set by the class that
+// allocates (MemoryKind scopes: CSR arrays, derived layouts, chunk records, restrictor planes, probe vectors ...).  A buffer
+// remembers the entry it was counted under and leaves it when it is released.  mfmg_hip_memory_inventory prints the table
+// (160 GB at 513^3 DoFs with no inventory).
+struct DeviceMemoryLedger
+{
+  struct Entry
+  {
+    int64_t live = 0, peak = 0;
+  };
+  std::mutex mutex;
+  std::map<std::string, Entry> entries;
+  static DeviceMemoryLedger &get()
+  {
+    static DeviceMemoryLedger l;
+    return l;
+  }
+  static std::string &phase()
+  {
+    static thread_local std::string p = "outside any setup section";
+    return p;
+  }
+  static char const *&kind()
+  {
+    static thread_local char const *k = "other";
+    return k;
+  }
+  Entry *add(int64_t bytes)
+  {
+    std::lock_guard<std::mutex> lock(mutex);
+    Entry &e = entries[phase() + " | " + kind()];
+    e.live += bytes;
+    e.peak = std::max(e.peak, e.live);
+    return &e; // (std::map nodes do not move)
+  }
+  void sub(Entry *e, int64_t bytes)
+  {
+    std::lock_guard<std::mutex> lock(mutex);
+    e->live -= bytes;
+  }
+  std::string report(int64_t at_least = 1 << 20)
+  {
+    std::lock_guard<std::mutex> lock(mutex);
+    std::string out;
+    int64_t total = 0;
+    for (auto const &kv : entries)
+    {
+      total += kv.second.live;
+      if (kv.second.live >= at_least)
+      {
+        char buf[320];
+        snprintf(buf, sizeof(buf), "%10.3f GB  %s\n", double(kv.second.live) * 1e-9, kv.first.c_str());
+        out += buf;
+      }
+    }
+    char buf[96];
+    snprintf(buf, sizeof(buf), "%10.3f GB  total in device buffers of the library\n", double(total) * 1e-9);
+    return out + buf;
+  }
+};
+struct MemoryKind
+{
+  explicit MemoryKind(char const *k) : _saved(DeviceMemoryLedger::kind()) { DeviceMemoryLedger::kind() = k; }
+  ~MemoryKind() { DeviceMemoryLedger::kind() = _saved; }
+  char const *_saved;
+};
+struct MemoryPhase
+{
+  explicit MemoryPhase(std::string const &p) : _saved(DeviceMemoryLedger::phase()) { DeviceMemoryLedger::phase() = p; }
+  ~MemoryPhase() { DeviceMemoryLedger::phase() = _saved; }
+  std::string _saved;
+};
+
 // ---- owning device buffer (cuda_malloc/cuda_free, include/mfmg/cuda/utils.cuh:66-99) ----
 template <typename T>
 class DeviceBuffer
@@ -120,10 +197,11 @@ public:
   explicit DeviceBuffer(size_t n) { resize(n); }
   DeviceBuffer(DeviceBuffer const &) = delete;
   DeviceBuffer &operator=(DeviceBuffer const &) = delete;
-  DeviceBuffer(DeviceBuffer &&o) noexcept : _ptr(o._ptr), _n(o._n)
+  DeviceBuffer(DeviceBuffer &&o) noexcept : _ptr(o._ptr), _n(o._n), _ledger(o._ledger)
   {
     o._ptr = nullptr;
     o._n = 0;
+    o._ledger = nullptr;
   }
   DeviceBuffer &operator=(DeviceBuffer &&o) noexcept
   {
@@ -132,8 +210,10 @@ public:
       release();
       _ptr = o._ptr;
       _n = o._n;
+      _ledger = o._ledger;
       o._ptr = nullptr;
       o._n = 0;
+      o._ledger = nullptr;
     }
     return *this;
   }
@@ -146,14 +226,20 @@ public:
     {
       MFMG_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&_ptr), n * sizeof(T)));
       _n = n;
+      _ledger = DeviceMemoryLedger::get().add((int64_t)(n * sizeof(T)));
     }
   }
   void release()
   {
     if (_ptr)
+    {
       (void)hipFree(_ptr);
+      if (_ledger)
+        DeviceMemoryLedger::get().sub(_ledger, (int64_t)(_n * sizeof(T)));
+    }
     _ptr = nullptr;
     _n = 0;
+    _ledger = nullptr;
   }
   void upload(T const *host, size_t n, hipStream_t stream = nullptr)
   {
@@ -182,6 +268,7 @@ public:
 private:
   T *_ptr = nullptr;
   size_t _n = 0;
+  DeviceMemoryLedger::Entry *_ledger = nullptr;
 };
 
 // ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) ----

@@ -864,6 +864,13 @@ HipSmoother::HipSmoother(std::shared_ptr<Operator<DVector> const> op, std::share
   // polynomial terms per sweep over the mesh (matrix-free operator, mf_cheb_fused.hip); 1 = one launch per term
   _fused_terms = this->_params->get("smoother.fused_terms", 3);
   ASSERT_THROW(_fused_terms >= 1 && _fused_terms <= 3, "smoother.fused_terms must be 1, 2 or 3");
+  // ... and the cell arithmetic of that sweep: "modes" (default) or "reference" (the one-term kernel's, bit for bit)
+  {
+    const std::string arith = to_lower(this->_params->get("smoother.sweep_arithmetic", "modes"));
+    ASSERT_THROW(arith == "modes" || arith == "reference", "smoother.sweep_arithmetic must be modes or reference");
+    if (auto mf = std::dynamic_pointer_cast<HipMatrixFreeOperator const>(_hip_operator))
+      mf->get_mesh_evaluator()->get_device_operator()->set_fused_reference(arith == "reference");
+  }
   if (_type == "jacobi")
   {
     _lambda_min = _lambda_max = 1.;

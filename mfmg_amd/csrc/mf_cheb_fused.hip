@@ -59,6 +59,7 @@ struct MfFusedArgs
   unsigned int rec_bytes;
   int dinv_in_record;
   T fax, fbx, fay, fby, faz, fbz, kd;
+  T lam[7]; // the cell matrix in mode space (MODES): lambda of the modes dss, sds, ssd, dds, dsd, sdd, ddd
   T alpha[3], beta[3];
   AffineIds aff;
   unsigned int vec_bytes, rec_total_bytes; // extents of the vectors / of the record array (descriptors; at most 2^32 - 1)
@@ -71,6 +72,50 @@ struct IntTag
 {
   static constexpr int value = V;
 };
+
+// The cell kernel in MODE SPACE (one coefficient per cell).  Per direction a Q1 cell acts on (u0, u1) through s = u0 + u1 and
+// d = u1 - u0 alone: the 1-D stiffness matrix is diag(0, 1), the mass matrices diag(1/2, 1/6) and f diag(1, 1/3) on (s, d), and the
+// result is (A_s - A_d, A_s + A_d).  So the 8 x 8 cell matrix is DIAGONAL on the eight modes (alpha, beta, gamma) in {s, d}^3
+// (lambda_sss = 0), and the transforms are butterflies that neighbouring cells share: the x-sums and differences belong to a NODE
+// (two operations per node instead of eight per cell), the y-butterfly to a cell row and node layer.  43 FP64 operations per cell
+// and 2 per node instead of 76 -- the sweep is bound by exactly these.  Different rounding from cell_apply_cc (same operator to
+// 1e-15 per cell): the sweep keeps both, `MODES = false` is the bit-for-bit twin of the one-term kernel.
+template <typename T>
+struct ModeFactors
+{
+  T dss, sds, ssd, dds, dsd, sdd, ddd;
+};
+
+// cell row q of a stage pass: P / Q = x-sum / x-difference at the node rows q (0) and q + 1 (1) of the lower (l) and upper (u)
+// node layer.  Out: what the row contributes to the node row below it (low: the b = 0 corners) and above it (up), as the
+// z-modes s (A) and d (B), already summed over the two cells of the row that share a node column.
+template <typename T>
+__device__ __forceinline__ void cell_row_modes(T Pl0, T Pl1, T Ql0, T Ql1, T Pu0, T Pu1, T Qu0, T Qu1, T cv, ModeFactors<T> const &m,
+                                               T &lowA, T &lowB, T &upA, T &upB)
+{
+#pragma clang fp contract(off)
+  // y butterfly (per node layer)
+  const T PPl = Pl0 + Pl1, PDl = Pl1 - Pl0, QPl = Ql0 + Ql1, QDl = Ql1 - Ql0;
+  const T PPu = Pu0 + Pu1, PDu = Pu1 - Pu0, QPu = Qu0 + Qu1, QDu = Qu1 - Qu0;
+  // z butterfly: the seven modes with a non-zero lambda, scaled by lambda and the cell's coefficient
+  const T w_ssd = (m.ssd * (PPu - PPl)) * cv;
+  const T w_sds = (m.sds * (PDl + PDu)) * cv;
+  const T w_sdd = (m.sdd * (PDu - PDl)) * cv;
+  const T w_dss = (m.dss * (QPl + QPu)) * cv;
+  const T w_dsd = (m.dsd * (QPu - QPl)) * cv;
+  const T w_dds = (m.dds * (QDl + QDu)) * cv;
+  const T w_ddd = (m.ddd * (QDu - QDl)) * cv;
+  // x back: corner a = 0 gets w_s - w_d, a = 1 gets w_s + w_d; the node column = its own cell's a = 0 + the left cell's a = 1
+  const T G_ss = from_prev_lane(w_dss) - w_dss;                 // (w_sss = 0)
+  const T G_sd = (w_ssd - w_dsd) + from_prev_lane(w_ssd + w_dsd); // (beta, gamma) = (s, d)
+  const T G_ds = (w_sds - w_dds) + from_prev_lane(w_sds + w_dds);
+  const T G_dd = (w_sdd - w_ddd) + from_prev_lane(w_sdd + w_ddd);
+  // y back: node row q (b = 0) gets G_s - G_d, node row q + 1 gets G_s + G_d
+  lowA = G_ss - G_ds;
+  upA = G_ss + G_ds;
+  lowB = G_sd - G_dd;
+  upB = G_sd + G_dd;
+}
 
 // ring s holds x_s: three slots where a later stage still reads the own value of the layer two below (the momentum term of
 // stage s + 2), two for the last one
@@ -110,7 +155,7 @@ struct BufIO<float>
 };
 
 // DBG (timing experiments only, wrong results): 1 = no barrier, 2 = no division, 3 = no global stores
-template <typename T, int K, int TY, bool DREC, int DBG = 0>
+template <typename T, int K, int TY, bool DREC, bool MODES, int DBG = 0>
 __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
 {
 #pragma clang fp contract(off)
@@ -176,6 +221,14 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
   fac.fby = a.fby;
   fac.faz = a.faz;
   fac.fbz = a.fbz;
+  ModeFactors<T> mf;
+  mf.dss = a.lam[0];
+  mf.sds = a.lam[1];
+  mf.ssd = a.lam[2];
+  mf.dds = a.lam[3];
+  mf.dsd = a.lam[4];
+  mf.sdd = a.lam[5];
+  mf.ddd = a.lam[6];
 
   // wave-uniform description of the node rows, one bit per row
   unsigned int rows_free = 0, rows_own = 0;
@@ -302,38 +355,80 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
       xln[r] = from_next_lane(xl[r]);
       xun[r] = from_next_lane(xu[r]);
     }
-    T s00[TY], s10[TY], s01[TY], s11[TY], sx[TY];
-#pragma unroll
-    for (int q = 0; q < TY; ++q)
+    // per cell row: what it contributes to the node row below (low) and above (up), two values each -- the corner sums of the
+    // d = 0 / d = 1 node layer (reference arithmetic) or the z-modes s / d (MODES)
+    T lowA[TY], lowB[TY], upA[TY], upB[TY], sx[TY];
+    if constexpr (MODES)
     {
-      T u[8], v[8];
-      u[0] = xl[q];
-      u[1] = xln[q];
-      u[2] = xl[q + 1];
-      u[3] = xln[q + 1];
-      u[4] = xu[q];
-      u[5] = xun[q];
-      u[6] = xu[q + 1];
-      u[7] = xun[q + 1];
-      const T cv = cq[S - 1][q];
-      cell_apply_cc<T>(u, cv, fac, v);
-      // x combine: DoF column ci gets the a=0 corners of its own cell and the a=1 corners of the cell of the lane to the left
-      s00[q] = v[0] + from_prev_lane(v[1]);
-      s10[q] = v[2] + from_prev_lane(v[3]);
-      s01[q] = v[4] + from_prev_lane(v[5]);
-      s11[q] = v[6] + from_prev_lane(v[7]);
-      sx[q] = T(0);
-      if constexpr (S == 1 && !DREC)
-        sx[q] = cv + from_prev_lane(cv);
+      T Pl[R], Ql[R], Pu[R], Qu[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+      {
+        Pl[r] = xl[r] + xln[r];
+        Ql[r] = xln[r] - xl[r];
+        Pu[r] = xu[r] + xun[r];
+        Qu[r] = xun[r] - xu[r];
+      }
+#pragma unroll
+      for (int q = 0; q < TY; ++q)
+      {
+        const T cv = cq[S - 1][q];
+        cell_row_modes<T>(Pl[q], Pl[q + 1], Ql[q], Ql[q + 1], Pu[q], Pu[q + 1], Qu[q], Qu[q + 1], cv, mf, lowA[q], lowB[q], upA[q], upB[q]);
+        sx[q] = T(0);
+        if constexpr (S == 1 && !DREC)
+          sx[q] = cv + from_prev_lane(cv);
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int q = 0; q < TY; ++q)
+      {
+        T u[8], v[8];
+        u[0] = xl[q];
+        u[1] = xln[q];
+        u[2] = xl[q + 1];
+        u[3] = xln[q + 1];
+        u[4] = xu[q];
+        u[5] = xun[q];
+        u[6] = xu[q + 1];
+        u[7] = xun[q + 1];
+        const T cv = cq[S - 1][q];
+        cell_apply_cc<T>(u, cv, fac, v);
+        // x combine: DoF column ci gets the a=0 corners of its own cell and the a=1 corners of the cell of the lane to the left
+        lowA[q] = v[0] + from_prev_lane(v[1]);
+        upA[q] = v[2] + from_prev_lane(v[3]);
+        lowB[q] = v[4] + from_prev_lane(v[5]);
+        upB[q] = v[6] + from_prev_lane(v[7]);
+        sx[q] = T(0);
+        if constexpr (S == 1 && !DREC)
+          sx[q] = cv + from_prev_lane(cv);
+      }
     }
     // the sums of the last cell row go up, those of the first go down (double-buffered by the parity of the pass)
     {
       T *xp = xport + (size_t)((ex & 1) * NW + wv) * 4 * 64;
-      xp[0] = s10[TY - 1];
-      xp[64] = s11[TY - 1];
-      xp[128] = s00[0];
-      xp[192] = s01[0];
+      xp[0] = upA[TY - 1];
+      xp[64] = upB[TY - 1];
+      xp[128] = lowA[0];
+      xp[192] = lowB[0];
     }
+    // a node row is complete: A, B = its two sums over the cell rows below and above; the value of the DoF layer c and the carry
+    // for the layer above (reference: A belongs to layer c, B to c + 1; MODES: the z butterfly back)
+    auto z_combine = [&](T A, T B, T &carry) -> T {
+      if constexpr (MODES)
+      {
+        const T yv = (A - B) + carry;
+        carry = A + B;
+        return yv;
+      }
+      else
+      {
+        const T yv = A + carry;
+        carry = B;
+        return yv;
+      }
+    };
     // one DoF (row r, layer c) of this stage is complete: yv = (A x_{S-1}) there
     auto finish = [&](auto rtag, T yv, T tcs) {
       constexpr int r = decltype(rtag)::value;
@@ -407,10 +502,9 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
     // the rows between the wavefront's own cells
     auto inner = [&](auto rtag) {
       constexpr int r = decltype(rtag)::value;
-      const T t0 = s00[r] + s10[r - 1];
-      const T t1 = s01[r] + s11[r - 1];
-      const T yv = t0 + pt[S - 1][r];
-      pt[S - 1][r] = t1;
+      const T t0 = lowA[r] + upA[r - 1];
+      const T t1 = lowB[r] + upB[r - 1];
+      const T yv = z_combine(t0, t1, pt[S - 1][r]);
       finish(rtag, yv, sx[r] + sx[r - 1]);
     };
     if constexpr (TY >= 2)
@@ -439,20 +533,18 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
         hi1 = ip[192];
       }
       {
-        const T t0 = s00[0] + lo0;
-        const T t1 = s01[0] + lo1;
-        const T yv = t0 + pt[S - 1][0];
-        pt[S - 1][0] = t1;
+        const T t0 = lowA[0] + lo0;
+        const T t1 = lowB[0] + lo1;
+        const T yv = z_combine(t0, t1, pt[S - 1][0]);
         T tcs = T(0);
         if constexpr (S == 1 && !DREC)
           tcs = sx[0] + (clo + from_prev_lane(clo));
         finish(IntTag<0>{}, yv, tcs);
       }
       {
-        const T t0 = hi0 + s10[TY - 1];
-        const T t1 = hi1 + s11[TY - 1];
-        const T yv = t0 + pt[S - 1][TY];
-        pt[S - 1][TY] = t1;
+        const T t0 = hi0 + upA[TY - 1];
+        const T t1 = hi1 + upB[TY - 1];
+        const T yv = z_combine(t0, t1, pt[S - 1][TY]);
         T tcs = T(0);
         if constexpr (S == 1 && !DREC)
           tcs = (chi + from_prev_lane(chi)) + sx[TY - 1];
@@ -529,10 +621,10 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
   }
 }
 
-template <typename T, int K, int TY, bool DREC, int DBG = 0>
+template <typename T, int K, int TY, bool DREC, bool MODES, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void mf_cheb_fused_kernel(MfFusedArgs<T> a)
 {
-  mf_cheb_fused_body<T, K, TY, DREC, DBG>(a);
+  mf_cheb_fused_body<T, K, TY, DREC, MODES, DBG>(a);
 }
 } // namespace
 
@@ -642,6 +734,14 @@ void MatrixFreeLaplaceDevice<T>::smoother_sweep(int n_terms, T const *alpha, T c
     a.faz = T(2. * f[2] * m00);
     a.fbz = T(2. * f[2] * m01);
     a.kd = T(2. * m00 * m00 * (f[0] + f[1] + f[2]));
+    // the cell matrix on the modes (cell_row_modes): stiffness diag(0, 1), masses diag(1/2, 1/6) and f diag(1, 1/3)
+    a.lam[0] = T(f[0] / 2.);
+    a.lam[1] = T(f[1] / 2.);
+    a.lam[2] = T(f[2] / 2.);
+    a.lam[3] = T((f[0] + f[1]) / 6.);
+    a.lam[4] = T((f[0] + f[2]) / 6.);
+    a.lam[5] = T((f[1] + f[2]) / 6.);
+    a.lam[6] = T((f[0] + f[1] + f[2]) / 18.);
   }
   for (int s = 0; s < 3; ++s)
   {
@@ -677,45 +777,49 @@ void MatrixFreeLaplaceDevice<T>::smoother_sweep(int n_terms, T const *alpha, T c
     }
     hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(64 * nw), lds, st, a);
   };
-  auto pick = [&](auto kt, auto dt) {
+  // the arithmetic of the cell kernel: mode space (default) or the bit-for-bit twin of the one-term kernel (set_fused_reference)
+  const bool modes = !_fused_reference_arithmetic;
+  auto pick = [&](auto kt, auto dt, auto mt) {
     constexpr int KK = decltype(kt)::value;
     constexpr bool DR = decltype(dt)::value != 0;
+    constexpr bool MO = decltype(mt)::value != 0;
     if (ty == 2)
-      go(mf_cheb_fused_kernel<T, KK, 2, DR>);
+      go(mf_cheb_fused_kernel<T, KK, 2, DR, MO>);
     else if (ty == 3)
-      go(mf_cheb_fused_kernel<T, KK, 3, DR>);
+      go(mf_cheb_fused_kernel<T, KK, 3, DR, MO>);
     else
-      go(mf_cheb_fused_kernel<T, KK, 4, DR>);
+      go(mf_cheb_fused_kernel<T, KK, 4, DR, MO>);
+  };
+  auto pick_k = [&](auto kt) {
+    if (_dinv_in_record)
+    {
+      if (modes)
+        pick(kt, IntTag<1>{}, IntTag<1>{});
+      else
+        pick(kt, IntTag<1>{}, IntTag<0>{});
+    }
+    else
+    {
+      if (modes)
+        pick(kt, IntTag<0>{}, IntTag<1>{});
+      else
+        pick(kt, IntTag<0>{}, IntTag<0>{});
+    }
   };
   static const int dbg = std::getenv("MFMG_MF_FUSED_DBG") ? std::atoi(std::getenv("MFMG_MF_FUSED_DBG")) : 0;
   if (dbg > 0 && n_terms == 3 && ty == 3 && !_dinv_in_record && std::is_same<T, double>::value)
   {
     if (dbg == 1)
-      go(mf_cheb_fused_kernel<T, 3, 3, false, 1>);
+      go(mf_cheb_fused_kernel<T, 3, 3, false, true, 1>);
     else
-      go(mf_cheb_fused_kernel<T, 3, 3, false, 2>);
+      go(mf_cheb_fused_kernel<T, 3, 3, false, true, 2>);
   }
   else if (n_terms == 1)
-  {
-    if (_dinv_in_record)
-      pick(IntTag<1>{}, IntTag<1>{});
-    else
-      pick(IntTag<1>{}, IntTag<0>{});
-  }
+    pick_k(IntTag<1>{});
   else if (n_terms == 2)
-  {
-    if (_dinv_in_record)
-      pick(IntTag<2>{}, IntTag<1>{});
-    else
-      pick(IntTag<2>{}, IntTag<0>{});
-  }
+    pick_k(IntTag<2>{});
   else
-  {
-    if (_dinv_in_record)
-      pick(IntTag<3>{}, IntTag<1>{});
-    else
-      pick(IntTag<3>{}, IntTag<0>{});
-  }
+    pick_k(IntTag<3>{});
   MFMG_HIP_CHECK(hipGetLastError());
   KernelProfiler::end(stop, st);
 }

@@ -807,6 +807,7 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
                                                     bool sub_mesh)
     : _handle(handle)
 {
+  MemoryKind kind("matrix-free operator: chunk records, diagonal");
   if (mesh.dim != 3 && mesh.dim != 2)
     ASSERT_THROW_NOT_IMPLEMENTED("the matrix-free HIP operator is implemented for dim = 2 and dim = 3");
   ASSERT_THROW(mesh.cell_dofs && mesh.coefficient && mesh.constrained,

@@ -111,6 +111,10 @@ public:
   }
   void get_fused_tile(int n_terms, int &nw, int &ty, int &tz) const { choose_fused_tile(n_terms, nw, ty, tz); }
   int halo_lanes() const { return _halo; }
+  // the sweep's cell kernel: mode space (default: ~30 % fewer FP64 operations, its own rounding) or the arithmetic of the
+  // one-term kernel (the sweep is then bit-identical to smoother_step after smoother_step)
+  void set_fused_reference(bool on) { _fused_reference_arithmetic = on; }
+  bool fused_reference() const { return _fused_reference_arithmetic; }
   // bytes one sweep of n_terms must move at least: x_0, b, one coefficient per cell (D^-1 where the records hold it), x_K
   double fused_sweep_bytes(bool with_prev) const { return double(_n_dofs) * sizeof(T) * (4. + (_dinv_in_record ? 1. : 0.) + (with_prev ? 1. : 0.)); }
 
@@ -183,6 +187,7 @@ private:
   void choose_tile(int &nw, int &ty, int &tz) const;
   void choose_fused_tile(int n_terms, int &nw, int &ty, int &tz) const;
   int _fused_tile[3] = {0, 0, 0};
+  bool _fused_reference_arithmetic = false;
 
   HipHandle &_handle;
   int _N[3]; // DoF grid

@@ -3,6 +3,8 @@
 // wall time accumulated per section, summary table on request.
 #pragma once
 
+#include "../common.hpp"
+
 #include <dlfcn.h>
 
 #include <chrono>
@@ -111,15 +113,29 @@ inline RoctxApi const &roctx_api()
   return api;
 }
 
+// (the open section is also the PHASE device allocations are booked under: common.hpp, DeviceMemoryLedger)
+inline std::vector<std::string> &memory_phase_stack()
+{
+  static thread_local std::vector<std::string> s;
+  return s;
+}
 inline void timer_enter_subsection(std::shared_ptr<TimerOutput> timer, std::string const &section)
 {
   if (roctx_api().push)
     roctx_api().push(section.c_str());
   if (timer)
     timer->enter_subsection(section);
+  memory_phase_stack().push_back(DeviceMemoryLedger::phase());
+  if (section != "Setup" && section.rfind("Apply", 0) != 0) // (the outer section and the apply sections keep the phase they run in)
+    DeviceMemoryLedger::phase() = section;
 }
 inline void timer_leave_subsection(std::shared_ptr<TimerOutput> timer)
 {
+  if (!memory_phase_stack().empty())
+  {
+    DeviceMemoryLedger::phase() = memory_phase_stack().back();
+    memory_phase_stack().pop_back();
+  }
   if (timer)
     timer->leave_subsection();
   if (roctx_api().pop)

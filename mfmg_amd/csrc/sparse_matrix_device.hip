@@ -1131,9 +1131,12 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
     ASSERT_THROW(cols_ok, "column index out of range");
   }
   // (the CSR arrays go to the device first: the layout analysis runs on them)
-  _val.upload(val.data(), val.size(), handle.stream);
-  _col.upload(col.data(), col.size(), handle.stream);
-  _row_ptr.upload(row_ptr.data(), row_ptr.size(), handle.stream);
+  {
+    MemoryKind kind("CSR arrays (val, col, row_ptr)");
+    _val.upload(val.data(), val.size(), handle.stream);
+    _col.upload(col.data(), col.size(), handle.stream);
+    _row_ptr.upload(row_ptr.data(), row_ptr.size(), handle.stream);
+  }
   _row_ptr_host = std::move(row_ptr);
   _col_host = std::move(col);
   _val_host = std::move(val);
@@ -1264,6 +1267,7 @@ void SparseMatrixDevice<T>::sample_rows(std::vector<int64_t> const &rows, std::v
 template <typename T>
 void SparseMatrixDevice<T>::choose_layouts(bool analyse)
 {
+  MemoryKind kind("derived layouts (planes, tables, node lists)");
   HipHandle &handle = _handle;
   const int64_t n_rows = _n_rows, n_cols = _n_cols;
   const double avg = n_rows > 0 ? double(_nnz) / double(n_rows) : 0.;

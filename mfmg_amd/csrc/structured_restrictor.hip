@@ -358,6 +358,7 @@ StructuredRestrictorDevice::create(HipHandle &handle, StructuredMesh const &mesh
                                    int const agg_dims[3], std::vector<int32_t> const &row_agglomerate,
                                    HostCsr const &R)
 {
+  MemoryKind kind("restrictor: planes, block tables, node lists");
   if (mesh.dim != 3 || R.n_rows == 0 || (int64_t)row_agglomerate.size() != R.n_rows)
     return nullptr;
   int64_t n_agg = 1, n_nodes = 1;

@@ -111,6 +111,7 @@ def load() -> C.CDLL:
         "mfmg_hip_rccl_unique_id": (C.c_int, [vp]),
         "mfmg_hip_rccl_available": (C.c_int, []),
         "mfmg_hip_abi_version": (C.c_int, []),
+        "mfmg_hip_memory_inventory": (C.c_int, [C.c_char_p, sz]),
         "mfmg_hip_context_use_rccl": (C.c_int, [vp, vp]),
         "mfmg_hip_context_use_host_transport": (C.c_int, [vp, vp, vp, vp, vp]),
         "mfmg_hip_context_use_reflecting_transport": (C.c_int, [vp]),
@@ -134,6 +135,8 @@ def load() -> C.CDLL:
         "mfmg_hip_mf_laplace_sweep_available": (C.c_int, [vp, C.c_int, P(C.c_int)]),
         "mfmg_hip_mf_laplace_smoother_sweep": (C.c_int, [vp, C.c_int, P(dbl), P(dbl), vp, vp, vp, vp]),
         "mfmg_hip_mf_laplace_set_sweep_tile": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+        "mfmg_hip_mf_laplace_set_sweep_reference": (C.c_int, [vp, C.c_int]),
+        "mfmg_hip_mf_laplace_f32_set_sweep_reference": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_mf_laplace_get_sweep_tile": (C.c_int, [vp, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int)]),
         "mfmg_hip_mf_laplace_f32_sweep_available": (C.c_int, [vp, C.c_int, P(C.c_int)]),
         "mfmg_hip_mf_laplace_f32_smoother_sweep": (C.c_int, [vp, C.c_int, P(C.c_float), P(C.c_float), vp, vp, vp, vp]),

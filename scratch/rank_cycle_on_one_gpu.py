@@ -35,15 +35,27 @@ if os.environ.get("AMG_REPLICATE_ROWS"):      # levels with fewer global rows ar
     params["solver"]["amg"]["replicate_rows"] = int(os.environ["AMG_REPLICATE_ROWS"])
 
 def cycles(ctx, h, n, steps=10, warmup=3):
+    """ms per cycle: median over five blocks of `steps` / 2 cycles, the collector off meanwhile (this process holds the Python
+    objects of eight ranks: a generation-2 collection in the middle of a block cost 20-90 ms in the first runs of round 4)."""
+    import gc
     x = torch.rand(n, dtype=torch.float64, device="cuda"); b = torch.zeros_like(x)
     for _ in range(warmup):
         h.apply(b, x)
-    ctx.synchronize(); torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(steps):
-        h.apply(b, x)
-    ctx.synchronize(); torch.cuda.synchronize()
-    return (time.perf_counter() - t) / steps * 1e3
+    gc.collect()
+    gc.disable()
+    try:
+        blocks = []
+        per = max(steps // 2, 1)
+        for _ in range(5):
+            ctx.synchronize(); torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(per):
+                h.apply(b, x)
+            ctx.synchronize(); torch.cuda.synchronize()
+            blocks.append((time.perf_counter() - t) / per * 1e3)
+    finally:
+        gc.enable()
+    return sorted(blocks)[len(blocks) // 2]
 
 # ---- what one grouped RCCL send/recv costs its stream before a byte crosses a wire: loop-back on this GPU
 loopback_us = None
@@ -56,6 +68,9 @@ except Exception as e:  # noqa: BLE001
     loopback_us = {"error": str(e)[:200]}
 delays = [float(v) for v in os.environ.get("DELAY_US", "").split(",") if v] or \
     ([round(loopback_us["2048 doubles"], 1)] if "2048 doubles" in loopback_us else [25.0])
+
+if os.environ.get("TRACE") == "1":  # (kernel trace: the LAST cycles of the process must be the free-wire ones)
+    delays = []
 
 # ---- one rank of the same size, no partition
 ctx1 = M.Context()
@@ -84,8 +99,35 @@ def worker(rank):
         if rank == timed_rank:
             tr.reflect()
             e0, v0, o0 = tr.n_exchanges(), tr.exchange_volume(), tr.n_overlapped()
+            if os.environ.get("DEBUG_PHASES") == "1":
+                # wall clock of the pieces of a cycle, each synchronised: where a rank stalls
+                nf, nc = h.level_size(0), h.level_size(1)
+                xx = torch.rand(nf, dtype=torch.float64, device="cuda"); bb = torch.rand_like(xx); yy = torch.empty_like(xx)
+                xc = torch.rand(nc, dtype=torch.float64, device="cuda"); yc = torch.empty_like(xc)
+                def tm(name, f, reps=10):
+                    f(); ctx.synchronize()
+                    t = time.perf_counter()
+                    for _ in range(reps):
+                        f()
+                    ctx.synchronize()
+                    print(f"[phase] {name:28s} {(time.perf_counter() - t) / reps * 1e3:8.3f} ms", flush=True)
+                tm("smoother_apply", lambda: h.smoother_apply(0, bb, xx))
+                tm("operator_apply", lambda: h.operator_apply(0, xx, yy))
+                tm("restrict_residual", lambda: h.restrict_residual(xx, bb, yc))
+                tm("coarse_apply", lambda: h.coarse_apply(xc, yc))
+                tm("prolongation", lambda: h.restrictor_apply(1, xc, yy, 1))
+                tm("whole cycle", lambda: h.apply(bb, xx))
+                zz = torch.zeros_like(xx)
+                tm("whole cycle, b = 0", lambda: h.apply(zz, xx))
+                x2 = torch.rand(nf, dtype=torch.float64, device="cuda")
+                each = []
+                for _ in range(14):
+                    ctx.synchronize(); t = time.perf_counter()
+                    h.apply(zz, x2)
+                    ctx.synchronize(); each.append(round((time.perf_counter() - t) * 1e3, 3))
+                print("[phase] per-cycle ms, fresh x, b = 0:", each, "max |x|", float(x2.abs().max()), flush=True)
             ms = cycles(ctx, h, h.level_size(0))
-            n_cyc = 13
+            n_cyc = 3 + 5 * 5
             result.update({"rank": rank, "grid": list(grid), "cells_per_rank": per, "local_cells": list(part.local_cells),
                            "ms_per_cycle_rank_alone_reflecting": ms, "ms_per_cycle_one_rank_same_size": ms_single,
                            "ratio": ms / ms_single, "exchanges_per_cycle": (tr.n_exchanges() - e0) / n_cyc,

@@ -1221,7 +1221,8 @@ def test_cycle_with_the_multi_term_sweep_is_the_term_by_term_cycle(ctx, n, degre
     term on chunk records with one halo lane: the same V-cycle bit for bit -- iterates and residual history, any number of
     smoothing steps (an odd number of out-of-place applications ends in the workspace vector and is copied back)."""
     prob = M.LaplaceProblem(n, "constant", device="cuda")
-    sm = {"type": "Chebyshev", "degree": degree, "smoothing_range": 20.0, "n_smoothing_steps": steps, "lambda_max": 1.9, "lambda_min": 0.095}
+    sm = {"type": "Chebyshev", "degree": degree, "smoothing_range": 20.0, "n_smoothing_steps": steps, "lambda_max": 1.9, "lambda_min": 0.095,
+          "sweep_arithmetic": "reference"}
     amg = {"coarsest_size": 300, "pre_smoothing_levels": 0}
     h_sweep = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, base_params(smoother=dict(sm), solver={"type": "amg", "amg": dict(amg)}))
     assert h_sweep.smoother_sweep_terms() == (min(degree - 1, 3) if degree >= 3 else 0, min(degree, 3))

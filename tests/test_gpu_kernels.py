@@ -370,6 +370,7 @@ def test_smoother_sweep_equals_term_by_term_bit_for_bit(ctx, n, material, n_term
     prob = _cellwise_problem(n) if material == "cellwise" else M.LaplaceProblem(n, material, device="cuda")
     op = M.MatrixFreeLaplace(ctx, prob)
     assert op.sweep_available(n_terms)
+    op.set_sweep_reference(True)          # the arithmetic of the one-term kernel (the default, mode space, rounds differently)
     N = prob.n_dofs
     g = torch.Generator(device="cuda")
     g.manual_seed(1234)
@@ -394,6 +395,20 @@ def test_smoother_sweep_equals_term_by_term_bit_for_bit(ctx, n, material, n_term
     op.smoother_sweep(al, be, b, x, out2, None)           # without the second output
     ctx.synchronize()
     assert torch.equal(out2, its[-1])
+    # the default arithmetic -- the cell matrix in mode space, butterflies shared between neighbouring cells -- is the same
+    # operator with its own rounding, and it does not depend on the tiling either (bit for bit)
+    op.set_sweep_reference(False)
+    outm = torch.full_like(x, float("nan"))
+    outmp = torch.full_like(x, float("nan"))
+    op.smoother_sweep(al, be, b, x, outm, outmp)
+    ctx.synchronize()
+    assert (outm - its[-1]).abs().max().item() <= 1e-13 * its[-1].abs().max().item()
+    assert (outmp - its[-2]).abs().max().item() <= 1e-13 * its[-2].abs().max().item()
+    op.set_sweep_tile(3, 3, 4)
+    outm2 = torch.full_like(x, float("nan"))
+    op.smoother_sweep(al, be, b, x, outm2, None)
+    ctx.synchronize()
+    assert torch.equal(outm2, outm)
 
 
 def test_smoother_sweep_against_the_oracle_and_other_layouts(ctx):
@@ -428,6 +443,7 @@ def test_smoother_sweep_against_the_oracle_and_other_layouts(ctx):
     assert relerr(host(out_s, ctx), want) < TOL
     op32 = M.MatrixFreeLaplaceF32(ctx, prob)
     assert op32.sweep_available(3)
+    op32.set_sweep_reference(True)
     o32 = torch.empty(mesh.n_dofs, dtype=torch.float32, device="cuda")
     x32, b32 = dev(x).float(), dev(b).float()
     op32.smoother_sweep(al, be, b32, x32, o32)
