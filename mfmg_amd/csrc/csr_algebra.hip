@@ -257,6 +257,7 @@ bool csr_transpose_device(HipHandle &h, int64_t n_rows, int64_t n_cols, int64_t 
     MFMG_HIP_CHECK(hipMemsetAsync(d_tptr.data(), 0, ((size_t)n_cols + 1) * sizeof(int32_t), st));
     return true;
   }
+  MemoryKind kind("CSR arrays (val, col, row_ptr)");
   DeviceBuffer<int32_t> count((size_t)n_cols + 1), cursor((size_t)n_cols);
   MFMG_HIP_CHECK(hipMemsetAsync(count.data(), 0, ((size_t)n_cols + 1) * sizeof(int32_t), st));
   MFMG_HIP_CHECK(hipMemsetAsync(cursor.data(), 0, (size_t)n_cols * sizeof(int32_t), st));

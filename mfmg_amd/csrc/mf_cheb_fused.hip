@@ -647,8 +647,10 @@ bool MatrixFreeLaplaceDevice<T>::fused_sweep_available(int n_terms) const
 template <typename T>
 void MatrixFreeLaplaceDevice<T>::choose_fused_tile(int n_terms, int &nw, int &ty, int &tz) const
 {
-  nw = 8;
-  ty = 3;
+  // (measured at 257^3 DoFs: three terms 8 x 3 rows -- four rows per wavefront spill --, two terms 4 x 4: two independent
+  // workgroups per CU, 0.31 against 0.34 ms)
+  nw = n_terms == 2 ? 4 : 8;
+  ty = n_terms == 2 ? 4 : 3;
   tz = 0;
   static const std::string env = std::getenv("MFMG_MF_FUSED_TILE") ? std::getenv("MFMG_MF_FUSED_TILE") : "";
   if (_fused_tile[0] > 0)

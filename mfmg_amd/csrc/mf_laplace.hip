@@ -152,7 +152,9 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
   const int id_lane = a.aff.base + ci * a.aff.s0; // (AFF) the part of the id that belongs to the lane
   const bool lane_in = ci >= 0 && ci < a.Nx;
   const bool lane_face = ((a.aff.faces & 1) && ci == 0) || ((a.aff.faces & 2) && ci == a.Nx - 1);
-  const bool lane_ghost = ci < a.aff.ghost_lo[0] || ci >= a.Nx - a.aff.ghost_hi[0];
+  // (one rank: no ghost planes at all -- the tests below would cost the eight-coefficient kernel a dozen scalar operations per row)
+  const bool any_ghost = (a.aff.ghost_lo[0] | a.aff.ghost_hi[0] | a.aff.ghost_lo[1] | a.aff.ghost_hi[1] | a.aff.ghost_lo[2] | a.aff.ghost_hi[2]) != 0;
+  const bool lane_ghost = any_ghost && (ci < a.aff.ghost_lo[0] || ci >= a.Nx - a.aff.ghost_hi[0]);
   auto own_id = [&](int kz, int jrow) {
     const int jr = min(max(jrow, 0), a.Ny - 1);
     if constexpr (AFF)
@@ -161,7 +163,7 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
       const int id_row = jr * a.aff.s1 + kz * a.aff.s2;
       const bool row_face = ((a.aff.faces & 4) && jr == 0) || ((a.aff.faces & 8) && jr == a.Ny - 1) ||
                             ((a.aff.faces & 16) && kz == 0) || ((a.aff.faces & 32) && kz == a.Nz - 1);
-      const bool row_ghost = kz < a.aff.ghost_lo[2] || kz >= a.Nz - a.aff.ghost_hi[2] || jr < a.aff.ghost_lo[1] || jr >= a.Ny - a.aff.ghost_hi[1];
+      const bool row_ghost = any_ghost && (kz < a.aff.ghost_lo[2] || kz >= a.Nz - a.aff.ghost_hi[2] || jr < a.aff.ghost_lo[1] || jr >= a.Ny - a.aff.ghost_hi[1]);
       // (a node on a Dirichlet face carries the Dirichlet flag only, also in a ghost plane: mfmg_amd/distributed.py, local_problem)
       const bool face = lane_face || row_face;
       const int id = (id_lane + id_row) | (face ? (int)kFlag : 0) | (((lane_ghost || row_ghost) && !face) ? (int)kGhost : 0);

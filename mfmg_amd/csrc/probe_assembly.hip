@@ -353,6 +353,7 @@ template <typename Geom, typename CountLaunch, typename FillLaunch>
 std::shared_ptr<SparseMatrixDevice<double>> assemble(HipHandle &h, int64_t n_rows, int64_t n_cols, char const *what, CountLaunch &&count,
                                                      FillLaunch &&fill)
 {
+  MemoryKind kind("CSR arrays (val, col, row_ptr)");
   DeviceBuffer<int32_t> row_ptr((size_t)n_rows + 1);
   MFMG_HIP_CHECK(hipMemsetAsync(row_ptr.data(), 0, ((size_t)n_rows + 1) * sizeof(int32_t), h.stream));
   count(row_ptr.data());
