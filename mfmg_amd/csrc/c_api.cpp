@@ -97,7 +97,7 @@ struct mfmg_hip_hierarchy_s
   mfmg_hip_csr_s restrictor_view, coarse_view, amg_view, fine_view;
   // "fine level precision" float: the matrix-free operator and its smoother in FP32 around the FP64 coarse levels
   std::shared_ptr<MatrixFreeLaplaceDevice<float>> fine_f32;
-  DeviceBuffer<float> f32_a, f32_b, f32_res;
+  DeviceBuffer<float> f32_a, f32_b, f32_c, f32_res;
   std::shared_ptr<DVector> f32_res64, f32_bc, f32_xc, f32_corr64;
 };
 
@@ -1124,25 +1124,53 @@ int mfmg_hip_hierarchy_apply_f32(mfmg_hip_hierarchy_t h, const float *b, float *
       h->f32_xc = levels[1].get_operator()->build_range_vector();
     }
     auto const &op = *h->fine_f32;
-    // x <- x - B^-1 (A x - b), one fused kernel per polynomial term, targets alternating so that the last lands in x
-    auto smooth = [&]() {
-      if (d == 1)
+    if (h->f32_c.size() == 0)
+      h->f32_c.resize(n);
+    // x_out <- x_in - B^-1 (A x_in - b) on two different vectors: the first K terms of the polynomial in one sweep where the
+    // FP32 operator offers it (all of them for degree <= smoother.fused_terms), else one fused kernel per term
+    const int fused = smoother->fused_terms();
+    auto smooth_to = [&](float const *x_in, float *x_out) {
+      float const *cur = x_in, *prev = nullptr;
+      int k0 = 0;
+      const int K = std::min(d, fused);
+      if (K >= 2 && coef[0].first == 0. && op.fused_sweep_available(K))
       {
-        op.smoother_step(b, x, nullptr, 0.f, (float)coef[0].second, h->f32_a.data());
-        MFMG_HIP_CHECK(hipMemcpyAsync(x, h->f32_a.data(), sizeof(float) * n, hipMemcpyDeviceToDevice, hd.stream));
-        return;
+        float alpha[3], beta[3];
+        for (int k = 0; k < K; ++k)
+        {
+          alpha[k] = (float)coef[k].first;
+          beta[k] = (float)coef[k].second;
+        }
+        if (K == d)
+        {
+          op.smoother_sweep(K, alpha, beta, b, x_in, x_out, nullptr);
+          return;
+        }
+        op.smoother_sweep(K, alpha, beta, b, x_in, h->f32_a.data(), h->f32_b.data());
+        cur = h->f32_a.data();
+        prev = h->f32_b.data();
+        k0 = K;
       }
-      std::vector<float *> target(d);
-      target[d - 1] = x;
-      for (int k = d - 2, flip = 0; k >= 0; --k, flip ^= 1)
-        target[k] = flip ? h->f32_b.data() : h->f32_a.data();
-      float const *cur = x, *prev = nullptr;
-      for (int k = 0; k < d; ++k)
+      for (int k = k0; k < d; ++k)
       {
-        op.smoother_step(b, cur, prev, (float)coef[k].first, (float)coef[k].second, target[k]);
+        // any scratch vector that is not x_k; x_{k-1} may be overwritten in place unless it is the caller's x_in
+        float *target = x_out;
+        if (k + 1 < d)
+        {
+          target = h->f32_a.data();
+          if (target == cur)
+            target = h->f32_b.data();
+        }
+        op.smoother_step(b, cur, prev, (float)coef[k].first, (float)coef[k].second, target);
         prev = cur;
-        cur = target[k];
+        cur = target;
       }
+    };
+    // the iterate alternates between x and a work vector, so that no application ends in a copy
+    float *it = x, *other = h->f32_c.data();
+    auto smooth = [&]() {
+      smooth_to(it, other);
+      std::swap(it, other);
     };
     if (h->hierarchy->is_preconditioner())
       MFMG_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(float) * n, hd.stream));
@@ -1152,17 +1180,19 @@ int mfmg_hip_hierarchy_apply_f32(mfmg_hip_hierarchy_t h, const float *b, float *
     auto hip_restrictor = std::dynamic_pointer_cast<HipMatrixOperator const>(restrictor);
     // b_c = R (A x - b): one pass over the FP32 vectors where the restrictor holds the rows of R A, otherwise the FP32
     // residual, widened, and the restriction
-    if (!(hip_restrictor && hip_restrictor->restrict_residual_f32(*levels[0].get_operator(), x, b, *h->f32_bc)))
+    if (!(hip_restrictor && hip_restrictor->restrict_residual_f32(*levels[0].get_operator(), it, b, *h->f32_bc)))
     {
-      op.residual(x, b, h->f32_res.data());
+      op.residual(it, b, h->f32_res.data());
       vec::widen(hd, n, h->f32_res.data(), h->f32_res64->get_values());
       restrictor->apply(*h->f32_res64, *h->f32_bc);
     }
     h->hierarchy->apply(*h->f32_bc, *h->f32_xc, 1);
     restrictor->apply(*h->f32_xc, *h->f32_corr64, OperatorMode::TRANS);
-    vec::subtract_narrowed(hd, n, h->f32_corr64->get_values(), x);
+    vec::subtract_narrowed(hd, n, h->f32_corr64->get_values(), it);
     for (unsigned int i = 0; i < h->hierarchy->n_smoothing_steps(); ++i)
       smooth();
+    if (it != x)
+      MFMG_HIP_CHECK(hipMemcpyAsync(x, it, sizeof(float) * n, hipMemcpyDeviceToDevice, hd.stream));
     (void)nc;
   });
 }

@@ -3,11 +3,12 @@ import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"].replace("void ", "").replace("mfmg::(anonymous namespace)::", "").replace("mfmg::vec::(anonymous namespace)::", "vec::"))
-mf = [i for i, r in enumerate(rows) if "mf_laplace" in r["Kernel_Name"] and "kernel" in r["Kernel_Name"] and "cc5" in r["Kernel_Name"] or "mf_laplace_kernel" in r["Kernel_Name"]]
 ncyc = 10
-# operator launches per cycle: 7 (3 + residual + 3), 6 where the residual is folded into the restriction
-per_cycle = 6 if any("residual_restriction_kernel" in r["Kernel_Name"] for r in rows[mf[-7]:]) else 7
-first = mf[-per_cycle * ncyc]
+# one restriction launch per cycle and nothing after the last cycle: the period is the distance between the last two
+marks = [i for i, r in enumerate(rows) if "residual_restriction_kernel" in r["Kernel_Name"] or "sr_restrict" in r["Kernel_Name"]]
+period = marks[-1] - marks[-2]
+assert all(marks[-k] - marks[-k - 1] == period for k in range(1, ncyc)), "the last cycles do not repeat"
+first = len(rows) - period * ncyc
 tail = rows[first:]
 span = int(tail[-1]["End_Timestamp"]) - int(tail[0]["Start_Timestamp"])
 busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tail)
