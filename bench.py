@@ -182,7 +182,12 @@ def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, mater
         h.apply(b, x)
     h.operator_apply(0, x, r)
     contraction8 = (ctx.l2_norm(r) / r8_0) ** 0.125 if r8_0 > 0 else 0.0
+    # device memory of the cycle's state: the caching allocator of torch hands back what the setup and this function no longer
+    # hold (otherwise its cache -- problem arrays of the legs before, temporaries -- is counted as in use)
+    del r
+    torch.cuda.empty_cache()
     free_b, total_b = torch.cuda.mem_get_info()
+    torch_gb = torch.cuda.memory_allocated() / 1e9
     kind = "matrix-free" if evaluator == "HipMatrixFreeMeshEvaluator" else "assembled CSR fine operator"
     return {"workload": f"{cells}^3 cells = {cells + 1}^3 DoFs, {kind}, material {material}, Chebyshev(3), same "
                         f"hierarchy parameters",
@@ -191,6 +196,9 @@ def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, mater
             "residual_contraction_per_cycle_first_8": contraction8,
             "ms_per_residual_decade": ms_per_decade(dt * 1e3, contraction8),
             "device_memory_in_use_GB": (total_b - free_b) / 1e9,
+            "device_memory_torch_tensors_GB": torch_gb,
+            "device_memory_note": "in use = hipMemGetInfo after torch.cuda.empty_cache(): the library's buffers (inventory below), the "
+                                  "tensors of the caller (mesh arrays of the LaplaceProblem, x, b), HIP / RCCL runtime",
             "device_memory_inventory_GB": {line[14:].strip(): float(line[:10]) for line in M.memory_inventory().splitlines() if line.strip()}}
 
 

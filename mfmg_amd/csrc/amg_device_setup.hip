@@ -264,25 +264,39 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     for (int d = 0; d < 3; ++d)
       period_a[d] = (int)std::max<int64_t>(1, std::min<int64_t>(2 * c.reach + 1, c.s.gn(d)));
     const int n_col_a = period_a[0] * period_a[1] * period_a[2] * C;
-    DeviceBuffer<double> Y((size_t)n_col_a * (size_t)n_c);
-    for (int col = 0; col < n_col_a; ++col)
+    // Near the bottom of the hierarchy the periods reach the whole level -- every coarse column its own probe (8192 at 513^3
+    // DoFs: 3.8 s) --: there P^T (A P) is formed by the CSR product on the device instead (csr_algebra.hip; rows of <= 8192
+    // columns in a table addressed by the column).  One rank only; a hierarchy rounded to float keeps the probes, whose
+    // assembly rounds.
+    std::shared_ptr<SparseMatrixDevice<double>> ac_mat;
+    const bool by_product = !distributed && !h.setup_values_float && n_col_a >= 1024 && n_c <= 8192 && n_col_a * 2 >= n_c;
+    if (by_product)
     {
-      const int comp = col % C, oc = col / C;
-      const int phase[3] = {oc % period_a[0], (oc / period_a[0]) % period_a[1], oc / (period_a[0] * period_a[1])};
-      double *y_c = Y.data() + (size_t)col * n_c;
-      vec::select_rows(h, cdims, C, 1, c_off, period_a, phase, comp, nullptr, u_c.get_values());
-      p_mat->vmult(y_f.get_values(), u_c.get_values());
-      h.exchange(g.space, y_f.get_values());
-      a_op->get_matrix()->vmult(z_f.get_values(), y_f.get_values());
-      pt_mat->vmult(y_c, z_f.get_values());
-      h.exchange_reverse_add(c.space, y_c);
+      auto ap = a_op->get_matrix()->mmult(*p_mat);
+      ac_mat = pt_mat->mmult(*ap);
     }
-    MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
-    auto ac_mat = coarse_operator_from_probes(h, c.s, c.reach, period_a, Y.data());
-    Y.release();
+    else
+    {
+      DeviceBuffer<double> Y((size_t)n_col_a * (size_t)n_c);
+      for (int col = 0; col < n_col_a; ++col)
+      {
+        const int comp = col % C, oc = col / C;
+        const int phase[3] = {oc % period_a[0], (oc / period_a[0]) % period_a[1], oc / (period_a[0] * period_a[1])};
+        double *y_c = Y.data() + (size_t)col * n_c;
+        vec::select_rows(h, cdims, C, 1, c_off, period_a, phase, comp, nullptr, u_c.get_values());
+        p_mat->vmult(y_f.get_values(), u_c.get_values());
+        h.exchange(g.space, y_f.get_values());
+        a_op->get_matrix()->vmult(z_f.get_values(), y_f.get_values());
+        pt_mat->vmult(y_c, z_f.get_values());
+        h.exchange_reverse_add(c.space, y_c);
+      }
+      MFMG_HIP_CHECK(hipStreamSynchronize(h.stream));
+      ac_mat = coarse_operator_from_probes(h, c.s, c.reach, period_a, Y.data());
+      Y.release();
+    }
     if (verbose)
-      std::fprintf(stderr, "[mfmg_hip] amg level %d on the device (%lld local rows, reach %d): P %d probes %.2f s, A_c %d probes %.2f s\n",
-                   level, (long long)n_f, g.reach, n_col_p, t1 - t0, n_col_a, wall_now() - t1);
+      std::fprintf(stderr, "[mfmg_hip] amg level %d on the device (%lld local rows, reach %d): P %d probes %.2f s, A_c %d %s %.2f s\n",
+                   level, (long long)n_f, g.reach, n_col_p, t1 - t0, n_col_a, by_product ? "columns by the CSR product" : "probes", wall_now() - t1);
 
     // ---- the level's operators
     AmgLevel L;

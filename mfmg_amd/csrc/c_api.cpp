@@ -98,6 +98,7 @@ struct mfmg_hip_hierarchy_s
   // "fine level precision" float: the matrix-free operator and its smoother in FP32 around the FP64 coarse levels
   std::shared_ptr<MatrixFreeLaplaceDevice<float>> fine_f32;
   DeviceBuffer<float> f32_a, f32_b, f32_c, f32_res;
+  bool setup_values_float = false; // "setup value precision" of THIS hierarchy: on the handle only while one of its setups runs
   std::shared_ptr<DVector> f32_res64, f32_bc, f32_xc, f32_corr64;
 };
 
@@ -1049,7 +1050,22 @@ int mfmg_hip_hierarchy_create(mfmg_hip_context_t ctx, const char *evaluator_type
     else
       ASSERT_THROW_NOT_IMPLEMENTED("mesh evaluator type \"" + type + "\" is not available in the HIP build");
     h->timer = std::make_shared<TimerOutput>();
-    h->hierarchy.reset(new Hierarchy<DVector>(nullptr, h->evaluator, params, h->timer));
+    {
+      // "setup value precision" reaches the probing kernels through the handle (HipHierarchyHelpers::build_restrictor sets it):
+      // it must not outlive this setup, or the next hierarchy / user-built operator of the context inherits it
+      struct Restore
+      {
+        HipHandle &hd;
+        bool &keep;
+        ~Restore()
+        {
+          keep = hd.setup_values_float;
+          hd.setup_values_float = false;
+        }
+      } restore{*ctx->handle, h->setup_values_float};
+      ctx->handle->setup_values_float = false;
+      h->hierarchy.reset(new Hierarchy<DVector>(nullptr, h->evaluator, params, h->timer));
+    }
     const std::string precision = params->get("fine level precision", "double");
     if (precision == "float")
     {
@@ -1391,7 +1407,16 @@ int mfmg_hip_hierarchy_set_restrictor(mfmg_hip_hierarchy_t h, int64_t n_rows, in
     std::vector<double> vl(val_host, val_host + nnz);
     auto m = std::make_shared<SparseMatrixDevice<double>>(*h->handle, n_rows, n_cols, std::move(rp), std::move(cl),
                                                           std::move(vl));
-    h->hierarchy->set_restrictor(std::make_shared<HipMatrixOperator>(m));
+    {
+      // the Galerkin product and the coarse solver are set up again, in the value precision this hierarchy was built with
+      struct Restore
+      {
+        HipHandle &hd;
+        ~Restore() { hd.setup_values_float = false; }
+      } restore{*h->handle};
+      h->handle->setup_values_float = h->setup_values_float;
+      h->hierarchy->set_restrictor(std::make_shared<HipMatrixOperator>(m));
+    }
     // scratch vectors of apply_f32 were sized for the old coarse space
     h->f32_bc.reset();
     h->f32_xc.reset();

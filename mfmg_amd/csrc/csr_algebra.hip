@@ -319,10 +319,80 @@ bool csr_transpose_device(HipHandle &h, int64_t n_rows, int64_t n_cols, int64_t 
   return true;
 }
 
+// The same for a B of few columns (the bottom levels of an aggregation hierarchy, whose rows are long and close to dense:
+// 65 536 x 8192 with 2000 x 300 candidates per row): the table is addressed by the column itself -- no hashing, no sort --
+// and compacted in column order.  Sums in the order of the host product, as above.
+constexpr int kMaxDirect = 8192; // columns of B the direct table holds
+template <typename T, bool NUMERIC>
+__global__ __launch_bounds__(256) void product_row_direct_kernel(int64_t a_rows, int32_t const *a_ptr, int32_t const *a_col, T const *a_val,
+                                                                  int32_t const *b_ptr, int32_t const *b_col, T const *b_val, int b_cols,
+                                                                  int32_t *c_len, int32_t const *c_ptr, int32_t *c_col, T *c_val)
+{
+#pragma clang fp contract(off)
+  extern __shared__ unsigned char smem[];
+  unsigned char *hit = smem;                                   // [kMaxDirect]
+  T *vals = reinterpret_cast<T *>(smem + kMaxDirect);          // [kMaxDirect]
+  __shared__ int part[256];
+  const int per = (b_cols + 255) / 256; // slots of one thread in the compaction: a contiguous run
+  for (int64_t r = blockIdx.x; r < a_rows; r += gridDim.x)
+  {
+    for (int i = threadIdx.x; i < b_cols; i += blockDim.x)
+    {
+      hit[i] = 0;
+      if (NUMERIC)
+        vals[i] = T(0);
+    }
+    __syncthreads();
+    for (int p = a_ptr[r]; p < a_ptr[r + 1]; ++p)
+    {
+      const int k = a_col[p];
+      const T av = NUMERIC ? a_val[p] : T(0);
+      for (int q = b_ptr[k] + threadIdx.x; q < b_ptr[k + 1]; q += blockDim.x)
+      {
+        const int c = b_col[q];
+        hit[c] = 1;
+        if (NUMERIC)
+          vals[c] += av * b_val[q]; // (the columns of one row of B are distinct)
+      }
+      __syncthreads();
+    }
+    const int i0 = min((int)threadIdx.x * per, b_cols), i1 = min(i0 + per, b_cols);
+    int mine = 0;
+    for (int i = i0; i < i1; ++i)
+      mine += hit[i];
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    if (!NUMERIC)
+    {
+      if (threadIdx.x == 0)
+      {
+        int total = 0;
+        for (int t = 0; t < 256; ++t)
+          total += part[t];
+        c_len[r] = total;
+      }
+      __syncthreads();
+      continue;
+    }
+    int before = 0;
+    for (int t = 0; t < (int)threadIdx.x; ++t)
+      before += part[t];
+    int o = c_ptr[r] + before;
+    for (int i = i0; i < i1; ++i)
+      if (hit[i])
+      {
+        c_col[o] = i;
+        c_val[o] = vals[i];
+        ++o;
+      }
+    __syncthreads();
+  }
+}
+
 template <typename T>
 bool csr_multiply_device(HipHandle &h, int64_t a_rows, int32_t const *a_ptr, int32_t const *a_col, T const *a_val, int32_t const *b_ptr,
                          int32_t const *b_col, T const *b_val, std::vector<int32_t> &c_ptr, std::vector<int32_t> &c_col,
-                         std::vector<T> &c_val)
+                         std::vector<T> &c_val, int64_t b_cols)
 {
   hipStream_t st = h.stream;
   c_ptr.assign(a_rows + 1, 0);
@@ -335,15 +405,29 @@ bool csr_multiply_device(HipHandle &h, int64_t a_rows, int32_t const *a_ptr, int
                      ub.data());
   MFMG_HIP_CHECK(hipGetLastError());
   std::vector<int32_t> hub = ub.download(st);
+  bool fits_hash = true;
   for (int32_t v : hub)
     if (2 * (int64_t)v > kMaxHash)
-      return false; // a row with more candidate columns than the LDS table holds at load factor 1/2: host path
-  const size_t lds = (size_t)kMaxHash * (sizeof(int) + sizeof(T));
+      fits_hash = false; // a row with more candidate columns than the LDS table holds at load factor 1/2
+  const bool direct = !fits_hash && b_cols > 0 && b_cols <= kMaxDirect;
+  if (!fits_hash && !direct)
+    return false; // host path
+  const size_t lds = direct ? (size_t)kMaxDirect * (1 + sizeof(T)) : (size_t)kMaxHash * (sizeof(int) + sizeof(T));
   const unsigned int product_grid = (unsigned int)std::min<int64_t>(a_rows, 1 << 20);
-  set_lds_limit(product_row_kernel<T, false>, lds);
-  set_lds_limit(product_row_kernel<T, true>, lds);
-  hipLaunchKernelGGL((product_row_kernel<T, false>), dim3(product_grid), dim3(256), lds, st, a_rows, a_ptr, a_col, a_val, b_ptr, b_col, b_val,
-                     ub.data(), len.data(), (int32_t const *)nullptr, (int32_t *)nullptr, (T *)nullptr);
+  if (direct)
+  {
+    set_lds_limit(product_row_direct_kernel<T, false>, lds);
+    set_lds_limit(product_row_direct_kernel<T, true>, lds);
+    hipLaunchKernelGGL((product_row_direct_kernel<T, false>), dim3(product_grid), dim3(256), lds, st, a_rows, a_ptr, a_col, a_val, b_ptr, b_col,
+                       b_val, (int)b_cols, len.data(), (int32_t const *)nullptr, (int32_t *)nullptr, (T *)nullptr);
+  }
+  else
+  {
+    set_lds_limit(product_row_kernel<T, false>, lds);
+    set_lds_limit(product_row_kernel<T, true>, lds);
+    hipLaunchKernelGGL((product_row_kernel<T, false>), dim3(product_grid), dim3(256), lds, st, a_rows, a_ptr, a_col, a_val, b_ptr, b_col, b_val,
+                       ub.data(), len.data(), (int32_t const *)nullptr, (int32_t *)nullptr, (T *)nullptr);
+  }
   MFMG_HIP_CHECK(hipGetLastError());
   std::vector<int32_t> hlen = len.download(st);
   int64_t total = 0;
@@ -360,8 +444,12 @@ bool csr_multiply_device(HipHandle &h, int64_t a_rows, int32_t const *a_ptr, int
   DeviceBuffer<int32_t> d_cptr, d_ccol((size_t)total);
   DeviceBuffer<T> d_cval((size_t)total);
   d_cptr.upload(c_ptr.data(), c_ptr.size(), st);
-  hipLaunchKernelGGL((product_row_kernel<T, true>), dim3(product_grid), dim3(256), lds, st, a_rows, a_ptr, a_col, a_val, b_ptr, b_col, b_val,
-                     ub.data(), (int32_t *)nullptr, d_cptr.data(), d_ccol.data(), d_cval.data());
+  if (direct)
+    hipLaunchKernelGGL((product_row_direct_kernel<T, true>), dim3(product_grid), dim3(256), lds, st, a_rows, a_ptr, a_col, a_val, b_ptr, b_col,
+                       b_val, (int)b_cols, (int32_t *)nullptr, d_cptr.data(), d_ccol.data(), d_cval.data());
+  else
+    hipLaunchKernelGGL((product_row_kernel<T, true>), dim3(product_grid), dim3(256), lds, st, a_rows, a_ptr, a_col, a_val, b_ptr, b_col, b_val,
+                       ub.data(), (int32_t *)nullptr, d_cptr.data(), d_ccol.data(), d_cval.data());
   MFMG_HIP_CHECK(hipGetLastError());
   MFMG_HIP_CHECK(hipMemcpyAsync(c_col.data(), d_ccol.data(), (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   MFMG_HIP_CHECK(hipMemcpyAsync(c_val.data(), d_cval.data(), (size_t)total * sizeof(T), hipMemcpyDeviceToHost, st));
@@ -379,8 +467,8 @@ template bool csr_transpose_device<float>(HipHandle &, int64_t, int64_t, int64_t
                                           std::vector<int32_t> &, std::vector<int32_t> &, std::vector<float> &);
 template bool csr_multiply_device<double>(HipHandle &, int64_t, int32_t const *, int32_t const *, double const *, int32_t const *,
                                           int32_t const *, double const *, std::vector<int32_t> &, std::vector<int32_t> &,
-                                          std::vector<double> &);
+                                          std::vector<double> &, int64_t);
 template bool csr_multiply_device<float>(HipHandle &, int64_t, int32_t const *, int32_t const *, float const *, int32_t const *,
                                          int32_t const *, float const *, std::vector<int32_t> &, std::vector<int32_t> &,
-                                         std::vector<float> &);
+                                         std::vector<float> &, int64_t);
 } // namespace mfmg

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <string>
 
 namespace mfmg
 {
@@ -38,6 +39,9 @@ struct RrArgs
   int main_last; // last agglomerate index i of a row the row-wise part takes
   int N[3], na[3];
   int segs;
+  // tile form: workgroups of kTileRows agglomerate rows marching through `ka` agglomerate layers
+  int tiles_j, ka;
+  int64_t n_tiles;
 };
 
 // two consecutive entries of x or b (FP64: 16 bytes at an 8-byte boundary; FP32, the fine level of apply_f32: 8 at a 4-byte one)
@@ -57,6 +61,42 @@ __device__ __forceinline__ double rr_prev(double v)
 __device__ __forceinline__ double rr_next(double v)
 {
   return __hiloint2double(rr_dpp_next(__double2hiint(v)), rr_dpp_next(__double2loint(v)));
+}
+
+// ---- the listed agglomerates (first in the grid: they overlap with the rest): sixteen lanes each, the 125 + 27 nodes
+// dealt round the lanes, every bound checked; the requests of a lane are in flight together, then a 16-lane reduction ----
+template <typename TI>
+__device__ __forceinline__ void rr_listed_part(RrArgs const &s, TI const *__restrict__ x, TI const *__restrict__ b, double *__restrict__ y)
+{
+  const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  const bool live = q < s.n_listed;
+  const int64_t ag = s.listed[live ? q : 0];
+  const int ai = (int)(ag % s.na[0]), aj = (int)((ag / s.na[0]) % s.na[1]), ak = (int)(ag / ((int64_t)s.na[0] * s.na[1]));
+  double2 const *t = s.table + (size_t)s.cls[ag] * kTab;
+  double s0 = 0., s1 = 0.;
+#pragma unroll
+  for (int it = 0; it < (kTab + 15) / 16; ++it)
+  {
+    const int m = min(it * 16 + sub, kTab - 1);
+    const bool foot = m < kFoot;
+    const int mm = foot ? m : m - kFoot, n = foot ? 5 : 3, o = foot ? 1 : 0;
+    const int gx = 2 * ai - o + mm % n, gy = 2 * aj - o + (mm / n) % n, gz = 2 * ak - o + mm / (n * n);
+    const bool in = it * 16 + sub < kTab && gx >= 0 && gx < s.N[0] && gy >= 0 && gy < s.N[1] && gz >= 0 && gz < s.N[2];
+    const int64_t node = ((int64_t)min(max(gz, 0), s.N[2] - 1) * s.N[1] + min(max(gy, 0), s.N[1] - 1)) * s.N[0] + min(max(gx, 0), s.N[0] - 1);
+    const double v = foot ? (double)x[node] : -(double)b[node];
+    const double2 w = t[m];
+    s0 += in ? w.x * v : 0.;
+    s1 += in ? w.y * v : 0.;
+  }
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1)
+  {
+    s0 += __shfl_xor(s0, d);
+    s1 += __shfl_xor(s1, d);
+  }
+  if (live && sub == 0)
+    reinterpret_cast<double2 *>(y)[ag] = make_double2(s0, s1);
 }
 
 template <int WAVES, typename TI>
@@ -169,37 +209,200 @@ residual_restriction_kernel(RrArgs s, TI const *__restrict__ x, TI const *__rest
     }
     return;
   }
-  // ---- the listed agglomerates (first in the grid: they overlap with the rest): sixteen lanes each, the 125 + 27 nodes
-  // dealt round the lanes, every bound checked; the requests of a lane are in flight together, then a 16-lane reduction ----
-  const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  const int sub = threadIdx.x & 15;
-  const bool live = q < s.n_listed;
-  const int64_t ag = s.listed[live ? q : 0];
-  const int ai = (int)(ag % s.na[0]), aj = (int)((ag / s.na[0]) % s.na[1]), ak = (int)(ag / ((int64_t)s.na[0] * s.na[1]));
-  double2 const *t = s.table + (size_t)s.cls[ag] * kTab;
-  double s0 = 0., s1 = 0.;
-#pragma unroll
-  for (int it = 0; it < (kTab + 15) / 16; ++it)
+  rr_listed_part<TI>(s, x, b, y);
+}
+
+// ---- tile form of the row-wise part -------------------------------------------------------------------------------------
+// The row-wise kernel above asks for 25 + 9 node rows per agglomerate row: every node row is requested (5/2)^2 times, by the
+// wavefronts of neighbouring agglomerate rows and layers.  Here a workgroup of eight wavefronts owns eight consecutive
+// agglomerate rows j and marches through `ka` agglomerate layers k: the 19 node rows of x (17 of b) that the eight share in
+// a node layer are requested once, one 16-byte request per lane and row, and staged in LDS; an agglomerate's five node layers
+// arrive in order, so three agglomerate layers are in flight per wavefront (the one that starts, the middle one, the one
+// that ends with this node layer) and a node layer is requested once per workgroup instead of 2.5 times.  The sums of an
+// agglomerate are formed in the order of the row-wise kernel (node layers, then node rows, five weights per row; b likewise):
+// the same bits.  Two LDS buffers: the rows of node layer g + 1 are written while g is used, one barrier per layer.
+constexpr int kTileRows = 8;                                 // wavefronts = agglomerate rows of a workgroup
+constexpr int kTileX = 2 * kTileRows + 3, kTileB = 2 * kTileRows + 1; // node rows of x and of b per node layer
+constexpr int kTileLds = kTileX + kTileB;                    // rows of 64 x 16 bytes per buffer
+
+template <typename TI>
+__global__ __launch_bounds__(64 * kTileRows) __attribute__((amdgpu_waves_per_eu(4, 4))) void
+residual_restriction_tile_kernel(RrArgs s, TI const *__restrict__ x, TI const *__restrict__ b, double *__restrict__ y)
+{
+  if (blockIdx.x < s.listed_blocks)
   {
-    const int m = min(it * 16 + sub, kTab - 1);
-    const bool foot = m < kFoot;
-    const int mm = foot ? m : m - kFoot, n = foot ? 5 : 3, o = foot ? 1 : 0;
-    const int gx = 2 * ai - o + mm % n, gy = 2 * aj - o + (mm / n) % n, gz = 2 * ak - o + mm / (n * n);
-    const bool in = it * 16 + sub < kTab && gx >= 0 && gx < s.N[0] && gy >= 0 && gy < s.N[1] && gz >= 0 && gz < s.N[2];
-    const int64_t node = ((int64_t)min(max(gz, 0), s.N[2] - 1) * s.N[1] + min(max(gy, 0), s.N[1] - 1)) * s.N[0] + min(max(gx, 0), s.N[0] - 1);
-    const double v = foot ? (double)x[node] : -(double)b[node];
-    const double2 w = t[m];
-    s0 += in ? w.x * v : 0.;
-    s1 += in ? w.y * v : 0.;
+    rr_listed_part<TI>(s, x, b, y);
+    return;
   }
+  extern __shared__ double2 rr_rows[]; // [2][kTileLds][64]
+  // a contiguous run of tiles per XCD (main_blocks is a multiple of 8): neighbouring tiles share node rows and layers
+  const unsigned int mb = blockIdx.x - s.listed_blocks;
+  const int64_t bid = (int64_t)(mb & 7) * (s.main_blocks >> 3) + (mb >> 3);
+  if (bid >= s.n_tiles)
+    return; // (the whole workgroup: no barrier is left waiting)
+  const int seg = (int)(bid % s.segs);
+  const int tj = (int)((bid / s.segs) % s.tiles_j);
+  const int tk = (int)(bid / ((int64_t)s.segs * s.tiles_j));
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int aj0 = tj * kTileRows, aj = aj0 + w;
+  const bool row_live = aj < s.na[1];
+  const int ak0 = tk * s.ka, ak1 = min(ak0 + s.ka, s.na[2]);
+  const int i0 = 1 + seg * kRun, last = min(s.main_last, i0 + kRun - 1);
+  const int ai = i0 + lane - 1;
+  const int aic = min(ai, s.na[0] - 1);
+  const int N0 = s.N[0], N1 = s.N[1], N2 = s.N[2];
+  using const_weights = __attribute__((address_space(4))) const double;
+  using pair_in = pair_of<TI>;
+  using pair8 = pair_of<double>;
+  // class of this wavefront's agglomerate row in layer ak: -1 where there is nothing to compute (outside the tile, run in the list)
+  auto class_of = [&](int ak) -> int {
+    if (!row_live || ak < ak0 || ak >= ak1)
+      return -1;
+    const unsigned int cw = s.seg_class[((int64_t)ak * s.segs + seg) * s.na[1] + aj];
+    return cw == 0xffffu ? -1 : __builtin_amdgcn_readfirstlane((int)cw);
+  };
+  auto weights = [&](int c) { return reinterpret_cast<const_weights *>(reinterpret_cast<uintptr_t>(s.table + (size_t)max(c, 0) * kTab)); };
+  // rows this wavefront fetches for the workgroup: r = w + 8 q < 36; r < 19 is row 2 aj0 - 1 + r of x, else row 2 aj0 + r - 19 of b
+  // (rows outside the box carry zero weights: clamped, as in the row-wise kernel)
+  constexpr int kFetch = (kTileLds + kTileRows - 1) / kTileRows;
+  int row_off[kFetch];
 #pragma unroll
-  for (int d = 8; d >= 1; d >>= 1)
+  for (int q = 0; q < kFetch; ++q)
   {
-    s0 += __shfl_xor(s0, d);
-    s1 += __shfl_xor(s1, d);
+    const int r = min(w + kTileRows * q, kTileLds - 1); // (the last round has rows for the first wavefronts only: the others repeat row 35)
+    const int yy = r < kTileX ? 2 * aj0 - 1 + r : 2 * aj0 + r - kTileX;
+    row_off[q] = min(max(yy, 0), N1 - 1) * N0 + 2 * aic;
   }
-  if (live && sub == 0)
-    reinterpret_cast<double2 *>(y)[ag] = make_double2(s0, s1);
+  const int g0 = 2 * ak0 - 1, n_layers = 2 * (ak1 - ak0) + 3;
+  pair8 pre[kFetch];
+  // the requests of a node layer leave together, without a branch between them: a row of b in a layer whose b nobody needs
+  // (the first and the last two of a tile) is asked of x instead, where the same row is in the tile anyway
+  auto fetch = [&](int li) {
+    const int g = g0 + li;
+    const int zoff = min(max(g, 0), N2 - 1) * N1 * N0;
+    const bool with_b = g >= 2 * ak0 && g <= 2 * ak1;
+    TI const *bsrc = with_b ? b : x;
+#pragma unroll
+    for (int q = 0; q < kFetch; ++q)
+    {
+      const int r = w + kTileRows * q; // (wave-uniform)
+      const pair_in p = *reinterpret_cast<pair_in const *>((r < kTileX ? x : bsrc) + (zoff + row_off[q]));
+      pre[q] = pair8{(double)p.x, (double)p.y};
+    }
+  };
+  auto stage = [&](int li) {
+    double2 *buf = rr_rows + (size_t)(li & 1) * kTileLds * 64;
+#pragma unroll
+    for (int q = 0; q < kFetch; ++q)
+    {
+      const int r = w + kTileRows * q;
+      if (kTileRows * q + kTileRows <= kTileLds || r < kTileLds)
+        buf[r * 64 + lane] = make_double2(pre[q].x, pre[q].y);
+    }
+  };
+  // three agglomerate layers in flight: P ends with the current odd node layer, C is in its middle, N starts
+  double Ps0 = 0., Ps1 = 0., Pr0 = 0., Pr1 = 0., Cs0 = 0., Cs1 = 0., Cr0 = 0., Cr1 = 0., Ns0 = 0., Ns1 = 0.;
+  int cP = -1, cC = -1, cN = -1;
+  // five weights of one node row of the footprint on the lane's five nodes
+  auto row_x = [&](double &s0, double &s1, const_weights *t, int mz, int my, double xm1, pair8 own, double xp2, double xp3) {
+    const int m = (mz * 5 + my) * 5;
+    s0 += t[2 * m] * xm1 + t[2 * m + 2] * own.x + t[2 * m + 4] * own.y + t[2 * m + 6] * xp2 + t[2 * m + 8] * xp3;
+    s1 += t[2 * m + 1] * xm1 + t[2 * m + 3] * own.x + t[2 * m + 5] * own.y + t[2 * m + 7] * xp2 + t[2 * m + 9] * xp3;
+    asm volatile("" : "+v"(s0), "+v"(s1));
+  };
+  auto row_b = [&](double &r0, double &r1, const_weights *t, int mz, int my, pair8 own, double bp2) {
+    const int m = kFoot + (mz * 3 + my) * 3;
+    r0 += t[2 * m] * own.x + t[2 * m + 2] * own.y + t[2 * m + 4] * bp2;
+    r1 += t[2 * m + 1] * own.x + t[2 * m + 3] * own.y + t[2 * m + 5] * bp2;
+    asm volatile("" : "+v"(r0), "+v"(r1));
+  };
+  fetch(0);
+  stage(0);
+  if (n_layers > 1)
+    fetch(1);
+  __syncthreads();
+  cN = class_of(ak0);
+  for (int li = 0; li < n_layers; ++li)
+  {
+    // the rows of the next node layer go to the other buffer (last read a layer ago, before the barrier), the requests of
+    // the one after leave before this layer's arithmetic
+    if (li + 1 < n_layers)
+      stage(li + 1);
+    if (li + 2 < n_layers)
+      fetch(li + 2);
+    double2 const *buf = rr_rows + (size_t)(li & 1) * kTileLds * 64;
+    const bool odd = (li & 1) == 0; // node layer g0 + li = 2 a + 1
+    const bool any = odd ? (cP >= 0 || cC >= 0 || cN >= 0) : (cP >= 0 || cC >= 0);
+    if (any)
+    {
+      const_weights *tP = weights(cP), *tC = weights(cC), *tN = weights(cN);
+      // the rows of this wavefront leave the LDS together, before the first of them is used
+      double2 xr[5], br[3];
+#pragma unroll
+      for (int my = 0; my < 5; ++my)
+        xr[my] = buf[(2 * w + my) * 64 + lane];
+#pragma unroll
+      for (int my = 0; my < 3; ++my)
+        br[my] = buf[(kTileX + 2 * w + my) * 64 + lane];
+#pragma unroll
+      for (int my = 0; my < 5; ++my)
+      {
+        const double2 v = xr[my];
+        const pair8 own{v.x, v.y};
+        const double xm1 = rr_prev(own.y), xp2 = rr_next(own.x), xp3 = rr_next(own.y);
+        if (odd)
+        {
+          if (cN >= 0)
+            row_x(Ns0, Ns1, tN, 0, my, xm1, own, xp2, xp3);
+          if (cC >= 0)
+            row_x(Cs0, Cs1, tC, 2, my, xm1, own, xp2, xp3);
+          if (cP >= 0)
+            row_x(Ps0, Ps1, tP, 4, my, xm1, own, xp2, xp3);
+        }
+        else
+        {
+          if (cC >= 0)
+            row_x(Cs0, Cs1, tC, 1, my, xm1, own, xp2, xp3);
+          if (cP >= 0)
+            row_x(Ps0, Ps1, tP, 3, my, xm1, own, xp2, xp3);
+        }
+      }
+      if (odd ? cC >= 0 : (cC >= 0 || cP >= 0))
+      {
+#pragma unroll
+        for (int my = 0; my < 3; ++my)
+        {
+          const double2 v = br[my];
+          const pair8 own{v.x, v.y};
+          const double bp2 = rr_next(own.x);
+          if (odd)
+            row_b(Cr0, Cr1, tC, 1, my, own, bp2);
+          else
+          {
+            if (cC >= 0)
+              row_b(Cr0, Cr1, tC, 0, my, own, bp2);
+            if (cP >= 0)
+              row_b(Pr0, Pr1, tP, 2, my, own, bp2);
+          }
+        }
+      }
+    }
+    if (odd)
+    {
+      // the oldest agglomerate layer is complete: (li - 3) / 2 layers above ak0
+      const int akP = ak0 + (li >> 1) - 2;
+      if (cP >= 0 && lane >= 1 && lane <= kRun && ai <= last)
+      {
+        const int64_t ag = ai + (int64_t)s.na[0] * (aj + (int64_t)s.na[1] * akP);
+        reinterpret_cast<double2 *>(y)[ag] = make_double2(Ps0 - Pr0, Ps1 - Pr1);
+      }
+      Ps0 = Cs0, Ps1 = Cs1, Pr0 = Cr0, Pr1 = Cr1, cP = cC;
+      Cs0 = Ns0, Cs1 = Ns1, Cr0 = 0., Cr1 = 0., cC = cN;
+      Ns0 = 0., Ns1 = 0., cN = class_of(ak0 + (li >> 1) + 1);
+    }
+    __syncthreads();
+  }
 }
 
 // table of one (class, eigenvector): the 125 values of w = A R^T e around the representative, the 27 of v = R^T e
@@ -389,8 +592,64 @@ void StructuredRestrictorDevice::restrict_residual_any(TI const *x, TI const *b,
   }
   s.segs = _rr_segs;
   s.main_last = _rr_main_last;
-  s.listed_blocks = (unsigned int)((s.n_listed + 15) / 16);
+  // MFMG_RR_KERNEL=rows: the row-wise kernel of rounds 2-3 (a wavefront per agglomerate row, no LDS) for comparisons
+  static const bool tile_form = [] {
+    char const *e = std::getenv("MFMG_RR_KERNEL");
+    return !(e && std::string(e) == "rows");
+  }();
   hipEvent_t stop = _handle.profiler.begin("residual_restriction", 2. * sizeof(TI) * double(_n_fine) + 8. * double(_n_coarse), _handle.stream);
+  if (tile_form)
+  {
+    // height of a tile: whole rounds of two workgroups per CU; a workgroup of ka agglomerate layers passes 2 ka + 3 node layers
+    static const int n_cus = [] {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        v = 256;
+      return v > 0 ? v : 256;
+    }();
+    static const int ka_env = std::getenv("MFMG_RR_TILE_LAYERS") ? std::atoi(std::getenv("MFMG_RR_TILE_LAYERS")) : 0;
+    s.tiles_j = (_na[1] + kTileRows - 1) / kTileRows;
+    int ka = ka_env > 0 ? std::min(ka_env, _na[2]) : 0;
+    if (ka == 0)
+    {
+      double best = 0.;
+      for (int nk = 1; nk <= _na[2]; ++nk)
+      {
+        const int t = (_na[2] + nk - 1) / nk;
+        if ((_na[2] + t - 1) / t != nk)
+          continue;
+        const int64_t tiles = (int64_t)_rr_segs * s.tiles_j * nk, slots = 2 * (int64_t)n_cus;
+        const double cost = double((tiles + slots - 1) / slots) * (2. * t + 3.);
+        if (ka == 0 || cost < best)
+        {
+          best = cost;
+          ka = t;
+        }
+      }
+    }
+    s.ka = std::max(ka, 1);
+    s.n_tiles = (int64_t)_rr_segs * s.tiles_j * ((_na[2] + s.ka - 1) / s.ka);
+    s.main_blocks = s.n_main_waves == 0 ? 0u : (unsigned int)((s.n_tiles + 7) / 8 * 8);
+    s.listed_blocks = (unsigned int)((s.n_listed + 16 * kTileRows / 4 - 1) / (16 * kTileRows / 4)); // sixteen lanes per agglomerate
+    static const int dbg = std::getenv("MFMG_RR_DEBUG") ? std::atoi(std::getenv("MFMG_RR_DEBUG")) : 0; // (timing experiments: 1 no list, 2 no tiles)
+    static int calls = 0; // (the check of the setup against the two steps sees the whole kernel)
+    if (dbg == 1 && ++calls > 3)
+      s.listed_blocks = 0, s.n_listed = 0;
+    if (dbg == 2 && ++calls > 3)
+      s.main_blocks = 0, s.n_tiles = 0;
+    constexpr size_t lds = 2 * (size_t)kTileLds * 64 * sizeof(double2);
+    static const bool attr = [] {
+      MFMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<void const *>(&residual_restriction_tile_kernel<TI>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      return true;
+    }();
+    (void)attr;
+    hipLaunchKernelGGL((residual_restriction_tile_kernel<TI>), dim3(s.main_blocks + s.listed_blocks), dim3(64 * kTileRows), lds, _handle.stream, s, x, b, y);
+    KernelProfiler::end(stop, _handle.stream);
+    MFMG_HIP_CHECK(hipGetLastError());
+    return;
+  }
+  s.listed_blocks = (unsigned int)((s.n_listed + 15) / 16);
   static const int waves = [] {
     char const *e = std::getenv("MFMG_RR_WAVES");
     return e ? std::atoi(e) : 4; // (3, 4 and 6 wavefronts per SIMD within 5 % of each other; 1, 2 and 8 slower)

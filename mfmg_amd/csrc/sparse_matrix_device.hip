@@ -1130,7 +1130,10 @@ SparseMatrixDevice<T>::SparseMatrixDevice(HipHandle &handle, int64_t n_rows, int
       cols_ok = cols_ok && col[p] >= 0 && col[p] < n_cols;
     ASSERT_THROW(cols_ok, "column index out of range");
   }
-  // (the CSR arrays go to the device first: the layout analysis runs on them)
+  // (the CSR arrays go to the device first: the layout analysis runs on them.  Without an analysis and with the host arrays
+  // kept -- the restrictor beside its agglomerate-wise form, 11 GB at 513^3 DoFs -- they go there when first asked for.)
+  _device_csr_deferred = keep_host && !analyse && _nnz > 0;
+  if (!_device_csr_deferred)
   {
     MemoryKind kind("CSR arrays (val, col, row_ptr)");
     _val.upload(val.data(), val.size(), handle.stream);
@@ -1221,6 +1224,18 @@ void SparseMatrixDevice<T>::ensure_host_copy() const
   if (!_row_ptr_host.empty() || _n_rows == 0)
     return;
   download(_row_ptr_host, _col_host, _val_host);
+}
+
+template <typename T>
+void SparseMatrixDevice<T>::ensure_device_csr() const
+{
+  if (!_device_csr_deferred)
+    return;
+  MemoryKind kind("CSR arrays (val, col, row_ptr)");
+  _val.upload(_val_host.data(), _val_host.size(), _handle.stream);
+  _col.upload(_col_host.data(), _col_host.size(), _handle.stream);
+  _row_ptr.upload(_row_ptr_host.data(), _row_ptr_host.size(), _handle.stream);
+  _device_csr_deferred = false;
 }
 
 // column indices of the rows `rows` (ascending), packed: row q occupies [ptr[q], ptr[q+1]) of cols
@@ -1355,6 +1370,7 @@ void SparseMatrixDevice<T>::choose_layouts(bool analyse)
 template <typename T>
 void SparseMatrixDevice<T>::build_block_diagonals()
 {
+  ensure_device_csr();
   const int64_t n = _n_rows;
   int best_c = 0;
   std::vector<int32_t> best_offs;
@@ -1737,6 +1753,7 @@ void SparseMatrixDevice<T>::build_block_diagonals()
 template <typename T>
 void SparseMatrixDevice<T>::build_node_classes()
 {
+  ensure_device_csr();
   const int64_t n = _n_rows, m = _n_cols;
   int best_c = 0;
   std::vector<int32_t> best_offs;
@@ -2037,6 +2054,7 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
   ASSERT_THROW(x != out, "SpMV cannot run in place (out aliases x)");
   if (_n_rows == 0)
     return;
+  ensure_device_csr();
   CsrArgs<T> a;
   a.val = _val.data();
   a.col = _col.data();
@@ -2298,6 +2316,7 @@ void SparseMatrixDevice<T>::inverse_diagonal(T *dinv) const
                                        " by " + std::to_string(_n_cols) + " .");
   if (_n_rows == 0)
     return;
+  ensure_device_csr();
   hipLaunchKernelGGL(csr_inv_diag_kernel<T>, dim3(n_blocks_for(_n_rows)), dim3(block_size), 0,
                      _handle.stream, _val.data(), _col.data(), _row_ptr.data(), _n_rows, dinv);
   MFMG_HIP_CHECK(hipGetLastError());
@@ -2307,6 +2326,7 @@ template <typename T>
 void SparseMatrixDevice<T>::row_ratios(T *dinv, T *ratio) const
 {
   ASSERT_THROW(_n_rows == _n_cols, "row_ratios needs a square matrix");
+  ensure_device_csr();
   hipLaunchKernelGGL(csr_row_ratio_kernel<T>, dim3(n_blocks_for(_n_rows)), dim3(block_size), 0, _handle.stream, _val.data(), _col.data(),
                      _row_ptr.data(), _n_rows, dinv, ratio);
   MFMG_HIP_CHECK(hipGetLastError());
@@ -2316,6 +2336,13 @@ template <typename T>
 void SparseMatrixDevice<T>::download(std::vector<int32_t> &row_ptr, std::vector<int32_t> &col,
                                      std::vector<T> &val) const
 {
+  if (_device_csr_deferred)
+  {
+    row_ptr = _row_ptr_host;
+    col = _col_host;
+    val = _val_host;
+    return;
+  }
   row_ptr = _row_ptr.download(_handle.stream);
   col = _col.download(_handle.stream);
   val = _val.download(_handle.stream);
@@ -2428,6 +2455,7 @@ std::shared_ptr<SparseMatrixDevice<T>> SparseMatrixDevice<T>::transpose() const
 {
   std::vector<int32_t> rp, cl, trp, tcl;
   std::vector<T> vl, tvl;
+  ensure_device_csr();
   const int64_t nnz = (int64_t)_val.size();
   if (csr_algebra_on_device() && nnz > 0)
   {
@@ -2455,11 +2483,13 @@ std::shared_ptr<SparseMatrixDevice<T>> SparseMatrixDevice<T>::mmult(SparseMatrix
 {
   ASSERT_THROW(_n_cols == b.m(), "The matrices cannot be multiplied together because their sizes are "
                                  "incompatible.");
+  ensure_device_csr();
+  b.ensure_device_csr();
   std::vector<int32_t> arp, acl, brp, bcl, crp, ccl;
   std::vector<T> avl, bvl, cvl;
   if (csr_algebra_on_device() && _val.size() > 0 && b._val.size() > 0 &&
       csr_multiply_device<T>(_handle, _n_rows, _row_ptr.data(), _col.data(), _val.data(), b._row_ptr.data(), b._col.data(),
-                             b._val.data(), crp, ccl, cvl))
+                             b._val.data(), crp, ccl, cvl, b.n()))
     return std::make_shared<SparseMatrixDevice<T>>(_handle, _n_rows, b.n(), std::move(crp), std::move(ccl), std::move(cvl));
   if (csr_algebra_on_device() && _val.size() > 0 && b._val.size() > 0)
     csr_algebra_fell_back("mmult");

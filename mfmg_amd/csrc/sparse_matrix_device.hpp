@@ -101,9 +101,24 @@ public:
   bool has_host_copy() const { return !_row_ptr_host.empty(); }
   void download(std::vector<int32_t> &row_ptr, std::vector<int32_t> &col, std::vector<T> &val) const;
 
-  T const *val_dev() const { return _val.data(); }
-  int32_t const *column_index_dev() const { return _col.data(); }
-  int32_t const *row_ptr_dev() const { return _row_ptr.data(); }
+  T const *val_dev() const
+  {
+    ensure_device_csr();
+    return _val.data();
+  }
+  int32_t const *column_index_dev() const
+  {
+    ensure_device_csr();
+    return _col.data();
+  }
+  int32_t const *row_ptr_dev() const
+  {
+    ensure_device_csr();
+    return _row_ptr.data();
+  }
+  // the CSR arrays on the device (a no-op unless the upload was deferred)
+  void ensure_device_csr() const;
+  bool device_csr_deferred() const { return _device_csr_deferred; }
   HipHandle &handle() const { return _handle; }
 
   bool uses_lds_path() const { return _use_lds; }
@@ -196,9 +211,12 @@ private:
   DeviceBuffer<T> _bdia_val;
   DeviceBuffer<float> _bdia_val_f32; // ... or these, when every value is representable in float (see the .hip file)
   DeviceBuffer<int32_t> _bdia_offs;
-  DeviceBuffer<T> _val;
-  DeviceBuffer<int32_t> _col;
-  DeviceBuffer<int32_t> _row_ptr;
+  // (mutable: a matrix built without layouts from host arrays it keeps -- the restrictor beside its agglomerate-wise form --
+  // uploads its CSR arrays only when somebody asks for them: ensure_device_csr)
+  mutable DeviceBuffer<T> _val;
+  mutable DeviceBuffer<int32_t> _col;
+  mutable DeviceBuffer<int32_t> _row_ptr;
+  mutable bool _device_csr_deferred = false;
   mutable std::vector<int32_t> _row_ptr_host, _col_host;
   mutable std::vector<T> _val_host;
 };

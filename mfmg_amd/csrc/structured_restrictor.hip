@@ -10,6 +10,8 @@
 //            every sector.
 #include "structured_restrictor.hpp"
 
+#include <omp.h>
+
 #include <algorithm>
 #include <cstring>
 #include <numeric>
@@ -480,10 +482,79 @@ StructuredRestrictorDevice::create(HipHandle &handle, StructuredMesh const &mesh
             return false;
       return true;
     };
-    std::unordered_map<uint64_t, std::vector<int>> by_hash; // hash -> classes with that hash
     std::vector<int64_t> first;
     std::vector<uint16_t> all(n_agg);
     bool fits = true;
+    // Classes numbered in the order of their first agglomerate.  In parallel: the first agglomerate of every hash value (per
+    // thread over its contiguous share, merged), classes in the order of those, then every agglomerate compared with the
+    // representative of its hash; a hash shared by two different blocks sends the whole step to the serial loop below,
+    // which compares block by block -- the same classes either way.
+    bool parallel_done = false;
+    {
+      const int nt = std::max(1, omp_get_max_threads());
+      std::vector<std::unordered_map<uint64_t, int64_t>> local(nt);
+      bool too_many = false;
+#pragma omp parallel num_threads(nt)
+      {
+        const int t = omp_get_thread_num();
+        const int64_t lo = n_agg * t / nt, hi = n_agg * (t + 1) / nt;
+        auto &m = local[t];
+        for (int64_t ag = lo; ag < hi; ++ag)
+        {
+          m.emplace(hash[ag], ag); // (keeps the first)
+          if (m.size() > 4096)
+          {
+#pragma omp atomic write
+            too_many = true;
+            break;
+          }
+        }
+      }
+      if (too_many)
+        fits = false, parallel_done = true; // (more than 4096 different blocks: the serial loop would give up as well)
+      else
+      {
+        std::unordered_map<uint64_t, int64_t> firsts;
+        for (auto const &m : local)
+          for (auto const &kv : m)
+          {
+            auto it = firsts.find(kv.first);
+            if (it == firsts.end())
+              firsts.emplace(kv.first, kv.second);
+            else if (kv.second < it->second)
+              it->second = kv.second;
+          }
+        if (firsts.size() > 4096)
+          fits = false, parallel_done = true;
+        else
+        {
+          std::vector<std::pair<int64_t, uint64_t>> order;
+          for (auto const &kv : firsts)
+            order.emplace_back(kv.second, kv.first);
+          std::sort(order.begin(), order.end());
+          std::unordered_map<uint64_t, int> class_of_hash;
+          for (size_t c = 0; c < order.size(); ++c)
+          {
+            class_of_hash.emplace(order[c].second, (int)c);
+            first.push_back(order[c].first);
+          }
+          bool exact = true;
+#pragma omp parallel for schedule(static) reduction(&& : exact)
+          for (int64_t ag = 0; ag < n_agg; ++ag)
+          {
+            const int c = class_of_hash.find(hash[ag])->second;
+            all[ag] = (uint16_t)c;
+            exact = exact && same_block(first[c], ag);
+          }
+          parallel_done = exact;
+          if (!exact)
+            first.clear();
+        }
+      }
+    }
+    if (!parallel_done)
+    {
+    std::unordered_map<uint64_t, std::vector<int>> by_hash; // hash -> classes with that hash
     for (int64_t ag = 0; ag < n_agg && fits; ++ag)
     {
       auto &cands = by_hash[hash[ag]];
@@ -506,6 +577,7 @@ StructuredRestrictorDevice::create(HipHandle &handle, StructuredMesh const &mesh
         cands.push_back(found);
       }
       all[ag] = (uint16_t)found;
+    }
     }
     if (fits)
       s->_cls_host = std::move(all);

@@ -5,7 +5,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"].replace("void ", "").replace("mfmg::(anonymous namespace)::", "").replace("mfmg::vec::(anonymous namespace)::", "vec::"))
 ncyc = 10
 # one restriction launch per cycle and nothing after the last cycle: the period is the distance between the last two
-marks = [i for i, r in enumerate(rows) if "residual_restriction_kernel" in r["Kernel_Name"] or "sr_restrict" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "residual_restriction" in r["Kernel_Name"] or "sr_restrict" in r["Kernel_Name"]]
 period = marks[-1] - marks[-2]
 assert all(marks[-k] - marks[-k - 1] == period for k in range(1, ncyc)), "the last cycles do not repeat"
 first = len(rows) - period * ncyc

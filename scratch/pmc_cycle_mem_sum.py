@@ -8,7 +8,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"gpurun_out/pmcc_{tag}/{c}/*counter_collection.csv"):
         rows = list(csv.DictReader(open(f)))
         last = max(int(r["Dispatch_Id"]) for r in rows)
-        marks = sorted({int(r["Dispatch_Id"]) for r in rows if "residual_restriction_kernel" in r["Kernel_Name"] or "sr_restrict" in r["Kernel_Name"]})
+        marks = sorted({int(r["Dispatch_Id"]) for r in rows if "residual_restriction" in r["Kernel_Name"] or "sr_restrict" in r["Kernel_Name"]})
         period = marks[-1] - marks[-2]                      # one restriction launch per cycle
         for r in rows:
             if int(r["Dispatch_Id"]) <= last - period * 5:  # the last 5 cycles

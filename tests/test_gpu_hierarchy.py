@@ -756,6 +756,7 @@ def test_shared_agglomerate_eigensolves_change_no_bit(ctx, monkeypatch, n, mater
     ((8, 8, 8), "constant", "HipMatrixFreeMeshEvaluator", None),         # too small for classes of agglomerates
     ((4, 16, 20), "constant", "HipMatrixFreeMeshEvaluator", None),       # two agglomerates in x: everything in the list
     ((180, 12, 6), "constant", "HipMatrixFreeMeshEvaluator", True),      # 90 agglomerates in x: a full and a partial run
+    ((130, 36, 6), "constant", "HipMatrixFreeMeshEvaluator", True),      # tiles of 8 agglomerate rows: 18 rows (a ragged tile), 3 layers
     ((132, 10, 8), "constant", "HipMeshEvaluator", True),                # assembled fine operator
     ((130, 2, 4), "constant", "HipMatrixFreeMeshEvaluator", None),       # one agglomerate in y (both faces), two in z
     ((128, 6, 2), "constant", "HipMatrixFreeMeshEvaluator", None),       # one agglomerate layer in z
@@ -1123,6 +1124,12 @@ def test_setup_value_precision_float(ctx, n, material, solver):
     np.testing.assert_allclose(res_32, res_o, rtol=HIST_TOL, atol=HIST_ATOL)
     res_64, _ = gpu_history(ctx, h64, lambda y, x: op.vmult(y, x), b, x0, n_cycles=n_hist)
     np.testing.assert_allclose(res_32, res_64, rtol=1e-4)        # the same preconditioner up to the rounding of its matrices
+    if solver["type"] == "lu_dense":
+        # the precision belongs to the hierarchy, not to the context: the FP64 hierarchy, its restrictor replaced AFTER the float
+        # one was built on the same context, forms its Galerkin operator unrounded
+        h64.set_restrictor(R64)
+        Ac64 = h64.coarse_operator().to_scipy()
+        assert not np.array_equal(Ac64.data, Ac64.data.astype(np.float32).astype(np.float64))
 
 
 @pytest.mark.parametrize("n,material,numbering", [((8, 8), "linear", "lexicographic"), ((6, 5, 4), "discontinuous", "random"),
