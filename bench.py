@@ -148,8 +148,13 @@ def ms_per_decade(ms_per_cycle, contraction):
 
 
 def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, material="constant",
-                         evaluator="HipMatrixFreeMeshEvaluator"):
-    """BASELINE.json configs[1]: the same V-cycle on a `cells`^3 mesh, wall clock around `steps` cycles."""
+                         evaluator="HipMatrixFreeMeshEvaluator", release_setup_matrices=False):
+    """BASELINE.json configs[1]: the same V-cycle on a `cells`^3 mesh, wall clock around `steps` cycles.
+    release_setup_matrices: the hierarchy frees the CSR arrays of its table-driven operators once it stands (the same cycle bit
+    for bit, tests/test_gpu_hierarchy.py::test_release_setup_matrices; only the exports of those matrices are gone)."""
+    if release_setup_matrices:
+        params = dict(params)
+        params["release setup matrices"] = True
     prob = M.LaplaceProblem((cells,) * 3, material, device="cuda")
     t_setup = time.perf_counter()
     h = M.Hierarchy(ctx, evaluator, prob, params)
@@ -197,6 +202,7 @@ def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, mater
             "ms_per_residual_decade": ms_per_decade(dt * 1e3, contraction8),
             "device_memory_in_use_GB": (total_b - free_b) / 1e9,
             "device_memory_torch_tensors_GB": torch_gb,
+            "release_setup_matrices": bool(release_setup_matrices),
             "device_memory_note": "in use = hipMemGetInfo after torch.cuda.empty_cache(): the library's buffers (inventory below), the "
                                   "tensors of the caller (mesh arrays of the LaplaceProblem, x, b), HIP / RCCL runtime",
             "device_memory_inventory_GB": {line[14:].strip(): float(line[:10]) for line in M.memory_inventory().splitlines() if line.strip()}}
@@ -880,7 +886,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             try:
-                out["vcycle_513cubed_1gpu"] = measure_vcycle_small(ctx, torch, M, 512, params, steps=5, warmup=2)
+                out["vcycle_513cubed_1gpu"] = measure_vcycle_small(ctx, torch, M, 512, params, steps=5, warmup=2, release_setup_matrices=True)
             except Exception as e:  # noqa: BLE001
                 if not args.allow_missing_extras:
                     raise

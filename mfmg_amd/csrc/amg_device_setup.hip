@@ -238,8 +238,11 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
       period_p[d] = (int)std::max<int64_t>(1, std::min<int64_t>((blk - 1 + 2 * g.reach) / blk + 1, c.s.gn(d)));
     const int n_col_p = period_p[0] * period_p[1] * period_p[2] * C;
     // (the probes stay on the device and the rows are assembled there: probe_assembly.hip)
-    MemoryKind probe_kind("probe vectors (freed after the level is assembled)");
-    DeviceBuffer<double> Z((size_t)n_col_p * (size_t)n_f);
+    DeviceBuffer<double> Z;
+    {
+      MemoryKind probe_kind("probe vectors (freed after the level is assembled)");
+      Z.resize((size_t)n_col_p * (size_t)n_f);
+    }
     for (int col = 0; col < n_col_p; ++col)
     {
       const int comp = col % C, oc = col / C;
@@ -277,7 +280,11 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     }
     else
     {
-      DeviceBuffer<double> Y((size_t)n_col_a * (size_t)n_c);
+      DeviceBuffer<double> Y;
+      {
+        MemoryKind probe_kind("probe vectors (freed after the level is assembled)");
+        Y.resize((size_t)n_col_a * (size_t)n_c);
+      }
       for (int col = 0; col < n_col_a; ++col)
       {
         const int comp = col % C, oc = col / C;

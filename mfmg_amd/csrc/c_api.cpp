@@ -1066,6 +1066,19 @@ int mfmg_hip_hierarchy_create(mfmg_hip_context_t ctx, const char *evaluator_type
       ctx->handle->setup_values_float = false;
       h->hierarchy.reset(new Hierarchy<DVector>(nullptr, h->evaluator, params, h->timer));
     }
+    // "release setup matrices" true: once the hierarchy stands, the table-driven operators (A_c, the operators of the aggregation
+    // levels) free their CSR arrays -- 12 B per entry that only the setup algebra and the exports (get_coarse_operator, the
+    // level matrices) read: those calls throw afterwards.  One rank.
+    if (params->get("release setup matrices", false))
+    {
+      require(!ctx->handle->comm.enabled(), "\"release setup matrices\" is not available in a distributed run");
+      auto const &lv = h->hierarchy->levels();
+      for (size_t l = 1; l < lv.size(); ++l)
+        if (auto op = std::dynamic_pointer_cast<HipMatrixOperator const>(lv[l].get_operator()))
+          op->get_matrix()->release_csr();
+      if (auto solver = std::dynamic_pointer_cast<HipSolver const>(lv.back().get_solver()))
+        std::const_pointer_cast<HipSolver>(solver)->release_setup_matrices();
+    }
     const std::string precision = params->get("fine level precision", "double");
     if (precision == "float")
     {

@@ -1682,7 +1682,7 @@ HipHierarchyHelpers<VectorType>::build_coarse_solver(std::shared_ptr<Operator<Ve
     // R 1 on the device (the row sums of R; downloading its 113 M entries for that cost 0.4 s)
     DVector ones(_handle, r->get_matrix()->n()), sums(_handle, r->get_matrix()->m());
     ones = 1.;
-    r->get_matrix()->vmult(sums.get_values(), ones.get_values());
+    r->apply_local(ones.get_values(), sums.get_values());
     near_null.resize((size_t)sums.size());
     MFMG_HIP_CHECK(hipMemcpyAsync(near_null.data(), sums.get_values(), near_null.size() * sizeof(double), hipMemcpyDeviceToHost, _handle.stream));
     MFMG_HIP_CHECK(hipStreamSynchronize(_handle.stream));

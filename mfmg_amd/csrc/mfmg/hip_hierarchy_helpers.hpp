@@ -145,6 +145,15 @@ public:
   // stays for the setup algebra and for get_restrictor
   void set_structured(std::shared_ptr<StructuredRestrictorDevice> s) { _structured = std::move(s); }
   bool has_structured() const { return _structured != nullptr; }
+  // y = R x on this rank's arrays, no exchange: through the agglomerate-wise form where there is one (the CSR arrays of such a
+  // restrictor stay on the host until somebody asks for them)
+  void apply_local(double const *x, double *y) const
+  {
+    if (_structured)
+      _structured->restrict_to_coarse(x, y);
+    else
+      _matrix->vmult(y, x);
+  }
   bool structured_float_planes() const { return _structured != nullptr && _structured->float_planes(); }
   // b_c = R (A x - b) in one pass (structured_restrictor.hpp): probes the rows of R A for `a`, checks the result against
   // residual + restriction on a random pair of vectors and keeps it only if the two agree to rounding
@@ -325,6 +334,17 @@ public:
     mutable std::shared_ptr<DVector> res, b_coarse, x_coarse, x_work;
   };
   std::vector<AmgLevel> const &amg_levels() const { return _amg; }
+  // "release setup matrices": the CSR arrays of the table-driven operators of the aggregation hierarchy (SparseMatrixDevice::
+  // release_csr); returns how many matrices let go of theirs
+  int release_setup_matrices()
+  {
+    int n = 0;
+    for (auto &L : _amg)
+      for (auto const &op : {L.a, L.restrictor, L.prolongator, L.smoothed_prolongator})
+        if (op && op->get_matrix() && op->get_matrix()->release_csr())
+          ++n;
+    return n;
+  }
   // index of the first level that is gathered and solved redundantly on every rank (-1: one rank / none)
   int amg_gather_level() const { return _amg_gather_level; }
 

@@ -45,6 +45,7 @@ struct CsrArgs
   T alpha, beta;
   int mode;
   int pairs; // every vector the mode touches is 16-byte aligned: the two rows of a node are one access per operand (store_node)
+  int32_t const *kept_ptr = nullptr; // after release_csr(): val / col hold the listed rows only, row q of the list at [kept_ptr[q], kept_ptr[q + 1])
 };
 
 // the fused epilogues of a row (the modes of CsrMode)
@@ -535,7 +536,8 @@ __device__ __forceinline__ void listed_row_wave(CsrArgs<T> const &a, int32_t con
     return;
   const int64_t row = rows[w];
   T sum = T(0);
-  for (int p = a.row_ptr[row] + lane, e = a.row_ptr[row + 1]; p < e; p += 64)
+  const int p0 = a.kept_ptr ? a.kept_ptr[w] : a.row_ptr[row], e = a.kept_ptr ? a.kept_ptr[w + 1] : a.row_ptr[row + 1];
+  for (int p = p0 + lane; p < e; p += 64)
     sum += a.val[p] * a.x[a.col[p]];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1)
@@ -1229,6 +1231,7 @@ void SparseMatrixDevice<T>::ensure_host_copy() const
 template <typename T>
 void SparseMatrixDevice<T>::ensure_device_csr() const
 {
+  ASSERT_THROW(!_csr_released, "the CSR arrays of this matrix were released after the setup (\"release setup matrices\")");
   if (!_device_csr_deferred)
     return;
   MemoryKind kind("CSR arrays (val, col, row_ptr)");
@@ -1236,6 +1239,75 @@ void SparseMatrixDevice<T>::ensure_device_csr() const
   _col.upload(_col_host.data(), _col_host.size(), _handle.stream);
   _row_ptr.upload(_row_ptr_host.data(), _row_ptr_host.size(), _handle.stream);
   _device_csr_deferred = false;
+}
+
+namespace
+{
+// rows `rows[q]` of a CSR matrix copied one after the other (a wavefront per row)
+template <typename T>
+__global__ void csr_keep_rows_kernel(int32_t const *row_ptr, int32_t const *col, T const *val, int32_t const *rows, int64_t n_q, int32_t const *kept_ptr,
+                                     int32_t *kept_col, T *kept_val)
+{
+  const int64_t q = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (q >= n_q)
+    return;
+  const int s = row_ptr[rows[q]], e = row_ptr[rows[q] + 1], o = kept_ptr[q];
+  for (int p = s + lane; p < e; p += 64)
+  {
+    kept_col[o + p - s] = col[p];
+    kept_val[o + p - s] = val[p];
+  }
+}
+__global__ void csr_listed_lengths_kernel(int32_t const *row_ptr, int32_t const *rows, int64_t n_q, int32_t *len)
+{
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n_q; q += (int64_t)gridDim.x * blockDim.x)
+    len[q] = row_ptr[rows[q] + 1] - row_ptr[rows[q]];
+}
+} // namespace
+
+template <typename T>
+bool SparseMatrixDevice<T>::release_csr()
+{
+  if (_csr_released)
+    return true;
+  const bool by_classes = _use_nodecls && _use_regular;
+  const bool by_diagonals = _use_bdia && _bdia_regular && _use_regular && (int64_t)_bdia_exc_rows.size() <= kListedWaveRows;
+  if (!by_classes && !by_diagonals)
+    return false;
+  ensure_device_csr();
+  hipStream_t st = _handle.stream;
+  DeviceBuffer<int32_t> const &rows = by_classes ? _nc_listed : _bdia_exc_rows;
+  const int64_t n_q = (int64_t)rows.size();
+  std::vector<int32_t> ptr((size_t)n_q + 1, 0);
+  if (n_q > 0)
+  {
+    DeviceBuffer<int32_t> len((size_t)n_q);
+    hipLaunchKernelGGL(csr_listed_lengths_kernel, dim3(n_blocks_for(n_q, 256, 1 << 16)), dim3(256), 0, st, _row_ptr.data(), rows.data(), n_q, len.data());
+    MFMG_HIP_CHECK(hipGetLastError());
+    const std::vector<int32_t> hl = len.download(st);
+    for (int64_t q = 0; q < n_q; ++q)
+      ptr[q + 1] = ptr[q] + hl[q];
+  }
+  MemoryKind kind("CSR arrays (val, col, row_ptr)");
+  _kept_ptr.upload(ptr.data(), ptr.size(), st);
+  _kept_col.resize((size_t)std::max<int32_t>(ptr[n_q], 1));
+  _kept_val.resize((size_t)std::max<int32_t>(ptr[n_q], 1));
+  if (n_q > 0)
+  {
+    hipLaunchKernelGGL(csr_keep_rows_kernel<T>, dim3((unsigned int)((n_q * 64 + 255) / 256)), dim3(256), 0, st, _row_ptr.data(), _col.data(), _val.data(),
+                       rows.data(), n_q, _kept_ptr.data(), _kept_col.data(), _kept_val.data());
+    MFMG_HIP_CHECK(hipGetLastError());
+  }
+  MFMG_HIP_CHECK(hipStreamSynchronize(st));
+  _val.release();
+  _col.release();
+  _row_ptr.release();
+  std::vector<int32_t>().swap(_row_ptr_host);
+  std::vector<int32_t>().swap(_col_host);
+  std::vector<T>().swap(_val_host);
+  _csr_released = true;
+  return true;
 }
 
 // column indices of the rows `rows` (ascending), packed: row q occupies [ptr[q], ptr[q+1]) of cols
@@ -1247,6 +1319,7 @@ void SparseMatrixDevice<T>::sample_rows(std::vector<int64_t> const &rows, std::v
   cols.clear();
   if (nq == 0)
     return;
+  ASSERT_THROW(!_csr_released, "the CSR arrays of this matrix were released after the setup (\"release setup matrices\")");
   if (has_host_copy())
   {
     for (int64_t q = 0; q < nq; ++q)
@@ -2054,11 +2127,20 @@ void SparseMatrixDevice<T>::launch(CsrMode mode, T const *x, T const *b, T const
   ASSERT_THROW(x != out, "SpMV cannot run in place (out aliases x)");
   if (_n_rows == 0)
     return;
-  ensure_device_csr();
+  if (!_csr_released)
+    ensure_device_csr();
   CsrArgs<T> a;
   a.val = _val.data();
   a.col = _col.data();
   a.row_ptr = _row_ptr.data();
+  if (_csr_released)
+  {
+    ASSERT_THROW((_use_nodecls && _use_regular) || (_use_bdia && _bdia_regular && _use_regular), "internal: released CSR arrays with a kernel that reads them");
+    a.val = _kept_val.data();
+    a.col = _kept_col.data();
+    a.row_ptr = nullptr;
+    a.kept_ptr = _kept_ptr.data();
+  }
   a.n_rows = _n_rows;
   a.x = x;
   a.b = b;
@@ -2336,6 +2418,7 @@ template <typename T>
 void SparseMatrixDevice<T>::download(std::vector<int32_t> &row_ptr, std::vector<int32_t> &col,
                                      std::vector<T> &val) const
 {
+  ASSERT_THROW(!_csr_released, "the CSR arrays of this matrix were released after the setup (\"release setup matrices\")");
   if (_device_csr_deferred)
   {
     row_ptr = _row_ptr_host;

@@ -116,6 +116,13 @@ public:
     ensure_device_csr();
     return _row_ptr.data();
   }
+  // Free the CSR arrays (device and host copies) of a matrix whose kernels read tables -- node classes, or block diagonals with
+  // regular rows and stencil classes --, keeping the few rows the tables do not cover as a compact CSR of their own
+  // ("release setup matrices": A_c and the operators of the aggregation levels hold 12 B per entry that only the setup
+  // algebra and the exports read).  False (nothing done) for a matrix whose kernels read the CSR arrays themselves.
+  // Afterwards download / transpose / mmult / the diagonal kernels and a change of kernel throw.
+  bool release_csr();
+  bool csr_released() const { return _csr_released; }
   // the CSR arrays on the device (a no-op unless the upload was deferred)
   void ensure_device_csr() const;
   bool device_csr_deferred() const { return _device_csr_deferred; }
@@ -129,6 +136,7 @@ public:
   // symmetric matrix is stored), 4 row-base storage, 5 node classes; each variant only where its data was built
   void set_kernel(int lanes_per_row, int use_lds)
   {
+    ASSERT_THROW(!_csr_released || use_lds < 0, "the CSR arrays of this matrix were released after the setup: its kernel is fixed");
     if (lanes_per_row > 0)
       _lanes_per_row = lanes_per_row;
     if (use_lds >= 0)
@@ -150,7 +158,11 @@ public:
   {
     return _use_regular && ((_use_bdia && _bdia_regular) || _use_nodecls);
   }
-  void set_regular_rows(bool on) { _use_regular = on; }
+  void set_regular_rows(bool on)
+  {
+    ASSERT_THROW(!_csr_released || on, "the CSR arrays of this matrix were released after the setup: its kernel is fixed");
+    _use_regular = on;
+  }
   // rows evaluated from stored values although the matrix has regular rows, and the stencil classes next to the regular one
   int64_t listed_rows() const { return (int64_t)(_use_nodecls ? _nc_listed.size() : _bdia_exc_rows.size()); }
   int stencil_classes() const { return _use_nodecls ? _nc_classes : _bdia_n_classes; }
@@ -217,6 +229,9 @@ private:
   mutable DeviceBuffer<int32_t> _col;
   mutable DeviceBuffer<int32_t> _row_ptr;
   mutable bool _device_csr_deferred = false;
+  bool _csr_released = false;
+  DeviceBuffer<int32_t> _kept_ptr, _kept_col; // the listed rows after release_csr(), in the order of the list
+  DeviceBuffer<T> _kept_val;
   mutable std::vector<int32_t> _row_ptr_host, _col_host;
   mutable std::vector<T> _val_host;
 };

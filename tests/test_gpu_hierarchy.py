@@ -1132,6 +1132,43 @@ def test_setup_value_precision_float(ctx, n, material, solver):
         assert not np.array_equal(Ac64.data, Ac64.data.astype(np.float32).astype(np.float64))
 
 
+@pytest.mark.parametrize("material", ["constant", "linear"])
+def test_release_setup_matrices(ctx, material):
+    """"release setup matrices" true: the table-driven operators (A_c, the operators of the aggregation levels) free their CSR
+    arrays once the hierarchy stands -- 12 B per entry that only the setup algebra and the exports read; the rows their tables
+    do not cover stay as a compact CSR.  The cycle is the same cycle bit for bit, the library holds less memory, and the exports
+    of the released matrices fail loudly instead of handing out nothing."""
+    n = (64, 64, 64)
+    prob = M.LaplaceProblem(n, material, device="cuda")
+    params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0},
+                         solver={"type": "amg", "amg": {"smoother_degree": 1, "smoothing_range": 4.0, "pre_smoothing_levels": 0}})
+
+    def library_bytes():
+        return float(M.memory_inventory().strip().splitlines()[-1].split()[0])
+    x0 = np.random.default_rng(8).random(prob.n_dofs) * (prob.constrained.cpu().numpy() != 1)
+    out, held = [], []
+    for release in (False, True):
+        before = library_bytes()
+        p = dict(params)
+        p["release setup matrices"] = release
+        h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, p)
+        held.append(library_bytes() - before)
+        x, b = dev(x0), dev(np.zeros(prob.n_dofs))
+        for _ in range(4):
+            h.apply(b, x)
+        ctx.synchronize()
+        out.append(x.cpu().numpy())
+        if release:
+            if h.coarse_operator().get_kernel()[1] in (2, 3, 5):       # table-driven: its CSR arrays are gone
+                with pytest.raises(L.MfmgError, match="released"):
+                    h.coarse_operator().to_scipy()
+            h.restrictor().to_scipy()                                  # (the restrictor keeps its host copy)
+        del h
+    assert np.array_equal(out[0], out[1])
+    if material == "constant":
+        assert held[1] < 0.8 * held[0]
+
+
 @pytest.mark.parametrize("n,material,numbering", [((8, 8), "linear", "lexicographic"), ((6, 5, 4), "discontinuous", "random"),
                                                    ((16, 12, 10), "linear", "lexicographic"), ((3, 3, 3), "constant", "random")])
 def test_fine_operator_assembled_on_the_device(ctx, n, material, numbering):

@@ -608,9 +608,10 @@ def test_csr_transpose_and_product_on_device(ctx, monkeypatch, shape, density, d
 
 
 def test_csr_algebra_falls_back_for_rows_beyond_lds(ctx, monkeypatch):
-    """Rows with more candidate columns than the LDS hash table holds (or transposed rows beyond the LDS sort) take the
-    host algorithm: the same result, and an error where the test insists on the device path."""
-    n = 5000
+    """Rows with more candidate columns than the LDS tables hold (hash: 2048 candidates; addressed by the column: 8192 columns
+    of B) or transposed rows beyond the LDS sort take the host algorithm: the same result, and an error where the test insists on
+    the device path.  Between the two limits the column-addressed table serves the row on the device."""
+    n = 9000
     A = sp.csr_matrix(np.ones((1, n)))
     B = sp.identity(n, format="csr") * 2.0
     Ad, Bd = M.SparseMatrixDevice(ctx, A), M.SparseMatrixDevice(ctx, B)
@@ -623,6 +624,17 @@ def test_csr_algebra_falls_back_for_rows_beyond_lds(ctx, monkeypatch):
         Ad.multiply(Bd)
     with pytest.raises(RuntimeError, match="LDS tables"):
         M.SparseMatrixDevice(ctx, sp.csr_matrix(np.ones((n, 1)))).transpose()
+    # 5000 candidates in a row, 5000 columns: beyond the hash table, within the column-addressed one -- on the device, and the
+    # bits of the host product (a dense-ish product with sums of several terms per entry)
+    rng = np.random.default_rng(4)
+    m = 5000
+    A2 = sp.random(40, 600, density=0.5, random_state=rng, format="csr", dtype=np.float64)
+    B2 = sp.random(600, m, density=0.3, random_state=rng, format="csr", dtype=np.float64)
+    C2 = M.SparseMatrixDevice(ctx, A2).multiply(M.SparseMatrixDevice(ctx, B2)).to_scipy()
+    monkeypatch.setenv("MFMG_CSR_ALGEBRA", "host")
+    C2h = M.SparseMatrixDevice(ctx, A2).multiply(M.SparseMatrixDevice(ctx, B2)).to_scipy()
+    assert np.array_equal(C2.indptr, C2h.indptr) and np.array_equal(C2.indices, C2h.indices) and np.array_equal(C2.data, C2h.data)
+    assert abs(C2 - A2 @ B2).max() <= 1e-13 * abs(C2h).max()
 
 
 def test_csr_fixture_random_pattern_and_jacobi(ctx):
