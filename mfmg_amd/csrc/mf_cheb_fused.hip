@@ -63,6 +63,9 @@ struct MfFusedArgs
   T alpha[3], beta[3];
   AffineIds aff;
   unsigned int vec_bytes, rec_total_bytes; // extents of the vectors / of the record array (descriptors; at most 2^32 - 1)
+  // narrow last chunk column (<= 32 - 2 halo owned columns): its tiles come last in the tile list and take TWO y-tiles each, one
+  // per half of the wavefront (wide_tiles = tiles of the other columns; ntiles_y2 = ceil(ntiles_y / 2); 0: no such tiles)
+  unsigned int wide_tiles, ntiles_y2;
 };
 
 namespace
@@ -155,8 +158,11 @@ struct BufIO<float>
 };
 
 // DBG (timing experiments only, wrong results): 1 = no barrier, 2 = no division, 3 = no global stores
-template <typename T, int K, int TY, bool DREC, bool MODES, int DBG = 0>
-__device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
+// NARROW: the tile of a narrow last chunk column.  Lanes 0-31 work on y-tile 2 t, lanes 32-63 on y-tile 2 t + 1 of the same
+// 32 columns: everything that depends on the y-tile (row numbers, row masks, the row part of an address) is per lane instead of
+// per wavefront; the halves exchange nothing (their edge lanes are halo lanes of either), owner computes as everywhere.
+template <typename T, int K, int TY, bool DREC, bool MODES, int DBG = 0, bool NARROW = false>
+__device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsigned int w)
 {
 #pragma clang fp contract(off)
   constexpr int R = TY + 1; // node rows of a wavefront
@@ -168,25 +174,30 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
   T *ring = reinterpret_cast<T *>(smem_raw) + (size_t)wv * (ring_planes(K) * R * 64) + lane;
   T *xport = reinterpret_cast<T *>(smem_raw) + (size_t)NW * (ring_planes(K) * R * 64) + lane;
 
-  // XCD-aware tile order (as mf_laplace_body): every XCD takes a contiguous run of the tile list
-  const unsigned int n_tiles = a.ncols * a.ntiles_y * a.ntiles_z;
-  unsigned int w = blockIdx.x;
-  if (n_tiles >= 64)
+  // (tile w of the list: the kernel has dealt the list to the XCDs in contiguous runs)
+  const int wcols = a.ntiles_y2 > 0 ? (int)a.ncols - 1 : (int)a.ncols; // chunk columns with tiles of their own width
+  int tc, tyi, tzi, lx = lane;
+  if constexpr (NARROW)
   {
-    const unsigned int per_xcd = (n_tiles + 7) / 8;
-    w = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    if (w >= n_tiles)
-      return; // the whole workgroup leaves
+    const unsigned int v = w - a.wide_tiles;
+    tc = (int)a.ncols - 1;
+    tyi = 2 * (int)(v % a.ntiles_y2) + (lane >> 5); // (per lane)
+    tzi = (int)(v / a.ntiles_y2);
+    lx = lane & 31;
   }
-  const int tc = w % a.ncols;
-  const int tyi = (w / a.ncols) % a.ntiles_y;
-  const int tzi = w / (a.ncols * a.ntiles_y);
+  else
+  {
+    tc = (int)(w % (unsigned int)wcols);
+    tyi = (int)((w / (unsigned int)wcols) % a.ntiles_y);
+    tzi = (int)(w / ((unsigned int)wcols * a.ntiles_y));
+  }
+  const bool tile_live = !NARROW || tyi < (int)a.ntiles_y; // (an odd number of y-tiles leaves the second half of the last pair idle)
 
-  const int ci = tc * a.own - a.halo + lane; // node / cell column of this lane
+  const int ci = tc * a.own - a.halo + lx; // node / cell column of this lane
   const bool lane_in = ci >= 0 && ci < a.Nx;
   const bool lane_face = ((a.aff.faces & 1) && ci == 0) || ((a.aff.faces & 2) && ci == a.Nx - 1);
   const bool lane_free = lane_in && !lane_face;
-  const bool col_owned = lane >= a.halo && lane < a.halo + a.own && ci < a.Nx - a.aff.ghost_hi[0] && ci >= a.aff.ghost_lo[0]; // (ghost DoFs: computed, never written)
+  const bool col_owned = tile_live && lx >= a.halo && lx < a.halo + a.own && ci < a.Nx - a.aff.ghost_hi[0] && ci >= a.aff.ghost_lo[0]; // (ghost DoFs: computed, never written)
   const int RY = NW * TY - 2 * K + 1;    // DoF rows a tile owns
   const int Yw = tyi * RY - K + wv * TY; // first node row of this wavefront: node rows Yw .. Yw + TY, cell rows Yw .. Yw + TY - 1
   const int own_y0 = tyi * RY, own_y1 = min(own_y0 + RY, a.Ny);
@@ -194,7 +205,7 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
   // per-lane part of an address: a 32-bit byte offset from a uniform base (lanes outside the mesh load at a clamped column;
   // what they load is never used)
   const unsigned int off_lane = (unsigned int)(a.aff.base + min(max(ci, 0), a.Nx - 1) * a.aff.s0) * (unsigned int)sizeof(T);
-  const unsigned int rec_lane = (unsigned int)lane * (unsigned int)sizeof(T);
+  const unsigned int rec_lane = (unsigned int)lx * (unsigned int)sizeof(T);
 
   // Arguments that only the epilogues and the requests need (alpha, beta, kd, the vector bases) are re-read from the kernel
   // argument segment where they are used (scalar loads through a pointer the compiler cannot see through): held in scalar
@@ -253,14 +264,42 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
   const unsigned int rec_col = (unsigned int)tc * a.rec_bytes;
   auto layer_free = [&](int n) { return n >= 0 && n < a.Nz && !(((a.aff.faces & 16) && n == 0) || ((a.aff.faces & 32) && n == a.Nz - 1)); };
   auto layer_own = [&](int n) { return n >= Z0 && n < Z1 && n >= a.aff.ghost_lo[2] && n < a.Nz - a.aff.ghost_hi[2]; };
-  auto vec_off = [&](int r, int n) -> unsigned int {
-    return (unsigned int)min(max(Yw + r, 0), a.Ny - 1) * row_stride + (unsigned int)min(max(n, 0), a.Nz - 1) * layer_stride;
+  // an address = per-lane part + wave-uniform part: the row belongs to the uniform part, except in a NARROW tile, whose halves
+  // work on different rows
+  struct Off
+  {
+    unsigned int v, s;
   };
-  auto rec_off = [&](int q, int n) -> unsigned int {
-    return rec_col + (unsigned int)min(max(n, 0), a.Nz - 1) * rec_layer + (unsigned int)min(max(Yw + q, 0), a.Ny - 1) * rec_row;
+  auto vec_off = [&](int r, int n) -> Off {
+    const unsigned int rowb = (unsigned int)min(max(Yw + r, 0), a.Ny - 1) * row_stride, layb = (unsigned int)min(max(n, 0), a.Nz - 1) * layer_stride;
+    if constexpr (NARROW)
+      return Off{off_lane + rowb, layb};
+    else
+      return Off{off_lane, rowb + layb};
   };
-  auto ld_coef = [&](__amdgpu_buffer_rsrc_t rs_rec, int q, int n) -> T { return BufIO<T>::ld(rs_rec, rec_lane, rec_off(q, n) + (unsigned int)Rec<T, true>::kCoefOff); };
-  auto ld_dinv = [&](__amdgpu_buffer_rsrc_t rs_rec, int r, int n) -> T { return BufIO<T>::ld(rs_rec, rec_lane, rec_off(r, n) + (unsigned int)Rec<T, true>::kDinvOff); };
+  auto rec_off = [&](int q, int n, unsigned int field) -> Off {
+    const unsigned int rowb = (unsigned int)min(max(Yw + q, 0), a.Ny - 1) * rec_row, layb = rec_col + (unsigned int)min(max(n, 0), a.Nz - 1) * rec_layer + field;
+    if constexpr (NARROW)
+      return Off{rec_lane + rowb, layb};
+    else
+      return Off{rec_lane, rowb + layb};
+  };
+  auto ld_vec = [&](__amdgpu_buffer_rsrc_t rs, int r, int n) -> T {
+    const Off o = vec_off(r, n);
+    return BufIO<T>::ld(rs, o.v, o.s);
+  };
+  auto st_vec = [&](T v, __amdgpu_buffer_rsrc_t rs, int r, int n) {
+    const Off o = vec_off(r, n);
+    BufIO<T>::st(v, rs, o.v, o.s);
+  };
+  auto ld_coef = [&](__amdgpu_buffer_rsrc_t rs_rec, int q, int n) -> T {
+    const Off o = rec_off(q, n, (unsigned int)Rec<T, true>::kCoefOff);
+    return BufIO<T>::ld(rs_rec, o.v, o.s);
+  };
+  auto ld_dinv = [&](__amdgpu_buffer_rsrc_t rs_rec, int r, int n) -> T {
+    const Off o = rec_off(r, n, (unsigned int)Rec<T, true>::kDinvOff);
+    return BufIO<T>::ld(rs_rec, o.v, o.s);
+  };
   // slot of a node layer in a ring of depth 2 / 3 (layers are >= -1 here)
   auto slot2 = [](int n) { return n & 1; };
   auto slot3 = [](int n) { return (int)((unsigned int)(n + 3) % 3u); };
@@ -301,9 +340,9 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
 #pragma unroll
     for (int r = 0; r < R; ++r)
     {
-      *ring_at(0, cb, r) = BufIO<T>::ld(rs_x, off_lane, vec_off(r, cb));
-      *ring_at(0, cb + 1, r) = BufIO<T>::ld(rs_x, off_lane, vec_off(r, cb + 1));
-      bq[0][r] = BufIO<T>::ld(rs_b, off_lane, vec_off(r, cb));
+      *ring_at(0, cb, r) = ld_vec(rs_x, r, cb);
+      *ring_at(0, cb + 1, r) = ld_vec(rs_x, r, cb + 1);
+      bq[0][r] = ld_vec(rs_b, r, cb);
       if constexpr (DREC)
         dq[0][r] = ld_dinv(rs_rec, r, cb);
     }
@@ -452,14 +491,14 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
         if constexpr (K == 1)
         {
           if (st && fr)
-            BufIO<T>::st(x1, rs_vec(offsetof(MfFusedArgs<T>, out)), off_lane, vec_off(r, c));
+            st_vec(x1, rs_vec(offsetof(MfFusedArgs<T>, out)), r, c);
         }
         else
         {
           *ring_at(1, c, r) = fr ? x1 : T(0);
           if constexpr (K == 2)
             if (st && fr && want_prev)
-              BufIO<T>::st(x1, rs_vec(offsetof(MfFusedArgs<T>, out_prev)), off_lane, vec_off(r, c));
+              st_vec(x1, rs_vec(offsetof(MfFusedArgs<T>, out_prev)), r, c);
         }
         // Dirichlet DoFs: identity rows with D^-1 = 1 (the stored diagonal says so too) -- the whole recurrence here
         if (st && !fr)
@@ -473,9 +512,9 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
             xa = xb;
             xb = xn;
           }
-          BufIO<T>::st(xb, rs_vec(offsetof(MfFusedArgs<T>, out)), off_lane, vec_off(r, c));
+          st_vec(xb, rs_vec(offsetof(MfFusedArgs<T>, out)), r, c);
           if (K > 1 && want_prev)
-            BufIO<T>::st(xa, rs_vec(offsetof(MfFusedArgs<T>, out_prev)), off_lane, vec_off(r, c));
+            st_vec(xa, rs_vec(offsetof(MfFusedArgs<T>, out_prev)), r, c);
         }
       }
       else
@@ -490,12 +529,12 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
           *ring_at(S, c, r) = fr ? xs : T(0);
           if constexpr (S == K - 1)
             if (st && fr && want_prev)
-              BufIO<T>::st(xs, rs_vec(offsetof(MfFusedArgs<T>, out_prev)), off_lane, vec_off(r, c));
+              st_vec(xs, rs_vec(offsetof(MfFusedArgs<T>, out_prev)), r, c);
         }
         else
         {
           if (st && fr)
-            BufIO<T>::st(xs, rs_vec(offsetof(MfFusedArgs<T>, out)), off_lane, vec_off(r, c));
+            st_vec(xs, rs_vec(offsetof(MfFusedArgs<T>, out)), r, c);
         }
       }
     };
@@ -564,8 +603,8 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
 #pragma unroll
     for (int r = 0; r < R; ++r)
     {
-      pfx[r] = BufIO<T>::ld(rs_x, off_lane, vec_off(r, c1 + 2));
-      pfb[r] = BufIO<T>::ld(rs_b, off_lane, vec_off(r, c1 + 1));
+      pfx[r] = ld_vec(rs_x, r, c1 + 2);
+      pfb[r] = ld_vec(rs_b, r, c1 + 1);
       pfd[r] = T(0);
       if constexpr (DREC)
         pfd[r] = ld_dinv(rs_rec, r, c1 + 1);
@@ -621,10 +660,30 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a)
   }
 }
 
-template <typename T, int K, int TY, bool DREC, bool MODES, int DBG = 0>
+// NARROW_TOO: the kernel carries the body for the tiles of a narrow last chunk column as well (twice the code: only the tile
+// shapes the sweeps use by default have it; any other shape runs that column with ordinary tiles, most of their lanes idle)
+template <typename T, int K, int TY, bool DREC, bool MODES, int DBG = 0, bool NARROW_TOO = false>
 __global__ __launch_bounds__(512, 2) void mf_cheb_fused_kernel(MfFusedArgs<T> a)
 {
-  mf_cheb_fused_body<T, K, TY, DREC, MODES, DBG>(a);
+  // XCD-aware tile order (as mf_laplace_body): every XCD takes a contiguous run of the tile list
+  const unsigned int n_tiles = a.wide_tiles + a.ntiles_y2 * a.ntiles_z;
+  unsigned int w = blockIdx.x;
+  if (n_tiles >= 64)
+  {
+    const unsigned int per_xcd = (n_tiles + 7) / 8;
+    w = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (w >= n_tiles)
+      return; // the whole workgroup leaves
+  }
+  if constexpr (NARROW_TOO)
+  {
+    if (w >= a.wide_tiles)
+    {
+      mf_cheb_fused_body<T, K, TY, DREC, MODES, DBG, true>(a, w);
+      return;
+    }
+  }
+  mf_cheb_fused_body<T, K, TY, DREC, MODES, DBG, false>(a, w);
 }
 } // namespace
 
@@ -681,7 +740,8 @@ void MatrixFreeLaplaceDevice<T>::choose_fused_tile(int n_terms, int &nw, int &ty
     return v > 0 ? v : 256;
   }();
   const int64_t slots = (int64_t)n_cus * (8 / nw);
-  const int64_t tiles_xy = (int64_t)_ncols * ((_N[1] + ry - 1) / ry);
+  const int64_t nty = (_N[1] + ry - 1) / ry;
+  const int64_t tiles_xy = (narrow_last_column() && fused_narrow_capable(n_terms, ty)) ? (int64_t)(_ncols - 1) * nty + (nty + 1) / 2 : (int64_t)_ncols * nty;
   double best = 0.;
   for (int nz = 1; nz <= _N[2]; ++nz)
   {
@@ -754,7 +814,12 @@ void MatrixFreeLaplaceDevice<T>::smoother_sweep(int n_terms, T const *alpha, T c
   a.vec_bytes = (unsigned int)std::min<uint64_t>((uint64_t)_n_dofs * sizeof(T), 0xffffffffull);
   ASSERT_THROW((uint64_t)_rec.size() <= 0xffffffffull, "chunk records beyond 4 GiB: the multi-term sweep addresses them with 32-bit offsets");
   a.rec_total_bytes = (unsigned int)_rec.size();
-  const uint64_t n_tiles = (uint64_t)a.ncols * a.ntiles_y * a.ntiles_z;
+  // a narrow last chunk column (mf_laplace.hip: at most 32 - 2 halo owned columns) is swept two y-tiles per workgroup by the
+  // kernels that carry the body for it
+  const bool narrow = narrow_last_column() && fused_narrow_capable(n_terms, ty);
+  a.ntiles_y2 = narrow ? (a.ntiles_y + 1) / 2 : 0u;
+  a.wide_tiles = (a.ncols - (narrow ? 1u : 0u)) * a.ntiles_y * a.ntiles_z;
+  const uint64_t n_tiles = (uint64_t)a.wide_tiles + (uint64_t)a.ntiles_y2 * a.ntiles_z;
   ASSERT_THROW(n_tiles < (1ull << 30), "tile of the multi-term sweep too small for this mesh (grid size limit)");
   const unsigned int n_blocks = (unsigned int)(n_tiles >= 64 ? ((n_tiles + 7) / 8) * 8 : n_tiles);
   const size_t lds = ((size_t)nw * ring_planes(n_terms) * (ty + 1) + (size_t)2 * nw * 4) * 64 * sizeof(T);
@@ -785,6 +850,19 @@ void MatrixFreeLaplaceDevice<T>::smoother_sweep(int n_terms, T const *alpha, T c
     constexpr int KK = decltype(kt)::value;
     constexpr bool DR = decltype(dt)::value != 0;
     constexpr bool MO = decltype(mt)::value != 0;
+    // (fused_narrow_capable: these two shapes carry the second body)
+    if constexpr (KK == 3)
+      if (narrow && ty == 3)
+      {
+        go(mf_cheb_fused_kernel<T, 3, 3, DR, MO, 0, true>);
+        return;
+      }
+    if constexpr (KK == 2)
+      if (narrow && ty == 4)
+      {
+        go(mf_cheb_fused_kernel<T, 2, 4, DR, MO, 0, true>);
+        return;
+      }
     if (ty == 2)
       go(mf_cheb_fused_kernel<T, KK, 2, DR, MO>);
     else if (ty == 3)

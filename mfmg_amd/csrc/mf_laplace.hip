@@ -885,6 +885,15 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   {
     _ncols = (_N[0] + (64 - 2 * _halo) - 1) / (64 - 2 * _halo);
     _own = (_N[0] + _ncols - 1) / _ncols;
+    // ... unless full chunks leave a last one of at most 32 - 2 halo columns (257 = 4 x 58 + 25): the sweep runs that column
+    // two y-tiles per workgroup (NARROW in mf_cheb_fused.hip), 4.5 columns of tiles instead of 5
+    const int full = 64 - 2 * _halo, rest = _N[0] - (_ncols - 1) * full;
+    static const bool narrow_off = std::getenv("MFMG_MF_NARROW") && std::string(std::getenv("MFMG_MF_NARROW")) == "0";
+    if (_ncols >= 2 && rest >= 1 && rest <= 32 - 2 * _halo && !narrow_off)
+    {
+      _own = full;
+      _narrow_last = true;
+    }
   }
   const size_t n_slots = (size_t)_ncols * _N[2] * _N[1] * 64;
   _n_slots = n_slots;

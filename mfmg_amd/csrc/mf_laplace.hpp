@@ -101,6 +101,10 @@ public:
   // out_prev and x must be three different vectors.  Available for the cell-constant layout with a numbering the kernel can
   // compute on one rank (fused_sweep_available); callers fall back to smoother_step otherwise.
   bool fused_sweep_available(int n_terms) const;
+  // the last chunk column owns at most 32 - 2 halo DoF columns: the sweep kernels of the default tile shapes (three terms 8 x 3
+  // rows, two terms 4 x 4) run it two y-tiles per workgroup, one per half of the wavefront
+  bool narrow_last_column() const { return _narrow_last; }
+  static bool fused_narrow_capable(int n_terms, int ty) { return (n_terms == 3 && ty == 3) || (n_terms == 2 && ty == 4); }
   void smoother_sweep(int n_terms, T const *alpha, T const *beta, T const *b, T const *x, T *out, T *out_prev) const;
   // tile of the sweep: nw wavefronts of ty cell rows, tz owned layers (0, 0, 0: chosen from the mesh)
   void set_fused_tile(int nw, int ty, int tz)
@@ -197,6 +201,7 @@ private:
   // internal layout (mf_laplace.hip): rows cut into aligned chunks of 64 cell slots (62 owned DoFs + the
   // halo cell); one record per chunk with the b=1 face ids, the coefficients and D^-1, plus the b=0 face ids
   int _ncols = 0;
+  bool _narrow_last = false; // (see narrow_last_column)
   int _own = 62, _halo = 1; // chunk c holds the node columns _own c - _halo + lane and owns its lanes [_halo, _halo + _own)
   size_t _n_slots = 0;
   // columns of a nearly empty last chunk, as a slab operator with x and y exchanged (mf_laplace.hip)

@@ -5,7 +5,7 @@ import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"].replace("void ", "").replace("mfmg::(anonymous namespace)::", "").replace("mfmg::vec::(anonymous namespace)::", "vec::"))
-rr = [i for i, r in enumerate(rows) if "residual_restriction_kernel" in r["Kernel_Name"]]
+rr = [i for i, r in enumerate(rows) if "residual_restriction" in r["Kernel_Name"]]
 ncyc = 10
 tail = rows[rr[-ncyc - 1]: rr[-1]]
 span = int(tail[-1]["End_Timestamp"]) - int(tail[0]["Start_Timestamp"])
