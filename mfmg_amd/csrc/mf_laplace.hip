@@ -889,7 +889,8 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
     // two y-tiles per workgroup (NARROW in mf_cheb_fused.hip), 4.5 columns of tiles instead of 5
     const int full = 64 - 2 * _halo, rest = _N[0] - (_ncols - 1) * full;
     static const bool narrow_off = std::getenv("MFMG_MF_NARROW") && std::string(std::getenv("MFMG_MF_NARROW")) == "0";
-    if (_ncols >= 2 && rest >= 1 && rest <= 32 - 2 * _halo && !narrow_off)
+    // (FP64 only: the FP32 sweep was slower with it, 1.08 against 1.02 ms per cycle at 257^3 -- one round of long tiles hides less)
+    if (_ncols >= 2 && rest >= 1 && rest <= 32 - 2 * _halo && !narrow_off && sizeof(T) == 8)
     {
       _own = full;
       _narrow_last = true;
