@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 #include <link.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -124,8 +125,17 @@ public:
   {
     _exchange_stream = s;
     char const *one = std::getenv("MFMG_RCCL_ONE_COMM");
-    if (_comm_x == nullptr && rccl().CommSplit != nullptr && !(one && std::string(one) == "1"))
-      rccl_check(rccl().CommSplit(_comm, 0, _rank, &_comm_x, nullptr), "ncclCommSplit");
+    if (_comm_x == nullptr && !_split_tried && rccl().CommSplit != nullptr && !(one && std::string(one) == "1"))
+    {
+      // (a refusal is not fatal: the exchanges of both streams then share the first communicator, as in round 3)
+      _split_tried = true;
+      const int status = rccl().CommSplit(_comm, 0, _rank, &_comm_x, nullptr);
+      if (status != ncclSuccess)
+      {
+        std::fprintf(stderr, "mfmg-hip: ncclCommSplit refused (%s): one communicator for both streams\n", rccl().GetErrorString(status));
+        _comm_x = nullptr;
+      }
+    }
   }
   ncclComm_t comm_for(hipStream_t s) const { return (_comm_x != nullptr && s == _exchange_stream) ? _comm_x : _comm; }
   int comm_ranks() const override
@@ -196,6 +206,7 @@ public:
 private:
   int _rank;
   ncclComm_t _comm = nullptr, _comm_x = nullptr;
+  bool _split_tried = false;
   hipStream_t _exchange_stream = nullptr;
   DeviceBuffer<double> _scalars;
 };

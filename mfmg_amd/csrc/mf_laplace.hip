@@ -151,6 +151,7 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
   // own id of node row `jrow` (clamped into the mesh) in the layer whose records start at `layer`
   const int id_lane = a.aff.base + ci * a.aff.s0; // (AFF) the part of the id that belongs to the lane
   const bool lane_in = ci >= 0 && ci < a.Nx;
+  const bool cell_lane = ci >= 0 && ci < a.Nx - 1; // the slot holds a real cell (the others carry coefficient zero)
   const bool lane_face = ((a.aff.faces & 1) && ci == 0) || ((a.aff.faces & 2) && ci == a.Nx - 1);
   // (one rank: no ghost planes at all -- the tests below would cost the eight-coefficient kernel a dozen scalar operations per row)
   const bool any_ghost = (a.aff.ghost_lo[0] | a.aff.ghost_hi[0] | a.aff.ghost_lo[1] | a.aff.ghost_hi[1] | a.aff.ghost_lo[2] | a.aff.ghost_hi[2]) != 0;
@@ -284,7 +285,15 @@ __device__ __forceinline__ void mf_laplace_body(MfArgs<T> const &a, unsigned int
         if constexpr (CC)
           c[b][0] = reinterpret_cast<T const *>(recp + Rec<T, true>::kCoefOff)[lane];
         else
-          load_coef<T, false>(recp, lane, c[b]);
+        {
+          // slots without a real cell (the lanes past the last cell column: 54 of the 64 lanes of the last chunk at 257 DoFs per
+          // row; the last DoF row and layer) are stored as zeros: do not fetch them (64 bytes per slot; the same bits)
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            c[b][q] = T(0);
+          if (cell_lane && j < a.Ny - 1 && k >= 0 && k < a.Nz - 1)
+            load_coef<T, false>(recp, lane, c[b]);
+        }
         if (jj > 0 && kk > 0 && a.mode != 0)
         {
           // the DoF row this cell row completes: node row jj, id = the layer-k id of the previous node row
