@@ -76,6 +76,10 @@ def parse_args():
                     help="N > 1: equal boxes on the grid the weak-scaling mesh grows by (1x1x2, 1x2x2, 2x2x2; SURVEY.md 8e) or slabs "
                          "along z")
     ap.add_argument("--grid", type=str, default="", help="px,py,pz: ranks along x, y, z of a box run (default: follows the mesh)")
+    ap.add_argument("--low-ghost", type=int, default=4, choices=[2, 4],
+                    help="N > 1: ghost cell layers of a rank's local mesh towards a lower neighbour: 4 (two agglomerates: the whole "
+                         "Chebyshev(3) smoother of a rank is ONE sweep, x exchanged once and three planes deep) or 2 (rounds 2-3: "
+                         "two terms per sweep + a launch for the third, two exchanges)")
     ap.add_argument("--tile", type=str, default="", help="ty,tz[,waves] override of the operator tile (default: timed choice)")
     return ap.parse_args()
 
@@ -536,7 +540,8 @@ def main():
                 rank_grid[2 - i % 3] *= 2
             rank_grid = tuple(rank_grid)
         assert rank_grid[0] * rank_grid[1] * rank_grid[2] == world, "--grid must multiply to --gpus"
-        part = M.BoxPartition((gx, gy, gz), rank, rank_grid, length=(gx / args.cells, gy / args.cells, gz / args.cells))
+        part = M.BoxPartition((gx, gy, gz), rank, rank_grid, length=(gx / args.cells, gy / args.cells, gz / args.cells),
+                              low_ghost_cells=args.low_ghost)
         if backend != "nccl":
             os.environ.setdefault("MFMG_BENCH_TRANSPORT", "host")
         transport = M.HaloTransport(ctx, part, 2, transport=os.environ.get("MFMG_BENCH_TRANSPORT") or None)

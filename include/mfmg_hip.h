@@ -112,9 +112,15 @@ typedef int (*mfmg_hip_host_allgather_fn)(void *user, const double *in, int64_t 
 int mfmg_hip_context_set_communicator(mfmg_hip_context_t ctx, int32_t rank, int32_t n_ranks, int32_t ghost_cells_low,
                                       int32_t ghost_cells_high);
 /* grid[3]: ranks along x, y, z (their product = the number of ranks); ghost_low / ghost_high[3]: ghost cell layers of the local
- * mesh per axis (2 towards an existing neighbour, else 0).  set_communicator(rank, n, lo, hi) is the grid 1 x 1 x n. */
+ * mesh per axis (2 towards an existing neighbour -- or 4 below, see mfmg_hip_context_set_low_ghost_cells --, else 0).  set_communicator(rank, n, lo, hi) is the grid 1 x 1 x n. */
 int mfmg_hip_context_set_communicator_box(mfmg_hip_context_t ctx, int32_t rank, const int32_t grid[3], const int32_t ghost_low[3],
                                           const int32_t ghost_high[3]);
+/* Ghost cell layers EVERY rank of the run holds towards a lower neighbour: 2 (default, one agglomerate) or 4 (two; then
+ * ghost_low[d] = 4 above).  The same value on every rank, also on ranks without a lower neighbour, after set_communicator*:
+ * the interface plane belongs to the upper box, so a box holds three ghost node planes above it and `cells` below, and a
+ * sweep of K smoother terms (one exchange of x, K planes deep, ghost DoFs computed redundantly) needs K on every side with a
+ * neighbour -- 4 lets the whole Chebyshev(3) smoother of a rank run as ONE sweep with ONE exchange. */
+int mfmg_hip_context_set_low_ghost_cells(mfmg_hip_context_t ctx, int32_t cells);
 int mfmg_hip_rccl_unique_id(unsigned char out[128]);
 /* MFMG_HIP_SUCCESS when librccl and the entry points the transport uses can be resolved in this process (dlopen / dlsym
  * only, no RCCL call is made).  Callers agree on the transport with a collective over this flag before they choose. */

@@ -155,9 +155,9 @@ int mfmg_hip_context_set_communicator(mfmg_hip_context_t ctx, int32_t rank, int3
   return guarded([&] {
     require(ctx != nullptr, "null context");
     require(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "rank out of range");
-    require((ghost_cells_low == 0 || ghost_cells_low == 2) && (ghost_cells_high == 0 || ghost_cells_high == 2),
-            "ghost cell layers must be 0 or 2 (one agglomerate layer)");
-    require((ghost_cells_low == 2) == (rank > 0) && (ghost_cells_high == 2) == (rank + 1 < n_ranks),
+    require((ghost_cells_low == 0 || ghost_cells_low == 2 || ghost_cells_low == 4) && (ghost_cells_high == 0 || ghost_cells_high == 2),
+            "ghost cell layers must be 0 or 2 (one agglomerate layer; 4 = two of them towards the lower neighbour)");
+    require((ghost_cells_low > 0) == (rank > 0) && (ghost_cells_high == 2) == (rank + 1 < n_ranks),
             "ghost layers must be present exactly towards existing neighbours");
     HaloCommunicator &c = ctx->handle->comm;
     auto transport = c.transport;
@@ -185,9 +185,9 @@ int mfmg_hip_context_set_communicator_box(mfmg_hip_context_t ctx, int32_t rank, 
     const int coord[3] = {rank % grid[0], (rank / grid[0]) % grid[1], rank / (grid[0] * grid[1])};
     for (int d = 0; d < 3; ++d)
     {
-      require((ghost_low[d] == 0 || ghost_low[d] == 2) && (ghost_high[d] == 0 || ghost_high[d] == 2),
-              "ghost cell layers must be 0 or 2 (one agglomerate layer)");
-      require((ghost_low[d] == 2) == (coord[d] > 0) && (ghost_high[d] == 2) == (coord[d] + 1 < grid[d]),
+      require((ghost_low[d] == 0 || ghost_low[d] == 2 || ghost_low[d] == 4) && (ghost_high[d] == 0 || ghost_high[d] == 2),
+              "ghost cell layers must be 0 or 2 (one agglomerate layer; 4 = two of them towards the lower neighbour)");
+      require((ghost_low[d] > 0) == (coord[d] > 0) && (ghost_high[d] == 2) == (coord[d] + 1 < grid[d]),
               "ghost layers must be present exactly towards existing neighbours");
     }
     HaloCommunicator &c = ctx->handle->comm;
@@ -205,6 +205,18 @@ int mfmg_hip_context_set_communicator_box(mfmg_hip_context_t ctx, int32_t rank, 
     }
     c.ghost_cells_low = ghost_low[2];
     c.ghost_cells_high = ghost_high[2];
+  });
+}
+
+int mfmg_hip_context_set_low_ghost_cells(mfmg_hip_context_t ctx, int32_t cells)
+{
+  return guarded([&] {
+    require(ctx != nullptr, "null context");
+    require(cells == 2 || cells == 4, "ghost cell layers towards a lower neighbour: 2 or 4");
+    HaloCommunicator &c = ctx->handle->comm;
+    for (int d = 0; d < 3; ++d)
+      require(c.ghost_lo[d] == 0 || c.ghost_lo[d] == cells, "the local mesh of this rank holds another number of ghost cell layers below");
+    c.low_ghost_cells = cells;
   });
 }
 

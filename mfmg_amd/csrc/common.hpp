@@ -473,6 +473,12 @@ struct HaloCommunicator
   int coord[3] = {0, 0, 0}; // this rank's position
   int ghost_lo[3] = {0, 0, 0}, ghost_hi[3] = {0, 0, 0}; // ghost cell layers of the local mesh per axis
   int ghost_cells_low = 0, ghost_cells_high = 0;        // ... those along z
+  // ghost cell layers EVERY rank of the run holds towards a lower neighbour (2 = one agglomerate, 4 = two; the same value on all
+  // ranks, also on those without a lower neighbour: what the ranks may do together follows from it).  The interface plane
+  // belongs to the upper box, so a box holds ghost_hi + 1 = 3 ghost node planes above but only low_ghost_cells below: a sweep of K
+  // smoother terms needs K on every side with a neighbour (mf_cheb_fused.hip)
+  int low_ghost_cells = 2;
+  int sweep_terms() const { return low_ghost_cells >= 4 ? 3 : 2; }
   std::shared_ptr<HaloTransport> transport;
   std::vector<HaloSpace> spaces = std::vector<HaloSpace>(3); // [0] rank-local, [1] fine DoFs, [2] first coarse level, then the aggregation levels
   int64_t n_exchanges = 0; // (diagnostics) point-to-point exchanges issued so far
@@ -553,8 +559,17 @@ struct HipHandle
   // and the one-pass residual restriction both read b at ghost DoFs; outside a cycle both exchange it themselves.
   double const *rhs_in_flight = nullptr, *rhs_fresh = nullptr, *rhs_of_cycle = nullptr;
   bool rhs_ghosts_wanted = false; // the fine smoother of this context reads b at ghost DoFs (distributed multi-term sweep)
-  // make the ghost entries of the fine-level vector b current on `stream`
-  void need_rhs_ghosts(double const *b)
+  int rhs_ghost_width = 1;        // ... that many planes deep (a sweep of K terms: K - 1; the residual restriction: 1)
+  int rhs_fresh_width = 0;        // depth of the exchange that made rhs_fresh / rhs_in_flight current
+  // the fine DoF space with ghost layers `width` planes deep
+  HaloSpace fine_space(int width) const
+  {
+    HaloSpace s = comm.spaces[1];
+    s.width = width;
+    return s;
+  }
+  // make the ghost entries of the fine-level vector b current on `stream`, `width` planes deep
+  void need_rhs_ghosts(double const *b, int width = 1)
   {
     if (!comm.enabled())
       return;
@@ -564,11 +579,13 @@ struct HipHandle
       rhs_fresh = b;
       rhs_in_flight = nullptr;
     }
-    else if (rhs_fresh != b)
+    if (rhs_fresh != b || rhs_fresh_width < width)
     {
-      exchange(1, const_cast<double *>(b));
-      if (rhs_of_cycle == b) // (fresh only while the cycle that announced this vector is running)
-        rhs_fresh = b;
+      if (!comm.transport)
+        throw std::runtime_error("no halo transport was registered with the context");
+      exchange_on(fine_space(std::max(width, rhs_ghost_width)), const_cast<double *>(b), stream, stream, false);
+      rhs_fresh_width = std::max(width, rhs_ghost_width);
+      rhs_fresh = rhs_of_cycle == b ? b : nullptr; // (fresh only while the cycle that announced this vector is running)
     }
   }
 
@@ -742,7 +759,10 @@ struct HipHandle
   {
     if (!comm.enabled() || space <= 0)
       return;
-    HaloSpace &s = space_checked(space);
+    exchange_async(space_checked(space), v);
+  }
+  void exchange_async(HaloSpace const &s, double *v)
+  {
     hipStream_t cs = exchange_stream();
     if (ev_async == nullptr)
       MFMG_HIP_CHECK(hipEventCreateWithFlags(&ev_async, hipEventDisableTiming));

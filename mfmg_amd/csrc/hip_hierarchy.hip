@@ -445,7 +445,8 @@ void HipMatrixOperator::prefetch_rhs(DVector const &b) const
   if (!hd.comm.enabled() || !hd.overlap_exchange || _domain_space <= 0 || b.size() != _matrix->n() ||
       !(restriction_reads_it || hd.rhs_ghosts_wanted))
     return;
-  hd.exchange_async(_domain_space, const_cast<double *>(b.get_values()));
+  hd.exchange_async(hd.fine_space(hd.rhs_ghosts_wanted ? hd.rhs_ghost_width : 1), const_cast<double *>(b.get_values()));
+  hd.rhs_fresh_width = hd.rhs_ghosts_wanted ? hd.rhs_ghost_width : 1;
   hd.rhs_in_flight = b.get_values();
   if (restriction_reads_it)
     _prefetched_rhs = b.get_values();
@@ -823,13 +824,13 @@ bool HipMatrixFreeOperator::smoother_sweep(int n_terms, double const *alpha, dou
   {
     // Distributed: term s of the sweep is right where the whole stencil of term s - 1 was, so the rank computes the ghost DoFs
     // next to its box redundantly: x travels n_terms ghost planes deep (ONE exchange for the n_terms terms instead of one each),
-    // b n_terms - 1 planes deep -- as much as the local mesh holds (one agglomerate = two cell layers per neighbour: two terms).
+    // b n_terms - 1 planes deep -- as much as the local mesh holds (one agglomerate = two cell layers of a lower neighbour: two
+    // terms; two agglomerates, BoxPartition(low_ghost_cells=4): three).
+    ASSERT_THROW(n_terms <= handle.comm.sweep_terms(), "internal: more terms per sweep than the ranks hold ghost planes for");
     handle.rhs_ghosts_wanted = true;
-    HaloSpace deep = handle.comm.spaces[1];
-    deep.width = n_terms;
-    handle.exchange_on(deep, const_cast<double *>(x.get_values()), handle.stream, handle.stream, false);
-    ASSERT_THROW(n_terms <= 2, "internal: the right-hand side is exchanged one plane deep");
-    handle.need_rhs_ghosts(b.get_values());
+    handle.rhs_ghost_width = std::max(handle.rhs_ghost_width, n_terms - 1);
+    handle.exchange_on(handle.fine_space(n_terms), const_cast<double *>(x.get_values()), handle.stream, handle.stream, false);
+    handle.need_rhs_ghosts(b.get_values(), n_terms - 1);
   }
   op->smoother_sweep(n_terms, alpha, beta, b.get_values(), x.get_values(), out.get_values(), out_prev ? out_prev->get_values() : nullptr);
   return true;
@@ -1595,8 +1596,8 @@ HipHierarchyHelpers<VectorType>::build_restrictor(Communicator, std::shared_ptr<
     {
       const bool low = comm.ghost_lo[d] > 0, high = comm.ghost_hi[d] > 0;
       ASSERT_THROW((!low && !high) || opts.agglomerate[d] == 2, "distributed runs need agglomerates of 2 cells along a split axis");
-      const int64_t own0 = low ? 1 : 0; // (2 ghost cell layers = one agglomerate)
-      const int64_t own_n = _grid_hint.dims[d] - own0 - (high ? 1 : 0);
+      const int64_t own0 = comm.ghost_lo[d] / 2; // (2 ghost cell layers = one agglomerate; two of them with deep low ghosts)
+      const int64_t own_n = _grid_hint.dims[d] - own0 - comm.ghost_hi[d] / 2;
       const int64_t g0 = (int64_t)comm.coord[d] * own_n - own0, gn = (int64_t)comm.grid[d] * own_n;
       if (d == 2)
       {

@@ -693,6 +693,9 @@ bool MatrixFreeLaplaceDevice<T>::fused_sweep_available(int n_terms) const
 {
   if (!(_dim == 3 && _compact && _affine_ids && !_tail && n_terms >= 1 && n_terms <= 3 && _halo >= n_terms && (uint64_t)_rec.size() <= 0xffffffffull))
     return false;
+  // distributed: the ranks exchange x once per sweep, n_terms planes deep -- all of them or none (what every rank can do)
+  if (_handle.comm.enabled() && n_terms > _handle.comm.sweep_terms())
+    return false;
   // a side with ghost planes (a neighbouring rank) must hold n_terms of them: the sweep computes them redundantly
   for (int d = 0; d < 3; ++d)
     if ((_affine.ghost_lo[d] > 0 && _affine.ghost_lo[d] < n_terms) || (_affine.ghost_hi[d] > 0 && _affine.ghost_hi[d] < n_terms))

@@ -883,8 +883,8 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   // serves the kernels that run one polynomial term per launch; the multi-term sweep (mf_cheb_fused.hip) needs as many halo lanes
   // as it runs terms, and then every chunk owns the same number of columns (no tail slab: 257 columns = 5 chunks of 52).
   // The slab operator and eight coefficients per cell keep the one-lane geometry (their smoother runs term by term).
-  // (a distributed rank holds two ghost planes per neighbour: at most two terms per sweep)
-  _halo = (sub_mesh || !_compact) ? 1 : std::min(std::max(handle.mf_fused_terms, 1), handle.comm.enabled() ? 2 : 3);
+  // (a distributed rank holds two ghost planes of a lower neighbour, or four: at most two resp. three terms per sweep)
+  _halo = (sub_mesh || !_compact) ? 1 : std::min(std::max(handle.mf_fused_terms, 1), handle.comm.enabled() ? handle.comm.sweep_terms() : 3);
   if (_halo == 1)
   {
     _own = 62;

@@ -27,7 +27,14 @@ class BoxPartition:
     agglomerate (2 cell layers) of each face neighbour, numbered lexicographically; interface planes belong to the upper
     box, the last box of an axis also owns the top plane.  (1, 1, n) are the slabs along z."""
 
-    def __init__(self, cells: Sequence[int], rank: int, grid: Sequence[int], length: Sequence[float] | float = 1.0):
+    def __init__(self, cells: Sequence[int], rank: int, grid: Sequence[int], length: Sequence[float] | float = 1.0,
+                 low_ghost_cells: int = 2):
+        """low_ghost_cells = 4: TWO agglomerates of every lower neighbour.  The interface plane belongs to the upper box, so a
+        box holds three ghost node planes above it but only low_ghost_cells below; with four the whole Chebyshev(3) smoother of
+        a rank is one sweep (mf_cheb_fused.hip: K terms need K ghost planes on every side with a neighbour) and x travels once
+        per smoother, three planes deep."""
+        assert low_ghost_cells in (2, 4)
+        self.low_ghost_cells = int(low_ghost_cells)
         self.cells = tuple(int(c) for c in cells)
         self.grid = tuple(int(g) for g in grid)
         assert len(self.cells) == 3 and len(self.grid) == 3
@@ -40,7 +47,7 @@ class BoxPartition:
                 raise ValueError("the cell layers must split into whole agglomerate layers per rank")
         self.per = tuple(self.cells[d] // self.grid[d] for d in range(3))
         self.c0 = tuple(self.coord[d] * self.per[d] for d in range(3))
-        self.ghost_lo = tuple(2 if self.coord[d] > 0 else 0 for d in range(3))
+        self.ghost_lo = tuple(self.low_ghost_cells if self.coord[d] > 0 else 0 for d in range(3))
         self.ghost_hi = tuple(2 if self.coord[d] + 1 < self.grid[d] else 0 for d in range(3))
         self.local_cells = tuple(self.per[d] + self.ghost_lo[d] + self.ghost_hi[d] for d in range(3))
         self.offset = tuple(self.c0[d] - self.ghost_lo[d] for d in range(3))     # global index of local cell / node 0
@@ -143,8 +150,8 @@ class BoxPartition:
 class SlabPartition(BoxPartition):
     """Owned cell layers [z0, z1) of rank `rank` out of `n_ranks` for a global mesh of `cells`: the grid 1 x 1 x n_ranks."""
 
-    def __init__(self, cells: Sequence[int], rank: int, n_ranks: int, length: Sequence[float] | float = 1.0):
-        super().__init__(cells, rank, (1, 1, int(n_ranks)), length)
+    def __init__(self, cells: Sequence[int], rank: int, n_ranks: int, length: Sequence[float] | float = 1.0, low_ghost_cells: int = 2):
+        super().__init__(cells, rank, (1, 1, int(n_ranks)), length, low_ghost_cells)
 
 
 def box_grid(n_ranks: int) -> tuple:
@@ -208,6 +215,8 @@ class HaloTransport:
         else:
             check(self._lib.mfmg_hip_context_set_communicator(ctx.handle, self.rank, self.n_ranks, part.ghost_low,
                                                               part.ghost_high))
+        if part.low_ghost_cells != 2:
+            check(self._lib.mfmg_hip_context_set_low_ghost_cells(ctx.handle, part.low_ghost_cells))
         if transport == "rccl":
             # can EVERY rank reach RCCL?  The probe resolves the library and its entry points only (no RCCL call, no
             # bootstrap thread); the decision is a MIN all-reduce over the ranks, so that no rank enters the gloo branch

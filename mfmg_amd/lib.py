@@ -130,6 +130,7 @@ def load() -> C.CDLL:
         "mfmg_hip_context_set_stored_diagonal": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_mf_laplace_diagonal_in_record": (C.c_int, [vp, P(C.c_int)]),
         "mfmg_hip_context_set_mf_fused_terms": (C.c_int, [vp, C.c_int]),
+        "mfmg_hip_context_set_low_ghost_cells": (C.c_int, [vp, C.c_int32]),
         "mfmg_hip_context_set_mf_shell": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_context_set_mf_emulate_split": (C.c_int, [vp, C.c_int]),
         "mfmg_hip_mf_laplace_sweep_available": (C.c_int, [vp, C.c_int, P(C.c_int)]),

@@ -8,8 +8,12 @@ stream fork and join, the all-gather of the gathered level and its replicated wo
 other ranks idle meanwhile.  The same cycle on one rank of the same mesh size is timed beside it.
 
 usage: rank_cycle_on_one_gpu.py [cells_per_rank] [gx,gy,gz] [rank]        (default 128 2,2,2 0)
-       env TRACE=1: only the timed rank's cycles run after the marker (for rocprofv3 --kernel-trace)"""
+       env TRACE=1: only the timed rank's cycles run after the marker (for rocprofv3 --kernel-trace)
+           LOW_GHOST=2|4: ghost cell layers towards a lower neighbour (4, the bench's default: the whole smoother one sweep)"""
 import os, sys, threading, time, json
+# eight ranks as threads of one process: with the default OpenMP team per rank (16 threads each, spinning between parallel
+# regions) the launching threads starve -- 4.2 ms per cycle where the same run with two threads per rank shows 2.0
+os.environ.setdefault("OMP_NUM_THREADS", "2")
 import numpy as np
 import torch
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -88,7 +92,7 @@ ready = threading.Barrier(n_ranks, timeout=3600)
 def worker(rank):
     try:
         torch.cuda.set_device(0)
-        part = M.BoxPartition(cells, rank, grid, length=length)
+        part = M.BoxPartition(cells, rank, grid, length=length, low_ghost_cells=int(os.environ.get("LOW_GHOST", "4")))
         ctx = M.Context()
         tr = M.HaloTransport(ctx, part, callbacks=mb.callbacks(rank))
         t0 = time.perf_counter()
@@ -134,7 +138,7 @@ def worker(rank):
                            "overlapped_per_cycle": (tr.n_overlapped() - o0) / n_cyc,
                            "mb_sent_per_cycle": (tr.exchange_volume() - v0) * 8e-6 / n_cyc, "setup_seconds_in_threads": setup_s,
                            "gathered_from_rows": h.coarse_amg_gather_rows(), "levels": h.coarse_amg_shapes(),
-                           "smoother_sweep_terms": list(h.smoother_sweep_terms()), "rccl_loopback_us_per_group": loopback_us})
+                           "smoother_sweep_terms": list(h.smoother_sweep_terms()), "low_ghost_cells": part.low_ghost_cells, "rccl_loopback_us_per_group": loopback_us})
             # ... and with a price on the wire: every grouped send/recv and collective holds its stream that long
             with_delay = {}
             for d_us in delays:

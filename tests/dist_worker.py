@@ -178,7 +178,7 @@ def mode_cpu_box(args):
     grid = parse_grid(args.grid, world)
     cells = tuple(8 * g if g > 1 else 6 for g in grid)
     material = "linear"
-    part = M.BoxPartition(cells, rank, grid, length=tuple(c / 8.0 for c in cells))
+    part = M.BoxPartition(cells, rank, grid, length=tuple(c / 8.0 for c in cells), low_ghost_cells=args.low_ghost)
     mesh = O.StructuredMesh(cells)
     mesh.h = part.h
     gprob = M.LaplaceProblem(cells, material, cell_size=part.h)
@@ -467,7 +467,7 @@ def mode_gpu(args):
     per, (cx, cy), material, amg = MESHES[args.mesh]
     # (cx, cy): cells per rank along x and y, `per` along z
     cells = (cx * grid[0], cy * grid[1], per * grid[2])
-    part = M.BoxPartition(cells, rank, grid, length=tuple(c / float(cells[0]) for c in cells))   # cubic cells
+    part = M.BoxPartition(cells, rank, grid, length=tuple(c / float(cells[0]) for c in cells), low_ghost_cells=args.low_ghost)   # cubic cells
     box = part.split_xy
     params = dict(PRM)
     params.update({"smoother": {"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0},
@@ -481,7 +481,9 @@ def mode_gpu(args):
     assert 1.4 < lmax < 2.2, lmax
     # one coefficient per cell: the first two Chebyshev terms run as ONE sweep (x exchanged two ghost planes deep once, the
     # ghost DoFs computed redundantly), the third as a launch of its own; eight coefficients per cell: a launch per term
-    assert h.smoother_sweep_terms() == ((2, 0) if material == "constant" else (0, 0)), h.smoother_sweep_terms()
+    # (with two agglomerates of every lower neighbour in the local mesh, --low-ghost 4, the whole Chebyshev(3) smoother of the
+    # cycle is one sweep: x three planes deep, b two; an in-place call keeps the last term as a launch of its own)
+    assert h.smoother_sweep_terms() == ((2, 3 if args.low_ghost == 4 else 0) if material == "constant" else (0, 0)), h.smoother_sweep_terms()
     # the halo spaces of the levels belong to this hierarchy: a second one on the same communicator context is refused
     # while it lives (every rank raises before any collective of the second setup)
     try:
@@ -638,6 +640,7 @@ if __name__ == "__main__":
     ap.add_argument("--mesh", default="small")
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--grid", default="", help="ranks along x, y, z as 2x2x1 (default: slabs, 1x1xworld)")
+    ap.add_argument("--low-ghost", type=int, default=2, help="ghost cell layers towards a lower neighbour: 2 or 4 (BoxPartition)")
     a = ap.parse_args()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if a.backend == "nccl":

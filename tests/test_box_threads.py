@@ -51,9 +51,12 @@ class Mailboxes:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("material,amg", [("linear", {"coarsest_size": 40, "replicate_rows": 40, "pre_smoothing_levels": 0}),
-                                          ("constant", {"coarsest_size": 300})])
-def test_box_2x2x2_eight_ranks_in_one_process(mfmg_lib, material, amg):
+@pytest.mark.parametrize("material,amg,low_ghost", [("linear", {"coarsest_size": 40, "replicate_rows": 40, "pre_smoothing_levels": 0}, 2),
+                                                    ("constant", {"coarsest_size": 300}, 2),
+                                                    ("constant", {"coarsest_size": 40, "replicate_rows": 40, "pre_smoothing_levels": 0}, 4)])
+def test_box_2x2x2_eight_ranks_in_one_process(mfmg_lib, material, amg, low_ghost):
+    """low_ghost = 4: two agglomerates of every lower neighbour in the local mesh -- the Chebyshev(3) smoother of every rank is
+    one sweep with one exchange of x, three ghost planes deep (asserted below)."""
     grid, per = (2, 2, 2), 24 if "replicate_rows" in amg else 16
     cells = tuple(per * g for g in grid)
     length = tuple(c / float(cells[0]) for c in cells)
@@ -87,13 +90,15 @@ def test_box_2x2x2_eight_ranks_in_one_process(mfmg_lib, material, amg):
     def worker(rank):
         try:
             torch.cuda.set_device(0)
-            part = M.BoxPartition(cells, rank, grid, length=length)
+            part = M.BoxPartition(cells, rank, grid, length=length, low_ghost_cells=low_ghost)
             ctx = M.Context()
             tr = M.HaloTransport(ctx, part, callbacks=mb.callbacks(rank))
             assert tr.name() == "host" and tr.selftest(1024) == 0.0
             h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", part.local_problem(material, "cuda"), params)
             _, lmin, lmax = h.smoother_info()
             assert abs(lmax - glmax) < 1e-9 * glmax and abs(lmin - glmin) < 1e-9 * glmax
+            if material == "constant":
+                assert h.smoother_sweep_terms() == (2, 3 if low_ghost == 4 else 0), h.smoother_sweep_terms()
             own_l, own_g, loc_g = (t.numpy() for t in tr.space_index(1))
             x = torch.from_numpy(x0g[loc_g]).cuda()
             # ghosts must come from the exchanges
@@ -136,7 +141,8 @@ def test_box_2x2x2_eight_ranks_in_one_process(mfmg_lib, material, amg):
     if "replicate_rows" in amg:
         # two aggregation levels stayed distributed along all three axes (spaces: local, fine, A_c, two levels), the third was
         # gathered through the permutation of the rank-ordered blocks
-        assert info[0][1] == 5 and 0 < info[0][2] < hg.level_size(1)
+        # (+ the two-planes-deep fine space of the one-pass residual restriction where the material lets it run)
+        assert info[0][1] == (6 if material == "constant" else 5) and 0 < info[0][2] < hg.level_size(1)
     # the oracle's restatement of the cycle, built from the single-process level matrices
     mesh = O.StructuredMesh(cells)
     mesh.h = h_cell

@@ -20,10 +20,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(mode, world, timeout=600, mesh="small", backend="gloo", grid=""):
+def _run(mode, world, timeout=600, mesh="small", backend="gloo", grid="", low_ghost=2):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--mesh", mesh, "--backend", backend, "--grid", grid]
+           os.path.join(ROOT, "tests", "dist_worker.py"), "--mode", mode, "--mesh", mesh, "--backend", backend, "--grid", grid,
+           "--low-ghost", str(low_ghost)]
     env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     if res.returncode != 0:
@@ -71,6 +72,19 @@ def test_box_partition_geometry(mfmg_lib):
         assert (flags[own] != 2).all() and (flags[~own] != 0).all()
         assert np.array_equal(p.local_global_index().numpy()[p.owned_local_index().numpy()], p.owned_global_index().numpy())
     assert (covered == 1).all()
+    # two agglomerates of every lower neighbour (low_ghost_cells=4: three ghost node planes on either side of a box, what a
+    # sweep of three smoother terms needs): the same owners, deeper ghosts below
+    covered[:] = 0
+    for r in range(8):
+        p = M.BoxPartition(cells, r, grid, low_ghost_cells=4)
+        covered[p.owned_global_index().numpy()] += 1
+        for d in range(3):
+            assert p.ghost_lo[d] == (4 if p.coord[d] > 0 else 0) and p.ghost_hi[d] == (2 if p.coord[d] == 0 else 0)
+            assert p.own0[d] == p.ghost_lo[d] and p.local_nodes[d] - p.own0[d] - p.own_n[d] == (3 if p.coord[d] == 0 else 0)
+        flags = p.local_problem("constant").constrained.numpy()
+        own = np.zeros(p.n_local_dofs, bool); own[p.owned_local_index().numpy()] = True
+        assert (flags[own] != 2).all() and (flags[~own] != 0).all()
+    assert (covered == 1).all()
     assert M.box_grid(2) == (1, 1, 2) and M.box_grid(4) == (1, 2, 2) and M.box_grid(8) == (2, 2, 2) and M.box_grid(3) == (1, 1, 3)
     with pytest.raises(ValueError):
         M.BoxPartition((10, 8, 8), 0, (2, 1, 1))
@@ -82,10 +96,11 @@ def test_box_partition_geometry(mfmg_lib):
     assert slab.exchange_doubles() / box.exchange_doubles() > 2.6
 
 
-@pytest.mark.parametrize("world,grid", [(2, "2x1x1"), (4, "2x2x1"), (4, "1x2x2"), (8, "2x2x2")])
-def test_box_construction_cpu_gloo(mfmg_lib, world, grid):
-    """Box partition: host setup on the local boxes + the all-neighbours exchange restated in numpy over gloo."""
-    assert "cpu box checks passed" in _run("cpu_box", world, grid=grid)
+@pytest.mark.parametrize("world,grid,low_ghost", [(2, "2x1x1", 2), (4, "2x2x1", 2), (4, "1x2x2", 2), (8, "2x2x2", 2), (2, "1x1x2", 4), (8, "2x2x2", 4)])
+def test_box_construction_cpu_gloo(mfmg_lib, world, grid, low_ghost):
+    """Box partition (SURVEY.md 8e): host setup on the local boxes + the all-neighbours exchange restated in numpy over gloo;
+    with one and with two agglomerates of the lower neighbours in the local mesh."""
+    assert "cpu box checks passed" in _run("cpu_box", world, grid=grid, low_ghost=low_ghost)
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -105,6 +120,15 @@ def test_distributed_setup_protocol_cpu_gloo(mfmg_lib, world):
 @pytest.mark.parametrize("world,mesh", [(2, "small"), (3, "small"), (2, "wide"), (2, "deep"), (4, "deep"), (2, "deep01")])
 def test_distributed_library_path_shared_gpu(mfmg_lib, world, mesh):
     assert "gpu distributed checks passed" in _run("gpu", world, mesh=mesh)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,grid,mesh", [(2, "1x1x2", "cube11"), (4, "2x1x2", "cube11"), (4, "2x2x1", "boxwide"), (4, "1x2x2", "cube")])
+def test_box_decomposition_with_two_ghost_agglomerates_below_shared_gpu(mfmg_lib, world, grid, mesh):
+    """BoxPartition(low_ghost_cells=4): the local mesh holds two agglomerates of every lower neighbour, so that the whole
+    Chebyshev(3) smoother of a rank is ONE sweep (x exchanged once, three ghost planes deep; asserted in the worker for the
+    constant material) -- every operator of the cycle and the 20-cycle history as in the test below."""
+    assert "gpu distributed checks passed; grid " + grid in _run("gpu", world, mesh=mesh, grid=grid, timeout=900, low_ghost=4)
 
 
 @pytest.mark.gpu
