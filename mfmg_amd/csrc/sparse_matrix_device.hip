@@ -1440,62 +1440,6 @@ void SparseMatrixDevice<T>::choose_layouts(bool analyse)
                  std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
 }
 
-// The regular nodes of a 3-D stencil operator, lexicographic, re-ordered for the eight L2 caches of the chip.  Workgroups are
-// dealt round-robin to the XCDs (block b -> XCD b % 8), and a block of the class kernel takes 256 consecutive list entries
-// (two node rows of a 128-wide level): in list order the XCD that works on a row is not the one that worked on the rows
-// below and above it in the previous node layer, so every XCD fetches all nine rows of x a row needs from the fabric (PMC,
-// profiles/r03_e: 71 L2 misses of 128 B per wavefront = the nine rows; 345 MB fetched where x, b, D^-1 are 100).  Here the
-// node rows of every layer are cut into eight strips and XCD s is handed strip s of layer after layer: its rows of x stay
-// in ITS L2 from one layer to the next, and all XCDs still move through the layers together.  `slot0` = list entries in
-// front of the regular class (earlier classes: they decide which XCD the first regular block lands on).  The sums of a node
-// do not depend on the order of the list.  MFMG_XCD_STRIPS=0: lexicographic.
-inline void xcd_strip_order(std::vector<int32_t> &nodes, std::vector<int32_t> const &offs, int64_t n_nodes, int64_t slot0)
-{
-  static const bool off = std::getenv("MFMG_XCD_STRIPS") && std::string(std::getenv("MFMG_XCD_STRIPS")) == "0";
-  if (off || offs.size() != 27 || nodes.size() < 8 * 4096)
-    return;
-  // 27 block diagonals of a lexicographic nx x ny x nz grid: -nxy - nx - 1 ... nxy + nx + 1 (ascending)
-  const int64_t nx = offs[16], nxy = offs[22];
-  if (nx < 8 || nxy % nx != 0 || n_nodes % nxy != 0 || offs[13] != 0 || offs[14] != 1 || offs[15] != nx - 1 || offs[17] != nx + 1 ||
-      offs[26] != nxy + nx + 1)
-    return;
-  const int64_t ny = nxy / nx;
-  if (ny < 16)
-    return;
-  std::vector<std::vector<int32_t>> strip(8);
-  for (int32_t nd : nodes)
-    strip[(size_t)(((int64_t)nd / nx) % ny * 8 / ny)].push_back(nd);
-  size_t at[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  std::vector<int32_t> out;
-  out.reserve(nodes.size());
-  while (out.size() < nodes.size())
-  {
-    // (a workgroup of the class kernel = 256 consecutive slots of the whole list)
-    const int64_t pos = slot0 + (int64_t)out.size(), block = pos / 256;
-    size_t want = std::min<size_t>((size_t)(256 - pos % 256), nodes.size() - out.size());
-    int s = (int)(block % 8);
-    while (want > 0)
-    {
-      if (at[s] == strip[s].size())
-      {
-        // this strip is used up: the one with the most nodes left lends a block
-        size_t best = 0;
-        for (int q = 0; q < 8; ++q)
-          if (strip[q].size() - at[q] > best)
-          {
-            best = strip[q].size() - at[q];
-            s = q;
-          }
-      }
-      const size_t take = std::min(want, strip[s].size() - at[s]);
-      out.insert(out.end(), strip[s].begin() + at[s], strip[s].begin() + at[s] + take);
-      at[s] += take;
-      want -= take;
-    }
-  }
-  nodes.swap(out);
-}
-
 template <typename T>
 void SparseMatrixDevice<T>::build_block_diagonals()
 {
@@ -1763,22 +1707,17 @@ void SparseMatrixDevice<T>::build_block_diagonals()
       if (n_classes > 0 && n_classes < kMaxClasses && n_nodes <= regular_as_class_nodes && n_regular > 0)
       {
         cls_table.insert(cls_table.end(), table.begin(), table.end());
-        std::vector<int32_t> regular_nodes;
+        int64_t q = 0;
         for (int64_t nd = 0; nd < n_nodes; ++nd)
           if (!exc[nd * c])
           {
-            regular_nodes.push_back((int32_t)nd);
+            if (q++ % 64 == 0)
+              cls_of_wave.push_back(n_classes);
+            cls_nodes.push_back((int32_t)nd);
             classed[nd] = 1;
             for (int rc = 0; rc < c; ++rc)
               exc[nd * c + rc] = 1;
           }
-        xcd_strip_order(regular_nodes, best_offs, n_nodes, (int64_t)cls_nodes.size());
-        for (size_t q = 0; q < regular_nodes.size(); ++q)
-        {
-          if (q % 64 == 0)
-            cls_of_wave.push_back(n_classes);
-          cls_nodes.push_back(regular_nodes[q]);
-        }
         while (cls_nodes.size() % 64 != 0)
           cls_nodes.push_back(-1);
         ++n_classes;
