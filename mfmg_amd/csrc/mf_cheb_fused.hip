@@ -63,7 +63,7 @@ struct MfFusedArgs
   T alpha[3], beta[3];
   AffineIds aff;
   unsigned int vec_bytes, rec_total_bytes; // extents of the vectors / of the record array (descriptors; at most 2^32 - 1)
-  // narrow last chunk column (<= 32 - 2 halo owned columns): its tiles come last in the tile list and take TWO y-tiles each, one
+  // narrow last chunk column (<= 32 - halo owned columns): its tiles come last in the tile list and take TWO y-tiles each, one
   // per half of the wavefront (wide_tiles = tiles of the other columns; ntiles_y2 = ceil(ntiles_y / 2); 0: no such tiles)
   unsigned int wide_tiles, ntiles_y2;
 };
@@ -160,7 +160,9 @@ struct BufIO<float>
 // DBG (timing experiments only, wrong results): 1 = no barrier, 2 = no division, 3 = no global stores
 // NARROW: the tile of a narrow last chunk column.  Lanes 0-31 work on y-tile 2 t, lanes 32-63 on y-tile 2 t + 1 of the same
 // 32 columns: everything that depends on the y-tile (row numbers, row masks, the row part of an address) is per lane instead of
-// per wavefront; the halves exchange nothing (their edge lanes are halo lanes of either), owner computes as everywhere.
+// per wavefront; the halves exchange nothing (lane 0 of a half is a halo lane; its last lane is at most the last column of the mesh,
+// whose cell is a phantom with coefficient zero: what arrives there from the other half is multiplied by it), owner computes as
+// everywhere.
 template <typename T, int K, int TY, bool DREC, bool MODES, int DBG = 0, bool NARROW = false>
 __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsigned int w)
 {

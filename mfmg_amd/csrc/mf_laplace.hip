@@ -894,12 +894,15 @@ MatrixFreeLaplaceDevice<T>::MatrixFreeLaplaceDevice(HipHandle &handle, mfmg_hip_
   {
     _ncols = (_N[0] + (64 - 2 * _halo) - 1) / (64 - 2 * _halo);
     _own = (_N[0] + _ncols - 1) / _ncols;
-    // ... unless full chunks leave a last one of at most 32 - 2 halo columns (257 = 4 x 58 + 25): the sweep runs that column
-    // two y-tiles per workgroup (NARROW in mf_cheb_fused.hip), 4.5 columns of tiles instead of 5
+    // ... unless full chunks leave a last one of at most 32 - halo columns (257 = 4 x 58 + 25; the 259 / 261 columns of a rank's
+    // local mesh: + 27 / 29): the sweep runs that column two y-tiles per workgroup, one per half of the wavefront (NARROW in
+    // mf_cheb_fused.hip), 4.5 columns of tiles instead of 5.  The column ends at the high face of the mesh: a half needs the halo
+    // lanes below its owned columns only (the lane above the last one belongs to the other half: it enters through a phantom cell,
+    // coefficient zero).
     const int full = 64 - 2 * _halo, rest = _N[0] - (_ncols - 1) * full;
     static const bool narrow_off = std::getenv("MFMG_MF_NARROW") && std::string(std::getenv("MFMG_MF_NARROW")) == "0";
     // (FP64 only: the FP32 sweep was slower with it, 1.08 against 1.02 ms per cycle at 257^3 -- one round of long tiles hides less)
-    if (_ncols >= 2 && rest >= 1 && rest <= 32 - 2 * _halo && !narrow_off && sizeof(T) == 8)
+    if (_ncols >= 2 && rest >= 1 && rest <= 32 - _halo && !narrow_off && sizeof(T) == 8)
     {
       _own = full;
       _narrow_last = true;

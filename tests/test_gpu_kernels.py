@@ -359,7 +359,7 @@ SWEEP_COEFS = [(0.0, 0.61), (0.23, 0.87), (0.31, 0.79)]     # (alpha, beta) of t
 
 
 @pytest.mark.parametrize("n,material", [((6, 5, 7), "constant"), ((20, 17, 9), "cellwise"), ((70, 30, 20), "constant"),
-                                        ((130, 40, 33), "cellwise")])
+                                        ((130, 40, 33), "cellwise"), ((86, 19, 11), "cellwise")])   # (87 = 58 + 29 columns: the widest narrow last chunk)
 @pytest.mark.parametrize("n_terms", [2, 3])
 @pytest.mark.parametrize("tile", [None, (4, 3, 8), (8, 3, 5), (2, 4, 7), (8, 2, 64), (1, 4, 3)])
 def test_smoother_sweep_equals_term_by_term_bit_for_bit(ctx, n, material, n_terms, tile):
