@@ -336,7 +336,9 @@ void HipSolver::setup_amg_on_device(std::shared_ptr<SparseMatrixDevice<double>> 
     // ... and only where the level operator repeats its stencils (a variable coefficient stores P~ entry by entry: 1 % of the cycle
     // for 1.5 s of setup)
     const bool large = level == 0 && g.reach == 1 && n_f >= large_rows && n_f <= (int64_t(1) << 23) && a_op->get_matrix()->stencil_classes() > 0;
-    const bool pays = distributed || n_f <= 16384 || large || (one_rank_on && n_f >= 262144);
+    // (MFMG_AMG_SMOOTHED_DISTRIBUTED=0: a distributed run decides like one rank -- measurement switch)
+    static const bool distributed_all = !(std::getenv("MFMG_AMG_SMOOTHED_DISTRIBUTED") && std::string(std::getenv("MFMG_AMG_SMOOTHED_DISTRIBUTED")) == "0");
+    const bool pays = (distributed && distributed_all) || n_f <= 16384 || large || (one_rank_on && n_f >= 262144);
     if (smoothed_env && pays && level >= _amg_pre_smoothing_levels && L.smoother->coefficients().size() == 1 && !h.setup_values_float &&
         this->_params->get("solver.amg.smoothed_prolongation", true))
     {
