@@ -827,37 +827,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, M, h, prob, lmin, lmax, torch)
         if world == 1 and not args.no_extras:
             try:
-                if not assembled:
-                    # what the PARTITION of a distributed run costs a rank by itself, measured here on one GPU: the fine operator
-                    # applied with the launches of a rank that has a neighbour along z (the grid at 2 ranks), y and z (4), x, y and
-                    # z (8) -- interior tiles, the shell around them beside them on the exchange stream -- and no exchange
-                    # (Context.set_mf_emulate_split; same bits as the single launch).  The smoother of a distributed run goes term by
-                    # term, so this leg builds its hierarchy with `smoother.fused_terms 1` and the one-halo-lane records.
-                    emu = {"what": "the headline cycle, smoother term by term (the cycle of a distributed rank), with the fine operator applied "
-                                   "as a rank of 1x1x2 / 1x2x2 / 2x2x2 would (interior tiles + one shell launch beside them, no exchange, "
-                                   "nothing on the wire): ms per cycle on this GPU"}
-                    p1 = json.loads(json.dumps(params))
-                    p1["smoother"]["fused_terms"] = 1
-                    ctx.set_mf_fused_terms(1)
-                    try:
-                        h1 = M.Hierarchy(ctx, evaluator, prob, p1)
-                    finally:
-                        ctx.set_mf_fused_terms(3)
-                    try:
-                        for grid_name in (None, "z", "yz", "xyz"):
-                            ctx.set_mf_emulate_split(grid_name)
-                            for _ in range(3):
-                                h1.apply(b, x)
-                            torch.cuda.synchronize()
-                            t_e = time.perf_counter()
-                            for _ in range(10):
-                                h1.apply(b, x)
-                            torch.cuda.synchronize()
-                            emu[{None: "unsplit", "z": "1x1x2", "yz": "1x2x2", "xyz": "2x2x2"}[grid_name]] = (time.perf_counter() - t_e) / 10 * 1e3
-                    finally:
-                        ctx.set_mf_emulate_split(None)
-                    del h1
-                    out["distributed_launch_structure_on_one_gpu"] = emu
+                # (what the partition of a distributed run costs a rank is measured by scratch/rank_cycle_on_one_gpu.py -- eight ranks as
+                # threads, one of them timed alone behind the reflecting transport: DESIGN.md 7, profiles/r04_h -- not here: the leg of
+                # round 3 that emulated the launch structure of a term-by-term smoother no longer describes a rank, whose whole
+                # Chebyshev(3) smoother is one sweep)
                 if with_f32:
                     out["vcycle_fp32_fine_level_config5"] = measure_vcycle_f32(ctx, torch, M, h, prob,
                                                                               lambda: M.MatrixFreeLaplace(ctx, prob))
