@@ -491,12 +491,18 @@ def cpu_baseline(args, M, h, prob, lmin, lmax, torch):
 
 def main():
     args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and os.environ.get("OMP_NUM_THREADS") in (None, "", "1"):
+        # torch.distributed.run gives every worker ONE OpenMP thread; the host parts of the setup (sorting, class detection, CSR
+        # assembly) are parallel: a share of the node's cores per rank, never more than there are (spinning teams of eight ranks on
+        # too few cores starve the threads that launch kernels: scratch/rank_cycle_on_one_gpu.py), and idle teams sleep
+        os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, (os.cpu_count() or world) // world)))
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU")
     backend = os.environ.get("MFMG_BENCH_BACKEND", "nccl")   # "gloo": rehearsal with ranks sharing a card
