@@ -218,6 +218,41 @@ def measure_vcycle_small(ctx, torch, M, cells, params, steps=10, warmup=3, mater
             "device_memory_inventory_GB": {line[14:].strip(): float(line[:10]) for line in M.memory_inventory().splitlines() if line.strip()}}
 
 
+def measure_cg_solve(ctx, torch, M, cells, params, reduction=1e-8, material="constant"):
+    """The reference's driver workflow (tests/hierarchy_driver.cc:103-116): dealii::SolverCG on the fine operator with the
+    hierarchy as preconditioner ("is preconditioner" true: every application starts from x = 0; the coarse cycle must be the
+    symmetric V(1,1)).  Right-hand side: A times a random vector (a known solution), start x = 0, stopped at `reduction` of the
+    initial residual (SolverControl takes the absolute norm).  Wall clock of the whole solve, one call through the C ABI."""
+    prob = M.LaplaceProblem((cells,) * 3, material, device="cuda")
+    p = json.loads(json.dumps(params))
+    p["is preconditioner"] = True
+    p["solver"].get("amg", {}).pop("pre_smoothing_levels", None)
+    h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, p)
+    n = h.level_size(0)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    free = (prob.constrained != 1).to(torch.float64)
+    x_true = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * free
+    b = torch.empty_like(x_true)
+    h.operator_apply(0, x_true, b)
+    b *= free
+    r0 = ctx.l2_norm(b)
+    out = None
+    for attempt in range(2):            # (the first solve warms the launches up; the second is timed)
+        x = torch.zeros_like(b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        its, hist = h.solve_cg(b, x, tolerance=reduction * r0, max_iterations=200)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        err = float((x - x_true).abs().max() / x_true.abs().max())
+        out = {"workload": f"{cells}^3 cells = {cells + 1}^3 DoFs, matrix-free, material {material}: CG preconditioned by one V-cycle "
+                           f"(Chebyshev(3), symmetric V(1,1) coarse cycle), x0 = 0, stopped at ||r|| <= {reduction:g} ||r0||",
+               "n_dofs": n, "iterations": int(its), "ms_total": dt * 1e3, "ms_per_iteration": dt * 1e3 / max(int(its), 1),
+               "value": n / dt, "unit": "DoF/s solved to the tolerance", "residual_reduction": float(hist[-1] / hist[0]),
+               "max_rel_error_vs_known_solution": err}
+    return out
+
+
 def measure_vcycle_f32(ctx, torch, M, h, prob, op_monitor_factory, steps=10, warmup=3):
     """BASELINE.json configs[4] (FP32) as a whole cycle: the fine level (smoother, residual) in FP32 through the FP32
     instance of the operator kernel, restriction / coarse solve / prolongation in FP64 (`Hierarchy.apply_f32`, the
@@ -859,6 +894,11 @@ def main():
                     p11 = json.loads(json.dumps(params))
                     p11["solver"]["amg"].pop("pre_smoothing_levels", None)
                     out["vcycle_256cubed_coarse_cycle_v11"] = measure_vcycle_small(ctx, torch, M, args.cells, p11)
+                    # ... and what the reference's driver does with it: a CG solve preconditioned by that cycle
+                    try:
+                        out["cg_solve_256cubed"] = measure_cg_solve(ctx, torch, M, args.cells, params)
+                    except Exception as e:  # noqa: BLE001 - an extra leg: reported, never fatal for the headline
+                        out["cg_solve_256cubed"] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 out["smoother_apply_256cubed_f32_config5"] = measure_smoother_f32(ctx, torch, M, 256, args.degree)
                 out["cell_contraction_256cubed_config5"] = measure_cell_contraction(ctx, torch, 256)
                 if not assembled:
