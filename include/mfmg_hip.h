@@ -325,7 +325,10 @@ int mfmg_hip_mf_laplace_smoother_step(mfmg_hip_mf_laplace_t op, const double *b,
  * - beta[s-1] dinv (A x_{s-1} - b); out = x_{n_terms}, out_prev (may be NULL) = x_{n_terms - 1}.  Bit for bit what n_terms calls
  * of mfmg_hip_mf_laplace_smoother_step return.  alpha[0] must be 0; x, out and out_prev must be different vectors.
  * MFMG_HIP_ERROR_NOT_IMPLEMENTED when the operator cannot run it (mfmg_hip_mf_laplace_sweep_available: cell-constant layout,
- * a numbering the kernel can compute, at least n_terms halo columns, one rank). */
+ * a numbering the kernel can compute, at least n_terms halo columns, one rank).
+ * x == NULL: the sweep from x_0 = 0, which is then not read and whose first term needs no operator application (x_1 = beta[0] dinv b:
+ * the pre-smoother of a preconditioner application, include/mfmg/common/hierarchy.hpp:253-259) -- three terms, default arithmetic;
+ * the result of the sweep run on a zeroed vector.  Hierarchy::apply uses it when "is preconditioner" is true. */
 int mfmg_hip_mf_laplace_sweep_available(mfmg_hip_mf_laplace_t op, int n_terms, int *available);
 int mfmg_hip_mf_laplace_smoother_sweep(mfmg_hip_mf_laplace_t op, int n_terms, const double *alpha, const double *beta,
                                        const double *b, const double *x, double *out, double *out_prev);

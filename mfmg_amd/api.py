@@ -380,11 +380,12 @@ class MatrixFreeLaplace:
         return bool(v.value)
 
     def smoother_sweep(self, alpha, beta, b, x, out, out_prev=None):
-        """len(alpha) smoother terms in one sweep; out = the last iterate, out_prev (optional) the one before."""
+        """len(alpha) smoother terms in one sweep; out = the last iterate, out_prev (optional) the one before.
+        x = None: from the zero vector, which is not read (three terms, the default arithmetic; raises where unavailable)."""
         n, k = self.n_dofs, len(alpha)
         a = (C.c_double * k)(*[float(v) for v in alpha])
         be = (C.c_double * k)(*[float(v) for v in beta])
-        check(self._lib.mfmg_hip_mf_laplace_smoother_sweep(self.handle, k, a, be, _dev_ptr(b, n), _dev_ptr(x, n), _dev_ptr(out, n),
+        check(self._lib.mfmg_hip_mf_laplace_smoother_sweep(self.handle, k, a, be, _dev_ptr(b, n), _dev_ptr(x, n) if x is not None else None, _dev_ptr(out, n),
                                                            _dev_ptr(out_prev, n) if out_prev is not None else None))
 
     def set_sweep_tile(self, waves: int, ty: int, tz: int):

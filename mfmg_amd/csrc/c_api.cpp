@@ -923,9 +923,12 @@ int mfmg_hip_mf_laplace_smoother_sweep(mfmg_hip_mf_laplace_t op, int n_terms, co
                                        const double *b, const double *x, double *out, double *out_prev)
 {
   return guarded([&] {
-    require(op && alpha && beta && b && x && out, "null argument");
+    require(op && alpha && beta && b && out, "null argument");
     if (!op->op->fused_sweep_available(n_terms))
       ASSERT_THROW_NOT_IMPLEMENTED("the multi-term smoother sweep is not available for this operator");
+    // x == NULL: the sweep from x_0 = 0, which is then not read (three terms, default arithmetic)
+    if (x == nullptr && !op->op->fused_zero_guess_available(n_terms))
+      ASSERT_THROW_NOT_IMPLEMENTED("the sweep from a zero guess is not available for this operator / tile / number of terms");
     op->op->smoother_sweep(n_terms, alpha, beta, b, x, out, out_prev);
   });
 }
@@ -1276,6 +1279,34 @@ int mfmg_hip_hierarchy_solve_cg(mfmg_hip_hierarchy_t h, const double *b, double 
     record(0, res);
     double rz = 0.;
     bool converged = res <= tolerance;
+    if (!handle.comm.enabled())
+    {
+      // One rank: the scalars of the iteration stay on the device (vec::cg_direction / cg_update read them there) -- ONE host
+      // round trip per iteration, for the stopping test, instead of three; x and r are updated in one pass.  The same sums in the
+      // same order as below: the same iterates.
+      DeviceBuffer<double> scal(4); // [0], [1]: (r, z) of this / the previous iteration, alternating; [2]: (p, A p); [3]: (r, r)
+      int cur = 0;
+      while (!converged && it < max_iterations)
+      {
+        h->hierarchy->vmult(z, r);
+        vec::dot_async<double>(handle, n, r.get_values(), z.get_values(), scal.data(), cur);
+        if (it == 0)
+          p = z;
+        else
+          vec::cg_direction<double>(handle, n, z.get_values(), p.get_values(), scal.data(), cur, 1 - cur); // p = z + beta p
+        op->apply(p, ap);
+        vec::dot_async<double>(handle, n, p.get_values(), ap.get_values(), scal.data(), 2);
+        vec::cg_update<double>(handle, n, p.get_values(), ap.get_values(), nullptr, xv.get_values(), r.get_values(), nullptr, scal.data(), cur, 2);
+        vec::dot_async<double>(handle, n, r.get_values(), r.get_values(), scal.data(), 3);
+        MFMG_HIP_CHECK(hipMemcpyAsync(handle.host_result, scal.data() + 3, sizeof(double), hipMemcpyDeviceToHost, handle.stream));
+        MFMG_HIP_CHECK(hipStreamSynchronize(handle.stream));
+        res = std::sqrt(handle.host_result[0]);
+        cur = 1 - cur;
+        ++it;
+        record(it, res);
+        converged = res <= tolerance;
+      }
+    }
     while (!converged && it < max_iterations)
     {
       h->hierarchy->vmult(z, r);

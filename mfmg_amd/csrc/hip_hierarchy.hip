@@ -836,6 +836,24 @@ bool HipMatrixFreeOperator::smoother_sweep(int n_terms, double const *alpha, dou
   return true;
 }
 
+bool HipMatrixFreeOperator::smoother_sweep_from_zero(int n_terms, double const *alpha, double const *beta, DVector const &b, DVector &out) const
+{
+  auto op = _mesh_evaluator->get_device_operator();
+  if (!op->fused_zero_guess_available(n_terms))
+    return false;
+  HipHandle &handle = get_hip_handle();
+  if (handle.comm.enabled())
+  {
+    // (x_0 = 0 on every rank: its ghost entries need no exchange; b as in smoother_sweep)
+    ASSERT_THROW(n_terms <= handle.comm.sweep_terms(), "internal: more terms per sweep than the ranks hold ghost planes for");
+    handle.rhs_ghosts_wanted = true;
+    handle.rhs_ghost_width = std::max(handle.rhs_ghost_width, n_terms - 1);
+    handle.need_rhs_ghosts(b.get_values(), n_terms - 1);
+  }
+  op->smoother_sweep(n_terms, alpha, beta, b.get_values(), nullptr, out.get_values(), nullptr);
+  return true;
+}
+
 double const *HipMatrixFreeOperator::get_diagonal_inverse() const
 {
   return _mesh_evaluator->matrix_free_get_diagonal_inverse();
@@ -1167,6 +1185,21 @@ void HipSmoother::apply_to(DVector const &b, DVector const &x_in, DVector &x_out
     }
   }
   run_terms(0, b, &x_in, nullptr, x_out);
+}
+
+bool HipSmoother::apply_from_zero(DVector const &b, DVector &x_out) const
+{
+  // the whole polynomial as one sweep that does not read x_0 = 0 (three terms: the kernels that carry the variant)
+  const int d = (int)_coefficients.size();
+  if (d != 3 || _fused_terms < 3 || _coefficients[0].first != 0.)
+    return false;
+  double alpha[3], beta[3];
+  for (int k = 0; k < 3; ++k)
+  {
+    alpha[k] = _coefficients[k].first;
+    beta[k] = _coefficients[k].second;
+  }
+  return _hip_operator->smoother_sweep_from_zero(3, alpha, beta, b, x_out);
 }
 
 // ---- HipSolver -----------------------------------------------------------------

@@ -163,7 +163,9 @@ struct BufIO<float>
 // per wavefront; the halves exchange nothing (lane 0 of a half is a halo lane; its last lane is at most the last column of the mesh,
 // whose cell is a phantom with coefficient zero: what arrives there from the other half is multiplied by it), owner computes as
 // everywhere.
-template <typename T, int K, int TY, bool DREC, bool MODES, int DBG = 0, bool NARROW = false>
+// ZERO0: x_0 = 0 (the pre-smoother of a preconditioner application, hierarchy.hpp:253-259): stage 1 is x_1 = beta_1 D^-1 b -- no
+// operator application, nothing read of x_0, no exchange between the wavefronts; the same bits as the sweep run on a zeroed vector.
+template <typename T, int K, int TY, bool DREC, bool MODES, int DBG = 0, bool NARROW = false, bool ZERO0 = false>
 __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsigned int w)
 {
 #pragma clang fp contract(off)
@@ -342,8 +344,11 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsi
 #pragma unroll
     for (int r = 0; r < R; ++r)
     {
-      *ring_at(0, cb, r) = ld_vec(rs_x, r, cb);
-      *ring_at(0, cb + 1, r) = ld_vec(rs_x, r, cb + 1);
+      if constexpr (!ZERO0)
+      {
+        *ring_at(0, cb, r) = ld_vec(rs_x, r, cb);
+        *ring_at(0, cb + 1, r) = ld_vec(rs_x, r, cb + 1);
+      }
       bq[0][r] = ld_vec(rs_b, r, cb);
       if constexpr (DREC)
         dq[0][r] = ld_dinv(rs_rec, r, cb);
@@ -374,6 +379,11 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsi
 #pragma unroll
     for (int r = 0; r < R; ++r)
     {
+      if constexpr (S == 1 && ZERO0)
+      {
+        xown[r] = xl[r] = xu[r] = T(0);
+        continue;
+      }
       const T l = *ring_at(S - 1, c, r), u = *ring_at(S - 1, c + 1, r);
       xown[r] = l;
       if constexpr (S == 1)
@@ -399,7 +409,21 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsi
     // per cell row: what it contributes to the node row below (low) and above (up), two values each -- the corner sums of the
     // d = 0 / d = 1 node layer (reference arithmetic) or the z-modes s / d (MODES)
     T lowA[TY], lowB[TY], upA[TY], upB[TY], sx[TY];
-    if constexpr (MODES)
+    if constexpr (S == 1 && ZERO0)
+    {
+      // A 0 = 0: no cell arithmetic; the coefficient sums of the diagonal remain
+#pragma unroll
+      for (int q = 0; q < TY; ++q)
+      {
+        lowA[q] = lowB[q] = upA[q] = upB[q] = sx[q] = T(0);
+        if constexpr (!DREC)
+        {
+          const T cv = cq[0][q];
+          sx[q] = cv + from_prev_lane(cv);
+        }
+      }
+    }
+    else if constexpr (MODES)
     {
       T Pl[R], Ql[R], Pu[R], Qu[R];
 #pragma unroll
@@ -447,6 +471,8 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsi
       }
     }
     // the sums of the last cell row go up, those of the first go down (double-buffered by the parity of the pass)
+    constexpr bool kExchange = !(S == 1 && ZERO0); // (all sums are zero: nothing to hand over, no barrier)
+    if constexpr (kExchange)
     {
       T *xp = xport + (size_t)((ex & 1) * NW + wv) * 4 * 64;
       xp[0] = upA[TY - 1];
@@ -523,7 +549,7 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsi
       {
         // x_{S-1} and x_{S-2} of the DoF (zero where it is not free: the result is dropped there)
         const T xo = xown[r];
-        const T xoo = *ring_at(S - 2, c, r);
+        const T xoo = (S == 2 && ZERO0) ? T(0) : *ring_at(S - 2, c, r);
         const T xoo_m = (S == 2) ? ((lane_free && ((rows_free >> r) & 1u) && lo_free) ? xoo : T(0)) : xoo; // (x_0 sits in its ring unmasked)
         const T xs = fmadd<T>(-(k_beta(S - 1) * dq[S - 1][r]), yv - bq[S - 1][r], fmadd<T>(k_alpha(S - 1), xo - xoo_m, xo));
         if constexpr (S < K)
@@ -556,18 +582,18 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsi
       inner(IntTag<3>{});
     // (LDS only: the requests of the next super-pass stay in flight across the barrier -- __syncthreads() would drain them.
     // Tried instead: a word per wavefront that its two neighbours poll, no workgroup-wide rendezvous -- 7 % slower.)
-    if constexpr (DBG != 1)
+    if constexpr (DBG != 1 && kExchange)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // the rows shared with the neighbours: both wavefronts complete them, with the same operands in the same order
     {
       T lo0 = T(0), lo1 = T(0), hi0 = T(0), hi1 = T(0);
-      if (wv > 0)
+      if (kExchange && wv > 0)
       {
         T const *ip = xport + (size_t)((ex & 1) * NW + wv - 1) * 4 * 64;
         lo0 = ip[0];
         lo1 = ip[64];
       }
-      if (wv + 1 < NW)
+      if (kExchange && wv + 1 < NW)
       {
         T const *ip = xport + (size_t)((ex & 1) * NW + wv + 1) * 4 * 64;
         hi0 = ip[128];
@@ -592,7 +618,8 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsi
         finish(IntTag<TY>{}, yv, tcs);
       }
     }
-    ++ex;
+    if constexpr (kExchange)
+      ++ex;
   };
 
   // ---- the march
@@ -605,7 +632,9 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsi
 #pragma unroll
     for (int r = 0; r < R; ++r)
     {
-      pfx[r] = ld_vec(rs_x, r, c1 + 2);
+      pfx[r] = T(0);
+      if constexpr (!ZERO0)
+        pfx[r] = ld_vec(rs_x, r, c1 + 2);
       pfb[r] = ld_vec(rs_b, r, c1 + 1);
       pfd[r] = T(0);
       if constexpr (DREC)
@@ -649,7 +678,8 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsi
       bq[0][r] = pfb[r];
       if constexpr (DREC)
         dq[0][r] = pfd[r];
-      *ring_at(0, c1 + 2, r) = pfx[r];
+      if constexpr (!ZERO0)
+        *ring_at(0, c1 + 2, r) = pfx[r];
     }
 #pragma unroll
     for (int q = 0; q < TY; ++q)
@@ -664,7 +694,7 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsi
 
 // NARROW_TOO: the kernel carries the body for the tiles of a narrow last chunk column as well (twice the code: only the tile
 // shapes the sweeps use by default have it; any other shape runs that column with ordinary tiles, most of their lanes idle)
-template <typename T, int K, int TY, bool DREC, bool MODES, int DBG = 0, bool NARROW_TOO = false>
+template <typename T, int K, int TY, bool DREC, bool MODES, int DBG = 0, bool NARROW_TOO = false, bool ZERO0 = false>
 __global__ __launch_bounds__(512, 2) void mf_cheb_fused_kernel(MfFusedArgs<T> a)
 {
   // XCD-aware tile order (as mf_laplace_body): every XCD takes a contiguous run of the tile list
@@ -681,11 +711,11 @@ __global__ __launch_bounds__(512, 2) void mf_cheb_fused_kernel(MfFusedArgs<T> a)
   {
     if (w >= a.wide_tiles)
     {
-      mf_cheb_fused_body<T, K, TY, DREC, MODES, DBG, true>(a, w);
+      mf_cheb_fused_body<T, K, TY, DREC, MODES, DBG, true, ZERO0>(a, w);
       return;
     }
   }
-  mf_cheb_fused_body<T, K, TY, DREC, MODES, DBG, false>(a, w);
+  mf_cheb_fused_body<T, K, TY, DREC, MODES, DBG, false, ZERO0>(a, w);
 }
 } // namespace
 
@@ -703,6 +733,18 @@ bool MatrixFreeLaplaceDevice<T>::fused_sweep_available(int n_terms) const
     if ((_affine.ghost_lo[d] > 0 && _affine.ghost_lo[d] < n_terms) || (_affine.ghost_hi[d] > 0 && _affine.ghost_hi[d] < n_terms))
       return false;
   return true;
+}
+
+// The sweep from x_0 = 0 (smoother_sweep with x == nullptr): the three-term kernels with three rows per wavefront and the default
+// arithmetic carry that variant.
+template <typename T>
+bool MatrixFreeLaplaceDevice<T>::fused_zero_guess_available(int n_terms) const
+{
+  if (n_terms != 3 || !fused_sweep_available(n_terms) || _fused_reference_arithmetic)
+    return false;
+  int nw, ty, tz;
+  choose_fused_tile(n_terms, nw, ty, tz);
+  return ty == 3;
 }
 
 // tile of the sweep: NW wavefronts of TY cell rows, TZ owned layers.  One workgroup of eight wavefronts per CU (two per
@@ -767,14 +809,16 @@ template <typename T>
 void MatrixFreeLaplaceDevice<T>::smoother_sweep(int n_terms, T const *alpha, T const *beta, T const *b, T const *x, T *out, T *out_prev) const
 {
   ASSERT_THROW(fused_sweep_available(n_terms), "the multi-term smoother sweep is not available for this operator");
-  ASSERT_THROW(x != nullptr && b != nullptr && out != nullptr, "null vector");
-  ASSERT_THROW(x != out && x != out_prev && out != out_prev, "the multi-term sweep cannot run in place");
+  const bool zero_guess = x == nullptr; // x_0 = 0: nothing is read of it (fused_zero_guess_available)
+  ASSERT_THROW(b != nullptr && out != nullptr, "null vector");
+  ASSERT_THROW(!zero_guess || fused_zero_guess_available(n_terms), "the sweep from a zero guess is not available for this operator / tile");
+  ASSERT_THROW((zero_guess || (x != out && x != out_prev)) && out != out_prev, "the multi-term sweep cannot run in place");
   ASSERT_THROW(alpha[0] == T(0), "the first term of a sweep takes no momentum");
   int nw, ty, tz;
   choose_fused_tile(n_terms, nw, ty, tz);
   MfFusedArgs<T> a{};
   a.rec = _rec.data();
-  a.x = x;
+  a.x = zero_guess ? b : x; // (never read from a zero guess; the descriptor wants an address)
   a.b = b;
   a.out = out;
   a.out_prev = out_prev;
@@ -892,7 +936,25 @@ void MatrixFreeLaplaceDevice<T>::smoother_sweep(int n_terms, T const *alpha, T c
     }
   };
   static const int dbg = std::getenv("MFMG_MF_FUSED_DBG") ? std::atoi(std::getenv("MFMG_MF_FUSED_DBG")) : 0;
-  if (dbg > 0 && n_terms == 3 && ty == 3 && !_dinv_in_record && std::is_same<T, double>::value)
+  if (zero_guess)
+  {
+    // (n_terms = 3, ty = 3, mode-space arithmetic: checked above)
+    if (_dinv_in_record)
+    {
+      if (narrow)
+        go(mf_cheb_fused_kernel<T, 3, 3, true, true, 0, true, true>);
+      else
+        go(mf_cheb_fused_kernel<T, 3, 3, true, true, 0, false, true>);
+    }
+    else
+    {
+      if (narrow)
+        go(mf_cheb_fused_kernel<T, 3, 3, false, true, 0, true, true>);
+      else
+        go(mf_cheb_fused_kernel<T, 3, 3, false, true, 0, false, true>);
+    }
+  }
+  else if (dbg > 0 && n_terms == 3 && ty == 3 && !_dinv_in_record && std::is_same<T, double>::value)
   {
     if (dbg == 1)
       go(mf_cheb_fused_kernel<T, 3, 3, false, true, 1>);
@@ -909,6 +971,8 @@ void MatrixFreeLaplaceDevice<T>::smoother_sweep(int n_terms, T const *alpha, T c
   KernelProfiler::end(stop, st);
 }
 
+template bool MatrixFreeLaplaceDevice<double>::fused_zero_guess_available(int) const;
+template bool MatrixFreeLaplaceDevice<float>::fused_zero_guess_available(int) const;
 template bool MatrixFreeLaplaceDevice<double>::fused_sweep_available(int) const;
 template bool MatrixFreeLaplaceDevice<float>::fused_sweep_available(int) const;
 template void MatrixFreeLaplaceDevice<double>::choose_fused_tile(int, int &, int &, int &) const;

@@ -101,6 +101,8 @@ public:
   // out_prev and x must be three different vectors.  Available for the cell-constant layout with a numbering the kernel can
   // compute on one rank (fused_sweep_available); callers fall back to smoother_step otherwise.
   bool fused_sweep_available(int n_terms) const;
+  // ... and from x_0 = 0 without reading it (smoother_sweep with x == nullptr: the pre-smoother of a preconditioner application)
+  bool fused_zero_guess_available(int n_terms) const;
   // the last chunk column owns at most 32 - 2 halo DoF columns: the sweep kernels of the default tile shapes (three terms 8 x 3
   // rows, two terms 4 x 4) run it two y-tiles per workgroup, one per half of the wavefront
   bool narrow_last_column() const { return _narrow_last; }

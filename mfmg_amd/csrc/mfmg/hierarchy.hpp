@@ -131,10 +131,14 @@ public:
     auto a = level_fine.get_operator();
 
     const bool coarsest = level_index == static_cast<int>(num_levels) - 1;
-    if ((level_index > 0 || _is_preconditioner) && !(coarsest && level_fine.get_solver()->ignores_initial_guess()))
+    const bool from_zero = level_index > 0 || _is_preconditioner;
+    // Zero out any garbage in x (hierarchy.hpp:253-259); a solver that does not read x needs no pass over it, and neither does a
+    // smoother that can start from zero by itself (Smoother::apply_from_zero, tried below).
+    bool zero_pending = from_zero && !(coarsest && level_fine.get_solver()->ignores_initial_guess());
+    if (zero_pending && (coarsest || _n_smoothing_steps == 0))
     {
-      // Zero out any garbage in x (hierarchy.hpp:253-259); a solver that does not read x needs no pass over it.
       x = 0.;
+      zero_pending = false;
     }
 
     if (coarsest)
@@ -158,8 +162,26 @@ public:
       // between x and a workspace vector; pre- and post-smoothing together switch an even number of times.
       auto smoother = level_fine.get_smoother();
       VectorType *cur = &x, *other = nullptr;
+      unsigned int first_step = 0;
+      if (zero_pending)
+      {
+        // the first pre-smoothing step from x = 0: the smoother writes its result into the workspace vector without reading x
+        bool done = false;
+        if (smoother->prefers_out_of_place())
+        {
+          other = level_fine.workspace_vector(3).get();
+          done = smoother->apply_from_zero(b, *other);
+        }
+        if (done)
+        {
+          std::swap(cur, other);
+          first_step = 1;
+        }
+        else
+          x = 0.;
+      }
       auto smooth = [&] {
-        for (unsigned int i = 0; i < _n_smoothing_steps; ++i)
+        for (unsigned int i = first_step; i < _n_smoothing_steps; ++i)
         {
           if (smoother->prefers_out_of_place())
           {
@@ -173,6 +195,7 @@ public:
         }
       };
       smooth();
+      first_step = 0;
 
       // negative residual -r = A x - b and its restriction: one pass where the restrictor holds the rows of R A,
       // otherwise one fused kernel for the residual and the restriction after it

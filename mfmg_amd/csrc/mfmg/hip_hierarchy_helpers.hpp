@@ -93,6 +93,12 @@ public:
     return false;
   }
   virtual bool sweep_available(int /*n_terms*/) const { return false; }
+  // the same sweep from x_0 = 0, which is not read (hierarchy.hpp:253-259: a preconditioner application starts from zero)
+  virtual bool smoother_sweep_from_zero(int /*n_terms*/, double const * /*alpha*/, double const * /*beta*/, DVector const & /*b*/,
+                                        DVector & /*out*/) const
+  {
+    return false;
+  }
   virtual double const *get_diagonal_inverse() const = 0; // device pointer
   virtual HipHandle &get_hip_handle() const = 0;
   // distributed vector space of the domain / range (0: rank-local, 1: fine DoFs, 2: first coarse level)
@@ -201,6 +207,7 @@ public:
   bool smoother_sweep(int n_terms, double const *alpha, double const *beta, DVector const &b, DVector const &x, DVector &out,
                       DVector *out_prev) const override;
   bool sweep_available(int n_terms) const override;
+  bool smoother_sweep_from_zero(int n_terms, double const *alpha, double const *beta, DVector const &b, DVector &out) const override;
   double const *get_diagonal_inverse() const override;
   HipHandle &get_hip_handle() const override { return _mesh_evaluator->get_hip_handle(); }
   std::shared_ptr<HipMatrixFreeMeshEvaluator> get_mesh_evaluator() const { return _mesh_evaluator; }
@@ -276,6 +283,7 @@ public:
   // same update from x_in into a different vector x_out: the whole polynomial in one sweep where the operator offers it
   // (smoother.fused_terms, default 3), no copy back from a scratch vector
   void apply_to(DVector const &b, DVector const &x_in, DVector &x_out) const override;
+  bool apply_from_zero(DVector const &b, DVector &x_out) const override;
   bool prefers_out_of_place() const override;
   int fused_terms() const { return _fused_terms; }
   // polynomial terms the fine smoother runs as ONE sweep: by apply() (in place: the last term is a launch of its own) and by

@@ -30,6 +30,9 @@ public:
     apply(b, x_out);
   }
   virtual bool prefers_out_of_place() const { return false; }
+  // Extension: x_out = the update from x = 0 WITHOUT a zeroed input vector (the pre-smoother of a preconditioner application,
+  // hierarchy.hpp:253-259).  False (nothing done): the caller zeroes x and applies as usual.
+  virtual bool apply_from_zero(vector_type const & /*b*/, vector_type & /*x_out*/) const { return false; }
 
 protected:
   std::shared_ptr<operator_type const> _operator;

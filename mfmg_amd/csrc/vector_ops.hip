@@ -211,7 +211,8 @@ __global__ void cg_update_kernel(int64_t n, T const *p, T const *Ap, T const *di
     x[i] += alpha * p[i];
     const T ri = r[i] - alpha * Ap[i];
     r[i] = ri;
-    z[i] = dinv[i] * ri;
+    if (dinv != nullptr) // (Jacobi-preconditioned CG of the coarse solver; the outer CG driver applies its preconditioner itself)
+      z[i] = dinv[i] * ri;
   }
 }
 

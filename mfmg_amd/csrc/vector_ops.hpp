@@ -50,7 +50,7 @@ double l2_norm(HipHandle &h, int64_t n, T const *x);
 
 // ---- device-scalar CG building blocks (no host round trip, graph-capturable) ----
 // scal[] slots hold dot products computed by dot_async.
-// x += (scal[rz]/scal[pap]) p ; r -= (scal[rz]/scal[pap]) Ap ; z = dinv .* r
+// x += (scal[rz]/scal[pap]) p ; r -= (scal[rz]/scal[pap]) Ap ; z = dinv .* r (dinv == nullptr: z is left alone)
 template <typename T>
 void cg_update(HipHandle &h, int64_t n, T const *p, T const *Ap, T const *dinv, T *x, T *r, T *z,
                double const *scal, int slot_rz, int slot_pap);

@@ -1325,3 +1325,38 @@ def test_smoothed_prolongation_equals_two_steps(ctx, cells):
     h2.coarse_apply(xc, y2)
     ctx.synchronize()
     assert relerr(y1.cpu().numpy(), y2.cpu().numpy()) < 1e-12
+
+
+@pytest.mark.parametrize("n", [(16, 12, 10), (70, 8, 6)])
+def test_preconditioner_application_starts_from_zero_without_zeroing(ctx, n):
+    """'is preconditioner' true (include/mfmg/common/hierarchy.hpp:253-259): x is zeroed before the cycle.  With the one-sweep
+    smoother the first pre-smoothing step neither zeroes nor reads x (Smoother::apply_from_zero: x_1 = beta_1 D^-1 b, two operator
+    applications instead of three) -- garbage in x must not matter, the cycle equals the oracle's from x = 0 and the cycle of a
+    hierarchy that takes the generic path (reference arithmetic of the sweep: x zeroed, three applications)."""
+    mesh = O.StructuredMesh(n)
+    coef = O.coefficient_table(mesh, "constant")
+    mf = O.MatrixFreeLaplace(mesh, coef)
+    rng = np.random.default_rng(11)
+    bf = rng.random(mesh.n_dofs) * (~mesh.constrained_mask())
+    outs = {}
+    for arithmetic in ("modes", "reference"):
+        prob = M.LaplaceProblem(n, "constant", device="cuda")
+        params = base_params(smoother={"type": "Chebyshev", "degree": 3, "smoothing_range": 20.0, "sweep_arithmetic": arithmetic})
+        params["is preconditioner"] = True
+        h = M.Hierarchy(ctx, "HipMatrixFreeMeshEvaluator", prob, params)
+        assert h.smoother_sweep_terms() == (2, 3)
+        xg = dev(1e6 * rng.random(mesh.n_dofs))
+        h.vmult(xg, dev(bf))
+        ctx.synchronize()
+        outs[arithmetic] = xg.cpu().numpy().copy()
+        if arithmetic == "modes":
+            deg, lmin, lmax = h.smoother_info()
+            R = h.restrictor().to_scipy()
+            Ac = h.coarse_operator().to_scipy()
+    assert np.isfinite(outs["modes"]).all()
+    assert relerr(outs["modes"], outs["reference"]) < 1e-12
+    p = O.ChebyshevParams(deg, lmax, lmin)
+    dinv = mf.diagonal_inverse()
+    smoother = lambda b, x: O.chebyshev_smoother_apply(mf.vmult, dinv, p, b, x)
+    ho = O.TwoLevelHierarchy(mf.vmult, smoother, R, O.direct_coarse_solver(Ac), 1, True)
+    np.testing.assert_allclose(outs["modes"], ho.apply(bf, np.zeros(mesh.n_dofs)), rtol=1e-10, atol=1e-12 * np.abs(outs["modes"]).max())

@@ -905,3 +905,39 @@ def test_direct_solvers_on_the_reference_tridiagonal_system(ctx):
         Ad.solve({"solver": {"type": "qr"}}, dev(rhs), x)
     with pytest.raises(L.MfmgNotImplementedError):                          # no AmgX shim
         Ad.solve({"solver": {"type": "amgx"}}, dev(rhs), x)
+
+
+@pytest.mark.parametrize("n,material,stored_dinv", [((6, 5, 7), "constant", False), ((70, 30, 20), "constant", False), ((86, 19, 11), "cellwise", False),
+                                                    ((130, 40, 33), "cellwise", True)])
+@pytest.mark.parametrize("tile", [None, (8, 3, 5), (4, 3, 8)])
+def test_smoother_sweep_from_zero_guess(ctx, n, material, stored_dinv, tile):
+    """The three-term sweep from x_0 = 0 WITHOUT reading x_0 (x = None: the pre-smoother of a preconditioner application,
+    include/mfmg/common/hierarchy.hpp:253-259; first term x_1 = beta_1 D^-1 b, no operator application) == the sweep run on a
+    zeroed vector (values equal; only the sign of an exact zero may differ), with a wide and a narrow last chunk column, the
+    diagonal derived in the kernel or stored; refused for two terms and for the reference arithmetic."""
+    ctx.set_stored_diagonal(stored_dinv)
+    try:
+        prob = _cellwise_problem(n) if material == "cellwise" else M.LaplaceProblem(n, material, device="cuda")
+        op = M.MatrixFreeLaplace(ctx, prob)
+    finally:
+        ctx.set_stored_diagonal(False)
+    assert op.sweep_available(3)
+    if tile is not None:
+        op.set_sweep_tile(*tile)
+    N = prob.n_dofs
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    b = torch.rand(N, dtype=torch.float64, device="cuda", generator=g)
+    al = [c[0] for c in SWEEP_COEFS]
+    be = [c[1] for c in SWEEP_COEFS]
+    ref = torch.full_like(b, float("nan"))
+    op.smoother_sweep(al, be, b, torch.zeros_like(b), ref)
+    out = torch.full_like(b, float("nan"))
+    op.smoother_sweep(al, be, b, None, out)
+    ctx.synchronize()
+    assert torch.isfinite(out).all() and torch.equal(out, ref)
+    with pytest.raises(L.MfmgNotImplementedError):
+        op.smoother_sweep(al[:2], be[:2], b, None, out)
+    op.set_sweep_reference(True)
+    with pytest.raises(L.MfmgNotImplementedError):
+        op.smoother_sweep(al, be, b, None, out)
