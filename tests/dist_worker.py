@@ -455,6 +455,10 @@ MESHES = {
     # boxwide: 133 node columns per rank = two column tiles of the operator + the tail slab, several y- and z-tiles: the exchange
     # of a box overlaps with the tiles that read no ghost plane along any axis, the shell of tiles around them follows
     "boxwide": (16, (130, 32), "constant", {"coarsest_size": 300}),
+    # boxnarrow: 80 cells per rank along x -- with two ghost agglomerates below, the local meshes of a 2 x ... grid are 83 and 85
+    # node columns wide: one full chunk column + a NARROW last one of 25 resp. 27 columns (the widest the sweep takes is 32 - halo:
+    # the 259 / 261 columns of a rank of the 2 x 2 x 2 bench run are 4 full ones + 27 / 29)
+    "boxnarrow": (16, (80, 32), "constant", {"coarsest_size": 300}),
 }
 
 

@@ -123,7 +123,8 @@ def test_distributed_library_path_shared_gpu(mfmg_lib, world, mesh):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,grid,mesh", [(2, "1x1x2", "cube11"), (4, "2x1x2", "cube11"), (4, "2x2x1", "boxwide"), (4, "1x2x2", "cube")])
+@pytest.mark.parametrize("world,grid,mesh", [(2, "1x1x2", "cube11"), (4, "2x1x2", "cube11"), (4, "2x2x1", "boxwide"), (4, "1x2x2", "cube"),
+                                             (2, "2x1x1", "boxnarrow")])
 def test_box_decomposition_with_two_ghost_agglomerates_below_shared_gpu(mfmg_lib, world, grid, mesh):
     """BoxPartition(low_ghost_cells=4): the local mesh holds two agglomerates of every lower neighbour, so that the whole
     Chebyshev(3) smoother of a rank is ONE sweep (x exchanged once, three ghost planes deep; asserted in the worker for the
