@@ -38,6 +38,9 @@ material = os.environ.get("MATERIAL", "constant")
 if os.environ.get("AMG_REPLICATE_ROWS"):      # levels with fewer global rows are gathered and solved redundantly (default 200000)
     params["solver"]["amg"]["replicate_rows"] = int(os.environ["AMG_REPLICATE_ROWS"])
 
+host_enqueue_ms = []   # (appended by cycles(): ms the host spends enqueueing one cycle; if it equals the cycle time the run is launch-bound)
+
+
 def cycles(ctx, h, n, steps=10, warmup=3):
     """ms per cycle: median over five blocks of `steps` / 2 cycles, the collector off meanwhile (this process holds the Python
     objects of eight ranks: a generation-2 collection in the middle of a block cost 20-90 ms in the first runs of round 4)."""
@@ -55,8 +58,10 @@ def cycles(ctx, h, n, steps=10, warmup=3):
             t = time.perf_counter()
             for _ in range(per):
                 h.apply(b, x)
+            t_host = time.perf_counter() - t          # every launch of the block is enqueued: what the HOST needs per cycle
             ctx.synchronize(); torch.cuda.synchronize()
             blocks.append((time.perf_counter() - t) / per * 1e3)
+            host_enqueue_ms.append(t_host / per * 1e3)
     finally:
         gc.enable()
     return sorted(blocks)[len(blocks) // 2]
@@ -130,7 +135,9 @@ def worker(rank):
                     h.apply(zz, x2)
                     ctx.synchronize(); each.append(round((time.perf_counter() - t) * 1e3, 3))
                 print("[phase] per-cycle ms, fresh x, b = 0:", each, "max |x|", float(x2.abs().max()), flush=True)
+            del host_enqueue_ms[:]
             ms = cycles(ctx, h, h.level_size(0))
+            result["host_enqueue_ms_per_cycle"] = sorted(host_enqueue_ms)[len(host_enqueue_ms) // 2]
             n_cyc = 3 + 5 * 5
             result.update({"rank": rank, "grid": list(grid), "cells_per_rank": per, "local_cells": list(part.local_cells),
                            "ms_per_cycle_rank_alone_reflecting": ms, "ms_per_cycle_one_rank_same_size": ms_single,
