@@ -176,6 +176,9 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsi
   const int NW = blockDim.x >> 6;
   // LDS: per wavefront the rings x_0 .. x_{K-1} ([planes][R rows][64 lanes]); then the exports [2][NW][4][64]
   T *ring = reinterpret_cast<T *>(smem_raw) + (size_t)wv * (ring_planes(K) * R * 64) + lane;
+  // the same planes as the NEXT lane sees them (the last lane: its own, what a DPP shift with the source as old value returns): the
+  // x_{s-1} values of the neighbour column are read from the ring, not shifted through the vector ALU, which bounds the sweep
+  T const *ring_next = ring + (lane == 63 ? 0 : 1);
   T *xport = reinterpret_cast<T *>(smem_raw) + (size_t)NW * (ring_planes(K) * R * 64) + lane;
 
   // (tile w of the list: the kernel has dealt the list to the XCDs in contiguous runs)
@@ -311,6 +314,10 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsi
     const int sl = ring_depth(s, K) == 3 ? slot3(n) : slot2(n);
     return ring + ((ring_base(s, K) + sl) * R + r) * 64;
   };
+  auto ring_next_at = [&](int s, int n, int r) -> T const * {
+    const int sl = ring_depth(s, K) == 3 ? slot3(n) : slot2(n);
+    return ring_next + ((ring_base(s, K) + sl) * R + r) * 64;
+  };
 
   // ---- per-lane state carried from super-pass to super-pass (stage s + 1 uses entry s)
   T bq[K][R];  // b of the DoF (row r, layer of the stage)
@@ -403,8 +410,19 @@ __device__ __forceinline__ void mf_cheb_fused_body(MfFusedArgs<T> const &a, unsi
 #pragma unroll
     for (int r = 0; r < R; ++r)
     {
-      xln[r] = from_next_lane(xl[r]);
-      xun[r] = from_next_lane(xu[r]);
+      if constexpr (S == 1)
+      {
+        // (x_0 sits in its ring unmasked: the masked values are shifted)
+        xln[r] = from_next_lane(xl[r]);
+        xun[r] = from_next_lane(xu[r]);
+      }
+      else
+      {
+        // x_{S-1} sits in its ring as the cells read it: the neighbour column straight from there (an LDS read instead of two
+        // DPP moves and their presets per value; the same numbers)
+        xln[r] = *ring_next_at(S - 1, c, r);
+        xun[r] = *ring_next_at(S - 1, c + 1, r);
+      }
     }
     // per cell row: what it contributes to the node row below (low) and above (up), two values each -- the corner sums of the
     // d = 0 / d = 1 node layer (reference arithmetic) or the z-modes s / d (MODES)
