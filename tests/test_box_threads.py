@@ -84,7 +84,7 @@ def test_box_2x2x2_eight_ranks_in_one_process(mfmg_lib, material, amg, low_ghost
     # ---- eight ranks, one thread each
     n_ranks = 8
     mb = Mailboxes(n_ranks)
-    hists, errors, info = [None] * n_ranks, [None] * n_ranks, [None] * n_ranks
+    hists, errors, info, overlapped = [None] * n_ranks, [None] * n_ranks, [None] * n_ranks, [0] * n_ranks
     x_final = np.zeros(ng)
 
     def worker(rank):
@@ -117,6 +117,26 @@ def test_box_2x2x2_eight_ranks_in_one_process(mfmg_lib, material, amg, low_ghost
             x_final[own_g] = x.cpu().numpy()[own_l]
             info[rank] = (tr.n_exchanges(), tr.space(1)["n_spaces"], h.coarse_amg_gather_rows())
             ctx.synchronize()
+            # ---- exchanges in flight on BOTH streams at once: behind the reflecting transport -- every message
+            # this rank sends is mirrored on the device, nothing synchronises the host -- the ghost entries of b travel on the
+            # exchange stream beside the pre-smoother while x is exchanged on the compute stream (per-stream staging buffers; a
+            # shared one let the packed regions of the two overwrite each other).  With the overlap switched off every exchange
+            # runs in program order on the compute stream: the same bits.  (The other ranks may still be in their cycles above: a
+            # reflecting rank needs no partner.)
+            tr.reflect()
+            gl = torch.Generator(device="cuda").manual_seed(100 + rank)
+            xa = torch.rand(len(loc_g), dtype=torch.float64, device="cuda", generator=gl)
+            br = torch.rand(len(loc_g), dtype=torch.float64, device="cuda", generator=gl)
+            xb = xa.clone()
+            for xv, overlap in ((xa, True), (xb, False)):
+                ctx.set_overlap_exchange(overlap)
+                for _ in range(3):
+                    h.apply(br, xv)
+            ctx.set_overlap_exchange(True)
+            ctx.synchronize()
+            own_t = torch.from_numpy(own_l).cuda()
+            assert torch.isfinite(xa[own_t]).all() and torch.equal(xa[own_t], xb[own_t]), "exchanges on two streams changed the result"
+            overlapped[rank] = tr.n_overlapped()
         except BaseException as e:  # noqa: BLE001 - reported by the main thread
             errors[rank] = e
             mb.barrier.abort()
@@ -133,6 +153,8 @@ def test_box_2x2x2_eight_ranks_in_one_process(mfmg_lib, material, amg, low_ghost
     if first is not None:
         raise first
     assert all(h is not None for h in hists)
+    if material == "constant":
+        assert sum(overlapped) > 0      # (the ghost entries of b did travel on the second stream: the smoother sweep / the one-pass restriction read them)
     for hst in hists[1:]:
         np.testing.assert_array_equal(hst, hists[0])          # every rank sees the same (all-reduced) norms
     floor = 1e-12 * hist_g[0]
