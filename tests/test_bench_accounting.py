@@ -48,3 +48,21 @@ def test_traffic_file_is_keyed_on_workload_and_tile():
     assert bench.committed_traffic(256, 3, True, (4, 3, 7)) is None      # another tile: no figure
     assert bench.committed_traffic(128, 3, True, (4, 3, 8)) is None      # another workload
     assert bench.committed_traffic(512, 3, False, (8, 2, 16), prefix="dofs") is not None
+
+
+def test_committed_traffic_is_keyed_on_the_tiles_the_bench_ran_with():
+    """roofline.traffic comes from the PMC passes committed under profiles/ (counters need rocprofv3 around the process), keyed on
+    workload AND tile: the committed bench line of the round must find its entries -- a tile the library chooses differently after a
+    change would silently turn the field into null."""
+    import json
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r04_j_bench_line.json")).read())
+    roof = line["roofline"]
+    assert "mf_cheb_fused_kernel" in roof["kernel"]
+    tile = tuple(roof["tile_waves_ty_tz"])
+    traffic = bench.committed_traffic(256, 3, True, tile, prefix="sweep_cells")
+    assert traffic is not None and 0.25 * roof["required_bytes_per_launch"] < traffic < roof["required_bytes_per_launch"]
+    assert traffic > roof["fused_form_bytes_per_launch"]            # (the fused form is the floor of what the sweep must move)
+    leg = line["north_star_512cubed_smoother"]
+    assert min(leg["frac_by_layout"].values()) >= 0.5               # north_star: >= 0.50 of 8 TB/s on every layout
+    gen = line["smoother_apply_512cubed_general_coefficient"]
+    assert bench.committed_traffic(512, 3, False, tuple(gen["tile_waves_ty_tz"]), prefix="dofs") is not None
