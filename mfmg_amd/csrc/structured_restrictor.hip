@@ -284,6 +284,9 @@ __global__ __launch_bounds__(256) void sr_prolong_block222_kernel(SrArgs s, doub
   if (t >= (int64_t)vx * vy * vz || blk_exc[t] != 0)
     return;
   const int vi = t % vx, vj = (t / vx) % vy, vk = t / ((int64_t)vx * vy);
+  // Every request of the thread is issued UNCONDITIONALLY, at a clamped position, and masked afterwards: with a branch around each
+  // of them (`has ? y[..] : 0`, `if (live) ...`) every load sat in a basic block of its own with its wait behind it -- twelve
+  // dependent round trips per wavefront (the ISA: 127 exec branches, 105 waits; the counters: 1.5 MB in flight, profiles/r04_n).
   double2 yv[8];
   bool has[8];
 #pragma unroll
@@ -291,12 +294,13 @@ __global__ __launch_bounds__(256) void sr_prolong_block222_kernel(SrArgs s, doub
   {
     const int qi = vi - (sidx & 1), qj = vj - ((sidx >> 1) & 1), qk = vk - (sidx >> 2);
     has[sidx] = qi >= 0 && qi < s.na[0] && qj >= 0 && qj < s.na[1] && qk >= 0 && qk < s.na[2];
-    yv[sidx] = has[sidx] ? reinterpret_cast<double2 const *>(y)[qi + (int64_t)s.na[0] * (qj + (int64_t)s.na[1] * qk)]
-                         : make_double2(0., 0.);
+    const int ci = min(max(qi, 0), s.na[0] - 1), cj = min(max(qj, 0), s.na[1] - 1), ck = min(max(qk, 0), s.na[2] - 1);
+    yv[sidx] = reinterpret_cast<double2 const *>(y)[ci + (int64_t)s.na[0] * (cj + (int64_t)s.na[1] * ck)];
   }
   const bool pair = 2 * vi + 1 < s.N[0];
   // the four rows this thread finishes: all four reads of `out` are requested up front, together with the y pairs above
-  // (row by row each read waited behind the store of the row before: out may alias out, four dependent round trips)
+  // (row by row each read waited behind the store of the row before: out may alias out, four dependent round trips).  The last
+  // position of a row (one node, no pair) reads the 16 bytes that END at its node.
   bool live[4];
   double *orow[4];
   sr_pair ov[4];
@@ -307,14 +311,17 @@ __global__ __launch_bounds__(256) void sr_prolong_block222_kernel(SrArgs s, doub
     live[dyz] = j < s.N[1] && k < s.N[2];
     orow[dyz] = out + 2 * vi + (int64_t)s.N[0] * (min(j, s.N[1] - 1) + (int64_t)s.N[1] * min(k, s.N[2] - 1));
     ov[dyz] = sr_pair{0., 0.};
-    if (live[dyz] && subtract)
+    if (subtract)
     {
-      if (pair)
-        ov[dyz] = *reinterpret_cast<sr_pair const *>(orow[dyz]);
-      else
-        ov[dyz].x = orow[dyz][0];
+      const sr_pair t = *reinterpret_cast<sr_pair const *>(orow[dyz] - (pair ? 0 : 1));
+      ov[dyz].x = pair ? t.x : t.y;
+      ov[dyz].y = pair ? t.y : 0.;
     }
   }
+#pragma unroll
+  for (int sidx = 0; sidx < 8; ++sidx)
+    if (!has[sidx])
+      yv[sidx] = make_double2(0., 0.); // (an agglomerate outside the mesh contributes exact zeros below)
 #pragma unroll
   for (int dyz = 0; dyz < 4; ++dyz)
   {
@@ -336,8 +343,6 @@ __global__ __launch_bounds__(256) void sr_prolong_block222_kernel(SrArgs s, doub
             if ((sx && dx) || (sy && dy) || (sz && dz))
               continue; // the previous agglomerate holds the node only on the shared boundary
             const int sidx = sx + 2 * sy + 4 * sz;
-            if (!has[sidx])
-              continue;
             const int m = (sx ? 2 : dx) + 3 * ((sy ? 2 : dy) + 3 * (sz ? 2 : dz));
             sum += s.table[2 * m] * yv[sidx].x;
             sum += s.table[2 * m + 1] * yv[sidx].y;
