@@ -258,10 +258,18 @@ struct __attribute__((aligned(8))) sr_pair
 // rest), the others one agglomerate position per thread.  The two nodes 2 i, 2 i + 1 of a row are read / written as one
 // 16-byte access: consecutive lanes, consecutive addresses (with 8-byte accesses at a stride of 16 every request used
 // half of what it touched).
-__global__ __launch_bounds__(256) void sr_prolong_block222_kernel(SrArgs s, double const *y, double *out, int subtract,
+// SUB (x -= R^T y, the cycle's form) is a template parameter: as a run-time flag every read of `out` sat in a block of its own
+// behind a uniform branch with a wait for ALL outstanding loads behind it -- four round trips in a row -- and the 54 table entries
+// were fetched by per-lane vector loads with three more waits (the ISA of round 4's kernel; a wavefront lived 11 us for 24 memory
+// instructions).  The table is read through the constant address space: scalar loads, whatever the stores of the kernel are.
+template <bool SUB>
+__global__ __launch_bounds__(256) void sr_prolong_block222_kernel(SrArgs s, double const *y, double *out,
                                                                   uint8_t const *blk_exc, int32_t const *blocks, int64_t n_blocks,
                                                                   unsigned int listed_blocks)
 {
+  constexpr int subtract = SUB ? 1 : 0;
+  typedef __attribute__((address_space(4))) const double ctable_t;
+  ctable_t *table = reinterpret_cast<ctable_t *>(reinterpret_cast<uintptr_t>(s.table));
   if (blockIdx.x < listed_blocks)
   {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -344,8 +352,8 @@ __global__ __launch_bounds__(256) void sr_prolong_block222_kernel(SrArgs s, doub
               continue; // the previous agglomerate holds the node only on the shared boundary
             const int sidx = sx + 2 * sy + 4 * sz;
             const int m = (sx ? 2 : dx) + 3 * ((sy ? 2 : dy) + 3 * (sz ? 2 : dz));
-            sum += s.table[2 * m] * yv[sidx].x;
-            sum += s.table[2 * m + 1] * yv[sidx].y;
+            sum += table[2 * m] * yv[sidx].x;
+            sum += table[2 * m + 1] * yv[sidx].y;
           }
       sums[dx] = sum;
     }
@@ -815,8 +823,13 @@ void StructuredRestrictorDevice::prolongate(double const *y, double *out, bool s
   {
     const int64_t n_pos = (int64_t)_blk_exc.size(), n_listed = (int64_t)_exc_blocks.size();
     const unsigned int listed_blocks = (unsigned int)((8 * n_listed + 255) / 256);
-    hipLaunchKernelGGL(sr_prolong_block222_kernel, dim3(listed_blocks + (unsigned int)((n_pos + 255) / 256)), dim3(256), 0,
-                       _handle.stream, s, y, out, subtract ? 1 : 0, _blk_exc.data(), _exc_blocks.data(), n_listed, listed_blocks);
+    const dim3 grid(listed_blocks + (unsigned int)((n_pos + 255) / 256));
+    if (subtract)
+      hipLaunchKernelGGL(sr_prolong_block222_kernel<true>, grid, dim3(256), 0, _handle.stream, s, y, out, _blk_exc.data(), _exc_blocks.data(),
+                         n_listed, listed_blocks);
+    else
+      hipLaunchKernelGGL(sr_prolong_block222_kernel<false>, grid, dim3(256), 0, _handle.stream, s, y, out, _blk_exc.data(), _exc_blocks.data(),
+                         n_listed, listed_blocks);
   }
   else
     hipLaunchKernelGGL(sr_prolong_kernel, dim3((unsigned int)((_n_fine + 255) / 256)), dim3(256), 0, _handle.stream,
