@@ -237,19 +237,23 @@ def measure_cg_solve(ctx, torch, M, cells, params, reduction=1e-8, material="con
     b *= free
     r0 = ctx.l2_norm(b)
     out = None
-    for attempt in range(2):            # (the first solve warms the launches up; the second is timed)
+    runs = []
+    for attempt in range(4):            # (the first solve warms the launches up; the median of the three after it is reported)
         x = torch.zeros_like(b)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         its, hist = h.solve_cg(b, x, tolerance=reduction * r0, max_iterations=200)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if attempt > 0:
+            runs.append(dt)
+            dt = sorted(runs)[len(runs) // 2]
         err = float((x - x_true).abs().max() / x_true.abs().max())
         out = {"workload": f"{cells}^3 cells = {cells + 1}^3 DoFs, matrix-free, material {material}: CG preconditioned by one V-cycle "
                            f"(Chebyshev(3), symmetric V(1,1) coarse cycle), x0 = 0, stopped at ||r|| <= {reduction:g} ||r0||",
                "n_dofs": n, "iterations": int(its), "ms_total": dt * 1e3, "ms_per_iteration": dt * 1e3 / max(int(its), 1),
                "value": n / dt, "unit": "DoF/s solved to the tolerance", "residual_reduction": float(hist[-1] / hist[0]),
-               "max_rel_error_vs_known_solution": err}
+               "max_rel_error_vs_known_solution": err, "ms_total_runs": [v * 1e3 for v in runs]}
     return out
 
 
